@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REAL reference.
+
+Run in the build container only (needs /root/reference, which does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+The reference is imported behind `oracle/stubs` (spikingjelly / timm stand-ins, see
+oracle/stubs/README.md).  No reference source or bytecode is written anywhere: the fixtures
+hold inputs' *seeds*, small inputs, and the reference's OUTPUTS.  Weights are regenerated from
+`sdformerflow_amd.synthetic` (name-keyed PCG64), so they are not stored either.
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle", "stubs"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from sdformerflow_amd.synthetic import synth_state_dict, synth_voxel, synth_label  # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.manual_seed(0)
+
+from spikingjelly.activation_based import functional, neuron  # noqa: E402
+from models.STSwinNet_SNN import Spiking_swin_transformer3D as ref_swin  # noqa: E402
+from models.STSwinNet_SNN.Spiking_submodules import PSN  # noqa: E402
+from models.STSwinNet_SNN.Spiking_STSwinNet import MS_SpikingformerFlowNet_en4  # noqa: E402
+from models.STSwinNet import swin_transformer3D_v2 as ref_ann  # noqa: E402
+from loss.flow_supervised import AEE  # noqa: E402
+from configs.parser import YAMLParser  # noqa: E402
+
+
+from sdformerflow_amd.synthetic import synth_uniform as rnd  # noqa: E402
+
+
+def load_synth(module, salt=0, psn_bias=-0.1):
+    # derived index/coordinate buffers keep their constructor values
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()
+              if not k.endswith(("relative_position_index", "relative_coords_table"))}
+    module.load_state_dict(synth_state_dict(shapes, salt, psn_bias), strict=False)
+    functional.reset_net(module)
+    functional.set_step_mode(module, "m")
+    module.eval()
+    return module
+
+
+def spk_kwargs(kind, T):
+    return {"num_steps": T, "v_reset": None, "v_th": 0.1, "neuron_type": kind,
+            "surrogate_fun": "surrogate.ATan()", "tau": 2.0, "detach_reset": True, "spike_norm": "BN"}
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        out[k] = v.numpy() if torch.is_tensor(v) else np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+# ------------------------------------------------------------------ 1. neurons
+def gold_neurons():
+    out = {}
+    for T in (2, 10, 20):
+        x = rnd((T, 4096), 100 + T, -0.3, 0.6)
+        x[:, :64] = 0.1                      # exactly at threshold: h = 0.05, 0.1-ish boundary cases
+        x[0, 64:128] = 0.2                   # h == v_th exactly at t = 0  (0 + 0.2/2 = 0.1)
+        for tag, v_reset in (("soft", None), ("hard", 0.0)):
+            n = neuron.LIFNode(tau=2.0, v_threshold=0.1, v_reset=v_reset, detach_reset=True, step_mode="m")
+            s = n(x)
+            out[f"lif_{tag}_T{T}_s"] = s.to(torch.uint8)
+            out[f"lif_{tag}_T{T}_v"] = n.v
+        p = PSN(T)
+        sd = synth_state_dict({"spiking_neuron.weight": (T, T), "spiking_neuron.bias": (T, 1)}, salt=T)
+        p.weight.copy_(sd["spiking_neuron.weight"])
+        p.bias.copy_(sd["spiking_neuron.bias"])
+        h = torch.addmm(p.bias, p.weight, x.flatten(1))
+        out[f"psn_T{T}_w"], out[f"psn_T{T}_b"] = p.weight.data.clone(), p.bias.data.clone()
+        out[f"psn_T{T}_h"] = h.to(torch.float32)
+        out[f"psn_T{T}_s"] = p(x).to(torch.uint8)
+    save("neurons", **out)
+
+
+# ------------------------------------------------------------------ 2. window index maps
+def gold_index_maps():
+    out = {}
+    for tag, (B, D, H, W), ws, shift in (("s0", (1, 10, 72, 96), (2, 9, 9), (1, 4, 4)),
+                                         ("odd", (2, 4, 18, 21), (2, 9, 9), (1, 4, 4)),
+                                         ("noshift", (2, 4, 18, 21), (2, 9, 9), (0, 0, 0))):
+        idx = torch.arange(B * D * H * W, dtype=torch.float32).view(B, D, H, W, 1) + 1.0   # 0 = padding
+        wsz, ssz = ref_ann.get_window_size((D, H, W), ws, shift)
+        pad_d = (wsz[0] - D % wsz[0]) % wsz[0]
+        pad_b = (wsz[1] - H % wsz[1]) % wsz[1]
+        pad_r = (wsz[2] - W % wsz[2]) % wsz[2]
+        x = torch.nn.functional.pad(idx, (0, 0, 0, pad_r, 0, pad_b, 0, pad_d))
+        _, Dp, Hp, Wp, _ = x.shape
+        if any(i > 0 for i in ssz):
+            x = torch.roll(x, shifts=(-ssz[0], -ssz[1], -ssz[2]), dims=(1, 2, 3))
+        win = ref_swin.window_partition_v2(x, wsz)                  # (Wd, B_, Wh, Ww, 1)
+        out[f"{tag}_gather"] = (win.reshape(win.shape[0] * win.shape[1], -1).to(torch.int64) - 1).to(torch.int32)
+        # inverse path: (B_, N, C) -> view(-1, *ws, C) -> window_reverse -> roll back -> crop
+        y = win.reshape(win.shape[1], -1, 1).view(-1, *wsz, 1)
+        y = ref_ann.window_reverse(y, wsz, B, Dp, Hp, Wp)
+        if any(i > 0 for i in ssz):
+            y = torch.roll(y, shifts=ssz, dims=(1, 2, 3))
+        y = y[:, :D, :H, :W, :]
+        out[f"{tag}_roundtrip_ok"] = np.array(bool(torch.equal(y, idx)))
+        out[f"{tag}_shape"] = np.array([B, D, H, W, *ws, *shift])
+        m = ref_swin.compute_mask(Dp, Hp, Wp, wsz, ssz, torch.device("cpu"))
+        out[f"{tag}_mask_sum"] = np.array(float(m.sum()))
+        if tag != "s0":
+            out[f"{tag}_mask"] = m.to(torch.int8)
+    save("index_maps", **out)
+
+
+# ------------------------------------------------------------------ 3. a5 QK attention
+def gold_qk_attention():
+    out = {}
+    for tag, (B_, C, nH), kind in (("c96_lif", (4, 96, 3), "lif"), ("c96_psn", (4, 96, 3), "psn"),
+                                   ("c192_lif", (2, 192, 6), "lif"), ("c384_psn", (1, 384, 12), "psn")):
+        m = ref_swin.Spiking_QK_WindowAttention3D(C, (2, 9, 9), (0, 0, 0), nH, norm="BN", **spk_kwargs(kind, 10))
+        load_synth(m)
+        x = rnd((2, B_, 9, 9, C), 7 + C, -0.5, 1.0)
+        y, _ = m(x)                                                   # (B_, 162, C)
+        out[f"{tag}_y"] = y
+        out[f"{tag}_cfg"] = np.array([B_, C, nH, 7 + C])
+    save("qk_attention", **out)
+
+
+# ------------------------------------------------------------------ 4. a9 SEW attention with mask
+def gold_sew_attention():
+    out = {}
+    for tag, kind in (("lif", "lif"), ("psn", "psn")):
+        C, nH, B, nW = 96, 3, 2, 4
+        m = ref_swin.Spiking_BN_WindowAttention3D(C, (2, 9, 9), (0, 0, 0), nH, version="swinv1", norm="BN",
+                                                  **spk_kwargs(kind, 10))
+        load_synth(m)
+        x = (rnd((2, B * nW, 9, 9, C), 11) > 0.4).float()           # spike input (SEW blocks feed spikes)
+        mask = ref_swin.compute_mask(2, 18, 18, (2, 9, 9), (1, 4, 4), torch.device("cpu"))
+        y, attn = m(x, mask)
+        out[f"{tag}_y"] = y.to(torch.uint8)
+        out[f"{tag}_attn_sum"] = attn.sum((-1, -2))
+        out[f"{tag}_attn00"] = attn[0, 0]
+        y2, _ = (functional.reset_net(m), m(x, None))[1]
+        out[f"{tag}_y_nomask"] = y2.to(torch.uint8)
+    save("sew_attention", **out)
+
+
+# ------------------------------------------------------------------ 5. a10 ANN window attention with mask
+def gold_ann_attention():
+    out = {}
+    C, nH, B, nW = 96, 3, 1, 4
+    m = ref_ann.WindowAttention3D(C, (2, 9, 9), (0, 0, 0), nH, qkv_bias=True)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if "relative" not in k}
+    sd = synth_state_dict(shapes)
+    m.load_state_dict(sd, strict=False)
+    m.eval()
+    x = rnd((B * nW, 162, C), 13, -1.0, 1.0)
+    mask = ref_ann.compute_mask(2, 18, 18, (2, 9, 9), (1, 4, 4), torch.device("cpu"))
+    y, attn = m(x, mask)
+    out["y"], out["attn00"] = y, attn[0, 0]
+    y2, _ = m(x, None)
+    out["y_nomask"] = y2
+    out["rel_index_sum"] = np.array(int(m.relative_position_index.sum()))
+    out["coords_table"] = m.relative_coords_table
+    save("ann_attention", **out)
+
+
+# ------------------------------------------------------------------ 6. full MS block, merge
+def gold_ms_block():
+    out = {}
+    C, nH = 96, 3
+    for tag, kind, (H, W), shift in (("lif_sw", "lif", (18, 21), (1, 4, 4)), ("lif_w", "lif", (9, 21), (0, 0, 0)),
+                                     ("psn_sw", "psn", (9, 21), (1, 4, 4))):
+        kw = spk_kwargs(kind, 4)
+        blk = ref_swin.MS_Spiking_SwinTransformerBlock3D(C, (H, W), nH, window_size=(2, 9, 9),
+                                                         shift_size=shift, norm_layer="BN", **kw)
+        load_synth(blk)
+        x = rnd((1, 4, H, W, C), 17, -0.5, 1.0)
+        Hp, Wp = -(-H // 9) * 9, -(-W // 9) * 9
+        wsz, ssz = ref_ann.get_window_size((4, H, W), (2, 9, 9), shift)
+        mask = ref_swin.compute_mask(4, Hp, Wp, wsz, ssz, torch.device("cpu"))
+        out[f"{tag}_y"] = blk(x, mask)
+        out[f"{tag}_cfg"] = np.array([H, W, *shift])
+    for kind in ("lif", "psn"):
+        pm = ref_swin.MS_SpikingPatchMerging((9, 21), C, norm_layer="BN", **spk_kwargs(kind, 4))
+        load_synth(pm)
+        out[f"{kind}_merge_y"] = pm(rnd((1, 4, 9, 21, C), 19, -0.5, 1.0))
+    save("ms_block", **out)
+
+
+# ------------------------------------------------------------------ 7. end to end
+def en4_config(kind):
+    cfg = YAMLParser("/root/reference/configs/train_DSEC_supervised_SDformerFlow_en4.yml")
+    config = cfg.combine_entries(cfg.config)
+    config["swin_transformer"]["input_size"] = [288, 384]
+    config["model"]["spiking_neuron"]["neuron_type"] = kind
+    return config
+
+
+def gold_end_to_end():
+    out = {}
+    for kind in ("lif", "psn"):
+        config = en4_config(kind)
+        model = MS_SpikingformerFlowNet_en4(config["model"].copy(), config["swin_transformer"].copy())
+        load_synth(model)
+        rates = []
+        hooks = []
+        for name, mod in model.named_modules():
+            if name.endswith("spiking_neuron"):
+                hooks.append(mod.register_forward_hook(
+                    lambda m, i, o, name=name: rates.append((name, float(o.mean())))))
+        vox = synth_voxel(1, 10, 288, 384, seed=1234 + 1)
+        # harness prep (eval_DSEC_flow_SNN.py:179-205), reference semantics, in place
+        chunk = torch.cat((torch.relu(vox).unsqueeze(2), torch.relu(-vox).unsqueeze(2)), dim=2)
+        lo, hi = chunk[chunk != 0].min(), chunk[chunk != 0].max()
+        chunk[chunk != 0] = (chunk[chunk != 0] - lo) / (hi - lo)
+        functional.reset_net(model)
+        res = model(chunk)
+        for h in hooks:
+            h.remove()
+        preds = model.sttmultires_unet(chunk) if False else None
+        for i, f in enumerate(res["flow"]):
+            s = f.shape[-1] // (24 * 2 ** i)                     # native resolution of prediction i
+            out[f"{kind}_flow{i}"] = f[:, :, ::s, ::s].contiguous()
+            out[f"{kind}_flow{i}_abs_mean"] = np.array(float(f.abs().mean()))
+        label, mask = synth_label(1, 288, 384)
+        m = AEE(res["flow"][-1], label, mask, 1)()
+        out[f"{kind}_aee"] = np.array([float(v.reshape(-1)[0]) for v in m])
+        out[f"{kind}_rates"] = np.array([r for _, r in rates], dtype=np.float32)
+        out[f"{kind}_rate_names"] = np.array([n for n, _ in rates])
+        out[f"{kind}_n_state"] = np.array(len(model.state_dict()))
+        out[f"{kind}_n_param"] = np.array(sum(p.numel() for p in model.parameters()))
+        out[f"{kind}_chunk_checksum"] = np.array(float(chunk.double().sum()))
+    save("end_to_end", **out)
+    # state_dict schema (names + shapes only) for the drop-in boundary test
+    for kind in ("lif", "psn"):
+        config = en4_config(kind)
+        model = MS_SpikingformerFlowNet_en4(config["model"].copy(), config["swin_transformer"].copy())
+        with open(os.path.join(HERE, f"state_schema_en4_{kind}.txt"), "w") as f:
+            for k, v in model.state_dict().items():
+                f.write(f"{k} {'x'.join(map(str, v.shape))}\n")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["neurons", "index_maps", "qk_attention", "sew_attention", "ann_attention",
+                             "ms_block", "end_to_end"]
+    for w in which:
+        globals()["gold_" + w]()

@@ -1,0 +1,247 @@
+"""Pin the CPU oracle (oracle/sdformer_oracle.py) against the golden fixtures that
+tests/golden/make_golden.py produced by running the real reference.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sdformer_oracle as O
+from sdformerflow_amd.synthetic import synth_state_dict, synth_uniform as rnd, synth_voxel, synth_label
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def ncfg(kind, T):
+    return O.NeuronCfg(kind, v_th=0.1, v_reset=None, tau=2.0, num_steps=T)
+
+
+def qk_shapes(C, nH, kind, T=2):
+    s = {"positional_encoding": (1, nH, 162, C // nH), "linear_q.weight": (C, C), "linear_k.weight": (C, C),
+         "proj.weight": (C, C), "proj.bias": (C,)}
+    for bn in ("bn_q", "bn_k", "proj_bn"):
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            s[f"{bn}.norm_layer.{leaf}"] = (C,)
+    if kind == "psn":
+        for sn in ("sn_q", "sn_k", "sn2_q", "attn_sn", "proj_sn"):
+            s[f"{sn}.spiking_neuron.weight"] = (T, T)
+            s[f"{sn}.spiking_neuron.bias"] = (T, 1)
+    return s
+
+
+def neuron_input(T):
+    x = rnd((T, 4096), 100 + T, -0.3, 0.6)
+    x[:, :64] = 0.1
+    x[0, 64:128] = 0.2
+    return x
+
+
+# ---------------------------------------------------------------- neurons (a1, a2)
+@pytest.mark.parametrize("T", [2, 10, 20])
+def test_lif_matches_reference_stub(T):
+    g = gold("neurons")
+    x = neuron_input(T)
+    for tag, vr in (("soft", None), ("hard", 0.0)):
+        s, v = O.lif_multistep(x, 2.0, 0.1, vr, return_v=True)
+        assert np.array_equal(s.numpy().astype(np.uint8), g[f"lif_{tag}_T{T}_s"])      # bit-exact spikes
+        assert np.array_equal(v.numpy(), g[f"lif_{tag}_T{T}_v"])                        # bit-exact membrane
+
+
+@pytest.mark.parametrize("T", [2, 10, 20])
+def test_psn_matches_reference(T):
+    g = gold("neurons")
+    x = neuron_input(T)
+    w, b = torch.from_numpy(g[f"psn_T{T}_w"]), torch.from_numpy(g[f"psn_T{T}_b"])
+    h = O.psn_h(x, w, b)
+    href = g[f"psn_T{T}_h"]
+    # torch.addmm's fp32 order is BLAS-defined; the oracle's fp64-ordered H must agree to fp32 rounding
+    assert np.abs(h.numpy() - href).max() <= 4e-7 * max(1.0, np.abs(href).max())
+    s = O.psn(x, w, b).numpy().astype(np.uint8)
+    diff = s != g[f"psn_T{T}_s"]
+    # spikes may only differ where the reference's own H is within rounding of the threshold
+    assert np.all(np.abs(href[diff]) < 1e-6)
+    assert diff.mean() < 1e-4
+
+
+# ---------------------------------------------------------------- window geometry (a4, a6, a11)
+@pytest.mark.parametrize("tag", ["s0", "odd", "noshift"])
+def test_slice_table_matches_reference(tag):
+    g = gold("index_maps")
+    B, D, H, W, w0, w1, w2, s0, s1, s2 = [int(v) for v in g[f"{tag}_shape"]]
+    ws, ss = O.get_window_size((D, H, W), (w0, w1, w2), (s0, s1, s2))
+    src, B_ = O.slice_table(B, D, H, W, ws, ss)
+    assert bool(g[f"{tag}_roundtrip_ok"])
+    assert np.array_equal(src.astype(np.int32), g[f"{tag}_gather"])
+    # scatter is the exact inverse on valid positions
+    x = rnd((B, D, H, W, 3), 5)
+    y, _ = O.gather_slices(x, ws, ss)
+    assert torch.equal(O.scatter_slices(y, B, D, H, W, ws, ss), x)
+    Dp, Hp, Wp = -(-D // ws[0]) * ws[0], -(-H // ws[1]) * ws[1], -(-W // ws[2]) * ws[2]
+    m = O.compute_mask(Dp, Hp, Wp, ws, ss)
+    assert float(m.sum()) == float(g[f"{tag}_mask_sum"])
+    if tag != "s0":
+        assert np.array_equal(m.numpy().astype(np.int8), g[f"{tag}_mask"])
+
+
+# ---------------------------------------------------------------- a5
+@pytest.mark.parametrize("tag,kind", [("c96_lif", "lif"), ("c96_psn", "psn"), ("c192_lif", "lif"), ("c384_psn", "psn")])
+def test_qk_attention_matches_reference(tag, kind):
+    g = gold("qk_attention")
+    B_, C, nH, seed = [int(v) for v in g[f"{tag}_cfg"]]
+    sd = synth_state_dict(qk_shapes(C, nH, kind))
+    x = rnd((2, B_, 9, 9, C), seed, -0.5, 1.0).reshape(2, B_, 81, C)
+    y, e, z = O.qk_attention(x, sd, "", nH, ncfg(kind, 2))
+    yref = g[f"{tag}_y"]                                                  # (B_,162,C) == raw reshape
+    assert np.abs(y.reshape(B_, 162, C).numpy() - yref).max() <= 2e-5
+    # explicit gather table == the reshape/permute formulation
+    tab = torch.from_numpy(O.z_gather_table(B_, nH, 2, 81, C // nH))
+    assert torch.equal(e.reshape(-1)[tab.reshape(-1)].view_as(z), z)
+
+
+# ---------------------------------------------------------------- a9
+def sew_shapes(C, nH, kind, T=2):
+    s = {"relative_position_bias_table": (3 * 17 * 17, nH), "proj.weight": (C, C), "proj.bias": (C,)}
+    for n in ("q", "k", "v"):
+        s[f"linear_{n}.weight"] = (C, C)
+    for bn in ("bn_q", "bn_k", "bn_v", "proj_bn"):
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            s[f"{bn}.norm_layer.{leaf}"] = (C,)
+    if kind == "psn":
+        for sn in ("sn_q", "sn_k", "sn_v", "attn_sn", "proj_sn"):
+            s[f"{sn}.spiking_neuron.weight"] = (T, T)
+            s[f"{sn}.spiking_neuron.bias"] = (T, 1)
+    return s
+
+
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+def test_sew_attention_matches_reference(kind):
+    g = gold("sew_attention")
+    C, nH, B, nW = 96, 3, 2, 4
+    sd = synth_state_dict(sew_shapes(C, nH, kind))
+    x = (rnd((2, B * nW, 9, 9, C), 11) > 0.4).float().reshape(2, B * nW, 81, C)
+    mask = O.compute_mask(2, 18, 18, (2, 9, 9), (1, 4, 4))
+    y, attn = O.sew_attention(x, sd, "", nH, (2, 9, 9), ncfg(kind, 2), mask)
+    assert np.abs(attn[0, 0].numpy() - g[f"{kind}_attn00"]).max() <= 1e-4
+    assert np.abs(attn.sum((-1, -2)).numpy() - g[f"{kind}_attn_sum"]).max() <= 0.5
+    yref = g[f"{kind}_y"].reshape(2, B * nW, 81, C)
+    assert (y.numpy().astype(np.uint8) != yref).mean() < 2e-4           # threshold-rounding flips only
+    y2, _ = O.sew_attention(x, sd, "", nH, (2, 9, 9), ncfg(kind, 2), None)
+    assert (y2.numpy().astype(np.uint8) != g[f"{kind}_y_nomask"].reshape(2, B * nW, 81, C)).mean() < 2e-4
+
+
+# ---------------------------------------------------------------- a10
+def test_ann_attention_matches_reference():
+    g = gold("ann_attention")
+    C, nH, B, nW = 96, 3, 1, 4
+    shapes = {"logit_scale": (nH, 1, 1), "cpb_mlp.0.weight": (512, 3), "cpb_mlp.0.bias": (512,),
+              "cpb_mlp.2.weight": (nH, 512), "qkv.weight": (3 * C, C), "qkv.bias": (3 * C,),
+              "proj.weight": (C, C), "proj.bias": (C,)}
+    sd = synth_state_dict(shapes)
+    assert np.allclose(O.relative_coords_table((2, 9, 9)).numpy(), g["coords_table"], atol=1e-6)
+    assert int(O.relative_position_index((2, 9, 9)).sum()) == int(g["rel_index_sum"])
+    x = rnd((B * nW, 162, C), 13, -1.0, 1.0)
+    mask = O.compute_mask(2, 18, 18, (2, 9, 9), (1, 4, 4))
+    y, attn = O.ann_window_attention(x, sd, "", nH, (2, 9, 9), mask)
+    assert np.abs(attn[0, 0].numpy() - g["attn00"]).max() <= 1e-6
+    assert np.abs(y.numpy() - g["y"]).max() <= 1e-5
+    y2, _ = O.ann_window_attention(x, sd, "", nH, (2, 9, 9), None)
+    assert np.abs(y2.numpy() - g["y_nomask"]).max() <= 1e-5
+
+
+# ---------------------------------------------------------------- a7, a8
+def block_shapes(C, nH, kind, T):
+    s = {"attn." + k: v for k, v in qk_shapes(C, nH, kind).items()}
+    s.update({"mlp.fc1.weight": (4 * C, C), "mlp.fc2.weight": (C, 4 * C)})
+    for bn, n in (("mlp.bn1", 4 * C), ("mlp.bn2", C)):
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            s[f"{bn}.norm_layer.{leaf}"] = (n,)
+    if kind == "psn":
+        for sn in ("mlp.sn1", "mlp.sn2"):
+            s[f"{sn}.spiking_neuron.weight"] = (T, T)
+            s[f"{sn}.spiking_neuron.bias"] = (T, 1)
+    return s
+
+
+@pytest.mark.parametrize("tag,kind", [("lif_sw", "lif"), ("lif_w", "lif"), ("psn_sw", "psn")])
+def test_ms_block_matches_reference(tag, kind):
+    g = gold("ms_block")
+    H, W, s0, s1, s2 = [int(v) for v in g[f"{tag}_cfg"]]
+    C, nH, T = 96, 3, 4
+    sd = synth_state_dict(block_shapes(C, nH, kind, T))
+    x = rnd((1, T, H, W, C), 17, -0.5, 1.0)
+    y = O.ms_block(x, sd, "", nH, (2, 9, 9), (s0, s1, s2), ncfg(kind, T))
+    d = np.abs(y.numpy() - g[f"{tag}_y"])
+    assert d.max() <= 5e-5, d.max()
+
+
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+def test_patch_merge_matches_reference(kind):
+    g = gold("ms_block")
+    C, T = 96, 4
+    s = {"reduction.weight": (2 * C, 4 * C)}
+    for leaf in ("weight", "bias", "running_mean", "running_var"):
+        s[f"norm.norm_layer.{leaf}"] = (2 * C,)
+    if kind == "psn":
+        s["sn.spiking_neuron.weight"], s["sn.spiking_neuron.bias"] = (T, T), (T, 1)
+    sd = synth_state_dict(s)
+    y = O.ms_patch_merge(rnd((1, T, 9, 21, C), 19, -0.5, 1.0), sd, "", ncfg(kind, T))
+    assert np.abs(y.numpy() - g[f"{kind}_merge_y"]).max() <= 2e-5
+
+
+# ---------------------------------------------------------------- end to end (BASELINE config 1)
+def load_schema(kind):
+    shapes = {}
+    with open(os.path.join(G, f"state_schema_en4_{kind}.txt")) as f:
+        for line in f:
+            name, _, shp = line.strip().partition(" ")
+            shapes[name] = tuple(int(v) for v in shp.split("x")) if shp else ()
+    return shapes
+
+
+def en4_cfg(kind):
+    return {"neuron": ncfg(kind, 10), "num_bins": 10, "window_size": (2, 9, 9), "depths": [2, 2, 6, 2],
+            "num_heads": [3, 6, 12, 24]}
+
+
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+def test_end_to_end_flow_matches_reference(kind):
+    g = gold("end_to_end")
+    shapes = load_schema(kind)
+    assert len(shapes) == int(g[f"{kind}_n_state"])
+    sd = synth_state_dict({k: v for k, v in shapes.items() if not k.endswith("num_batches_tracked")})
+    chunk = O.prepare_chunk(synth_voxel(1, 10, 288, 384, seed=1235))
+    assert abs(float(chunk.double().sum()) - float(g[f"{kind}_chunk_checksum"])) < 1e-6
+    O.PSN_MODE = "addmm"          # the reference's literal op: the net is chaotic, 1 flipped spike decorrelates it
+    O.RATE_LOG = []
+    try:
+        with torch.no_grad():
+            flows = O.forward_flownet(chunk, sd, en4_cfg(kind))
+        rates = dict(O.RATE_LOG)
+    finally:
+        O.PSN_MODE, O.RATE_LOG = "exact64", None
+    # (1) robust on any host: per-layer firing rates (the dead `attn_sn` call is not on the forward path)
+    ref_rates = {str(n) + ".": float(r) for n, r in zip(g[f"{kind}_rate_names"], g[f"{kind}_rates"])
+                 if "attn_sn" not in str(n)}
+    assert set(ref_rates) == set(rates) and len(rates) == 93
+    assert max(abs(rates[k] - ref_rates[k]) for k in rates) < 2e-3
+    # (2) bit-level: same ATen/MKL build as the generator => flows within the north-star 1e-3 bound.
+    # On another CPU/BLAS the 1-ulp differences decorrelate the (chaotic) random-weight net, so the
+    # strict check is only meaningful when nothing upstream moved.
+    strict = all(abs(rates[k] - ref_rates[k]) < 1e-7 for k in rates)
+    for i, f in enumerate(flows):
+        s = f.shape[-1] // (24 * 2 ** i)
+        ref = g[f"{kind}_flow{i}"]
+        d = np.abs(f[:, :, ::s, ::s].numpy() - ref)
+        scale = np.abs(ref).mean()
+        if strict:
+            assert d.max() <= 1e-3 * scale, (i, d.max(), scale)
+        else:
+            assert abs(np.abs(f.numpy()).mean() - float(g[f"{kind}_flow{i}_abs_mean"])) < 0.1 * scale
+    label, mask = synth_label(1, 288, 384)
+    m = O.aee(flows[-1], label, mask, 1.0)
+    got = np.array([float(v.reshape(-1)[0]) for v in m])
+    assert np.allclose(got, g[f"{kind}_aee"], rtol=1e-5 if strict else 5e-2, atol=1e-6 if strict else 5e-2)
