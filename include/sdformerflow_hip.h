@@ -1,0 +1,150 @@
+/* sdformerflow_hip.h - C ABI of libsdformerflow_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the SDformerFlow forward hot path.  The reference is
+ * pure Python; the only native code on its path is SpikingJelly's CuPy multi-step neuron kernel,
+ * switched on with `functional.set_backend(model, "cupy", neurontype)` (reference
+ * eval_DSEC_flow_SNN.py:118-119).  Every entry point below names the reference call it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *   - the library never allocates or frees device memory and never synchronises; all work is
+ *     enqueued on `stream` (a hipStream_t passed as void*; NULL = the legacy default stream)
+ *   - return value: 0 = launched, <0 = argument error detected before any launch
+ *     (SDF_E_*), >0 = the hipError_t of the failed launch.  No C++ exception crosses the ABI.
+ *   - spikes are {0,1}; `*_dtype` selects their storage: SDF_F32 (the reference's own format)
+ *     or SDF_U8 (1 byte/spike, the operand format of the spike GEMM)
+ */
+#ifndef SDFORMERFLOW_HIP_H
+#define SDFORMERFLOW_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDF_VERSION 100
+
+enum { SDF_F32 = 0, SDF_U8 = 1 };
+enum { SDF_LIF = 0, SDF_PSN = 1, SDF_IF = 2 };
+enum {
+  SDF_E_NULL = -1,    /* required pointer is NULL            */
+  SDF_E_SHAPE = -2,   /* size / divisibility requirement     */
+  SDF_E_DTYPE = -3,   /* unknown dtype / kind selector       */
+  SDF_E_ALIGN = -4    /* pointer or stride alignment         */
+};
+
+int sdf_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-step LIF over the leading (time) axis of a contiguous fp32 (T, N) tensor.
+ * Replaces: neuron.LIFNode multi-step forward (reference Spiking_modules.py:40-47,98-99; the
+ * CuPy backend of eval_DSEC_flow_SNN.py:118-119).  Arithmetic (each op separately rounded):
+ *   h = v + (x_t - v)/tau ; s = (h - v_th >= 0) ; v = h - s*v_th (soft) | (1-s)*h + s*v_reset
+ * v starts at 0 (soft) or v_reset (hard).  `v_last` (fp32, N) receives the final membrane or is NULL.
+ */
+int sdf_lif_fwd(const float* x, void* spike, float* v_last, int T, int64_t N, float tau, float v_th,
+                int soft_reset, float v_reset, int spike_dtype, void* stream);
+
+/* Parallel Spiking Neuron: H = b + W X over time, S = (H >= 0).
+ * Replaces: PSN.forward (reference Spiking_submodules.py:207-211).  H[t] is the fp32 fmaf chain
+ *   h = b[t]; for k = 0..T-1: h = fmaf(W[t,k], x[k], h)
+ * (an order the oracle restates exactly; torch.addmm's own order is BLAS-defined).
+ * W is (T,T) row-major fp32, b is (T) fp32, both device memory.  T <= 32.
+ */
+int sdf_psn_fwd(const float* x, const float* W, const float* b, void* spike, int T, int64_t N,
+                int spike_dtype, void* stream);
+
+/* General neuron launch: strided / gathered input, fused eval-BatchNorm and additive prologue.
+ * Replaces the reference idiom  SN( BN( y.permute(..) ).permute(..) [+ positional_encoding] )
+ * (Spiking_swin_transformer3D.py:670-680, 168-174, 970) and the pad / roll / window_partition_v2
+ * gather in front of it (:789-804), without materialising any of the permutes.
+ *
+ * One time step holds nb*ni logical elements; element (b, r) of step t lives at
+ *     x   + b*x_sb + t*x_st + r          (dense mode,  rowmap == NULL)
+ *     x   + rowmap[t*rows + row]*rowlen + col ,  row = (b*ni + r)/rowlen, col = (b*ni+r)%rowlen,
+ *           rows = nb*ni/rowlen, a negative map entry reads as 0.0      (gather mode)
+ *     out + b*o_sb + t*o_st + r
+ * Prologue (in this order, all optional):  y = fmaf(x, alpha[c], beta[c]) with c = (r/inner) % C;
+ *     y = y + add[t*add_st + r % add_period].
+ * ni, all strides, rowlen, inner*C-blocks and add_period must be multiples of 4 unless inner == 1
+ * is replaced by C % 4 == 0 (the kernel moves 4 elements per lane).
+ */
+typedef struct SdfNeuronDesc {
+  const float* x;
+  void* out;
+  float* v_last;            /* LIF/IF only, dense (nb*ni) or NULL */
+  int32_t T;
+  int32_t out_dtype;        /* SDF_F32 | SDF_U8 */
+  int64_t nb, ni;
+  int64_t x_sb, x_st;
+  int64_t o_sb, o_st;
+  const int32_t* rowmap;    /* NULL = dense */
+  int32_t rowlen;
+  int32_t kind;             /* SDF_LIF | SDF_PSN | SDF_IF */
+  const float* alpha;       /* NULL = no affine */
+  const float* beta;
+  int32_t C;
+  int32_t inner;
+  const float* add;         /* NULL = none */
+  int64_t add_st, add_period;
+  float tau, v_th, v_reset;
+  int32_t soft_reset;
+  const float* psn_w;       /* (T,T) */
+  const float* psn_b;       /* (T)   */
+} SdfNeuronDesc;
+
+int sdf_neuron_fwd(const SdfNeuronDesc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Spike GEMM:  out[M,N] = epilogue( A[M,K] (binary, u8) x W[N,K]^T ).
+ * Replaces: sj_layer.Linear on spike tensors + the BatchNorm that follows it + the residual add
+ * (reference Spiking_swin_transformer3D.py:170-178, 671-677, 712-714, 840, 845, 971-972).
+ *
+ * W is passed as `nsplit` bf16 planes (device, plane-major [nsplit][N][K]) with
+ * W = plane0 + plane1 + plane2 (hi / mid / lo split made by sdf_split_weight_bf16); binary A is
+ * exact in bf16, so nsplit = 3 reproduces the fp32 product to fp32 rounding on the bf16 MFMA path.
+ * Epilogue, in order:  acc (+ bias[n]) ; fmaf(., alpha[n], beta[n]) if alpha ; (+ resid[row][n]) ;
+ * stored fp32 at out[row*ldo + n] where row = out_rowmap ? out_rowmap[m] : m (negative = dropped)
+ * and resid uses the same row.  `resid` may alias `out` (in-place residual update).
+ *
+ * A addressing: zg_nH == 0: A[m*lda + k].  zg_nH > 0: the reference's head-scramble
+ *   Z[t,b,n,g*32+d] = E_flat[((((b*nH+g)*Tq+t)*N1+n)*32+d]   (Spiking_swin_transformer3D.py:709-710)
+ * with m = (t*zg_B + b)*zg_N1 + n, k = g*32 + d, Tq = zg_T; requires K == nH*32.
+ * Requirements: K % 32 == 0, N % 32 == 0, lda % 16 == 0.
+ */
+typedef struct SdfSpikeGemmDesc {
+  const uint8_t* A;
+  const uint16_t* Wp;       /* bf16 bits, [nsplit][N][K] */
+  float* out;
+  int64_t M;
+  int32_t N, K;
+  int64_t lda, ldo;
+  int32_t nsplit;           /* 1..3 */
+  const float* bias;        /* NULL ok */
+  const float* alpha;       /* NULL ok */
+  const float* beta;
+  const float* resid;       /* NULL ok */
+  const int32_t* out_rowmap;/* NULL ok */
+  int32_t zg_nH, zg_T, zg_B, zg_N1;
+} SdfSpikeGemmDesc;
+
+int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream);
+
+/* W (fp32, n elements) -> nsplit bf16 planes (round-to-nearest-even residual split). */
+int sdf_split_weight_bf16(const float* W, uint16_t* planes, int64_t n, int nsplit, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Token gate of Spiking_QK_WindowAttention3D (reference Spiking_swin_transformer3D.py:687-694):
+ *   a[t,b,n,g] = sum_{d<32} q[t,b,n,g*32+d] ; A = neuron_T'(a) ; E = k * A (broadcast over d).
+ * q, k, e: u8 spikes laid out (Tq, rows, C) with rows = B_*N1, C % 32 == 0; the neuron runs over Tq
+ * with the same kind/params semantics as sdf_neuron_fwd (LIF | PSN).
+ */
+int sdf_qk_gate_fwd(const uint8_t* q, const uint8_t* k, uint8_t* e, int Tq, int64_t rows, int C,
+                    int kind, float tau, float v_th, float v_reset, int soft_reset,
+                    const float* psn_w, const float* psn_b, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDFORMERFLOW_HIP_H */

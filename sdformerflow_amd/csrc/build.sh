@@ -1,0 +1,17 @@
+#!/usr/bin/env bash
+# Build libsdformerflow_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -Wall -Wno-unused-function"
+mkdir -p obj
+pids=()
+for f in neuron spike_gemm qk_gate; do
+  if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ common.h -nt obj/$f.o ] || [ ../../include/sdformerflow_hip.h -nt obj/$f.o ]; then
+    $HIPCC $FLAGS -c $f.hip -o obj/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libsdformerflow_hip.so obj/*.o
+echo "built $(pwd)/libsdformerflow_hip.so"

@@ -1,0 +1,182 @@
+"""ctypes binding of libsdformerflow_hip.so (the C ABI declared in include/sdformerflow_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every compute call goes through the
+C ABI with raw pointers.  There is NO CPU fallback: if the library is missing or a tensor is not on
+the GPU the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsdformerflow_hip.so")
+
+SDF_F32, SDF_U8 = 0, 1
+SDF_LIF, SDF_PSN, SDF_IF = 0, 1, 2
+KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
+
+EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
+           "sdf_split_weight_bf16", "sdf_qk_gate_fwd")
+
+
+class SdfError(RuntimeError):
+    pass
+
+
+class NeuronDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("v_last", C.c_void_p),
+                ("T", C.c_int32), ("out_dtype", C.c_int32),
+                ("nb", C.c_int64), ("ni", C.c_int64),
+                ("x_sb", C.c_int64), ("x_st", C.c_int64),
+                ("o_sb", C.c_int64), ("o_st", C.c_int64),
+                ("rowmap", C.c_void_p), ("rowlen", C.c_int32), ("kind", C.c_int32),
+                ("alpha", C.c_void_p), ("beta", C.c_void_p), ("C", C.c_int32), ("inner", C.c_int32),
+                ("add", C.c_void_p), ("add_st", C.c_int64), ("add_period", C.c_int64),
+                ("tau", C.c_float), ("v_th", C.c_float), ("v_reset", C.c_float), ("soft_reset", C.c_int32),
+                ("psn_w", C.c_void_p), ("psn_b", C.c_void_p)]
+
+
+class SpikeGemmDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("Wp", C.c_void_p), ("out", C.c_void_p),
+                ("M", C.c_int64), ("N", C.c_int32), ("K", C.c_int32),
+                ("lda", C.c_int64), ("ldo", C.c_int64), ("nsplit", C.c_int32),
+                ("bias", C.c_void_p), ("alpha", C.c_void_p), ("beta", C.c_void_p),
+                ("resid", C.c_void_p), ("out_rowmap", C.c_void_p),
+                ("zg_nH", C.c_int32), ("zg_T", C.c_int32), ("zg_B", C.c_int32), ("zg_N1", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; fail loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SdfError(f"{LIB_PATH} not built - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(sdformerflow_amd/csrc/build.sh); there is no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.sdf_version.restype = C.c_int
+        for name in EXPORTS[1:]:
+            getattr(_lib, name).restype = C.c_int
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        kind = "argument error" if rc < 0 else "hipError_t"
+        raise SdfError(f"{what} failed: {kind} {rc}")
+
+
+def _ptr(t, dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SdfError("HIP path needs device tensors (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise SdfError(f"expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class NeuronParams:
+    """Neuron hyper-parameters (the YAML `spiking_neuron` block) plus PSN weights when kind == 'psn'."""
+
+    def __init__(self, kind="lif", tau=2.0, v_th=1.0, v_reset=None, psn_w=None, psn_b=None):
+        self.kind, self.tau, self.v_th, self.v_reset = kind, float(tau), float(v_th), v_reset
+        self.psn_w, self.psn_b = psn_w, psn_b
+
+
+def neuron_fwd(x, out, T, nb, ni, x_sb, x_st, o_sb, o_st, p: NeuronParams, rowmap=None, rowlen=0,
+               alpha=None, beta=None, Cch=0, inner=1, add=None, add_st=0, add_period=0, v_last=None):
+    """sdf_neuron_fwd: see include/sdformerflow_hip.h for the addressing contract."""
+    d = NeuronDesc()
+    d.x, d.out, d.v_last = _ptr(x, torch.float32), _ptr(out), _ptr(v_last, torch.float32)
+    d.T = T
+    d.out_dtype = SDF_F32 if out.dtype == torch.float32 else SDF_U8
+    if out.dtype not in (torch.float32, torch.uint8):
+        raise SdfError(f"spike dtype {out.dtype} unsupported")
+    d.nb, d.ni, d.x_sb, d.x_st, d.o_sb, d.o_st = nb, ni, x_sb, x_st, o_sb, o_st
+    d.rowmap, d.rowlen = _ptr(rowmap, torch.int32), rowlen
+    d.kind = KIND[p.kind]
+    d.alpha, d.beta, d.C, d.inner = _ptr(alpha, torch.float32), _ptr(beta, torch.float32), Cch, inner
+    d.add, d.add_st, d.add_period = _ptr(add, torch.float32), add_st, add_period
+    d.tau, d.v_th = p.tau, p.v_th
+    d.v_reset = 0.0 if p.v_reset is None else float(p.v_reset)
+    d.soft_reset = 1 if p.v_reset is None else 0
+    d.psn_w, d.psn_b = _ptr(p.psn_w, torch.float32), _ptr(p.psn_b, torch.float32)
+    _check(lib().sdf_neuron_fwd(C.byref(d), _stream()), "sdf_neuron_fwd")
+    return out
+
+
+def lif_fwd(x, tau=2.0, v_th=1.0, v_reset=None, out_dtype=torch.float32, return_v=False):
+    """Multi-step LIF over dim 0 of a contiguous tensor (sdf_lif_fwd)."""
+    x = x.contiguous()
+    T, N = x.shape[0], x[0].numel()
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    v = torch.empty(x.shape[1:], dtype=torch.float32, device=x.device) if return_v else None
+    rc = lib().sdf_lif_fwd(C.c_void_p(_ptr(x, torch.float32)), C.c_void_p(_ptr(out)), C.c_void_p(_ptr(v)),
+                           C.c_int(T), C.c_int64(N), C.c_float(tau), C.c_float(v_th),
+                           C.c_int(1 if v_reset is None else 0), C.c_float(0.0 if v_reset is None else v_reset),
+                           C.c_int(SDF_F32 if out_dtype == torch.float32 else SDF_U8), _stream())
+    _check(rc, "sdf_lif_fwd")
+    return (out, v) if return_v else out
+
+
+def psn_fwd(x, W, b, out_dtype=torch.float32):
+    """Parallel spiking neuron over dim 0 of a contiguous tensor (sdf_psn_fwd)."""
+    x = x.contiguous()
+    T, N = x.shape[0], x[0].numel()
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    rc = lib().sdf_psn_fwd(C.c_void_p(_ptr(x, torch.float32)), C.c_void_p(_ptr(W.contiguous(), torch.float32)),
+                           C.c_void_p(_ptr(b.contiguous().view(-1), torch.float32)), C.c_void_p(_ptr(out)),
+                           C.c_int(T), C.c_int64(N), C.c_int(SDF_F32 if out_dtype == torch.float32 else SDF_U8),
+                           _stream())
+    _check(rc, "sdf_psn_fwd")
+    return out
+
+
+def split_weight(W, nsplit=3):
+    """fp32 weight (N,K) -> bf16 planes (nsplit,N,K) stored as int16 bit patterns (sdf_split_weight_bf16)."""
+    W = W.contiguous()
+    planes = torch.empty((nsplit,) + tuple(W.shape), dtype=torch.int16, device=W.device)
+    _check(lib().sdf_split_weight_bf16(C.c_void_p(_ptr(W, torch.float32)), C.c_void_p(planes.data_ptr()),
+                                       C.c_int64(W.numel()), C.c_int(nsplit), _stream()), "sdf_split_weight_bf16")
+    return planes
+
+
+def spike_gemm(A, Wp, out, M, N, K, lda=None, ldo=None, bias=None, alpha=None, beta=None, resid=None,
+               out_rowmap=None, zg=None):
+    """sdf_spike_gemm_fwd.  A: u8 spikes, Wp: int16 (nsplit,N,K) bf16 planes, out: fp32.
+    zg = (nH, Tq, B_, N1) selects the head-scramble A addressing."""
+    d = SpikeGemmDesc()
+    d.A, d.Wp, d.out = _ptr(A, torch.uint8), _ptr(Wp, torch.int16), _ptr(out, torch.float32)
+    d.M, d.N, d.K = M, N, K
+    d.lda = K if lda is None else lda
+    d.ldo = N if ldo is None else ldo
+    d.nsplit = Wp.shape[0]
+    d.bias, d.alpha, d.beta = _ptr(bias, torch.float32), _ptr(alpha, torch.float32), _ptr(beta, torch.float32)
+    d.resid, d.out_rowmap = _ptr(resid, torch.float32), _ptr(out_rowmap, torch.int32)
+    if zg is not None:
+        d.zg_nH, d.zg_T, d.zg_B, d.zg_N1 = zg
+    _check(lib().sdf_spike_gemm_fwd(C.byref(d), _stream()), "sdf_spike_gemm_fwd")
+    return out
+
+
+def qk_gate(q, k, e, Tq, rows, Cch, p: NeuronParams):
+    """sdf_qk_gate_fwd on u8 spike tensors laid out (Tq, rows, C)."""
+    rc = lib().sdf_qk_gate_fwd(C.c_void_p(_ptr(q, torch.uint8)), C.c_void_p(_ptr(k, torch.uint8)),
+                               C.c_void_p(_ptr(e, torch.uint8)), C.c_int(Tq), C.c_int64(rows), C.c_int(Cch),
+                               C.c_int(KIND[p.kind]), C.c_float(p.tau), C.c_float(p.v_th),
+                               C.c_float(0.0 if p.v_reset is None else p.v_reset),
+                               C.c_int(1 if p.v_reset is None else 0),
+                               C.c_void_p(_ptr(p.psn_w, torch.float32)), C.c_void_p(_ptr(p.psn_b, torch.float32)),
+                               _stream())
+    _check(rc, "sdf_qk_gate_fwd")
+    return e

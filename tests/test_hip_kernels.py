@@ -1,0 +1,173 @@
+"""GPU parity tests: each HIP kernel, through the C ABI, against the CPU oracle on identical inputs.
+Spikes are compared bit-for-bit; fp32 GEMM outputs to 1e-5 relative (tolerance stated per test)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import neuron_ref as R
+from oracle import sdformer_oracle as O
+from sdformerflow_amd import hip
+from sdformerflow_amd.synthetic import synth_uniform as rnd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def neuron_input(T, N=4096, seed=0):
+    x = rnd((T, N), 100 + T + seed, -0.3, 0.6)
+    x[:, :64] = 0.1
+    x[0, 64:128] = 0.2
+    return x
+
+
+@pytest.mark.parametrize("T", [1, 2, 4, 7, 10, 20])
+@pytest.mark.parametrize("v_reset", [None, 0.0, 0.05])
+def test_lif_bit_exact(T, v_reset):
+    x = neuron_input(T)
+    ref, vref = R.neuron_ref(x, "lif", 2.0, 0.1, v_reset, return_aux=True)
+    for dt in (torch.float32, torch.uint8):
+        s, v = hip.lif_fwd(x.to(DEV), 2.0, 0.1, v_reset, dt, return_v=True)
+        assert torch.equal(s.cpu().float(), ref)
+        assert torch.equal(v.cpu(), vref)
+
+
+def test_lif_non_power_of_two_tau():
+    x = neuron_input(10)
+    ref = R.neuron_ref(x, "lif", 3.0, 0.1, None)
+    assert torch.equal(hip.lif_fwd(x.to(DEV), 3.0, 0.1, None).cpu(), ref)
+
+
+@pytest.mark.parametrize("T", [2, 4, 10, 20])
+def test_psn_bit_exact(T):
+    x = neuron_input(T)
+    W = rnd((T, T), 5 + T, -0.5, 0.5) + 0.5 * torch.eye(T)
+    b = torch.full((T, 1), -0.1)
+    ref = R.neuron_ref(x, "psn", psn_w=W, psn_b=b)
+    s = hip.psn_fwd(x.to(DEV), W.to(DEV), b.to(DEV), torch.uint8)
+    assert torch.equal(s.cpu().float(), ref)
+    assert 0.05 < ref.mean() < 0.95
+
+
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+def test_neuron_fused_bn_pe_channel_last(kind):
+    """SN(BN(x)+PE) over T'=2 on a (T', rows, C) tensor: Spiking_swin_transformer3D.py:675-680."""
+    Tq, B_, N1, Cc = 2, 6, 81, 96
+    x = rnd((Tq, B_ * N1, Cc), 3, -1.0, 1.0)
+    alpha, beta = rnd((Cc,), 4, 0.5, 1.5), rnd((Cc,), 5, -0.2, 0.2)
+    pe = rnd((Tq, N1 * Cc), 6, -0.3, 0.3)
+    W, b = rnd((Tq, Tq), 7, -0.5, 0.5) + 0.5 * torch.eye(Tq), torch.full((Tq,), -0.1)
+    ref = R.neuron_ref(x, kind, 2.0, 0.1, None, psn_w=W, psn_b=b, alpha=alpha, beta=beta, inner=1, add=pe,
+                       add_period=N1 * Cc)
+    p = hip.NeuronParams(kind, 2.0, 0.1, None, W.to(DEV), b.to(DEV))
+    out = torch.empty((Tq, B_ * N1, Cc), dtype=torch.uint8, device=DEV)
+    n = B_ * N1 * Cc
+    hip.neuron_fwd(x.to(DEV), out, Tq, 1, n, 0, n, 0, n, p, alpha=alpha.to(DEV), beta=beta.to(DEV), Cch=Cc, inner=1,
+                   add=pe.to(DEV), add_st=N1 * Cc, add_period=N1 * Cc)
+    assert torch.equal(out.cpu().float(), ref)
+
+
+def test_neuron_fused_bn_nchw_and_strided_time():
+    """BN over dim 2 of (T,B,C,H,W) then LIF; and the (B,D,...) layout where time is the second axis."""
+    T, B, Cc, H, W = 10, 2, 8, 6, 10
+    x = rnd((T, B, Cc, H, W), 8, -1.0, 1.0)
+    alpha, beta = rnd((Cc,), 9, 0.5, 1.5), rnd((Cc,), 10, -0.2, 0.2)
+    ref = R.neuron_ref(x, "lif", 2.0, 0.1, None, alpha=alpha, beta=beta, inner=H * W)
+    p = hip.NeuronParams("lif", 2.0, 0.1, None)
+    out = torch.empty_like(x, device=DEV)
+    n = B * Cc * H * W
+    hip.neuron_fwd(x.to(DEV), out, T, 1, n, 0, n, 0, n, p, alpha=alpha.to(DEV), beta=beta.to(DEV), Cch=Cc, inner=H * W)
+    assert torch.equal(out.cpu(), ref)
+    # (B, T, inner) memory, neuron over T (the MLP's x.permute(1,0,2,3,4), :845)
+    xb = x.permute(1, 0, 2, 3, 4).contiguous()
+    ni = Cc * H * W
+    out2 = torch.empty(xb.shape, dtype=torch.uint8, device=DEV)
+    hip.neuron_fwd(xb.to(DEV), out2, T, B, ni, T * ni, ni, T * ni, ni, p, alpha=alpha.to(DEV), beta=beta.to(DEV), Cch=Cc,
+                   inner=H * W)
+    assert torch.equal(out2.cpu().float().permute(1, 0, 2, 3, 4), ref)
+
+
+@pytest.mark.parametrize("shape,shift", [((1, 4, 18, 21), (1, 4, 4)), ((2, 4, 9, 21), (0, 0, 0))])
+def test_neuron_window_gather(shape, shift):
+    """pad + roll + window_partition_v2 folded into the load (Spiking_swin_transformer3D.py:789-804, 670)."""
+    B, D, H, W = shape
+    Cc = 32
+    x = rnd((B, D, H, W, Cc), 11, -0.5, 1.0)
+    ws, ss = O.get_window_size((D, H, W), (2, 9, 9), shift)
+    xs, B_ = O.gather_slices(x, ws, ss)                                    # (2*B_, 81, C)
+    ref = O.lif_multistep(xs.view(2, B_ * 81, Cc), 2.0, 0.1, None)
+    src, _ = O.slice_table(B, D, H, W, ws, ss)
+    rowmap = torch.from_numpy(src.reshape(-1).astype(np.int32)).to(DEV)     # [t'*B_*81 + row]
+    out = torch.empty((2, B_ * 81, Cc), dtype=torch.uint8, device=DEV)
+    n = B_ * 81 * Cc
+    hip.neuron_fwd(x.to(DEV), out, 2, 1, n, 0, 0, 0, n, hip.NeuronParams("lif", 2.0, 0.1, None), rowmap=rowmap, rowlen=Cc)
+    assert torch.equal(out.cpu().float(), ref)
+
+
+def test_split_weight_reconstructs_fp32():
+    W = rnd((96, 384), 12, -0.2, 0.2)
+    W[0, 0], W[0, 1] = 1.0, -3.0e-5
+    planes = hip.split_weight(W.to(DEV), 3).cpu()
+    rec = sum((planes[i].to(torch.int32) << 16).view(torch.float32).double() for i in range(3))
+    assert (rec - W.double()).abs().max() <= 2.0 ** -24 * W.abs().max()
+
+
+def spikes(shape, seed, rate=0.3):
+    return (rnd(shape, seed, 0.0, 1.0) < rate).to(torch.uint8)
+
+
+@pytest.mark.parametrize("M,N,K", [(162 * 4, 96, 96), (1000, 384, 96), (333, 96, 384), (256, 192, 768), (130, 64, 32)])
+def test_spike_gemm_plain(M, N, K):
+    A = spikes((M, K), 20 + M)
+    W = rnd((N, K), 21, -0.3, 0.3)
+    ref = A.double() @ W.double().t()
+    out = torch.full((M, N), float("nan"), device=DEV)
+    hip.spike_gemm(A.to(DEV), hip.split_weight(W.to(DEV), 3), out, M, N, K)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= 1e-5 * ref.abs().max().item(), err          # fp32-grade: 3 bf16 planes, fp32 accumulate
+
+
+def test_spike_gemm_epilogue_bias_bn_resid_scatter():
+    M, N, K = 500, 96, 192
+    A = spikes((M, K), 30)
+    W, bias = rnd((N, K), 31, -0.3, 0.3), rnd((N,), 32, -0.1, 0.1)
+    alpha, beta = rnd((N,), 33, 0.5, 1.5), rnd((N,), 34, -0.2, 0.2)
+    perm = torch.randperm(M + 50, generator=torch.Generator().manual_seed(0))[:M].to(torch.int32)
+    perm[::7] = -1                                              # dropped rows (window padding)
+    resid = rnd((M + 50, N), 35)
+    ref = resid.clone().double()
+    y = (A.double() @ W.double().t() + bias.double()) * alpha.double() + beta.double()
+    keep = perm >= 0
+    ref[perm[keep].long()] = y[keep] + resid.double()[perm[keep].long()]
+    out = resid.clone().to(DEV)
+    hip.spike_gemm(A.to(DEV), hip.split_weight(W.to(DEV), 3), out, M, N, K, bias=bias.to(DEV), alpha=alpha.to(DEV),
+                   beta=beta.to(DEV), resid=out, out_rowmap=perm.to(DEV))
+    assert (out.cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("B_,nH", [(4, 3), (2, 6), (1, 12)])
+def test_spike_gemm_head_scramble(B_, nH):
+    """A addressed through Z[t,b,n,g*32+d] = E_flat[((((b*nH+g)*2+t)*81+n)*32+d] (:709-710)."""
+    Tq, N1, hd = 2, 81, 32
+    Cc = nH * hd
+    E = spikes((Tq, B_, N1, Cc), 40 + nH)
+    tab = torch.from_numpy(O.z_gather_table(B_, nH, Tq, N1, hd))
+    Z = E.reshape(-1)[tab.reshape(-1)].view(Tq * B_ * N1, Cc)
+    W = rnd((Cc, Cc), 41, -0.3, 0.3)
+    ref = Z.double() @ W.double().t()
+    out = torch.empty((Tq * B_ * N1, Cc), device=DEV)
+    hip.spike_gemm(E.to(DEV), hip.split_weight(W.to(DEV), 3), out, Tq * B_ * N1, Cc, Cc, zg=(nH, Tq, B_, N1))
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+def test_qk_gate(kind):
+    Tq, rows, Cc, nH = 2, 81 * 5, 96, 3
+    q, k = spikes((Tq, rows, Cc), 50, 0.2), spikes((Tq, rows, Cc), 51, 0.5)
+    W, b = rnd((Tq, Tq), 52, 0.0, 0.2) + 0.1 * torch.eye(Tq), torch.full((Tq,), -0.5)
+    a = q.float().view(Tq, rows, nH, 32).sum(-1)
+    A = R.neuron_ref(a, kind, 2.0, 0.1, None, psn_w=W, psn_b=b)
+    ref = k.float() * A.repeat_interleave(32, dim=-1)
+    e = torch.empty((Tq, rows, Cc), dtype=torch.uint8, device=DEV)
+    hip.qk_gate(q.to(DEV), k.to(DEV), e, Tq, rows, Cc, hip.NeuronParams(kind, 2.0, 0.1, None, W.to(DEV), b.to(DEV)))
+    assert torch.equal(e.cpu().float(), ref)
+    assert 0.02 < ref.mean() < 0.6
