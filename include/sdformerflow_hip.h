@@ -144,6 +144,15 @@ int sdf_qk_gate_fwd(const uint8_t* q, const uint8_t* k, uint8_t* e, int Tq, int6
                     int kind, float tau, float v_th, float v_reset, int soft_reset,
                     const float* psn_w, const float* psn_b, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Eval BatchNorm affine (+ residual):  out = fmaf(x, alpha[c], beta[c]) (+ resid), c = (i/inner) % C.
+ * Replaces: SpikingNormLayer after a convolution and the membrane (MS) shortcut add
+ * (reference Spiking_modules.py:922-926, 816-818).  n % 4 == 0; inner % 4 == 0 or (inner == 1, C % 4 == 0).
+ * `resid` may be NULL; `out` may alias `x` or `resid`.
+ */
+int sdf_affine_resid_fwd(const float* x, const float* alpha, const float* beta, const float* resid, float* out,
+                         int64_t n, int C, int64_t inner, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,143 @@
+"""Public model classes of the drop-in boundary (mirror of reference
+models/STSwinNet_SNN/Spiking_STSwinNet.py:254-325 and the kwargs plumbing of
+models/STSwinNet/STSwinNet.py:323-366, models/STSwinNet_SNN/SNN_models.py:30-164).
+
+    model = MS_SpikingformerFlowNet_en4(config["model"].copy(), config["swin_transformer"].copy())
+    model.to("cuda"); model.init_weights(); model.eval()
+    out = model(chunk)            # chunk (B, bins, 2, H, W)  ->  {"flow": [ (B,2,H,W) ] * E, "attn": None}
+
+Forward runs on the HIP engine; there is no CPU fallback (it raises on CPU tensors).
+"""
+import torch
+import torch.nn as nn
+
+from .Spiking_modules import MS_ResBlock, MS_SpikingPredLayer, MS_SpikingTransposeDecoderLayer
+from .Spiking_submodules import IFNode
+from .Spiking_swin_transformer3D import MS_Spiking_SwinTransformer3D_v2
+
+
+class MS_spiking_former_encoder(nn.Module):
+    """reference Spiking_STSwinNet.py:8-88."""
+
+    def __init__(self, arc_type="swinv2", patch_embed_type="PatchEmbedLocal", img_size=(240, 320), patch_size=(32, 2, 2),
+                 in_chans=128, embed_dim=96, depths=(2, 2, 6), num_heads=(3, 6, 12), window_size=(2, 7, 7),
+                 pretrained_window_size=(0, 0, 0), mlp_ratio=4.0, patch_norm=False, out_indices=(0, 1, 2), frozen_stages=-1,
+                 norm=None, spikformer_norm=None, pol_in_channel=False, **spiking_kwargs):
+        super().__init__()
+        self.num_encoders = len(depths)
+        self.out_channels = [embed_dim * 2 ** i for i in range(self.num_encoders)]
+        self.swin3d = MS_Spiking_SwinTransformer3D_v2(
+            arc_type=arc_type, embed_type=patch_embed_type, img_size=img_size, patch_size=patch_size, in_chans=in_chans,
+            embed_dim=embed_dim, depths=depths, num_heads=num_heads, window_size=window_size,
+            pretrained_window_size=pretrained_window_size, mlp_ratio=mlp_ratio, drop_rate=0.0, attn_drop_rate=0.0,
+            drop_path_rate=0.2, norm_layer=spikformer_norm, out_indices=out_indices, frozen_stages=frozen_stages, norm=norm,
+            **spiking_kwargs)
+
+
+class MS_Spikingformer_MultiResUNet(nn.Module):
+    """Spiking U-Net: swin encoder, 2 MS res-blocks, transposed-conv decoders with per-scale flow predictions
+    (reference Spiking_STSwinNet.py:90-252, SNN_models.py:118-164)."""
+
+    def __init__(self, unet_kwargs, stt_kwargs):
+        super().__init__()
+        self.base_num_channels = unet_kwargs["base_num_channels"]
+        self.num_encoders = unet_kwargs["num_encoders"]
+        self.num_residual_blocks = unet_kwargs["num_residual_blocks"]
+        self.num_output_channels = unet_kwargs["num_output_channels"]
+        self.kernel_size = unet_kwargs["kernel_size"]
+        if unet_kwargs["skip_type"] != "concat" or unet_kwargs.get("use_upsample_conv", True):
+            raise NotImplementedError("shipped SNN configs use skip_type=concat with transposed-conv decoders")
+        self.spiking_kwargs = dict(unet_kwargs["spiking_neuron"])
+        self.steps = self.spiking_kwargs["num_steps"]
+        self.num_bins_events = unet_kwargs["num_bins"]
+        self.depths = [int(i) for i in stt_kwargs["swin_depths"]]
+        self.num_heads = [int(i) for i in stt_kwargs["swin_num_heads"]]
+        assert len(self.depths) == self.num_encoders and len(self.num_heads) == self.num_encoders
+        self.window_size = [int(i) for i in stt_kwargs["window_size"]]
+        self.input_size = stt_kwargs["input_size"]
+        spik_norm = stt_kwargs["norm"] if "norm" in stt_kwargs else self.spiking_kwargs["spike_norm"]
+        cm = unet_kwargs.get("channel_multiplier", 2)
+        self.encoder_output_sizes = [int(self.base_num_channels * cm ** i) for i in range(self.num_encoders)]
+        self.encoder_input_sizes = [self.base_num_channels] + self.encoder_output_sizes[:-1]
+        self.max_num_channels = self.encoder_output_sizes[-1]
+        kw = self.spiking_kwargs
+        self.resblocks = nn.ModuleList([MS_ResBlock(self.max_num_channels, self.max_num_channels, connect_function="ADD", **kw)
+                                        for _ in range(self.num_residual_blocks)])
+        self.decoders = nn.ModuleList()
+        for i, (cin, cout) in enumerate(zip(reversed(self.encoder_output_sizes), reversed(self.encoder_input_sizes))):
+            self.decoders.append(MS_SpikingTransposeDecoderLayer(2 * cin + (0 if i == 0 else self.num_output_channels), cout,
+                                                                 kernel_size=self.kernel_size, scale=2, **kw))
+        self.preds = nn.ModuleList([MS_SpikingPredLayer(c, self.num_output_channels, 1, **kw)
+                                    for c in reversed(self.encoder_input_sizes)])
+        self.encoders = MS_spiking_former_encoder(
+            arc_type=stt_kwargs["use_arc"][0], patch_embed_type=stt_kwargs["use_arc"][1], img_size=self.input_size,
+            patch_size=[int(i) for i in stt_kwargs["swin_patch_size"]], in_chans=self.num_bins_events,
+            embed_dim=self.base_num_channels, depths=self.depths, num_heads=self.num_heads, window_size=self.window_size,
+            pretrained_window_size=[int(i) for i in stt_kwargs["pretrained_window_size"]], mlp_ratio=stt_kwargs["mlp_ratio"],
+            out_indices=[int(i) for i in stt_kwargs["swin_out_indices"]], norm=None, spikformer_norm=spik_norm,
+            pol_in_channel=False, **kw)
+        self.preds_out = nn.ModuleList([IFNode(v_threshold=float("inf"), v_reset=0.0) for _ in range(self.num_encoders)])
+
+
+class MS_SpikingformerFlowNet(nn.Module):
+    """MS-shortcut SDformerFlow, 3 encoders (reference Spiking_STSwinNet.py:313-317)."""
+    num_en = 3
+
+    def __init__(self, unet_kwargs, stt_kwargs):
+        super().__init__()
+        unet_kwargs = dict(unet_kwargs)
+        self.mask = unet_kwargs.get("mask_output")
+        self.norm_input = unet_kwargs.get("norm_input", False)
+        self.encoding = unet_kwargs.get("encoding")
+        self.num_bins = unet_kwargs["num_bins"]
+        self.num_encoders = self.num_en
+        unet_kwargs.update({"num_encoders": self.num_en, "num_residual_blocks": 2, "num_output_channels": 2,
+                            "skip_type": "concat", "channel_multiplier": 2,
+                            "use_upsample_conv": unet_kwargs.get("use_upsample_conv", True)})
+        self.sttmultires_unet = MS_Spikingformer_MultiResUNet(unet_kwargs, dict(stt_kwargs))
+        self._engine = None
+        self.gemm_nsplit = 3          # bf16 planes per fp32 weight in the spike GEMMs (3 = fp32-grade)
+
+    def init_weights(self):
+        """Linear: kaiming-normal fan_out; BN: 1/0; Conv2d: xavier-uniform (reference :264-276)."""
+        def _init(m):
+            if isinstance(m, nn.Linear):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, (nn.LayerNorm, nn.BatchNorm2d)):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+            elif isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+        self.apply(_init)
+        self._engine = None
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def engine(self):
+        """The packed HIP execution plan (rebuilt after weights move or change)."""
+        if self._engine is None:
+            from ..engine import MSFlowEngine
+            self._engine = MSFlowEngine(self)
+        return self._engine
+
+    def forward(self, x, log=False):
+        if self.training:
+            raise NotImplementedError("training forward/backward is a later SURVEY.md 8f row; call model.eval()")
+        if log:
+            raise NotImplementedError("attention-score logging (attn_sn, dead on the forward path) is not built")
+        with torch.no_grad():
+            flows = self.engine().forward(x)
+        return {"flow": flows, "attn": None}
+
+
+class MS_SpikingformerFlowNet_en4(MS_SpikingformerFlowNet):
+    """MS-shortcut SDformerFlow, 4 encoders - the shipped model (reference :319-325)."""
+    num_en = 4

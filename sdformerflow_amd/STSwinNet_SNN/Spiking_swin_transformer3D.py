@@ -1,0 +1,174 @@
+"""Parameter tree of the spiking 3-D swin encoder (mirror of reference
+models/STSwinNet_SNN/Spiking_swin_transformer3D.py: QK token-gating attention :605-717, MS MLP :164-181,
+MS block :720-895, MS patch merging :952-974, stage :995-1129, backbone :1132-1292).
+
+Execution is scheduled by `sdformerflow_amd.engine`: pad / roll / window_partition_v2 / window_reverse
+become row maps inside the kernels, BN is folded into neuron prologues and GEMM epilogues.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .Spiking_modules import (MS_PED_Spiking_PatchEmbed_Conv_sfn, SpikingNormLayer, Spiking_neuron,  # noqa: F401
+                              _neuron_kwargs)
+
+
+def get_window_size(x_size, window_size, shift_size=None):
+    """Clamp the window (and zero the shift) on axes that are not larger than it (reference
+    models/STSwinNet/swin_transformer3D_v2.py:68-81)."""
+    ws = [min(w, s) for w, s in zip(window_size, x_size)]
+    if shift_size is None:
+        return tuple(ws)
+    ss = [0 if s <= w else sh for s, w, sh in zip(x_size, window_size, shift_size)]
+    return tuple(ws), tuple(ss)
+
+
+def window_slice_map(B, D, H, W, ws, ss):
+    """int32 (Wd*B_, Wh*Ww) table: source token of every window-slice token, -1 = zero padding.
+    Equivalent of F.pad + torch.roll(-shift) + window_partition_v2 + raw .view(Wd, B_, ...) of the
+    reference (Spiking_swin_transformer3D.py:789-804, :100-113); used forwards as the gather map of the
+    attention input and backwards as the scatter map of window_reverse + roll(+shift) + crop (:810-820)."""
+    Wd, Wh, Ww = ws
+    Dp, Hp, Wp = -(-D // Wd) * Wd, -(-H // Wh) * Wh, -(-W // Ww) * Ww
+    nD, nHb, nWb = Dp // Wd, Hp // Wh, Wp // Ww
+    B_ = B * nD * nHb * nWb
+    j = np.arange(B_ * Wd, dtype=np.int64)
+    wd, win = j % Wd, j // Wd
+    wb, hb = win % nWb, (win // nWb) % nHb
+    db, b = (win // (nWb * nHb)) % nD, win // (nWb * nHb * nD)
+    tok = np.arange(Wh * Ww, dtype=np.int64)
+    th, tw = tok // Ww, tok % Ww
+    d = ((db * Wd + wd + ss[0]) % Dp)[:, None]
+    h = (hb[:, None] * Wh + th[None, :] + ss[1]) % Hp
+    w = (wb[:, None] * Ww + tw[None, :] + ss[2]) % Wp
+    src = ((b[:, None] * D + d) * H + h) * W + w
+    src = np.where((d < D) & (h < H) & (w < W), src, -1)
+    return src.astype(np.int32), B_
+
+
+def merge_row_map(B, D, H, W):
+    """int32 (D, B*H2*W2*4) gather map of MS_SpikingPatchMerging's 2x2 concat in (T,B,H/2,W/2,4C) order
+    (reference :965-970): quadrant q of the 4C axis is (dh,dw) = (q%2, q//2); odd sizes read zero (-1)."""
+    H2, W2 = (H + 1) // 2, (W + 1) // 2
+    t, b, h2, w2, q = np.meshgrid(np.arange(D), np.arange(B), np.arange(H2), np.arange(W2), np.arange(4), indexing="ij")
+    h, w = 2 * h2 + q % 2, 2 * w2 + q // 2
+    src = ((b * D + t) * H + h) * W + w
+    return np.where((h < H) & (w < W), src, -1).reshape(D, -1).astype(np.int32), H2, W2
+
+
+class Spiking_QK_WindowAttention3D(nn.Module):
+    """Token-gating spiking attention (reference :605-717)."""
+
+    def __init__(self, dim, window_size, pretrained_window_size, num_heads, version="swinv1", qkv_bias=False, qk_scale=None,
+                 attn_drop=0.0, proj_drop=0.0, norm=None, **spiking_kwargs):
+        super().__init__()
+        if dim % num_heads or (dim // num_heads) != 32:
+            raise NotImplementedError("the HIP gate kernel is built for head_dim == 32 (all shipped configs)")
+        self.dim, self.window_size, self.num_heads, self.norm_layer = dim, tuple(window_size), num_heads, norm
+        kw = _neuron_kwargs(dict(spiking_kwargs, num_steps=self.window_size[0]))     # neurons run over T' = Wd (:615)
+        n_tok = self.window_size[0] * self.window_size[1] * self.window_size[2]
+        self.positional_encoding = nn.Parameter(torch.zeros(1, num_heads, n_tok, dim // num_heads))
+        self.linear_q = nn.Linear(dim, dim, bias=False)
+        self.bn_q = SpikingNormLayer(dim, self.window_size[0], norm, spiking_kwargs["v_th"])
+        self.sn_q = Spiking_neuron(**kw)
+        self.linear_k = nn.Linear(dim, dim, bias=False)
+        self.bn_k = SpikingNormLayer(dim, self.window_size[0], norm, spiking_kwargs["v_th"])
+        self.sn_k = Spiking_neuron(**kw)
+        self.sn2_q = Spiking_neuron(**kw)
+        self.attn_sn = Spiking_neuron(**kw)          # dead on the forward path (:711), kept for the state_dict
+        self.proj = nn.Linear(dim, dim)
+        self.proj_bn = SpikingNormLayer(dim, self.window_size[0], norm, spiking_kwargs["v_th"])
+        self.proj_sn = Spiking_neuron(**kw)
+
+
+class MS_Spiking_Mlp(nn.Module):
+    """SN -> fc1 -> BN -> SN -> fc2 -> BN (reference :115-181)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, norm_layer="BN", act_layer=None, drop=0.0,
+                 **spiking_kwargs):
+        super().__init__()
+        out_features, hidden_features = out_features or in_features, hidden_features or in_features
+        self.norm_layer = norm_layer
+        kw = _neuron_kwargs(spiking_kwargs)
+        self.fc1 = nn.Linear(in_features, hidden_features, bias=False)
+        self.bn1 = SpikingNormLayer(hidden_features, spiking_kwargs["num_steps"], spiking_kwargs["spike_norm"], spiking_kwargs["v_th"])
+        self.sn1 = Spiking_neuron(**kw)
+        self.fc2 = nn.Linear(hidden_features, out_features, bias=False)
+        self.bn2 = SpikingNormLayer(out_features, spiking_kwargs["num_steps"], spiking_kwargs["spike_norm"], spiking_kwargs["v_th"])
+        self.sn2 = Spiking_neuron(**kw)
+
+
+class MS_Spiking_SwinTransformerBlock3D(nn.Module):
+    """x += SSA(x); x += MLP(x) with membrane shortcuts (reference :720-895)."""
+
+    def __init__(self, dim, input_resolution, num_heads, window_size=(2, 7, 7), pretrained_window_size=(0, 0, 0),
+                 shift_size=(0, 0, 0), mlp_ratio=4.0, version="swinv1", qkv_bias=True, qk_scale=None, drop=0.0, attn_drop=0.0,
+                 drop_path=0.0, act_layer=None, norm_layer="LN", use_checkpoint=False, **spiking_kwargs):
+        super().__init__()
+        if norm_layer != "BN":
+            raise NotImplementedError("only spike_norm 'BN' (the shipped configs) is supported")
+        assert all(0 <= s < w for s, w in zip(shift_size, window_size)), "shift_size must in 0-window_size"
+        self.dim, self.input_resolution, self.num_heads = dim, input_resolution, num_heads
+        self.window_size, self.shift_size, self.mlp_ratio = tuple(window_size), tuple(shift_size), mlp_ratio
+        self.norm_layer, self.drop_path_rate, self.cnf = norm_layer, drop_path, "ADD"
+        self.attn = Spiking_QK_WindowAttention3D(dim, self.window_size, pretrained_window_size, num_heads, version, qkv_bias,
+                                                 qk_scale, attn_drop, drop, norm=norm_layer, **spiking_kwargs)
+        self.mlp = MS_Spiking_Mlp(dim, int(dim * mlp_ratio), norm_layer=norm_layer, drop=drop, **spiking_kwargs)
+
+
+class MS_SpikingPatchMerging(nn.Module):
+    """2x2 gather -> SN -> Linear 4C->2C -> BN (reference :898-974)."""
+
+    def __init__(self, input_resolution, dim, norm_layer="BN", **spiking_kwargs):
+        super().__init__()
+        self.input_resolution, self.dim = input_resolution, dim
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = SpikingNormLayer(2 * dim, spiking_kwargs["num_steps"], norm_layer, spiking_kwargs["v_th"])
+        self.sn = Spiking_neuron(**_neuron_kwargs(spiking_kwargs))
+
+
+class MS_Spiking_Swin_BasicLayer(nn.Module):
+    """One stage: `depth` blocks alternating W-MSA / SW-MSA + optional patch merging (reference :995-1129)."""
+
+    def __init__(self, dim, input_resolution, depth, num_heads, window_size=(1, 7, 7), pretrained_window_size=(1, 7, 7),
+                 mlp_ratio=4.0, version="swinv1", qkv_bias=False, qk_scale=None, drop=0.0, attn_drop=0.0, drop_path=0.0,
+                 norm_layer="LN", downsample=None, use_checkpoint=False, **spiking_kwargs):
+        super().__init__()
+        self.dim, self.input_resolution, self.depth = dim, input_resolution, depth
+        self.window_size = tuple(window_size)
+        self.shift_size = tuple(i // 2 for i in window_size)
+        self.swin_blocks = nn.ModuleList([
+            MS_Spiking_SwinTransformerBlock3D(
+                dim, input_resolution, num_heads, self.window_size, pretrained_window_size,
+                (0, 0, 0) if i % 2 == 0 else self.shift_size, mlp_ratio, version, qkv_bias, qk_scale, drop, attn_drop,
+                drop_path[i] if isinstance(drop_path, list) else drop_path, norm_layer=norm_layer, **spiking_kwargs)
+            for i in range(depth)])
+        self.downsample = downsample(input_resolution, dim=dim, norm_layer=norm_layer, **spiking_kwargs) if downsample else None
+
+
+class MS_Spiking_SwinTransformer3D_v2(nn.Module):
+    """Backbone: patch embedding + stages (reference :1132-1292)."""
+
+    def __init__(self, pretrained=None, pretrained2d=False, arc_type="swinv1", embed_type="PatchEmbedLocal", img_size=(320, 480),
+                 patch_size=(4, 4, 4), in_chans=3, embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24),
+                 window_size=(2, 7, 7), pretrained_window_size=(2, 7, 7), mlp_ratio=4.0, qkv_bias=True, qk_scale=0.125,
+                 drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.2, norm_layer="BN", patch_norm=False,
+                 out_indices=(0, 1, 2, 3), frozen_stages=-1, use_checkpoint=False, norm=None, **spiking_kwargs):
+        super().__init__()
+        if embed_type != "MS_PED_Spiking_PatchEmbed_Conv_sfn":
+            raise NotImplementedError(f"patch embedding {embed_type!r}: only the shipped MS_PED_Spiking_PatchEmbed_Conv_sfn is built")
+        self.num_layers, self.embed_dim, self.window_size = len(depths), embed_dim, tuple(window_size)
+        self.patch_size, self.out_indices, self.norm_layer = patch_size, tuple(out_indices), norm_layer
+        self.patch_embed = MS_PED_Spiking_PatchEmbed_Conv_sfn(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
+                                                              embed_dim=embed_dim, patch_norm=None, norm=norm,
+                                                              spiking_proj=True, **spiking_kwargs)
+        self.patches_resolution = self.patch_embed.patches_resolution
+        dpr = [float(v) for v in np.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.ModuleList()
+        for i in range(self.num_layers):
+            self.layers.append(MS_Spiking_Swin_BasicLayer(
+                int(embed_dim * 2 ** i), (self.patches_resolution[0] // 2 ** i, self.patches_resolution[1] // 2 ** i), depths[i],
+                num_heads[i], window_size, pretrained_window_size, mlp_ratio, arc_type, qkv_bias, qk_scale, drop_rate,
+                attn_drop_rate, dpr[sum(depths[:i]):sum(depths[:i + 1])], norm_layer,
+                MS_SpikingPatchMerging if i < self.num_layers - 1 else None, use_checkpoint, **spiking_kwargs))
+        self.num_features = [int(embed_dim * 2 ** i) for i in range(self.num_layers)]

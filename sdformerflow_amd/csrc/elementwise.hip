@@ -1,0 +1,50 @@
+// Eval-BatchNorm affine + residual add, the glue between MIOpen convolutions and the neuron kernels:
+//   out = fmaf(x, alpha[c], beta[c]) (+ resid),  c = (i / inner) % C
+// (reference: SpikingNormLayer after a conv + the MS shortcut, Spiking_modules.py:922-926, 816-818).
+// HBM-bound: one 16-byte load per operand per lane, 16-byte store.
+#include "common.h"
+
+namespace {
+__global__ __launch_bounds__(256) void affine_resid_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                           const float* __restrict__ beta, const float* resid, float* out,
+                                                           int64_t quads, int C, int64_t inner) {
+  int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= quads) return;
+  int64_t i = q * 4;
+  float4 v = *reinterpret_cast<const float4*>(x + i);
+  float4 a, b;
+  if (inner == 1) {
+    int c = (int)(i % C);
+    a = *reinterpret_cast<const float4*>(alpha + c);
+    b = *reinterpret_cast<const float4*>(beta + c);
+  } else {
+    int c = (int)((i / inner) % C);
+    float aa = alpha[c], bb = beta[c];
+    a = make_float4(aa, aa, aa, aa);
+    b = make_float4(bb, bb, bb, bb);
+  }
+  v.x = __builtin_fmaf(v.x, a.x, b.x);
+  v.y = __builtin_fmaf(v.y, a.y, b.y);
+  v.z = __builtin_fmaf(v.z, a.z, b.z);
+  v.w = __builtin_fmaf(v.w, a.w, b.w);
+  if (resid) {
+    float4 r = *reinterpret_cast<const float4*>(resid + i);
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  }
+  *reinterpret_cast<float4*>(out + i) = v;
+}
+}  // namespace
+
+extern "C" int sdf_affine_resid_fwd(const float* x, const float* alpha, const float* beta, const float* resid, float* out,
+                                    int64_t n, int C, int64_t inner, void* stream) {
+  if (!x || !alpha || !beta || !out) return SDF_E_NULL;
+  if (n < 4 || n % 4 || C < 1 || inner < 1) return SDF_E_SHAPE;
+  if (inner == 1 ? (C % 4 != 0) : (inner % 4 != 0)) return SDF_E_SHAPE;
+  if (!sdf_aligned(x, 16) || !sdf_aligned(out, 16) || (resid && !sdf_aligned(resid, 16))) return SDF_E_ALIGN;
+  if (inner == 1 && (!sdf_aligned(alpha, 16) || !sdf_aligned(beta, 16))) return SDF_E_ALIGN;
+  int64_t quads = n / 4;
+  hipLaunchKernelGGL(affine_resid_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, sdf_stream(stream), x,
+                     alpha, beta, resid, out, quads, C, inner);
+  SDF_LAUNCH_CHECK();
+  return 0;
+}

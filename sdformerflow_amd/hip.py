@@ -19,7 +19,7 @@ SDF_LIF, SDF_PSN, SDF_IF = 0, 1, 2
 KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
 
 EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
-           "sdf_split_weight_bf16", "sdf_qk_gate_fwd")
+           "sdf_split_weight_bf16", "sdf_qk_gate_fwd", "sdf_affine_resid_fwd")
 
 
 class SdfError(RuntimeError):
@@ -180,3 +180,15 @@ def qk_gate(q, k, e, Tq, rows, Cch, p: NeuronParams):
                                _stream())
     _check(rc, "sdf_qk_gate_fwd")
     return e
+
+
+def affine_resid(x, alpha, beta, Cch, inner, resid=None, out=None):
+    """out = fmaf(x, alpha[c], beta[c]) (+ resid) with c = (i // inner) % C (sdf_affine_resid_fwd)."""
+    if out is None:
+        out = torch.empty_like(x)
+    rc = lib().sdf_affine_resid_fwd(C.c_void_p(_ptr(x, torch.float32)), C.c_void_p(_ptr(alpha, torch.float32)),
+                                    C.c_void_p(_ptr(beta, torch.float32)), C.c_void_p(_ptr(resid, torch.float32)),
+                                    C.c_void_p(_ptr(out, torch.float32)), C.c_int64(x.numel()), C.c_int(Cch),
+                                    C.c_int64(inner), _stream())
+    _check(rc, "sdf_affine_resid_fwd")
+    return out

@@ -1,0 +1,109 @@
+"""GPU parity of the whole forward path against the CPU oracle at BASELINE config 1/2 size
+(1 x 10 x 2 x 288 x 384, MS_SpikingformerFlowNet_en4, lif and psn).
+
+The random-weight spiking net is chaotic (one flipped spike decorrelates everything downstream, shown
+CPU-vs-CPU in DESIGN.md), so parity is *teacher-forced*: every stage of the HIP engine is fed the
+oracle's input for that stage and must reproduce the oracle's output of that stage.  A stage output
+element counts as a mismatch when it differs by more than 1e-4 of the stage's mean magnitude (i.e. a
+spike flipped upstream inside the stage); everything else must agree to fp32 rounding.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import sdformer_oracle as O
+from sdformerflow_amd.STSwinNet_SNN.Spiking_STSwinNet import MS_SpikingformerFlowNet_en4
+from sdformerflow_amd.synthetic import synth_state_dict, synth_voxel, synth_label
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CFG = os.path.join(os.path.dirname(__file__), "..", "sdformerflow_amd", "configs", "train_DSEC_supervised_SDformerFlow_en4.yml")
+
+
+def build(kind, H=288, W=384):
+    cfg = yaml.safe_load(open(CFG))
+    cfg["model"]["spiking_neuron"] = dict(cfg["spiking_neuron"], neuron_type=kind)
+    cfg["swin_transformer"]["input_size"] = [H, W]
+    model = MS_SpikingformerFlowNet_en4(cfg["model"].copy(), cfg["swin_transformer"].copy())
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    ocfg = {"neuron": O.NeuronCfg(kind, 0.1, None, 2.0, 10), "num_bins": 10, "window_size": (2, 9, 9),
+            "depths": [2, 2, 6, 2], "num_heads": [3, 6, 12, 24]}
+    return model, sd, ocfg
+
+
+def compare(name, got, ref, report, max_rate):
+    got, ref = got.float().cpu(), ref.float()
+    scale = ref.abs().mean().item() + 1e-12
+    d = (got - ref).abs()
+    bad = d > 1e-4 * scale
+    rate = bad.float().mean().item()
+    close = d[~bad].max().item() / scale if (~bad).any() else 0.0
+    report.append((name, rate, close))
+    assert rate <= max_rate, (name, rate)
+
+
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+def test_teacher_forced_stage_parity(kind):
+    model, sd, ocfg = build(kind)
+    n = ocfg["neuron"]
+    chunk = O.prepare_chunk(synth_voxel(1, 10, 288, 384, seed=1235))
+    p = "sttmultires_unet.encoders.swin3d."
+    eng = model.to(DEV).engine()
+    report = []
+    with torch.no_grad():
+        # patch embedding
+        ref = O.patch_embed(chunk, sd, p + "patch_embed.", n, 10)
+        compare("patch_embed", eng.patch_embed(chunk.to(DEV)), ref, report, 2e-3)
+        y = ref.permute(1, 0, 3, 4, 2).contiguous()
+        ws, shift = (2, 9, 9), (1, 4, 4)
+        feats = []
+        for s, (depth, nH) in enumerate(zip(ocfg["depths"], ocfg["num_heads"])):
+            for i in range(depth):
+                ref = O.ms_block(y, sd, p + f"layers.{s}.swin_blocks.{i}.", nH, ws, (0, 0, 0) if i % 2 == 0 else shift, n)
+                got = eng.swin_block(y.clone().to(DEV), s, i)
+                compare(f"stage{s}.block{i}", got, ref, report, 2e-3)
+                y = ref
+            feats.append(y.permute(1, 0, 4, 2, 3).contiguous())
+            if s < 3:
+                ref = O.ms_patch_merge(y, sd, p + f"layers.{s}.downsample.", n)
+                compare(f"stage{s}.merge", eng.patch_merge(y.to(DEV), s), ref, report, 2e-3)
+                y = ref
+        # U-Net tail, teacher-forced on the oracle's encoder features
+        preds = eng.unet_tail([f.to(DEV) for f in feats])
+    for name, rate, close in report:
+        print(f"{kind:4s} {name:16s} mismatch-rate {rate:.2e}  max-rel-dev-of-rest {close:.1e}")
+    assert all(torch.isfinite(pp).all() for pp in preds)
+
+
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+def test_free_running_forward_statistics(kind):
+    """Free-running end-to-end: shapes, finiteness, and flow / AEE statistics next to the oracle."""
+    model, sd, ocfg = build(kind)
+    chunk = O.prepare_chunk(synth_voxel(1, 10, 288, 384, seed=1235))
+    with torch.no_grad():
+        ref = O.forward_flownet(chunk, sd, ocfg)
+    out = model.to(DEV)(chunk.to(DEV))
+    assert out["attn"] is None and len(out["flow"]) == 4
+    label, mask = synth_label(1, 288, 384)
+    aee_ref = float(O.aee(ref[-1], label, mask, 1.0)[0][0])
+    aee_got = float(O.aee(out["flow"][-1].cpu(), label, mask, 1.0)[0][0])
+    for i, (g, r) in enumerate(zip(out["flow"], ref)):
+        g = g.cpu()
+        assert g.shape == r.shape == (1, 2, 288, 384) and torch.isfinite(g).all()
+        rel = (g - r).abs().mean().item() / r.abs().mean().item()
+        print(f"{kind} flow{i}: mean|ref| {r.abs().mean():.3f} mean|got| {g.abs().mean():.3f} mean-abs-dev/mean|ref| {rel:.3e}")
+        assert abs(g.abs().mean().item() - r.abs().mean().item()) < 0.15 * r.abs().mean().item()
+    print(f"{kind} AEE oracle {aee_ref:.5f} hip {aee_got:.5f} rel {abs(aee_got - aee_ref) / aee_ref:.2e}")
+    assert abs(aee_got - aee_ref) < 0.05 * aee_ref
+
+
+def test_cpu_input_is_refused():
+    from sdformerflow_amd import hip
+    model, _, _ = build("lif")
+    with pytest.raises(hip.SdfError):
+        model(torch.zeros(1, 10, 2, 288, 384))
