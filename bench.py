@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Benchmark of the SDformerFlow forward hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--neuron lif|psn] [--no-cpu]
+
+One "step" = one forward of MS_SpikingformerFlowNet_en4 over one synthetic 1 x 10 x 2 x 288 x 384 event
+voxel (BASELINE config 2) already resident in HBM.  For N > 1 the driver launches one process per GPU
+(torch.distributed.run); the forward does not shard inside a micro-batch (batch elements are
+coupled by the reference's raw reshapes), so every rank runs an independent replica: weak scaling, no
+data-path collective, value = N*K / max-over-ranks(time).
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant own kernel, timed live with HIP events on the
+launch stream) and `cpu_baseline` (the CPU oracle = port of the reference, timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_DENSE_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+PEAK_HBM_GBPS = 8000.0              # same guide: 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def build_model(kind, device):
+    from sdformerflow_amd.STSwinNet_SNN.Spiking_STSwinNet import MS_SpikingformerFlowNet_en4
+    from sdformerflow_amd.synthetic import synth_state_dict
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "sdformerflow_amd", "configs", "train_DSEC_supervised_SDformerFlow_en4.yml")))
+    cfg["model"]["spiking_neuron"] = dict(cfg["spiking_neuron"], neuron_type=kind)
+    cfg["swin_transformer"]["input_size"] = [288, 384]
+    model = MS_SpikingformerFlowNet_en4(cfg["model"].copy(), cfg["swin_transformer"].copy())
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    return model.to(device), sd
+
+
+def synthetic_chunk():
+    """Harness input prep of eval_DSEC_flow_SNN.py:179-205 on a seeded DSEC-like voxel."""
+    from sdformerflow_amd.harness import prepare_chunk
+    from sdformerflow_amd.synthetic import synth_voxel
+    return prepare_chunk(synth_voxel(1, 10, 288, 384, seed=1235))
+
+
+def time_dominant_kernels(model, iters=20):
+    """Live HIP-event timing (on the launch stream = torch's current stream) of the two kernel families
+    that carry the block: the stage-0 fc1 spike GEMM (MFMA-bound) and the T=10 neuron update (HBM-bound)."""
+    from sdformerflow_amd import hip
+    eng = model.engine()
+    dev = eng.device
+    blk = eng.stages[0][0]
+    M, K, N = 10 * 72 * 96, blk.fc1.K, blk.fc1.N
+    A = (torch.rand((M, K), device=dev) < 0.3).to(torch.uint8)
+    out = torch.empty((M, N), device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        hip.spike_gemm(A, blk.fc1.Wp, out, M, N, K, alpha=blk.fc1.alpha, beta=blk.fc1.beta)
+    e0.record()
+    for _ in range(iters):
+        hip.spike_gemm(A, blk.fc1.Wp, out, M, N, K, alpha=blk.fc1.alpha, beta=blk.fc1.beta)
+    e1.record()
+    torch.cuda.synchronize()
+    t_gemm = e0.elapsed_time(e1) / iters * 1e-3
+    gemm = {"kernel": "spike_gemm_kernel<3> (stage0 fc1: M=69120 N=384 K=96)", "bound": "mfma",
+            "achieved": 2.0 * M * N * K / t_gemm / 1e12, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+            "us_per_launch": t_gemm * 1e6, "traffic": None}
+    gemm["frac"] = gemm["achieved"] / gemm["peak"]
+    # neuron: T=10 over the stage-0 MLP hidden tensor (10 x 72*96*384 fp32 in, u8 out)
+    n = 72 * 96 * 384
+    x = torch.rand((10, n), device=dev) - 0.3
+    s = torch.empty((10, n), dtype=torch.uint8, device=dev)
+    p = blk.sn2
+    for _ in range(3):
+        hip.neuron_fwd(x, s, 10, 1, n, 0, n, 0, n, p)
+    e0.record()
+    for _ in range(iters):
+        hip.neuron_fwd(x, s, 10, 1, n, 0, n, 0, n, p)
+    e1.record()
+    torch.cuda.synchronize()
+    t_n = e0.elapsed_time(e1) / iters * 1e-3
+    neuron = {"kernel": "neuron_kernel<10> (stage0 MLP hidden: 26.5 M neurons x T=10, f32 in / u8 out)", "bound": "hbm",
+              "achieved": 10.0 * n * 5 / t_n / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "us_per_launch": t_n * 1e6,
+              "traffic": None}
+    neuron["frac"] = neuron["achieved"] / neuron["peak"]
+    return gemm, neuron
+
+
+def cpu_baseline(kind, sd, chunk, budget_s=25.0):
+    """The oracle (a bit-level port of the reference's CPU path, see tests/test_oracle_golden.py) on the host cores."""
+    from oracle import sdformer_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ocfg = {"neuron": O.NeuronCfg(kind, 0.1, None, 2.0, 10), "num_bins": 10, "window_size": (2, 9, 9),
+            "depths": [2, 2, 6, 2], "num_heads": [3, 6, 12, 24]}
+    sd = {k: v for k, v in sd.items() if not k.endswith("num_batches_tracked")}
+    with torch.no_grad():
+        t0 = time.time()
+        O.forward_flownet(chunk, sd, ocfg)                      # warm-up (also sizes the sample)
+        first = time.time() - t0
+        reps = max(1, min(5, int(budget_s / max(first, 1e-3)) - 1))
+        t0 = time.time()
+        for _ in range(reps):
+            O.forward_flownet(chunk, sd, ocfg)
+        dt = (time.time() - t0) / reps
+    return {"value": 1.0 / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} full forwards of the same 1x10x2x288x384 voxel after 1 warm-up ({dt:.2f} s each), fp32, torch CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--neuron", default="lif", choices=["lif", "psn"])
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    if dist:
+        import torch.distributed as td
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group("nccl")                            # RCCL over xGMI; used only for the timing barrier
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    model, sd = build_model(args.neuron, dev)
+    chunk_cpu = synthetic_chunk()
+    chunk = chunk_cpu.to(dev)
+
+    def barrier():
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            model(chunk)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model(chunk)
+        barrier()
+        dt = time.perf_counter() - t0
+    assert torch.isfinite(out["flow"][-1]).all()
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        n_gpus = world if dist else args.gpus
+        gemm, neuron = time_dominant_kernels(model)
+        res = {
+            "metric": "event-frames/sec fwd (1x10x2x288x384)", "value": n_gpus * args.steps / dt, "unit": "samples/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: MS_SpikingformerFlowNet_en4 forward, batch 1 per GPU, 10-bin "
+                                   "288x384 voxel, neuron=" + args.neuron + ", spike GEMMs on bf16 MFMA with 3-plane "
+                                   "(fp32-grade) weights, convolutions fp32 via MIOpen, replicas per GPU"},
+            "roofline": gemm, "roofline_neuron": neuron,
+            "attention_gemm_roofline_frac": 183.7e9 / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12),
+        }
+        if not args.no_cpu and n_gpus == 1:
+            res["cpu_baseline"] = cpu_baseline(args.neuron, sd, chunk_cpu)
+            res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+        print(json.dumps(res))
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
