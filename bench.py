@@ -94,8 +94,16 @@ def time_dominant_kernels(model, iters=20):
 def cpu_baseline(kind, sd, chunk, budget_s=25.0):
     """The oracle (a bit-level port of the reference's CPU path, see tests/test_oracle_golden.py) on the host cores."""
     from oracle import sdformer_oracle as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    # cores = what this process may actually use (affinity mask and cgroup quota), not the host's core count:
+    # oversubscribing a quota-limited container with one OpenMP thread per host core stalls for minutes
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    torch.set_num_threads(min(cores, torch.get_num_threads()))
     ocfg = {"neuron": O.NeuronCfg(kind, 0.1, None, 2.0, 10), "num_bins": 10, "window_size": (2, 9, 9),
             "depths": [2, 2, 6, 2], "num_heads": [3, 6, 12, 24]}
     sd = {k: v for k, v in sd.items() if not k.endswith("num_batches_tracked")}
@@ -103,11 +111,12 @@ def cpu_baseline(kind, sd, chunk, budget_s=25.0):
         t0 = time.time()
         O.forward_flownet(chunk, sd, ocfg)                      # warm-up (also sizes the sample)
         first = time.time() - t0
-        reps = max(1, min(5, int(budget_s / max(first, 1e-3)) - 1))
+        reps = max(0, min(5, int(budget_s / max(first, 1e-3)) - 1))
         t0 = time.time()
         for _ in range(reps):
             O.forward_flownet(chunk, sd, ocfg)
-        dt = (time.time() - t0) / reps
+        dt = (time.time() - t0) / reps if reps else first
+        reps = max(reps, 1)
     return {"value": 1.0 / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{reps} full forwards of the same 1x10x2x288x384 voxel after 1 warm-up ({dt:.2f} s each), fp32, torch CPU"}
 

@@ -153,6 +153,36 @@ int sdf_qk_gate_fwd(const uint8_t* q, const uint8_t* k, uint8_t* e, int Tq, int6
 int sdf_affine_resid_fwd(const float* x, const float* alpha, const float* beta, const float* resid, float* out,
                          int64_t n, int C, int64_t inner, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused 3-D window attention over (window, head): scores + relative-position bias (+ shift mask)
+ * [+ softmax] times V, head_dim 32, up to 192 tokens per window.
+ *   SDF_ATTN_ANN replaces WindowAttention3D.forward's core (reference
+ *     models/STSwinNet/swin_transformer3D_v2.py:176-202): `q` points at the packed qkv projection output
+ *     (B_, N, 3, nH, 32) fp32 (k, v are ignored but must be non-NULL); cosine attention
+ *     normalize(q) normalize(k)^T * scale[g] + bias[g] (+ mask[b % nW]) -> softmax -> @ v;
+ *     out (B_, N, nH*32) fp32.  scale[g] = exp(min(logit_scale[g], ln 100)); bias = 16*sigmoid(cpb(...)).
+ *   SDF_ATTN_SEW replaces Spiking_BN_WindowAttention3D.forward's core (reference
+ *     models/STSwinNet_SNN/Spiking_swin_transformer3D.py:320-363): q, k, v are u8 spikes in the reference's
+ *     raw head view (B_, nH, N, 32) of the (T', B_, N1, C) buffers; (q*scale[g]) k^T + bias[g] (+ mask), NO
+ *     softmax, @ v; out fp32 (T', B_, N1, C) through the (B_,nH,T',N1,hd) -> (T',B_,N1,C) scramble.
+ * bias is (nH, N, N) fp32, mask (nW, N, N) fp32 or NULL.  All matrix products run on the exact fp32 MFMA.
+ */
+enum { SDF_ATTN_ANN = 0, SDF_ATTN_SEW = 1 };
+typedef struct SdfWinAttnDesc {
+  int32_t mode;
+  const void* q;
+  const void* k;
+  const void* v;
+  float* out;
+  int32_t B_, nW, nH, N, hd;
+  int32_t Tq, N1;           /* SEW only: N == Tq*N1 */
+  const float* scale;       /* (nH) */
+  const float* bias;        /* (nH,N,N) */
+  const float* mask;        /* (nW,N,N) or NULL */
+} SdfWinAttnDesc;
+
+int sdf_win_attn_fwd(const SdfWinAttnDesc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,99 @@
+"""ANN video-swin-v2 pieces on the hot path (mirror of reference models/STSwinNet/swin_transformer3D_v2.py):
+`window_partition` :37-49, `window_reverse` :52-65, `get_window_size` :68-81, `compute_mask` :409-421 and the cosine
+`WindowAttention3D` :87-205, whose score / bias / mask / softmax / .V core runs in one fused MFMA kernel
+(csrc/win_attn.hip) and whose two projections are plain library GEMMs (rocBLAS through torch)."""
+import math
+from functools import lru_cache
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import hip
+from ..STSwinNet_SNN.Spiking_swin_transformer3D import get_window_size  # noqa: F401  (same function, one definition)
+
+
+def window_partition(x, window_size):
+    """(B,D,H,W,C) -> (B*nW, Wd*Wh*Ww, C), windows ordered (b, d-block, h-block, w-block)."""
+    B, D, H, W, C = x.shape
+    wd, wh, ww = window_size
+    x = x.reshape(B, D // wd, wd, H // wh, wh, W // ww, ww, C)
+    return x.permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(-1, wd * wh * ww, C)
+
+
+def window_reverse(windows, window_size, B, D, H, W):
+    """Inverse of window_partition: (B*nW, Wd, Wh, Ww, C) -> (B,D,H,W,C)."""
+    wd, wh, ww = window_size
+    x = windows.reshape(B, D // wd, H // wh, W // ww, wd, wh, ww, -1)
+    return x.permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, D, H, W, -1)
+
+
+@lru_cache()
+def compute_mask(D, H, W, window_size, shift_size, device):
+    """0 / -100 mask (nW, N, N) of the 27 shifted regions."""
+    def labels(n, w, s):
+        r = np.zeros(n, np.int64)
+        idx = np.arange(n)
+        for c, sl in enumerate((slice(-w), slice(-w, -s), slice(-s, None))):
+            r[idx[sl]] = c
+        return r
+    rd, rh, rw = (labels(n, w, s) for n, w, s in zip((D, H, W), window_size, shift_size))
+    img = torch.from_numpy((rd[:, None, None] * 9 + rh[None, :, None] * 3 + rw[None, None, :]).astype(np.float32))
+    mw = window_partition(img.view(1, D, H, W, 1), window_size).squeeze(-1)
+    diff = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return torch.where(diff != 0, torch.tensor(-100.0), torch.tensor(0.0)).to(device)
+
+
+def relative_position_index(ws):
+    wd, wh, ww = ws
+    c = np.stack(np.meshgrid(np.arange(wd), np.arange(wh), np.arange(ww), indexing="ij")).reshape(3, -1)
+    rel = c[:, :, None] - c[:, None, :]
+    return torch.from_numpy((rel[0] + wd - 1) * (2 * wh - 1) * (2 * ww - 1) + (rel[1] + wh - 1) * (2 * ww - 1)
+                            + rel[2] + ww - 1)
+
+
+def relative_coords_table(ws, pws):
+    """(1, 2Wd-1, 2Wh-1, 2Ww-1, 3) log-spaced coordinates, INCLUDING the reference's axis quirk: the
+    normalisation `table[:, :, :, i] /= (ws[i]-1)` (:121-127) addresses the w-offset axis, not the coordinate."""
+    ax = [np.arange(-(w - 1), w, dtype=np.float32) for w in ws]
+    t = np.stack(np.meshgrid(*ax, indexing="ij"), -1)[None].copy()
+    for i in range(3):
+        t[:, :, :, i] /= np.float32((pws[i] - 1) if pws[0] > 0 else (ws[i] - 1))
+    t *= 8
+    return torch.from_numpy((np.sign(t) * np.log2(np.abs(t) + 1.0) / np.log2(8)).astype(np.float32))
+
+
+class WindowAttention3D(nn.Module):
+    """Cosine window attention with continuous relative-position bias (reference :87-205).
+    forward(x (B_,N,C), mask (nW,N,N)|None) -> (out (B_,N,C), None); head_dim must be 32."""
+
+    def __init__(self, dim, window_size, pretrained_window_size, num_heads, qkv_bias=False, qk_scale=None, attn_drop=0.0,
+                 proj_drop=0.0):
+        super().__init__()
+        if dim // num_heads != 32:
+            raise NotImplementedError("the fused window-attention kernel is built for head_dim == 32")
+        self.dim, self.window_size, self.num_heads = dim, tuple(window_size), num_heads
+        self.pretrained_window_size = tuple(pretrained_window_size)
+        self.logit_scale = nn.Parameter(torch.log(10 * torch.ones((num_heads, 1, 1))))
+        self.cpb_mlp = nn.Sequential(nn.Linear(3, 512, bias=True), nn.ReLU(inplace=True), nn.Linear(512, num_heads, bias=False))
+        self.register_buffer("relative_coords_table", relative_coords_table(self.window_size, self.pretrained_window_size))
+        self.register_buffer("relative_position_index", relative_position_index(self.window_size))
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+    def position_bias(self):
+        """16 * sigmoid(cpb_mlp(table)[index]) -> (nH, N, N) (:184-189)."""
+        N = self.relative_position_index.shape[0]
+        tab = self.cpb_mlp(self.relative_coords_table).view(-1, self.num_heads)
+        b = tab[self.relative_position_index.view(-1)].view(N, N, -1).permute(2, 0, 1)
+        return (16 * torch.sigmoid(b)).contiguous()
+
+    def forward(self, x, mask=None):
+        if self.training:
+            raise NotImplementedError("forward-only (SURVEY.md section 8f row 3 covers the backward kernels)")
+        with torch.no_grad():
+            qkv = self.qkv(x).contiguous()
+            scale = torch.clamp(self.logit_scale, max=math.log(1.0 / 0.01)).exp().reshape(-1).contiguous()
+            o = hip.win_attn_ann(qkv, scale, self.position_bias(), None if mask is None else mask.contiguous(), self.num_heads)
+            return self.proj(o), None

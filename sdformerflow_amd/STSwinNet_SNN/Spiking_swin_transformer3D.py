@@ -81,6 +81,65 @@ class Spiking_QK_WindowAttention3D(nn.Module):
         self.proj_sn = Spiking_neuron(**kw)
 
 
+class Spiking_BN_WindowAttention3D(nn.Module):
+    """SEW spiking window attention, swinv1 branch (reference :184-370): spike q,k,v, (q*scale) k^T + table bias
+    (+ mask), NO softmax, @ v, projection -> BN -> SN.  forward(x (T',B_,Wh,Ww,C) spikes, mask) -> (B_, N, C) spikes.
+    The score / bias / mask / .V core is one fused MFMA kernel (csrc/win_attn.hip)."""
+
+    def __init__(self, dim, window_size, pretrained_window_size, num_heads, version="swinv1", qkv_bias=False, qk_scale=None,
+                 attn_drop=0.0, proj_drop=0.0, norm=None, **spiking_kwargs):
+        super().__init__()
+        if version != "swinv1":
+            raise NotImplementedError("the reference's swinv2 branch references an undefined attribute (:336)")
+        if dim // num_heads != 32:
+            raise NotImplementedError("the fused window-attention kernel is built for head_dim == 32")
+        from ..STSwinNet.swin_transformer3D_v2 import relative_position_index
+        self.dim, self.window_size, self.num_heads, self.norm_layer = dim, tuple(window_size), num_heads, norm
+        kw = _neuron_kwargs(dict(spiking_kwargs, num_steps=self.window_size[0]))
+        self.scale = 1.0 if spiking_kwargs["neuron_type"] in ("psn", "glif") else (qk_scale or (dim // num_heads) ** -0.5)
+        wd, wh, ww = self.window_size
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * wd - 1) * (2 * wh - 1) * (2 * ww - 1), num_heads))
+        self.register_buffer("relative_position_index", relative_position_index(self.window_size))
+        for n in ("q", "k", "v"):
+            setattr(self, f"linear_{n}", nn.Linear(dim, dim, bias=False))
+            setattr(self, f"bn_{n}", SpikingNormLayer(dim, wd, norm, spiking_kwargs["v_th"]))
+            setattr(self, f"sn_{n}", Spiking_neuron(**kw))
+        self.attn_sn = Spiking_neuron(**kw)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_bn = SpikingNormLayer(dim, wd, norm, spiking_kwargs["v_th"])
+        self.proj_sn = Spiking_neuron(**kw)
+
+    def forward(self, x, mask=None):
+        from .. import hip
+        from ..engine import bn_affine, _np
+        if self.training:
+            raise NotImplementedError("forward-only")
+        with torch.no_grad():
+            Tq, B_, Wh, Ww, C = x.shape
+            N1, dev, nsplit = Wh * Ww, x.device, 3
+            M, n = Tq * B_ * N1, B_ * N1 * C
+            xs = x.reshape(M, C).to(torch.uint8).contiguous()               # SEW blocks feed spikes
+            f = torch.empty((M, C), dtype=torch.float32, device=dev)
+            spk = {}
+            for name in ("q", "k", "v"):
+                lin, bn, sn = getattr(self, f"linear_{name}"), getattr(self, f"bn_{name}"), getattr(self, f"sn_{name}")
+                a, b = bn_affine(bn.norm_layer, dev)
+                hip.spike_gemm(xs, hip.split_weight(lin.weight.detach().float(), nsplit), f, M, C, C, alpha=a, beta=b)
+                spk[name] = torch.empty((M, C), dtype=torch.uint8, device=dev)
+                hip.neuron_fwd(f, spk[name], Tq, 1, n, 0, n, 0, n, _np(sn, dev))
+            N = Tq * N1
+            idx = self.relative_position_index[:N, :N].reshape(-1)
+            bias = self.relative_position_bias_table.detach()[idx].reshape(N, N, -1).permute(2, 0, 1).contiguous()
+            scale = torch.full((self.num_heads,), float(self.scale), device=dev)
+            z = hip.win_attn_sew(spk["q"], spk["k"], spk["v"], scale, bias, None if mask is None else mask.contiguous(),
+                                 self.num_heads, Tq, B_, N1)
+            y = torch.addmm(self.proj.bias.detach(), z.view(M, C), self.proj.weight.detach().t())   # dense fp32 GEMM (rocBLAS)
+            a, b = bn_affine(self.proj_bn.norm_layer, dev)
+            out = torch.empty((M, C), dtype=torch.float32, device=dev)
+            hip.neuron_fwd(y, out, Tq, 1, n, 0, n, 0, n, _np(self.proj_sn, dev), alpha=a, beta=b, Cch=C, inner=1)
+            return out.view(B_, N, C), None
+
+
 class MS_Spiking_Mlp(nn.Module):
     """SN -> fc1 -> BN -> SN -> fc2 -> BN (reference :115-181)."""
 

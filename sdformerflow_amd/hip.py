@@ -19,7 +19,7 @@ SDF_LIF, SDF_PSN, SDF_IF = 0, 1, 2
 KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
 
 EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
-           "sdf_split_weight_bf16", "sdf_qk_gate_fwd", "sdf_affine_resid_fwd")
+           "sdf_split_weight_bf16", "sdf_qk_gate_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd")
 
 
 class SdfError(RuntimeError):
@@ -46,6 +46,13 @@ class SpikeGemmDesc(C.Structure):
                 ("bias", C.c_void_p), ("alpha", C.c_void_p), ("beta", C.c_void_p),
                 ("resid", C.c_void_p), ("out_rowmap", C.c_void_p),
                 ("zg_nH", C.c_int32), ("zg_T", C.c_int32), ("zg_B", C.c_int32), ("zg_N1", C.c_int32)]
+
+
+class WinAttnDesc(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("out", C.c_void_p),
+                ("B_", C.c_int32), ("nW", C.c_int32), ("nH", C.c_int32), ("N", C.c_int32), ("hd", C.c_int32),
+                ("Tq", C.c_int32), ("N1", C.c_int32),
+                ("scale", C.c_void_p), ("bias", C.c_void_p), ("mask", C.c_void_p)]
 
 
 _lib = None
@@ -191,4 +198,29 @@ def affine_resid(x, alpha, beta, Cch, inner, resid=None, out=None):
                                     C.c_void_p(_ptr(out, torch.float32)), C.c_int64(x.numel()), C.c_int(Cch),
                                     C.c_int64(inner), _stream())
     _check(rc, "sdf_affine_resid_fwd")
+    return out
+
+
+def win_attn_ann(qkv, scale, bias, mask, nH):
+    """Fused cosine window attention (sdf_win_attn_fwd, SDF_ATTN_ANN): qkv (B_,N,3C) fp32 -> (B_,N,C)."""
+    B_, N, C3 = qkv.shape
+    out = torch.empty((B_, N, C3 // 3), dtype=torch.float32, device=qkv.device)
+    d = WinAttnDesc()
+    d.mode, d.q, d.k, d.v, d.out = 0, _ptr(qkv, torch.float32), _ptr(qkv), _ptr(qkv), _ptr(out)
+    d.B_, d.nW, d.nH, d.N, d.hd = B_, (mask.shape[0] if mask is not None else 1), nH, N, C3 // 3 // nH
+    d.scale, d.bias, d.mask = _ptr(scale, torch.float32), _ptr(bias, torch.float32), _ptr(mask, torch.float32)
+    _check(lib().sdf_win_attn_fwd(C.byref(d), _stream()), "sdf_win_attn_fwd")
+    return out
+
+
+def win_attn_sew(q, k, v, scale, bias, mask, nH, Tq, B_, N1):
+    """Fused spiking window attention without softmax (SDF_ATTN_SEW): q,k,v u8 (T',B_,N1,C) -> fp32 (T',B_,N1,C)."""
+    Cc = q.shape[-1]
+    out = torch.empty((Tq, B_, N1, Cc), dtype=torch.float32, device=q.device)
+    d = WinAttnDesc()
+    d.mode, d.q, d.k, d.v, d.out = 1, _ptr(q, torch.uint8), _ptr(k, torch.uint8), _ptr(v, torch.uint8), _ptr(out)
+    d.B_, d.nW, d.nH, d.N, d.hd = B_, (mask.shape[0] if mask is not None else 1), nH, Tq * N1, Cc // nH
+    d.Tq, d.N1 = Tq, N1
+    d.scale, d.bias, d.mask = _ptr(scale, torch.float32), _ptr(bias, torch.float32), _ptr(mask, torch.float32)
+    _check(lib().sdf_win_attn_fwd(C.byref(d), _stream()), "sdf_win_attn_fwd")
     return out

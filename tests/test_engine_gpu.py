@@ -58,7 +58,7 @@ def test_teacher_forced_stage_parity(kind):
     with torch.no_grad():
         # patch embedding
         ref = O.patch_embed(chunk, sd, p + "patch_embed.", n, 10)
-        compare("patch_embed", eng.patch_embed(chunk.to(DEV)), ref, report, 5e-2)   # 7 MIOpen convs deep
+        compare("patch_embed", eng.patch_embed(chunk.to(DEV)), ref, report, 3e-2)   # 7 MIOpen (Winograd fp32) convs deep
         y = ref.permute(1, 0, 3, 4, 2).contiguous()
         ws, shift = (2, 9, 9), (1, 4, 4)
         feats = []
@@ -66,12 +66,12 @@ def test_teacher_forced_stage_parity(kind):
             for i in range(depth):
                 ref = O.ms_block(y, sd, p + f"layers.{s}.swin_blocks.{i}.", nH, ws, (0, 0, 0) if i % 2 == 0 else shift, n)
                 got = eng.swin_block(y.clone().to(DEV), s, i)
-                compare(f"stage{s}.block{i}", got, ref, report, 5e-2)
+                compare(f"stage{s}.block{i}", got, ref, report, 5e-3)
                 y = ref
             feats.append(y.permute(1, 0, 4, 2, 3).contiguous())
             if s < 3:
                 ref = O.ms_patch_merge(y, sd, p + f"layers.{s}.downsample.", n)
-                compare(f"stage{s}.merge", eng.patch_merge(y.to(DEV), s), ref, report, 5e-2)
+                compare(f"stage{s}.merge", eng.patch_merge(y.to(DEV), s), ref, report, 1e-3)
                 y = ref
         # U-Net tail, teacher-forced on the oracle's encoder features
         preds = eng.unet_tail([f.to(DEV) for f in feats])
@@ -99,7 +99,7 @@ def test_free_running_forward_statistics(kind):
         print(f"{kind} flow{i}: mean|ref| {r.abs().mean():.3f} mean|got| {g.abs().mean():.3f} mean-abs-dev/mean|ref| {rel:.3e}")
         assert abs(g.abs().mean().item() - r.abs().mean().item()) < 0.15 * r.abs().mean().item()
     print(f"{kind} AEE oracle {aee_ref:.5f} hip {aee_got:.5f} rel {abs(aee_got - aee_ref) / aee_ref:.2e}")
-    assert abs(aee_got - aee_ref) < 0.05 * aee_ref
+    assert abs(aee_got - aee_ref) < 2e-3 * aee_ref     # north star: AEE within 1e-3 (measured 1.4e-4 .. 3.9e-4)
 
 
 def test_cpu_input_is_refused():
@@ -107,3 +107,43 @@ def test_cpu_input_is_refused():
     model, _, _ = build("lif")
     with pytest.raises(hip.SdfError):
         model(torch.zeros(1, 10, 2, 288, 384))
+
+
+# ---------------------------------------------------------------- module-level drop-ins of a9 / a10 vs the fixtures
+def test_ann_window_attention_module_matches_reference_fixture():
+    from sdformerflow_amd.STSwinNet.swin_transformer3D_v2 import WindowAttention3D, compute_mask
+    from sdformerflow_amd.synthetic import synth_uniform as rnd
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ann_attention.npz"))
+    m = WindowAttention3D(96, (2, 9, 9), (0, 0, 0), 3, qkv_bias=True)
+    assert np.allclose(m.relative_coords_table.numpy(), g["coords_table"], atol=1e-6)
+    assert int(m.relative_position_index.sum()) == int(g["rel_index_sum"])
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items() if "relative" not in k})
+    m.load_state_dict(sd, strict=False)
+    m = m.eval().to(DEV)
+    x = rnd((4, 162, 96), 13, -1.0, 1.0).to(DEV)
+    mask = compute_mask(2, 18, 18, (2, 9, 9), (1, 4, 4), DEV)
+    y, _ = m(x, mask)
+    assert np.abs(y.cpu().numpy() - g["y"]).max() <= 5e-5            # reference WindowAttention3D output, fp32
+    y2, _ = m(x, None)
+    assert np.abs(y2.cpu().numpy() - g["y_nomask"]).max() <= 5e-5
+
+
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+def test_sew_window_attention_module_matches_reference_fixture(kind):
+    from sdformerflow_amd.STSwinNet.swin_transformer3D_v2 import compute_mask
+    from sdformerflow_amd.STSwinNet_SNN.Spiking_swin_transformer3D import Spiking_BN_WindowAttention3D
+    from sdformerflow_amd.synthetic import synth_uniform as rnd
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sew_attention.npz"))
+    kw = {"num_steps": 10, "v_reset": None, "v_th": 0.1, "neuron_type": kind, "surrogate_fun": "surrogate.ATan()",
+          "tau": 2.0, "detach_reset": True, "spike_norm": "BN"}
+    m = Spiking_BN_WindowAttention3D(96, (2, 9, 9), (0, 0, 0), 3, version="swinv1", norm="BN", **kw)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items() if not k.endswith("relative_position_index")})
+    m.load_state_dict(sd, strict=False)
+    m = m.eval().to(DEV)
+    x = (rnd((2, 8, 9, 9, 96), 11) > 0.4).float().to(DEV)
+    mask = compute_mask(2, 18, 18, (2, 9, 9), (1, 4, 4), DEV)
+    y, _ = m(x, mask)
+    ref = g[f"{kind}_y"]                                            # (B_, 162, C) spikes of the reference module
+    assert (y.cpu().numpy().astype(np.uint8) != ref).mean() < 5e-4   # threshold-rounding flips only
+    y2, _ = m(x, None)
+    assert (y2.cpu().numpy().astype(np.uint8) != g[f"{kind}_y_nomask"]).mean() < 5e-4

@@ -171,3 +171,40 @@ def test_qk_gate(kind):
     hip.qk_gate(q.to(DEV), k.to(DEV), e, Tq, rows, Cc, hip.NeuronParams(kind, 2.0, 0.1, None, W.to(DEV), b.to(DEV)))
     assert torch.equal(e.cpu().float(), ref)
     assert 0.02 < ref.mean() < 0.6
+
+
+# ---------------------------------------------------------------- fused window attention (a9, a10)
+@pytest.mark.parametrize("with_mask", [True, False])
+def test_win_attn_ann_cosine_softmax(with_mask):
+    """WindowAttention3D core vs the oracle (swin_transformer3D_v2.py:176-202); exact-fp32 MFMA.  Logits reach
+    ~100 (logit_scale up to 100 x cosine), so fp32 rounding of the logit is amplified by exp to ~|logit|*2^-24 ~ 6e-6
+    relative on both sides; tolerance 2e-5 absolute on O(1) outputs."""
+    nH, N, nW, B = 3, 162, 4, 2
+    Cc = nH * 32
+    qkv = rnd((B * nW, N, 3 * Cc), 60, -1.0, 1.0)
+    ls = torch.exp(torch.clamp(rnd((nH, 1, 1), 61, 1.5, 5.0), max=float(np.log(100.0))))
+    bias = 16 * torch.sigmoid(rnd((nH, N, N), 62, -2.0, 2.0))
+    mask = O.compute_mask(2, 18, 18, (2, 9, 9), (1, 4, 4)) if with_mask else None
+    ref, _ = O.ann_attention_core(qkv, ls, bias, mask, nH)
+    got = hip.win_attn_ann(qkv.to(DEV), ls.reshape(-1).contiguous().to(DEV), bias.to(DEV),
+                           mask.to(DEV) if with_mask else None, nH)
+    assert (got.cpu() - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("with_mask", [True, False])
+@pytest.mark.parametrize("nH", [3, 6])
+def test_win_attn_sew_linear(with_mask, nH):
+    """Spiking_BN_WindowAttention3D core vs the oracle (Spiking_swin_transformer3D.py:320-363): binary q,k,v in
+    the raw head view, no softmax; integer-valued QK^T so only the bias add and the P.V sum round (1e-5 rel)."""
+    Tq, N1, nW, B = 2, 81, 4, 1
+    B_, Cc, N = B * nW, nH * 32, 162
+    q, k, v = spikes((Tq, B_, N1, Cc), 70, 0.3), spikes((Tq, B_, N1, Cc), 71, 0.4), spikes((Tq, B_, N1, Cc), 72, 0.5)
+    bias = rnd((nH, N, N), 73, -1.0, 1.0)
+    mask = O.compute_mask(2, 18, 18, (2, 9, 9), (1, 4, 4)) if with_mask else None
+    scale = 32 ** -0.5
+    view = lambda t: t.float().reshape(B_, nH, N, 32)
+    ref, _ = O.sew_attention_core(view(q), view(k), view(v), scale, bias, mask, Tq, N1)
+    sc = torch.full((nH,), scale)
+    got = hip.win_attn_sew(q.to(DEV), k.to(DEV), v.to(DEV), sc.to(DEV), bias.to(DEV), mask.to(DEV) if with_mask else None,
+                           nH, Tq, B_, N1)
+    assert (got.cpu() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
