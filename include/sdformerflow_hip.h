@@ -120,13 +120,29 @@ typedef struct SdfSpikeGemmDesc {
   int64_t M;
   int32_t N, K;
   int64_t lda, ldo;
-  int32_t nsplit;           /* 1..3 */
+  int32_t nsplit;           /* 1 (bf16 weights) or 3 (fp32-grade hi/mid/lo) */
   const float* bias;        /* NULL ok */
   const float* alpha;       /* NULL ok */
   const float* beta;
   const float* resid;       /* NULL ok */
   const int32_t* out_rowmap;/* NULL ok */
   int32_t zg_nH, zg_T, zg_B, zg_N1;
+  /* Fused neuron epilogue (sn_T > 0):  out_spike = SN_T( fmaf(acc, alpha, beta) [+ add] ), 1-byte spikes, the fp32
+   * pre-activation never leaves the chip.  Replaces Linear -> BN -> [+ positional_encoding] -> Spiking_neuron
+   * (reference Spiking_swin_transformer3D.py:170-174, 671-680).  The M = pos_count*sn_T rows are (position, t)
+   * pairs: row(P, t) = (P / pos_inner)*pos_ostride + P % pos_inner + t*t_stride, used for A and out_spike alike
+   * (MLP on a (B,D,HW,.) tensor: pos_inner = HW, pos_ostride = D*HW, t_stride = HW; attention (T',rows,.):
+   * pos_inner = rows, t_stride = rows).  add is (sn_T, add_prows, N) fp32 indexed [t][P % add_prows][n] or NULL.
+   * sn_T in {2,4,5,10,20}; bias / resid / out_rowmap / zg_* must be unset; N % 16 == 0. */
+  int32_t sn_T, sn_kind;    /* sn_T == 0: fp32 epilogue */
+  float tau, v_th, v_reset;
+  int32_t soft_reset;
+  const float* psn_w;
+  const float* psn_b;
+  int64_t pos_count, pos_inner, pos_ostride, t_stride;
+  const float* add;
+  int64_t add_prows;
+  uint8_t* out_spike;       /* (rows, N) u8 */
 } SdfSpikeGemmDesc;
 
 int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream);

@@ -1,21 +1,35 @@
-// Spike GEMM for gfx950:  out[M,N] = epilogue( A[M,K] (binary u8 spikes) x W[N,K]^T ).
+// Spike GEMM for gfx950:  out = epilogue( A[M,K] (binary u8 spikes) x W[N,K]^T ).
 //
-// MFMA-tiled (v_mfma_f32_32x32x16_bf16, 64-lane wavefronts).  A binary operand is exact in bf16, so the
-// fp32 weights are carried as up to three bf16 planes (hi/mid/lo residual split) and the product is
-// accumulated in fp32 by the matrix cores: fp32-grade results at bf16 MFMA rate (3 MFMAs per 32x32x16
-// sub-product instead of 8 f32-input MFMAs).  The 1-byte spikes are expanded to bf16 in registers.
+// MFMA-tiled (v_mfma_f32_32x32x16_bf16, 64-lane wavefronts).  A binary operand is exact in bf16, so the fp32
+// weights are carried as up to three bf16 planes (hi/mid/lo residual split) and the product is accumulated in
+// fp32 by the matrix cores: fp32-grade results at bf16 MFMA rate.  The 1-byte spikes are expanded to bf16 in
+// registers (v_perm + one multiply per pair).
 //
-// Workgroup = 4 waves; tile 128 (M) x 96 (N) x 96 (K stage); wave w owns rows [32w, 32w+32) and all
-// three 32-column sub-tiles (3 accumulators of 16 VGPRs).  LDS rows are padded so that the ds_read_b64
-// A-fragment reads (26-dword stride) and the ds_read_b128 B-fragment reads (52-dword stride) are
-// bank-conflict free.  Epilogue fuses bias, eval-BN affine (fmaf), residual add and an optional output
-// row scatter (window_reverse + roll + crop of the reference as a precomputed row map).
+// Structure: PERSISTENT workgroups (4 waves) walk a contiguous range of output tiles; tile = 128*RB rows x 32*NB
+// columns, K in stages of 96.  Each wave owns 32*RB rows (RB MFMA row blocks) x NB column blocks.  The next
+// stage - of this tile or of the NEXT tile - is prefetched global -> VGPR while the current one is multiplied, so
+// the load latency, the index prologue and the epilogue of a tile overlap the neighbouring tiles' work instead
+// of being paid once per workgroup launch.  Tiles are ordered column-block-major, so a workgroup keeps its
+// weight tile in LDS across row tiles whenever K fits one stage (weight-stationary for the K = 96 layers, which
+// carry most of the rows).  LDS rows are padded (A: 26-dword stride for ds_read_b64, W: 52-dword stride for
+// ds_read_b128) so fragment reads are bank-conflict free.
+//
+// Two epilogues:
+//   F32   : (+bias) -> fmaf(., alpha, beta) -> (+resid) -> fp32 store, optional output row scatter
+//           (window_reverse + roll + crop as a row map) and the reference's head-scramble on the A side.
+//   SPIKE : fmaf(., alpha, beta) (+ positional term) -> LIF / IF / PSN over the T time steps of each position
+//           -> 1-byte spikes.  The tile's rows are laid out so that all T steps of a position sit in the 16*RB
+//           accumulator slots one lane holds per column (slot = 16*rowblock + reg; position = slot / T,
+//           t = slot % T), i.e. the recurrence runs in registers straight out of the MFMA accumulators and the
+//           fp32 pre-activation never touches HBM.  Spikes are staged through LDS to leave as 16-byte stores.
+// Compiled with -ffp-contract=off: the neuron arithmetic is the same separately-rounded op sequence as neuron.hip.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 96, KC = 96;
-constexpr int A_LD = KC + 8;          // bytes per A row in LDS (104 B = 26 dwords)
+constexpr int KC = 96;
+constexpr int A_LD = KC + 8;          // bytes per A row in LDS (104 B = 26 dwords), written as 2 x 8 B
 constexpr int W_LD = KC + 8;          // bf16 elements per W row in LDS (208 B = 52 dwords)
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
@@ -23,150 +37,333 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 struct GemmParams {
   SdfSpikeGemmDesc d;
+  int tiles_m, tiles_n, ntiles;
+  float inv_tau;
 };
 
 // 8 spike bytes {0,1} -> 8 bf16 {0, 1.0}
 __device__ __forceinline__ bf16x8 expand_spikes(uint2 v) {
   union { bf16x8 h; uint32_t u[4]; } r;
-  // bytes [b0 b1 b2 b3] -> (b0 | b1 << 16) * 0x3F80 ; (b2 | b3 << 16) * 0x3F80
-  r.u[0] = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u) * 0x3F80u;
+  r.u[0] = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u) * 0x3F80u;   // (b0 | b1 << 16) * bf16(1.0)
   r.u[1] = __builtin_amdgcn_perm(0u, v.x, 0x0c030c02u) * 0x3F80u;
   r.u[2] = __builtin_amdgcn_perm(0u, v.y, 0x0c010c00u) * 0x3F80u;
   r.u[3] = __builtin_amdgcn_perm(0u, v.y, 0x0c030c02u) * 0x3F80u;
   return r.h;
 }
 
-template <int NSPLIT>
-__global__ __launch_bounds__(256) void spike_gemm_kernel(GemmParams P) {
-  __shared__ __attribute__((aligned(16))) uint8_t A_s[BM * A_LD];
-  __shared__ __attribute__((aligned(16))) uint16_t W_s[NSPLIT * BN * W_LD];
+// WAVES = 8 (512 threads): two waves per SIMD share one weight tile, so one wave's address / epilogue VALU work
+// overlaps the other's MFMAs.  WAVES = 4 (256 threads) with small tiles is for problems with few rows.
+template <int NSPLIT, int NB, int RB, int TT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void spike_gemm_kernel(GemmParams P) {
+  constexpr bool SPIKE = TT > 0;
+  constexpr int T = SPIKE ? TT : 1;
+  constexpr int NT = 64 * WAVES;                                 // threads per workgroup
+  constexpr int BM = 32 * RB * WAVES, BN = 32 * NB, WR = 32 * RB;   // tile rows, tile cols, rows per wave
+  constexpr int NPOS = (16 * RB) / T;                            // SPIKE: positions per lane-half
+  constexpr int A_CH = BM * (KC / 16);                           // 16-byte chunks of an A stage
+  constexpr int AIT = A_CH / NT;                                 // 3 * RB per thread
+  constexpr int WCH = NSPLIT * BN * (KC / 8);                    // 16-byte chunks of a W stage
+  constexpr int WIT = (WCH + NT - 1) / NT;
+  static_assert(!SPIKE || NPOS >= 1, "T does not fit the accumulator slots of one lane");
+  __shared__ __attribute__((aligned(16))) uint8_t smem[BM * A_LD + NSPLIT * BN * W_LD * 2];
+  uint8_t* A_s = smem;
+  uint16_t* W_s = reinterpret_cast<uint16_t*>(smem + BM * A_LD);
 
   const SdfSpikeGemmDesc& d = P.d;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
   const int K = d.K, N = d.N;
+  const int nstages = (K + KC - 1) / KC;
 
-  f32x16 acc[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  // contiguous tile range of this workgroup (column-block-major tile order: t = cb * tiles_m + rt)
+  const int G = gridDim.x, wg = blockIdx.x;
+  const int base = P.ntiles / G, rem = P.ntiles % G;
+  const int t_begin = wg * base + (wg < rem ? wg : rem);
+  const int t_end = t_begin + base + (wg < rem ? 1 : 0);
+  if (t_begin >= t_end) return;
 
-  // per-thread A staging coordinates: 3 chunks of 16 B; chunk id c -> row c/6, 16-byte column c%6
-  int a_row[3], a_c16[3];
-  int64_t a_base[3];            // row base offset (normal) or -1 when row >= M
-  int zt[3], zb[3], zn[3];
+  // ---- per-thread staging coordinates (tile independent) ----
+  int a_row[AIT], a_c16[AIT];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    int c = tid + 256 * i;
-    a_row[i] = c / 6;
-    a_c16[i] = c % 6;
-    int64_t m = m0 + a_row[i];
-    if (m < d.M) {
-      a_base[i] = m * d.lda;
-      if (d.zg_nH > 0) {
-        int64_t bn = (int64_t)d.zg_B * d.zg_N1;
-        zt[i] = (int)(m / bn);
-        int64_t rem = m - (int64_t)zt[i] * bn;
-        zb[i] = (int)(rem / d.zg_N1);
-        zn[i] = (int)(rem - (int64_t)zb[i] * d.zg_N1);
-      }
-    } else {
-      a_base[i] = -1;
-    }
+  for (int i = 0; i < AIT; ++i) {
+    const int c = tid + NT * i;
+    a_row[i] = c / (KC / 16);
+    a_c16[i] = c % (KC / 16);
   }
 
-  for (int k0 = 0; k0 < K; k0 += KC) {
-    // ---- stage A tile (u8) ----
-    uint4 areg[3];
+  // global row (or -1) of tile-row R of row-tile rt
+  auto tile_row = [&](int rt, int R) -> int64_t {
+    if (SPIKE) {
+      const int w = R / WR, rloc = R % WR;
+      const int rb = rloc >> 5, rr = rloc & 31;
+      const int h = (rr >> 2) & 1, r = (rr & 3) + 4 * (rr >> 3);
+      const int slot = rb * 16 + r;
+      const int pl = slot / T, t = slot - pl * T;
+      const int64_t pos = (int64_t)rt * (2 * WAVES * NPOS) + (w * 2 + h) * NPOS + pl;
+      if (pl >= NPOS || pos >= d.pos_count) return -1;
+      const uint32_t po = (uint32_t)pos / (uint32_t)d.pos_inner;         // positions < 2^31
+      return (int64_t)po * d.pos_ostride + ((uint32_t)pos - po * (uint32_t)d.pos_inner) + (int64_t)t * d.t_stride;
+    }
+    const int64_t m = (int64_t)rt * BM + R;
+    return m < d.M ? m : -1;
+  };
+
+  uint4 areg[AIT], wreg[WIT];
+  int64_t a_off[AIT];                // source offset of each staged chunk's row for the tile being LOADED
+  const int64_t zg_gstride = (int64_t)d.zg_T * d.zg_N1 * 32;     // head-scramble: offset between channel groups
+  auto set_rows = [&](int rt) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      int k = k0 + 16 * a_c16[i];
+    for (int i = 0; i < AIT; ++i) {
+      const int64_t g = tile_row(rt, a_row[i]);
+      a_off[i] = g < 0 ? -1 : g * d.lda;
+      if (!SPIKE && d.zg_nH > 0 && g >= 0) {
+        // Z[t,b,n,g*32+d] = E_flat[((((b*nH+g)*T+t)*N1+n)*32+d]  ->  base(t,b,n) + g*(T*N1*32) + d
+        const uint32_t bn = (uint32_t)(d.zg_B * d.zg_N1);
+        const uint32_t zt = (uint32_t)g / bn;
+        const uint32_t r2 = (uint32_t)g - zt * bn;
+        const uint32_t zb = r2 / (uint32_t)d.zg_N1;
+        const uint32_t zn = r2 - zb * (uint32_t)d.zg_N1;
+        a_off[i] = (((int64_t)zb * d.zg_nH * d.zg_T + zt) * d.zg_N1 + zn) * 32;
+      }
+    }
+  };
+  auto load_stage = [&](int cb, int k0, bool with_w) {
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+      const int k = k0 + 16 * a_c16[i];
       areg[i] = make_uint4(0, 0, 0, 0);
-      if (a_base[i] >= 0 && k < K) {
+      if (a_off[i] >= 0 && k < K) {
         const uint8_t* src;
-        if (d.zg_nH > 0) {
-          int g = k >> 5, dd = k & 31;
-          src = d.A + ((((int64_t)zb[i] * d.zg_nH + g) * d.zg_T + zt[i]) * d.zg_N1 + zn[i]) * 32 + dd;
+        if (!SPIKE && d.zg_nH > 0) {
+          src = d.A + a_off[i] + (k >> 5) * zg_gstride + (k & 31);
         } else {
-          src = d.A + a_base[i] + k;
+          src = d.A + a_off[i] + k;
         }
         areg[i] = *reinterpret_cast<const uint4*>(src);
       }
     }
-    // ---- stage W tile (bf16 planes) ----
-    constexpr int WCH = NSPLIT * BN * (KC / 8);                 // 16-byte chunks
-    constexpr int WIT = (WCH + 255) / 256;
-    uint4 wreg[WIT];
+    if (with_w) {
+      const int n0 = cb * BN;
 #pragma unroll
-    for (int i = 0; i < WIT; ++i) {
-      int c = tid + 256 * i;
-      wreg[i] = make_uint4(0, 0, 0, 0);
-      if (c < WCH) {
-        int p = c / (BN * (KC / 8));
-        int rem = c - p * (BN * (KC / 8));
-        int n = rem / (KC / 8), c16 = rem % (KC / 8);
-        int k = k0 + 8 * c16;
-        if (n0 + n < N && k < K)
-          wreg[i] = *reinterpret_cast<const uint4*>(d.Wp + ((int64_t)p * N + n0 + n) * K + k);
-      }
-    }
-    __syncthreads();                                             // previous stage's reads are done
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      *reinterpret_cast<uint4*>(&A_s[a_row[i] * A_LD + 16 * a_c16[i]]) = areg[i];
-#pragma unroll
-    for (int i = 0; i < WIT; ++i) {
-      int c = tid + 256 * i;
-      if (c < WCH) {
-        int p = c / (BN * (KC / 8));
-        int rem = c - p * (BN * (KC / 8));
-        int n = rem / (KC / 8), c16 = rem % (KC / 8);
-        *reinterpret_cast<uint4*>(&W_s[(p * BN + n) * W_LD + 8 * c16]) = wreg[i];
-      }
-    }
-    __syncthreads();
-
-    // ---- MFMA over the stage ----
-#pragma unroll
-    for (int ks = 0; ks < KC / 16; ++ks) {
-      uint2 av = *reinterpret_cast<const uint2*>(&A_s[(wave * 32 + l31) * A_LD + ks * 16 + 8 * lh]);
-      bf16x8 a = expand_spikes(av);
-#pragma unroll
-      for (int nt = 0; nt < 3; ++nt) {
-#pragma unroll
-        for (int p = 0; p < NSPLIT; ++p) {
-          bf16x8 b = *reinterpret_cast<const bf16x8*>(&W_s[(p * BN + nt * 32 + l31) * W_LD + ks * 16 + 8 * lh]);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nt], 0, 0, 0);
+      for (int i = 0; i < WIT; ++i) {
+        const int c = tid + NT * i;
+        wreg[i] = make_uint4(0, 0, 0, 0);
+        if (c < WCH) {
+          const int p = c / (BN * (KC / 8));
+          const int r2 = c - p * (BN * (KC / 8));
+          const int n = r2 / (KC / 8), c16 = r2 % (KC / 8);
+          const int k = k0 + 8 * c16;
+          if (n0 + n < N && k < K) wreg[i] = *reinterpret_cast<const uint4*>(d.Wp + ((int64_t)p * N + n0 + n) * K + k);
         }
       }
     }
-  }
-
-  // ---- epilogue ----
+  };
+  auto store_stage = [&](bool with_w) {
 #pragma unroll
-  for (int nt = 0; nt < 3; ++nt) {
-    const int n = n0 + nt * 32 + l31;
-    if (n >= N) continue;
-    const float bs = d.bias ? d.bias[n] : 0.f;
-    const float al = d.alpha ? d.alpha[n] : 1.f;
-    const float be = d.alpha ? d.beta[n] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int64_t m = m0 + row;
-      if (m >= d.M) continue;
-      int64_t dst = d.out_rowmap ? (int64_t)d.out_rowmap[m] : m;
-      if (dst < 0) continue;
-      float v = acc[nt][r];
-      if (d.bias) v = v + bs;
-      if (d.alpha) v = __builtin_fmaf(v, al, be);
-      if (d.resid) v = v + d.resid[dst * d.ldo + n];
-      d.out[dst * d.ldo + n] = v;
+    for (int i = 0; i < AIT; ++i) {
+      uint2* dst = reinterpret_cast<uint2*>(&A_s[a_row[i] * A_LD + 16 * a_c16[i]]);   // rows are 8-byte aligned
+      dst[0] = make_uint2(areg[i].x, areg[i].y);
+      dst[1] = make_uint2(areg[i].z, areg[i].w);
     }
+    if (with_w) {
+#pragma unroll
+      for (int i = 0; i < WIT; ++i) {
+        const int c = tid + NT * i;
+        if (c < WCH) {
+          const int p = c / (BN * (KC / 8));
+          const int r2 = c - p * (BN * (KC / 8));
+          const int n = r2 / (KC / 8), c16 = r2 % (KC / 8);
+          *reinterpret_cast<uint4*>(&W_s[(p * BN + n) * W_LD + 8 * c16]) = wreg[i];
+        }
+      }
+    }
+  };
+
+  f32x16 acc[RB][NB];
+  const bool soft = d.soft_reset != 0;
+  const bool reset0 = soft || d.v_reset == 0.f;
+
+  // ---- software pipeline over (tile, stage) ----
+  int tl = t_begin, st = 0;                         // stage being computed
+  int cb = tl / P.tiles_m, rt = tl - cb * P.tiles_m;
+  int w_cb = -1;                                    // column block whose single-stage W tile sits in LDS
+  set_rows(rt);
+  bool cur_w = true;
+  load_stage(cb, 0, true);
+  while (true) {
+    __syncthreads();                                // previous stage's LDS reads (and spike staging) are done
+    store_stage(cur_w);
+    if (nstages == 1) w_cb = cb;
+    __syncthreads();
+    // advance the loader to the next (tile, stage) and prefetch it
+    int ntl = tl, nst = st + 1;
+    if (nst == nstages) { nst = 0; ntl = tl + 1; }
+    const bool more = ntl < t_end;
+    int ncb = cb, nrt = rt;
+    bool nxt_w = true;
+    if (more) {
+      if (ntl != tl) {
+        ncb = ntl / P.tiles_m;
+        nrt = ntl - ncb * P.tiles_m;
+        set_rows(nrt);
+        nxt_w = !(nstages == 1 && ncb == w_cb);
+      }
+      load_stage(ncb, nst * KC, nxt_w);
+    }
+    if (st == 0) {
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KC / 16; ++ks) {
+      bf16x8 a[RB];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+        a[rb] = expand_spikes(*reinterpret_cast<const uint2*>(&A_s[(wave * WR + rb * 32 + l31) * A_LD + ks * 16 + 8 * lh]));
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int p = 0; p < NSPLIT; ++p) {
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>(&W_s[(p * BN + nb * 32 + l31) * W_LD + ks * 16 + 8 * lh]);
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], b, acc[rb][nb], 0, 0, 0);
+        }
+      }
+    }
+
+    if (st == nstages - 1) {
+      const int n0 = cb * BN;
+      if (!SPIKE) {
+        // ---- fp32 epilogue: one base pointer per (column block, row block), wave-uniform row strides ----
+        const int mrow0 = rt * BM + wave * WR + 4 * lh;            // first row this lane holds (M < 2^31)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const int n = n0 + nb * 32 + l31;
+          if (n < N) {
+            const float bs = d.bias ? d.bias[n] : 0.f;
+            const float al = d.alpha ? d.alpha[n] : 1.f;
+            const float be = d.alpha ? d.beta[n] : 0.f;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+              const int mrow = mrow0 + rb * 32;
+              const int left = (int)d.M - mrow;                    // rows (8*q4 + j) < left are inside the matrix
+              if (!d.out_rowmap) {
+                float* op = d.out + (int64_t)mrow * d.ldo + n;
+                const float* rp = d.resid ? d.resid + (int64_t)mrow * d.ldo + n : nullptr;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                  float rs[4] = {0.f, 0.f, 0.f, 0.f};
+                  if (rp) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                      if (8 * q4 + j < left) rs[j] = rp[(int64_t)(8 * q4 + j) * d.ldo];
+                  }
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) {
+                    float v = acc[rb][nb][q4 * 4 + j];
+                    if (d.bias) v = v + bs;
+                    if (d.alpha) v = __builtin_fmaf(v, al, be);
+                    v = v + rs[j];
+                    if (8 * q4 + j < left) op[(int64_t)(8 * q4 + j) * d.ldo] = v;
+                  }
+                }
+              } else {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {                   // 4 consecutive rows per group: batch the loads
+                  int dst[4];
+                  float rs[4];
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) dst[j] = (8 * q4 + j < left) ? d.out_rowmap[mrow + 8 * q4 + j] : -1;
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) rs[j] = (d.resid && dst[j] >= 0) ? d.resid[(int64_t)dst[j] * d.ldo + n] : 0.f;
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) {
+                    float v = acc[rb][nb][q4 * 4 + j];
+                    if (d.bias) v = v + bs;
+                    if (d.alpha) v = __builtin_fmaf(v, al, be);
+                    v = v + rs[j];
+                    if (dst[j] >= 0) d.out[(int64_t)dst[j] * d.ldo + n] = v;
+                  }
+                }
+              }
+            }
+          }
+        }
+      } else {
+        // ---- spike epilogue: BN (+add) -> neuron over T -> bytes, staged through LDS ----
+        __syncthreads();                                     // every wave is done reading A_s for this stage
+        uint8_t* S_s = smem + wave * WR * BN;                // this wave's WR x BN byte tile (aliases A_s)
+        const int64_t pos0 = (int64_t)rt * (2 * WAVES * NPOS) + (wave * 2 + lh) * NPOS;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const int n = n0 + nb * 32 + l31;
+          const bool ncol = n < N;
+          const float al = (d.alpha && ncol) ? d.alpha[n] : 1.f;
+          const float be = (d.alpha && ncol) ? d.beta[n] : 0.f;
+#pragma unroll
+          for (int pl = 0; pl < NPOS; ++pl) {
+            const int64_t pos = pos0 + pl;
+            const bool live = ncol && pos < d.pos_count;
+            const float* addp = (d.add && live) ? d.add + ((uint32_t)pos % (uint32_t)d.add_prows) * (int64_t)N + n : nullptr;
+            float xs[T], sp[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              const int slot = pl * T + t;                   // compile-time after unrolling
+              float x = acc[slot >> 4][nb][slot & 15];
+              if (d.alpha) x = __builtin_fmaf(x, al, be);
+              if (addp) x = x + addp[(int64_t)t * d.add_prows * N];
+              xs[t] = x;
+            }
+            if (d.sn_kind == SDF_PSN) {
+#pragma unroll
+              for (int t = 0; t < T; ++t) {
+                float hh = d.psn_b[t];
+#pragma unroll
+                for (int k = 0; k < T; ++k) hh = __builtin_fmaf(d.psn_w[t * T + k], xs[k], hh);
+                sp[t] = hh >= 0.f ? 1.f : 0.f;
+              }
+            } else {
+              float v = soft ? 0.f : d.v_reset;
+#pragma unroll
+              for (int t = 0; t < T; ++t) {
+                float hcur;
+                if (d.sn_kind == SDF_IF) {
+                  hcur = v + xs[t];
+                } else {
+                  const float dl = reset0 ? (xs[t] - v) : (xs[t] - (v - d.v_reset));
+                  hcur = v + ((P.inv_tau != 0.f) ? dl * P.inv_tau : dl / d.tau);
+                }
+                sp[t] = (hcur - d.v_th >= 0.f) ? 1.f : 0.f;
+                v = soft ? (hcur - sp[t] * d.v_th) : ((1.f - sp[t]) * hcur + sp[t] * d.v_reset);
+              }
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              const int slot = pl * T + t;
+              const int rowl = (slot >> 4) * 32 + (slot & 3) + 8 * ((slot & 15) >> 2) + 4 * lh;
+              S_s[rowl * BN + nb * 32 + l31] = (uint8_t)(sp[t] != 0.f);
+            }
+          }
+        }
+        __syncthreads();                                     // spike bytes of the whole tile are in LDS
+        constexpr int CPR = BN / 16;                         // 16-byte chunks per row
+#pragma unroll
+        for (int c = lane; c < WR * CPR; c += 64) {
+          const int rowl = c / CPR, c16 = c - rowl * CPR;
+          const int64_t g = tile_row(rt, wave * WR + rowl);
+          const int n = n0 + 16 * c16;
+          if (g >= 0 && n < N)
+            *reinterpret_cast<uint4*>(d.out_spike + g * N + n) = *reinterpret_cast<const uint4*>(&S_s[rowl * BN + 16 * c16]);
+        }
+      }
+    }
+    if (!more) break;
+    tl = ntl; st = nst; cb = ncb; rt = nrt; cur_w = nxt_w;
   }
 }
 
@@ -176,11 +373,38 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
   if (i >= n) return;
   float r = W[i];
   for (int p = 0; p < nsplit; ++p) {
-    // round-to-nearest-even fp32 -> bf16 (finite weights)
-    uint32_t u = __float_as_uint(r);
+    uint32_t u = __float_as_uint(r);                       // round-to-nearest-even fp32 -> bf16 (finite weights)
     uint32_t h = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
     planes[(int64_t)p * n + i] = (uint16_t)h;
-    r = r - __uint_as_float(h << 16);       // exact: the residual fits fp32
+    r = r - __uint_as_float(h << 16);                      // exact: the residual fits fp32
+  }
+}
+
+template <int NSPLIT, int NB, int RB, int WAVES>
+int launch(const GemmParams& P, dim3 grid, hipStream_t s) {
+#define SDF_GEMM_T(TT)                                                                                      \
+  case TT:                                                                                                  \
+    if constexpr (TT == 0 || (16 * RB) / (TT ? TT : 1) >= 1) {                                              \
+      hipLaunchKernelGGL((spike_gemm_kernel<NSPLIT, NB, RB, TT, WAVES>), grid, dim3(64 * WAVES), 0, s, P);  \
+      return 0;                                                                                             \
+    }                                                                                                       \
+    return SDF_E_SHAPE;
+  switch (P.d.sn_T) {
+    SDF_GEMM_T(0) SDF_GEMM_T(2) SDF_GEMM_T(4) SDF_GEMM_T(5) SDF_GEMM_T(10) SDF_GEMM_T(20)
+    default: return SDF_E_SHAPE;
+  }
+#undef SDF_GEMM_T
+}
+
+// configurations built: big = 8 waves x (RB=2, NB=3) [512 x 96 tiles]; mid = 8 waves x (RB=1, NB=3) [256 x 96];
+// small = 4 waves x (RB=2 | 1, NB=1) [256|128 x 32]
+template <int NSPLIT>
+int launch_cfg(const GemmParams& P, int cfg, dim3 grid, hipStream_t s) {
+  switch (cfg) {
+    case 0: return launch<NSPLIT, 3, 2, 8>(P, grid, s);
+    case 1: return launch<NSPLIT, 3, 1, 8>(P, grid, s);
+    case 2: return launch<NSPLIT, 1, 2, 4>(P, grid, s);
+    default: return launch<NSPLIT, 1, 1, 4>(P, grid, s);
   }
 }
 
@@ -188,26 +412,67 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
 
 extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
   if (!d) return SDF_E_NULL;
-  if (!d->A || !d->Wp || !d->out) return SDF_E_NULL;
-  if (d->M < 1 || d->N < 32 || d->K < 32 || d->K % 32 || d->N % 32) return SDF_E_SHAPE;
-  if (d->nsplit < 1 || d->nsplit > 3) return SDF_E_DTYPE;
+  if (!d->A || !d->Wp) return SDF_E_NULL;
+  const bool spike = d->sn_T > 0;
+  if (spike ? !d->out_spike : !d->out) return SDF_E_NULL;
+  if (d->M < 1 || d->M >= (1LL << 31) || d->N < 32 || d->K < 32 || d->K % 32 || d->N % 32) return SDF_E_SHAPE;
+  if (d->nsplit != 1 && d->nsplit != 3) return SDF_E_DTYPE;       // 1 = bf16 weights, 3 = fp32-grade
   if (d->alpha && !d->beta) return SDF_E_NULL;
-  if (d->zg_nH > 0) {
-    if (d->K != d->zg_nH * 32 || d->zg_T < 1 || d->zg_B < 1 || d->zg_N1 < 1) return SDF_E_SHAPE;
-    if ((int64_t)d->zg_T * d->zg_B * d->zg_N1 != d->M) return SDF_E_SHAPE;
-  } else if (d->lda % 16) {
-    return SDF_E_SHAPE;
-  }
-  if (!sdf_aligned(d->A, 16) || !sdf_aligned(d->Wp, 16) || !sdf_aligned(d->out, 4)) return SDF_E_ALIGN;
+  if (d->lda % 16) return SDF_E_SHAPE;
   GemmParams P;
   P.d = *d;
-  dim3 grid((unsigned)((d->M + BM - 1) / BM), (unsigned)((d->N + BN - 1) / BN)), block(256);
-  hipStream_t s = sdf_stream(stream);
-  switch (d->nsplit) {
-    case 1: hipLaunchKernelGGL(spike_gemm_kernel<1>, grid, block, 0, s, P); break;
-    case 2: hipLaunchKernelGGL(spike_gemm_kernel<2>, grid, block, 0, s, P); break;
-    default: hipLaunchKernelGGL(spike_gemm_kernel<3>, grid, block, 0, s, P); break;
+  P.inv_tau = 0.f;
+  if (spike) {
+    if (d->pos_count < 1 || d->pos_inner < 1 || d->pos_count * d->sn_T != d->M) return SDF_E_SHAPE;
+    if (d->sn_kind != SDF_LIF && d->sn_kind != SDF_PSN && d->sn_kind != SDF_IF) return SDF_E_DTYPE;
+    if (d->sn_kind == SDF_PSN && (!d->psn_w || !d->psn_b)) return SDF_E_NULL;
+    if (d->sn_kind == SDF_LIF && !(d->tau > 1.f)) return SDF_E_SHAPE;
+    if (d->add && d->add_prows < 1) return SDF_E_SHAPE;
+    if (d->zg_nH > 0 || d->out_rowmap || d->resid || d->bias) return SDF_E_SHAPE;   // F32-only features
+    if (!sdf_aligned(d->out_spike, 16) || d->N % 16) return SDF_E_ALIGN;
+    int ex;
+    if (d->sn_kind == SDF_LIF && frexpf(d->tau, &ex) == 0.5f) P.inv_tau = 1.0f / d->tau;
+  } else if (d->zg_nH > 0) {
+    if (d->K != d->zg_nH * 32 || d->zg_T < 1 || d->zg_B < 1 || d->zg_N1 < 1) return SDF_E_SHAPE;
+    if ((int64_t)d->zg_T * d->zg_B * d->zg_N1 != d->M) return SDF_E_SHAPE;
   }
+  if (!sdf_aligned(d->A, 16) || !sdf_aligned(d->Wp, 16)) return SDF_E_ALIGN;
+
+  // ---- tile configuration ----
+  // cfg 0: 512x96 (8 waves, 2 row blocks)   cfg 1: 256x96 (8 waves)   cfg 2: 256x32 (4 waves)   cfg 3: 128x32 (4 waves)
+  // 96-wide tiles reuse every A fragment 3x; the fused neuron needs 2 row blocks when T > 8 (16*RB slots per lane).
+  static const int CFG_NB[4] = {3, 3, 1, 1}, CFG_RB[4] = {2, 1, 2, 1}, CFG_WAVES[4] = {8, 8, 4, 4};
+  auto ok = [&](int c) { return (CFG_NB[c] == 1 || d->N % 96 == 0) && (!spike || (16 * CFG_RB[c]) / d->sn_T >= 1); };
+  auto ntiles_for = [&](int c) -> int64_t {
+    const int64_t per = spike ? 2 * CFG_WAVES[c] * ((16 * CFG_RB[c]) / d->sn_T) : 32 * CFG_RB[c] * CFG_WAVES[c];
+    const int64_t rows = spike ? d->pos_count : d->M;
+    return ((rows + per - 1) / per) * ((d->N + 32 * CFG_NB[c] - 1) / (32 * CFG_NB[c]));
+  };
+  // Measured on MI355X (tools/gemm_microbench.py, profiles/r1_gemm_microbench.txt): these layers have K = 96..3072
+  // and are bound by the per-element epilogue / addressing VALU work, not by the MFMAs, so the smallest tile
+  // (most waves in flight) wins for the fp32 and T' = 2 epilogues; the T >= 5 neuron epilogue needs the 96-wide
+  // 8-wave tile to amortise its staging.  (ntiles_for() is kept for the tuning override.)
+  (void)ntiles_for;
+  int cfg = (spike && d->sn_T >= 5) ? (ok(1) ? 1 : 2) : 3;
+  if (!ok(cfg)) cfg = ok(2) ? 2 : 0;
+  if (const char* e = getenv("SDF_GEMM_CFG")) {                  // tuning override: 0..3
+    const int c = e[0] - '0';
+    if (c >= 0 && c < 4 && ok(c)) cfg = c;
+  }
+  if (!ok(cfg)) return SDF_E_SHAPE;
+  const int nb = CFG_NB[cfg], rb = CFG_RB[cfg], waves = CFG_WAVES[cfg];
+  const int npos = spike ? (16 * rb) / d->sn_T : 0;
+  P.tiles_m = (int)(spike ? (d->pos_count + 2 * waves * npos - 1) / (2 * waves * npos)
+                          : (d->M + 32 * rb * waves - 1) / (32 * rb * waves));
+  P.tiles_n = (d->N + 32 * nb - 1) / (32 * nb);
+  P.ntiles = P.tiles_m * P.tiles_n;
+  const size_t lds = (size_t)32 * rb * waves * A_LD + (size_t)d->nsplit * 32 * nb * W_LD * 2;
+  const int wg_per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
+  const int G = P.ntiles < 256 * wg_per_cu ? P.ntiles : 256 * wg_per_cu;
+  dim3 grid((unsigned)G);
+  hipStream_t s = sdf_stream(stream);
+  const int rc = d->nsplit == 1 ? launch_cfg<1>(P, cfg, grid, s) : launch_cfg<3>(P, cfg, grid, s);
+  if (rc) return rc;
   SDF_LAUNCH_CHECK();
   return 0;
 }

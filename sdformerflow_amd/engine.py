@@ -178,13 +178,12 @@ class MSFlowEngine:
         dev = x.device
         xs = torch.empty((M, Cc), dtype=torch.uint8, device=dev)
         hip.neuron_fwd(x, xs, Tq, 1, n, 0, 0, 0, n, blk.sn_proj, rowmap=rowmap, rowlen=Cc)
-        f = torch.empty((M, Cc), dtype=torch.float32, device=dev)
+        # q = SN(BN(xs Wq^T)), k = SN(BN(xs Wk^T) + PE): GEMM with the neuron fused into its epilogue (u8 out)
         q = torch.empty((M, Cc), dtype=torch.uint8, device=dev)
-        hip.spike_gemm(xs, blk.q.Wp, f, M, Cc, Cc, alpha=blk.q.alpha, beta=blk.q.beta)
-        hip.neuron_fwd(f, q, Tq, 1, n, 0, n, 0, n, blk.sn_q)
+        hip.spike_gemm_sn(xs, blk.q.Wp, q, Cc, Cc, Tq, rows, rows, 0, rows, blk.sn_q, alpha=blk.q.alpha, beta=blk.q.beta)
         k = torch.empty((M, Cc), dtype=torch.uint8, device=dev)
-        hip.spike_gemm(xs, blk.k.Wp, f, M, Cc, Cc, alpha=blk.k.alpha, beta=blk.k.beta)
-        hip.neuron_fwd(f, k, Tq, 1, n, 0, n, 0, n, blk.sn_k, add=blk.pe, add_st=N1 * Cc, add_period=N1 * Cc)
+        hip.spike_gemm_sn(xs, blk.k.Wp, k, Cc, Cc, Tq, rows, rows, 0, rows, blk.sn_k, alpha=blk.k.alpha, beta=blk.k.beta,
+                          add=blk.pe, add_prows=N1)
         hip.qk_gate(q, k, xs, Tq, rows, Cc, blk.sn2_q)                                  # E overwrites xs
         hip.spike_gemm(xs, blk.p.Wp, x, M, Cc, Cc, bias=blk.p.bias, alpha=blk.p.alpha, beta=blk.p.beta, resid=x,
                        out_rowmap=rowmap, zg=(blk.nH, Tq, B_, N1))
@@ -198,10 +197,10 @@ class MSFlowEngine:
         dev = x.device
         s1 = torch.empty((ntok, Cc), dtype=torch.uint8, device=dev)
         hip.neuron_fwd(x, s1, D, B, hw * Cc, D * hw * Cc, hw * Cc, D * hw * Cc, hw * Cc, blk.sn1)
-        h = torch.empty((ntok, Ch), dtype=torch.float32, device=dev)
-        hip.spike_gemm(s1, blk.fc1.Wp, h, ntok, Ch, Cc, alpha=blk.fc1.alpha, beta=blk.fc1.beta)
+        # s2 = SN(BN(s1 W1^T)) over the D time steps of every (b, h, w): fused GEMM + neuron, hidden never in fp32
         s2 = torch.empty((ntok, Ch), dtype=torch.uint8, device=dev)
-        hip.neuron_fwd(h, s2, D, B, hw * Ch, D * hw * Ch, hw * Ch, D * hw * Ch, hw * Ch, blk.sn2)
+        hip.spike_gemm_sn(s1, blk.fc1.Wp, s2, Ch, Cc, D, B * hw, hw, D * hw, hw, blk.sn2, alpha=blk.fc1.alpha,
+                          beta=blk.fc1.beta)
         hip.spike_gemm(s2, blk.fc2.Wp, x, ntok, Cc, Ch, alpha=blk.fc2.alpha, beta=blk.fc2.beta, resid=x)
         return x
 

@@ -45,7 +45,12 @@ class SpikeGemmDesc(C.Structure):
                 ("lda", C.c_int64), ("ldo", C.c_int64), ("nsplit", C.c_int32),
                 ("bias", C.c_void_p), ("alpha", C.c_void_p), ("beta", C.c_void_p),
                 ("resid", C.c_void_p), ("out_rowmap", C.c_void_p),
-                ("zg_nH", C.c_int32), ("zg_T", C.c_int32), ("zg_B", C.c_int32), ("zg_N1", C.c_int32)]
+                ("zg_nH", C.c_int32), ("zg_T", C.c_int32), ("zg_B", C.c_int32), ("zg_N1", C.c_int32),
+                ("sn_T", C.c_int32), ("sn_kind", C.c_int32),
+                ("tau", C.c_float), ("v_th", C.c_float), ("v_reset", C.c_float), ("soft_reset", C.c_int32),
+                ("psn_w", C.c_void_p), ("psn_b", C.c_void_p),
+                ("pos_count", C.c_int64), ("pos_inner", C.c_int64), ("pos_ostride", C.c_int64), ("t_stride", C.c_int64),
+                ("add", C.c_void_p), ("add_prows", C.c_int64), ("out_spike", C.c_void_p)]
 
 
 class WinAttnDesc(C.Structure):
@@ -174,6 +179,23 @@ def spike_gemm(A, Wp, out, M, N, K, lda=None, ldo=None, bias=None, alpha=None, b
         d.zg_nH, d.zg_T, d.zg_B, d.zg_N1 = zg
     _check(lib().sdf_spike_gemm_fwd(C.byref(d), _stream()), "sdf_spike_gemm_fwd")
     return out
+
+
+def spike_gemm_sn(A, Wp, out_spike, N, K, T, pos_count, pos_inner, pos_ostride, t_stride, p: NeuronParams,
+                  alpha=None, beta=None, add=None, add_prows=0, lda=None):
+    """sdf_spike_gemm_fwd with the fused neuron epilogue: out_spike (rows,N) u8 = SN_T(BN(A W^T) [+ add])."""
+    d = SpikeGemmDesc()
+    d.A, d.Wp, d.out_spike = _ptr(A, torch.uint8), _ptr(Wp, torch.int16), _ptr(out_spike, torch.uint8)
+    d.M, d.N, d.K = pos_count * T, N, K
+    d.lda, d.ldo, d.nsplit = (K if lda is None else lda), N, Wp.shape[0]
+    d.alpha, d.beta = _ptr(alpha, torch.float32), _ptr(beta, torch.float32)
+    d.sn_T, d.sn_kind, d.tau, d.v_th = T, KIND[p.kind], p.tau, p.v_th
+    d.v_reset, d.soft_reset = (0.0 if p.v_reset is None else float(p.v_reset)), (1 if p.v_reset is None else 0)
+    d.psn_w, d.psn_b = _ptr(p.psn_w, torch.float32), _ptr(p.psn_b, torch.float32)
+    d.pos_count, d.pos_inner, d.pos_ostride, d.t_stride = pos_count, pos_inner, pos_ostride, t_stride
+    d.add, d.add_prows = _ptr(add, torch.float32), add_prows
+    _check(lib().sdf_spike_gemm_fwd(C.byref(d), _stream()), "sdf_spike_gemm_fwd")
+    return out_spike
 
 
 def qk_gate(q, k, e, Tq, rows, Cch, p: NeuronParams):

@@ -208,3 +208,31 @@ def test_win_attn_sew_linear(with_mask, nH):
     got = hip.win_attn_sew(q.to(DEV), k.to(DEV), v.to(DEV), sc.to(DEV), bias.to(DEV), mask.to(DEV) if with_mask else None,
                            nH, Tq, B_, N1)
     assert (got.cpu() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+# ---------------------------------------------------------------- spike GEMM with the fused neuron epilogue
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+@pytest.mark.parametrize("T,B,HW,K,N", [(10, 2, 50, 96, 384), (10, 1, 37, 192, 96), (2, 1, 81 * 5, 96, 96), (4, 3, 20, 32, 64),
+                                         (20, 1, 9, 96, 96), (5, 2, 33, 64, 32)])
+def test_spike_gemm_fused_neuron(kind, T, B, HW, K, N):
+    """SN_T(BN(A W^T) [+ add]) as one kernel vs GEMM(fp64) -> C oracle neuron.  Rows are (b, t, hw) like the MLP
+    hidden layer (Spiking_swin_transformer3D.py:170-174).  The pre-activation differs from the fp64 one by fp32
+    rounding, so a spike may flip only when it is within that rounding of the threshold: rate bound 2e-4."""
+    A = spikes((B, T, HW, K), 80 + T)
+    W = rnd((N, K), 81, -0.3, 0.3)
+    alpha, beta = rnd((N,), 82, 0.5, 1.5), rnd((N,), 83, -0.2, 0.2)
+    add = rnd((T, 7, N), 84, -0.3, 0.3)
+    Wn, bn = rnd((T, T), 85, -0.5, 0.5) + 0.5 * torch.eye(T), torch.full((T,), -0.1)
+    h = ((A.double() @ W.double().t()) * alpha.double() + beta.double())               # (B,T,HW,N)
+    pos = torch.arange(B * HW) % 7
+    h = h + add.double()[:, pos].view(T, B, HW, N).permute(1, 0, 2, 3)
+    x = h.permute(1, 0, 2, 3).float().contiguous()                                      # (T,B,HW,N)
+    ref = R.neuron_ref(x, kind, 2.0, 0.1, None, psn_w=Wn, psn_b=bn).permute(1, 0, 2, 3)
+    out = torch.zeros((B * T * HW, N), dtype=torch.uint8, device=DEV)
+    p = hip.NeuronParams(kind, 2.0, 0.1, None, Wn.to(DEV), bn.to(DEV))
+    hip.spike_gemm_sn(A.view(-1, K).to(DEV), hip.split_weight(W.to(DEV), 3), out, N, K, T, B * HW, HW, T * HW, HW, p,
+                      alpha=alpha.to(DEV), beta=beta.to(DEV), add=add.to(DEV), add_prows=7)
+    got = out.cpu().view(B, T, HW, N).float()
+    rate = (got != ref).float().mean().item()
+    assert rate <= 2e-4, rate
+    assert 0.03 < ref.mean() < 0.97
