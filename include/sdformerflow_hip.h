@@ -147,6 +147,28 @@ typedef struct SdfSpikeGemmDesc {
 
 int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Spike convolution (implicit GEMM):  out = epilogue( im2col(X) x W^T ) with X an NHWC u8 spike image batch.
+ * Replaces: layer.Conv2d / nn.Conv2d / ConvTranspose2d on spikes + the SpikingNormLayer, shortcut add and
+ * Spiking_neuron around it in the patch embedding and the U-Net tail (reference Spiking_modules.py:339-347,
+ * 467-474, 811-818, 906-926).  `g` is used as in sdf_spike_gemm_fwd with:
+ *   g.A  = X (imgs, H, W, Cin) u8, Cin % 16 == 0, Cin >= 48;   g.M = imgs*OH*OW;   g.N = Cout (multiple of 96)
+ *   g.K  = KH*KW*Cin, weights packed [nsplit][Cout][(ky, kx, cin)] bf16 planes
+ *   row m = (img, oy, ox) reads input pixel (oy*sy + dy[ky], ox*sx + dx[kx]); zero outside the image
+ *     (a 3x3 / pad 1 convolution: dy = dx = {-1, 0, 1}; the parity classes of a stride-2 transposed convolution
+ *     are 1- or 2-tap grids with their own offsets and an out_rowmap that places the class's outputs)
+ *   epilogue: the fp32 one (alpha/beta/resid/out_rowmap, out is (rows, Cout) fp32 NHWC) or, with sn_T == 10,
+ *     the fused neuron (out_spike u8 NHWC); pos_* describe how the imgs dimension factors into (time, position).
+ */
+typedef struct SdfSpikeConvDesc {
+  SdfSpikeGemmDesc g;
+  int32_t H, W, Cin, OH, OW;
+  int32_t KH, KW, sy, sx;
+  int32_t dy[3], dx[3];
+} SdfSpikeConvDesc;
+
+int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream);
+
 /* W (fp32, n elements) -> nsplit bf16 planes (round-to-nearest-even residual split). */
 int sdf_split_weight_bf16(const float* W, uint16_t* planes, int64_t n, int nsplit, void* stream);
 

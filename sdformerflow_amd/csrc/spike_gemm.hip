@@ -35,8 +35,17 @@ constexpr int W_LD = KC + 8;          // bf16 elements per W row in LDS (208 B =
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// Implicit-GEMM convolution geometry (CONV kernels): A row g = (img, oy, ox) over an OH x OW output grid; K is
+// ordered (tap, channel) with taps on a KHc x KWc grid; tap (ky, kx) reads input pixel
+// (oy*sy + dy[ky], ox*sx + dx[kx]) of an NHWC u8 image, zero outside [0,H) x [0,W).
+struct ConvGeom {
+  int H, W, Cin, OH, OW, sy, sx, KWc, kw_mul;     // kw_mul: (tap * kw_mul) >> 5 == tap / KWc for tap < 9
+  int dy[3], dx[3];
+};
+
 struct GemmParams {
   SdfSpikeGemmDesc d;
+  ConvGeom cv;
   int tiles_m, tiles_n, ntiles;
   float inv_tau;
 };
@@ -53,7 +62,7 @@ __device__ __forceinline__ bf16x8 expand_spikes(uint2 v) {
 
 // WAVES = 8 (512 threads): two waves per SIMD share one weight tile, so one wave's address / epilogue VALU work
 // overlaps the other's MFMAs.  WAVES = 4 (256 threads) with small tiles is for problems with few rows.
-template <int NSPLIT, int NB, int RB, int TT, int WAVES>
+template <int NSPLIT, int NB, int RB, int TT, int WAVES, bool CONV>
 __global__ __launch_bounds__(64 * WAVES) void spike_gemm_kernel(GemmParams P) {
   constexpr bool SPIKE = TT > 0;
   constexpr int T = SPIKE ? TT : 1;
@@ -111,13 +120,24 @@ __global__ __launch_bounds__(64 * WAVES) void spike_gemm_kernel(GemmParams P) {
 
   uint4 areg[AIT], wreg[WIT];
   int64_t a_off[AIT];                // source offset of each staged chunk's row for the tile being LOADED
+  int a_iyx[CONV ? AIT : 1];         // CONV: (oy*sy) << 16 | (ox*sx) of that row
   const int64_t zg_gstride = (int64_t)d.zg_T * d.zg_N1 * 32;     // head-scramble: offset between channel groups
   auto set_rows = [&](int rt) {
 #pragma unroll
     for (int i = 0; i < AIT; ++i) {
       const int64_t g = tile_row(rt, a_row[i]);
       a_off[i] = g < 0 ? -1 : g * d.lda;
-      if (!SPIKE && d.zg_nH > 0 && g >= 0) {
+      if (CONV) {
+        if (g >= 0) {
+          const ConvGeom& cv = P.cv;
+          const uint32_t ohw = (uint32_t)(cv.OH * cv.OW);
+          const uint32_t img = (uint32_t)g / ohw;
+          const uint32_t r2 = (uint32_t)g - img * ohw;
+          const uint32_t oy = r2 / (uint32_t)cv.OW, ox = r2 - oy * (uint32_t)cv.OW;
+          a_off[i] = (int64_t)img * cv.H * cv.W;                       // pixel index of the image origin
+          a_iyx[i] = (int)((oy * cv.sy) << 16 | (ox * cv.sx));         // un-offset input coordinates
+        }
+      } else if (!SPIKE && d.zg_nH > 0 && g >= 0) {
         // Z[t,b,n,g*32+d] = E_flat[((((b*nH+g)*T+t)*N1+n)*32+d]  ->  base(t,b,n) + g*(T*N1*32) + d
         const uint32_t bn = (uint32_t)(d.zg_B * d.zg_N1);
         const uint32_t zt = (uint32_t)g / bn;
@@ -129,13 +149,25 @@ __global__ __launch_bounds__(64 * WAVES) void spike_gemm_kernel(GemmParams P) {
     }
   };
   auto load_stage = [&](int cb, int k0, bool with_w) {
+    // CONV: wave-uniform part of the (tap, channel) split of this stage; Cin >= 48 so a chunk wraps at most twice
+    const int tap0 = CONV ? k0 / P.cv.Cin : 0, c0 = CONV ? k0 - tap0 * P.cv.Cin : 0;
 #pragma unroll
     for (int i = 0; i < AIT; ++i) {
       const int k = k0 + 16 * a_c16[i];
       areg[i] = make_uint4(0, 0, 0, 0);
       if (a_off[i] >= 0 && k < K) {
         const uint8_t* src;
-        if (!SPIKE && d.zg_nH > 0) {
+        if (CONV) {
+          const ConvGeom& cv = P.cv;
+          int tap = tap0, c = c0 + 16 * a_c16[i];
+          if (c >= cv.Cin) { c -= cv.Cin; ++tap; }
+          if (c >= cv.Cin) { c -= cv.Cin; ++tap; }
+          const int ky = (tap * cv.kw_mul) >> 5, kx = tap - ky * cv.KWc;
+          const int iy = (a_iyx[i] >> 16) + (ky == 0 ? cv.dy[0] : (ky == 1 ? cv.dy[1] : cv.dy[2]));
+          const int ix = (a_iyx[i] & 0xffff) + (kx == 0 ? cv.dx[0] : (kx == 1 ? cv.dx[1] : cv.dx[2]));
+          if ((unsigned)iy >= (unsigned)cv.H || (unsigned)ix >= (unsigned)cv.W) continue;
+          src = d.A + (a_off[i] + (int64_t)iy * cv.W + ix) * cv.Cin + c;
+        } else if (!SPIKE && d.zg_nH > 0) {
           src = d.A + a_off[i] + (k >> 5) * zg_gstride + (k & 31);
         } else {
           src = d.A + a_off[i] + k;
@@ -380,18 +412,25 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
   }
 }
 
-template <int NSPLIT, int NB, int RB, int WAVES>
+template <int NSPLIT, int NB, int RB, int WAVES, bool CONV = false>
 int launch(const GemmParams& P, dim3 grid, hipStream_t s) {
 #define SDF_GEMM_T(TT)                                                                                      \
   case TT:                                                                                                  \
     if constexpr (TT == 0 || (16 * RB) / (TT ? TT : 1) >= 1) {                                              \
-      hipLaunchKernelGGL((spike_gemm_kernel<NSPLIT, NB, RB, TT, WAVES>), grid, dim3(64 * WAVES), 0, s, P);  \
+      hipLaunchKernelGGL((spike_gemm_kernel<NSPLIT, NB, RB, TT, WAVES, CONV>), grid, dim3(64 * WAVES), 0, s, P);  \
       return 0;                                                                                             \
     }                                                                                                       \
     return SDF_E_SHAPE;
-  switch (P.d.sn_T) {
-    SDF_GEMM_T(0) SDF_GEMM_T(2) SDF_GEMM_T(4) SDF_GEMM_T(5) SDF_GEMM_T(10) SDF_GEMM_T(20)
-    default: return SDF_E_SHAPE;
+  if constexpr (CONV) {          // convolutions: fp32 epilogue, or the fused neuron over T = 10 steps
+    switch (P.d.sn_T) {
+      SDF_GEMM_T(0) SDF_GEMM_T(10)
+      default: return SDF_E_SHAPE;
+    }
+  } else {
+    switch (P.d.sn_T) {
+      SDF_GEMM_T(0) SDF_GEMM_T(2) SDF_GEMM_T(4) SDF_GEMM_T(5) SDF_GEMM_T(10) SDF_GEMM_T(20)
+      default: return SDF_E_SHAPE;
+    }
   }
 #undef SDF_GEMM_T
 }
@@ -472,6 +511,56 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
   dim3 grid((unsigned)G);
   hipStream_t s = sdf_stream(stream);
   const int rc = d->nsplit == 1 ? launch_cfg<1>(P, cfg, grid, s) : launch_cfg<3>(P, cfg, grid, s);
+  if (rc) return rc;
+  SDF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution on spike images (NHWC u8): the same persistent MFMA kernel with an im2col loader.
+extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
+  if (!c) return SDF_E_NULL;
+  const SdfSpikeGemmDesc* d = &c->g;
+  if (!d->A || !d->Wp) return SDF_E_NULL;
+  const bool spike = d->sn_T > 0;
+  if (spike ? !d->out_spike : !d->out) return SDF_E_NULL;
+  if (c->H < 1 || c->W < 1 || c->H > 32767 || c->W > 32767 || c->OH < 1 || c->OW < 1) return SDF_E_SHAPE;
+  if (c->Cin < 48 || c->Cin % 16 || c->KH < 1 || c->KH > 3 || c->KW < 1 || c->KW > 3 || c->sy < 1 || c->sx < 1) return SDF_E_SHAPE;
+  if (d->K != c->KH * c->KW * c->Cin || d->N % 96 || d->M % ((int64_t)c->OH * c->OW) || d->M >= (1LL << 31)) return SDF_E_SHAPE;
+  if ((d->M / ((int64_t)c->OH * c->OW)) * c->H * c->W >= (1LL << 31)) return SDF_E_SHAPE;
+  if (d->nsplit != 1 && d->nsplit != 3) return SDF_E_DTYPE;
+  if (d->alpha && !d->beta) return SDF_E_NULL;
+  if (d->zg_nH > 0) return SDF_E_SHAPE;
+  GemmParams P;
+  P.d = *d;
+  P.d.lda = 0;
+  P.inv_tau = 0.f;
+  if (spike) {
+    if (d->sn_T != 10 || d->pos_count < 1 || d->pos_inner < 1 || d->pos_count * d->sn_T != d->M) return SDF_E_SHAPE;
+    if (d->sn_kind != SDF_LIF && d->sn_kind != SDF_PSN && d->sn_kind != SDF_IF) return SDF_E_DTYPE;
+    if (d->sn_kind == SDF_PSN && (!d->psn_w || !d->psn_b)) return SDF_E_NULL;
+    if (d->sn_kind == SDF_LIF && !(d->tau > 1.f)) return SDF_E_SHAPE;
+    if (d->out_rowmap || d->resid || d->bias || d->add) return SDF_E_SHAPE;
+    if (!sdf_aligned(d->out_spike, 16)) return SDF_E_ALIGN;
+    int ex;
+    if (d->sn_kind == SDF_LIF && frexpf(d->tau, &ex) == 0.5f) P.inv_tau = 1.0f / d->tau;
+  }
+  if (!sdf_aligned(d->A, 16) || !sdf_aligned(d->Wp, 16)) return SDF_E_ALIGN;
+  ConvGeom& cv = P.cv;
+  cv.H = c->H; cv.W = c->W; cv.Cin = c->Cin; cv.OH = c->OH; cv.OW = c->OW; cv.sy = c->sy; cv.sx = c->sx;
+  cv.KWc = c->KW;
+  cv.kw_mul = c->KW == 1 ? 32 : (c->KW == 2 ? 16 : 11);
+  for (int i = 0; i < 3; ++i) { cv.dy[i] = c->dy[i]; cv.dx[i] = c->dx[i]; }
+  // one configuration: 256 x 96 tiles, 8 waves (K = taps*Cin >= 432: MFMA-dominated, weights streamed per stage)
+  const int waves = 8, rb = 1, nb = 3;
+  const int npos = spike ? (16 * rb) / d->sn_T : 0;
+  P.tiles_m = (int)(spike ? (d->pos_count + 2 * waves * npos - 1) / (2 * waves * npos) : (d->M + 32 * rb * waves - 1) / (32 * rb * waves));
+  P.tiles_n = d->N / (32 * nb);
+  P.ntiles = P.tiles_m * P.tiles_n;
+  const int G = P.ntiles < 256 ? P.ntiles : 256;
+  dim3 grid((unsigned)G);
+  hipStream_t s = sdf_stream(stream);
+  const int rc = d->nsplit == 1 ? launch<1, 3, 1, 8, true>(P, grid, s) : launch<3, 3, 1, 8, true>(P, grid, s);
   if (rc) return rc;
   SDF_LAUNCH_CHECK();
   return 0;

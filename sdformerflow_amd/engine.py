@@ -69,11 +69,54 @@ class _Block:
         self.sn1, self.sn2 = _np(m.sn1, device), _np(m.sn2, device)
 
 
+def _conv_planes(w, nsplit, cin_pad=None):
+    return hip.pack_conv_weight(w.detach().float(), nsplit, cin_pad)
+
+
 class _ResBlock:
-    def __init__(self, rb, device):
-        self.w1, self.w2 = rb.conv1[0].weight.detach(), rb.conv2[0].weight.detach()
+    """MS_ResBlock weights for the spike-convolution path (3x3, pad 1, NHWC)."""
+
+    def __init__(self, rb, device, nsplit):
+        self.C = rb.conv1[0].weight.shape[0]
+        self.w1, self.w2 = _conv_planes(rb.conv1[0].weight, nsplit), _conv_planes(rb.conv2[0].weight, nsplit)
         self.bn1, self.bn2 = bn_affine(rb.norm1.norm_layer, device), bn_affine(rb.norm2.norm_layer, device)
         self.sn1, self.sn2 = _np(rb.sn1, device), _np(rb.sn2, device)
+
+
+_DECONV_ROWMAPS = {}
+
+
+def deconv_classes(w, imgs, H, W, cin_pad, nsplit, device):
+    """ConvTranspose2d(k=3, s=2, p=1, output_padding=1) as four output-parity classes.
+
+    out[2y'+py, 2x'+px] only receives the taps whose kernel index has the right parity
+    (oy = 2*iy - 1 + ky): py = 0 -> (ky=1, iy=y'); py = 1 -> (ky=2, iy=y') and (ky=0, iy=y'+1); same in x.
+    Each class is a 1- or 2-tap implicit GEMM over the INPUT grid whose rows are scattered to the class's
+    output pixels by an int32 row map.  w is the reference layout (Cin, Cout, 3, 3)."""
+    Cin, Cout = w.shape[:2]
+    taps = {0: [(0, 1)], 1: [(0, 2), (1, 0)]}            # parity -> [(input offset, kernel index)]
+    out = []
+    for py in (0, 1):
+        for px in (0, 1):
+            ty, tx = taps[py], taps[px]
+            wk = torch.zeros((Cout, len(ty), len(tx), cin_pad), dtype=torch.float32, device=w.device)
+            for a, (_, ky) in enumerate(ty):
+                for b, (_, kx) in enumerate(tx):
+                    wk[:, a, b, :Cin] = w.detach().float()[:, :, ky, kx].t()
+            key = (imgs, H, W, py, px, str(device))
+            if key not in _DECONV_ROWMAPS:
+                i = torch.arange(imgs).view(-1, 1, 1)
+                y = torch.arange(H).view(1, -1, 1)
+                x = torch.arange(W).view(1, 1, -1)
+                rm = ((i * 2 * H + 2 * y + py) * 2 * W + 2 * x + px).reshape(-1).to(torch.int32)
+                _DECONV_ROWMAPS[key] = rm.to(device)
+            out.append({"Wp": hip.split_weight(wk.reshape(Cout, -1), nsplit), "KH": len(ty), "KW": len(tx),
+                        "dy": [t[0] for t in ty], "dx": [t[0] for t in tx], "rowmap": _DECONV_ROWMAPS[key]})
+    return out
+
+
+def _pad16(c):
+    return (c + 15) // 16 * 16
 
 
 class MSFlowEngine:
@@ -84,15 +127,17 @@ class MSFlowEngine:
                                "(there is no CPU fallback; the CPU restatement lives in oracle/ for tests)")
         hip.lib()
         dev, ns = self.device, model.gemm_nsplit
+        self.nsplit = ns
         unet = model.sttmultires_unet
         sw = unet.encoders.swin3d
         pe = sw.patch_embed
         self.num_bins, self.num_steps = pe.num_bins, pe.num_steps
-        self.head_w = pe.head.conv[0].weight.detach()
+        self.head_w = pe.head.conv[0].weight.detach().contiguous(memory_format=torch.channels_last)
         self.head_bn, self.head_sn = bn_affine(pe.head.norm_layer.norm_layer, dev), _np(pe.head.sn, dev)
-        self.conv_w, self.conv_bn = pe.conv.conv[0].weight.detach(), bn_affine(pe.conv.norm_layer.norm_layer, dev)
-        self.pe_res = [_ResBlock(rb, dev) for rb in pe.residual_encoding.resblocks]
-        self.proj_res_w, self.proj_w = pe.proj.conv_res.weight.detach(), pe.proj.conv.weight.detach()
+        self.conv_w, self.conv_bn = _conv_planes(pe.conv.conv[0].weight, ns), bn_affine(pe.conv.norm_layer.norm_layer, dev)
+        self.pe_res = [_ResBlock(rb, dev, ns) for rb in pe.residual_encoding.resblocks]
+        self.proj_res_w = pe.proj.conv_res.weight.detach().contiguous(memory_format=torch.channels_last)
+        self.proj_w = _conv_planes(pe.proj.conv.weight, ns)
         self.proj_bn, self.proj_sn = bn_affine(pe.proj.norm_layer, dev), _np(pe.proj.sn, dev)
         self.stages, self.merges = [], []
         for layer in sw.layers:
@@ -100,11 +145,11 @@ class MSFlowEngine:
             if layer.downsample is not None:
                 d = layer.downsample
                 self.merges.append((_Lin(d.reduction, d.norm.norm_layer, dev, ns), _np(d.sn, dev)))
-        self.unet_res = [_ResBlock(rb, dev) for rb in unet.resblocks]
-        self.decoders = [(d.deconv[0].weight.detach(), bn_affine(d.norm_layer.norm_layer, dev), _np(d.sn, dev),
-                          d.deconv[0].kernel_size[0]) for d in unet.decoders]
-        self.preds = [(p.conv[0].weight.detach(), p.conv[0].bias.detach(), _np(p.sn, dev)) for p in unet.preds]
-        self._maps = {}
+        self.unet_res = [_ResBlock(rb, dev, ns) for rb in unet.resblocks]
+        self.decoders = [(d.deconv[0].weight.detach(), bn_affine(d.norm_layer.norm_layer, dev), _np(d.sn, dev)) for d in unet.decoders]
+        self.preds = [(p.conv[0].weight.detach().float().reshape(p.conv[0].weight.shape[0], -1).t().contiguous(),
+                       p.conv[0].bias.detach().float(), _np(p.sn, dev)) for p in unet.preds]
+        self._maps, self._deconv = {}, {}
 
     # ------------------------------------------------------------------ helpers
     def _slice_map(self, B, D, H, W, ws, ss):
@@ -127,45 +172,65 @@ class MSFlowEngine:
             self._maps[key] = (torch.from_numpy(src.reshape(-1)).to(self.device), H2, W2, out_map)
         return self._maps[key]
 
-    def _neuron_nchw(self, y, T, p, bn=None, out_dtype=torch.float32):
-        """Neuron over the leading T of a (T*B, C, h, w) conv output, BN fused when given."""
-        TB, Cc, h, w = y.shape
-        n = (TB // T) * Cc * h * w
-        out = torch.empty(y.shape, dtype=out_dtype, device=y.device)
+    def _neuron_bd(self, x, p, bn=None, out_dtype=torch.uint8):
+        """Neuron over D of a channel-last (B,D,h,w,C) activation, BN fused when given."""
+        B, D, h, w, Cc = x.shape
+        out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
         a, b = bn if bn is not None else (None, None)
-        hip.neuron_fwd(y, out, T, 1, n, 0, n, 0, n, p, alpha=a, beta=b, Cch=Cc, inner=h * w)
+        n = h * w * Cc
+        hip.neuron_fwd(x, out, D, B, n, D * n, n, D * n, n, p, alpha=a, beta=b, Cch=Cc, inner=1)
         return out
 
-    def _resblock(self, m, T, rb):
-        """MS_ResBlock on a (T*B, C, h, w) membrane (reference Spiking_modules.py:906-933)."""
-        Cc, hw = m.shape[1], m.shape[2] * m.shape[3]
-        s = self._neuron_nchw(m, T, rb.sn1)
-        y = F.conv2d(s, rb.w1, None, 1, 1)
-        s = self._neuron_nchw(y, T, rb.sn2, rb.bn1)
-        y = F.conv2d(s, rb.w2, None, 1, 1)
-        return hip.affine_resid(y, rb.bn2[0], rb.bn2[1], Cc, hw, resid=m)
+    def _conv3x3(self, s, Wp, Cout, stride=1, bn=None, resid=None, sn=None):
+        """3x3 / pad 1 spike convolution on (B,D,h,w,Cin) u8 -> (B,D,oh,ow,Cout): fp32 (BN, + resid) or, with `sn`,
+        spikes of the fused BN + neuron over D."""
+        B, D, h, w, Cin = s.shape
+        oh, ow = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+        a, b = bn if bn is not None else (None, None)
+        if sn is None:
+            out = torch.empty((B, D, oh, ow, Cout), dtype=torch.float32, device=s.device)
+            hip.spike_conv2d(s, Wp, B * D, h, w, Cin, oh, ow, 3, 3, stride, (-1, 0, 1), (-1, 0, 1), out=out, alpha=a, beta=b,
+                             resid=resid)
+            return out
+        out = torch.empty((B, D, oh, ow, Cout), dtype=torch.uint8, device=s.device)
+        hip.spike_conv2d(s, Wp, B * D, h, w, Cin, oh, ow, 3, 3, stride, (-1, 0, 1), (-1, 0, 1), out_spike=out, alpha=a, beta=b,
+                         sn=sn, sn_T=D, pos=(B * oh * ow, oh * ow, D * oh * ow, oh * ow))
+        return out
+
+    def _resblock(self, m, rb):
+        """MS_ResBlock on a (B,D,h,w,C) membrane: SN -> conv+BN+SN (one kernel) -> conv+BN+identity (one kernel)
+        (reference Spiking_modules.py:906-933)."""
+        D = m.shape[1]
+        s1 = self._neuron_bd(m, rb.sn1)
+        if D == 10:
+            s2 = self._conv3x3(s1, rb.w1, rb.C, bn=rb.bn1, sn=rb.sn2)
+        else:                                            # fused neuron epilogue is built for T = 10
+            s2 = self._neuron_bd(self._conv3x3(s1, rb.w1, rb.C), rb.sn2, bn=rb.bn1)
+        return self._conv3x3(s2, rb.w2, rb.C, bn=rb.bn2, resid=m)
 
     # ------------------------------------------------------------------ stages (each usable stand-alone in tests)
     def patch_embed(self, x):
-        """(B,bins,2,H,W) -> membrane (T,B,C,H/4,W/4) (reference Spiking_modules.py:1770-1790)."""
+        """(B,bins,2,H,W) -> membrane (B,D,H/4,W/4,C), channel-last (reference Spiking_modules.py:1770-1790)."""
         if x.size(1) > self.num_bins:
             x = x[:, :self.num_bins]
         B, T = x.shape[0], self.num_steps
+        H, W = x.shape[-2:]
         num_ch = self.num_bins * 2 // T
-        ev = x.permute(0, 2, 3, 4, 1)
-        xr = torch.stack([ev[:, i % 2, :, :, (i // 2) * T:(i // 2 + 1) * T] for i in range(num_ch)], 1)
-        xr = xr.permute(4, 0, 1, 2, 3).contiguous().flatten(0, 1)                        # (T*B, num_ch, H, W)
-        y = F.conv2d(xr, self.head_w, None, 1, 1)
-        s = self._neuron_nchw(y, T, self.head_sn, self.head_bn)
-        y = F.conv2d(s, self.conv_w, None, 2, 1)
-        m = hip.affine_resid(y, self.conv_bn[0], self.conv_bn[1], y.shape[1], y.shape[2] * y.shape[3])
+        ev = x.permute(0, 2, 3, 4, 1)                                                     # (B,2,H,W,bins)
+        xr = torch.stack([ev[:, i % 2, :, :, (i // 2) * T:(i // 2 + 1) * T] for i in range(num_ch)], -1)   # (B,H,W,T,ch)
+        xr = xr.permute(0, 3, 1, 2, 4).contiguous().view(B * T, H, W, num_ch)               # NHWC, image = (b,t)
+        # head: real-valued 2-channel input -> stock convolution (channels_last), then BN + SN fused in the neuron kernel
+        y = F.conv2d(xr.permute(0, 3, 1, 2), self.head_w, None, 1, 1).contiguous(memory_format=torch.channels_last)
+        s = self._neuron_bd(y.permute(0, 2, 3, 1).view(B, T, H, W, -1), self.head_sn, bn=self.head_bn)
+        m = self._conv3x3(s, self.conv_w, self.conv_w.shape[1], stride=2, bn=self.conv_bn)
         for rb in self.pe_res:
-            m = self._resblock(m, T, rb)
-        res = F.conv2d(m, self.proj_res_w, None, 2)
-        s = self._neuron_nchw(m, T, self.proj_sn)
-        z = F.conv2d(s, self.proj_w, None, 2, 1)
-        out = hip.affine_resid(z, self.proj_bn[0], self.proj_bn[1], z.shape[1], z.shape[2] * z.shape[3], resid=res)
-        return out.view(T, B, *out.shape[1:])
+            m = self._resblock(m, rb)
+        # PED projection: 1x1 stride-2 shortcut on the (real-valued) membrane + SN -> conv3x3 s2 -> BN, summed in the epilogue
+        Bm, Dm, h, w, Cc = m.shape
+        res = F.conv2d(m.view(B * T, h, w, Cc).permute(0, 3, 1, 2), self.proj_res_w, None, 2)
+        res = res.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        s = self._neuron_bd(m, self.proj_sn)
+        return self._conv3x3(s, self.proj_w, self.proj_w.shape[1], stride=2, bn=self.proj_bn, resid=res)
 
     def attention(self, x, blk: _Block):
         """x (B,D,H,W,C) += SSA(x), in place (reference Spiking_swin_transformer3D.py:781-821, 661-717, :840)."""
@@ -221,46 +286,57 @@ class MSFlowEngine:
         return out
 
     def encoder(self, x):
-        """-> per-stage features (D,B,C,h,w) (reference :1223-1246 + Spiking_STSwinNet.py:77-85)."""
-        m = self.patch_embed(x)                                         # (T,B,C,h,w)
-        y = m.permute(1, 0, 3, 4, 2).contiguous()                       # (B,D,h,w,C)
+        """-> per-stage features, channel-last (B,D,h,w,C) (reference :1223-1246 + Spiking_STSwinNet.py:77-85)."""
+        y = self.patch_embed(x)
         feats = []
         for s, blocks in enumerate(self.stages):
             for i in range(len(blocks)):
                 y = self.swin_block(y, s, i)
-            feats.append(y.permute(1, 0, 4, 2, 3).contiguous())
             if s < len(self.merges):
+                feats.append(y.clone())                     # blocks update y in place; the skip needs this stage's value
                 y = self.patch_merge(y, s)
+            else:
+                feats.append(y)
         return feats
 
-    @staticmethod
-    def _skip_cat(x1, x2):
-        dY, dX = x2.shape[-2] - x1.shape[-2], x2.shape[-1] - x1.shape[-1]
-        if dY or dX:
-            x1 = F.pad(x1, (dX // 2, dX - dX // 2, dY // 2, dY - dY // 2))
-        return torch.cat([x1, x2], dim=2)
+    def _deconv_classes(self, i, B, D, h, w, cin_pad):
+        key = (i, B, D, h, w)
+        if key not in self._deconv:
+            self._deconv[key] = deconv_classes(self.decoders[i][0], B * D, h, w, cin_pad, self.nsplit, self.device)
+        return self._deconv[key]
 
     def unet_tail(self, feats):
-        """res-blocks + decoders + per-scale predictions (reference Spiking_STSwinNet.py:161-182)."""
-        T, B = feats[-1].shape[:2]
-        y = feats[-1].flatten(0, 1)
+        """res-blocks + decoders + per-scale predictions on channel-last (B,D,h,w,C) features
+        (reference Spiking_STSwinNet.py:161-182)."""
+        y = feats[-1]
         for rb in self.unet_res:
-            y = self._resblock(y, T, rb)
-        y = y.view(T, B, *y.shape[1:])
+            y = self._resblock(y, rb)
         preds, E = [], len(feats)
         for i in range(E):
-            y = self._skip_cat(y, feats[E - 1 - i])
-            if i > 0:
-                y = self._skip_cat(preds[-1], y)
-            w, bn, sn, k = self.decoders[i]
-            s = self._neuron_nchw(y.flatten(0, 1).contiguous(), T, sn)
-            z = F.conv_transpose2d(s, w, None, stride=2, padding=k // 2, output_padding=1)
-            z = hip.affine_resid(z, bn[0], bn[1], z.shape[1], z.shape[2] * z.shape[3])
+            skip = feats[E - 1 - i]
+            B, D, h, w, _ = skip.shape
+            parts = ([preds[-1]] if i > 0 else []) + [y, skip]          # skip_concat(pred, skip_concat(y, skip)) on channels
+            if any(p.shape[2:4] != (h, w) for p in parts):
+                parts = [F.pad(p, (0, 0, (w - p.shape[3]) // 2, w - p.shape[3] - (w - p.shape[3]) // 2,
+                                   (h - p.shape[2]) // 2, h - p.shape[2] - (h - p.shape[2]) // 2)) for p in parts]
+            cin = sum(p.shape[-1] for p in parts)
+            cp = _pad16(cin)
+            cat = torch.zeros((B, D, h, w, cp), dtype=torch.float32, device=y.device) if cp != cin else None
+            if cat is None:
+                cat = torch.cat(parts, dim=-1)
+            else:
+                torch.cat(parts, dim=-1, out=cat[..., :cin])
+            wdec, bn, sn = self.decoders[i]
+            s = self._neuron_bd(cat, sn)                                  # MS decoder: SN -> ConvT -> BN
+            cout = wdec.shape[1]
+            z = torch.empty((B, D, 2 * h, 2 * w, cout), dtype=torch.float32, device=y.device)
+            for cls in self._deconv_classes(i, B, D, h, w, cp):
+                hip.spike_conv2d(s, cls["Wp"], B * D, h, w, cp, h, w, cls["KH"], cls["KW"], 1, cls["dy"], cls["dx"], out=z,
+                                 alpha=bn[0], beta=bn[1], out_rowmap=cls["rowmap"])
             pw, pb, psn = self.preds[i]
-            sp = self._neuron_nchw(z, T, psn)
-            p = F.conv2d(sp, pw, pb)
-            y = z.view(T, B, *z.shape[1:])
-            preds.append(p.view(T, B, *p.shape[1:]))
+            sp = self._neuron_bd(z, psn, out_dtype=torch.float32)         # MS pred: SN -> conv1x1 (+bias), 2 outputs
+            preds.append(torch.addmm(pb, sp.view(-1, cout), pw).view(B, D, 2 * h, 2 * w, -1))
+            y = z
         return preds
 
     def forward(self, x):
@@ -272,6 +348,6 @@ class MSFlowEngine:
         preds = self.unet_tail(self.encoder(x))
         flows = []
         for p in preds:
-            f = p.sum(0)
+            f = p.sum(1).permute(0, 3, 1, 2)                              # sum over time, -> (B,2,h,w)
             flows.append(F.interpolate(f, scale_factor=(H / f.shape[-2], W / f.shape[-1])))
         return flows

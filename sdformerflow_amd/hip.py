@@ -19,7 +19,7 @@ SDF_LIF, SDF_PSN, SDF_IF = 0, 1, 2
 KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
 
 EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
-           "sdf_split_weight_bf16", "sdf_qk_gate_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd")
+           "sdf_split_weight_bf16", "sdf_qk_gate_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd")
 
 
 class SdfError(RuntimeError):
@@ -51,6 +51,12 @@ class SpikeGemmDesc(C.Structure):
                 ("psn_w", C.c_void_p), ("psn_b", C.c_void_p),
                 ("pos_count", C.c_int64), ("pos_inner", C.c_int64), ("pos_ostride", C.c_int64), ("t_stride", C.c_int64),
                 ("add", C.c_void_p), ("add_prows", C.c_int64), ("out_spike", C.c_void_p)]
+
+
+class SpikeConvDesc(C.Structure):
+    _fields_ = [("g", SpikeGemmDesc), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("OH", C.c_int32),
+                ("OW", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("sy", C.c_int32), ("sx", C.c_int32),
+                ("dy", C.c_int32 * 3), ("dx", C.c_int32 * 3)]
 
 
 class WinAttnDesc(C.Structure):
@@ -246,3 +252,40 @@ def win_attn_sew(q, k, v, scale, bias, mask, nH, Tq, B_, N1):
     d.scale, d.bias, d.mask = _ptr(scale, torch.float32), _ptr(bias, torch.float32), _ptr(mask, torch.float32)
     _check(lib().sdf_win_attn_fwd(C.byref(d), _stream()), "sdf_win_attn_fwd")
     return out
+
+
+def pack_conv_weight(w, nsplit=3, cin_pad=None):
+    """Conv2d weight (Cout, Cin, KH, KW) fp32 -> bf16 planes (nsplit, Cout, KH*KW*Cin_pad) in (ky, kx, cin) K order
+    (zero rows for padded input channels)."""
+    Cout, Cin, KH, KW = w.shape
+    cp = Cin if cin_pad is None else cin_pad
+    wk = torch.zeros((Cout, KH, KW, cp), dtype=torch.float32, device=w.device)
+    wk[..., :Cin] = w.detach().float().permute(0, 2, 3, 1)
+    return split_weight(wk.reshape(Cout, KH * KW * cp), nsplit)
+
+
+def spike_conv2d(x, Wp, imgs, H, W, Cin, OH, OW, KH, KW, stride, dy, dx, out=None, out_spike=None, alpha=None, beta=None,
+                 resid=None, out_rowmap=None, sn=None, sn_T=0, pos=None):
+    """sdf_spike_conv2d_fwd.  x: u8 spikes NHWC (imgs,H,W,Cin); Wp: planes (nsplit, Cout, KH*KW*Cin).
+    fp32 epilogue -> `out` (rows, Cout); fused neuron (sn, sn_T=10, pos=(count, inner, ostride, t_stride)) -> `out_spike`."""
+    d = SpikeConvDesc()
+    g = d.g
+    g.A, g.Wp = _ptr(x, torch.uint8), _ptr(Wp, torch.int16)
+    g.M, g.N, g.K = imgs * OH * OW, Wp.shape[1], KH * KW * Cin
+    g.lda, g.ldo, g.nsplit = 0, Wp.shape[1], Wp.shape[0]
+    g.alpha, g.beta = _ptr(alpha, torch.float32), _ptr(beta, torch.float32)
+    g.resid, g.out_rowmap = _ptr(resid, torch.float32), _ptr(out_rowmap, torch.int32)
+    if sn is not None:
+        g.out_spike = _ptr(out_spike, torch.uint8)
+        g.sn_T, g.sn_kind, g.tau, g.v_th = sn_T, KIND[sn.kind], sn.tau, sn.v_th
+        g.v_reset, g.soft_reset = (0.0 if sn.v_reset is None else float(sn.v_reset)), (1 if sn.v_reset is None else 0)
+        g.psn_w, g.psn_b = _ptr(sn.psn_w, torch.float32), _ptr(sn.psn_b, torch.float32)
+        g.pos_count, g.pos_inner, g.pos_ostride, g.t_stride = pos
+    else:
+        g.out = _ptr(out, torch.float32)
+    d.H, d.W, d.Cin, d.OH, d.OW, d.KH, d.KW, d.sy, d.sx = H, W, Cin, OH, OW, KH, KW, stride, stride
+    for i in range(3):
+        d.dy[i] = dy[i] if i < len(dy) else 0
+        d.dx[i] = dx[i] if i < len(dx) else 0
+    _check(lib().sdf_spike_conv2d_fwd(C.byref(d), _stream()), "sdf_spike_conv2d_fwd")
+    return out if sn is None else out_spike

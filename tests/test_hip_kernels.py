@@ -236,3 +236,57 @@ def test_spike_gemm_fused_neuron(kind, T, B, HW, K, N):
     rate = (got != ref).float().mean().item()
     assert rate <= 2e-4, rate
     assert 0.03 < ref.mean() < 0.97
+
+
+# ---------------------------------------------------------------- spike convolution (implicit GEMM)
+@pytest.mark.parametrize("imgs,H,W,Cin,Cout,stride", [(3, 20, 24, 48, 96, 2), (2, 18, 22, 96, 96, 1), (2, 9, 12, 192, 192, 1)])
+def test_spike_conv3x3_fp32_epilogue(imgs, H, W, Cin, Cout, stride):
+    """3x3 / pad 1 convolution on NHWC u8 spikes + BN + residual vs torch conv2d in fp64 (1e-5 relative)."""
+    x = spikes((imgs, H, W, Cin), 90 + Cin)
+    w = rnd((Cout, Cin, 3, 3), 91, -0.1, 0.1)
+    alpha, beta = rnd((Cout,), 92, 0.5, 1.5), rnd((Cout,), 93, -0.2, 0.2)
+    OH, OW = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    resid = rnd((imgs * OH * OW, Cout), 94)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, stride, 1).permute(0, 2, 3, 1)
+    ref = ref.reshape(-1, Cout) * alpha.double() + beta.double() + resid.double()
+    out = torch.empty((imgs * OH * OW, Cout), device=DEV)
+    hip.spike_conv2d(x.to(DEV), hip.pack_conv_weight(w.to(DEV), 3), imgs, H, W, Cin, OH, OW, 3, 3, stride, (-1, 0, 1), (-1, 0, 1),
+                     out=out, alpha=alpha.to(DEV), beta=beta.to(DEV), resid=resid.to(DEV))
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+def test_spike_conv3x3_fused_neuron():
+    """conv -> BN -> LIF over T=10 in one kernel (MS_ResBlock conv1 -> norm1 -> sn2, Spiking_modules.py:914-920)."""
+    T, B, H, W, Cc = 10, 2, 7, 9, 96
+    x = spikes((T * B, H, W, Cc), 95)
+    w = rnd((Cc, Cc, 3, 3), 96, -0.1, 0.1)
+    alpha, beta = rnd((Cc,), 97, 0.5, 1.5), rnd((Cc,), 98, -0.2, 0.2)
+    h = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 1, 1).permute(0, 2, 3, 1)
+    h = (h * alpha.double() + beta.double()).float().view(T, B * H * W * Cc)
+    ref = R.neuron_ref(h, "lif", 2.0, 0.1, None).view(T * B, H, W, Cc)
+    out = torch.zeros((T * B * H * W, Cc), dtype=torch.uint8, device=DEV)
+    n = B * H * W
+    hip.spike_conv2d(x.to(DEV), hip.pack_conv_weight(w.to(DEV), 3), T * B, H, W, Cc, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1),
+                     out_spike=out, alpha=alpha.to(DEV), beta=beta.to(DEV), sn=hip.NeuronParams("lif", 2.0, 0.1, None), sn_T=T,
+                     pos=(n, n, 0, n))
+    rate = (out.cpu().view(T * B, H, W, Cc).float() != ref).float().mean().item()
+    assert rate <= 2e-4, rate
+    assert 0.03 < ref.mean() < 0.97
+
+
+def test_spike_conv_transpose_parity_classes():
+    """ConvTranspose2d(k=3, s=2, p=1, output_padding=1) on spikes as four parity-class implicit GEMMs
+    (MS_SpikingTransposeDecoderLayer, Spiking_modules.py:416-446) vs torch conv_transpose2d in fp64."""
+    from sdformerflow_amd.engine import deconv_classes
+    imgs, H, W, Cin, Cout = 3, 9, 12, 200, 96               # Cin padded to 208 like the decoder concat buffers
+    cp = 208
+    x = torch.zeros((imgs, H, W, cp), dtype=torch.uint8)
+    x[..., :Cin] = spikes((imgs, H, W, Cin), 99)
+    w = rnd((Cin, Cout, 3, 3), 100, -0.1, 0.1)
+    ref = torch.nn.functional.conv_transpose2d(x[..., :Cin].permute(0, 3, 1, 2).double(), w.double(), None, 2, 1, 1)
+    ref = ref.permute(0, 2, 3, 1).reshape(-1, Cout)
+    out = torch.full((imgs * 2 * H * 2 * W, Cout), float("nan"), device=DEV)
+    for cls in deconv_classes(w.to(DEV), imgs, H, W, cp, 3, DEV):
+        hip.spike_conv2d(x.to(DEV), cls["Wp"], imgs, H, W, cp, H, W, cls["KH"], cls["KW"], 1, cls["dy"], cls["dx"], out=out,
+                         out_rowmap=cls["rowmap"])
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()

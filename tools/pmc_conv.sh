@@ -1,0 +1,21 @@
+#!/usr/bin/env bash
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+TAG=$1; shift
+python3 tools/conv_one.py "$@"
+for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_INSTS_SMEM" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" \
+           "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"; do
+  timeout 120 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_$TAG -- python3 tools/conv_one.py "$@" > /dev/null 2>&1
+done
+python3 - <<PY
+import csv, glob, collections
+acc = collections.defaultdict(list)
+for f in glob.glob("gpurun_out/pmc_$TAG/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "spike_gemm_kernel" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k in sorted(acc):
+    v = acc[k]
+    print(f"{k:28s} {sum(v)/len(v):16.0f}  (n={len(v)})")
+PY
