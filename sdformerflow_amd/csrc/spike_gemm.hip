@@ -23,42 +23,15 @@
 //           t = slot % T), i.e. the recurrence runs in registers straight out of the MFMA accumulators and the
 //           fp32 pre-activation never touches HBM.  Spikes are staged through LDS to leave as 16-byte stores.
 // Compiled with -ffp-contract=off: the neuron arithmetic is the same separately-rounded op sequence as neuron.hip.
-#include "common.h"
+#include "spike_mm.h"
 #include <stdlib.h>
 
 namespace {
+using namespace sdfmm;
 
 constexpr int KC = 96;
 constexpr int A_LD = KC + 8;          // bytes per A row in LDS (104 B = 26 dwords), written as 2 x 8 B
 constexpr int W_LD = KC + 8;          // bf16 elements per W row in LDS (208 B = 52 dwords)
-
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-// Implicit-GEMM convolution geometry (CONV kernels): A row g = (img, oy, ox) over an OH x OW output grid; K is
-// ordered (tap, channel) with taps on a KHc x KWc grid; tap (ky, kx) reads input pixel
-// (oy*sy + dy[ky], ox*sx + dx[kx]) of an NHWC u8 image, zero outside [0,H) x [0,W).
-struct ConvGeom {
-  int H, W, Cin, OH, OW, sy, sx, KWc, kw_mul;     // kw_mul: (tap * kw_mul) >> 5 == tap / KWc for tap < 9
-  int dy[3], dx[3];
-};
-
-struct GemmParams {
-  SdfSpikeGemmDesc d;
-  ConvGeom cv;
-  int tiles_m, tiles_n, ntiles;
-  float inv_tau;
-};
-
-// 8 spike bytes {0,1} -> 8 bf16 {0, 1.0}
-__device__ __forceinline__ bf16x8 expand_spikes(uint2 v) {
-  union { bf16x8 h; uint32_t u[4]; } r;
-  r.u[0] = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u) * 0x3F80u;   // (b0 | b1 << 16) * bf16(1.0)
-  r.u[1] = __builtin_amdgcn_perm(0u, v.x, 0x0c030c02u) * 0x3F80u;
-  r.u[2] = __builtin_amdgcn_perm(0u, v.y, 0x0c010c00u) * 0x3F80u;
-  r.u[3] = __builtin_amdgcn_perm(0u, v.y, 0x0c030c02u) * 0x3F80u;
-  return r.h;
-}
 
 // WAVES = 8 (512 threads): two waves per SIMD share one weight tile, so one wave's address / epilogue VALU work
 // overlaps the other's MFMAs.  WAVES = 4 (256 threads) with small tiles is for problems with few rows.
@@ -421,16 +394,9 @@ int launch(const GemmParams& P, dim3 grid, hipStream_t s) {
       return 0;                                                                                             \
     }                                                                                                       \
     return SDF_E_SHAPE;
-  if constexpr (CONV) {          // convolutions: fp32 epilogue, or the fused neuron over T = 10 steps
-    switch (P.d.sn_T) {
-      SDF_GEMM_T(0) SDF_GEMM_T(10)
-      default: return SDF_E_SHAPE;
-    }
-  } else {
-    switch (P.d.sn_T) {
-      SDF_GEMM_T(0) SDF_GEMM_T(2) SDF_GEMM_T(4) SDF_GEMM_T(5) SDF_GEMM_T(10) SDF_GEMM_T(20)
-      default: return SDF_E_SHAPE;
-    }
+  switch (P.d.sn_T) {
+    SDF_GEMM_T(0) SDF_GEMM_T(2) SDF_GEMM_T(4) SDF_GEMM_T(5) SDF_GEMM_T(10) SDF_GEMM_T(20)
+    default: return SDF_E_SHAPE;
   }
 #undef SDF_GEMM_T
 }
@@ -498,6 +464,17 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
     const int c = e[0] - '0';
     if (c >= 0 && c < 4 && ok(c)) cfg = c;
   }
+  // warp-specialised 256 x 96 kernel (spike_mm_ws.hip) for the shapes it is built for
+  {
+    const char* e = getenv("SDF_GEMM_WS");                   // tuning override: 0 = never, 1 = whenever legal
+    const bool legal = d->N % 96 == 0 && (d->sn_T == 0 || d->sn_T == 2 || d->sn_T == 10);
+    const int64_t ws_tiles = ((spike ? d->pos_count : d->M) + (spike ? 8 * (32 / d->sn_T) : 256) - 1) /
+                             (spike ? 8 * (32 / d->sn_T) : 256) * (d->N / 96);
+    bool use_ws = legal && ws_tiles >= 192 && d->K >= 192;
+    if (e && e[0] == '0') use_ws = false;
+    if (e && e[0] == '1') use_ws = legal;
+    if (use_ws) return launch_spike_mm_ws(P, false, sdf_stream(stream));
+  }
   if (!ok(cfg)) return SDF_E_SHAPE;
   const int nb = CFG_NB[cfg], rb = CFG_RB[cfg], waves = CFG_WAVES[cfg];
   const int npos = spike ? (16 * rb) / d->sn_T : 0;
@@ -551,19 +528,8 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
   cv.KWc = c->KW;
   cv.kw_mul = c->KW == 1 ? 32 : (c->KW == 2 ? 16 : 11);
   for (int i = 0; i < 3; ++i) { cv.dy[i] = c->dy[i]; cv.dx[i] = c->dx[i]; }
-  // one configuration: 256 x 96 tiles, 8 waves (K = taps*Cin >= 432: MFMA-dominated, weights streamed per stage)
-  const int waves = 8, rb = 1, nb = 3;
-  const int npos = spike ? (16 * rb) / d->sn_T : 0;
-  P.tiles_m = (int)(spike ? (d->pos_count + 2 * waves * npos - 1) / (2 * waves * npos) : (d->M + 32 * rb * waves - 1) / (32 * rb * waves));
-  P.tiles_n = d->N / (32 * nb);
-  P.ntiles = P.tiles_m * P.tiles_n;
-  const int G = P.ntiles < 256 ? P.ntiles : 256;
-  dim3 grid((unsigned)G);
-  hipStream_t s = sdf_stream(stream);
-  const int rc = d->nsplit == 1 ? launch<1, 3, 1, 8, true>(P, grid, s) : launch<3, 3, 1, 8, true>(P, grid, s);
-  if (rc) return rc;
-  SDF_LAUNCH_CHECK();
-  return 0;
+  // warp-specialised kernel: 256 x 96 tiles, producers do the im2col addressing (K = taps*Cin >= 432: MFMA-dominated)
+  return launch_spike_mm_ws(P, true, sdf_stream(stream));
 }
 
 extern "C" int sdf_split_weight_bf16(const float* W, uint16_t* planes, int64_t n, int nsplit, void* stream) {

@@ -4,7 +4,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sdformerflow_amd import hip
 dev = "cuda:0"
-CFGS = ("auto", "0", "1", "2", "3")   # tile configs (see sdf_spike_gemm_fwd); "auto" = library heuristic
+CFGS = ("ws", "1", "2", "3")   # tile configs (see sdf_spike_gemm_fwd); "auto" = library heuristic
 
 def timeit(fn, iters=20):
     for _ in range(3): fn()
@@ -21,6 +21,7 @@ def run(tag, M, N, K, T=0, HW=None):
     al, be = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev) * 0.1
     res = []
     for cfg in CFGS:
+        os.environ["SDF_GEMM_WS"] = "1" if cfg == "ws" else "0"
         os.environ["SDF_GEMM_CFG"] = cfg
         if T == 0:
             out = torch.empty((M, N), device=dev)
