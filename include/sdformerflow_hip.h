@@ -143,6 +143,10 @@ typedef struct SdfSpikeGemmDesc {
   const float* add;
   int64_t add_prows;
   uint8_t* out_spike;       /* (rows, N) u8 */
+  /* Optional scratch for split-K (small M, large K): caller-owned device memory; when it holds at least
+   * 2*M*N floats the library may run the product as K chunks + a deterministic k-ordered reduction. */
+  void* workspace;
+  int64_t workspace_bytes;
 } SdfSpikeGemmDesc;
 
 int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream);

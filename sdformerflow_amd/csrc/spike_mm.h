@@ -20,6 +20,8 @@ struct GemmParams {
   ConvGeom cv;
   int tiles_m, tiles_n, ntiles;
   float inv_tau;
+  int ksplit, spc;            // split-K (warp-specialised kernel): K chunks per tile, stages per chunk
+  float* partial;             // [ksplit][M][N] fp32 partial sums in the caller's workspace
 };
 
 // 8 spike bytes {0,1} -> 8 bf16 {0, 1.0}

@@ -83,11 +83,14 @@ __global__ __launch_bounds__(512) void spike_mm_ws_kernel(GemmParams P) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int K = d.K, N = d.N;
-  const int nstages = (K + KC - 1) / KC;
+  const int nstages = P.spc;                                     // stages per work item (= all of K unless split-K)
+  const int ksplit = P.ksplit;
 
-  // contiguous tile range of this workgroup (column-block-major tile order: t = cb * tiles_m + rt)
+  // contiguous range of work items of this workgroup; item = tile * ksplit + kchunk, tiles column-block-major
+  // (t = cb * tiles_m + rt).  Every item streams `spc` stages; stages past K load zeros.
   const int G = gridDim.x, wg = blockIdx.x;
-  const int base = P.ntiles / G, rem = P.ntiles % G;
+  const int nitems = P.ntiles * ksplit;
+  const int base = nitems / G, rem = nitems % G;
   const int t_begin = wg * base + (wg < rem ? wg : rem);
   const int n_my = base + (wg < rem ? 1 : 0);
   if (n_my == 0) return;
@@ -128,11 +131,12 @@ __global__ __launch_bounds__(512) void spike_mm_ws_kernel(GemmParams P) {
       w_lds[i] = A_BYTES + (row * W_LD + 8 * cc) * 2;
     }
     // stage iterator of the LOADER (no divisions in steady state)
-    int ld_st = 0, ld_cb = t_begin / P.tiles_m, ld_rt = t_begin - (t_begin / P.tiles_m) * P.tiles_m;
+    int ld_st = 0, ld_kc = t_begin % ksplit;
+    int ld_cb = (t_begin / ksplit) / P.tiles_m, ld_rt = (t_begin / ksplit) - ld_cb * P.tiles_m;
     bool ld_new = true;
     uint32_t a_valid = 0;                                        // CONV: bit tap = input pixel of that tap is inside the image
     auto load = [&]() {
-      const int k0 = ld_st * KC;
+      const int k0 = (ld_kc * nstages + ld_st) * KC;
       if (ld_new) {                                              // new tile: decode this lane's row once
         ld_new = false;
         const int64_t g = tile_row(ld_rt, ptid);
@@ -206,8 +210,11 @@ __global__ __launch_bounds__(512) void spike_mm_ws_kernel(GemmParams P) {
       }
       // advance
       if (++ld_st == nstages) {
-        ld_st = 0; ld_new = true;
-        if (++ld_rt == P.tiles_m) { ld_rt = 0; ++ld_cb; }
+        ld_st = 0;
+        if (++ld_kc == ksplit) {
+          ld_kc = 0; ld_new = true;
+          if (++ld_rt == P.tiles_m) { ld_rt = 0; ++ld_cb; }
+        }
       }
     };
     auto store = [&](int buf) {
@@ -290,7 +297,8 @@ __global__ __launch_bounds__(512) void spike_mm_ws_kernel(GemmParams P) {
 
     STAMP(c1);
     if (st == nstages - 1) {
-      const int t = t_begin + tl;
+      const int item = t_begin + tl;
+      const int t = item / ksplit, kc = item - t * ksplit;
       const int cb = t / P.tiles_m, rt = t - cb * P.tiles_m;
       const int n0 = cb * BN;
       if (!SPIKE) {
@@ -328,7 +336,23 @@ __global__ __launch_bounds__(512) void spike_mm_ws_kernel(GemmParams P) {
           o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
           return o;
         };
-        if (!has_map && !has_res) {
+        if (ksplit > 1) {
+          // split-K: raw fp32 partial sums; bias / BN / residual / scatter happen in splitk_reduce_kernel
+          float* pbase = P.partial + (int64_t)kc * d.M * N;
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              const int m = mrow0 + rb * 32 + 8 * q4;
+              float* op = pbase + (int64_t)m * N + n0 + 4 * qd;
+#pragma unroll
+              for (int nb = 0; nb < 3; ++nb) {
+                float v[4] = {acc[rb][nb][q4 * 4 + 0], acc[rb][nb][q4 * 4 + 1], acc[rb][nb][q4 * 4 + 2], acc[rb][nb][q4 * 4 + 3]};
+                quad_transpose(v, ql);
+                if (m < (int)d.M) *reinterpret_cast<float4*>(op + nb * 32) = make_float4(v[0], v[1], v[2], v[3]);
+              }
+            }
+        } else if (!has_map && !has_res) {
 #pragma unroll
           for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -473,6 +497,33 @@ __global__ __launch_bounds__(512) void spike_mm_ws_kernel(GemmParams P) {
 #endif
 }
 
+// Second pass of split-K: out = epilogue( sum_k partial[k] ), chunks added in k order (deterministic).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int ksplit, int64_t M, int N,
+                                                            const float* bias, const float* alpha, const float* beta,
+                                                            const float* resid, const int* rowmap, float* out, int64_t ldo) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int nq = N / 4;
+  if (q >= M * nq) return;
+  const int64_t m = q / nq;
+  const int n = (int)(q - m * nq) * 4;
+  float4 a = *reinterpret_cast<const float4*>(partial + m * N + n);
+  for (int k = 1; k < ksplit; ++k) {
+    const float4 b = *reinterpret_cast<const float4*>(partial + ((int64_t)k * M + m) * N + n);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + n); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+  if (alpha) {
+    const float4 al = *reinterpret_cast<const float4*>(alpha + n), be = *reinterpret_cast<const float4*>(beta + n);
+    a.x = __builtin_fmaf(a.x, al.x, be.x); a.y = __builtin_fmaf(a.y, al.y, be.y);
+    a.z = __builtin_fmaf(a.z, al.z, be.z); a.w = __builtin_fmaf(a.w, al.w, be.w);
+  }
+  int64_t dst = m;
+  if (rowmap) dst = rowmap[m];
+  if (dst < 0) return;
+  if (resid) { const float4 r = *reinterpret_cast<const float4*>(resid + dst * ldo + n); a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
+  *reinterpret_cast<float4*>(out + dst * ldo + n) = a;
+}
+
 template <int NSPLIT, bool CONV>
 int launch_t(const GemmParams& P, dim3 grid, hipStream_t s) {
   switch (P.d.sn_T) {
@@ -497,7 +548,25 @@ int launch_spike_mm_ws(const GemmParams& Pin, bool conv, hipStream_t s) {
   P.tiles_m = (int)(spike ? (d.pos_count + 8 * npos - 1) / (8 * npos) : (d.M + BM - 1) / BM);
   P.tiles_n = d.N / BN;
   P.ntiles = P.tiles_m * P.tiles_n;
-  const int G = P.ntiles < 256 ? P.ntiles : 256;
+  // split-K when the tiles alone cannot occupy the chip (small M, large K): needs the fp32 epilogue and a
+  // caller-provided workspace of ksplit*M*N floats; partial sums are combined in k order by a second kernel
+  const int S = (d.K + KC - 1) / KC;
+  P.ksplit = 1;
+  P.spc = S;
+  P.partial = nullptr;
+  if (!spike && P.ntiles <= 128 && S >= 4 && d.workspace) {
+    int ks = (256 + P.ntiles - 1) / P.ntiles;
+    if (ks > S / 2) ks = S / 2;
+    if (ks > 16) ks = 16;
+    while (ks > 1 && (int64_t)ks * d.M * d.N * 4 > d.workspace_bytes) --ks;
+    if (ks > 1 && sdf_aligned(d.workspace, 16)) {
+      P.ksplit = ks;
+      P.spc = (S + ks - 1) / ks;
+      P.partial = reinterpret_cast<float*>(d.workspace);
+    }
+  }
+  const int nitems = P.ntiles * P.ksplit;
+  const int G = nitems < 256 ? nitems : 256;
   dim3 grid((unsigned)G);
   int rc;
   if (conv)
@@ -506,7 +575,15 @@ int launch_spike_mm_ws(const GemmParams& Pin, bool conv, hipStream_t s) {
     rc = d.nsplit == 1 ? launch_t<1, false>(P, grid, s) : launch_t<3, false>(P, grid, s);
   if (rc) return rc;
   hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : (int)e;
+  if (e != hipSuccess) return (int)e;
+  if (P.ksplit > 1) {
+    const int64_t quads = d.M * (d.N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, P.partial, P.ksplit, d.M,
+                       d.N, d.bias, d.alpha, d.beta, d.resid, d.out_rowmap, d.out, d.ldo);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
 }
 
 }  // namespace sdfmm

@@ -200,11 +200,12 @@ class MSFlowEngine:
     def _resblock(self, m, rb):
         """MS_ResBlock on a (B,D,h,w,C) membrane: SN -> conv+BN+SN (one kernel) -> conv+BN+identity (one kernel)
         (reference Spiking_modules.py:906-933)."""
-        D = m.shape[1]
+        B, D, h, w, _ = m.shape
         s1 = self._neuron_bd(m, rb.sn1)
-        if D == 10:
+        tiles = (B * D * h * w + 255) // 256 * (rb.C // 96)
+        if D == 10 and tiles >= 128:
             s2 = self._conv3x3(s1, rb.w1, rb.C, bn=rb.bn1, sn=rb.sn2)
-        else:                                            # fused neuron epilogue is built for T = 10
+        else:       # few rows (U-Net bottleneck): the fp32 epilogue can split K over the chip; neuron as its own launch
             s2 = self._neuron_bd(self._conv3x3(s1, rb.w1, rb.C), rb.sn2, bn=rb.bn1)
         return self._conv3x3(s2, rb.w2, rb.C, bn=rb.bn2, resid=m)
 

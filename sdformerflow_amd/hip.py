@@ -50,7 +50,8 @@ class SpikeGemmDesc(C.Structure):
                 ("tau", C.c_float), ("v_th", C.c_float), ("v_reset", C.c_float), ("soft_reset", C.c_int32),
                 ("psn_w", C.c_void_p), ("psn_b", C.c_void_p),
                 ("pos_count", C.c_int64), ("pos_inner", C.c_int64), ("pos_ostride", C.c_int64), ("t_stride", C.c_int64),
-                ("add", C.c_void_p), ("add_prows", C.c_int64), ("out_spike", C.c_void_p)]
+                ("add", C.c_void_p), ("add_prows", C.c_int64), ("out_spike", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
 class SpikeConvDesc(C.Structure):
@@ -101,6 +102,22 @@ def _ptr(t, dtype=None):
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_WS = {}
+
+
+def workspace(device, nbytes=96 << 20):
+    """One caller-owned scratch buffer per device for the split-K path of the spike matmul / conv kernels."""
+    key = str(device)
+    if key not in _WS or _WS[key].numel() < nbytes:
+        _WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return _WS[key]
+
+
+def _set_ws(g, like):
+    ws = workspace(like.device)
+    g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
 
 
 class NeuronParams:
@@ -183,6 +200,7 @@ def spike_gemm(A, Wp, out, M, N, K, lda=None, ldo=None, bias=None, alpha=None, b
     d.resid, d.out_rowmap = _ptr(resid, torch.float32), _ptr(out_rowmap, torch.int32)
     if zg is not None:
         d.zg_nH, d.zg_T, d.zg_B, d.zg_N1 = zg
+    _set_ws(d, A)
     _check(lib().sdf_spike_gemm_fwd(C.byref(d), _stream()), "sdf_spike_gemm_fwd")
     return out
 
@@ -283,6 +301,7 @@ def spike_conv2d(x, Wp, imgs, H, W, Cin, OH, OW, KH, KW, stride, dy, dx, out=Non
         g.pos_count, g.pos_inner, g.pos_ostride, g.t_stride = pos
     else:
         g.out = _ptr(out, torch.float32)
+        _set_ws(g, x)
     d.H, d.W, d.Cin, d.OH, d.OW, d.KH, d.KW, d.sy, d.sx = H, W, Cin, OH, OW, KH, KW, stride, stride
     for i in range(3):
         d.dy[i] = dy[i] if i < len(dy) else 0

@@ -290,3 +290,24 @@ def test_spike_conv_transpose_parity_classes():
         hip.spike_conv2d(x.to(DEV), cls["Wp"], imgs, H, W, cp, H, W, cls["KH"], cls["KW"], 1, cls["dy"], cls["dx"], out=out,
                          out_rowmap=cls["rowmap"])
     assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+def test_spike_conv_small_m_split_k():
+    """Small-M / large-K convolution (U-Net res-block shape: 10 x 9 x 12 pixels, 768 -> 768 channels): the library
+    splits K over workgroups and reduces the partial sums in k order; same 1e-5 bound, and bit-identical run to run."""
+    imgs, H, W, Cc = 10, 9, 12, 768
+    x = spikes((imgs, H, W, Cc), 110)
+    w = rnd((Cc, Cc, 3, 3), 111, -0.05, 0.05)
+    alpha, beta = rnd((Cc,), 112, 0.5, 1.5), rnd((Cc,), 113, -0.2, 0.2)
+    resid = rnd((imgs * H * W, Cc), 114)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 1, 1).permute(0, 2, 3, 1)
+    ref = ref.reshape(-1, Cc) * alpha.double() + beta.double() + resid.double()
+    Wp = hip.pack_conv_weight(w.to(DEV), 3)
+    outs = []
+    for _ in range(2):
+        out = torch.empty((imgs * H * W, Cc), device=DEV)
+        hip.spike_conv2d(x.to(DEV), Wp, imgs, H, W, Cc, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=out, alpha=alpha.to(DEV),
+                         beta=beta.to(DEV), resid=resid.to(DEV))
+        outs.append(out.cpu())
+    assert (outs[0].double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    assert torch.equal(outs[0], outs[1])
