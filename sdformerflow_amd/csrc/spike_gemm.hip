@@ -244,60 +244,83 @@ __global__ __launch_bounds__(64 * WAVES) void spike_gemm_kernel(GemmParams P) {
     if (st == nstages - 1) {
       const int n0 = cb * BN;
       if (!SPIKE) {
-        // ---- fp32 epilogue: one base pointer per (column block, row block), wave-uniform row strides ----
-        const int mrow0 = rt * BM + wave * WR + 4 * lh;            // first row this lane holds (M < 2^31)
+        // ---- fp32 epilogue ----
+        // Quad transpose -> each lane owns 4 consecutive columns of one row -> 16-byte loads / stores.  Two wave-uniform
+        // paths (vmcnt counts loads AND stores in order on CDNA4): without row map / residual there is no load at all
+        // and the stores stream; otherwise every row-map / residual load of a row block is issued before its first
+        // store.  Parameter loads are pinned in straight-line code; no per-lane "load or constant" selects.
+        const int qd = l31 >> 2, ql = l31 & 3;
+        const int mrow0 = rt * BM + wave * WR + 4 * lh + ql;       // + rb*32 + 8*q4
+        const bool has_map = d.out_rowmap != nullptr, has_res = d.resid != nullptr;
+        float4 bs[NB], al[NB], be[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          const int n = n0 + nb * 32 + l31;
-          if (n < N) {
-            const float bs = d.bias ? d.bias[n] : 0.f;
-            const float al = d.alpha ? d.alpha[n] : 1.f;
-            const float be = d.alpha ? d.beta[n] : 0.f;
+          const int n = n0 + nb * 32 + 4 * qd;                       // N % 32 == 0: a column block is whole or absent
+          const int nc = n < N ? n : 0;
+          bs[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
+          al[nb] = make_float4(1.f, 1.f, 1.f, 1.f);
+          be[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (d.bias) bs[nb] = *reinterpret_cast<const float4*>(d.bias + nc);
+          if (d.alpha) { al[nb] = *reinterpret_cast<const float4*>(d.alpha + nc); be[nb] = *reinterpret_cast<const float4*>(d.beta + nc); }
+        }
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-              const int mrow = mrow0 + rb * 32;
-              const int left = (int)d.M - mrow;                    // rows (8*q4 + j) < left are inside the matrix
-              if (!d.out_rowmap) {
-                float* op = d.out + (int64_t)mrow * d.ldo + n;
-                const float* rp = d.resid ? d.resid + (int64_t)mrow * d.ldo + n : nullptr;
+        for (int nb = 0; nb < NB; ++nb)
+          asm volatile("" :: "v"(bs[nb].x), "v"(bs[nb].w), "v"(al[nb].x), "v"(al[nb].w), "v"(be[nb].x), "v"(be[nb].w));
+        auto finish = [&](int nb, int rb, int q4, float4 r) -> float4 {
+          float v[4] = {acc[rb][nb][q4 * 4 + 0], acc[rb][nb][q4 * 4 + 1], acc[rb][nb][q4 * 4 + 2], acc[rb][nb][q4 * 4 + 3]};
+          quad_transpose(v, ql);
+          float4 o = make_float4(v[0], v[1], v[2], v[3]);
+          o.x += bs[nb].x; o.y += bs[nb].y; o.z += bs[nb].z; o.w += bs[nb].w;
+          o.x = __builtin_fmaf(o.x, al[nb].x, be[nb].x); o.y = __builtin_fmaf(o.y, al[nb].y, be[nb].y);
+          o.z = __builtin_fmaf(o.z, al[nb].z, be[nb].z); o.w = __builtin_fmaf(o.w, al[nb].w, be[nb].w);
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+          return o;
+        };
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                  float rs[4] = {0.f, 0.f, 0.f, 0.f};
-                  if (rp) {
+        for (int rb = 0; rb < RB; ++rb) {
+          int dst[4];
+          unsigned okm = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                      if (8 * q4 + j < left) rs[j] = rp[(int64_t)(8 * q4 + j) * d.ldo];
-                  }
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int m = mrow0 + rb * 32 + 8 * q4;
+            const bool in = m < (int)d.M;
+            dst[q4] = in ? m : 0;
+            if (in) okm |= 1u << q4;
+          }
+          if (has_map) {
 #pragma unroll
-                  for (int j = 0; j < 4; ++j) {
-                    float v = acc[rb][nb][q4 * 4 + j];
-                    if (d.bias) v = v + bs;
-                    if (d.alpha) v = __builtin_fmaf(v, al, be);
-                    v = v + rs[j];
-                    if (8 * q4 + j < left) op[(int64_t)(8 * q4 + j) * d.ldo] = v;
-                  }
-                }
-              } else {
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {                   // 4 consecutive rows per group: batch the loads
-                  int dst[4];
-                  float rs[4];
-#pragma unroll
-                  for (int j = 0; j < 4; ++j) dst[j] = (8 * q4 + j < left) ? d.out_rowmap[mrow + 8 * q4 + j] : -1;
-#pragma unroll
-                  for (int j = 0; j < 4; ++j) rs[j] = (d.resid && dst[j] >= 0) ? d.resid[(int64_t)dst[j] * d.ldo + n] : 0.f;
-#pragma unroll
-                  for (int j = 0; j < 4; ++j) {
-                    float v = acc[rb][nb][q4 * 4 + j];
-                    if (d.bias) v = v + bs;
-                    if (d.alpha) v = __builtin_fmaf(v, al, be);
-                    v = v + rs[j];
-                    if (dst[j] >= 0) d.out[(int64_t)dst[j] * d.ldo + n] = v;
-                  }
-                }
-              }
+            for (int q4 = 0; q4 < 4; ++q4) {
+              const int r = d.out_rowmap[dst[q4]];
+              if (r < 0) okm &= ~(1u << q4);
+              dst[q4] = r >= 0 ? r : 0;
             }
           }
+          float4 rs[4][NB];
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) rs[q4][nb] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (has_res) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb) {
+                const int n = n0 + nb * 32 + 4 * qd;
+                rs[q4][nb] = *reinterpret_cast<const float4*>(d.resid + (int64_t)dst[q4] * d.ldo + (n < N ? n : 0));
+              }
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb) asm volatile("" :: "v"(rs[q4][nb].x), "v"(rs[q4][nb].w));
+          }
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+              const int n = n0 + nb * 32 + 4 * qd;
+              const float4 o = finish(nb, rb, q4, rs[q4][nb]);
+              if (((okm >> q4) & 1u) && n < N) *reinterpret_cast<float4*>(d.out + (int64_t)dst[q4] * d.ldo + n) = o;
+            }
         }
       } else {
         // ---- spike epilogue: BN (+add) -> neuron over T -> bytes, staged through LDS ----
@@ -313,16 +336,17 @@ __global__ __launch_bounds__(64 * WAVES) void spike_gemm_kernel(GemmParams P) {
 #pragma unroll
           for (int pl = 0; pl < NPOS; ++pl) {
             const int64_t pos = pos0 + pl;
-            const bool live = ncol && pos < d.pos_count;
-            const float* addp = (d.add && live) ? d.add + ((uint32_t)pos % (uint32_t)d.add_prows) * (int64_t)N + n : nullptr;
             float xs[T], sp[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
               const int slot = pl * T + t;                   // compile-time after unrolling
-              float x = acc[slot >> 4][nb][slot & 15];
-              if (d.alpha) x = __builtin_fmaf(x, al, be);
-              if (addp) x = x + addp[(int64_t)t * d.add_prows * N];
-              xs[t] = x;
+              xs[t] = __builtin_fmaf(acc[slot >> 4][nb][slot & 15], al, be);      // al = 1, be = 0 without BN
+            }
+            if (d.add) {                                     // wave-uniform; loads unconditional (clamped position / column)
+              const int64_t pc = pos < d.pos_count ? pos : 0;
+              const float* addp = d.add + ((uint32_t)pc % (uint32_t)d.add_prows) * (int64_t)N + (ncol ? n : 0);
+#pragma unroll
+              for (int t = 0; t < T; ++t) xs[t] = xs[t] + addp[(int64_t)t * d.add_prows * N];
             }
             if (d.sn_kind == SDF_PSN) {
 #pragma unroll
@@ -442,6 +466,9 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
     if ((int64_t)d->zg_T * d->zg_B * d->zg_N1 != d->M) return SDF_E_SHAPE;
   }
   if (!sdf_aligned(d->A, 16) || !sdf_aligned(d->Wp, 16)) return SDF_E_ALIGN;
+  if (!spike && (d->ldo % 4 || !sdf_aligned(d->out, 16) || (d->resid && !sdf_aligned(d->resid, 16)) ||
+                 (d->bias && !sdf_aligned(d->bias, 16)) || (d->alpha && (!sdf_aligned(d->alpha, 16) || !sdf_aligned(d->beta, 16)))))
+    return SDF_E_ALIGN;                                          // the fp32 epilogue moves 16 bytes per lane
 
   // ---- tile configuration ----
   // cfg 0: 512x96 (8 waves, 2 row blocks)   cfg 1: 256x96 (8 waves)   cfg 2: 256x32 (4 waves)   cfg 3: 128x32 (4 waves)
@@ -458,7 +485,7 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
   // (most waves in flight) wins for the fp32 and T' = 2 epilogues; the T >= 5 neuron epilogue needs the 96-wide
   // 8-wave tile to amortise its staging.  (ntiles_for() is kept for the tuning override.)
   (void)ntiles_for;
-  int cfg = (spike && d->sn_T >= 5) ? (ok(1) ? 1 : 2) : 3;
+  int cfg = (spike && d->sn_T >= 5) ? (ok(1) ? 1 : 2) : ((!spike && d->M >= 16384) ? 2 : 3);
   if (!ok(cfg)) cfg = ok(2) ? 2 : 0;
   if (const char* e = getenv("SDF_GEMM_CFG")) {                  // tuning override: 0..3
     const int c = e[0] - '0';
@@ -470,7 +497,8 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
     const bool legal = d->N % 96 == 0 && (d->sn_T == 0 || d->sn_T == 2 || d->sn_T == 10);
     const int64_t ws_tiles = ((spike ? d->pos_count : d->M) + (spike ? 8 * (32 / d->sn_T) : 256) - 1) /
                              (spike ? 8 * (32 / d->sn_T) : 256) * (d->N / 96);
-    bool use_ws = legal && ws_tiles >= 192 && d->K >= 192;
+    bool use_ws = false;          // measured: the small-tile kernels win on every Linear of the model (K <= 3072, epilogue-bound)
+    (void)ws_tiles;
     if (e && e[0] == '0') use_ws = false;
     if (e && e[0] == '1') use_ws = legal;
     if (use_ws) return launch_spike_mm_ws(P, false, sdf_stream(stream));

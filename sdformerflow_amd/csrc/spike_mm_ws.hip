@@ -47,26 +47,6 @@ constexpr int A_LD = KC + 8;                 // bytes per A row   (72 B  = 18 dw
 constexpr int W_LD = KC + 8;                 // bf16 per W row    (144 B = 36 dwords)
 constexpr int A_BYTES = BM * A_LD;           // 18432
 
-// 4x4 transpose inside every quad of lanes (two DPP butterflies): in: lane q holds v[j] = X[row j][col q];
-// out: lane q holds v[k] = X[row q][col k], i.e. 16 contiguous bytes of one output row.
-__device__ __forceinline__ void quad_transpose(float (&v)[4], int q) {
-  const bool o1 = q & 1, o2 = q & 2;
-  // butterfly 1: lanes q <-> q^1 on (v0,v1) and (v2,v3)
-  {
-    const float s0 = o1 ? v[0] : v[1], s1 = o1 ? v[2] : v[3];
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, false));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, false));
-    if (o1) { v[0] = r0; v[2] = r1; } else { v[1] = r0; v[3] = r1; }
-  }
-  // butterfly 2: lanes q <-> q^2 on the pairs
-  {
-    const float s0 = o2 ? v[0] : v[2], s1 = o2 ? v[1] : v[3];
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0x4E, 0xF, 0xF, false));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0x4E, 0xF, 0xF, false));
-    if (o2) { v[0] = r0; v[1] = r1; } else { v[2] = r0; v[3] = r1; }
-  }
-}
-
 template <int NSPLIT, int TT, bool CONV>
 __global__ __launch_bounds__(512) void spike_mm_ws_kernel(GemmParams P) {
   constexpr bool SPIKE = TT > 0;
