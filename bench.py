@@ -49,42 +49,52 @@ def synthetic_chunk():
 
 
 def time_dominant_kernels(model, iters=20):
-    """Live HIP-event timing (on the launch stream = torch's current stream) of the two kernel families
-    that carry the block: the stage-0 fc1 spike GEMM (MFMA-bound) and the T=10 neuron update (HBM-bound)."""
+    """Live HIP-event timing (on the launch stream = torch's current stream, the one passed through the C ABI) of the
+    dominant kernel of the forward - the warp-specialised spike convolution on the patch-embedding res-block shape
+    (10 images of 144x192, 96 -> 96 channels, 3x3: 4 of the 26 convolution launches and ~0.8 ms of the step) - and of
+    the HBM-bound neuron update."""
     from sdformerflow_amd import hip
     eng = model.engine()
     dev = eng.device
-    blk = eng.stages[0][0]
-    M, K, N = 10 * 72 * 96, blk.fc1.K, blk.fc1.N
-    A = (torch.rand((M, K), device=dev) < 0.3).to(torch.uint8)
-    out = torch.empty((M, N), device=dev)
+    imgs, H, W, Cc = 10, 144, 192, 96
+    rb = eng.pe_res[0]
+    x = (torch.rand((imgs, H, W, Cc), device=dev) < 0.3).to(torch.uint8)
+    out = torch.empty((imgs * H * W, Cc), device=dev)
+    resid = torch.rand((imgs * H * W, Cc), device=dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def conv():
+        hip.spike_conv2d(x, rb.w2, imgs, H, W, Cc, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=out, alpha=rb.bn2[0],
+                         beta=rb.bn2[1], resid=resid)
     for _ in range(3):
-        hip.spike_gemm(A, blk.fc1.Wp, out, M, N, K, alpha=blk.fc1.alpha, beta=blk.fc1.beta)
+        conv()
     e0.record()
     for _ in range(iters):
-        hip.spike_gemm(A, blk.fc1.Wp, out, M, N, K, alpha=blk.fc1.alpha, beta=blk.fc1.beta)
+        conv()
     e1.record()
     torch.cuda.synchronize()
-    t_gemm = e0.elapsed_time(e1) / iters * 1e-3
-    gemm = {"kernel": "spike_gemm_kernel<3> (stage0 fc1: M=69120 N=384 K=96)", "bound": "mfma",
-            "achieved": 2.0 * M * N * K / t_gemm / 1e12, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-            "us_per_launch": t_gemm * 1e6, "traffic": None}
+    t_conv = e0.elapsed_time(e1) / iters * 1e-3
+    flops = 2.0 * imgs * H * W * Cc * 9 * Cc                    # algorithmic: one multiply-add per (pixel, cout, tap, cin)
+    gemm = {"kernel": "sdfmm::spike_mm_ws_kernel<3,0,true> (3x3 spike conv 96->96 @ 10x144x192, BN + residual epilogue)",
+            "bound": "mfma", "achieved": flops / t_conv / 1e12, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+            "us_per_launch": t_conv * 1e6, "traffic": None,
+            "note": "algorithmic flops; the kernel issues 3 bf16 MFMAs per product (fp32-grade weights), i.e. 3x this on the matrix pipe"}
     gemm["frac"] = gemm["achieved"] / gemm["peak"]
-    # neuron: T=10 over the stage-0 MLP hidden tensor (10 x 72*96*384 fp32 in, u8 out)
+    # neuron: T=10 over the stage-0 MLP hidden tensor shape (10 x 72*96*384 fp32 in, u8 out)
+    blk = eng.stages[0][0]
     n = 72 * 96 * 384
-    x = torch.rand((10, n), device=dev) - 0.3
+    xx = torch.rand((10, n), device=dev) - 0.3
     s = torch.empty((10, n), dtype=torch.uint8, device=dev)
     p = blk.sn2
     for _ in range(3):
-        hip.neuron_fwd(x, s, 10, 1, n, 0, n, 0, n, p)
+        hip.neuron_fwd(xx, s, 10, 1, n, 0, n, 0, n, p)
     e0.record()
     for _ in range(iters):
-        hip.neuron_fwd(x, s, 10, 1, n, 0, n, 0, n, p)
+        hip.neuron_fwd(xx, s, 10, 1, n, 0, n, 0, n, p)
     e1.record()
     torch.cuda.synchronize()
     t_n = e0.elapsed_time(e1) / iters * 1e-3
-    neuron = {"kernel": "neuron_kernel<10> (stage0 MLP hidden: 26.5 M neurons x T=10, f32 in / u8 out)", "bound": "hbm",
+    neuron = {"kernel": "neuron_kernel<10> (26.5 M neurons x T=10, f32 in / u8 out)", "bound": "hbm",
               "achieved": 10.0 * n * 5 / t_n / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "us_per_launch": t_n * 1e6,
               "traffic": None}
     neuron["frac"] = neuron["achieved"] / neuron["peak"]
@@ -172,9 +182,9 @@ def main():
             "metric": "event-frames/sec fwd (1x10x2x288x384)", "value": n_gpus * args.steps / dt, "unit": "samples/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: MS_SpikingformerFlowNet_en4 forward, batch 1 per GPU, 10-bin "
-                                   "288x384 voxel, neuron=" + args.neuron + ", spike GEMMs on bf16 MFMA with 3-plane "
-                                   "(fp32-grade) weights, convolutions fp32 via MIOpen, replicas per GPU"},
+            "config": {"workload": "BASELINE configs[1]: MS_SpikingformerFlowNet_en4 forward, batch 1 per GPU, 10-bin 288x384 "
+                                   "voxel, neuron=" + args.neuron + "; spike GEMMs and spike convolutions on bf16 MFMA with "
+                                   "3-plane (fp32-grade) weights and fp32 accumulate; replicas per GPU"},
             "roofline": gemm, "roofline_neuron": neuron,
             "attention_gemm_roofline_frac": 183.7e9 / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12),
         }
