@@ -23,16 +23,19 @@ DEV = "cuda:0"
 CFG = os.path.join(os.path.dirname(__file__), "..", "sdformerflow_amd", "configs", "train_DSEC_supervised_SDformerFlow_en4.yml")
 
 
-def build(kind, H=288, W=384):
+def build(kind, H=288, W=384, cls=MS_SpikingformerFlowNet_en4, T=10):
     cfg = yaml.safe_load(open(CFG))
-    cfg["model"]["spiking_neuron"] = dict(cfg["spiking_neuron"], neuron_type=kind)
+    cfg["model"]["spiking_neuron"] = dict(cfg["spiking_neuron"], neuron_type=kind, num_steps=T)
+    cfg["model"]["num_bins"] = T
     cfg["swin_transformer"]["input_size"] = [H, W]
-    model = MS_SpikingformerFlowNet_en4(cfg["model"].copy(), cfg["swin_transformer"].copy())
+    if cls.num_en == 3:
+        cfg["swin_transformer"].update(swin_depths=[2, 2, 6], swin_num_heads=[3, 6, 12], swin_out_indices=[0, 1, 2])
+    model = cls(cfg["model"].copy(), cfg["swin_transformer"].copy())
     sd = synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
     model.load_state_dict(sd, strict=True)
     model.eval()
-    ocfg = {"neuron": O.NeuronCfg(kind, 0.1, None, 2.0, 10), "num_bins": 10, "window_size": (2, 9, 9),
-            "depths": [2, 2, 6, 2], "num_heads": [3, 6, 12, 24]}
+    ocfg = {"neuron": O.NeuronCfg(kind, 0.1, None, 2.0, T), "num_bins": T, "window_size": (2, 9, 9),
+            "depths": [2, 2, 6, 2][:cls.num_en], "num_heads": [3, 6, 12, 24][:cls.num_en]}
     return model, sd, ocfg
 
 
@@ -175,3 +178,64 @@ def test_sew_window_attention_module_matches_reference_fixture(kind):
     assert (y.cpu().numpy().astype(np.uint8) != ref).mean() < 5e-4   # threshold-rounding flips only
     y2, _ = m(x, None)
     assert (y2.cpu().numpy().astype(np.uint8) != g[f"{kind}_y_nomask"]).mean() < 5e-4
+
+
+def test_batch2_three_encoder_model_teacher_forced():
+    """B = 2 (the reference couples batch elements through its raw reshapes) on the 3-encoder
+    MS_SpikingformerFlowNet at 144x192: every stage must reproduce the oracle *at that batch size*."""
+    from sdformerflow_amd.STSwinNet_SNN.Spiking_STSwinNet import MS_SpikingformerFlowNet
+    model, sd, ocfg = build("lif", 144, 192, MS_SpikingformerFlowNet)
+    n = ocfg["neuron"]
+    chunk = O.prepare_chunk(synth_voxel(2, 10, 144, 192, seed=77))
+    p = "sttmultires_unet.encoders.swin3d."
+    eng = model.to(DEV).engine()
+    report = []
+    with torch.no_grad():
+        ref = O.patch_embed(chunk, sd, p + "patch_embed.", n, 10)
+        compare("patch_embed", eng.patch_embed(chunk.to(DEV)), ref.permute(1, 0, 3, 4, 2), report, 2e-2)
+        y = ref.permute(1, 0, 3, 4, 2).contiguous()
+        feats = []
+        for s_, (depth, nH) in enumerate(zip(ocfg["depths"], ocfg["num_heads"])):
+            for i in range(depth):
+                ref = O.ms_block(y, sd, p + f"layers.{s_}.swin_blocks.{i}.", nH, (2, 9, 9), (0, 0, 0) if i % 2 == 0 else (1, 4, 4), n)
+                compare(f"stage{s_}.block{i}", eng.swin_block(y.clone().to(DEV), s_, i), ref, report, 5e-3)
+                y = ref
+            feats.append(y.contiguous())
+            if s_ < 2:
+                ref = O.ms_patch_merge(y, sd, p + f"layers.{s_}.downsample.", n)
+                compare(f"stage{s_}.merge", eng.patch_merge(y.to(DEV), s_), ref, report, 1e-3)
+                y = ref
+        preds = eng.unet_tail([f.to(DEV) for f in feats])
+        ref_preds = unet_tail_oracle([f.permute(1, 0, 4, 2, 3).contiguous() for f in feats], sd, n)
+        for i, (gp, rp) in enumerate(zip(preds, ref_preds)):
+            compare(f"unet.pred{i}", gp.permute(1, 0, 4, 2, 3), rp, report, 1e-1)
+        # and the two samples really are coupled: sample 0 of the batch differs from sample 0 run alone
+        alone = O.forward_flownet(chunk[:1], sd, ocfg)[-1]
+        both = O.forward_flownet(chunk, sd, ocfg)[-1][:1]
+        assert (alone - both).abs().max() > 1e-3
+    for name, rate, close in report:
+        print(f"B=2 {name:16s} mismatch-rate {rate:.2e}  max-rel-dev-of-rest {close:.1e}")
+    out = model(chunk.to(DEV))
+    assert len(out["flow"]) == 3 and out["flow"][-1].shape == (2, 2, 144, 192)
+
+
+def test_long_T20_stage_parity():
+    """BASELINE configs[4] flavour: 20 bins / T = 20 (long LIF scan, T = 20 GEMM epilogue, unfused conv path)."""
+    model, sd, ocfg = build("lif", 144, 192, T=20)
+    n = ocfg["neuron"]
+    chunk = O.prepare_chunk(synth_voxel(1, 20, 144, 192, seed=78))
+    p = "sttmultires_unet.encoders.swin3d."
+    eng = model.to(DEV).engine()
+    report = []
+    with torch.no_grad():
+        ref = O.patch_embed(chunk, sd, p + "patch_embed.", n, 20)
+        compare("patch_embed", eng.patch_embed(chunk.to(DEV)), ref.permute(1, 0, 3, 4, 2), report, 2e-2)
+        y = ref.permute(1, 0, 3, 4, 2).contiguous()
+        for i in range(2):
+            r = O.ms_block(y, sd, p + f"layers.0.swin_blocks.{i}.", 3, (2, 9, 9), (0, 0, 0) if i % 2 == 0 else (1, 4, 4), n)
+            compare(f"stage0.block{i}", eng.swin_block(y.clone().to(DEV), 0, i), r, report, 5e-3)
+            y = r
+        r = O.ms_patch_merge(y, sd, p + "layers.0.downsample.", n)
+        compare("stage0.merge", eng.patch_merge(y.to(DEV), 0), r, report, 1e-3)
+    for name, rate, close in report:
+        print(f"T=20 {name:16s} mismatch-rate {rate:.2e}  max-rel-dev-of-rest {close:.1e}")
