@@ -172,8 +172,16 @@ class MSFlowEngine:
             self._maps[key] = (torch.from_numpy(src.reshape(-1)).to(self.device), H2, W2, out_map)
         return self._maps[key]
 
+    @staticmethod
+    def _check_cl(x):
+        """The kernels address activations as dense channel-last (B,D,h,w,C) fp32 buffers (and update them in place)."""
+        if x.dim() != 5 or not x.is_contiguous() or x.dtype != torch.float32:
+            raise hip.SdfError(f"expected a contiguous fp32 (B,D,h,w,C) tensor, got shape {tuple(x.shape)} strides {x.stride()} "
+                               f"{x.dtype}; call .contiguous() (the update is in place)")
+
     def _neuron_bd(self, x, p, bn=None, out_dtype=torch.uint8):
         """Neuron over D of a channel-last (B,D,h,w,C) activation, BN fused when given."""
+        self._check_cl(x)
         B, D, h, w, Cc = x.shape
         out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
         a, b = bn if bn is not None else (None, None)
@@ -235,6 +243,7 @@ class MSFlowEngine:
 
     def attention(self, x, blk: _Block):
         """x (B,D,H,W,C) += SSA(x), in place (reference Spiking_swin_transformer3D.py:781-821, 661-717, :840)."""
+        self._check_cl(x)
         B, D, H, W, Cc = x.shape
         ws, ss = get_window_size((D, H, W), blk.window_size, blk.shift_size)
         rowmap, B_ = self._slice_map(B, D, H, W, ws, ss)
@@ -257,6 +266,7 @@ class MSFlowEngine:
 
     def mlp(self, x, blk: _Block):
         """x (B,D,H,W,C) += MLP(x) over the true time axis D, in place (reference :164-181, :845)."""
+        self._check_cl(x)
         B, D, H, W, Cc = x.shape
         ntok, hw = B * D * H * W, H * W
         Ch = blk.fc1.N
@@ -277,6 +287,7 @@ class MSFlowEngine:
     def patch_merge(self, x, s):
         """(B,D,H,W,C) -> (B,D,H/2,W/2,2C) (reference :952-974)."""
         lin, sn = self.merges[s]
+        self._check_cl(x)
         B, D, H, W, Cc = x.shape
         rowmap, H2, W2, out_map = self._merge_map(B, D, H, W)
         rows = B * H2 * W2

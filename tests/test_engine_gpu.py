@@ -92,16 +92,16 @@ def test_teacher_forced_stage_parity(kind):
         for s, (depth, nH) in enumerate(zip(ocfg["depths"], ocfg["num_heads"])):
             for i in range(depth):
                 ref = O.ms_block(y, sd, p + f"layers.{s}.swin_blocks.{i}.", nH, ws, (0, 0, 0) if i % 2 == 0 else shift, n)
-                got = eng.swin_block(y.clone().to(DEV), s, i)
+                got = eng.swin_block(y.contiguous().to(DEV), s, i)
                 compare(f"stage{s}.block{i}", got, ref, report, 5e-3)
                 y = ref
             feats.append(y.contiguous())
             if s < 3:
                 ref = O.ms_patch_merge(y, sd, p + f"layers.{s}.downsample.", n)
-                compare(f"stage{s}.merge", eng.patch_merge(y.to(DEV), s), ref, report, 1e-3)
+                compare(f"stage{s}.merge", eng.patch_merge(y.contiguous().to(DEV), s), ref, report, 1e-3)
                 y = ref
         # U-Net tail, teacher-forced on the oracle's encoder features; compared on its per-scale flow sums
-        preds = eng.unet_tail([f.to(DEV) for f in feats])
+        preds = eng.unet_tail([f.contiguous().to(DEV) for f in feats])
         O_feats = [f.permute(1, 0, 4, 2, 3).contiguous() for f in feats]
         ref_preds = unet_tail_oracle(O_feats, sd, n)
         for i, (gp, rp) in enumerate(zip(preds, ref_preds)):
@@ -198,14 +198,14 @@ def test_batch2_three_encoder_model_teacher_forced():
         for s_, (depth, nH) in enumerate(zip(ocfg["depths"], ocfg["num_heads"])):
             for i in range(depth):
                 ref = O.ms_block(y, sd, p + f"layers.{s_}.swin_blocks.{i}.", nH, (2, 9, 9), (0, 0, 0) if i % 2 == 0 else (1, 4, 4), n)
-                compare(f"stage{s_}.block{i}", eng.swin_block(y.clone().to(DEV), s_, i), ref, report, 5e-3)
+                compare(f"stage{s_}.block{i}", eng.swin_block(y.contiguous().to(DEV), s_, i), ref, report, 5e-3)
                 y = ref
             feats.append(y.contiguous())
             if s_ < 2:
                 ref = O.ms_patch_merge(y, sd, p + f"layers.{s_}.downsample.", n)
-                compare(f"stage{s_}.merge", eng.patch_merge(y.to(DEV), s_), ref, report, 1e-3)
+                compare(f"stage{s_}.merge", eng.patch_merge(y.contiguous().to(DEV), s_), ref, report, 1e-3)
                 y = ref
-        preds = eng.unet_tail([f.to(DEV) for f in feats])
+        preds = eng.unet_tail([f.contiguous().to(DEV) for f in feats])
         ref_preds = unet_tail_oracle([f.permute(1, 0, 4, 2, 3).contiguous() for f in feats], sd, n)
         for i, (gp, rp) in enumerate(zip(preds, ref_preds)):
             compare(f"unet.pred{i}", gp.permute(1, 0, 4, 2, 3), rp, report, 1e-1)
@@ -233,9 +233,9 @@ def test_long_T20_stage_parity():
         y = ref.permute(1, 0, 3, 4, 2).contiguous()
         for i in range(2):
             r = O.ms_block(y, sd, p + f"layers.0.swin_blocks.{i}.", 3, (2, 9, 9), (0, 0, 0) if i % 2 == 0 else (1, 4, 4), n)
-            compare(f"stage0.block{i}", eng.swin_block(y.clone().to(DEV), 0, i), r, report, 5e-3)
+            compare(f"stage0.block{i}", eng.swin_block(y.contiguous().to(DEV), 0, i), r, report, 5e-3)
             y = r
         r = O.ms_patch_merge(y, sd, p + "layers.0.downsample.", n)
-        compare("stage0.merge", eng.patch_merge(y.to(DEV), 0), r, report, 1e-3)
+        compare("stage0.merge", eng.patch_merge(y.contiguous().to(DEV), 0), r, report, 1e-3)
     for name, rate, close in report:
         print(f"T=20 {name:16s} mismatch-rate {rate:.2e}  max-rel-dev-of-rest {close:.1e}")
