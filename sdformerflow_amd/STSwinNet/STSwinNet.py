@@ -1,0 +1,162 @@
+"""ANN counterpart of the flow network (BASELINE config 3; mirror of reference models/STSwinNet/STSwinNet.py):
+`STT_encoder` :14-138, `STT_MultiResUNet` :140-283, `STTFlowNet` :309-481, `STTFlowNet_4en` :486-497.
+The window-attention core (section 8 row a10) is this framework's fused HIP kernel; the dense glue around it
+(LayerNorm, Linear, GELU, fp32 convolutions, bilinear upsampling) is library work through torch on the GPU.
+Forward-only: the modules refuse training mode and CPU tensors (no fallback path)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import hip
+from .PatchEmbed import PatchEmbedLocal, ResidualBlock
+from .swin_transformer3D_v2 import SwinTransformer3D_v2
+
+
+class ConvLayer(nn.Module):
+    """conv2d + optional relu (reference models/submodules.py:14-67, norm None)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, activation="relu"):
+        super().__init__()
+        self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, stride, kernel_size // 2)
+        self.activation = activation
+
+    def forward(self, x):
+        y = self.conv2d(x)
+        return torch.relu(y) if self.activation == "relu" else y
+
+
+class UpsampleConvLayer(ConvLayer):
+    """bilinear x2 (align_corners False) -> conv2d -> relu (reference models/submodules.py:117-157)."""
+
+    def forward(self, x):
+        return super().forward(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False))
+
+
+class STT_encoder(nn.Module):
+    """Swin backbone + one 1x1 projection per (stage, time block) whose outputs are concatenated along channels."""
+
+    def __init__(self, img_size, patch_size, in_chans, embed_dim, depths, num_heads, window_size, pretrained_window_size,
+                 mlp_ratio, out_indices):
+        super().__init__()
+        pe = PatchEmbedLocal(img_size, patch_size, in_chans, embed_dim)
+        self.num_blocks = pe.num_blocks
+        self.swin3d = SwinTransformer3D_v2(pe, embed_dim, depths, num_heads, window_size, mlp_ratio, True, out_indices,
+                                           pretrained_window_size)
+        self.projections = nn.ModuleList([
+            nn.ModuleList([nn.Conv2d(embed_dim * 2 ** i, embed_dim * 2 ** i // self.num_blocks, 1) for _ in range(self.num_blocks)])
+            for i in range(len(depths))])
+
+    def forward(self, x):
+        feats = self.swin3d(x)
+        outs = []
+        for f, ps in zip(feats, self.projections):
+            B, _, _, h, w = f.shape
+            outs.append(torch.cat([p(c.reshape(B, -1, h, w)) for c, p in zip(f.chunk(self.num_blocks, 2), ps)], dim=1))
+        return outs
+
+
+class STT_MultiResUNet(nn.Module):
+    """Encoder -> 2 residual blocks -> decoders with concat skips and a flow prediction per scale."""
+
+    def __init__(self, unet_kwargs, stt_kwargs):
+        super().__init__()
+        base, E = unet_kwargs["base_num_channels"], unet_kwargs["num_encoders"]
+        k, n_out = unet_kwargs["kernel_size"], unet_kwargs["num_output_channels"]
+        if unet_kwargs.get("norm") is not None or not unet_kwargs.get("use_upsample_conv", True):
+            raise NotImplementedError("only the shipped configuration (norm Null, upsample-conv decoders) is built")
+        depths = list(stt_kwargs["swin_depths"])
+        if len(depths) != E:
+            raise ValueError("swin_depths must list one depth per encoder")
+        self.num_encoders = E
+        self.encoders = STT_encoder(stt_kwargs.get("input_size", [240, 320]), stt_kwargs["swin_patch_size"], unet_kwargs["num_bins"],
+                                    stt_kwargs.get("base_num_channels", base), depths, stt_kwargs["swin_num_heads"],
+                                    stt_kwargs["window_size"], stt_kwargs.get("pretrained_window_size", [0, 0, 0]),
+                                    stt_kwargs.get("mlp_ratio", 4), stt_kwargs["swin_out_indices"])
+        sizes = [base * 2 ** i for i in range(E)]
+        top = sizes[-1]
+        self.resblocks = nn.ModuleList([ResidualBlock(top, top) for _ in range(unet_kwargs["num_residual_blocks"])])
+        self.decoders, self.preds = nn.ModuleList(), nn.ModuleList()
+        ins = list(reversed(sizes))
+        outs = list(reversed([base] + sizes[:-1]))
+        for i, (ci, co) in enumerate(zip(ins, outs)):
+            self.decoders.append(UpsampleConvLayer(2 * ci + (0 if i == 0 else n_out), co, k))
+            self.preds.append(ConvLayer(co, n_out, 1, activation=None))
+
+    def forward(self, x):
+        blocks = self.encoders(x)
+        y = blocks[-1]
+        for rb in self.resblocks:
+            y = rb(y)
+        preds = []
+        for i, (dec, pred) in enumerate(zip(self.decoders, self.preds)):
+            y = torch.cat([y, blocks[self.num_encoders - 1 - i]], dim=1)
+            if i > 0:
+                y = torch.cat([preds[-1], y], dim=1)
+            y = dec(y)
+            preds.append(pred(y))
+        return preds, None
+
+
+class STTFlowNet(nn.Module):
+    """forward(event_voxel (B,num_bins,H,W), event_cnt, log=False) -> {"flow": [..(B,2,H,W)], "attn": None,
+    "spiking_rates": None}; same constructor dictionaries as the reference (`model:` and `swin_transformer:` yaml blocks)."""
+    num_en = 3
+
+    def __init__(self, unet_kwargs, stt_kwargs):
+        super().__init__()
+        unet_kwargs = dict(unet_kwargs)
+        self.encoding = unet_kwargs["encoding"]
+        self.num_bins = unet_kwargs["num_bins"]
+        self.norm_input = unet_kwargs.get("norm_input", False)
+        self.mask = unet_kwargs["mask_output"]
+        self.num_encoders = self.num_en
+        self.num_split = self.num_bins // stt_kwargs["swin_patch_size"][0]
+        unet_kwargs.update(num_encoders=self.num_en, num_residual_blocks=2, num_output_channels=2)
+        self.sttmultires_unet = STT_MultiResUNet(unet_kwargs, stt_kwargs)
+
+    def detach_states(self):
+        pass
+
+    def reset_states(self):
+        pass
+
+    @staticmethod
+    def normalize(x):
+        nz = x != 0
+        mean, std = x[nz].mean(), x[nz].std()
+        if std > 0:
+            x[nz] = (x[nz] - mean) / std
+        return x
+
+    def forward(self, event_voxel, event_cnt=None, log=False):
+        if self.training:
+            raise NotImplementedError("forward-only (SURVEY.md section 8f row 3 covers the backward kernels)")
+        if self.encoding == "voxel":
+            x = event_voxel
+        elif self.encoding == "cnt":
+            x = event_cnt
+        else:
+            raise AttributeError("Model error: Incorrect input encoding.")
+        if not x.is_cuda:
+            raise hip.SdfError("STTFlowNet runs on the GPU only (no CPU fallback)")
+        if log:
+            raise NotImplementedError("attention-score logging is analysis tooling outside the forward path")
+        with torch.no_grad():
+            if x.size(1) != self.num_bins:                     # DSEC double-chunk input: last block of chunk 1 + chunk 2
+                c1, c2 = x[:, :self.num_bins], x[:, self.num_bins:]
+                if self.norm_input:
+                    c1, c2 = self.normalize(c1), self.normalize(c2)
+                parts = (c1.chunk(self.num_split, dim=1)[-1],) + tuple(c2.chunk(self.num_split, dim=1))
+            else:
+                parts = x.chunk(self.num_split, dim=1)
+            x = torch.stack(list(parts), dim=0)                # (T,B,bins/T,H,W)
+            H, W = x.shape[-2:]
+            if H % 2 or W % 2:
+                x = F.pad(x, (0, W % 2, 0, H % 2))
+            flows, _ = self.sttmultires_unet(x)
+            flow_list = [F.interpolate(f, scale_factor=(H / f.shape[2], W / f.shape[3])) for f in flows]
+        return {"flow": flow_list, "attn": None, "spiking_rates": None}
+
+
+class STTFlowNet_4en(STTFlowNet):
+    num_en = 4

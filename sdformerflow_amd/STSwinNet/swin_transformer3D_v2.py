@@ -97,3 +97,113 @@ class WindowAttention3D(nn.Module):
             scale = torch.clamp(self.logit_scale, max=math.log(1.0 / 0.01)).exp().reshape(-1).contiguous()
             o = hip.win_attn_ann(qkv, scale, self.position_bias(), None if mask is None else mask.contiguous(), self.num_heads)
             return self.proj(o), None
+
+
+class Mlp(nn.Module):
+    """fc1 -> GELU -> fc2 (reference :15-34; dropout is identity in eval)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class SwinTransformerBlock3D(nn.Module):
+    """Pre-norm video-swin block (reference :208-336): x + attn(LN(x)) over (shifted) 3-D windows, then x + MLP(LN(x)).
+    Input and output (B,D,H,W,C)."""
+
+    def __init__(self, dim, num_heads, window_size=(2, 7, 7), shift_size=(0, 0, 0), mlp_ratio=4.0, qkv_bias=True,
+                 pretrained_window_size=(0, 0, 0)):
+        super().__init__()
+        self.dim, self.num_heads = dim, num_heads
+        self.window_size, self.shift_size = tuple(window_size), tuple(shift_size)
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = WindowAttention3D(dim, self.window_size, pretrained_window_size, num_heads, qkv_bias=qkv_bias)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, x, mask_matrix=None):
+        B, D, H, W, C = x.shape
+        ws, ss = get_window_size((D, H, W), self.window_size, self.shift_size)
+        y = self.norm1(x)
+        pd, pb, pr = (-D) % ws[0], (-H) % ws[1], (-W) % ws[2]
+        y = F.pad(y, (0, 0, 0, pr, 0, pb, 0, pd))
+        Dp, Hp, Wp = y.shape[1:4]
+        shifted = any(s > 0 for s in ss)
+        if shifted:
+            y = torch.roll(y, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
+            mask = mask_matrix if mask_matrix is not None else compute_mask(Dp, Hp, Wp, ws, ss, x.device)
+        else:
+            mask = None
+        a, _ = self.attn(window_partition(y, ws), mask)
+        a = window_reverse(a, ws, B, Dp, Hp, Wp)
+        if shifted:
+            a = torch.roll(a, shifts=ss, dims=(1, 2, 3))
+        x = x + a[:, :D, :H, :W]
+        return x + self.mlp(self.norm2(x))
+
+
+class PatchMerging(nn.Module):
+    """2x2 spatial concat -> LN(4C) -> Linear(4C, 2C, no bias) (reference :343-393)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = nn.LayerNorm(4 * dim)
+
+    def forward(self, x):
+        H, W = x.shape[2:4]
+        if H % 2 or W % 2:
+            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+        x = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
+        return self.reduction(self.norm(x))
+
+
+class Swin_BasicLayer(nn.Module):
+    """One stage (reference :424-512): `depth` blocks alternating plain / shifted windows, then the optional merge.
+    forward((B,D,H,W,C)) -> (stage output, merged output)."""
+
+    def __init__(self, dim, depth, num_heads, window_size, mlp_ratio=4.0, qkv_bias=True, downsample=None,
+                 pretrained_window_size=(0, 0, 0)):
+        super().__init__()
+        self.window_size = tuple(window_size)
+        self.shift_size = tuple(i // 2 for i in window_size)
+        self.swin_blocks = nn.ModuleList([
+            SwinTransformerBlock3D(dim, num_heads, self.window_size, (0, 0, 0) if i % 2 == 0 else self.shift_size, mlp_ratio,
+                                   qkv_bias, pretrained_window_size) for i in range(depth)])
+        self.downsample = downsample(dim) if downsample is not None else None
+
+    def forward(self, x):
+        for blk in self.swin_blocks:
+            x = blk(x)
+        return x, (self.downsample(x) if self.downsample is not None else x)
+
+
+class SwinTransformer3D_v2(nn.Module):
+    """Backbone (reference :538-763): patch embedding -> stages; every stage output goes through its own LayerNorm
+    `norm{i}` and is returned channel-first (B,C,D,h,w)."""
+
+    def __init__(self, patch_embed, embed_dim, depths, num_heads, window_size, mlp_ratio=4.0, qkv_bias=True,
+                 out_indices=(0, 1, 2), pretrained_window_size=(0, 0, 0)):
+        super().__init__()
+        self.patch_embed = patch_embed
+        self.num_layers, self.out_indices = len(depths), tuple(out_indices)
+        self.num_features = [embed_dim * 2 ** i for i in range(self.num_layers)]
+        self.layers = nn.ModuleList([
+            Swin_BasicLayer(self.num_features[i], depths[i], num_heads[i], window_size, mlp_ratio, qkv_bias,
+                            PatchMerging if i < self.num_layers - 1 else None, pretrained_window_size)
+            for i in range(self.num_layers)])
+        for i in self.out_indices:
+            self.add_module(f"norm{i}", nn.LayerNorm(self.num_features[i]))
+
+    def forward(self, x):
+        x = self.patch_embed(x).permute(0, 2, 3, 4, 1).contiguous()                 # (B,D,h,w,C)
+        outs = []
+        for i, layer in enumerate(self.layers):
+            o, x = layer(x)
+            if i in self.out_indices:
+                outs.append(getattr(self, f"norm{i}")(o).permute(0, 4, 1, 2, 3))
+        return outs

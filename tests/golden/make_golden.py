@@ -248,8 +248,34 @@ def gold_end_to_end():
                 f.write(f"{k} {'x'.join(map(str, v.shape))}\n")
 
 
+# ------------------------------------------------------------------ 8. ANN STTFlowNet end to end (BASELINE config 3 family)
+def gold_ann_end_to_end():
+    from models.STSwinNet.STSwinNet import STTFlowNet, STTFlowNet_4en
+    cfg = YAMLParser("/root/reference/configs/train_DSEC_supervised_STT_voxel.yml")
+    config = cfg.combine_entries(cfg.config)
+    config["swin_transformer"]["input_size"] = [144, 192]
+    model = STTFlowNet(config["model"].copy(), config["swin_transformer"].copy())
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()
+              if not k.endswith(("relative_position_index", "relative_coords_table"))}
+    model.load_state_dict(synth_state_dict(shapes), strict=False)
+    model.eval()
+    x = synth_voxel(2, 20, 144, 192, seed=1234 + 3)
+    res = model(x, None)
+    out = {}
+    for i, f in enumerate(res["flow"]):
+        s = f.shape[-1] // (24 * 2 ** i)                       # predictions live at 18x24, 36x48, 72x96
+        out[f"flow{i}"] = f[:, :, ::s, ::s].contiguous()
+    out["n_state"] = np.array(len(model.state_dict()))
+    save("ann_end_to_end", **out)
+    with open(os.path.join(HERE, "state_schema_sttflownet.txt"), "w") as fh:
+        for k, v in model.state_dict().items():
+            fh.write(f"{k} {'x'.join(map(str, v.shape))}\n")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["neurons", "index_maps", "qk_attention", "sew_attention", "ann_attention",
-                             "ms_block", "end_to_end"]
+                             "ms_block", "end_to_end", "ann_end_to_end"]
     for w in which:
         globals()["gold_" + w]()
+
+

@@ -1,0 +1,92 @@
+"""ANN STTFlowNet (BASELINE config 3): the model-level caller of the fused window-attention kernel (section 8 row a10).
+CPU: the module tree has the reference's state_dict schema.  GPU: flows vs the CPU oracle (itself pinned to the
+reference by tests/test_oracle_golden.py::test_ann_sttflownet_end_to_end_matches_reference) and vs the golden file."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from sdformerflow_amd.synthetic import synth_state_dict, synth_voxel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def build(cls_name="STTFlowNet", size=(144, 192)):
+    from sdformerflow_amd.STSwinNet import STSwinNet
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "sdformerflow_amd", "configs", "train_DSEC_supervised_STT_voxel.yml")))
+    model = dict(cfg["model"], spiking_neuron=None)
+    swin = dict(cfg["swin_transformer"], input_size=list(size))
+    if cls_name == "STTFlowNet_4en":
+        swin.update(swin_depths=[2, 2, 6, 2], swin_num_heads=[3, 6, 12, 24], swin_out_indices=[0, 1, 2, 3])
+    return getattr(STSwinNet, cls_name)(model, swin)
+
+
+def load_synth(net):
+    skip = ("relative_position_index", "relative_coords_table", "num_batches_tracked")
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items() if not k.endswith(skip)})
+    net.load_state_dict(sd, strict=False)
+    return sd
+
+
+def test_sttflownet_state_schema_matches_reference():
+    net = build()
+    mine = [(k, "x".join(str(d) for d in v.shape)) for k, v in net.state_dict().items()]
+    ref = []
+    with open(os.path.join(G, "state_schema_sttflownet.txt")) as f:
+        for line in f:
+            n, _, shp = line.strip().partition(" ")
+            ref.append((n, shp))
+    assert mine == ref
+
+
+def test_sttflownet_refuses_cpu_and_training():
+    from sdformerflow_amd import hip
+    net = build().eval()
+    with pytest.raises(hip.SdfError):
+        net(torch.zeros(1, 20, 144, 192), None)
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros(1, 20, 144, 192), None)
+
+
+@pytest.mark.gpu
+def test_sttflownet_flows_match_oracle_and_golden():
+    from oracle import sdformer_oracle as O
+    net = build().eval()
+    sd = load_synth(net)
+    vox = synth_voxel(2, 20, 144, 192, seed=1237)
+    cfg = {"num_bins": 20, "patch_size": (10, 4, 4), "window_size": (2, 9, 9), "depths": [2, 2, 6], "num_heads": [3, 6, 12]}
+    with torch.no_grad():
+        ref = O.forward_sttflownet(vox, sd, cfg)
+    net = net.cuda()
+    net.norm_input = False                                       # the fixture was generated on the single-chunk input
+    got = net(vox.cuda(), None)["flow"]
+    g = np.load(os.path.join(G, "ann_end_to_end.npz"))
+    assert len(got) == len(ref) == 3
+    for i, (a, b) in enumerate(zip(got, ref)):
+        a = a.cpu()
+        tol = 1e-3 * b.abs().mean().item()                       # north star: flow within 1e-3 relative (fp32)
+        assert (a - b).abs().max().item() <= tol, (i, (a - b).abs().max().item(), tol)
+        s = a.shape[-1] // (24 * 2 ** i)
+        assert np.abs(a[:, :, ::s, ::s].numpy() - g[f"flow{i}"]).max() <= tol
+
+
+@pytest.mark.gpu
+def test_sttflownet_4en_matches_oracle():
+    from oracle import sdformer_oracle as O
+    net = build("STTFlowNet_4en", (288, 384)).eval()
+    sd = load_synth(net)
+    vox = synth_voxel(1, 20, 288, 384, seed=77)           # BASELINE config 3 crop; 4 scales need /32
+    cfg = {"num_bins": 20, "patch_size": (10, 4, 4), "window_size": (2, 9, 9), "depths": [2, 2, 6, 2], "num_heads": [3, 6, 12, 24]}
+    with torch.no_grad():
+        ref = O.forward_sttflownet(vox, sd, cfg)
+    net = net.cuda()
+    net.norm_input = False
+    got = net(vox.cuda(), None)["flow"]
+    assert len(got) == len(ref) == 4
+    for i, (a, b) in enumerate(zip(got, ref)):
+        d = (a.cpu() - b).abs().max().item()
+        assert d <= 1e-3 * b.abs().mean().item(), (i, d)

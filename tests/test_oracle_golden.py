@@ -245,3 +245,24 @@ def test_end_to_end_flow_matches_reference(kind):
     m = O.aee(flows[-1], label, mask, 1.0)
     got = np.array([float(v.reshape(-1)[0]) for v in m])
     assert np.allclose(got, g[f"{kind}_aee"], rtol=1e-5 if strict else 5e-2, atol=1e-6 if strict else 5e-2)
+
+
+# ---------------------------------------------------------------- ANN STTFlowNet end to end (BASELINE config 3 family)
+def test_ann_sttflownet_end_to_end_matches_reference():
+    g = gold("ann_end_to_end")
+    shapes = {}
+    with open(os.path.join(G, "state_schema_sttflownet.txt")) as f:
+        for line in f:
+            name, _, shp = line.strip().partition(" ")
+            shapes[name] = tuple(int(v) for v in shp.split("x")) if shp else ()
+    assert len(shapes) == int(g["n_state"])
+    sd = synth_state_dict({k: v for k, v in shapes.items()
+                           if not k.endswith(("relative_position_index", "relative_coords_table", "num_batches_tracked"))})
+    cfg = {"num_bins": 20, "patch_size": (10, 4, 4), "window_size": (2, 9, 9), "depths": [2, 2, 6], "num_heads": [3, 6, 12]}
+    with torch.no_grad():
+        flows = O.forward_sttflownet(synth_voxel(2, 20, 144, 192, seed=1237), sd, cfg)
+    for i, f in enumerate(flows):
+        s = f.shape[-1] // (24 * 2 ** i)
+        ref = g[f"flow{i}"]
+        d = np.abs(f[:, :, ::s, ::s].numpy() - ref)
+        assert d.max() <= 1e-3 * np.abs(ref).mean(), (i, d.max(), np.abs(ref).mean())      # north-star bound (ANN is not chaotic)
