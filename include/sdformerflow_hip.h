@@ -120,7 +120,7 @@ typedef struct SdfSpikeGemmDesc {
   int64_t M;
   int32_t N, K;
   int64_t lda, ldo;
-  int32_t nsplit;           /* 1 (bf16 weights) or 3 (fp32-grade hi/mid/lo) */
+  int32_t nsplit;           /* 1: one bf16 plane; 2: two fp16 planes of wscale*W (22 bits); 3: three bf16 planes (24 bits) */
   const float* bias;        /* NULL ok */
   const float* alpha;       /* NULL ok */
   const float* beta;
@@ -147,6 +147,12 @@ typedef struct SdfSpikeGemmDesc {
    * 2*M*N floats the library may run the product as K chunks + a deterministic k-ordered reduction. */
   void* workspace;
   int64_t workspace_bytes;
+  /* nsplit == 2 only: 1 / wscale of the planes made by sdf_split_weight_f16x2 (a power of two); the accumulator is
+   * multiplied by it - exactly - before the epilogue.  0 or 1 otherwise. */
+  float acc_scale;
+  /* With out_rowmap: number of rows of out / resid (an upper bound of the scattered row indices + 1); 0 = unknown.
+   * Lets the library pick kernels that address the output with 32-bit offsets. */
+  int64_t out_rows;
 } SdfSpikeGemmDesc;
 
 int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream);
@@ -175,6 +181,13 @@ int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream);
 
 /* W (fp32, n elements) -> nsplit bf16 planes (round-to-nearest-even residual split). */
 int sdf_split_weight_bf16(const float* W, uint16_t* planes, int64_t n, int nsplit, void* stream);
+
+/* W (fp32, n elements) -> two fp16 planes [2][n] with  scale * W = hi + lo  (|error| <= 2^-22 |W|).  `scale` is a
+ * power of two chosen by the caller so that scale * max|W| < 2^15 (fp16 range; small weights stay far above the
+ * fp16 subnormal spacing); pass acc_scale = 1 / scale with nsplit = 2.  Spikes are exact in fp16, the MFMA
+ * accumulates in fp32 and the rescaling is exact, so the result differs from the 3-plane one only by the 2^-22
+ * weight truncation - below the rounding noise of the fp32 accumulation itself - at 2/3 of its MFMA work. */
+int sdf_split_weight_f16x2(const float* W, uint16_t* planes, int64_t n, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Token gate of Spiking_QK_WindowAttention3D (reference Spiking_swin_transformer3D.py:687-694):

@@ -3,10 +3,11 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -Wall -Wno-unused-function"
+# -fno-slp-vectorize: packed f32 VALU (v_pk_*) costs more than two scalar ops beside MFMAs and widens register pairs
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function -Wno-pass-failed"
 mkdir -p obj
 pids=()
-for f in neuron spike_gemm spike_mm_ws qk_gate elementwise win_attn; do
+for f in neuron spike_gemm spike_mm_ws spike_mm_pp qk_gate elementwise win_attn; do
   if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ common.h -nt obj/$f.o ] || [ spike_mm.h -nt obj/$f.o ] || [ ../../include/sdformerflow_hip.h -nt obj/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o obj/$f.o &
     pids+=($!)

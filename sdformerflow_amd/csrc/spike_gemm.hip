@@ -186,6 +186,7 @@ __global__ __launch_bounds__(64 * WAVES) void spike_gemm_kernel(GemmParams P) {
   };
 
   f32x16 acc[RB][NB];
+  const float asc = P.acc_scale;                     // 1 / weight scale of the fp16 planes (a power of two), else 1
   const bool soft = d.soft_reset != 0;
   const bool reset0 = soft || d.v_reset == 0.f;
 
@@ -229,14 +230,14 @@ __global__ __launch_bounds__(64 * WAVES) void spike_gemm_kernel(GemmParams P) {
       bf16x8 a[RB];
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
-        a[rb] = expand_spikes(*reinterpret_cast<const uint2*>(&A_s[(wave * WR + rb * 32 + l31) * A_LD + ks * 16 + 8 * lh]));
+        a[rb] = expand_spikes<NSPLIT>(*reinterpret_cast<const uint2*>(&A_s[(wave * WR + rb * 32 + l31) * A_LD + ks * 16 + 8 * lh]));
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
         for (int p = 0; p < NSPLIT; ++p) {
           const bf16x8 b = *reinterpret_cast<const bf16x8*>(&W_s[(p * BN + nb * 32 + l31) * W_LD + ks * 16 + 8 * lh]);
 #pragma unroll
-          for (int rb = 0; rb < RB; ++rb) acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], b, acc[rb][nb], 0, 0, 0);
+          for (int rb = 0; rb < RB; ++rb) acc[rb][nb] = mma<NSPLIT>(a[rb], b, acc[rb][nb]);
         }
       }
     }
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(64 * WAVES) void spike_gemm_kernel(GemmParams P) {
         auto finish = [&](int nb, int rb, int q4, float4 r) -> float4 {
           float v[4] = {acc[rb][nb][q4 * 4 + 0], acc[rb][nb][q4 * 4 + 1], acc[rb][nb][q4 * 4 + 2], acc[rb][nb][q4 * 4 + 3]};
           quad_transpose(v, ql);
-          float4 o = make_float4(v[0], v[1], v[2], v[3]);
+          float4 o = make_float4(v[0] * asc, v[1] * asc, v[2] * asc, v[3] * asc);
           o.x += bs[nb].x; o.y += bs[nb].y; o.z += bs[nb].z; o.w += bs[nb].w;
           o.x = __builtin_fmaf(o.x, al[nb].x, be[nb].x); o.y = __builtin_fmaf(o.y, al[nb].y, be[nb].y);
           o.z = __builtin_fmaf(o.z, al[nb].z, be[nb].z); o.w = __builtin_fmaf(o.w, al[nb].w, be[nb].w);
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(64 * WAVES) void spike_gemm_kernel(GemmParams P) {
 #pragma unroll
             for (int t = 0; t < T; ++t) {
               const int slot = pl * T + t;                   // compile-time after unrolling
-              xs[t] = __builtin_fmaf(acc[slot >> 4][nb][slot & 15], al, be);      // al = 1, be = 0 without BN
+              xs[t] = __builtin_fmaf(acc[slot >> 4][nb][slot & 15] * asc, al, be);      // al = 1, be = 0 without BN
             }
             if (d.add) {                                     // wave-uniform; loads unconditional (clamped position / column)
               const int64_t pc = pos < d.pos_count ? pos : 0;
@@ -409,6 +410,18 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
   }
 }
 
+// W * scale (fp32, n elements; scale a power of two) -> two fp16 planes hi + lo (round-to-nearest-even residual split)
+__global__ __launch_bounds__(256) void split_weight_f16_kernel(const float* __restrict__ W, uint16_t* __restrict__ planes,
+                                                               int64_t n, float scale) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float w = W[i] * scale;                            // exact
+  const _Float16 hi = (_Float16)w;                         // RNE
+  const _Float16 lo = (_Float16)(w - (float)hi);           // the residual is exact in fp32
+  planes[i] = __builtin_bit_cast(uint16_t, hi);
+  planes[n + i] = __builtin_bit_cast(uint16_t, lo);
+}
+
 template <int NSPLIT, int NB, int RB, int WAVES, bool CONV = false>
 int launch(const GemmParams& P, dim3 grid, hipStream_t s) {
 #define SDF_GEMM_T(TT)                                                                                      \
@@ -437,6 +450,14 @@ int launch_cfg(const GemmParams& P, int cfg, dim3 grid, hipStream_t s) {
   }
 }
 
+// acc_scale: only the fp16 planes carry a weight scale; it must be a power of two (exact rescaling of the accumulator)
+bool sdf_scale_ok(const SdfSpikeGemmDesc* d) {
+  if (d->nsplit != 2) return d->acc_scale == 0.f || d->acc_scale == 1.f;
+  int ex;
+  return d->acc_scale > 0.f && frexpf(d->acc_scale, &ex) == 0.5f;
+}
+float sdf_acc_scale(const SdfSpikeGemmDesc* d) { return d->nsplit == 2 ? d->acc_scale : 1.f; }
+
 }  // namespace
 
 extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
@@ -445,12 +466,14 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
   const bool spike = d->sn_T > 0;
   if (spike ? !d->out_spike : !d->out) return SDF_E_NULL;
   if (d->M < 1 || d->M >= (1LL << 31) || d->N < 32 || d->K < 32 || d->K % 32 || d->N % 32) return SDF_E_SHAPE;
-  if (d->nsplit != 1 && d->nsplit != 3) return SDF_E_DTYPE;       // 1 = bf16 weights, 3 = fp32-grade
+  if (d->nsplit < 1 || d->nsplit > 3) return SDF_E_DTYPE;         // 1 = bf16, 2 = fp16 hi/lo (scaled), 3 = bf16 hi/mid/lo
+  if (!sdf_scale_ok(d)) return SDF_E_DTYPE;
   if (d->alpha && !d->beta) return SDF_E_NULL;
   if (d->lda % 16) return SDF_E_SHAPE;
   GemmParams P;
   P.d = *d;
   P.inv_tau = 0.f;
+  P.acc_scale = sdf_acc_scale(d);
   if (spike) {
     if (d->pos_count < 1 || d->pos_inner < 1 || d->pos_count * d->sn_T != d->M) return SDF_E_SHAPE;
     if (d->sn_kind != SDF_LIF && d->sn_kind != SDF_PSN && d->sn_kind != SDF_IF) return SDF_E_DTYPE;
@@ -500,8 +523,9 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
     bool use_ws = false;          // measured: the small-tile kernels win on every Linear of the model (K <= 3072, epilogue-bound)
     (void)ws_tiles;
     if (e && e[0] == '0') use_ws = false;
-    if (e && e[0] == '1') use_ws = legal;
+    if (e && e[0] == '1') use_ws = legal && d->nsplit != 2;
     if (use_ws) return launch_spike_mm_ws(P, false, sdf_stream(stream));
+    if (e && e[0] == '2' && legal && spike_mm_pp_supports(P, false)) return launch_spike_mm_pp(P, false, sdf_stream(stream));
   }
   if (!ok(cfg)) return SDF_E_SHAPE;
   const int nb = CFG_NB[cfg], rb = CFG_RB[cfg], waves = CFG_WAVES[cfg];
@@ -515,7 +539,7 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
   const int G = P.ntiles < 256 * wg_per_cu ? P.ntiles : 256 * wg_per_cu;
   dim3 grid((unsigned)G);
   hipStream_t s = sdf_stream(stream);
-  const int rc = d->nsplit == 1 ? launch_cfg<1>(P, cfg, grid, s) : launch_cfg<3>(P, cfg, grid, s);
+  const int rc = d->nsplit == 1 ? launch_cfg<1>(P, cfg, grid, s) : (d->nsplit == 2 ? launch_cfg<2>(P, cfg, grid, s) : launch_cfg<3>(P, cfg, grid, s));
   if (rc) return rc;
   SDF_LAUNCH_CHECK();
   return 0;
@@ -533,13 +557,15 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
   if (c->Cin < 48 || c->Cin % 16 || c->KH < 1 || c->KH > 3 || c->KW < 1 || c->KW > 3 || c->sy < 1 || c->sx < 1) return SDF_E_SHAPE;
   if (d->K != c->KH * c->KW * c->Cin || d->N % 96 || d->M % ((int64_t)c->OH * c->OW) || d->M >= (1LL << 31)) return SDF_E_SHAPE;
   if ((d->M / ((int64_t)c->OH * c->OW)) * c->H * c->W >= (1LL << 31)) return SDF_E_SHAPE;
-  if (d->nsplit != 1 && d->nsplit != 3) return SDF_E_DTYPE;
+  if (d->nsplit < 1 || d->nsplit > 3) return SDF_E_DTYPE;
+  if (!sdf_scale_ok(d)) return SDF_E_DTYPE;
   if (d->alpha && !d->beta) return SDF_E_NULL;
   if (d->zg_nH > 0) return SDF_E_SHAPE;
   GemmParams P;
   P.d = *d;
   P.d.lda = 0;
   P.inv_tau = 0.f;
+  P.acc_scale = sdf_acc_scale(d);
   if (spike) {
     if (d->sn_T != 10 || d->pos_count < 1 || d->pos_inner < 1 || d->pos_count * d->sn_T != d->M) return SDF_E_SHAPE;
     if (d->sn_kind != SDF_LIF && d->sn_kind != SDF_PSN && d->sn_kind != SDF_IF) return SDF_E_DTYPE;
@@ -556,8 +582,22 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
   cv.KWc = c->KW;
   cv.kw_mul = c->KW == 1 ? 32 : (c->KW == 2 ? 16 : 11);
   for (int i = 0; i < 3; ++i) { cv.dy[i] = c->dy[i]; cv.dx[i] = c->dx[i]; }
-  // warp-specialised kernel: 256 x 96 tiles, producers do the im2col addressing (K = taps*Cin >= 432: MFMA-dominated)
+  // 256 x 96 tiles, producer waves do the im2col addressing; the ping-pong kernel overlaps epilogues with the MFMAs
+  const char* e = getenv("SDF_CONV_PP");                      // tuning override: 0 = barrier-synchronised kernel
+  if (spike_mm_pp_supports(P, true) && !(e && e[0] == '0')) return launch_spike_mm_pp(P, true, sdf_stream(stream));
+  if (d->nsplit == 2) return SDF_E_DTYPE;
   return launch_spike_mm_ws(P, true, sdf_stream(stream));
+}
+
+extern "C" int sdf_split_weight_f16x2(const float* W, uint16_t* planes, int64_t n, float scale, void* stream) {
+  if (!W || !planes) return SDF_E_NULL;
+  if (n < 1) return SDF_E_SHAPE;
+  int ex;
+  if (!(scale > 0.f) || frexpf(scale, &ex) != 0.5f) return SDF_E_DTYPE;
+  hipLaunchKernelGGL(split_weight_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sdf_stream(stream), W, planes, n,
+                     scale);
+  SDF_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int sdf_split_weight_bf16(const float* W, uint16_t* planes, int64_t n, int nsplit, void* stream) {

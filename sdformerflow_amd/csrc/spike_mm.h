@@ -22,15 +22,30 @@ struct GemmParams {
   float inv_tau;
   int ksplit, spc;            // split-K (warp-specialised kernel): K chunks per tile, stages per chunk
   float* partial;             // [ksplit][M][N] fp32 partial sums in the caller's workspace
+  float acc_scale;            // multiplies the accumulator before the epilogue (1 / weight scale of the fp16 planes; else 1)
 };
 
-// 8 spike bytes {0,1} -> 8 bf16 {0, 1.0}
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+// Weight planes: NSPLIT = 1 / 3 -> bf16 planes (W = p0 [+ p1 + p2]); NSPLIT = 2 -> two fp16 planes of wscale * W.
+// Binary spikes are exact in both 16-bit formats; the accumulation is fp32 inside the matrix cores.
+template <int NSPLIT>
+__device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (NSPLIT == 2)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// 8 spike bytes {0,1} -> 8 x 16-bit {0, 1.0}: (b0 | b1 << 16) * ONE with ONE = 0x3F80 (bf16) or 0x3C00 (fp16)
+template <int NSPLIT>
 __device__ __forceinline__ bf16x8 expand_spikes(uint2 v) {
+  constexpr uint32_t ONE = NSPLIT == 2 ? 0x3C00u : 0x3F80u;
   union { bf16x8 h; uint32_t u[4]; } r;
-  r.u[0] = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u) * 0x3F80u;   // (b0 | b1 << 16) * bf16(1.0)
-  r.u[1] = __builtin_amdgcn_perm(0u, v.x, 0x0c030c02u) * 0x3F80u;
-  r.u[2] = __builtin_amdgcn_perm(0u, v.y, 0x0c010c00u) * 0x3F80u;
-  r.u[3] = __builtin_amdgcn_perm(0u, v.y, 0x0c030c02u) * 0x3F80u;
+  r.u[0] = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u) * ONE;
+  r.u[1] = __builtin_amdgcn_perm(0u, v.x, 0x0c030c02u) * ONE;
+  r.u[2] = __builtin_amdgcn_perm(0u, v.y, 0x0c010c00u) * ONE;
+  r.u[3] = __builtin_amdgcn_perm(0u, v.y, 0x0c030c02u) * ONE;
   return r.h;
 }
 
@@ -57,5 +72,11 @@ __device__ __forceinline__ void quad_transpose(float (&v)[4], int q) {
 
 // warp-specialised kernel (spike_mm_ws.hip): 256 x 96 tiles, N % 96 == 0; returns 0 or an SDF_E_* / hipError code
 int launch_spike_mm_ws(const GemmParams& P, bool conv, hipStream_t s);
+// ping-pong kernel (spike_mm_pp.hip): same tiles, consumer groups alternate tiles so epilogues overlap the MFMAs
+bool spike_mm_pp_supports(const GemmParams& P, bool conv);
+int launch_spike_mm_pp(const GemmParams& P, bool conv, hipStream_t s);
+// split-K planning (fills ksplit / spc / partial from the descriptor's workspace) and the k-ordered second pass
+void plan_splitk(GemmParams& P, int kc);
+int launch_splitk_reduce(const GemmParams& P, hipStream_t s);
 
 }  // namespace sdfmm

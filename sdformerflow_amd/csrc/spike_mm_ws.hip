@@ -238,6 +238,7 @@ __global__ __launch_bounds__(512) void spike_mm_ws_kernel(GemmParams P) {
 
   // =============================== CONSUMERS ===============================
   const int l31 = lane & 31, lh = lane >> 5;
+  const float asc = P.acc_scale;
   f32x16 acc[2][3];
   const bool soft = d.soft_reset != 0;
   const bool reset0 = soft || d.v_reset == 0.f;
@@ -263,14 +264,14 @@ __global__ __launch_bounds__(512) void spike_mm_ws_kernel(GemmParams P) {
       bf16x8 a[2];
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
-        a[rb] = expand_spikes(*reinterpret_cast<const uint2*>(&A_s[(wave * 64 + rb * 32 + l31) * A_LD + ks * 16 + 8 * lh]));
+        a[rb] = expand_spikes<NSPLIT>(*reinterpret_cast<const uint2*>(&A_s[(wave * 64 + rb * 32 + l31) * A_LD + ks * 16 + 8 * lh]));
 #pragma unroll
       for (int nb = 0; nb < 3; ++nb) {
 #pragma unroll
         for (int p = 0; p < NSPLIT; ++p) {
           const bf16x8 b = *reinterpret_cast<const bf16x8*>(&W_s[(p * BN + nb * 32 + l31) * W_LD + ks * 16 + 8 * lh]);
-          acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b, acc[0][nb], 0, 0, 0);
-          acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b, acc[1][nb], 0, 0, 0);
+          acc[0][nb] = mma<NSPLIT>(a[0], b, acc[0][nb]);
+          acc[1][nb] = mma<NSPLIT>(a[1], b, acc[1][nb]);
         }
       }
     }
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(512) void spike_mm_ws_kernel(GemmParams P) {
         auto finish = [&](int nb, int rb, int q4, float4 r) -> float4 {
           float v[4] = {acc[rb][nb][q4 * 4 + 0], acc[rb][nb][q4 * 4 + 1], acc[rb][nb][q4 * 4 + 2], acc[rb][nb][q4 * 4 + 3]};
           quad_transpose(v, ql);
-          float4 o = make_float4(v[0], v[1], v[2], v[3]);
+          float4 o = make_float4(v[0] * asc, v[1] * asc, v[2] * asc, v[3] * asc);
           o.x += bs[nb].x; o.y += bs[nb].y; o.z += bs[nb].z; o.w += bs[nb].w;
           o.x = __builtin_fmaf(o.x, al[nb].x, be[nb].x); o.y = __builtin_fmaf(o.y, al[nb].y, be[nb].y);
           o.z = __builtin_fmaf(o.z, al[nb].z, be[nb].z); o.w = __builtin_fmaf(o.w, al[nb].w, be[nb].w);
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(512) void spike_mm_ws_kernel(GemmParams P) {
 #pragma unroll
             for (int t2 = 0; t2 < T; ++t2) {
               const int slot = pl * T + t2;
-              xs[t2] = __builtin_fmaf(acc[slot >> 4][nb][slot & 15], al, be);   // al = 1, be = 0 when there is no BN
+              xs[t2] = __builtin_fmaf(acc[slot >> 4][nb][slot & 15] * asc, al, be);   // al = 1, be = 0 when there is no BN
             }
             if (d.add) {                                         // wave-uniform; loads unconditional (clamped position)
               const int64_t pc = pos < d.pos_count ? pos : 0;
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(512) void spike_mm_ws_kernel(GemmParams P) {
 
 // Second pass of split-K: out = epilogue( sum_k partial[k] ), chunks added in k order (deterministic).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int ksplit, int64_t M, int N,
-                                                            const float* bias, const float* alpha, const float* beta,
+                                                            float asc, const float* bias, const float* alpha, const float* beta,
                                                             const float* resid, const int* rowmap, float* out, int64_t ldo) {
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int nq = N / 4;
@@ -491,6 +492,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const float4 b = *reinterpret_cast<const float4*>(partial + ((int64_t)k * M + m) * N + n);
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
   }
+  a.x *= asc; a.y *= asc; a.z *= asc; a.w *= asc;                // power of two: exact
   if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + n); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
   if (alpha) {
     const float4 al = *reinterpret_cast<const float4*>(alpha + n), be = *reinterpret_cast<const float4*>(beta + n);
@@ -516,6 +518,37 @@ int launch_t(const GemmParams& P, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
+// split-K when the tiles alone cannot occupy the chip (small M, large K): needs the fp32 epilogue and a
+// caller-provided workspace of ksplit*M*N floats; partial sums are combined in k order by a second kernel
+void plan_splitk(GemmParams& P, int kc) {
+  const SdfSpikeGemmDesc& d = P.d;
+  const int S = (d.K + kc - 1) / kc;
+  P.ksplit = 1;
+  P.spc = S;
+  P.partial = nullptr;
+  if (d.sn_T == 0 && P.ntiles <= 128 && S >= 4 && d.workspace) {
+    int ks = (256 + P.ntiles - 1) / P.ntiles;
+    if (ks > S / 2) ks = S / 2;
+    if (ks > 16) ks = 16;
+    while (ks > 1 && (int64_t)ks * d.M * d.N * 4 > d.workspace_bytes) --ks;
+    if (ks > 1 && sdf_aligned(d.workspace, 16)) {
+      P.ksplit = ks;
+      P.spc = (S + ks - 1) / ks;
+      P.partial = reinterpret_cast<float*>(d.workspace);
+    }
+  }
+}
+
+int launch_splitk_reduce(const GemmParams& P, hipStream_t s) {
+  if (P.ksplit <= 1) return 0;
+  const SdfSpikeGemmDesc& d = P.d;
+  const int64_t quads = d.M * (d.N / 4);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, P.partial, P.ksplit, d.M,
+                     d.N, P.acc_scale, d.bias, d.alpha, d.beta, d.resid, d.out_rowmap, d.out, d.ldo);
+  const hipError_t e = hipGetLastError();
+  return e != hipSuccess ? (int)e : 0;
+}
+
 int launch_spike_mm_ws(const GemmParams& Pin, bool conv, hipStream_t s) {
   GemmParams P = Pin;
   const SdfSpikeGemmDesc& d = P.d;
@@ -528,23 +561,7 @@ int launch_spike_mm_ws(const GemmParams& Pin, bool conv, hipStream_t s) {
   P.tiles_m = (int)(spike ? (d.pos_count + 8 * npos - 1) / (8 * npos) : (d.M + BM - 1) / BM);
   P.tiles_n = d.N / BN;
   P.ntiles = P.tiles_m * P.tiles_n;
-  // split-K when the tiles alone cannot occupy the chip (small M, large K): needs the fp32 epilogue and a
-  // caller-provided workspace of ksplit*M*N floats; partial sums are combined in k order by a second kernel
-  const int S = (d.K + KC - 1) / KC;
-  P.ksplit = 1;
-  P.spc = S;
-  P.partial = nullptr;
-  if (!spike && P.ntiles <= 128 && S >= 4 && d.workspace) {
-    int ks = (256 + P.ntiles - 1) / P.ntiles;
-    if (ks > S / 2) ks = S / 2;
-    if (ks > 16) ks = 16;
-    while (ks > 1 && (int64_t)ks * d.M * d.N * 4 > d.workspace_bytes) --ks;
-    if (ks > 1 && sdf_aligned(d.workspace, 16)) {
-      P.ksplit = ks;
-      P.spc = (S + ks - 1) / ks;
-      P.partial = reinterpret_cast<float*>(d.workspace);
-    }
-  }
+  plan_splitk(P, KC);
   const int nitems = P.ntiles * P.ksplit;
   const int G = nitems < 256 ? nitems : 256;
   dim3 grid((unsigned)G);
@@ -556,14 +573,7 @@ int launch_spike_mm_ws(const GemmParams& Pin, bool conv, hipStream_t s) {
   if (rc) return rc;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  if (P.ksplit > 1) {
-    const int64_t quads = d.M * (d.N / 4);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, P.partial, P.ksplit, d.M,
-                       d.N, d.bias, d.alpha, d.beta, d.resid, d.out_rowmap, d.out, d.ldo);
-    e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-  }
-  return 0;
+  return launch_splitk_reduce(P, s);
 }
 
 }  // namespace sdfmm

@@ -19,7 +19,7 @@ SDF_LIF, SDF_PSN, SDF_IF = 0, 1, 2
 KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
 
 EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
-           "sdf_split_weight_bf16", "sdf_qk_gate_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd")
+           "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd")
 
 
 class SdfError(RuntimeError):
@@ -51,7 +51,7 @@ class SpikeGemmDesc(C.Structure):
                 ("psn_w", C.c_void_p), ("psn_b", C.c_void_p),
                 ("pos_count", C.c_int64), ("pos_inner", C.c_int64), ("pos_ostride", C.c_int64), ("t_stride", C.c_int64),
                 ("add", C.c_void_p), ("add_prows", C.c_int64), ("out_spike", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("acc_scale", C.c_float), ("out_rows", C.c_int64)]
 
 
 class SpikeConvDesc(C.Structure):
@@ -178,12 +178,32 @@ def psn_fwd(x, W, b, out_dtype=torch.float32):
 
 
 def split_weight(W, nsplit=3):
-    """fp32 weight (N,K) -> bf16 planes (nsplit,N,K) stored as int16 bit patterns (sdf_split_weight_bf16)."""
+    """fp32 weight (N,K) -> 16-bit planes (nsplit,N,K) stored as int16 bit patterns.
+    nsplit 1 / 3: bf16 planes (sdf_split_weight_bf16).  nsplit 2: two fp16 planes of scale * W
+    (sdf_split_weight_f16x2) with scale the power of two that puts max|W| in [2^14, 2^15); the matching accumulator
+    scale 1 / scale travels with the tensor as the attribute `sdf_acc_scale`."""
     W = W.contiguous()
     planes = torch.empty((nsplit,) + tuple(W.shape), dtype=torch.int16, device=W.device)
+    if nsplit == 2:
+        import math
+        mx = float(W.detach().abs().max())
+        scale = 2.0 ** (14 - math.floor(math.log2(mx))) if mx > 0 and math.isfinite(mx) else 1.0
+        scale = min(max(scale, 2.0 ** -100), 2.0 ** 100)
+        _check(lib().sdf_split_weight_f16x2(C.c_void_p(_ptr(W, torch.float32)), C.c_void_p(planes.data_ptr()),
+                                            C.c_int64(W.numel()), C.c_float(scale), _stream()), "sdf_split_weight_f16x2")
+        planes.sdf_acc_scale = 1.0 / scale
+        return planes
     _check(lib().sdf_split_weight_bf16(C.c_void_p(_ptr(W, torch.float32)), C.c_void_p(planes.data_ptr()),
                                        C.c_int64(W.numel()), C.c_int(nsplit), _stream()), "sdf_split_weight_bf16")
     return planes
+
+
+def _acc_scale(Wp):
+    if Wp.shape[0] != 2:
+        return 0.0
+    if not hasattr(Wp, "sdf_acc_scale"):
+        raise SdfError("fp16 weight planes without their scale: use the tensor returned by split_weight(W, 2) as is")
+    return Wp.sdf_acc_scale
 
 
 def spike_gemm(A, Wp, out, M, N, K, lda=None, ldo=None, bias=None, alpha=None, beta=None, resid=None,
@@ -195,9 +215,11 @@ def spike_gemm(A, Wp, out, M, N, K, lda=None, ldo=None, bias=None, alpha=None, b
     d.M, d.N, d.K = M, N, K
     d.lda = K if lda is None else lda
     d.ldo = N if ldo is None else ldo
-    d.nsplit = Wp.shape[0]
+    d.nsplit, d.acc_scale = Wp.shape[0], _acc_scale(Wp)
     d.bias, d.alpha, d.beta = _ptr(bias, torch.float32), _ptr(alpha, torch.float32), _ptr(beta, torch.float32)
     d.resid, d.out_rowmap = _ptr(resid, torch.float32), _ptr(out_rowmap, torch.int32)
+    if out_rowmap is not None:
+        d.out_rows = out.numel() // d.ldo
     if zg is not None:
         d.zg_nH, d.zg_T, d.zg_B, d.zg_N1 = zg
     _set_ws(d, A)
@@ -211,7 +233,7 @@ def spike_gemm_sn(A, Wp, out_spike, N, K, T, pos_count, pos_inner, pos_ostride, 
     d = SpikeGemmDesc()
     d.A, d.Wp, d.out_spike = _ptr(A, torch.uint8), _ptr(Wp, torch.int16), _ptr(out_spike, torch.uint8)
     d.M, d.N, d.K = pos_count * T, N, K
-    d.lda, d.ldo, d.nsplit = (K if lda is None else lda), N, Wp.shape[0]
+    d.lda, d.ldo, d.nsplit, d.acc_scale = (K if lda is None else lda), N, Wp.shape[0], _acc_scale(Wp)
     d.alpha, d.beta = _ptr(alpha, torch.float32), _ptr(beta, torch.float32)
     d.sn_T, d.sn_kind, d.tau, d.v_th = T, KIND[p.kind], p.tau, p.v_th
     d.v_reset, d.soft_reset = (0.0 if p.v_reset is None else float(p.v_reset)), (1 if p.v_reset is None else 0)
@@ -290,9 +312,11 @@ def spike_conv2d(x, Wp, imgs, H, W, Cin, OH, OW, KH, KW, stride, dy, dx, out=Non
     g = d.g
     g.A, g.Wp = _ptr(x, torch.uint8), _ptr(Wp, torch.int16)
     g.M, g.N, g.K = imgs * OH * OW, Wp.shape[1], KH * KW * Cin
-    g.lda, g.ldo, g.nsplit = 0, Wp.shape[1], Wp.shape[0]
+    g.lda, g.ldo, g.nsplit, g.acc_scale = 0, Wp.shape[1], Wp.shape[0], _acc_scale(Wp)
     g.alpha, g.beta = _ptr(alpha, torch.float32), _ptr(beta, torch.float32)
     g.resid, g.out_rowmap = _ptr(resid, torch.float32), _ptr(out_rowmap, torch.int32)
+    if out_rowmap is not None and out is not None:
+        g.out_rows = out.numel() // g.ldo
     if sn is not None:
         g.out_spike = _ptr(out_spike, torch.uint8)
         g.sn_T, g.sn_kind, g.tau, g.v_th = sn_T, KIND[sn.kind], sn.tau, sn.v_th

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Bisect a patch-embedding mismatch: the engine's patch_embed under kernel / weight-plane settings vs the CPU oracle."""
+import os, sys, torch
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import test_engine_gpu as T
+from oracle import sdformer_oracle as O
+from sdformerflow_amd.synthetic import synth_voxel
+
+kind = sys.argv[1] if len(sys.argv) > 1 else "psn"
+torch.set_num_threads(16)
+chunk = O.prepare_chunk(synth_voxel(1, 10, 288, 384, seed=1235))
+model, sd, ocfg = T.build(kind)
+with torch.no_grad():
+    ref = O.patch_embed(chunk, sd, "sttmultires_unet.encoders.swin3d.patch_embed.", ocfg["neuron"], 10).permute(1, 0, 3, 4, 2)
+sc = ref.abs().mean()
+model = model.cuda()
+for ns, pp in ((3, "0"), (3, "1"), (2, "1")):
+    os.environ["SDF_CONV_PP"] = pp
+    model.gemm_nsplit = ns
+    model._engine = None if hasattr(model, "_engine") else None
+    from sdformerflow_amd.engine import MSFlowEngine
+    eng = MSFlowEngine(model)
+    with torch.no_grad():
+        x = eng.patch_embed(chunk.cuda()).float().cpu()
+    d = (x - ref).abs()
+    print(kind, "nsplit", ns, "pp", pp, "mismatch rate vs oracle", float((d > 1e-4 * sc).float().mean()), "max", float(d.max()), flush=True)
+
+# ---- per-launch bisect: record every conv launch's output under (3, ws) and (2, pp) and report the first that differs
+from sdformerflow_amd import hip as H
+from sdformerflow_amd.engine import MSFlowEngine
+logs = {}
+orig = H.spike_conv2d
+def rec(tag):
+    def f(x, Wp, *a, **k):
+        r = orig(x, Wp, *a, **k)
+        logs.setdefault(tag, []).append((x.clone(), r.clone(), dict(nsplit=Wp.shape[0], shape=tuple(r.shape), sn=k.get("sn") is not None,
+                                                                    resid=k.get("resid") is not None)))
+        return r
+    return f
+for ns, pp in ((3, "0"), (2, "1")):
+    os.environ["SDF_CONV_PP"] = pp
+    model.gemm_nsplit = ns
+    eng = MSFlowEngine(model)
+    import sdformerflow_amd.engine as E
+    E.hip.spike_conv2d = rec((ns, pp))
+    with torch.no_grad():
+        eng.patch_embed(chunk.cuda())
+E.hip.spike_conv2d = orig
+for i, (a, b) in enumerate(zip(logs[(3, "0")], logs[(2, "1")])):
+    same_in = bool((a[0] == b[0]).all())
+    d = (a[1].float() - b[1].float()).abs()
+    print(i, a[2], "inputs identical:", same_in, "out mismatch rate", float((d > 1e-4 * a[1].float().abs().mean()).float().mean()), "max", float(d.max()), flush=True)

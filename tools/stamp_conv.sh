@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 cp sdformerflow_amd/csrc/libsdformerflow_hip.so /tmp/lib_product.so
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -DSDF_STAMP -c sdformerflow_amd/csrc/spike_mm_ws.hip -o /tmp/ws_stamp.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-slp-vectorize -Wno-pass-failed -DSDF_STAMP -c sdformerflow_amd/csrc/spike_mm_ws.hip -o /tmp/ws_stamp.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o sdformerflow_amd/csrc/libsdformerflow_hip.so /tmp/ws_stamp.o $(ls sdformerflow_amd/csrc/obj/*.o | grep -v spike_mm_ws)
 python3 - "$@" <<'PY'
 import ctypes, sys, os, torch
