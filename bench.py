@@ -75,10 +75,12 @@ def time_dominant_kernels(model, iters=20):
     torch.cuda.synchronize()
     t_conv = e0.elapsed_time(e1) / iters * 1e-3
     flops = 2.0 * imgs * H * W * Cc * 9 * Cc                    # algorithmic: one multiply-add per (pixel, cout, tap, cin)
-    gemm = {"kernel": "sdfmm::spike_mm_ws_kernel<3,0,true> (3x3 spike conv 96->96 @ 10x144x192, BN + residual epilogue)",
+    ns = int(rb.w2.shape[0])
+    gemm = {"kernel": f"sdfmm::spike_mm_pp_kernel<{ns},0,true> (3x3 spike conv 96->96 @ 10x144x192, BN + residual epilogue)",
             "bound": "mfma", "achieved": flops / t_conv / 1e12, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
             "us_per_launch": t_conv * 1e6, "traffic": None,
-            "note": "algorithmic flops; the kernel issues 3 bf16 MFMAs per product (fp32-grade weights), i.e. 3x this on the matrix pipe"}
+            "note": f"algorithmic flops (2 per multiply-add of the convolution); the kernel issues {ns} 16-bit MFMAs per product "
+                    f"(fp32 weights carried as {ns} planes), i.e. {ns}x this on the matrix pipe; dense peak of the f16/bf16 MFMA"}
     gemm["frac"] = gemm["achieved"] / gemm["peak"]
     # neuron: T=10 over the stage-0 MLP hidden tensor shape (10 x 72*96*384 fp32 in, u8 out)
     blk = eng.stages[0][0]
@@ -183,8 +185,8 @@ def main():
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: MS_SpikingformerFlowNet_en4 forward, batch 1 per GPU, 10-bin 288x384 "
-                                   "voxel, neuron=" + args.neuron + "; spike GEMMs and spike convolutions on bf16 MFMA with "
-                                   "3-plane (fp32-grade) weights and fp32 accumulate; replicas per GPU"},
+                                   "voxel, neuron=" + args.neuron + f"; spike GEMMs and spike convolutions on 16-bit MFMA with "
+                                   f"{model.gemm_nsplit}-plane fp32-grade weights and fp32 accumulate; replicas per GPU"},
             "roofline": gemm, "roofline_neuron": neuron,
             "attention_gemm_roofline_frac": 183.7e9 / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12),
         }

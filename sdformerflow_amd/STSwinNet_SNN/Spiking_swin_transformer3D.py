@@ -116,7 +116,7 @@ class Spiking_BN_WindowAttention3D(nn.Module):
             raise NotImplementedError("forward-only")
         with torch.no_grad():
             Tq, B_, Wh, Ww, C = x.shape
-            N1, dev, nsplit = Wh * Ww, x.device, 3
+            N1, dev, nsplit = Wh * Ww, x.device, 2
             M, n = Tq * B_ * N1, B_ * N1 * C
             xs = x.reshape(M, C).to(torch.uint8).contiguous()               # SEW blocks feed spikes
             f = torch.empty((M, C), dtype=torch.float32, device=dev)

@@ -111,22 +111,39 @@ def test_split_weight_reconstructs_fp32():
     assert (rec - W.double()).abs().max() <= 2.0 ** -24 * W.abs().max()
 
 
+def test_split_weight_f16x2_carries_22_bits():
+    W = rnd((96, 384), 12, -0.2, 0.2)
+    W[0, 0], W[0, 1], W[0, 2] = 1.0, -3.0e-5, 1.0e-9
+    planes = hip.split_weight(W.to(DEV), 2)
+    inv = planes.sdf_acc_scale
+    assert inv > 0 and np.log2(inv) == int(np.log2(inv))         # a power of two: the rescale is exact
+    rec = planes.cpu().view(torch.float16).double().sum(0) * inv
+    err = (rec - W.double()).abs()
+    assert (err <= 2.0 ** -22 * W.double().abs() + 2.0 ** -24 * inv).all()    # 22 bits; fp16-subnormal floor for tiny weights
+    assert float(planes.cpu().view(torch.float16).abs().max()) < 2.0 ** 15
+
+
+PLANES = [2, 3]        # weight formats of the spike matmuls: 2 = fp16 hi+lo (scaled), 3 = bf16 hi+mid+lo
+
+
 def spikes(shape, seed, rate=0.3):
     return (rnd(shape, seed, 0.0, 1.0) < rate).to(torch.uint8)
 
 
+@pytest.mark.parametrize("ns", PLANES)
 @pytest.mark.parametrize("M,N,K", [(162 * 4, 96, 96), (1000, 384, 96), (333, 96, 384), (256, 192, 768), (130, 64, 32)])
-def test_spike_gemm_plain(M, N, K):
+def test_spike_gemm_plain(M, N, K, ns):
     A = spikes((M, K), 20 + M)
     W = rnd((N, K), 21, -0.3, 0.3)
     ref = A.double() @ W.double().t()
     out = torch.full((M, N), float("nan"), device=DEV)
-    hip.spike_gemm(A.to(DEV), hip.split_weight(W.to(DEV), 3), out, M, N, K)
+    hip.spike_gemm(A.to(DEV), hip.split_weight(W.to(DEV), ns), out, M, N, K)
     err = (out.cpu().double() - ref).abs().max().item()
-    assert err <= 1e-5 * ref.abs().max().item(), err          # fp32-grade: 3 bf16 planes, fp32 accumulate
+    assert err <= 1e-5 * ref.abs().max().item(), err          # fp32-grade: exact / 22-bit weights, fp32 accumulate
 
 
-def test_spike_gemm_epilogue_bias_bn_resid_scatter():
+@pytest.mark.parametrize("ns", PLANES)
+def test_spike_gemm_epilogue_bias_bn_resid_scatter(ns):
     M, N, K = 500, 96, 192
     A = spikes((M, K), 30)
     W, bias = rnd((N, K), 31, -0.3, 0.3), rnd((N,), 32, -0.1, 0.1)
@@ -139,13 +156,14 @@ def test_spike_gemm_epilogue_bias_bn_resid_scatter():
     keep = perm >= 0
     ref[perm[keep].long()] = y[keep] + resid.double()[perm[keep].long()]
     out = resid.clone().to(DEV)
-    hip.spike_gemm(A.to(DEV), hip.split_weight(W.to(DEV), 3), out, M, N, K, bias=bias.to(DEV), alpha=alpha.to(DEV),
+    hip.spike_gemm(A.to(DEV), hip.split_weight(W.to(DEV), ns), out, M, N, K, bias=bias.to(DEV), alpha=alpha.to(DEV),
                    beta=beta.to(DEV), resid=out, out_rowmap=perm.to(DEV))
     assert (out.cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("ns", PLANES)
 @pytest.mark.parametrize("B_,nH", [(4, 3), (2, 6), (1, 12)])
-def test_spike_gemm_head_scramble(B_, nH):
+def test_spike_gemm_head_scramble(B_, nH, ns):
     """A addressed through Z[t,b,n,g*32+d] = E_flat[((((b*nH+g)*2+t)*81+n)*32+d] (:709-710)."""
     Tq, N1, hd = 2, 81, 32
     Cc = nH * hd
@@ -155,7 +173,7 @@ def test_spike_gemm_head_scramble(B_, nH):
     W = rnd((Cc, Cc), 41, -0.3, 0.3)
     ref = Z.double() @ W.double().t()
     out = torch.empty((Tq * B_ * N1, Cc), device=DEV)
-    hip.spike_gemm(E.to(DEV), hip.split_weight(W.to(DEV), 3), out, Tq * B_ * N1, Cc, Cc, zg=(nH, Tq, B_, N1))
+    hip.spike_gemm(E.to(DEV), hip.split_weight(W.to(DEV), ns), out, Tq * B_ * N1, Cc, Cc, zg=(nH, Tq, B_, N1))
     assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
 
 
@@ -211,10 +229,11 @@ def test_win_attn_sew_linear(with_mask, nH):
 
 
 # ---------------------------------------------------------------- spike GEMM with the fused neuron epilogue
+@pytest.mark.parametrize("ns", PLANES)
 @pytest.mark.parametrize("kind", ["lif", "psn"])
 @pytest.mark.parametrize("T,B,HW,K,N", [(10, 2, 50, 96, 384), (10, 1, 37, 192, 96), (2, 1, 81 * 5, 96, 96), (4, 3, 20, 32, 64),
                                          (20, 1, 9, 96, 96), (5, 2, 33, 64, 32)])
-def test_spike_gemm_fused_neuron(kind, T, B, HW, K, N):
+def test_spike_gemm_fused_neuron(kind, T, B, HW, K, N, ns):
     """SN_T(BN(A W^T) [+ add]) as one kernel vs GEMM(fp64) -> C oracle neuron.  Rows are (b, t, hw) like the MLP
     hidden layer (Spiking_swin_transformer3D.py:170-174).  The pre-activation differs from the fp64 one by fp32
     rounding, so a spike may flip only when it is within that rounding of the threshold: rate bound 2e-4."""
@@ -230,7 +249,7 @@ def test_spike_gemm_fused_neuron(kind, T, B, HW, K, N):
     ref = R.neuron_ref(x, kind, 2.0, 0.1, None, psn_w=Wn, psn_b=bn).permute(1, 0, 2, 3)
     out = torch.zeros((B * T * HW, N), dtype=torch.uint8, device=DEV)
     p = hip.NeuronParams(kind, 2.0, 0.1, None, Wn.to(DEV), bn.to(DEV))
-    hip.spike_gemm_sn(A.view(-1, K).to(DEV), hip.split_weight(W.to(DEV), 3), out, N, K, T, B * HW, HW, T * HW, HW, p,
+    hip.spike_gemm_sn(A.view(-1, K).to(DEV), hip.split_weight(W.to(DEV), ns), out, N, K, T, B * HW, HW, T * HW, HW, p,
                       alpha=alpha.to(DEV), beta=beta.to(DEV), add=add.to(DEV), add_prows=7)
     got = out.cpu().view(B, T, HW, N).float()
     rate = (got != ref).float().mean().item()
@@ -239,8 +258,10 @@ def test_spike_gemm_fused_neuron(kind, T, B, HW, K, N):
 
 
 # ---------------------------------------------------------------- spike convolution (implicit GEMM)
-@pytest.mark.parametrize("imgs,H,W,Cin,Cout,stride", [(3, 20, 24, 48, 96, 2), (2, 18, 22, 96, 96, 1), (2, 9, 12, 192, 192, 1)])
-def test_spike_conv3x3_fp32_epilogue(imgs, H, W, Cin, Cout, stride):
+@pytest.mark.parametrize("ns", PLANES)
+@pytest.mark.parametrize("imgs,H,W,Cin,Cout,stride", [(3, 20, 24, 48, 96, 2), (2, 18, 22, 96, 96, 1), (2, 9, 12, 192, 192, 1),
+                                                      (10, 72, 96, 96, 96, 1)])
+def test_spike_conv3x3_fp32_epilogue(imgs, H, W, Cin, Cout, stride, ns):
     """3x3 / pad 1 convolution on NHWC u8 spikes + BN + residual vs torch conv2d in fp64 (1e-5 relative)."""
     x = spikes((imgs, H, W, Cin), 90 + Cin)
     w = rnd((Cout, Cin, 3, 3), 91, -0.1, 0.1)
@@ -250,31 +271,42 @@ def test_spike_conv3x3_fp32_epilogue(imgs, H, W, Cin, Cout, stride):
     ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, stride, 1).permute(0, 2, 3, 1)
     ref = ref.reshape(-1, Cout) * alpha.double() + beta.double() + resid.double()
     out = torch.empty((imgs * OH * OW, Cout), device=DEV)
-    hip.spike_conv2d(x.to(DEV), hip.pack_conv_weight(w.to(DEV), 3), imgs, H, W, Cin, OH, OW, 3, 3, stride, (-1, 0, 1), (-1, 0, 1),
+    hip.spike_conv2d(x.to(DEV), hip.pack_conv_weight(w.to(DEV), ns), imgs, H, W, Cin, OH, OW, 3, 3, stride, (-1, 0, 1), (-1, 0, 1),
                      out=out, alpha=alpha.to(DEV), beta=beta.to(DEV), resid=resid.to(DEV))
     assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
 
 
-def test_spike_conv3x3_fused_neuron():
-    """conv -> BN -> LIF over T=10 in one kernel (MS_ResBlock conv1 -> norm1 -> sn2, Spiking_modules.py:914-920)."""
-    T, B, H, W, Cc = 10, 2, 7, 9, 96
+@pytest.mark.parametrize("ns", PLANES)
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+@pytest.mark.parametrize("B,H,W", [(2, 7, 9), (1, 72, 96)])
+def test_spike_conv3x3_fused_neuron(kind, B, H, W, ns):
+    """conv -> BN -> neuron over T=10 in one kernel (MS_ResBlock conv1 -> norm1 -> sn2, Spiking_modules.py:914-920).
+    The 72 x 96 case runs several tiles per workgroup with both consumer groups and the producers busy - the
+    configuration in which SLP-packed f32 FMAs once corrupted the PSN sums of the last 16 lanes."""
+    T, Cc = 10, 96
     x = spikes((T * B, H, W, Cc), 95)
     w = rnd((Cc, Cc, 3, 3), 96, -0.1, 0.1)
     alpha, beta = rnd((Cc,), 97, 0.5, 1.5), rnd((Cc,), 98, -0.2, 0.2)
+    Wn, bn = rnd((T, T), 85, -0.5, 0.5) + 0.5 * torch.eye(T), torch.full((T,), -0.1)
     h = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 1, 1).permute(0, 2, 3, 1)
     h = (h * alpha.double() + beta.double()).float().view(T, B * H * W * Cc)
-    ref = R.neuron_ref(h, "lif", 2.0, 0.1, None).view(T * B, H, W, Cc)
-    out = torch.zeros((T * B * H * W, Cc), dtype=torch.uint8, device=DEV)
+    ref = R.neuron_ref(h, kind, 2.0, 0.1, None, psn_w=Wn, psn_b=bn).view(T * B, H, W, Cc)
     n = B * H * W
-    hip.spike_conv2d(x.to(DEV), hip.pack_conv_weight(w.to(DEV), 3), T * B, H, W, Cc, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1),
-                     out_spike=out, alpha=alpha.to(DEV), beta=beta.to(DEV), sn=hip.NeuronParams("lif", 2.0, 0.1, None), sn_T=T,
-                     pos=(n, n, 0, n))
-    rate = (out.cpu().view(T * B, H, W, Cc).float() != ref).float().mean().item()
+    sn = hip.NeuronParams(kind, 2.0, 0.1, None, Wn.to(DEV), bn.to(DEV))
+    outs = []
+    for _ in range(2):
+        out = torch.zeros((T * B * H * W, Cc), dtype=torch.uint8, device=DEV)
+        hip.spike_conv2d(x.to(DEV), hip.pack_conv_weight(w.to(DEV), ns), T * B, H, W, Cc, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1),
+                         out_spike=out, alpha=alpha.to(DEV), beta=beta.to(DEV), sn=sn, sn_T=T, pos=(n, n, 0, n))
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])                         # deterministic run to run
+    rate = (outs[0].view(T * B, H, W, Cc).float() != ref).float().mean().item()
     assert rate <= 2e-4, rate
     assert 0.03 < ref.mean() < 0.97
 
 
-def test_spike_conv_transpose_parity_classes():
+@pytest.mark.parametrize("ns", PLANES)
+def test_spike_conv_transpose_parity_classes(ns):
     """ConvTranspose2d(k=3, s=2, p=1, output_padding=1) on spikes as four parity-class implicit GEMMs
     (MS_SpikingTransposeDecoderLayer, Spiking_modules.py:416-446) vs torch conv_transpose2d in fp64."""
     from sdformerflow_amd.engine import deconv_classes
@@ -286,13 +318,14 @@ def test_spike_conv_transpose_parity_classes():
     ref = torch.nn.functional.conv_transpose2d(x[..., :Cin].permute(0, 3, 1, 2).double(), w.double(), None, 2, 1, 1)
     ref = ref.permute(0, 2, 3, 1).reshape(-1, Cout)
     out = torch.full((imgs * 2 * H * 2 * W, Cout), float("nan"), device=DEV)
-    for cls in deconv_classes(w.to(DEV), imgs, H, W, cp, 3, DEV):
+    for cls in deconv_classes(w.to(DEV), imgs, H, W, cp, ns, DEV):
         hip.spike_conv2d(x.to(DEV), cls["Wp"], imgs, H, W, cp, H, W, cls["KH"], cls["KW"], 1, cls["dy"], cls["dx"], out=out,
                          out_rowmap=cls["rowmap"])
     assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
 
 
-def test_spike_conv_small_m_split_k():
+@pytest.mark.parametrize("ns", PLANES)
+def test_spike_conv_small_m_split_k(ns):
     """Small-M / large-K convolution (U-Net res-block shape: 10 x 9 x 12 pixels, 768 -> 768 channels): the library
     splits K over workgroups and reduces the partial sums in k order; same 1e-5 bound, and bit-identical run to run."""
     imgs, H, W, Cc = 10, 9, 12, 768
@@ -302,7 +335,7 @@ def test_spike_conv_small_m_split_k():
     resid = rnd((imgs * H * W, Cc), 114)
     ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 1, 1).permute(0, 2, 3, 1)
     ref = ref.reshape(-1, Cc) * alpha.double() + beta.double() + resid.double()
-    Wp = hip.pack_conv_weight(w.to(DEV), 3)
+    Wp = hip.pack_conv_weight(w.to(DEV), ns)
     outs = []
     for _ in range(2):
         out = torch.empty((imgs * H * W, Cc), device=DEV)
