@@ -198,6 +198,11 @@ int sdf_split_weight_f16x2(const float* W, uint16_t* planes, int64_t n, float sc
 int sdf_qk_gate_fwd(const uint8_t* q, const uint8_t* k, uint8_t* e, int Tq, int64_t rows, int C,
                     int kind, float tau, float v_th, float v_reset, int soft_reset,
                     const float* psn_w, const float* psn_b, void* stream);
+/* Same, with q and k rows ldq / ldk bytes apart (multiples of 16, >= C): q and k may be the two halves of the
+ * (Tq*rows, 2C) output of ONE fused-neuron spike GEMM over the stacked weights [Wq; Wk].  e stays (Tq, rows, C). */
+int sdf_qk_gate_strided_fwd(const uint8_t* q, const uint8_t* k, uint8_t* e, int Tq, int64_t rows, int C,
+                            int64_t ldq, int64_t ldk, int kind, float tau, float v_th, float v_reset,
+                            int soft_reset, const float* psn_w, const float* psn_b, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Eval BatchNorm affine (+ residual):  out = fmaf(x, alpha[c], beta[c]) (+ resid), c = (i/inner) % C.

@@ -12,6 +12,7 @@ constexpr int TQ_MAX = 4;
 struct GateParams {
   const uint8_t* q; const uint8_t* k; uint8_t* e;
   int Tq; int64_t rows; int C; int G;
+  int64_t ldq, ldk;              // row strides of q and k in bytes (>= C; the fused q|k GEMM writes both into one buffer)
   int kind; float tau, inv_tau, v_th, v_reset; int soft;
   const float* psn_w; const float* psn_b;
 };
@@ -21,17 +22,20 @@ __global__ __launch_bounds__(256) void qk_gate_kernel(GateParams P) {
   if (i >= P.rows * P.G) return;
   const int64_t step = P.rows * (int64_t)P.C;
   const int64_t off = i * 32;                       // (row*G + g)*32 == row*C + g*32
+  const int64_t row = i / P.G;
+  const int g32 = (int)(i - row * P.G) * 32;
+  const int64_t qoff = row * P.ldq + g32, koff = row * P.ldk + g32;
   float a[TQ_MAX];
   uint4 k0[TQ_MAX], k1[TQ_MAX];
 #pragma unroll
   for (int t = 0; t < TQ_MAX; ++t) {
     if (t < P.Tq) {
-      const uint4* qp = reinterpret_cast<const uint4*>(P.q + t * step + off);
+      const uint4* qp = reinterpret_cast<const uint4*>(P.q + t * P.rows * P.ldq + qoff);
       uint4 x0 = qp[0], x1 = qp[1];
       int s = __popc(x0.x) + __popc(x0.y) + __popc(x0.z) + __popc(x0.w) + __popc(x1.x) + __popc(x1.y) + __popc(x1.z) +
               __popc(x1.w);
       a[t] = (float)s;
-      const uint4* kp = reinterpret_cast<const uint4*>(P.k + t * step + off);
+      const uint4* kp = reinterpret_cast<const uint4*>(P.k + t * P.rows * P.ldk + koff);
       k0[t] = kp[0];
       k1[t] = kp[1];
     }
@@ -80,17 +84,19 @@ __global__ __launch_bounds__(256) void qk_gate_kernel(GateParams P) {
 }
 }  // namespace
 
-extern "C" int sdf_qk_gate_fwd(const uint8_t* q, const uint8_t* k, uint8_t* e, int Tq, int64_t rows, int C, int kind,
-                               float tau, float v_th, float v_reset, int soft_reset, const float* psn_w,
-                               const float* psn_b, void* stream) {
+extern "C" int sdf_qk_gate_strided_fwd(const uint8_t* q, const uint8_t* k, uint8_t* e, int Tq, int64_t rows, int C, int64_t ldq,
+                                       int64_t ldk, int kind, float tau, float v_th, float v_reset, int soft_reset,
+                                       const float* psn_w, const float* psn_b, void* stream) {
   if (!q || !k || !e) return SDF_E_NULL;
   if (Tq < 1 || Tq > TQ_MAX || rows < 1 || C < 32 || C % 32) return SDF_E_SHAPE;
+  if (ldq < C || ldk < C || ldq % 16 || ldk % 16) return SDF_E_SHAPE;
   if (kind != SDF_LIF && kind != SDF_PSN && kind != SDF_IF) return SDF_E_DTYPE;
   if (kind == SDF_PSN && (!psn_w || !psn_b)) return SDF_E_NULL;
   if (kind == SDF_LIF && !(tau > 1.f)) return SDF_E_SHAPE;
   if (!sdf_aligned(q, 16) || !sdf_aligned(k, 16) || !sdf_aligned(e, 16)) return SDF_E_ALIGN;
   GateParams P;
   P.q = q; P.k = k; P.e = e; P.Tq = Tq; P.rows = rows; P.C = C; P.G = C / 32;
+  P.ldq = ldq; P.ldk = ldk;
   P.kind = kind; P.tau = tau; P.v_th = v_th; P.v_reset = v_reset; P.soft = soft_reset;
   int ex;
   P.inv_tau = (kind == SDF_LIF && frexpf(tau, &ex) == 0.5f) ? 1.0f / tau : 0.f;
@@ -99,4 +105,10 @@ extern "C" int sdf_qk_gate_fwd(const uint8_t* q, const uint8_t* k, uint8_t* e, i
   hipLaunchKernelGGL(qk_gate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sdf_stream(stream), P);
   SDF_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int sdf_qk_gate_fwd(const uint8_t* q, const uint8_t* k, uint8_t* e, int Tq, int64_t rows, int C, int kind,
+                               float tau, float v_th, float v_reset, int soft_reset, const float* psn_w,
+                               const float* psn_b, void* stream) {
+  return sdf_qk_gate_strided_fwd(q, k, e, Tq, rows, C, C, C, kind, tau, v_th, v_reset, soft_reset, psn_w, psn_b, stream);
 }

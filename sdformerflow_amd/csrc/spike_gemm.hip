@@ -188,7 +188,6 @@ __global__ __launch_bounds__(64 * WAVES) void spike_gemm_kernel(GemmParams P) {
   f32x16 acc[RB][NB];
   const float asc = P.acc_scale;                     // 1 / weight scale of the fp16 planes (a power of two), else 1
   const bool soft = d.soft_reset != 0;
-  const bool reset0 = soft || d.v_reset == 0.f;
 
   // ---- software pipeline over (tile, stage) ----
   int tl = t_begin, st = 0;                         // stage being computed
@@ -358,19 +357,7 @@ __global__ __launch_bounds__(64 * WAVES) void spike_gemm_kernel(GemmParams P) {
                 sp[t] = hh >= 0.f ? 1.f : 0.f;
               }
             } else {
-              float v = soft ? 0.f : d.v_reset;
-#pragma unroll
-              for (int t = 0; t < T; ++t) {
-                float hcur;
-                if (d.sn_kind == SDF_IF) {
-                  hcur = v + xs[t];
-                } else {
-                  const float dl = reset0 ? (xs[t] - v) : (xs[t] - (v - d.v_reset));
-                  hcur = v + ((P.inv_tau != 0.f) ? dl * P.inv_tau : dl / d.tau);
-                }
-                sp[t] = (hcur - d.v_th >= 0.f) ? 1.f : 0.f;
-                v = soft ? (hcur - sp[t] * d.v_th) : ((1.f - sp[t]) * hcur + sp[t] * d.v_reset);
-              }
+              lif_steps<T>(xs, sp, d.sn_kind, soft, d.v_reset, d.v_th, d.tau, P.inv_tau);
             }
 #pragma unroll
             for (int t = 0; t < T; ++t) {
@@ -514,18 +501,19 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
     const int c = e[0] - '0';
     if (c >= 0 && c < 4 && ok(c)) cfg = c;
   }
-  // warp-specialised 256 x 96 kernel (spike_mm_ws.hip) for the shapes it is built for
+  // Ping-pong 256 x 96 kernel (spike_mm_pp.hip) where it measured faster than the small-tile kernel on the model's
+  // layers (tools/gemm_shapes.py, profiles/r1_gemm_shapes.txt): the fused T = 10 neuron epilogue (the MLP's fc1 - long
+  // epilogues that the other consumer group hides) and fp32 epilogues with a long K loop over many rows or a very
+  // long one.  SDF_GEMM_WS: 0 = never, 2 = whenever legal, 1 = the barrier-synchronised predecessor (spike_mm_ws.hip).
   {
-    const char* e = getenv("SDF_GEMM_WS");                   // tuning override: 0 = never, 1 = whenever legal
-    const bool legal = d->N % 96 == 0 && (d->sn_T == 0 || d->sn_T == 2 || d->sn_T == 10);
-    const int64_t ws_tiles = ((spike ? d->pos_count : d->M) + (spike ? 8 * (32 / d->sn_T) : 256) - 1) /
-                             (spike ? 8 * (32 / d->sn_T) : 256) * (d->N / 96);
-    bool use_ws = false;          // measured: the small-tile kernels win on every Linear of the model (K <= 3072, epilogue-bound)
-    (void)ws_tiles;
-    if (e && e[0] == '0') use_ws = false;
-    if (e && e[0] == '1') use_ws = legal && d->nsplit != 2;
-    if (use_ws) return launch_spike_mm_ws(P, false, sdf_stream(stream));
-    if (e && e[0] == '2' && legal && spike_mm_pp_supports(P, false)) return launch_spike_mm_pp(P, false, sdf_stream(stream));
+    const char* e = getenv("SDF_GEMM_WS");
+    const bool legal = d->N % 96 == 0 && spike_mm_pp_supports(P, false);
+    bool use_pp = legal && ((spike && d->sn_T == 10) || (!spike && ((d->K >= 384 && d->M >= 32768) || d->K >= 2048)));
+    if (e && e[0] == '0') use_pp = false;
+    if (e && e[0] == '2') use_pp = legal;
+    if (e && e[0] == '1' && d->N % 96 == 0 && d->nsplit != 2 && (d->sn_T == 0 || d->sn_T == 2 || d->sn_T == 10))
+      return launch_spike_mm_ws(P, false, sdf_stream(stream));
+    if (use_pp) return launch_spike_mm_pp(P, false, sdf_stream(stream));
   }
   if (!ok(cfg)) return SDF_E_SHAPE;
   const int nb = CFG_NB[cfg], rb = CFG_RB[cfg], waves = CFG_WAVES[cfg];

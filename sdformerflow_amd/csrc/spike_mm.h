@@ -50,6 +50,37 @@ __device__ __forceinline__ bf16x8 expand_spikes(uint2 v) {
 }
 
 
+// LIF / IF recurrence over the T pre-activations a lane holds (same separately-rounded op sequence as neuron.hip).
+// All flags are wave-uniform; the shipped configuration (LIF, soft reset, power-of-two tau) gets a branch-free body.
+template <int T>
+__device__ __forceinline__ void lif_steps(const float (&xs)[T], float (&sp)[T], int kind, bool soft, float v_reset, float v_th,
+                                          float tau, float inv_tau) {
+  if (kind == SDF_LIF && soft && inv_tau != 0.f) {
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const float hcur = v + (xs[t] - v) * inv_tau;
+      sp[t] = (hcur - v_th >= 0.f) ? 1.f : 0.f;
+      v = hcur - sp[t] * v_th;
+    }
+    return;
+  }
+  const bool reset0 = soft || v_reset == 0.f;
+  float v = soft ? 0.f : v_reset;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    float hcur;
+    if (kind == SDF_IF) {
+      hcur = v + xs[t];
+    } else {
+      const float dl = reset0 ? (xs[t] - v) : (xs[t] - (v - v_reset));
+      hcur = v + ((inv_tau != 0.f) ? dl * inv_tau : dl / tau);
+    }
+    sp[t] = (hcur - v_th >= 0.f) ? 1.f : 0.f;
+    v = soft ? (hcur - sp[t] * v_th) : ((1.f - sp[t]) * hcur + sp[t] * v_reset);
+  }
+}
+
 // 4x4 transpose inside every quad of lanes (two DPP butterflies): in: lane q holds v[j] = X[row j][col q];
 // out: lane q holds v[k] = X[row q][col k], i.e. 16 contiguous bytes of one output row.
 __device__ __forceinline__ void quad_transpose(float (&v)[4], int q) {

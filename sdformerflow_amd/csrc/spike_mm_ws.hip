@@ -241,7 +241,6 @@ __global__ __launch_bounds__(512) void spike_mm_ws_kernel(GemmParams P) {
   const float asc = P.acc_scale;
   f32x16 acc[2][3];
   const bool soft = d.soft_reset != 0;
-  const bool reset0 = soft || d.v_reset == 0.f;
   lds_barrier();                                               // matches the producers' "stage 0 is in LDS"
 #ifdef SDF_STAMP
   unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, s_mma = 0, s_epi = 0, s_cbar = 0;
@@ -429,19 +428,7 @@ __global__ __launch_bounds__(512) void spike_mm_ws_kernel(GemmParams P) {
                 sp[t2] = hh >= 0.f ? 1.f : 0.f;
               }
             } else {
-              float v = soft ? 0.f : d.v_reset;
-#pragma unroll
-              for (int t2 = 0; t2 < T; ++t2) {
-                float hcur;
-                if (d.sn_kind == SDF_IF) {
-                  hcur = v + xs[t2];
-                } else {
-                  const float dl = reset0 ? (xs[t2] - v) : (xs[t2] - (v - d.v_reset));
-                  hcur = v + ((P.inv_tau != 0.f) ? dl * P.inv_tau : dl / d.tau);
-                }
-                sp[t2] = (hcur - d.v_th >= 0.f) ? 1.f : 0.f;
-                v = soft ? (hcur - sp[t2] * d.v_th) : ((1.f - sp[t2]) * hcur + sp[t2] * d.v_reset);
-              }
+              lif_steps<T>(xs, sp, d.sn_kind, soft, d.v_reset, d.v_th, d.tau, P.inv_tau);
             }
 #pragma unroll
             for (int t2 = 0; t2 < T; ++t2) {

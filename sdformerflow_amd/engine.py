@@ -63,6 +63,17 @@ class _Block:
         self.p = _Lin(a.proj, a.proj_bn.norm_layer, device, nsplit)
         self.pe = a.positional_encoding.detach().float().to(device).contiguous()
         self.sn_proj, self.sn_q, self.sn_k, self.sn2_q = (_np(m, device) for m in (a.proj_sn, a.sn_q, a.sn_k, a.sn2_q))
+        # q and k read the same spikes: with parameter-free neurons of equal settings (LIF / IF) they run as ONE fused GEMM
+        # over the stacked weights [Wq; Wk]; the positional term only exists for the k half (q adds zeros)
+        self.qk = None
+        sq, sk = self.sn_q, self.sn_k
+        if sq.kind != "psn" and (sq.kind, sq.tau, sq.v_th, sq.v_reset) == (sk.kind, sk.tau, sk.v_th, sk.v_reset):
+            w = torch.cat([a.linear_q.weight.detach().float(), a.linear_k.weight.detach().float()], 0).to(device).contiguous()
+            self.qk = {"Wp": hip.split_weight(w, nsplit), "alpha": torch.cat([self.q.alpha, self.k.alpha]).contiguous(),
+                       "beta": torch.cat([self.q.beta, self.k.beta]).contiguous(),
+                       # the positional table is consumed as flat (Tq, N1, C) memory (the reference's raw reshape, :678-679)
+                       "add": torch.cat([torch.zeros((self.pe.numel() // self.q.N, self.q.N), device=device),
+                                         self.pe.reshape(-1, self.q.N)], -1).contiguous()}
         m = blk.mlp
         self.fc1 = _Lin(m.fc1, m.bn1.norm_layer, device, nsplit)
         self.fc2 = _Lin(m.fc2, m.bn2.norm_layer, device, nsplit)
@@ -147,8 +158,16 @@ class MSFlowEngine:
                 self.merges.append((_Lin(d.reduction, d.norm.norm_layer, dev, ns), _np(d.sn, dev)))
         self.unet_res = [_ResBlock(rb, dev, ns) for rb in unet.resblocks]
         self.decoders = [(d.deconv[0].weight.detach(), bn_affine(d.norm_layer.norm_layer, dev), _np(d.sn, dev)) for d in unet.decoders]
-        self.preds = [(p.conv[0].weight.detach().float().reshape(p.conv[0].weight.shape[0], -1).t().contiguous(),
-                       p.conv[0].bias.detach().float(), _np(p.sn, dev)) for p in unet.preds]
+        # flow prediction = 1x1 convolution with 2 output channels on spikes: the spike GEMM with the weight rows padded
+        # to one 32-column block (columns 2.. are zero and never read back)
+        self.preds = []
+        for p in unet.preds:
+            w2 = p.conv[0].weight.detach().float().reshape(p.conv[0].weight.shape[0], -1)        # (2, Cin)
+            wp = torch.zeros((32, w2.shape[1]), dtype=torch.float32, device=dev)
+            wp[:w2.shape[0]] = w2
+            bp = torch.zeros(32, dtype=torch.float32, device=dev)
+            bp[:w2.shape[0]] = p.conv[0].bias.detach().float()
+            self.preds.append((hip.split_weight(wp, ns), bp, _np(p.sn, dev), w2.shape[0]))
         self._maps, self._deconv = {}, {}
 
     # ------------------------------------------------------------------ helpers
@@ -254,6 +273,14 @@ class MSFlowEngine:
         xs = torch.empty((M, Cc), dtype=torch.uint8, device=dev)
         hip.neuron_fwd(x, xs, Tq, 1, n, 0, 0, 0, n, blk.sn_proj, rowmap=rowmap, rowlen=Cc)
         # q = SN(BN(xs Wq^T)), k = SN(BN(xs Wk^T) + PE): GEMM with the neuron fused into its epilogue (u8 out)
+        if blk.qk is not None:
+            qk = torch.empty((M, 2 * Cc), dtype=torch.uint8, device=dev)
+            hip.spike_gemm_sn(xs, blk.qk["Wp"], qk, 2 * Cc, Cc, Tq, rows, rows, 0, rows, blk.sn_q, alpha=blk.qk["alpha"],
+                              beta=blk.qk["beta"], add=blk.qk["add"], add_prows=N1)
+            hip.qk_gate(qk, qk[:, Cc:], xs, Tq, rows, Cc, blk.sn2_q, ldq=2 * Cc, ldk=2 * Cc)      # E overwrites xs
+            hip.spike_gemm(xs, blk.p.Wp, x, M, Cc, Cc, bias=blk.p.bias, alpha=blk.p.alpha, beta=blk.p.beta, resid=x,
+                           out_rowmap=rowmap, zg=(blk.nH, Tq, B_, N1))
+            return x
         q = torch.empty((M, Cc), dtype=torch.uint8, device=dev)
         hip.spike_gemm_sn(xs, blk.q.Wp, q, Cc, Cc, Tq, rows, rows, 0, rows, blk.sn_q, alpha=blk.q.alpha, beta=blk.q.beta)
         k = torch.empty((M, Cc), dtype=torch.uint8, device=dev)
@@ -345,9 +372,11 @@ class MSFlowEngine:
             for cls in self._deconv_classes(i, B, D, h, w, cp):
                 hip.spike_conv2d(s, cls["Wp"], B * D, h, w, cp, h, w, cls["KH"], cls["KW"], 1, cls["dy"], cls["dx"], out=z,
                                  alpha=bn[0], beta=bn[1], out_rowmap=cls["rowmap"])
-            pw, pb, psn = self.preds[i]
-            sp = self._neuron_bd(z, psn, out_dtype=torch.float32)         # MS pred: SN -> conv1x1 (+bias), 2 outputs
-            preds.append(torch.addmm(pb, sp.view(-1, cout), pw).view(B, D, 2 * h, 2 * w, -1))
+            pw, pb, psn, nout = self.preds[i]
+            sp = self._neuron_bd(z, psn)                                  # MS pred: SN -> conv1x1 (+bias), 2 outputs
+            po = torch.empty((B * D * 4 * h * w, 32), dtype=torch.float32, device=y.device)
+            hip.spike_gemm(sp, pw, po, po.shape[0], 32, cout, bias=pb)
+            preds.append(po.view(B, D, 2 * h, 2 * w, 32)[..., :nout])
             y = z
         return preds
 

@@ -19,7 +19,7 @@ SDF_LIF, SDF_PSN, SDF_IF = 0, 1, 2
 KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
 
 EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
-           "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd")
+           "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd")
 
 
 class SdfError(RuntimeError):
@@ -244,16 +244,18 @@ def spike_gemm_sn(A, Wp, out_spike, N, K, T, pos_count, pos_inner, pos_ostride, 
     return out_spike
 
 
-def qk_gate(q, k, e, Tq, rows, Cch, p: NeuronParams):
-    """sdf_qk_gate_fwd on u8 spike tensors laid out (Tq, rows, C)."""
-    rc = lib().sdf_qk_gate_fwd(C.c_void_p(_ptr(q, torch.uint8)), C.c_void_p(_ptr(k, torch.uint8)),
+def qk_gate(q, k, e, Tq, rows, Cch, p: NeuronParams, ldq=None, ldk=None):
+    """sdf_qk_gate_strided_fwd on u8 spike tensors laid out (Tq, rows, C); q / k rows may be ldq / ldk bytes apart
+    (the halves of a fused q|k GEMM output)."""
+    rc = lib().sdf_qk_gate_strided_fwd(C.c_void_p(_ptr(q, torch.uint8)), C.c_void_p(_ptr(k, torch.uint8)),
                                C.c_void_p(_ptr(e, torch.uint8)), C.c_int(Tq), C.c_int64(rows), C.c_int(Cch),
+                               C.c_int64(Cch if ldq is None else ldq), C.c_int64(Cch if ldk is None else ldk),
                                C.c_int(KIND[p.kind]), C.c_float(p.tau), C.c_float(p.v_th),
                                C.c_float(0.0 if p.v_reset is None else p.v_reset),
                                C.c_int(1 if p.v_reset is None else 0),
                                C.c_void_p(_ptr(p.psn_w, torch.float32)), C.c_void_p(_ptr(p.psn_b, torch.float32)),
                                _stream())
-    _check(rc, "sdf_qk_gate_fwd")
+    _check(rc, "sdf_qk_gate_strided_fwd")
     return e
 
 
