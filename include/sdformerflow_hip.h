@@ -205,6 +205,40 @@ int sdf_qk_gate_strided_fwd(const uint8_t* q, const uint8_t* k, uint8_t* e, int 
                             int soft_reset, const float* psn_w, const float* psn_b, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Head of the patch embedding: conv3x3 / pad 1 (no bias) on the real-valued event voxel -> eval BatchNorm -> neuron over T,
+ * one kernel, spikes out.  Replaces MS_PED_Spiking_PatchEmbed_Conv_sfn.head (reference Spiking_modules.py:1770-1776).
+ *   x   (B*T, H, W, Cin) fp32, NHWC, image index = b*T + t          w (Cout, Cin, 3, 3) fp32 (the module's layout)
+ *   out (B*T, H, W, Cout) u8 spikes                                  alpha / beta (Cout) or NULL
+ * Accumulation: one fmaf chain per output in (ky, kx, cin) order starting from 0.  Built for (Cin, Cout) in
+ * {(2,32), (2,48), (2,64), (4,48)}, T in {5, 10, 20}, W % 16 == 0; anything else returns SDF_E_SHAPE and the caller keeps
+ * its library convolution + sdf_neuron_fwd pair.
+ */
+typedef struct SdfHeadConvDesc {
+  const float* x;
+  const float* w;
+  const float* alpha;
+  const float* beta;
+  uint8_t* out;
+  int32_t B, T, H, W, Cin, Cout;
+  int32_t sn_kind;
+  float tau, v_th, v_reset;
+  int32_t soft_reset;
+  const float* psn_w;
+  const float* psn_b;
+} SdfHeadConvDesc;
+
+int sdf_head_conv_sn_fwd(const SdfHeadConvDesc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Flow read-out: out[b,c,Y,X] = sum_t pred[b,t,ys,xs,c] with (ys, xs) the nearest-neighbour source pixel of (Y, X) for
+ * scale factors (scale_y, scale_x) - exactly F.interpolate(pred.sum(time), scale_factor=...)
+ * (reference Spiking_STSwinNet.py:289-303).  pred is (B, D, h, w, ldp) fp32 of which the first C columns are read;
+ * out is (B, C, H, W) fp32.
+ */
+int sdf_flow_out_fwd(const float* pred, float* out, int B, int D, int h, int w, int64_t ldp, int C, int H, int W,
+                     float scale_y, float scale_x, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Eval BatchNorm affine (+ residual):  out = fmaf(x, alpha[c], beta[c]) (+ resid), c = (i/inner) % C.
  * Replaces: SpikingNormLayer after a convolution and the membrane (MS) shortcut add
  * (reference Spiking_modules.py:922-926, 816-818).  n % 4 == 0; inner % 4 == 0 or (inner == 1, C % 4 == 0).

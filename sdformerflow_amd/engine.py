@@ -144,6 +144,7 @@ class MSFlowEngine:
         pe = sw.patch_embed
         self.num_bins, self.num_steps = pe.num_bins, pe.num_steps
         self.head_w = pe.head.conv[0].weight.detach().contiguous(memory_format=torch.channels_last)
+        self.head_w_oihw = pe.head.conv[0].weight.detach().float().contiguous()
         self.head_bn, self.head_sn = bn_affine(pe.head.norm_layer.norm_layer, dev), _np(pe.head.sn, dev)
         self.conv_w, self.conv_bn = _conv_planes(pe.conv.conv[0].weight, ns), bn_affine(pe.conv.norm_layer.norm_layer, dev)
         self.pe_res = [_ResBlock(rb, dev, ns) for rb in pe.residual_encoding.resblocks]
@@ -247,9 +248,13 @@ class MSFlowEngine:
         ev = x.permute(0, 2, 3, 4, 1)                                                     # (B,2,H,W,bins)
         xr = torch.stack([ev[:, i % 2, :, :, (i // 2) * T:(i // 2 + 1) * T] for i in range(num_ch)], -1)   # (B,H,W,T,ch)
         xr = xr.permute(0, 3, 1, 2, 4).contiguous().view(B * T, H, W, num_ch)               # NHWC, image = (b,t)
-        # head: real-valued 2-channel input -> stock convolution (channels_last), then BN + SN fused in the neuron kernel
-        y = F.conv2d(xr.permute(0, 3, 1, 2), self.head_w, None, 1, 1).contiguous(memory_format=torch.channels_last)
-        s = self._neuron_bd(y.permute(0, 2, 3, 1).view(B, T, H, W, -1), self.head_sn, bn=self.head_bn)
+        # head: real-valued 2-channel input -> conv + BN + SN as one kernel (shapes outside its build: library convolution,
+        # then BN + SN fused in the neuron kernel)
+        if hip.head_conv_sn_supported(T, H, W, num_ch, self.head_w_oihw.shape[0]):
+            s = hip.head_conv_sn(xr, self.head_w_oihw, B, T, H, W, self.head_sn, alpha=self.head_bn[0], beta=self.head_bn[1])
+        else:
+            y = F.conv2d(xr.permute(0, 3, 1, 2), self.head_w, None, 1, 1).contiguous(memory_format=torch.channels_last)
+            s = self._neuron_bd(y.permute(0, 2, 3, 1).view(B, T, H, W, -1), self.head_sn, bn=self.head_bn)
         m = self._conv3x3(s, self.conv_w, self.conv_w.shape[1], stride=2, bn=self.conv_bn)
         for rb in self.pe_res:
             m = self._resblock(m, rb)
@@ -332,7 +337,7 @@ class MSFlowEngine:
             for i in range(len(blocks)):
                 y = self.swin_block(y, s, i)
             if s < len(self.merges):
-                feats.append(y.clone())                     # blocks update y in place; the skip needs this stage's value
+                feats.append(y)                             # the merge writes a new tensor; nothing touches y after this
                 y = self.patch_merge(y, s)
             else:
                 feats.append(y)
@@ -387,8 +392,5 @@ class MSFlowEngine:
         x = x.float().contiguous()
         H, W = x.shape[-2:]
         preds = self.unet_tail(self.encoder(x))
-        flows = []
-        for p in preds:
-            f = p.sum(1).permute(0, 3, 1, 2)                              # sum over time, -> (B,2,h,w)
-            flows.append(F.interpolate(f, scale_factor=(H / f.shape[-2], W / f.shape[-1])))
-        return flows
+        # sum over time + nearest upsampling to the input size, one small kernel per scale
+        return [hip.flow_out(p, H, W, H / p.shape[2], W / p.shape[3]) for p in preds]

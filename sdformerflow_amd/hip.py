@@ -19,7 +19,8 @@ SDF_LIF, SDF_PSN, SDF_IF = 0, 1, 2
 KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
 
 EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
-           "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd")
+           "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd", "sdf_head_conv_sn_fwd",
+           "sdf_flow_out_fwd")
 
 
 class SdfError(RuntimeError):
@@ -58,6 +59,13 @@ class SpikeConvDesc(C.Structure):
     _fields_ = [("g", SpikeGemmDesc), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("OH", C.c_int32),
                 ("OW", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("sy", C.c_int32), ("sx", C.c_int32),
                 ("dy", C.c_int32 * 3), ("dx", C.c_int32 * 3)]
+
+
+class HeadConvDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("alpha", C.c_void_p), ("beta", C.c_void_p), ("out", C.c_void_p),
+                ("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+                ("sn_kind", C.c_int32), ("tau", C.c_float), ("v_th", C.c_float), ("v_reset", C.c_float),
+                ("soft_reset", C.c_int32), ("psn_w", C.c_void_p), ("psn_b", C.c_void_p)]
 
 
 class WinAttnDesc(C.Structure):
@@ -334,3 +342,37 @@ def spike_conv2d(x, Wp, imgs, H, W, Cin, OH, OW, KH, KW, stride, dy, dx, out=Non
         d.dx[i] = dx[i] if i < len(dx) else 0
     _check(lib().sdf_spike_conv2d_fwd(C.byref(d), _stream()), "sdf_spike_conv2d_fwd")
     return out if sn is None else out_spike
+
+
+def head_conv_sn_supported(T, H, W, Cin, Cout):
+    """Shapes sdf_head_conv_sn_fwd is built for (see include/sdformerflow_hip.h)."""
+    return (Cin, Cout) in ((2, 32), (2, 48), (2, 64), (4, 48)) and T in (5, 10, 20) and W % 16 == 0
+
+
+def head_conv_sn(x, w, B, T, H, W, p: NeuronParams, alpha=None, beta=None):
+    """sdf_head_conv_sn_fwd: x (B*T,H,W,Cin) fp32 NHWC, w (Cout,Cin,3,3) fp32 -> u8 spikes (B,T,H,W,Cout)."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    if not x.is_contiguous() or not w.is_contiguous():
+        raise SdfError("head_conv_sn needs contiguous NHWC input and OIHW weights")
+    out = torch.empty((B, T, H, W, Cout), dtype=torch.uint8, device=x.device)
+    d = HeadConvDesc()
+    d.x, d.w, d.out = _ptr(x, torch.float32), _ptr(w, torch.float32), _ptr(out, torch.uint8)
+    d.alpha, d.beta = _ptr(alpha, torch.float32), _ptr(beta, torch.float32)
+    d.B, d.T, d.H, d.W, d.Cin, d.Cout = B, T, H, W, Cin, Cout
+    d.sn_kind, d.tau, d.v_th = KIND[p.kind], p.tau, p.v_th
+    d.v_reset, d.soft_reset = (0.0 if p.v_reset is None else float(p.v_reset)), (1 if p.v_reset is None else 0)
+    d.psn_w, d.psn_b = _ptr(p.psn_w, torch.float32), _ptr(p.psn_b, torch.float32)
+    _check(lib().sdf_head_conv_sn_fwd(C.byref(d), _stream()), "sdf_head_conv_sn_fwd")
+    return out
+
+
+def flow_out(pred, H, W, scale_y, scale_x):
+    """sdf_flow_out_fwd: pred (B,D,h,w,C) fp32 (last-dim stride 1, rows ldp floats apart) -> (B,C,H,W) = nearest-upsampled time sum."""
+    B, D, h, w, Cc = pred.shape
+    if pred.stride(4) != 1 or pred.stride(2) != w * pred.stride(3) or pred.stride(1) != h * pred.stride(2) or pred.stride(0) != D * pred.stride(1):
+        raise SdfError("flow_out needs a (B,D,h,w,C) view of a dense (rows, ldp) buffer")
+    out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=pred.device)
+    _check(lib().sdf_flow_out_fwd(C.c_void_p(_ptr(pred, torch.float32)), C.c_void_p(out.data_ptr()), C.c_int(B), C.c_int(D), C.c_int(h),
+                                  C.c_int(w), C.c_int64(pred.stride(3)), C.c_int(Cc), C.c_int(H), C.c_int(W), C.c_float(scale_y),
+                                  C.c_float(scale_x), _stream()), "sdf_flow_out_fwd")
+    return out

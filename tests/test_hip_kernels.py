@@ -344,3 +344,37 @@ def test_spike_conv_small_m_split_k(ns):
         outs.append(out.cpu())
     assert (outs[0].double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
     assert torch.equal(outs[0], outs[1])
+
+
+# ---------------------------------------------------------------- the two ends of the forward
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+@pytest.mark.parametrize("B,T,H,W,Cout", [(1, 10, 9, 32, 48), (2, 5, 6, 16, 32)])
+def test_head_conv_bn_neuron(kind, B, T, H, W, Cout):
+    """conv3x3(real-valued 2-channel voxel) -> BN -> neuron over T in one kernel vs conv2d(fp64) -> BN -> C oracle neuron
+    (MS_PED_Spiking_PatchEmbed_Conv_sfn.head, Spiking_modules.py:1770-1776).  fp32-vs-fp64 rounding may flip a spike only
+    when the pre-activation is within rounding of the threshold."""
+    x = rnd((B * T, H, W, 2), 120, -1.0, 3.0)
+    x[x.abs() < 0.8] = 0.0                                               # sparse event counts
+    w = rnd((Cout, 2, 3, 3), 121, -0.5, 0.5)
+    alpha, beta = rnd((Cout,), 122, 0.5, 1.5), rnd((Cout,), 123, -0.2, 0.2)
+    Wn, bn = rnd((T, T), 85, -0.5, 0.5) + 0.5 * torch.eye(T), torch.full((T,), -0.1)
+    h = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 1, 1).permute(0, 2, 3, 1)
+    h = (h * alpha.double() + beta.double()).float().view(B, T, H * W * Cout).permute(1, 0, 2).contiguous()
+    ref = R.neuron_ref(h.view(T, -1), kind, 2.0, 0.1, None, psn_w=Wn, psn_b=bn).view(T, B, H, W, Cout).permute(1, 0, 2, 3, 4)
+    assert hip.head_conv_sn_supported(T, H, W, 2, Cout)
+    p = hip.NeuronParams(kind, 2.0, 0.1, None, Wn.to(DEV), bn.to(DEV))
+    out = hip.head_conv_sn(x.to(DEV), w.to(DEV), B, T, H, W, p, alpha=alpha.to(DEV), beta=beta.to(DEV))
+    rate = (out.cpu().float() != ref).float().mean().item()
+    assert rate <= 2e-4, rate
+    assert 0.03 < ref.mean() < 0.97
+
+
+@pytest.mark.parametrize("h,w,H,W", [(9, 12, 288, 384), (36, 48, 288, 384), (5, 7, 20, 28)])
+def test_flow_out_sum_and_nearest_upsample(h, w, H, W):
+    B, D = 2, 10
+    buf = rnd((B * D * h * w, 32), 130, -1.0, 1.0).to(DEV)
+    pred = buf.view(B, D, h, w, 32)[..., :2]
+    ref = torch.nn.functional.interpolate(pred.cpu().double().sum(1).permute(0, 3, 1, 2), scale_factor=(H / h, W / w))
+    got = hip.flow_out(pred, H, W, H / h, W / w)
+    assert got.shape == ref.shape
+    assert (got.cpu().double() - ref).abs().max().item() <= 1e-5
