@@ -523,7 +523,8 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
   P.tiles_n = (d->N + 32 * nb - 1) / (32 * nb);
   P.ntiles = P.tiles_m * P.tiles_n;
   const size_t lds = (size_t)32 * rb * waves * A_LD + (size_t)d->nsplit * 32 * nb * W_LD * 2;
-  const int wg_per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
+  int wg_per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);   // more resident workgroups measured no faster (profiles/r1_gemm_shapes.txt)
+  if (const char* e = getenv("SDF_GEMM_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 8) wg_per_cu = v; }   // tuning override
   const int G = P.ntiles < 256 * wg_per_cu ? P.ntiles : 256 * wg_per_cu;
   dim3 grid((unsigned)G);
   hipStream_t s = sdf_stream(stream);

@@ -22,10 +22,11 @@ def f32(M, N, K, resid=True):
     al, be = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev) * 0.1
     out = torch.randn((M, N), device=dev)
     r = {}
-    for name, ws in (("base", "0"), ("pp", "2")):
+    for name, ws, wgs in (("base", "0", "3"), ("b2", "0", "2"), ("b4", "0", "4"), ("b6", "0", "6"), ("pp", "2", "3")):
         os.environ["SDF_GEMM_WS"] = ws
+        os.environ["SDF_GEMM_WGS"] = wgs
         r[name] = timeit(lambda: hip.spike_gemm(A, Wp, out, M, N, K, alpha=al, beta=be, resid=out if resid else None))
-    print(f"f32  M={M:6d} N={N:4d} K={K:4d} resid={int(resid)}: base {r['base']:6.1f} us   pp {r['pp']:6.1f} us   {'PP' if r['pp'] < r['base'] else 'base'}")
+    print(f"f32  M={M:6d} N={N:4d} K={K:4d} resid={int(resid)}: wg/cu 2|3|4|6 {r['b2']:6.1f} {r['base']:6.1f} {r['b4']:6.1f} {r['b6']:6.1f} us   pp {r['pp']:6.1f} us")
 
 def fused(T, pos, N, K):
     M = pos * T
@@ -35,16 +36,17 @@ def fused(T, pos, N, K):
     out = torch.zeros((M, N), dtype=torch.uint8, device=dev)
     p = hip.NeuronParams("lif", 2.0, 0.1, None)
     r = {}
-    for name, ws in (("base", "0"), ("pp", "2")):
+    for name, ws, wgs in (("base", "0", "3"), ("b2", "0", "2"), ("b4", "0", "4"), ("b6", "0", "6"), ("pp", "2", "3")):
         os.environ["SDF_GEMM_WS"] = ws
+        os.environ["SDF_GEMM_WGS"] = wgs
         r[name] = timeit(lambda: hip.spike_gemm_sn(A, Wp, out, N, K, T, pos, pos, 0, pos, p, alpha=al, beta=be))
-    print(f"sn{T:<2d} M={M:6d} N={N:4d} K={K:4d}        : base {r['base']:6.1f} us   pp {r['pp']:6.1f} us   {'PP' if r['pp'] < r['base'] else 'base'}")
+    print(f"sn{T:<2d} M={M:6d} N={N:4d} K={K:4d}        : wg/cu 2|3|4|6 {r['b2']:6.1f} {r['base']:6.1f} {r['b4']:6.1f} {r['b6']:6.1f} us   pp {r['pp']:6.1f} us")
 
 tok = [69120, 17280, 4320, 1080]
 win = [71280, 19440, 6480, 3240]        # window-padded rows of the attention GEMMs (2 x B_ x 81)
 for s in range(4):
     C = 96 * 2 ** s
-    fused(2, win[s] // 2, C, C)          # q / k
+    fused(2, win[s] // 2, 2 * C, C)      # q | k stacked
     f32(win[s], C, C, True)              # proj (+ scatter in the model)
     fused(10, tok[s] // 10, 4 * C, C)    # fc1
     f32(tok[s], C, 4 * C, True)          # fc2
