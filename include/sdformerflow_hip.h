@@ -206,7 +206,7 @@ int sdf_qk_gate_strided_fwd(const uint8_t* q, const uint8_t* k, uint8_t* e, int 
 
 /* ---------------------------------------------------------------------------------------------
  * Head of the patch embedding: conv3x3 / pad 1 (no bias) on the real-valued event voxel -> eval BatchNorm -> neuron over T,
- * one kernel, spikes out.  Replaces MS_PED_Spiking_PatchEmbed_Conv_sfn.head (reference Spiking_modules.py:1770-1776).
+ * one kernel, spikes out.  Replaces MS_PED_Spiking_PatchEmbed_Conv_sfn.head (reference Spiking_modules.py:1782).
  *   x   (B*T, H, W, Cin) fp32, NHWC, image index = b*T + t          w (Cout, Cin, 3, 3) fp32 (the module's layout)
  *   out (B*T, H, W, Cout) u8 spikes                                  alpha / beta (Cout) or NULL
  * Accumulation: one fmaf chain per output in (ky, kx, cin) order starting from 0.  Built for (Cin, Cout) in

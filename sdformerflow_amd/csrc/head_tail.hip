@@ -3,7 +3,7 @@
 //  sdf_head_conv_sn_fwd : the patch embedding's head - 3x3 / pad 1 convolution of the REAL-valued event voxel (2 input
 //      channels) -> eval BatchNorm -> neuron over the T time steps - as one kernel.  The fp32 pre-activation
 //      (imgs x H x W x Cout, 212 MB at 288 x 384) never exists; the kernel reads the 8.8 MB voxel and writes 1-byte spikes.
-//      (reference Spiking_modules.py:1770-1776: head = conv -> SpikingNormLayer -> Spiking_neuron.)
+//      (reference Spiking_modules.py:1782: head = conv -> SpikingNormLayer -> Spiking_neuron.)
 //      A workgroup = 16 pixels of one image row x 16 channel lanes (Cout / 16 channels each), all T steps: the input
 //      patch goes through LDS, the 18 * Cout weights live in registers, the accumulation is one fmaf chain per output
 //      in (ky, kx, cin) order, the recurrence runs in registers, spikes leave through LDS as 16-byte stores.

@@ -351,7 +351,7 @@ def test_spike_conv_small_m_split_k(ns):
 @pytest.mark.parametrize("B,T,H,W,Cout", [(1, 10, 9, 32, 48), (2, 5, 6, 16, 32)])
 def test_head_conv_bn_neuron(kind, B, T, H, W, Cout):
     """conv3x3(real-valued 2-channel voxel) -> BN -> neuron over T in one kernel vs conv2d(fp64) -> BN -> C oracle neuron
-    (MS_PED_Spiking_PatchEmbed_Conv_sfn.head, Spiking_modules.py:1770-1776).  fp32-vs-fp64 rounding may flip a spike only
+    (MS_PED_Spiking_PatchEmbed_Conv_sfn.head, Spiking_modules.py:1782).  fp32-vs-fp64 rounding may flip a spike only
     when the pre-activation is within rounding of the threshold."""
     x = rnd((B * T, H, W, 2), 120, -1.0, 3.0)
     x[x.abs() < 0.8] = 0.0                                               # sparse event counts
