@@ -230,6 +230,18 @@ typedef struct SdfHeadConvDesc {
 int sdf_head_conv_sn_fwd(const SdfHeadConvDesc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * col2im + eval BatchNorm of a ConvTranspose2d(k=3, s=2, p=1, output_padding=1) on spikes whose nine per-tap products were
+ * computed by ONE plain sdf_spike_gemm_fwd over the stacked tap weights (N = 9*Cout, column = (ky*3+kx)*Cout + co):
+ *   out[img, oy, ox, co] = fmaf( sum_{taps reaching (oy,ox)} Y[(img, iy, ix)][(ky*3+kx)*Cout + co], alpha[co], beta[co] ),
+ *   oy = 2*iy - 1 + ky, ox = 2*ix - 1 + kx.   Replaces MS_SpikingTransposeDecoderLayer's deconv + norm
+ * (reference Spiking_modules.py:461-474) for the small decoder levels, where one GEMM fills the chip and four
+ * parity-class convolutions (the other form this library offers, see sdf_spike_conv2d_fwd) do not.
+ *   Y (imgs*H*W, 9*Cout) fp32;  out (imgs, 2H, 2W, Cout) fp32;  alpha / beta (Cout) or NULL;  Cout % 4 == 0.
+ */
+int sdf_deconv_col2im_fwd(const float* Y, const float* alpha, const float* beta, float* out, int imgs, int H, int W,
+                          int Cout, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Flow read-out: out[b,c,Y,X] = sum_t pred[b,t,ys,xs,c] with (ys, xs) the nearest-neighbour source pixel of (Y, X) for
  * scale factors (scale_y, scale_x) - exactly F.interpolate(pred.sum(time), scale_factor=...)
  * (reference Spiking_STSwinNet.py:289-303).  pred is (B, D, h, w, ldp) fp32 of which the first C columns are read;

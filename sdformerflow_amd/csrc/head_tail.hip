@@ -122,6 +122,38 @@ __global__ __launch_bounds__(256) void flow_out_kernel(const float* __restrict__
   out[i] = s;
 }
 
+// col2im of a stride-2 3x3 transposed convolution whose nine per-tap products Y[(img, iy, ix)][tap][co] came out of ONE plain
+// spike GEMM over the stacked tap weights: out[img, oy, ox, co] = BN( sum of the 1, 2 or 4 taps that reach (oy, ox) ),
+// oy = 2 iy - 1 + ky.  Taps are added in a fixed order (ky = 2 before ky = 0, kx likewise): deterministic.
+__global__ __launch_bounds__(256) void deconv_col2im_kernel(const float* __restrict__ Y, const float* __restrict__ alpha,
+                                                            const float* __restrict__ beta, float* __restrict__ out, int imgs, int H,
+                                                            int W, int Cout) {
+  const int cq = Cout / 4;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)imgs * 4 * H * W * cq) return;
+  const int c4 = (int)(i % cq) * 4;
+  const int64_t pix = i / cq;
+  const int ox = (int)(pix % (2 * W)), oy = (int)((pix / (2 * W)) % (2 * H)), img = (int)(pix / ((int64_t)4 * H * W));
+  const int y0 = oy >> 1, x0 = ox >> 1;
+  // (input row, kernel row) pairs reaching oy: even -> (y0, 1); odd -> (y0, 2), (y0 + 1, 0)
+  const int ny = (oy & 1) ? ((y0 + 1 < H) ? 2 : 1) : 1, nx = (ox & 1) ? ((x0 + 1 < W) ? 2 : 1) : 1;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int a = 0; a < ny; ++a) {
+    const int iy = y0 + a, ky = (oy & 1) ? (a == 0 ? 2 : 0) : 1;
+    for (int b = 0; b < nx; ++b) {
+      const int ix = x0 + b, kx = (ox & 1) ? (b == 0 ? 2 : 0) : 1;
+      const float4 v = *reinterpret_cast<const float4*>(Y + (((int64_t)img * H + iy) * W + ix) * (9 * (int64_t)Cout) + (ky * 3 + kx) * Cout + c4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  if (alpha) {
+    const float4 al = *reinterpret_cast<const float4*>(alpha + c4), be = *reinterpret_cast<const float4*>(beta + c4);
+    acc.x = __builtin_fmaf(acc.x, al.x, be.x); acc.y = __builtin_fmaf(acc.y, al.y, be.y);
+    acc.z = __builtin_fmaf(acc.z, al.z, be.z); acc.w = __builtin_fmaf(acc.w, al.w, be.w);
+  }
+  *reinterpret_cast<float4*>(out + pix * Cout + c4) = acc;
+}
+
 template <int T>
 int launch_head(const HeadParams& P, dim3 grid, hipStream_t s) {
   if (P.d.Cin == 2 && P.d.Cout == 48) { hipLaunchKernelGGL((head_conv_sn_kernel<T, 3, 2>), grid, dim3(256), 0, s, P); return 0; }
@@ -167,6 +199,20 @@ extern "C" int sdf_flow_out_fwd(const float* pred, float* out, int B, int D, int
   const int64_t n = (int64_t)B * C * H * W;
   hipLaunchKernelGGL(flow_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sdf_stream(stream), pred, out, B, D, h, w,
                      ldp, C, H, W, 1.0f / scale_y, 1.0f / scale_x);
+  SDF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sdf_deconv_col2im_fwd(const float* Y, const float* alpha, const float* beta, float* out, int imgs, int H, int W,
+                                     int Cout, void* stream) {
+  if (!Y || !out) return SDF_E_NULL;
+  if (alpha && !beta) return SDF_E_NULL;
+  if (imgs < 1 || H < 1 || W < 1 || Cout < 4 || Cout % 4) return SDF_E_SHAPE;
+  if (!sdf_aligned(Y, 16) || !sdf_aligned(out, 16) || (alpha && (!sdf_aligned(alpha, 16) || !sdf_aligned(beta, 16)))) return SDF_E_ALIGN;
+  const int64_t n = (int64_t)imgs * 4 * H * W * (Cout / 4);
+  if ((n + 255) / 256 >= (1LL << 31)) return SDF_E_SHAPE;
+  hipLaunchKernelGGL(deconv_col2im_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sdf_stream(stream), Y, alpha, beta, out,
+                     imgs, H, W, Cout);
   SDF_LAUNCH_CHECK();
   return 0;
 }

@@ -24,6 +24,7 @@
 // LDS rows are padded (A 18-dword stride for ds_read_b64, W 36-dword stride for ds_read_b128): conflict-free.
 // Compiled with -ffp-contract=off (the neuron arithmetic is the separately-rounded op sequence of neuron.hip).
 #include "spike_mm.h"
+#include <stdlib.h>
 
 #ifdef SDF_STAMP
 // diagnostic build only: per-role cycle accounting of workgroup 0 (never compiled into the product library)
@@ -515,8 +516,9 @@ void plan_splitk(GemmParams& P, int kc) {
   P.partial = nullptr;
   if (d.sn_T == 0 && P.ntiles <= 128 && S >= 4 && d.workspace) {
     int ks = (256 + P.ntiles - 1) / P.ntiles;
+    if (const char* e = getenv("SDF_KSPLIT_MULT")) ks *= atoi(e) > 0 ? atoi(e) : 1;   // tuning override: oversubscribe the chip
     if (ks > S / 2) ks = S / 2;
-    if (ks > 16) ks = 16;
+    if (ks > 32) ks = 32;
     while (ks > 1 && (int64_t)ks * d.M * d.N * 4 > d.workspace_bytes) --ks;
     if (ks > 1 && sdf_aligned(d.workspace, 16)) {
       P.ksplit = ks;

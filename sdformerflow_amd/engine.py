@@ -130,6 +130,19 @@ def _pad16(c):
     return (c + 15) // 16 * 16
 
 
+def _pad32(c):
+    return (c + 31) // 32 * 32
+
+
+def deconv_tap_weights(w, cin_pad, nsplit):
+    """ConvTranspose2d weight (Cin, Cout, 3, 3) -> planes of the stacked per-tap matrices (9*Cout, cin_pad): row
+    (ky*3+kx)*Cout + co holds w[:, co, ky, kx] (zero for padded input channels)."""
+    Cin, Cout = w.shape[:2]
+    wk = torch.zeros((9 * Cout, cin_pad), dtype=torch.float32, device=w.device)
+    wk[:, :Cin] = w.detach().float().permute(2, 3, 1, 0).reshape(9 * Cout, Cin)
+    return hip.split_weight(wk, nsplit)
+
+
 class MSFlowEngine:
     def __init__(self, model):
         self.device = next(model.parameters()).device
@@ -364,17 +377,27 @@ class MSFlowEngine:
                 parts = [F.pad(p, (0, 0, (w - p.shape[3]) // 2, w - p.shape[3] - (w - p.shape[3]) // 2,
                                    (h - p.shape[2]) // 2, h - p.shape[2] - (h - p.shape[2]) // 2)) for p in parts]
             cin = sum(p.shape[-1] for p in parts)
-            cp = _pad16(cin)
+            wdec, bn, sn = self.decoders[i]
+            cout = wdec.shape[1]
+            # small levels: ONE plain spike GEMM over the nine stacked tap matrices + a col2im pass fills the chip; the four
+            # parity-class convolutions (no 9x intermediate) are kept where that intermediate would cost more than it saves
+            as_gemm = B * D * h * w * 9 * cout * 4 <= 64 << 20
+            cp = _pad32(cin) if as_gemm else _pad16(cin)
             cat = torch.zeros((B, D, h, w, cp), dtype=torch.float32, device=y.device) if cp != cin else None
             if cat is None:
                 cat = torch.cat(parts, dim=-1)
             else:
                 torch.cat(parts, dim=-1, out=cat[..., :cin])
-            wdec, bn, sn = self.decoders[i]
             s = self._neuron_bd(cat, sn)                                  # MS decoder: SN -> ConvT -> BN
-            cout = wdec.shape[1]
             z = torch.empty((B, D, 2 * h, 2 * w, cout), dtype=torch.float32, device=y.device)
-            for cls in self._deconv_classes(i, B, D, h, w, cp):
+            if as_gemm:
+                key = ("taps", i, cp)
+                if key not in self._deconv:
+                    self._deconv[key] = deconv_tap_weights(wdec, cp, self.nsplit)
+                Y = torch.empty((B * D * h * w, 9 * cout), dtype=torch.float32, device=y.device)
+                hip.spike_gemm(s, self._deconv[key], Y, B * D * h * w, 9 * cout, cp)
+                hip.deconv_col2im(Y, B * D, h, w, cout, alpha=bn[0], beta=bn[1], out=z)
+            for cls in ([] if as_gemm else self._deconv_classes(i, B, D, h, w, cp)):
                 hip.spike_conv2d(s, cls["Wp"], B * D, h, w, cp, h, w, cls["KH"], cls["KW"], 1, cls["dy"], cls["dx"], out=z,
                                  alpha=bn[0], beta=bn[1], out_rowmap=cls["rowmap"])
             pw, pb, psn, nout = self.preds[i]

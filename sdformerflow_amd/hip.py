@@ -20,7 +20,7 @@ KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
 
 EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
            "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd", "sdf_head_conv_sn_fwd",
-           "sdf_flow_out_fwd")
+           "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd")
 
 
 class SdfError(RuntimeError):
@@ -375,4 +375,14 @@ def flow_out(pred, H, W, scale_y, scale_x):
     _check(lib().sdf_flow_out_fwd(C.c_void_p(_ptr(pred, torch.float32)), C.c_void_p(out.data_ptr()), C.c_int(B), C.c_int(D), C.c_int(h),
                                   C.c_int(w), C.c_int64(pred.stride(3)), C.c_int(Cc), C.c_int(H), C.c_int(W), C.c_float(scale_y),
                                   C.c_float(scale_x), _stream()), "sdf_flow_out_fwd")
+    return out
+
+
+def deconv_col2im(Y, imgs, H, W, Cout, alpha=None, beta=None, out=None):
+    """sdf_deconv_col2im_fwd: Y (imgs*H*W, 9*Cout) fp32 per-tap products -> (imgs, 2H, 2W, Cout) fp32, BN fused."""
+    if out is None:
+        out = torch.empty((imgs, 2 * H, 2 * W, Cout), dtype=torch.float32, device=Y.device)
+    _check(lib().sdf_deconv_col2im_fwd(C.c_void_p(_ptr(Y, torch.float32)), C.c_void_p(_ptr(alpha, torch.float32)),
+                                       C.c_void_p(_ptr(beta, torch.float32)), C.c_void_p(_ptr(out, torch.float32)), C.c_int(imgs),
+                                       C.c_int(H), C.c_int(W), C.c_int(Cout), _stream()), "sdf_deconv_col2im_fwd")
     return out

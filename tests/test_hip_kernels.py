@@ -378,3 +378,23 @@ def test_flow_out_sum_and_nearest_upsample(h, w, H, W):
     got = hip.flow_out(pred, H, W, H / h, W / w)
     assert got.shape == ref.shape
     assert (got.cpu().double() - ref).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("ns", PLANES)
+def test_spike_conv_transpose_as_gemm_plus_col2im(ns):
+    """The same ConvTranspose2d(k=3, s=2, p=1, output_padding=1) as ONE spike GEMM over the nine stacked tap matrices followed
+    by the col2im + BN kernel (the form the engine uses for the small decoder levels) vs torch conv_transpose2d in fp64."""
+    from sdformerflow_amd.engine import deconv_tap_weights
+    imgs, H, W, Cin, Cout = 3, 9, 12, 200, 96
+    cp = 224                                                     # Cin padded to a multiple of 32 (GEMM K)
+    x = torch.zeros((imgs, H, W, cp), dtype=torch.uint8)
+    x[..., :Cin] = spikes((imgs, H, W, Cin), 99)
+    w = rnd((Cin, Cout, 3, 3), 100, -0.1, 0.1)
+    alpha, beta = rnd((Cout,), 101, 0.5, 1.5), rnd((Cout,), 102, -0.2, 0.2)
+    ref = torch.nn.functional.conv_transpose2d(x[..., :Cin].permute(0, 3, 1, 2).double(), w.double(), None, 2, 1, 1)
+    ref = ref.permute(0, 2, 3, 1) * alpha.double() + beta.double()
+    Y = torch.empty((imgs * H * W, 9 * Cout), device=DEV)
+    hip.spike_gemm(x.to(DEV), deconv_tap_weights(w.to(DEV), cp, ns), Y, imgs * H * W, 9 * Cout, cp)
+    out = hip.deconv_col2im(Y, imgs, H, W, Cout, alpha=alpha.to(DEV), beta=beta.to(DEV))
+    assert out.shape == (imgs, 2 * H, 2 * W, Cout)
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
