@@ -503,12 +503,13 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
   }
   // Ping-pong 256 x 96 kernel (spike_mm_pp.hip) where it measured faster than the small-tile kernel on the model's
   // layers (tools/gemm_shapes.py, profiles/r1_gemm_shapes.txt): the fused T = 10 neuron epilogue (the MLP's fc1 - long
-  // epilogues that the other consumer group hides) and fp32 epilogues with a long K loop over many rows or a very
-  // long one.  SDF_GEMM_WS: 0 = never, 2 = whenever legal, 1 = the barrier-synchronised predecessor (spike_mm_ws.hip).
+  // epilogues that the other consumer group hides) and fp32 epilogues with a long K loop over many rows, a very
+  // long one, or many column tiles per row tile (the decoders' stacked tap matrices).  SDF_GEMM_WS: 0 = never, 2 = whenever legal, 1 = the barrier-synchronised predecessor (spike_mm_ws.hip).
   {
     const char* e = getenv("SDF_GEMM_WS");
     const bool legal = d->N % 96 == 0 && spike_mm_pp_supports(P, false);
-    bool use_pp = legal && ((spike && d->sn_T == 10) || (!spike && ((d->K >= 384 && d->M >= 32768) || d->K >= 2048)));
+    bool use_pp = legal && ((spike && d->sn_T == 10) ||
+                           (!spike && ((d->K >= 384 && d->M >= 32768) || d->K >= 2048 || (d->K >= 384 && d->N >= 864))));
     if (e && e[0] == '0') use_pp = false;
     if (e && e[0] == '2') use_pp = legal;
     if (e && e[0] == '1' && d->N % 96 == 0 && d->nsplit != 2 && (d->sn_T == 0 || d->sn_T == 2 || d->sn_T == 10))

@@ -52,3 +52,7 @@ for s in range(4):
     f32(tok[s], C, 4 * C, True)          # fc2
     if s < 3:
         f32(tok[s] // 4, 2 * C, 4 * C, False)   # patch merge
+print("decoder tap GEMMs (M = imgs*h*w, N = 9*Cout, K = padded Cin)")
+f32(1080, 3456, 1536, False)
+f32(4320, 1728, 800, False)
+f32(17280, 864, 416, False)
