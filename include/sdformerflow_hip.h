@@ -169,6 +169,9 @@ int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream);
  *     are 1- or 2-tap grids with their own offsets and an out_rowmap that places the class's outputs)
  *   epilogue: the fp32 one (alpha/beta/resid/out_rowmap, out is (rows, Cout) fp32 NHWC) or, with sn_T == 10,
  *     the fused neuron (out_spike u8 NHWC); pos_* describe how the imgs dimension factors into (time, position).
+ *     With sn_T == 10 and g.out != NULL the pre-activation  fmaf(acc, alpha, beta) (+ g.resid)  is ALSO stored to g.out
+ *     (fp32, row stride g.ldo) and the neuron runs on that sum: MS_ResBlock's conv2 -> BN -> + identity and the next
+ *     block's sn1 in one launch (reference Spiking_modules.py:922-933).
  */
 typedef struct SdfSpikeConvDesc {
   SdfSpikeGemmDesc g;

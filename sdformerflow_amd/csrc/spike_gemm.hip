@@ -561,7 +561,9 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
     if (d->sn_kind != SDF_LIF && d->sn_kind != SDF_PSN && d->sn_kind != SDF_IF) return SDF_E_DTYPE;
     if (d->sn_kind == SDF_PSN && (!d->psn_w || !d->psn_b)) return SDF_E_NULL;
     if (d->sn_kind == SDF_LIF && !(d->tau > 1.f)) return SDF_E_SHAPE;
-    if (d->out_rowmap || d->resid || d->bias || d->add) return SDF_E_SHAPE;
+    if (d->out_rowmap || d->bias || d->add) return SDF_E_SHAPE;
+    if (d->resid && !d->out) return SDF_E_NULL;                   // a residual only exists for the membrane output
+    if (d->out && (d->ldo < d->N || !sdf_aligned(d->out, 4))) return SDF_E_SHAPE;
     if (!sdf_aligned(d->out_spike, 16)) return SDF_E_ALIGN;
     int ex;
     if (d->sn_kind == SDF_LIF && frexpf(d->tau, &ex) == 0.5f) P.inv_tau = 1.0f / d->tau;
@@ -575,7 +577,7 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
   // 256 x 96 tiles, producer waves do the im2col addressing; the ping-pong kernel overlaps epilogues with the MFMAs
   const char* e = getenv("SDF_CONV_PP");                      // tuning override: 0 = barrier-synchronised kernel
   if (spike_mm_pp_supports(P, true) && !(e && e[0] == '0')) return launch_spike_mm_pp(P, true, sdf_stream(stream));
-  if (d->nsplit == 2) return SDF_E_DTYPE;
+  if (d->nsplit == 2 || (spike && d->out)) return SDF_E_DTYPE;   // only the ping-pong kernel has these
   return launch_spike_mm_ws(P, true, sdf_stream(stream));
 }
 

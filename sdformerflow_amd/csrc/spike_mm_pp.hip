@@ -485,6 +485,34 @@ __global__ __launch_bounds__(768) void spike_mm_pp_kernel(GemmParams P) {
       uint8_t* S_s = smem + NSLOT * BUF + wave * 32 * BN;        // private 32 x 96 byte staging strip of this wave
       const int64_t pos0 = (int64_t)rt * (8 * NPOS) + (cw * 2 + lh) * NPOS;
       uint32_t bits[3];                                          // per column block: bit slot = spike of accumulator slot
+      // Membrane output (d.out != NULL): the pre-activation (+ residual) is ALSO stored as fp32 - the MS shortcut stream
+      // and the spikes of the next layer's neuron leave one kernel (MS_ResBlock: conv2 -> BN -> + identity, then the next
+      // block's sn1, reference Spiking_modules.py:922-933).  Row of (position, t) as for the spikes; 4-byte stores, 32 lanes
+      // = one 128-byte line.
+      const bool memb = d.out != nullptr;
+      const __amdgpu_buffer_rsrc_t mo_rs = make_rsrc(memb ? d.out : nullptr), mr_rs = make_rsrc(d.resid);
+      uint32_t grow[NPOS];                                       // byte offset of row (position pl, t = 0) in out / resid, or INV
+      if (memb) {
+#pragma unroll
+        for (int pl = 0; pl < NPOS; ++pl) {
+          const int64_t pos = pos0 + pl;
+          const uint32_t pc = pos < d.pos_count ? (uint32_t)pos : 0u;
+          const uint32_t po = pc / (uint32_t)d.pos_inner;
+          const uint32_t g0 = po * (uint32_t)d.pos_ostride + (pc - po * (uint32_t)d.pos_inner);
+          grow[pl] = pos < d.pos_count ? g0 * (uint32_t)d.ldo * 4u : INV;
+        }
+      }
+      const uint32_t tstep = (uint32_t)d.t_stride * (uint32_t)d.ldo * 4u;
+      // residual of (column block, position) j + 1 is requested before the stores of j go out (vmcnt retires in order)
+      float rsd[2][T];
+      auto load_rsd = [&](int j, float (&r)[T]) __attribute__((always_inline)) {
+        const int nb = j / NPOS, pl = j - nb * NPOS;
+        const uint32_t base = grow[pl] + (uint32_t)(n0 + nb * 32 + l31) * 4u;
+#pragma unroll
+        for (int t2 = 0; t2 < T; ++t2) r[t2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mr_rs, base + (uint32_t)t2 * tstep, 0, 0));
+      };
+      const bool has_rsd = memb && d.resid != nullptr;
+      if (has_rsd) load_rsd(0, rsd[0]);
 #pragma unroll
       for (int nb = 0; nb < 3; ++nb) {
         const int n = n0 + nb * 32 + l31;
@@ -493,12 +521,23 @@ __global__ __launch_bounds__(768) void spike_mm_pp_kernel(GemmParams P) {
         uint32_t bm = 0;
 #pragma unroll
         for (int pl = 0; pl < NPOS; ++pl) {
+          const int j = nb * NPOS + pl;
           const int64_t pos = pos0 + pl;
           float xs[T], sp[T];
 #pragma unroll
           for (int t2 = 0; t2 < T; ++t2) {
             const int slot = pl * T + t2;
             xs[t2] = __builtin_fmaf(acc[slot >> 4][nb][slot & 15] * asc, al, be);   // al = 1, be = 0 when there is no BN
+          }
+          if (memb) {
+            if (has_rsd) {
+              if (j + 1 < 3 * NPOS) load_rsd(j + 1, rsd[(j + 1) & 1]);
+#pragma unroll
+              for (int t2 = 0; t2 < T; ++t2) xs[t2] = xs[t2] + rsd[j & 1][t2];
+            }
+#pragma unroll
+            for (int t2 = 0; t2 < T; ++t2)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xs[t2]), mo_rs, grow[pl] + (uint32_t)t2 * tstep + (uint32_t)n * 4u, 0, 0);
           }
           if (d.add) {                                           // wave-uniform; loads unconditional (clamped position)
             const int64_t pc = pos < d.pos_count ? pos : 0;
@@ -589,6 +628,7 @@ bool spike_mm_pp_supports(const GemmParams& P, bool conv) {
   const int64_t a_bytes = conv ? (d.M / ((int64_t)P.cv.OH * P.cv.OW)) * P.cv.H * P.cv.W * P.cv.Cin
                                : (d.zg_nH > 0 ? d.M * d.K : rows * d.lda);
   if (a_bytes >= lim || (int64_t)d.nsplit * d.N * d.K * 2 >= lim || (d.sn_T > 0 && rows * d.N >= lim)) return false;
+  if (d.sn_T > 0 && d.out && rows * d.ldo * 4 >= lim) return false;          // membrane output of the fused-neuron epilogue
   if (d.sn_T == 0) {
     const int64_t max_rows = d.out_rowmap ? (d.out_rows > 0 ? d.out_rows : lim) : d.M;   // scattered rows need the caller's bound
     if (max_rows * d.ldo * 4 >= lim) return false;

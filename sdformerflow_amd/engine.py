@@ -222,9 +222,9 @@ class MSFlowEngine:
         hip.neuron_fwd(x, out, D, B, n, D * n, n, D * n, n, p, alpha=a, beta=b, Cch=Cc, inner=1)
         return out
 
-    def _conv3x3(self, s, Wp, Cout, stride=1, bn=None, resid=None, sn=None):
+    def _conv3x3(self, s, Wp, Cout, stride=1, bn=None, resid=None, sn=None, membrane=False):
         """3x3 / pad 1 spike convolution on (B,D,h,w,Cin) u8 -> (B,D,oh,ow,Cout): fp32 (BN, + resid) or, with `sn`,
-        spikes of the fused BN + neuron over D."""
+        spikes of the fused BN + neuron over D; with `membrane` as well, (fp32 BN + resid, spikes of SN(that)) from one launch."""
         B, D, h, w, Cin = s.shape
         oh, ow = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
         a, b = bn if bn is not None else (None, None)
@@ -234,21 +234,32 @@ class MSFlowEngine:
                              resid=resid)
             return out
         out = torch.empty((B, D, oh, ow, Cout), dtype=torch.uint8, device=s.device)
-        hip.spike_conv2d(s, Wp, B * D, h, w, Cin, oh, ow, 3, 3, stride, (-1, 0, 1), (-1, 0, 1), out_spike=out, alpha=a, beta=b,
-                         sn=sn, sn_T=D, pos=(B * oh * ow, oh * ow, D * oh * ow, oh * ow))
-        return out
+        m = torch.empty((B, D, oh, ow, Cout), dtype=torch.float32, device=s.device) if membrane else None
+        hip.spike_conv2d(s, Wp, B * D, h, w, Cin, oh, ow, 3, 3, stride, (-1, 0, 1), (-1, 0, 1), out=m, out_spike=out, alpha=a, beta=b,
+                         resid=resid if membrane else None, sn=sn, sn_T=D, pos=(B * oh * ow, oh * ow, D * oh * ow, oh * ow))
+        return (m, out) if membrane else out
 
-    def _resblock(self, m, rb):
+    @staticmethod
+    def _fusable(B, D, h, w, C):
+        """The fused-neuron convolution epilogue is built for T = 10 and pays off once the tiles fill the chip."""
+        return D == 10 and (B * D * h * w + 255) // 256 * (C // 96) >= 128
+
+    def _resblock(self, m, rb, s1=None, next_sn=None):
         """MS_ResBlock on a (B,D,h,w,C) membrane: SN -> conv+BN+SN (one kernel) -> conv+BN+identity (one kernel)
-        (reference Spiking_modules.py:906-933)."""
+        (reference Spiking_modules.py:906-933).  `s1` = SN1(m) if the producer of m already made it; with `next_sn` the
+        second convolution also emits the spikes of the NEXT layer's neuron on its output: returns (m', SN_next(m'))."""
         B, D, h, w, _ = m.shape
-        s1 = self._neuron_bd(m, rb.sn1)
-        tiles = (B * D * h * w + 255) // 256 * (rb.C // 96)
-        if D == 10 and tiles >= 128:
+        if s1 is None:
+            s1 = self._neuron_bd(m, rb.sn1)
+        fus = self._fusable(B, D, h, w, rb.C)
+        if fus:
             s2 = self._conv3x3(s1, rb.w1, rb.C, bn=rb.bn1, sn=rb.sn2)
         else:       # few rows (U-Net bottleneck): the fp32 epilogue can split K over the chip; neuron as its own launch
             s2 = self._neuron_bd(self._conv3x3(s1, rb.w1, rb.C), rb.sn2, bn=rb.bn1)
-        return self._conv3x3(s2, rb.w2, rb.C, bn=rb.bn2, resid=m)
+        if next_sn is not None and fus:
+            return self._conv3x3(s2, rb.w2, rb.C, bn=rb.bn2, resid=m, sn=next_sn, membrane=True)
+        m2 = self._conv3x3(s2, rb.w2, rb.C, bn=rb.bn2, resid=m)
+        return (m2, self._neuron_bd(m2, next_sn)) if next_sn is not None else m2
 
     # ------------------------------------------------------------------ stages (each usable stand-alone in tests)
     def patch_embed(self, x):
@@ -268,15 +279,22 @@ class MSFlowEngine:
         else:
             y = F.conv2d(xr.permute(0, 3, 1, 2), self.head_w, None, 1, 1).contiguous(memory_format=torch.channels_last)
             s = self._neuron_bd(y.permute(0, 2, 3, 1).view(B, T, H, W, -1), self.head_sn, bn=self.head_bn)
-        m = self._conv3x3(s, self.conv_w, self.conv_w.shape[1], stride=2, bn=self.conv_bn)
-        for rb in self.pe_res:
-            m = self._resblock(m, rb)
+        # every membrane of the patch embedding leaves its convolution together with the spikes of the neuron that reads it
+        sns = [rb.sn1 for rb in self.pe_res] + [self.proj_sn]
+        C0 = self.conv_w.shape[1]
+        oh, ow = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        if self._fusable(B, T, oh, ow, C0):
+            m, s1 = self._conv3x3(s, self.conv_w, C0, stride=2, bn=self.conv_bn, sn=sns[0], membrane=True)
+        else:
+            m = self._conv3x3(s, self.conv_w, C0, stride=2, bn=self.conv_bn)
+            s1 = self._neuron_bd(m, sns[0])
+        for i, rb in enumerate(self.pe_res):
+            m, s1 = self._resblock(m, rb, s1=s1, next_sn=sns[i + 1])
         # PED projection: 1x1 stride-2 shortcut on the (real-valued) membrane + SN -> conv3x3 s2 -> BN, summed in the epilogue
         Bm, Dm, h, w, Cc = m.shape
         res = F.conv2d(m.view(B * T, h, w, Cc).permute(0, 3, 1, 2), self.proj_res_w, None, 2)
         res = res.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
-        s = self._neuron_bd(m, self.proj_sn)
-        return self._conv3x3(s, self.proj_w, self.proj_w.shape[1], stride=2, bn=self.proj_bn, resid=res)
+        return self._conv3x3(s1, self.proj_w, self.proj_w.shape[1], stride=2, bn=self.proj_bn, resid=res)
 
     def attention(self, x, blk: _Block):
         """x (B,D,H,W,C) += SSA(x), in place (reference Spiking_swin_transformer3D.py:781-821, 661-717, :840)."""

@@ -329,6 +329,7 @@ def spike_conv2d(x, Wp, imgs, H, W, Cin, OH, OW, KH, KW, stride, dy, dx, out=Non
         g.out_rows = out.numel() // g.ldo
     if sn is not None:
         g.out_spike = _ptr(out_spike, torch.uint8)
+        g.out = _ptr(out, torch.float32)                          # optional membrane output (pre-activation + resid)
         g.sn_T, g.sn_kind, g.tau, g.v_th = sn_T, KIND[sn.kind], sn.tau, sn.v_th
         g.v_reset, g.soft_reset = (0.0 if sn.v_reset is None else float(sn.v_reset)), (1 if sn.v_reset is None else 0)
         g.psn_w, g.psn_b = _ptr(sn.psn_w, torch.float32), _ptr(sn.psn_b, torch.float32)

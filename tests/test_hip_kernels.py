@@ -398,3 +398,27 @@ def test_spike_conv_transpose_as_gemm_plus_col2im(ns):
     out = hip.deconv_col2im(Y, imgs, H, W, Cout, alpha=alpha.to(DEV), beta=beta.to(DEV))
     assert out.shape == (imgs, 2 * H, 2 * W, Cout)
     assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("ns", PLANES)
+@pytest.mark.parametrize("with_resid", [True, False])
+def test_spike_conv3x3_fused_neuron_with_membrane_output(with_resid, ns):
+    """conv -> BN -> (+ identity) stored as fp32 AND the T=10 neuron on that sum, one launch (MS_ResBlock conv2 + the next
+    block's sn1, Spiking_modules.py:922-933): membrane within 1e-5 of fp64, spikes = C-oracle neuron of the kernel's own
+    membrane bit for bit."""
+    T, B, H, W, Cc = 10, 1, 36, 48, 96
+    x = spikes((T * B, H, W, Cc), 140)
+    w = rnd((Cc, Cc, 3, 3), 141, -0.1, 0.1)
+    alpha, beta = rnd((Cc,), 142, 0.5, 1.5), rnd((Cc,), 143, -0.2, 0.2)
+    resid = rnd((T * B * H * W, Cc), 144) if with_resid else None
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 1, 1).permute(0, 2, 3, 1).reshape(-1, Cc)
+    ref = ref * alpha.double() + beta.double() + (resid.double() if with_resid else 0)
+    n = B * H * W
+    m = torch.full((T * n, Cc), float("nan"), device=DEV)
+    sp = torch.zeros((T * n, Cc), dtype=torch.uint8, device=DEV)
+    hip.spike_conv2d(x.to(DEV), hip.pack_conv_weight(w.to(DEV), ns), T * B, H, W, Cc, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=m,
+                     out_spike=sp, alpha=alpha.to(DEV), beta=beta.to(DEV), resid=None if resid is None else resid.to(DEV),
+                     sn=hip.NeuronParams("lif", 2.0, 0.1, None), sn_T=T, pos=(n, n, 0, n))
+    assert (m.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    want = R.neuron_ref(m.cpu().view(T, -1), "lif", 2.0, 0.1, None).view(T * n, Cc)
+    assert torch.equal(sp.cpu().float(), want)
