@@ -494,8 +494,13 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
   // and are bound by the per-element epilogue / addressing VALU work, not by the MFMAs, so the smallest tile
   // (most waves in flight) wins for the fp32 and T' = 2 epilogues; the T >= 5 neuron epilogue needs the 96-wide
   // 8-wave tile to amortise its staging.  (ntiles_for() is kept for the tuning override.)
-  (void)ntiles_for;
-  int cfg = (spike && d->sn_T >= 5) ? (ok(1) ? 1 : 2) : ((!spike && d->M >= 16384) ? 2 : 3);
+  int cfg = (spike && d->sn_T >= 5) ? (ok(1) ? 1 : 2) : 3;
+  if (!spike) {
+    // fp32 epilogue: 256 x 32 or 128 x 32 tiles, whichever needs less time in whole rounds of the 768 resident workgroups
+    // (a 256-row tile costs two 128-row ones); ties go to the larger tile (fewer weight reloads).  tools/gemm_cfg_sweep.py
+    const int64_t r2 = (ntiles_for(2) + 767) / 768 * 2, r3 = (ntiles_for(3) + 767) / 768;
+    cfg = r2 <= r3 ? 2 : 3;
+  }
   if (!ok(cfg)) cfg = ok(2) ? 2 : 0;
   if (const char* e = getenv("SDF_GEMM_CFG")) {                  // tuning override: 0..3
     const int c = e[0] - '0';
