@@ -137,6 +137,22 @@ def cpu_baseline(kind, sd, chunk, budget_s=25.0):
             "sample": f"{reps} full forwards of the same 1x10x2x288x384 voxel after 1 warm-up ({dt:.2f} s each), fp32, torch CPU"}
 
 
+def max_over_ranks(dt, device, dist):
+    """The timed region's length is the slowest rank's: MAX all-reduce of the per-rank wall time (the only data the
+    inference path exchanges between ranks).  Also exercised on CPU with gloo (tests/test_replicas_gloo.py)."""
+    if not dist:
+        return dt
+    import torch.distributed as td
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    return float(t.item())
+
+
+def whole_job_rate(n_gpus, steps, dt):
+    """Replicas: every rank runs `steps` forwards of its own sample in `dt` seconds -> aggregate samples / s."""
+    return n_gpus * steps / dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,7 +169,10 @@ def main():
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
         td.init_process_group("nccl")                            # RCCL over xGMI; used only for the timing barrier
+    ndev = max(torch.cuda.device_count(), 1)
+    local_rank %= ndev                                           # more ranks than visible GPUs: share (never silently fail)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -176,16 +195,13 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
     assert torch.isfinite(out["flow"][-1]).all()
-    if dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt, dev, dist)
 
     if rank == 0:
         n_gpus = world if dist else args.gpus
         gemm, neuron = time_dominant_kernels(model)
         res = {
-            "metric": "event-frames/sec fwd (1x10x2x288x384)", "value": n_gpus * args.steps / dt, "unit": "samples/s",
+            "metric": "event-frames/sec fwd (1x10x2x288x384)", "value": whole_job_rate(n_gpus, args.steps, dt), "unit": "samples/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: MS_SpikingformerFlowNet_en4 forward, batch 1 per GPU, 10-bin 288x384 "

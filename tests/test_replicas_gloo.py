@@ -10,6 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = textwrap.dedent("""
     import os, sys, time, json, torch, torch.distributed as td
+    sys.path.insert(0, os.environ["SDF_ROOT"])
+    import bench                                  # the functions bench.py's main() itself uses for N > 1
     td.init_process_group("gloo")
     rank, world = td.get_rank(), td.get_world_size()
     td.barrier()
@@ -17,10 +19,9 @@ WORKER = textwrap.dedent("""
     time.sleep(0.05 * (rank + 1))            # ranks finish at different times
     td.barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64)
-    td.all_reduce(t, op=td.ReduceOp.MAX)
+    mx = bench.max_over_ranks(dt if rank else dt * 0.5, torch.device("cpu"), True)   # rank 0 pretends to be faster
     if rank == 0:
-        print(json.dumps({"n": world, "max_t": float(t.item()), "mine": dt}))
+        print(json.dumps({"n": world, "max_t": mx, "mine": dt, "rate": bench.whole_job_rate(world, 20, mx)}))
     td.barrier()
     td.destroy_process_group()
 """)
@@ -35,9 +36,11 @@ def test_two_rank_gloo_timing_protocol(tmp_path):
     s.close()
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
-                         capture_output=True, text=True, timeout=180, cwd=ROOT)
+                         capture_output=True, text=True, timeout=180, cwd=ROOT, env=dict(os.environ, SDF_ROOT=ROOT))
     assert out.returncode == 0, out.stderr[-2000:]
     import json
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     r = json.loads(line)
     assert r["n"] == 2 and r["max_t"] >= 0.1 - 1e-3            # the slower rank (0.10 s) defines the step time
+    assert r["max_t"] > 0.6 * r["mine"]                         # rank 0 reported half its time: the maximum came from rank 1
+    assert abs(r["rate"] - 2 * 20 / r["max_t"]) < 1e-6          # whole-job rate = all ranks' samples / slowest rank's time
