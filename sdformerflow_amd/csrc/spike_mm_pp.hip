@@ -98,8 +98,6 @@ __global__ __launch_bounds__(768) void spike_mm_pp_kernel(GemmParams P) {
   constexpr int W_BYTES = NSPLIT * BN * W_LD * 2;
   constexpr int BUF = A_BYTES + W_BYTES;                         // 46080 (2 planes) / 59904 (3 planes)
   constexpr int NSLOT = (SPIKE || NSPLIT == 3) ? 2 : 3;
-  // fragment prefetch needs a second register set (8 + 12*planes registers): only where the 168-register budget holds it
-  constexpr bool PREFETCH = NSPLIT <= 2 && !SPIKE;
   constexpr int STG = SPIKE ? 8 * 32 * BN : 0;                   // per consumer wave: 32 x 96 spike bytes (one row block at a time)
   constexpr int WCH = NSPLIT * BN * (KC / 8);                    // 16-byte chunks of a W stage
   constexpr int WIT = WCH / 256;                                 // 3 / 6 / 9 per producer lane
@@ -359,55 +357,38 @@ __global__ __launch_bounds__(768) void spike_mm_pp_kernel(GemmParams P) {
       STAMP(c1);
       const uint8_t* A_s = smem + slot * BUF;
       const uint16_t* W_s = reinterpret_cast<const uint16_t*>(A_s + A_BYTES);
-      if constexpr (PREFETCH) {
-        // Fragment reads run one 16-deep k-step ahead of the MFMAs that use them (two register sets): the 2 + 3*planes
-        // ds_reads of step ks + 1 are in flight while the 6*planes MFMAs of step ks execute, so an s_waitcnt lgkmcnt in front of
-        // an MFMA finds its operands already landed instead of exposing the LDS latency once per pair of MFMAs.
-        uint2 fa[2][2];
-        bf16x8 fb[2][NSPLIT][3];
-        auto frag_load = [&](int ks, uint2 (&xa)[2], bf16x8 (&xb)[NSPLIT][3]) __attribute__((always_inline)) {
-  #pragma unroll
+      // Fragment reads run one (k-step, plane) unit ahead of the MFMAs that use them: the 3 ds_read_b128 of the next unit's
+      // weight fragments (and, at a new k-step, the 2 ds_read_b64 of its spike fragments) are in flight while the 6 MFMAs of the
+      // current unit execute (192 cycles > LDS latency), so the s_waitcnt lgkmcnt in front of an MFMA finds its operands
+      // landed.  Two sets of 3 x 4 + 2 x 2 registers - small enough for every variant of the kernel.
+      constexpr int UNITS = (KC / 16) * NSPLIT;
+      uint2 fa[2][2];
+      bf16x8 fb[2][3];
+      auto frag_load = [&](int u, uint2 (&xa)[2], bf16x8 (&xb)[3], bool with_a) __attribute__((always_inline)) {
+        const int ks = u / NSPLIT, p = u - ks * NSPLIT;
+        if (with_a) {
+#pragma unroll
           for (int rb = 0; rb < 2; ++rb)
             xa[rb] = *reinterpret_cast<const uint2*>(&A_s[(cw * 64 + rb * 32 + l31) * A_LD + ks * 16 + 8 * lh]);
-  #pragma unroll
-          for (int p = 0; p < NSPLIT; ++p)
-  #pragma unroll
-            for (int nb = 0; nb < 3; ++nb)
-              xb[p][nb] = *reinterpret_cast<const bf16x8*>(&W_s[(p * BN + nb * 32 + l31) * W_LD + ks * 16 + 8 * lh]);
-        };
-        frag_load(0, fa[0], fb[0]);
-  #pragma unroll
-        for (int ks = 0; ks < KC / 16; ++ks) {
-          if (ks + 1 < KC / 16) frag_load(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
-          __builtin_amdgcn_sched_barrier(0);                       // keep the prefetch above this step's MFMAs
-          const bf16x8 a0 = expand_spikes<NSPLIT>(fa[ks & 1][0]), a1 = expand_spikes<NSPLIT>(fa[ks & 1][1]);
-  #pragma unroll
-          for (int p = 0; p < NSPLIT; ++p) {                       // plane-outer: an accumulator is revisited after 5 other MFMAs
-  #pragma unroll
-            for (int nb = 0; nb < 3; ++nb) {
-              acc[0][nb] = mma<NSPLIT>(a0, fb[ks & 1][p][nb], acc[0][nb]);
-              acc[1][nb] = mma<NSPLIT>(a1, fb[ks & 1][p][nb], acc[1][nb]);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
         }
-      } else {
 #pragma unroll
-        for (int ks = 0; ks < KC / 16; ++ks) {
-          bf16x8 a[2];
+        for (int nb = 0; nb < 3; ++nb)
+          xb[nb] = *reinterpret_cast<const bf16x8*>(&W_s[(p * BN + nb * 32 + l31) * W_LD + ks * 16 + 8 * lh]);
+      };
+      frag_load(0, fa[0], fb[0], true);
+      bf16x8 a0, a1;
 #pragma unroll
-          for (int rb = 0; rb < 2; ++rb)
-            a[rb] = expand_spikes<NSPLIT>(*reinterpret_cast<const uint2*>(&A_s[(cw * 64 + rb * 32 + l31) * A_LD + ks * 16 + 8 * lh]));
+      for (int u = 0; u < UNITS; ++u) {
+        const int ks = u / NSPLIT, p = u - ks * NSPLIT;
+        if (u + 1 < UNITS) frag_load(u + 1, fa[((u + 1) / NSPLIT) & 1], fb[(u + 1) & 1], (u + 1) % NSPLIT == 0);
+        __builtin_amdgcn_sched_barrier(0);                       // keep the prefetch above this unit's MFMAs
+        if (p == 0) { a0 = expand_spikes<NSPLIT>(fa[ks & 1][0]); a1 = expand_spikes<NSPLIT>(fa[ks & 1][1]); }
 #pragma unroll
-          for (int p = 0; p < NSPLIT; ++p) {                       // plane-outer: an accumulator is revisited after 5 other MFMAs
-#pragma unroll
-            for (int nb = 0; nb < 3; ++nb) {
-              const bf16x8 b = *reinterpret_cast<const bf16x8*>(&W_s[(p * BN + nb * 32 + l31) * W_LD + ks * 16 + 8 * lh]);
-              acc[0][nb] = mma<NSPLIT>(a[0], b, acc[0][nb]);
-              acc[1][nb] = mma<NSPLIT>(a[1], b, acc[1][nb]);
-            }
-          }
+        for (int nb = 0; nb < 3; ++nb) {
+          acc[0][nb] = mma<NSPLIT>(a0, fb[u & 1][nb], acc[0][nb]);
+          acc[1][nb] = mma<NSPLIT>(a1, fb[u & 1][nb], acc[1][nb]);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
       signal(&empty[slot], lane);                                // every fragment of this slot is in registers
       STAMP(c2);
