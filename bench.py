@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 PEAK_HBM_GBPS = 8000.0              # same guide: 8.0 TB/s spec (6.3 TB/s achievable)
-CONV_TRAFFIC_BYTES = (2 * 75463.6 + 104192.0) * 1024     # PMC, see roofline.traffic_source
+CONV_TRAFFIC_BYTES = (2 * 75516.1 + 104192.0) * 1024     # PMC, see roofline.traffic_source
 
 
 def build_model(kind, device):
@@ -81,7 +81,7 @@ def time_dominant_kernels(model, iters=20):
             "bound": "mfma", "achieved": flops / t_conv / 1e12, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
             "us_per_launch": t_conv * 1e6, "traffic": CONV_TRAFFIC_BYTES if ns == 2 else None,
             "traffic_unit": "bytes per launch (HBM read + write)",
-            "traffic_source": "profiles/r1h_pmc_traffic_conv.txt: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and WRITE_SIZE in separate "
+            "traffic_source": "profiles/r1m_pmc_traffic_conv.txt: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and WRITE_SIZE in separate "
                               "passes on this exact launch; algorithmic bytes 239.2e6",
             "note": f"algorithmic flops (2 per multiply-add of the convolution); the kernel issues {ns} 16-bit MFMAs per product "
                     f"(fp32 weights carried as {ns} planes), i.e. {ns}x this on the matrix pipe; dense peak of the f16/bf16 MFMA"}
