@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
 """Benchmark of the SDformerFlow forward hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--neuron lif|psn] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--neuron lif|psn] [--no-cpu] [--inflight F] [--eager]
 
 One "step" = one forward of MS_SpikingformerFlowNet_en4 over one synthetic 1 x 10 x 2 x 288 x 384 event
 voxel (BASELINE config 2) already resident in HBM.  For N > 1 the driver launches one process per GPU
 (torch.distributed.run); the forward does not shard inside a micro-batch (batch elements are
 coupled by the reference's raw reshapes), so every rank runs an independent replica: weak scaling, no
 data-path collective, value = N*K / max-over-ranks(time).
+
+Every rank keeps F (default 3) independent forwards in flight on F HIP streams, each captured once as a HIP graph and
+replayed (`--eager` launches kernel by kernel instead): the layers of a batch-1 forward are too small to fill 256 CUs one
+kernel at a time, independent samples overlap.  A step is still one whole forward of one sample; the K timed steps are dealt
+round-robin to the streams.  The single-stream latency is reported next to the throughput.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant own kernel, timed live with HIP events on the
 launch stream) and `cpu_baseline` (the CPU oracle = port of the reference, timed on this box's host cores).
@@ -156,11 +161,15 @@ def whole_job_rate(n_gpus, steps, dt):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--neuron", default="lif", choices=["lif", "psn"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--inflight", type=int, default=3, help="independent forwards in flight per GPU (HIP streams)")
+    ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying HIP graphs")
     args = ap.parse_args()
+    if args.inflight < 1:
+        ap.error("--inflight must be >= 1")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -186,14 +195,55 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
-        for _ in range(args.warmup):
+        # single-stream latency of one forward (reported beside the throughput; not part of the timed region)
+        for _ in range(2):
             model(chunk)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            model(chunk)
+        torch.cuda.synchronize()
+        latency_ms = (time.perf_counter() - t0) / 5 * 1e3
+
+        # F independent forwards in flight: own stream, own static input, own graph (own activation memory)
+        F_ = args.inflight
+        streams = [torch.cuda.Stream(device=dev) for _ in range(F_)]
+        inputs, outputs, graphs = [], [], []
+        for st in streams:
+            x = chunk.clone()
+            with torch.cuda.stream(st):
+                for _ in range(2):
+                    o = model(x)                                 # also creates this stream's split-K workspace and plan caches
+            torch.cuda.synchronize()
+            g = None
+            if not args.eager:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    o = model(x)
+            inputs.append(x); outputs.append(o); graphs.append(g)
+        torch.cuda.synchronize()
+
+        def step(i):
+            j = i % F_
+            with torch.cuda.stream(streams[j]):
+                if graphs[j] is not None:
+                    graphs[j].replay()
+                else:
+                    outputs[j] = model(inputs[j])
+
+        for i in range(args.warmup):
+            step(i)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = model(chunk)
+        for i in range(args.steps):
+            step(i)
         barrier()
         dt = time.perf_counter() - t0
+    out = outputs[0]
+    with torch.no_grad():
+        ref = model(chunk)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for o in outputs for a, b in zip(o["flow"], ref["flow"])), "in-flight forwards differ from a plain one"
     assert torch.isfinite(out["flow"][-1]).all()
     dt = max_over_ranks(dt, dev, dist)
 
@@ -203,10 +253,13 @@ def main():
         res = {
             "metric": "event-frames/sec fwd (1x10x2x288x384)", "value": whole_job_rate(n_gpus, args.steps, dt), "unit": "samples/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "latency_ms_single_stream": latency_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: MS_SpikingformerFlowNet_en4 forward, batch 1 per GPU, 10-bin 288x384 "
                                    "voxel, neuron=" + args.neuron + f"; spike GEMMs and spike convolutions on 16-bit MFMA with "
-                                   f"{model.gemm_nsplit}-plane fp32-grade weights and fp32 accumulate; replicas per GPU"},
+                                   f"{model.gemm_nsplit}-plane fp32-grade weights and fp32 accumulate; {args.inflight} independent forwards in flight "
+                                   f"per GPU on HIP streams ({'eager launches' if args.eager else 'HIP-graph replay'}); replicas per GPU",
+                       "in_flight": args.inflight, "hip_graph": not args.eager},
             "roofline": gemm, "roofline_neuron": neuron,
             "attention_gemm_roofline_frac": 183.7e9 / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12),
         }

@@ -116,8 +116,9 @@ _WS = {}
 
 
 def workspace(device, nbytes=96 << 20):
-    """One caller-owned scratch buffer per device for the split-K path of the spike matmul / conv kernels."""
-    key = str(device)
+    """One caller-owned scratch buffer per (device, stream) for the split-K path of the spike matmul / conv kernels:
+    forwards running concurrently on different streams must not share partial sums."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     if key not in _WS or _WS[key].numel() < nbytes:
         _WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
     return _WS[key]
