@@ -276,3 +276,31 @@ def test_mdr_config_window8_T5_psn():
     assert abs(out[-1].abs().mean().item() - refs[-1].abs().mean().item()) < 0.2 * refs[-1].abs().mean().item()
     for name, rate, close in report:
         print(f"MDR {name:16s} mismatch-rate {rate:.2e}  max-rel-dev-of-rest {close:.1e}")
+
+
+def test_forwards_in_flight_on_streams_and_graph_replay_are_bit_equal():
+    """bench.py keeps several independent forwards in flight (own HIP stream, own HIP graph): every one of them must be
+    the plain forward bit for bit - separate split-K workspaces, no shared scratch, deterministic kernels."""
+    from sdformerflow_amd.STSwinNet_SNN.Spiking_STSwinNet import MS_SpikingformerFlowNet
+    model, sd, ocfg = build("lif", 144, 192, MS_SpikingformerFlowNet)
+    model = model.to(DEV)
+    xs = [O.prepare_chunk(synth_voxel(1, 10, 144, 192, seed=200 + i)).to(DEV) for i in range(3)]
+    with torch.no_grad():
+        refs = [[f.clone() for f in model(x)["flow"]] for x in xs]
+        streams = [torch.cuda.Stream() for _ in xs]
+        graphs, outs = [], []
+        for st, x in zip(streams, xs):
+            with torch.cuda.stream(st):
+                model(x)                                                 # this stream's workspace / plan caches
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                o = model(x)
+            graphs.append(g); outs.append(o)
+        for _ in range(3):                                               # all three in flight, several rounds
+            for st, g in zip(streams, graphs):
+                with torch.cuda.stream(st):
+                    g.replay()
+        torch.cuda.synchronize()
+    for o, r in zip(outs, refs):
+        assert all(torch.equal(a, b) for a, b in zip(o["flow"], r))
