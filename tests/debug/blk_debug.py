@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Bisect a swin-block mismatch: attention with / without the fused q|k GEMM, MLP with / without the ping-pong kernel."""
 import os, sys, torch
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import test_engine_gpu as T
 model, sd, ocfg = T.build("lif")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Bisect a patch-embedding mismatch: the engine's patch_embed under kernel / weight-plane settings vs the CPU oracle."""
 import os, sys, torch
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import test_engine_gpu as T
 from oracle import sdformer_oracle as O
