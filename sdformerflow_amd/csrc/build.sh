@@ -4,7 +4,7 @@ set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 # -fno-slp-vectorize: packed f32 VALU (v_pk_*) costs more than two scalar ops beside MFMAs and widens register pairs
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function -Wno-pass-failed"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function -Wno-pass-failed ${SDF_EXTRA_FLAGS:-}"
 mkdir -p obj
 pids=()
 for f in neuron spike_gemm spike_mm_ws spike_mm_pp qk_gate elementwise win_attn head_tail; do

@@ -582,6 +582,32 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
   // 256 x 96 tiles, producer waves do the im2col addressing; the ping-pong kernel overlaps epilogues with the MFMAs
   const char* e = getenv("SDF_CONV_PP");                      // tuning override: 0 = barrier-synchronised kernel
   if (spike_mm_pp_supports(P, true) && !(e && e[0] == '0')) return launch_spike_mm_pp(P, true, sdf_stream(stream));
+  // operands beyond the kernel's 31-bit buffer offsets (e.g. 80 images of 240 x 320 x 96 fp32 out): images are
+  // independent, so the fp32 epilogue form is launched in image chunks that fit
+  const int64_t imgs = d->M / ((int64_t)c->OH * c->OW);
+  if (!spike && imgs > 1 && !(e && e[0] == '0')) {
+    for (int64_t nch = 2; nch <= imgs; ++nch) {
+      const int64_t per = (imgs + nch - 1) / nch;
+      GemmParams Q = P;
+      Q.d.M = per * c->OH * c->OW;
+      if (!spike_mm_pp_supports(Q, true)) continue;
+      for (int64_t i0 = 0; i0 < imgs; i0 += per) {
+        const int64_t n = imgs - i0 < per ? imgs - i0 : per, r0 = i0 * c->OH * c->OW;
+        Q = P;
+        Q.d.M = n * c->OH * c->OW;
+        Q.d.A = d->A + i0 * c->H * c->W * c->Cin;
+        if (d->out_rowmap) {
+          Q.d.out_rowmap = d->out_rowmap + r0;
+        } else {
+          Q.d.out = d->out + r0 * d->ldo;
+          if (d->resid) Q.d.resid = d->resid + r0 * d->ldo;
+        }
+        const int rc = launch_spike_mm_pp(Q, true, sdf_stream(stream));
+        if (rc) return rc;
+      }
+      return 0;
+    }
+  }
   if (d->nsplit == 2 || (spike && d->out)) return SDF_E_DTYPE;   // only the ping-pong kernel has these
   return launch_spike_mm_ws(P, true, sdf_stream(stream));
 }

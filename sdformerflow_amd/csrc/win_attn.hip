@@ -8,7 +8,7 @@
 //        (B_,nH,N,hd) head view, (q*scale) k^T + bias[g] (+ mask[w]), NO softmax, @ v, output written through
 //        the reference's (B_,nH,T',N1,hd) -> (T',B_,N1,C) scramble.
 //
-// One workgroup (4 wavefronts of 64) per (window, head).  q/k/v (N<=192 tokens x 32 dims, fp32) are staged
+// Two kernels.  win_attn_kernel (below) is the general one (any N <= 192): q/k/v (N tokens x 32 dims, fp32) staged
 // once in LDS (k and q L2-normalised on the way in for the ANN mode).  Each wave owns 16-query tiles and keeps
 // the whole 16 x N score strip in registers: S^T = K Q^T is computed with v_mfma_f32_16x16x4_f32 (exact fp32,
 // k-ordered fmaf chain) so that the accumulator of key tile jt *is* the A operand of the P.V product
@@ -215,6 +215,289 @@ __global__ __launch_bounds__(256) void win_attn_kernel(AttnParams P) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// win_attn_tiled_kernel: the same arithmetic for even N with a compile-time tile count NTC = ceil(N / 16), built so
+// that the MFMA pipe is the limiter rather than load latency:
+//   * only K (row-major) and V (TRANSPOSED, Vt[d][key]) live in LDS - 48 KB for N = 162, three workgroups per CU;
+//     the P.V B operand is then one ds_read_b128 per 4 MFMAs instead of one ds_read_b32 per MFMA;
+//   * the Q fragment of a 16-query tile (8 floats per lane) comes straight from global memory, one tile ahead;
+//   * bias and mask of the whole 16 x N strip are requested with raw-buffer 8-byte loads (out-of-range offset ->
+//     zeros, no branches) BEFORE the K Q^T MFMAs, so their L2 latency is covered by those MFMAs;
+//   * no control flow inside the strip (NTC is a template parameter): the compiler software-pipelines LDS reads;
+//   * softmax normalisation multiplies by one reciprocal per row.
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+constexpr uint32_t INV_OFF = 0x80000000u;
+
+#ifndef SDF_ATTN_WPE
+#define SDF_ATTN_WPE 3
+#endif
+template <int MODE, int NTC, bool HAS_MASK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WPE, 4))) void win_attn_tiled_kernel(AttnParams P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const SdfWinAttnDesc& d = P.d;
+  constexpr int NP = NTC * 16, LDT = NP + 4;
+  const int N = d.N;
+  float* Ks = lds;                     // [NP][LDW]
+  float* Vt = Ks + NP * LDW;           // [HD][LDT]
+
+  // Workgroup -> (window b, head g).  Consecutive workgroup ids go round-robin over the 8 XCDs (one L2 each), so the
+  // id is first turned into an XCD-contiguous sequence number L; L then walks mask-window-major: the B_/nW batch
+  // copies x nH heads that add the same (N x N) mask are neighbours on one XCD and re-read it from that L2.
+  const int total = gridDim.x, per_xcd = total >> 3;
+  int L = blockIdx.x;
+  if (L < per_xcd * 8) L = (L & 7) * per_xcd + (L >> 3);
+  const int share = (d.B_ / d.nW) * d.nH;                   // workgroups per mask window
+  const int w = L / share, rest = L - w * share;
+  const int bc = rest / d.nH, g = rest - bc * d.nH;
+  const int b = bc * d.nW + w;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int C = d.nH * HD;
+
+  // Q fragment of query tile qt for this lane: Q[qt*16 + l15][8 lg .. 8 lg + 7] (normalised / scaled)
+  auto load_q = [&](int qt, float (&qr)[8]) __attribute__((always_inline)) {
+    const int qi = qt * 16 + l15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qr[i] = 0.f;
+    if (MODE == SDF_ATTN_ANN) {
+      if (qi < N) {
+        const float* base = reinterpret_cast<const float*>(d.q) + ((int64_t)b * N + qi) * 3 * C + g * HD + 8 * lg;
+        const float4 a = *reinterpret_cast<const float4*>(base), c = *reinterpret_cast<const float4*>(base + 4);
+        qr[0] = a.x; qr[1] = a.y; qr[2] = a.z; qr[3] = a.w; qr[4] = c.x; qr[5] = c.y; qr[6] = c.z; qr[7] = c.w;
+      }
+    } else {
+      if (qi < N) {
+        const uint8_t* qp = reinterpret_cast<const uint8_t*>(d.q) + (((int64_t)b * d.nH + g) * N + qi) * HD + 8 * lg;
+        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(qp), w1 = *reinterpret_cast<const uint32_t*>(qp + 4);
+        const float sc = d.scale[g];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          qr[i] = ((w0 >> (8 * i)) & 0xff) ? sc : 0.f;
+          qr[4 + i] = ((w1 >> (8 * i)) & 0xff) ? sc : 0.f;
+        }
+      }
+    }
+  };
+  auto norm_q = [&](float (&qr)[8]) __attribute__((always_inline)) {
+    if (MODE == SDF_ATTN_ANN) {                          // F.normalize(q, dim=-1)
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ss += qr[i] * qr[i];
+      ss += __shfl_xor(ss, 16);
+      ss += __shfl_xor(ss, 32);
+      const float iq = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) qr[i] *= iq;
+    }
+  };
+
+  // 11 query tiles over 4 waves leaves one wave a tile short; rotating the start by the workgroup number moves that
+  // light wave from SIMD to SIMD across the co-resident workgroups
+  const int wv = (wave + L) & 3;
+  float qnext[8];
+  load_q(wv, qnext);                                   // in flight while K / V are staged
+
+  // this window's mask is shared by B_/nW x nH workgroups but cold in L2 for the first of them: touch every 128-byte
+  // line of it now, so that the miss latency is paid together with the K / V loads below, not in front of a softmax
+  float warm = 0.f;
+  if (HAS_MASK) {
+    const float* mw = d.mask + (int64_t)(b % d.nW) * N * N;
+    for (int i = tid * 32; i < N * N; i += 256 * 32) warm += mw[i];
+  }
+  // ---- stage K rows and V^T: 8 lanes per token row (one float4 each) - whole 128-byte lines per request ----
+  {
+    constexpr int IT = (NP * 8 + 255) / 256;
+    const int piece = tid & 7;
+    float4 kq[IT], vq[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int r = (tid >> 3) + 32 * it;
+      kq[it] = vq[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < N) {
+        if (MODE == SDF_ATTN_ANN) {
+          const float* base = reinterpret_cast<const float*>(d.q) + ((int64_t)b * N + r) * 3 * C + g * HD + 4 * piece;
+          kq[it] = *reinterpret_cast<const float4*>(base + C);
+          vq[it] = *reinterpret_cast<const float4*>(base + 2 * C);
+        } else {
+          const int64_t off = (((int64_t)b * d.nH + g) * N + r) * HD + 4 * piece;
+          const uint32_t wk = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(d.k) + off);
+          const uint32_t wv = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(d.v) + off);
+          kq[it] = make_float4((float)(wk & 0xff), (float)((wk >> 8) & 0xff), (float)((wk >> 16) & 0xff), (float)(wk >> 24));
+          vq[it] = make_float4((float)(wv & 0xff), (float)((wv >> 8) & 0xff), (float)((wv >> 16) & 0xff), (float)(wv >> 24));
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int r = (tid >> 3) + 32 * it;
+      float4 kv = kq[it];
+      if (MODE == SDF_ATTN_ANN) {                        // F.normalize(k, dim=-1): the row's 8 lanes are neighbours
+        float sk = kv.x * kv.x + kv.y * kv.y + kv.z * kv.z + kv.w * kv.w;
+        sk += __shfl_xor(sk, 1);
+        sk += __shfl_xor(sk, 2);
+        sk += __shfl_xor(sk, 4);
+        const float ik = 1.f / fmaxf(sqrtf(sk), 1e-12f);
+        kv.x *= ik; kv.y *= ik; kv.z *= ik; kv.w *= ik;
+      }
+      if (r < NP) {
+        *reinterpret_cast<float4*>(&Ks[r * LDW + 4 * piece]) = kv;
+        Vt[(4 * piece + 0) * LDT + r] = vq[it].x;
+        Vt[(4 * piece + 1) * LDT + r] = vq[it].y;
+        Vt[(4 * piece + 2) * LDT + r] = vq[it].z;
+        Vt[(4 * piece + 3) * LDT + r] = vq[it].w;
+      }
+    }
+  }
+  asm volatile("" ::"v"(warm));                                  // the touches only have to have been issued
+  __syncthreads();
+
+  const float ls = (MODE == SDF_ATTN_ANN) ? d.scale[g] : 1.f;
+  const uint32_t tbytes = (uint32_t)N * (uint32_t)N * 4u;
+  const __amdgpu_buffer_rsrc_t bias_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.bias + (int64_t)g * N * N), 0, (int)tbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mask_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(HAS_MASK ? d.mask + (int64_t)(b % d.nW) * N * N : d.bias), 0, HAS_MASK ? (int)tbytes : 0, 0x00020000);
+  const float NEG = (MODE == SDF_ATTN_ANN) ? -INFINITY : 0.f;
+
+  for (int qt = wv; qt < NTC; qt += 4) {
+    if (qt * 16 >= N) break;
+    const int qi = qt * 16 + l15;
+    float qreg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qreg[i] = qnext[i];
+    norm_q(qreg);
+    if (qt + 4 < NTC) load_q(qt + 4, qnext);
+    // ---- request bias / mask of the strip: lane needs [qi][16 jt + 4 lg .. + 3]; whole tiles with one 16-byte load
+    //      (rows are only 8-byte aligned - fine for buffer loads), the ragged last tile with two 8-byte loads ----
+    u32x4 bb[NTC], mm[NTC];
+    const uint32_t rowoff = (uint32_t)qi * (uint32_t)N * 4u;
+    auto load_strip = [&](const __amdgpu_buffer_rsrc_t& rs, u32x4 (&dst)[NTC]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int jt = 0; jt < NTC; ++jt) {
+        const int kb = jt * 16 + 4 * lg;
+        if (jt < NTC - 1) {                                        // 16 (NTC-1) < N: every tile but the last is whole
+          dst[jt] = __builtin_amdgcn_raw_buffer_load_b128(rs, qi < N ? rowoff + (uint32_t)kb * 4u : INV_OFF, 0, 0);
+        } else {
+          const uint32_t o0 = (qi < N && kb < N) ? rowoff + (uint32_t)kb * 4u : INV_OFF;
+          const uint32_t o1 = (qi < N && kb + 2 < N) ? rowoff + (uint32_t)kb * 4u + 8u : INV_OFF;
+          const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(rs, o0, 0, 0);
+          const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(rs, o1, 0, 0);
+          dst[jt] = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+      }
+    };
+    load_strip(bias_rs, bb);
+    if (HAS_MASK) load_strip(mask_rs, mm);
+    // ---- S^T = K Q^T ----
+    f32x4 st[NTC];
+#pragma unroll
+    for (int jt = 0; jt < NTC; ++jt) {
+      const int kj = jt * 16 + l15;
+      const float4 a = *reinterpret_cast<const float4*>(&Ks[kj * LDW + 8 * lg]);
+      const float4 c = *reinterpret_cast<const float4*>(&Ks[kj * LDW + 8 * lg + 4]);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, qreg[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, qreg[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, qreg[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, qreg[3], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.x, qreg[4], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.y, qreg[5], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.z, qreg[6], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w, qreg[7], acc, 0, 0, 0);
+      st[jt] = acc;
+    }
+    // ---- attn = qk * logit_scale + bias (+ mask), separately rounded as the reference computes it ----
+#pragma unroll
+    for (int jt = 0; jt < NTC; ++jt) {
+      const int kb = jt * 16 + 4 * lg;
+      const uint32_t b0 = bb[jt].x, b1 = bb[jt].y, b2 = bb[jt].z, b3 = bb[jt].w;
+      float s0 = st[jt][0] * ls + __uint_as_float(b0), s1 = st[jt][1] * ls + __uint_as_float(b1);
+      float s2 = st[jt][2] * ls + __uint_as_float(b2), s3 = st[jt][3] * ls + __uint_as_float(b3);
+      if (HAS_MASK) {
+        const uint32_t m0 = mm[jt].x, m1 = mm[jt].y, m2 = mm[jt].z, m3 = mm[jt].w;
+        s0 += __uint_as_float(m0); s1 += __uint_as_float(m1); s2 += __uint_as_float(m2); s3 += __uint_as_float(m3);
+      }
+      if (jt == NTC - 1) {                                         // only the last tile can be ragged
+        s0 = (kb + 0 < N) ? s0 : NEG; s1 = (kb + 1 < N) ? s1 : NEG;
+        s2 = (kb + 2 < N) ? s2 : NEG; s3 = (kb + 3 < N) ? s3 : NEG;
+      }
+      st[jt][0] = s0; st[jt][1] = s1; st[jt][2] = s2; st[jt][3] = s3;
+    }
+    if (MODE == SDF_ATTN_ANN) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int jt = 0; jt < NTC; ++jt) m = fmaxf(fmaxf(fmaxf(m, st[jt][0]), fmaxf(st[jt][1], st[jt][2])), st[jt][3]);
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      // exp(x - m) = 2^(x log2e - m log2e): one fma + the hardware exp2 (1 ulp) instead of the ~14-instruction expf;
+      // the argument rounding adds <= |x - m| * 2^-24 relative error - far inside the 1e-3 flow tolerance
+      const float L2E = 1.4426950408889634f, mneg = -m * L2E;
+      float sum = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < NTC; ++jt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(st[jt][r], L2E, mneg));
+          st[jt][r] = e;
+          sum += e;
+        }
+      }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      const float inv = 1.f / sum;
+#pragma unroll
+      for (int jt = 0; jt < NTC; ++jt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[jt][r] *= inv;
+      }
+    }
+    // ---- O = P V : A = P (registers), B = Vt[d = 16 dt + l15][key = 16 jt + 4 lg + s] ----
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jt = 0; jt < NTC; ++jt) {
+      const float4 v0 = *reinterpret_cast<const float4*>(&Vt[l15 * LDT + jt * 16 + 4 * lg]);
+      const float4 v1 = *reinterpret_cast<const float4*>(&Vt[(16 + l15) * LDT + jt * 16 + 4 * lg]);
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(st[jt][0], v0.x, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(st[jt][0], v1.x, o1, 0, 0, 0);
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(st[jt][1], v0.y, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(st[jt][1], v1.y, o1, 0, 0, 0);
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(st[jt][2], v0.z, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(st[jt][2], v1.z, o1, 0, 0, 0);
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(st[jt][3], v0.w, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(st[jt][3], v1.w, o1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = qt * 16 + 4 * lg + r;
+      if (i < N) {
+        int64_t off;
+        if (MODE == SDF_ATTN_ANN) {
+          off = ((int64_t)b * N + i) * C + g * HD;
+        } else {
+          const int t = i / d.N1, n1 = i - t * d.N1;
+          off = (((int64_t)t * d.B_ + b) * d.N1 + n1) * C + g * HD;
+        }
+        d.out[off + l15] = o0[r];
+        d.out[off + 16 + l15] = o1[r];
+      }
+    }
+  }
+}
+
+template <int MODE, int NTC>
+int launch_tiled(const AttnParams& P, hipStream_t s) {
+  constexpr size_t lds = (size_t)(NTC * 16 * LDW + HD * (NTC * 16 + 4)) * sizeof(float);
+  dim3 grid((unsigned)(P.d.B_ * P.d.nH)), block(256);
+  if (P.d.mask) {
+    hipLaunchKernelGGL((win_attn_tiled_kernel<MODE, NTC, true>), grid, block, lds, s, P);
+  } else {
+    hipLaunchKernelGGL((win_attn_tiled_kernel<MODE, NTC, false>), grid, block, lds, s, P);
+  }
+  SDF_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int sdf_win_attn_fwd(const SdfWinAttnDesc* d, void* stream) {
@@ -232,6 +515,18 @@ extern "C" int sdf_win_attn_fwd(const SdfWinAttnDesc* d, void* stream) {
   const size_t lds = (size_t)3 * NP * LDW * sizeof(float);
   dim3 grid((unsigned)(d->B_ * d->nH)), block(256);
   hipStream_t s = sdf_stream(stream);
+  // even N that fits a compiled tile count: the MFMA-paced kernel (8-byte bias / mask loads need N % 2 == 0)
+  const char* ge = getenv("SDF_ATTN_GENERIC");                 // A/B override: 1 = always the general kernel
+  if (d->N % 2 == 0 && (int64_t)d->N * d->N * 4 < (1LL << 31) && !(ge && ge[0] == '1')) {
+    const int nt = (d->N + 15) / 16;                         // compiled tile counts: windows (2,8,8) and (2,9,9)
+    if (d->mode == SDF_ATTN_ANN) {
+      if (nt == 8) return launch_tiled<SDF_ATTN_ANN, 8>(P, s);
+      if (nt == 11) return launch_tiled<SDF_ATTN_ANN, 11>(P, s);
+    } else {
+      if (nt == 8) return launch_tiled<SDF_ATTN_SEW, 8>(P, s);
+      if (nt == 11) return launch_tiled<SDF_ATTN_SEW, 11>(P, s);
+    }
+  }
   static bool lds_opt_in = false;       // > 64 KiB of dynamic LDS needs a one-time opt-in (read-only afterwards)
   if (!lds_opt_in) {
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn_kernel<SDF_ATTN_ANN>),

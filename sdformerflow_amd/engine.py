@@ -415,9 +415,17 @@ class MSFlowEngine:
                 Y = torch.empty((B * D * h * w, 9 * cout), dtype=torch.float32, device=y.device)
                 hip.spike_gemm(s, self._deconv[key], Y, B * D * h * w, 9 * cout, cp)
                 hip.deconv_col2im(Y, B * D, h, w, cout, alpha=bn[0], beta=bn[1], out=z)
+            # the conv kernel addresses its operands with 31-bit byte offsets: a larger z (config 5: 80 images of
+            # 240 x 320 x 96 fp32) goes image chunk by image chunk - the row map of the first n images serves every chunk
+            imgs = per = B * D
+            while per * 4 * h * w * cout * 4 >= 1 << 31:
+                per = (per + 1) // 2
             for cls in ([] if as_gemm else self._deconv_classes(i, B, D, h, w, cp)):
-                hip.spike_conv2d(s, cls["Wp"], B * D, h, w, cp, h, w, cls["KH"], cls["KW"], 1, cls["dy"], cls["dx"], out=z,
-                                 alpha=bn[0], beta=bn[1], out_rowmap=cls["rowmap"])
+                for i0 in range(0, imgs, per):
+                    n = min(per, imgs - i0)
+                    hip.spike_conv2d(s.view(imgs, h, w, cp)[i0:i0 + n], cls["Wp"], n, h, w, cp, h, w, cls["KH"], cls["KW"], 1,
+                                     cls["dy"], cls["dx"], out=z.view(imgs, 4 * h * w, cout)[i0:i0 + n], alpha=bn[0], beta=bn[1],
+                                     out_rowmap=cls["rowmap"][:n * h * w])
             pw, pb, psn, nout = self.preds[i]
             sp = self._neuron_bd(z, psn)                                  # MS pred: SN -> conv1x1 (+bias), 2 outputs
             po = torch.empty((B * D * 4 * h * w, 32), dtype=torch.float32, device=y.device)

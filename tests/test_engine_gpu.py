@@ -304,3 +304,75 @@ def test_forwards_in_flight_on_streams_and_graph_replay_are_bit_equal():
         torch.cuda.synchronize()
     for o, r in zip(outs, refs):
         assert all(torch.equal(a, b) for a, b in zip(o["flow"], r))
+
+
+def test_config5_full_size_T20_batch4_properties():
+    """BASELINE configs[4] at FULL size: 20 bins / T = 20, 480 x 640, batch 4 (stage 0: 120 x 160 tokens padded to
+    126 x 162, 10 080 windows; 80 images of 240 x 320 x 96 fp32 in the decoder, i.e. operands beyond the conv kernel's
+    31-bit offsets, launched in image chunks).  The oracle needs minutes per sample at this size, so the checks are
+    the size-independent ones: shapes, finiteness, run-to-run bit equality, batch coupling (sample 0
+    inside a batch differs from sample 0 alone), and the chunked convolution against the same convolution launched
+    on each half of the images separately (bit-equal)."""
+    from sdformerflow_amd import hip
+    model, sd, ocfg = build("lif", 480, 640, T=20)
+    model = model.to(DEV)
+    chunk = O.prepare_chunk(synth_voxel(4, 20, 480, 640, seed=1234 + 5)).to(DEV)
+    with torch.no_grad():
+        a = [f.clone() for f in model(chunk)["flow"]]
+        b = model(chunk)["flow"]
+        one = model(chunk[:1])["flow"]
+    assert len(a) == 4 and all(f.shape == (4, 2, 480, 640) and torch.isfinite(f).all() for f in a)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert not torch.equal(a[-1][:1], one[-1])
+    assert 0.5 < a[-1].abs().mean().item() / one[-1].abs().mean().item() < 2.0
+    # a convolution whose fp32 output (80 x 240 x 320 x 96 x 4 B = 2.36 GB) exceeds 2^31 bytes: chunked == per-half
+    g = torch.Generator(device=DEV).manual_seed(3)
+    imgs, H, W, Cin, Cout = 80, 240, 320, 48, 96
+    x = (torch.rand((imgs, H, W, Cin), device=DEV, generator=g) < 0.2).to(torch.uint8)
+    Wp = hip.pack_conv_weight(torch.randn((Cout, Cin, 3, 3), device=DEV, generator=g) * 0.05, 2)
+    al, be = torch.rand(Cout, device=DEV, generator=g) + 0.5, torch.randn(Cout, device=DEV, generator=g) * 0.1
+    full = torch.empty((imgs * H * W, Cout), device=DEV)
+    hip.spike_conv2d(x, Wp, imgs, H, W, Cin, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=full, alpha=al, beta=be)
+    half = torch.empty((imgs // 2 * H * W, Cout), device=DEV)
+    for h in range(2):
+        hip.spike_conv2d(x[h * imgs // 2:(h + 1) * imgs // 2], Wp, imgs // 2, H, W, Cin, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1),
+                         out=half, alpha=al, beta=be)
+        assert torch.equal(full[h * imgs // 2 * H * W:(h + 1) * imgs // 2 * H * W], half)
+
+
+def test_large_window_15x15_T20():
+    """The large-window variant of config 5 (window (2,15,15), N = 450 tokens per window, the value left commented in the
+    reference's configs/valid_DSEC_supervised.yml:18): stage 0 teacher-forced against the oracle at 120 x 160 input
+    (one stage-0 window row), then the full 480 x 640 forward for shapes / finiteness / determinism."""
+    cfg = yaml.safe_load(open(CFG))
+    cfg["model"]["spiking_neuron"] = dict(cfg["spiking_neuron"], neuron_type="lif", num_steps=20)
+    cfg["model"]["num_bins"] = 20
+    cfg["swin_transformer"].update(input_size=[120, 160], window_size=[2, 15, 15])
+    model = MS_SpikingformerFlowNet_en4(cfg["model"].copy(), cfg["swin_transformer"].copy())
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict(sd, strict=True)
+    model = model.eval().to(DEV)
+    n = O.NeuronCfg("lif", 0.1, None, 2.0, 20)
+    chunk = O.prepare_chunk(synth_voxel(1, 20, 120, 160, seed=81))
+    p = "sttmultires_unet.encoders.swin3d."
+    eng = model.engine()
+    report = []
+    with torch.no_grad():
+        ref = O.patch_embed(chunk, sd, p + "patch_embed.", n, 20)
+        y = ref.permute(1, 0, 3, 4, 2).contiguous()
+        for i in range(2):
+            r = O.ms_block(y, sd, p + f"layers.0.swin_blocks.{i}.", 3, (2, 15, 15), (0, 0, 0) if i % 2 == 0 else (1, 7, 7), n)
+            compare(f"stage0.block{i}", eng.swin_block(y.contiguous().to(DEV), 0, i), r, report, 1e-2)
+            y = r
+    for name, rate, close in report:
+        print(f"window15 {name:16s} mismatch-rate {rate:.2e}  max-rel-dev-of-rest {close:.1e}")
+    cfg["swin_transformer"].update(input_size=[480, 640])
+    model2 = MS_SpikingformerFlowNet_en4(cfg["model"].copy(), cfg["swin_transformer"].copy())
+    model2.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in model2.state_dict().items()}), strict=True)
+    model2 = model2.eval().to(DEV)
+    big = O.prepare_chunk(synth_voxel(1, 20, 480, 640, seed=82)).to(DEV)
+    with torch.no_grad():
+        a = [f.clone() for f in model2(big)["flow"]]
+        b = model2(big)["flow"]
+    assert all(f.shape == (1, 2, 480, 640) and torch.isfinite(f).all() for f in a)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
