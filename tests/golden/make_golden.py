@@ -272,9 +272,58 @@ def gold_ann_end_to_end():
             fh.write(f"{k} {'x'.join(map(str, v.shape))}\n")
 
 
+def gold_formats():
+    """On-disk formats: the reference's `load_pretrained_interpolate` on seeded position tensors
+    (window 9 -> 15, i.e. the large-window variant of BASELINE config 5) and its `DSECDatasetLite` read-back of the tiny
+    tree of tests/golden/dsec_tree.py.  h5py / torchvision are imported by the reference's dataset module but not used
+    on this path: empty module objects stand in for them here (generation time only)."""
+    import tempfile
+    import types
+    from models.STSwinNet.load_pretrained import load_pretrained_interpolate as ref_interp
+    src = {"blk.attn.relative_position_bias_table": rnd((3 * 17 * 17, 3), 11, -1.0, 2.0),
+           "blk.attn.positional_encoding": rnd((1, 3, 162, 32), 12, -1.0, 2.0),
+           "absolute_pos_embed": rnd((1, 16, 8), 13, -1.0, 2.0),
+           "blk.attn.relative_position_index": torch.zeros(162, 162),
+           "blk.attn.relative_coords_table": torch.zeros(1, 3, 17, 17, 3),
+           "blk.attn_mask": torch.zeros(4, 162, 162),
+           "blk.mlp.fc1.weight": rnd((8, 4), 14, -1.0, 2.0)}
+
+    class Target(torch.nn.Module):
+        def state_dict(self, *a, **k):
+            return {"blk.attn.relative_position_bias_table": torch.zeros(3 * 29 * 29, 3),
+                    "blk.attn.positional_encoding": torch.zeros(1, 3, 450, 32),
+                    "absolute_pos_embed": torch.zeros(1, 36, 8), "blk.mlp.fc1.weight": torch.zeros(8, 4)}
+    sd = {k: v.clone() for k, v in src.items()}
+    ref_interp(Target(), sd)
+    out = {"interp_keys": np.array(sorted(sd.keys()))}
+    for k, v in sd.items():
+        out["interp/" + k] = v
+    for name in ("h5py", "torchvision", "torchvision.transforms"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    from DSEC_dataloader.DSEC_dataset_lite import DSECDatasetLite as RefDS
+    from dsec_tree import make_tree, config
+    with tempfile.TemporaryDirectory() as root:
+        make_tree(root)
+        for tag, kw in (("vox1", {}), ("vox2", {"num_chunks": 2}), ("pol1", {"polarity": False}),
+                        ("cnt2", {"encoding": "cnt", "num_chunks": 2}), ("list1", {"encoding": "list", "preprocessed": False})):
+            ds = RefDS(config(root, **kw), "train")
+            out[f"ds/{tag}/len"] = np.array(len(ds))
+            for i in (0, len(ds) - 1):
+                chunk, mask, label = ds[i]
+                if isinstance(chunk, dict):
+                    for kk, vv in chunk.items():
+                        out[f"ds/{tag}/{i}/chunk_{kk}"] = vv
+                else:
+                    out[f"ds/{tag}/{i}/chunk"] = chunk
+                out[f"ds/{tag}/{i}/mask"] = mask
+                out[f"ds/{tag}/{i}/label"] = label
+    save("formats", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["neurons", "index_maps", "qk_attention", "sew_attention", "ann_attention",
-                             "ms_block", "end_to_end", "ann_end_to_end"]
+                             "ms_block", "end_to_end", "ann_end_to_end", "formats"]
     for w in which:
         globals()["gold_" + w]()
 
