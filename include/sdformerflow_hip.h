@@ -55,6 +55,28 @@ int sdf_lif_fwd(const float* x, void* spike, float* v_last, int T, int64_t N, fl
 int sdf_psn_fwd(const float* x, const float* W, const float* b, void* spike, int T, int64_t N,
                 int spike_dtype, void* stream);
 
+/* ---- training path: backward of the neurons -------------------------------------------------
+ * Replaces: autograd through spikingjelly's multi-step LIFNode / IFNode (torch backend; the reference builds them in
+ * Spiking_modules.py:40-66 with `surrogate_function=ATan()`, `detach_reset` from the YAML) - BPTT over the T steps:
+ *   gh_t = gv_t * dv_t/dh_t + (gs_t [+ reset path unless detach_reset]) * g'(h_t - v_th)
+ *   gx_t = gh_t / tau ;  gv_{t-1} = gh_t - gh_t / tau           (IF: gx_t = gv_{t-1} = gh_t)
+ *   g'(u) = alpha/2 / (1 + (pi/2 * alpha * u)^2)                (surrogate.ATan, the only one the configs use)
+ * x, grad_spike, grad_x: (T, N) fp32 contiguous, N % 4 == 0, 16-byte aligned.  The membrane trajectory is recomputed
+ * from x with the forward's exact arithmetic - the forward saves nothing.  T in {1,2,4,5,8,10,16,20}.
+ * Bit-equal to the CPU autograd of the reference formulas for detach_reset = 1. */
+#define SDF_SURROGATE_ATAN 0
+int sdf_lif_bwd(const float* x, const float* grad_spike, float* grad_x, int T, int64_t N, int kind, float tau,
+                float v_th, int soft_reset, float v_reset, int detach_reset, int surrogate, float alpha, void* stream);
+
+/* Backward of PSN.forward (reference Spiking_submodules.py:207-211): gh = grad_spike * g'(H), grad_x = W^T gh,
+ * grad_W = gh X^T, grad_b = sum_n gh.  grad_W / grad_b (T*T, T fp32) are optional (both or neither, T <= 10): they are
+ * reduced deterministically through `workspace` (sdf_psn_bwd_workspace_bytes, caller-owned).  grad_h (T, N) is an
+ * optional copy of gh (for T > 10 form grad_W = grad_h X^T with a library GEMM). */
+int64_t sdf_psn_bwd_workspace_bytes(int T, int64_t N);
+int sdf_psn_bwd(const float* x, const float* W, const float* b, const float* grad_spike, float* grad_x, float* grad_W,
+                float* grad_b, float* grad_h, void* workspace, int64_t workspace_bytes, int T, int64_t N, int surrogate,
+                float alpha, void* stream);
+
 /* General neuron launch: strided / gathered input, fused eval-BatchNorm and additive prologue.
  * Replaces the reference idiom  SN( BN( y.permute(..) ).permute(..) [+ positional_encoding] )
  * (Spiking_swin_transformer3D.py:670-680, 168-174, 970) and the pad / roll / window_partition_v2

@@ -41,6 +41,10 @@ class LIFNode(_NodeBase):
         return hip.NeuronParams(self.kind, self.tau, self.v_threshold, self.v_reset)
 
     def forward(self, x_seq):
+        if torch.is_grad_enabled() and x_seq.requires_grad:        # training path: HIP forward + HIP BPTT backward
+            from ..autograd import LIFFunction
+            return LIFFunction.apply(x_seq, self.tau, self.v_threshold, self.v_reset, self.detach_reset,
+                                     getattr(self.surrogate_function, "alpha", 2.0), self.kind)
         out, v = hip.lif_fwd(x_seq, self.tau, self.v_threshold, self.v_reset, torch.float32, return_v=True)
         self.v = v
         return out
@@ -80,6 +84,9 @@ class PSN(nn.Module):
                                 psn_b=self.bias.detach().reshape(-1).contiguous())
 
     def forward(self, x_seq):
+        if torch.is_grad_enabled() and (x_seq.requires_grad or self.weight.requires_grad):
+            from ..autograd import PSNFunction
+            return PSNFunction.apply(x_seq, self.weight, self.bias, getattr(self.surrogate_function, "alpha", 2.0))
         return hip.psn_fwd(x_seq, self.weight.detach(), self.bias.detach(), torch.float32)
 
     def extra_repr(self):

@@ -1,0 +1,45 @@
+"""torch.autograd bridges for the training path: forward and backward are both HIP kernels
+(csrc/neuron.hip, csrc/neuron_bwd.hip); nothing is saved between them except the input itself - the backward
+recomputes the membrane trajectory.  No CPU fallback: CPU tensors raise `SdfError` inside `hip`."""
+import torch
+
+from . import hip
+
+
+class LIFFunction(torch.autograd.Function):
+    """Multi-step LIF / IF over dim 0: spikes = LIF(x); dL/dx by BPTT with the ATan surrogate
+    (reference: autograd through spikingjelly's LIFNode as built in Spiking_modules.py:40-66)."""
+
+    @staticmethod
+    def forward(ctx, x, tau, v_th, v_reset, detach_reset, alpha, kind):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.cfg = (tau, v_th, v_reset, detach_reset, alpha, kind)
+        if kind == "if":
+            raise hip.SdfError("IFNode has no forward call site in the reference (Spiking_STSwinNet.py:154-156)")
+        return hip.lif_fwd(x, tau, v_th, v_reset, torch.float32)
+
+    @staticmethod
+    def backward(ctx, grad_spike):
+        (x,) = ctx.saved_tensors
+        tau, v_th, v_reset, detach_reset, alpha, kind = ctx.cfg
+        return hip.lif_bwd(x, grad_spike, tau, v_th, v_reset, detach_reset, alpha, kind), None, None, None, None, None, None
+
+
+class PSNFunction(torch.autograd.Function):
+    """Parallel spiking neuron over dim 0: spikes = (b + W x >= 0); (dL/dx, dL/dW, dL/db) with the ATan surrogate
+    (reference PSN.forward, Spiking_submodules.py:207-211)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, alpha):
+        x = x.contiguous()
+        ctx.save_for_backward(x, W, b)
+        ctx.alpha = alpha
+        return hip.psn_fwd(x, W.detach(), b.detach(), torch.float32)
+
+    @staticmethod
+    def backward(ctx, grad_spike):
+        x, W, b = ctx.saved_tensors
+        need = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        gx, gW, gb = hip.psn_bwd(x, W.detach(), b.detach(), grad_spike, ctx.alpha, need_param_grads=need)
+        return gx, gW, (gb.view_as(b) if gb is not None else None), None

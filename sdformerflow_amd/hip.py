@@ -20,7 +20,7 @@ KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
 
 EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
            "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd", "sdf_head_conv_sn_fwd",
-           "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd")
+           "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes")
 
 
 class SdfError(RuntimeError):
@@ -89,6 +89,7 @@ def lib():
         _lib.sdf_version.restype = C.c_int
         for name in EXPORTS[1:]:
             getattr(_lib, name).restype = C.c_int
+        _lib.sdf_psn_bwd_workspace_bytes.restype = C.c_int64
     return _lib
 
 
@@ -171,6 +172,42 @@ def lif_fwd(x, tau=2.0, v_th=1.0, v_reset=None, out_dtype=torch.float32, return_
                            C.c_int(SDF_F32 if out_dtype == torch.float32 else SDF_U8), _stream())
     _check(rc, "sdf_lif_fwd")
     return (out, v) if return_v else out
+
+
+def lif_bwd(x, grad_spike, tau=2.0, v_th=1.0, v_reset=None, detach_reset=True, alpha=2.0, kind="lif"):
+    """BPTT through the multi-step LIF / IF over dim 0 (sdf_lif_bwd): dL/dx from x and dL/dspike; ATan surrogate."""
+    x, g = x.contiguous(), grad_spike.contiguous()
+    T, N = x.shape[0], x[0].numel()
+    gx = torch.empty_like(x)
+    rc = lib().sdf_lif_bwd(C.c_void_p(_ptr(x, torch.float32)), C.c_void_p(_ptr(g, torch.float32)), C.c_void_p(_ptr(gx)),
+                           C.c_int(T), C.c_int64(N), C.c_int(KIND[kind]), C.c_float(tau), C.c_float(v_th),
+                           C.c_int(1 if v_reset is None else 0), C.c_float(0.0 if v_reset is None else v_reset),
+                           C.c_int(1 if detach_reset else 0), C.c_int(0), C.c_float(alpha), _stream())
+    _check(rc, "sdf_lif_bwd")
+    return gx
+
+
+def psn_bwd(x, W, b, grad_spike, alpha=2.0, need_param_grads=True):
+    """Backward of the parallel spiking neuron (sdf_psn_bwd): (dL/dx, dL/dW, dL/db); ATan surrogate.
+    T <= 10 reduces dW / db in the kernel; larger T takes grad_h from the kernel and one library GEMM."""
+    x, g = x.contiguous(), grad_spike.contiguous()
+    T, N = x.shape[0], x[0].numel()
+    gx = torch.empty_like(x)
+    fused = need_param_grads and T <= 10
+    gW = torch.empty((T, T), dtype=torch.float32, device=x.device) if fused else None
+    gb = torch.empty((T,), dtype=torch.float32, device=x.device) if fused else None
+    gh = torch.empty_like(x) if (need_param_grads and not fused) else None
+    nbytes = lib().sdf_psn_bwd_workspace_bytes(C.c_int(T), C.c_int64(N)) if fused else 0
+    ws = torch.empty((max(nbytes, 4) // 4,), dtype=torch.float32, device=x.device) if fused else None
+    rc = lib().sdf_psn_bwd(C.c_void_p(_ptr(x, torch.float32)), C.c_void_p(_ptr(W.contiguous(), torch.float32)),
+                           C.c_void_p(_ptr(b.contiguous().view(-1), torch.float32)), C.c_void_p(_ptr(g, torch.float32)),
+                           C.c_void_p(_ptr(gx)), C.c_void_p(_ptr(gW)), C.c_void_p(_ptr(gb)), C.c_void_p(_ptr(gh)),
+                           C.c_void_p(_ptr(ws)), C.c_int64(nbytes), C.c_int(T), C.c_int64(N), C.c_int(0), C.c_float(alpha),
+                           _stream())
+    _check(rc, "sdf_psn_bwd")
+    if gh is not None:
+        gW, gb = gh.view(T, -1) @ x.view(T, -1).t(), gh.view(T, -1).sum(1)
+    return gx, gW, gb
 
 
 def psn_fwd(x, W, b, out_dtype=torch.float32):

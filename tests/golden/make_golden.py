@@ -272,6 +272,43 @@ def gold_ann_end_to_end():
             fh.write(f"{k} {'x'.join(map(str, v.shape))}\n")
 
 
+def gold_neuron_grads():
+    """Gradients through the reference's own `Spiking_neuron` factory (Spiking_modules.py:26-99): autograd over the
+    spikingjelly-stub LIFNode (torch backend) and the in-tree PSN, ATan surrogate, seeded x and upstream gradient."""
+    from models.STSwinNet_SNN.Spiking_modules import Spiking_neuron
+    out = {}
+    with torch.enable_grad():
+        for T in (2, 10):
+            x0 = rnd((T, 2048), 300 + T, -0.3, 0.6)
+            x0[:, :64] = 0.1
+            x0[0, 64:128] = 0.2                                   # h == v_th exactly at t = 0
+            g = rnd((T, 2048), 400 + T, -1.0, 2.0)
+            for tag, kw in (("soft_detach", dict(v_reset=None, detach_reset=True)), ("soft_nodetach", dict(v_reset=None, detach_reset=False)),
+                            ("hard_detach", dict(v_reset=0.0, detach_reset=True)), ("hard_nodetach", dict(v_reset=0.0, detach_reset=False)),
+                            ("tau3_soft_detach", dict(v_reset=None, detach_reset=True, tau=3.0))):
+                kw = dict(dict(tau=2.0), **kw)
+                n = Spiking_neuron(num_steps=T, neuron_type="lif", v_th=0.1, surrogate_fun="surrogate.ATan()", **kw)
+                functional.set_step_mode(n, "m")
+                x = x0.clone().requires_grad_(True)
+                s = n(x)
+                s.backward(g)
+                out[f"lif_{tag}_T{T}_s"] = s.detach().to(torch.uint8)
+                out[f"lif_{tag}_T{T}_gx"] = x.grad.clone()
+            n = Spiking_neuron(num_steps=T, neuron_type="psn", v_th=0.1, surrogate_fun="surrogate.ATan()")
+            sd = synth_state_dict({"spiking_neuron.weight": (T, T), "spiking_neuron.bias": (T, 1)}, salt=T)
+            with torch.no_grad():
+                n.spiking_neuron.weight.copy_(sd["spiking_neuron.weight"])
+                n.spiking_neuron.bias.copy_(sd["spiking_neuron.bias"])
+            x = x0.clone().requires_grad_(True)
+            s = n(x)
+            s.backward(g)
+            out[f"psn_T{T}_s"] = s.detach().to(torch.uint8)
+            out[f"psn_T{T}_gx"] = x.grad.clone()
+            out[f"psn_T{T}_gW"] = n.spiking_neuron.weight.grad.clone()
+            out[f"psn_T{T}_gb"] = n.spiking_neuron.bias.grad.clone()
+    save("neuron_grads", **out)
+
+
 def gold_formats():
     """On-disk formats: the reference's `load_pretrained_interpolate` on seeded position tensors
     (window 9 -> 15, i.e. the large-window variant of BASELINE config 5) and its `DSECDatasetLite` read-back of the tiny
@@ -323,7 +360,7 @@ def gold_formats():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["neurons", "index_maps", "qk_attention", "sew_attention", "ann_attention",
-                             "ms_block", "end_to_end", "ann_end_to_end", "formats"]
+                             "ms_block", "end_to_end", "ann_end_to_end", "formats", "neuron_grads"]
     for w in which:
         globals()["gold_" + w]()
 

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "sdformerflow_hip.h")).read()
-    return sorted(set(re.findall(r"^int (sdf_\w+)\(", src, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|int64_t) (sdf_\w+)\(", src, flags=re.M)))
 
 
 def test_header_declares_the_expected_entry_points():

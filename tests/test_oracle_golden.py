@@ -266,3 +266,45 @@ def test_ann_sttflownet_end_to_end_matches_reference():
         ref = g[f"flow{i}"]
         d = np.abs(f[:, :, ::s, ::s].numpy() - ref)
         assert d.max() <= 1e-3 * np.abs(ref).mean(), (i, d.max(), np.abs(ref).mean())      # north-star bound (ANN is not chaotic)
+
+
+# ------------------------------------------------------------------ neuron backward (training path)
+NG = np.load(os.path.join(os.path.dirname(__file__), "golden", "neuron_grads.npz"))
+LIF_GRAD_CASES = [("soft_detach", None, True, 2.0), ("soft_nodetach", None, False, 2.0), ("hard_detach", 0.0, True, 2.0),
+                  ("hard_nodetach", 0.0, False, 2.0), ("tau3_soft_detach", None, True, 3.0)]
+
+
+def neuron_grad_inputs(T):
+    from sdformerflow_amd.synthetic import synth_uniform as rnd
+    x = rnd((T, 2048), 300 + T, -0.3, 0.6)
+    x[:, :64] = 0.1
+    x[0, 64:128] = 0.2
+    return x, rnd((T, 2048), 400 + T, -1.0, 2.0)
+
+
+@pytest.mark.parametrize("T", [2, 10])
+@pytest.mark.parametrize("tag,v_reset,detach,tau", LIF_GRAD_CASES)
+def test_oracle_lif_backward_matches_reference_autograd(T, tag, v_reset, detach, tau):
+    from oracle import neuron_bwd_ref as B
+    x, g = neuron_grad_inputs(T)
+    _, s = B.lif_forward_h(x, tau, 0.1, v_reset)
+    assert np.array_equal(s.numpy().astype(np.uint8), NG[f"lif_{tag}_T{T}_s"])
+    gx = B.lif_backward(x, g, tau, 0.1, v_reset, detach, 2.0)
+    ref = torch.from_numpy(NG[f"lif_{tag}_T{T}_gx"])
+    if detach and tau == 2.0:
+        assert torch.equal(gx, ref)                               # two-term sums only: bit-equal to autograd
+    else:
+        assert (gx - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("T", [2, 10])
+def test_oracle_psn_backward_matches_reference_autograd(T):
+    from oracle import neuron_bwd_ref as B
+    from sdformerflow_amd.synthetic import synth_state_dict
+    x, g = neuron_grad_inputs(T)
+    sd = synth_state_dict({"spiking_neuron.weight": (T, T), "spiking_neuron.bias": (T, 1)}, salt=T)
+    gx, gW, gb = B.psn_backward(x, sd["spiking_neuron.weight"], sd["spiking_neuron.bias"], g, 2.0)
+    for got, key in ((gx, "gx"), (gW, "gW"), (gb, "gb")):
+        ref = torch.from_numpy(NG[f"psn_T{T}_{key}"])
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item(), key
