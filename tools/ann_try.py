@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""BASELINE config 3: STTFlowNet (ANN, STT_voxel config: 20 bins, patch (10,4,4), window (2,9,9), depths 2/2/6) forward at
+batch 8, 288 x 384 - ms per batch and samples/s.  usage: ann_try.py [B] [H] [W]"""
+import os, sys, time, torch, yaml
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+from sdformerflow_amd.STSwinNet import STSwinNet
+from sdformerflow_amd.synthetic import synth_state_dict, synth_voxel
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+H, W = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (288, 384)
+cfg = yaml.safe_load(open(os.path.join(R, "sdformerflow_amd", "configs", "train_DSEC_supervised_STT_voxel.yml")))
+net = STSwinNet.STTFlowNet(dict(cfg["model"], spiking_neuron=None), dict(cfg["swin_transformer"], input_size=[H, W])).eval()
+skip = ("relative_position_index", "relative_coords_table", "num_batches_tracked")
+net.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items() if not k.endswith(skip)}), strict=False)
+net = net.to("cuda:0")
+vox = synth_voxel(B, 20, H, W, seed=1237).to("cuda:0")
+with torch.no_grad():
+    a = [f.clone() for f in net(vox, None)["flow"]]
+    b = net(vox, None)["flow"]
+    torch.cuda.synchronize()
+    fin = [bool(torch.isfinite(f).all()) for f in a]
+    same = [bool(torch.equal(x, y)) for x, y in zip(a, b)]
+    if not (all(fin) and all(same)):
+        print("finite per scale", fin, "bit-equal run to run per scale", same,
+              "max |a-b|", [float((x - y).abs().max()) for x, y in zip(a, b)], "mean |flow|", [float(x.abs().mean()) for x in a])
+    for _ in range(3): net(vox, None)
+    torch.cuda.synchronize(); t0 = time.time()
+    n = 10
+    for _ in range(n): net(vox, None)
+    torch.cuda.synchronize(); dt = (time.time() - t0) / n
+print(f"STTFlowNet B={B} 20 bins {H}x{W}: {dt*1e3:.2f} ms per batch = {B/dt:.1f} samples/s; {len(a)} finite flow maps {tuple(a[-1].shape)}, "
+      f"run-to-run bit-equal {all(same)}; peak memory {torch.cuda.max_memory_allocated()/2**30:.2f} GiB")
