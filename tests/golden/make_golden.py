@@ -309,6 +309,91 @@ def gold_neuron_grads():
     save("neuron_grads", **out)
 
 
+def _no_drop_path(model):
+    """DropPath (timm, stochastic depth 0.2 hard-wired at Spiking_STSwinNet.py:65) draws from the global RNG: replaced by
+    the identity for the fixtures so that they are a function of the seeded inputs only."""
+    for m in model.modules():
+        if hasattr(m, "drop_path"):
+            m.drop_path = torch.nn.Identity()
+
+
+def gold_train_block():
+    """TRAIN-mode forward + backward of the reference's MS swin block and patch merging (batch-stat BN, ATan surrogate,
+    detached reset) on seeded inputs: output, dL/dx, parameter gradients, BN running-stat updates."""
+    out = {}
+    C, nH = 96, 3
+    with torch.enable_grad():
+        for tag, kind, (B, H, W), shift in (("lif_sw", "lif", (2, 18, 21), (1, 4, 4)), ("psn_w", "psn", (1, 9, 21), (0, 0, 0))):
+            kw = spk_kwargs(kind, 4)
+            blk = ref_swin.MS_Spiking_SwinTransformerBlock3D(C, (H, W), nH, window_size=(2, 9, 9), shift_size=shift,
+                                                             norm_layer="BN", **kw)
+            load_synth(blk)
+            blk.train()
+            _no_drop_path(blk)
+            functional.reset_net(blk)
+            x = rnd((B, 4, H, W, C), 17, -0.5, 1.0).requires_grad_(True)
+            g = rnd((B, 4, H, W, C), 18, -1.0, 2.0)
+            Hp, Wp = -(-H // 9) * 9, -(-W // 9) * 9
+            wsz, ssz = ref_ann.get_window_size((4, H, W), (2, 9, 9), shift)
+            mask = ref_swin.compute_mask(4, Hp, Wp, wsz, ssz, torch.device("cpu"))
+            y = blk(x, mask)
+            y.backward(g)
+            out[f"{tag}_y"], out[f"{tag}_gx"] = y.detach(), x.grad.clone()
+            out[f"{tag}_cfg"] = np.array([B, H, W, *shift])
+            for n, prm in blk.named_parameters():
+                if prm.grad is not None:
+                    out[f"{tag}_g/{n}"] = prm.grad.clone()
+            for n, buf in blk.named_buffers():
+                if n.endswith(("running_mean", "running_var")):
+                    out[f"{tag}_r/{n}"] = buf.clone()
+        pm = ref_swin.MS_SpikingPatchMerging((9, 21), C, norm_layer="BN", **spk_kwargs("lif", 4))
+        load_synth(pm)
+        pm.train()
+        functional.reset_net(pm)
+        x = rnd((2, 4, 9, 21, C), 19, -0.5, 1.0).requires_grad_(True)
+        y = pm(x)
+        g = rnd(tuple(y.shape), 20, -1.0, 2.0)
+        y.backward(g)
+        out["merge_y"], out["merge_gx"] = y.detach(), x.grad.clone()
+        out["merge_g/reduction.weight"] = pm.reduction.weight.grad.clone()
+    save("train_block", **out)
+
+
+def gold_train_step():
+    """One TRAIN-mode forward + backward of the whole reference model (3-encoder MS_SpikingformerFlowNet, 144 x 144, batch 2,
+    lif) with the reference's loss (`flow_loss_supervised`, gamma None): loss, flows, gradient norm of every parameter."""
+    from models.STSwinNet_SNN.Spiking_STSwinNet import MS_SpikingformerFlowNet
+    from loss.flow_supervised import flow_loss_supervised
+    config = en4_config("lif")
+    config["swin_transformer"].update(input_size=[144, 144], swin_depths=[2, 2, 6], swin_num_heads=[3, 6, 12], swin_out_indices=[0, 1, 2])
+    out = {}
+    with torch.enable_grad():
+        model = MS_SpikingformerFlowNet(config["model"].copy(), config["swin_transformer"].copy())
+        load_synth(model)
+        model.train()
+        _no_drop_path(model)
+        functional.reset_net(model)
+        vox = synth_voxel(2, 10, 144, 144, seed=1234 + 4)
+        chunk = torch.cat((torch.relu(vox).unsqueeze(2), torch.relu(-vox).unsqueeze(2)), dim=2)
+        lo, hi = chunk[chunk != 0].min(), chunk[chunk != 0].max()
+        chunk[chunk != 0] = (chunk[chunk != 0] - lo) / (hi - lo)
+        label, mask = synth_label(2, 144, 144)
+        res = model(chunk)
+        loss = flow_loss_supervised(config, "cpu")(res["flow"], label, mask, gamma=None)
+        loss.backward()
+        out["loss"] = np.array(float(loss))
+        for i, f in enumerate(res["flow"]):
+            out[f"flow{i}_abs_mean"] = np.array(float(f.abs().mean()))
+        names, norms = [], []
+        for n, prm in model.named_parameters():
+            names.append(n)
+            norms.append(float(prm.grad.norm()) if prm.grad is not None else -1.0)
+        out["grad_names"], out["grad_norms"] = np.array(names), np.array(norms, dtype=np.float64)
+        out["g/preds.2.conv.0.weight"] = model.sttmultires_unet.preds[2].conv[0].weight.grad.clone()
+        out["g/preds.2.conv.0.bias"] = model.sttmultires_unet.preds[2].conv[0].bias.grad.clone()
+    save("train_step", **out)
+
+
 def gold_formats():
     """On-disk formats: the reference's `load_pretrained_interpolate` on seeded position tensors
     (window 9 -> 15, i.e. the large-window variant of BASELINE config 5) and its `DSECDatasetLite` read-back of the tiny
@@ -360,7 +445,7 @@ def gold_formats():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["neurons", "index_maps", "qk_attention", "sew_attention", "ann_attention",
-                             "ms_block", "end_to_end", "ann_end_to_end", "formats", "neuron_grads"]
+                             "ms_block", "end_to_end", "ann_end_to_end", "formats", "neuron_grads", "train_block", "train_step"]
     for w in which:
         globals()["gold_" + w]()
 

@@ -13,6 +13,10 @@ net = STSwinNet.STTFlowNet(dict(cfg["model"], spiking_neuron=None), dict(cfg["sw
 skip = ("relative_position_index", "relative_coords_table", "num_batches_tracked")
 net.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items() if not k.endswith(skip)}), strict=False)
 net = net.to("cuda:0")
+if os.environ.get("ANN_CL") == "1":
+    net = net.to(memory_format=torch.channels_last)
+if os.environ.get("ANN_BENCH") == "1":
+    torch.backends.cudnn.benchmark = True
 vox = synth_voxel(B, 20, H, W, seed=1237).to("cuda:0")
 with torch.no_grad():
     a = [f.clone() for f in net(vox, None)["flow"]]
