@@ -134,8 +134,9 @@ class MS_SpikingformerFlowNet(nn.Module):
         return self._engine
 
     def forward(self, x, log=False):
-        if self.training:
-            raise NotImplementedError("training forward/backward is a later SURVEY.md 8f row; call model.eval()")
+        if self.training:                     # train-mode forward under autograd (batch-stat BN, HIP neurons both ways)
+            from ..train import forward_train
+            return {"flow": forward_train(self, x), "attn": None}
         if log:
             raise NotImplementedError("attention-score logging (attn_sn, dead on the forward path) is not built")
         with torch.no_grad():

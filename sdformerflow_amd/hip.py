@@ -160,9 +160,27 @@ def neuron_fwd(x, out, T, nb, ni, x_sb, x_st, o_sb, o_st, p: NeuronParams, rowma
     return out
 
 
+def _pad4(*ts):
+    """The streaming neuron kernels move 4 neurons per lane: a per-step size that is not a multiple of 4 (e.g. the
+    (T', B_, 81, 3) token gate of the QK attention) is run on a zero-padded (T, N4) copy and sliced back."""
+    shape = ts[0].shape
+    T, N = shape[0], ts[0][0].numel()
+    if N % 4 == 0:
+        return [t.contiguous() for t in ts], None
+    pad = 4 - N % 4
+    return [torch.nn.functional.pad(t.reshape(T, N), (0, pad)) for t in ts], (shape, N)
+
+
+def _unpad4(out, info):
+    return out if info is None else out[:, :info[1]].reshape(info[0])
+
+
 def lif_fwd(x, tau=2.0, v_th=1.0, v_reset=None, out_dtype=torch.float32, return_v=False):
     """Multi-step LIF over dim 0 of a contiguous tensor (sdf_lif_fwd)."""
-    x = x.contiguous()
+    (x,), info = _pad4(x)
+    if info is not None:
+        out = lif_fwd(x, tau, v_th, v_reset, out_dtype, return_v)
+        return (_unpad4(out[0], info), out[1][:info[1]].reshape(info[0][1:])) if return_v else _unpad4(out, info)
     T, N = x.shape[0], x[0].numel()
     out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     v = torch.empty(x.shape[1:], dtype=torch.float32, device=x.device) if return_v else None
@@ -176,7 +194,9 @@ def lif_fwd(x, tau=2.0, v_th=1.0, v_reset=None, out_dtype=torch.float32, return_
 
 def lif_bwd(x, grad_spike, tau=2.0, v_th=1.0, v_reset=None, detach_reset=True, alpha=2.0, kind="lif"):
     """BPTT through the multi-step LIF / IF over dim 0 (sdf_lif_bwd): dL/dx from x and dL/dspike; ATan surrogate."""
-    x, g = x.contiguous(), grad_spike.contiguous()
+    (x, g), info = _pad4(x, grad_spike)
+    if info is not None:
+        return _unpad4(lif_bwd(x, g, tau, v_th, v_reset, detach_reset, alpha, kind), info)
     T, N = x.shape[0], x[0].numel()
     gx = torch.empty_like(x)
     rc = lib().sdf_lif_bwd(C.c_void_p(_ptr(x, torch.float32)), C.c_void_p(_ptr(g, torch.float32)), C.c_void_p(_ptr(gx)),
@@ -190,7 +210,10 @@ def lif_bwd(x, grad_spike, tau=2.0, v_th=1.0, v_reset=None, detach_reset=True, a
 def psn_bwd(x, W, b, grad_spike, alpha=2.0, need_param_grads=True):
     """Backward of the parallel spiking neuron (sdf_psn_bwd): (dL/dx, dL/dW, dL/db); ATan surrogate.
     T <= 10 reduces dW / db in the kernel; larger T takes grad_h from the kernel and one library GEMM."""
-    x, g = x.contiguous(), grad_spike.contiguous()
+    (x, g), info = _pad4(x, grad_spike)
+    if info is not None:                     # padded columns carry x = 0, dL/ds = 0: they add nothing to dW / db
+        gx, gW, gb = psn_bwd(x, W, b, g, alpha, need_param_grads)
+        return _unpad4(gx, info), gW, gb
     T, N = x.shape[0], x[0].numel()
     gx = torch.empty_like(x)
     fused = need_param_grads and T <= 10
@@ -212,7 +235,9 @@ def psn_bwd(x, W, b, grad_spike, alpha=2.0, need_param_grads=True):
 
 def psn_fwd(x, W, b, out_dtype=torch.float32):
     """Parallel spiking neuron over dim 0 of a contiguous tensor (sdf_psn_fwd)."""
-    x = x.contiguous()
+    (x,), info = _pad4(x)
+    if info is not None:
+        return _unpad4(psn_fwd(x, W, b, out_dtype), info)
     T, N = x.shape[0], x[0].numel()
     out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     rc = lib().sdf_psn_fwd(C.c_void_p(_ptr(x, torch.float32)), C.c_void_p(_ptr(W.contiguous(), torch.float32)),

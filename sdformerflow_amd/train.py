@@ -1,0 +1,271 @@
+"""Training path of the MS SDformerFlow models (BASELINE config 4): train-mode forward under
+autograd, the supervised loss, one optimiser step, and the data-parallel gradient all-reduce.
+
+What is hand-written HIP here: every spiking neuron, forward AND backward (`autograd.LIFFunction` / `PSNFunction` ->
+csrc/neuron.hip, csrc/neuron_bwd.hip; 105 neuron calls per forward).  The dense operators between them - Linear /
+Conv2d / ConvTranspose2d and their gradients, batch-statistics BatchNorm - are library work through torch on the same
+stream (rocBLAS / MIOpen); their spike-aware replacements are the next row.  Nothing here touches `oracle/`, and CPU
+tensors are refused by the neuron kernels (`SdfError`).
+
+Reference semantics mirrored (file:line under /root/reference):
+  model forward           models/STSwinNet_SNN/Spiking_STSwinNet.py:278-305, 161-182
+  patch embedding         models/STSwinNet_SNN/Spiking_modules.py:1770-1790 (+ :291-296, :339-347, :811-819, :906-933)
+  stage / block / SSA     models/STSwinNet_SNN/Spiking_swin_transformer3D.py:1065-1088, 824-847, 781-821
+  QK attention            ...:661-717      window_partition_v2 :100-113    window_reverse swin_transformer3D_v2.py:52-65
+  MLP / patch merging     ...:164-181 / :952-974
+  BatchNorm in train mode spikingjelly layer.BatchNorm2d, multi-step: flatten (T,B) -> nn.BatchNorm2d (batch statistics)
+  DropPath                timm 0.6.13 `drop_path` (per-sample Bernoulli keep mask / keep_prob), SSA branch only (:840)
+  loss                    loss/flow_supervised.py:80-105 (gamma None), :14-30
+  step                    train_flow_parallel_supervised_SNN.py:233-336 (reset, forward, loss, backward, clip 100, AdamW)
+  data parallelism        the reference wraps the model in DataParallel: replicas, local batch statistics, summed
+                          gradients; here one process per GPU and ONE bucketed all-reduce(sum)/world per step (RCCL)
+"""
+import torch
+import torch.nn.functional as F
+
+from . import hip
+
+
+# ---------------------------------------------------------------------------------------------- layers
+def _bn(x_nc, bn):
+    """Batch-statistics BatchNorm over dim 1 of (N, C, ...) with the module's parameters; running stats updated in place."""
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return F.batch_norm(x_nc, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps)
+
+
+def _bn_last(x, bn):
+    """(T, B, ..., C): the reference permutes channels to dim 2, flattens (T, B) and applies BatchNorm2d."""
+    C = x.shape[-1]
+    y = _bn(x.reshape(x.shape[0] * x.shape[1], -1, C).permute(0, 2, 1), bn)
+    return y.permute(0, 2, 1).reshape(x.shape)
+
+
+def _bn_ch2(x, bn):
+    """(T, B, C, H, W) -> BatchNorm2d on the (T*B, C, H, W) view."""
+    return _bn(x.flatten(0, 1), bn).view(x.shape)
+
+
+def _conv_seq(x, conv, stride=None, padding=None):
+    """layer.Conv2d in multi-step mode: (T, B, C, H, W) through one conv2d call on the flattened batch."""
+    T, B = x.shape[:2]
+    y = F.conv2d(x.flatten(0, 1), conv.weight, conv.bias, conv.stride if stride is None else stride,
+                 conv.padding if padding is None else padding)
+    return y.view(T, B, *y.shape[1:])
+
+
+def _drop_path(x, p, training):
+    if p <= 0.0 or not training:
+        return x
+    keep = 1.0 - p
+    mask = torch.empty((x.shape[0],) + (1,) * (x.dim() - 1), dtype=x.dtype, device=x.device).bernoulli_(keep)
+    return x * (mask / keep)
+
+
+def rebin_events(x, num_bins, num_steps):
+    """(B, bins, 2, H, W) -> (T, B, num_ch, H, W): time step t takes bin t of each polarity (patch embedding :1775-1784)."""
+    if x.size(1) > num_bins:
+        x = x[:, :num_bins]
+    num_ch = num_bins * 2 // num_steps
+    ev = x.permute(0, 2, 3, 4, 1)
+    chans = [ev[:, i % 2, :, :, (i // 2) * num_steps:(i // 2 + 1) * num_steps] for i in range(num_ch)]
+    return torch.stack(chans, 1).permute(4, 0, 1, 2, 3).contiguous()
+
+
+def ms_resblock(x, rb):
+    y = rb.sn1(x)
+    y = _bn_ch2(_conv_seq(y, rb.conv1[0]), rb.norm1.norm_layer)
+    y = rb.sn2(y)
+    y = _bn_ch2(_conv_seq(y, rb.conv2[0]), rb.norm2.norm_layer)
+    return y + x
+
+
+def patch_embed(x, pe):
+    x = rebin_events(x, pe.num_bins, pe.num_steps)
+    y = pe.head.sn(_bn_ch2(_conv_seq(x, pe.head.conv[0]), pe.head.norm_layer.norm_layer))
+    y = _bn_ch2(_conv_seq(y, pe.conv.conv[0]), pe.conv.norm_layer.norm_layer)
+    for rb in pe.residual_encoding.resblocks:
+        y = ms_resblock(y, rb)
+    T, B = y.shape[:2]
+    res = F.conv2d(y.flatten(0, 1), pe.proj.conv_res.weight, pe.proj.conv_res.bias, stride=2)
+    s = pe.proj.sn(y)
+    z = F.conv2d(s.flatten(0, 1), pe.proj.conv.weight, pe.proj.conv.bias, stride=2, padding=1)
+    z = _bn(z, pe.proj.norm_layer) + res
+    return z.view(T, B, *z.shape[1:])
+
+
+def get_window_size(x_size, window_size, shift_size):
+    ws, ss = list(window_size), list(shift_size)
+    for i in range(3):
+        if x_size[i] <= window_size[i]:
+            ws[i], ss[i] = x_size[i], 0
+    return tuple(ws), tuple(ss)
+
+
+def qk_attention(x, attn):
+    """x (T', B_, N1, C): slice list of the windows, T' = window depth.  Returns (T', B_, N1, C)."""
+    Tq, B_, N1, C = x.shape
+    nH = attn.num_heads
+    hd = C // nH
+    xs = attn.proj_sn(x)
+    q = attn.sn_q(_bn_last(F.linear(xs, attn.linear_q.weight), attn.bn_q.norm_layer))
+    k = _bn_last(F.linear(xs, attn.linear_k.weight), attn.bn_k.norm_layer)
+    k = attn.sn_k(k + attn.positional_encoding.reshape(Tq, 1, N1, C))
+    a = attn.sn2_q(q.reshape(Tq, B_, N1, nH, hd).sum(-1))              # token gate per head: sum over the head's channels
+    e = k * a.repeat_interleave(hd, dim=-1)
+    z = e.reshape(B_, nH, Tq, N1, hd).permute(2, 0, 3, 1, 4).reshape(Tq, B_, N1, C)     # the reference's raw head reshape
+    return _bn_last(F.linear(z, attn.proj.weight, attn.proj.bias), attn.proj_bn.norm_layer)
+
+
+def ssa(x, blk):
+    """pad -> cyclic shift -> window_partition_v2 (raw view to (Wd, B_, Wh, Ww, C)) -> attention -> reverse -> crop."""
+    B, D, H, W, C = x.shape
+    (Wd, Wh, Ww), ss = get_window_size((D, H, W), blk.window_size, blk.shift_size)
+    pd, ph, pw = (Wd - D % Wd) % Wd, (Wh - H % Wh) % Wh, (Ww - W % Ww) % Ww
+    x = F.pad(x, (0, 0, 0, pw, 0, ph, 0, pd))
+    Dp, Hp, Wp = D + pd, H + ph, W + pw
+    if any(s > 0 for s in ss):
+        x = torch.roll(x, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
+    xw = x.view(B, Dp // Wd, Wd, Hp // Wh, Wh, Wp // Ww, Ww, C).permute(0, 1, 3, 5, 2, 4, 6, 7).contiguous()
+    B_ = B * (Dp // Wd) * (Hp // Wh) * (Wp // Ww)
+    y = qk_attention(xw.view(Wd, B_, Wh * Ww, C), blk.attn)              # raw view: step t' of window b' is slice t' B_ + b'
+    y = y.reshape(B, Dp // Wd, Hp // Wh, Wp // Ww, Wd, Wh, Ww, C).permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, Dp, Hp, Wp, C)
+    if any(s > 0 for s in ss):
+        y = torch.roll(y, shifts=ss, dims=(1, 2, 3))
+    return y[:, :D, :H, :W, :].contiguous()
+
+
+def ms_mlp(x, mlp):
+    h = _bn_last(F.linear(mlp.sn1(x), mlp.fc1.weight, mlp.fc1.bias), mlp.bn1.norm_layer)
+    return _bn_last(F.linear(mlp.sn2(h), mlp.fc2.weight, mlp.fc2.bias), mlp.bn2.norm_layer)
+
+
+def ms_block(x, blk, training=True):
+    x = _drop_path(ssa(x, blk), blk.drop_path_rate, training) + x
+    return ms_mlp(x.permute(1, 0, 2, 3, 4).contiguous(), blk.mlp).permute(1, 0, 2, 3, 4) + x
+
+
+def ms_patch_merge(x, pm):
+    B, D, H, W, C = x.shape
+    if H % 2 or W % 2:
+        x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+    x = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
+    x = pm.sn(x.permute(1, 0, 2, 3, 4).contiguous())
+    return _bn_last(F.linear(x, pm.reduction.weight), pm.norm.norm_layer).permute(1, 0, 2, 3, 4)
+
+
+def skip_concat_ch(x1, x2):
+    dY, dX = x2.shape[-2] - x1.shape[-2], x2.shape[-1] - x1.shape[-1]
+    return torch.cat([F.pad(x1, (dX // 2, dX - dX // 2, dY // 2, dY - dY // 2)), x2], dim=2)
+
+
+def forward_train(model, x):
+    """(B, bins, 2, H, W) on the GPU -> list of flow maps (B, 2, H, W), differentiable; BN running stats are updated."""
+    if not x.is_cuda:
+        raise hip.SdfError("the training path runs on the GPU only (no CPU fallback)")
+    H, W = x.shape[-2:]
+    unet = model.sttmultires_unet
+    sw = unet.encoders.swin3d
+    y = patch_embed(x.float(), sw.patch_embed).permute(1, 0, 3, 4, 2).contiguous()          # (B, D, h, w, C)
+    blocks = []
+    for i, layer in enumerate(sw.layers):
+        for blk in layer.swin_blocks:
+            y = ms_block(y, blk, model.training)
+        if i in sw.out_indices:
+            blocks.append(y.permute(1, 0, 4, 2, 3).contiguous())                            # (D, B, C, h, w)
+        if layer.downsample is not None:
+            y = ms_patch_merge(y, layer.downsample)
+    y = blocks[-1]
+    for rb in unet.resblocks:
+        y = ms_resblock(y, rb)
+    preds, E = [], len(blocks)
+    for i in range(E):
+        y = skip_concat_ch(y, blocks[E - i - 1])
+        if i > 0:
+            y = skip_concat_ch(preds[-1], y)
+        dec, pr = unet.decoders[i], unet.preds[i]
+        s = dec.sn(y.contiguous())
+        T, B = s.shape[:2]
+        dc = dec.deconv[0]
+        z = F.conv_transpose2d(s.flatten(0, 1), dc.weight, dc.bias, stride=2, padding=dc.kernel_size[0] // 2, output_padding=1)
+        y = _bn_ch2(z.view(T, B, *z.shape[1:]), dec.norm_layer.norm_layer)
+        preds.append(_conv_seq(pr.sn(y), pr.conv[0], padding=0))
+    flows = []
+    for f in preds:
+        f = f.sum(0)
+        flows.append(F.interpolate(f, scale_factor=(H / f.shape[-2], W / f.shape[-1])))
+    return flows
+
+
+# ---------------------------------------------------------------------------------------------- loss, step, all-reduce
+def flow_loss_supervised(pred_list, gt_flow, mask, flow_scaling=1.0, lambda_mod=1.0):
+    n = torch.sum(mask)
+    cur = 0.0
+    for pred in pred_list:
+        flow = pred * flow_scaling
+        err = torch.sqrt((flow - gt_flow).pow(2).sum(1) + 1e-8).view(flow.shape[0], -1) * mask.reshape(flow.shape[0], -1)
+        cur = cur + lambda_mod * (torch.sum(err, dim=1) / (n + 1e-9))
+    return torch.mean(cur / len(pred_list))
+
+
+class GradientBuckets:
+    """Flat fp32 gradient buckets for the data-parallel step: the parameters' `.grad` are VIEWS into a few large
+    contiguous buffers (default 64 MiB - ring all-reduce over xGMI is per-link bound, few large messages beat many small
+    ones; the whole en4 model is 220 MB = 4 buckets), so `all_reduce()` is one collective per bucket with no packing
+    copies, launched asynchronously bucket by bucket and waited once."""
+
+    def __init__(self, params, bucket_bytes=64 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets, cur, cur_n = [], [], 0
+        for p in reversed(self.params):                                # backward produces gradients last layer first
+            if cur and (cur_n + p.numel()) * 4 > bucket_bytes:
+                self.buckets.append(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            self.buckets.append(cur)
+        self.flat = []
+        for b in self.buckets:
+            buf = torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device)
+            off = 0
+            for p in b:
+                p.grad = buf[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            self.flat.append(buf)
+
+    def zero(self):
+        for buf in self.flat:
+            buf.zero_()
+
+    def all_reduce(self, dist=None, world=1):
+        """Sum over ranks / world.  Parameters that received no gradient on any rank (the dead attn_sn of the PSN model)
+        contribute zeros on every rank alike."""
+        if dist is None or world <= 1:
+            return
+        works = [dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True) for buf in self.flat]
+        for w in works:
+            w.wait()
+        for buf in self.flat:
+            buf.div_(world)
+
+
+def train_step(model, optimizer, chunk, label, mask, buckets=None, dist=None, world=1, clip_grad=100.0, flow_scaling=1.0,
+               lambda_mod=1.0):
+    """One step of train_flow_parallel_supervised_SNN.py's loop body on this rank's micro-batch; returns the loss tensor."""
+    from .spikingjelly_compat import functional
+    model.train()
+    functional.reset_net(model)
+    if buckets is not None:
+        buckets.zero()
+    else:
+        optimizer.zero_grad(set_to_none=True)
+    flows = forward_train(model, chunk)
+    loss = flow_loss_supervised(flows, label, mask, flow_scaling, lambda_mod)
+    loss.backward()
+    if buckets is not None:
+        buckets.all_reduce(dist, world)
+    if clip_grad is not None:
+        torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], clip_grad)
+    optimizer.step()
+    return loss.detach()

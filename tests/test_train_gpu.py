@@ -1,0 +1,140 @@
+"""Training path (BASELINE config 4) on the GPU: train-mode forward + backward of the product
+(HIP neurons both ways, batch-stat BN, library GEMMs / convs) against fixtures produced by the REAL reference's
+autograd (tests/golden/make_golden.py `train_block`, `train_step`) and against the CPU oracle's train mode.
+
+Tolerances: an element counts as a mismatch when it is off by more than 1e-3 of the tensor's mean magnitude; the
+allowed mismatch RATE is what the spike flips between two GEMM implementations (rocBLAS here, MKL in the fixture) cause
+inside one block - the same teacher-forced logic as the forward parity tests."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from sdformerflow_amd import train
+from sdformerflow_amd.STSwinNet_SNN import Spiking_swin_transformer3D as SW
+from sdformerflow_amd.STSwinNet_SNN.Spiking_STSwinNet import MS_SpikingformerFlowNet
+from sdformerflow_amd.synthetic import synth_label, synth_state_dict, synth_uniform as rnd, synth_voxel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+HERE = os.path.dirname(os.path.abspath(__file__))
+TB = np.load(os.path.join(HERE, "golden", "train_block.npz"))
+TS = np.load(os.path.join(HERE, "golden", "train_step.npz"))
+CFG = os.path.join(HERE, "..", "sdformerflow_amd", "configs", "train_DSEC_supervised_SDformerFlow_en4.yml")
+
+
+def kw(kind, T):
+    return {"num_steps": T, "v_reset": None, "v_th": 0.1, "neuron_type": kind, "surrogate_fun": "surrogate.ATan()", "tau": 2.0,
+            "detach_reset": True, "spike_norm": "BN"}
+
+
+def load_synth(mod):
+    mod.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in mod.state_dict().items()}), strict=True)
+    return mod.to(DEV).train()
+
+
+def rate(got, ref):
+    got, ref = got.detach().float().cpu(), torch.as_tensor(ref).float()
+    assert got.shape == ref.shape
+    scale = ref.abs().mean().item() + 1e-12
+    return ((got - ref).abs() > 1e-3 * scale).float().mean().item()
+
+
+@pytest.mark.parametrize("tag,kind", [("lif_sw", "lif"), ("psn_w", "psn")])
+def test_train_mode_block_matches_reference_autograd(tag, kind):
+    B, H, W, *shift = (int(v) for v in TB[f"{tag}_cfg"])
+    blk = load_synth(SW.MS_Spiking_SwinTransformerBlock3D(96, (H, W), 3, window_size=(2, 9, 9), shift_size=tuple(shift),
+                                                           norm_layer="BN", **kw(kind, 4)))
+    x = rnd((B, 4, H, W, 96), 17, -0.5, 1.0).to(DEV).requires_grad_(True)
+    g = rnd((B, 4, H, W, 96), 18, -1.0, 2.0).to(DEV)
+    y = train.ms_block(x, blk, training=True)
+    y.backward(g)
+    report = {"y": rate(y, TB[f"{tag}_y"]), "gx": rate(x.grad, TB[f"{tag}_gx"])}
+    params = dict(blk.named_parameters())
+    for k in TB.files:
+        if k.startswith(tag + "_g/"):
+            name = k[len(tag) + 3:]
+            if params[name].grad is None:
+                assert float(np.abs(TB[k]).max()) == 0.0, name
+            elif name.endswith("proj.bias"):               # a bias in front of a batch-stat BN: rounding noise on both sides
+                assert params[name].grad.abs().max().item() < 1e-3 * float(np.abs(TB[f"{tag}_g/attn.proj.weight"]).mean())
+            else:
+                report[name] = rate(params[name].grad, TB[k])
+        if k.startswith(tag + "_r/"):
+            name = k[len(tag) + 3:]
+            report["running:" + name] = rate(dict(blk.named_buffers())[name], TB[k])
+    worst = max(report.values())
+    print(f"train block {tag}: mismatch rates y {report['y']:.2e} gx {report['gx']:.2e} worst {worst:.2e} "
+          f"({max(report, key=report.get)})")
+    assert report["y"] <= 1e-2 and report["gx"] <= 2e-2 and worst <= 5e-2, report
+
+
+def test_train_mode_patch_merging_matches_reference_autograd():
+    pm = load_synth(SW.MS_SpikingPatchMerging((9, 21), 96, norm_layer="BN", **kw("lif", 4)))
+    x = rnd((2, 4, 9, 21, 96), 19, -0.5, 1.0).to(DEV).requires_grad_(True)
+    y = train.ms_patch_merge(x, pm)
+    y.backward(rnd(tuple(y.shape), 20, -1.0, 2.0).to(DEV))
+    assert rate(y, TB["merge_y"]) <= 1e-3 and rate(x.grad, TB["merge_gx"]) <= 1e-3
+    assert rate(pm.reduction.weight.grad, TB["merge_g/reduction.weight"]) <= 1e-3
+
+
+def small_model():
+    cfg = yaml.safe_load(open(CFG))
+    cfg["model"]["spiking_neuron"] = dict(cfg["spiking_neuron"], neuron_type="lif")
+    cfg["swin_transformer"].update(input_size=[144, 144], swin_depths=[2, 2, 6], swin_num_heads=[3, 6, 12], swin_out_indices=[0, 1, 2])
+    model = load_synth(MS_SpikingformerFlowNet(cfg["model"].copy(), cfg["swin_transformer"].copy()))
+    for m in model.modules():
+        if hasattr(m, "drop_path_rate"):
+            m.drop_path_rate = 0.0                                     # the fixture was made with DropPath = identity
+    from sdformerflow_amd import harness
+    chunk = harness.prepare_chunk(synth_voxel(2, 10, 144, 144, seed=1234 + 4)).to(DEV)
+    label, mask = synth_label(2, 144, 144)
+    return model, chunk, label.to(DEV), mask.to(DEV)
+
+
+def test_whole_model_train_step_matches_reference():
+    """Loss and per-parameter gradient norms of one train-mode forward + backward (3-encoder model, 144 x 144, batch 2)
+    against the reference's (fixture `train_step`): loss within 2 %, 90 % of the gradient norms within 20 % (the net is
+    chaotic, DESIGN.md section 2 - the CPU oracle meets the same bar against the same fixture)."""
+    model, chunk, label, mask = small_model()
+    flows = model(chunk)["flow"]
+    assert len(flows) == 3 and all(f.shape == (2, 2, 144, 144) for f in flows)
+    loss = train.flow_loss_supervised(flows, label, mask, 1.0, 1.0)
+    loss.backward()
+    ref_loss = float(TS["loss"])
+    assert abs(loss.item() - ref_loss) <= 0.02 * ref_loss, (loss.item(), ref_loss)
+    params = dict(model.named_parameters())
+    ok = tot = 0
+    for n, r in zip((str(n) for n in TS["grad_names"]), TS["grad_norms"]):
+        g = params[n].grad
+        if r < 0:
+            assert g is None or float(g.abs().max()) == 0.0, n
+            continue
+        tot += 1
+        ok += abs(float(g.norm()) - r) <= 0.2 * r + 1e-12
+    print(f"train step: loss {loss.item():.6f} vs reference {ref_loss:.6f}; {ok} of {tot} gradient norms within 20 %")
+    assert ok >= 0.9 * tot, (ok, tot)
+    gb = params["sttmultires_unet.preds.2.conv.0.bias"].grad.cpu()
+    assert torch.allclose(gb, torch.from_numpy(TS["g/preds.2.conv.0.bias"]), rtol=0.05), gb      # last layer: 2 numbers
+
+
+def test_adamw_steps_reduce_the_loss_and_update_running_stats():
+    """The loop body of train_flow_parallel_supervised_SNN.py (reset, forward, loss, backward, clip 100, AdamW 1e-4) on a
+    fixed micro-batch, through flat gradient buckets: the loss goes down, running statistics move, eval still works."""
+    model, chunk, label, mask = small_model()
+    buckets = train.GradientBuckets(model.parameters())
+    assert all(p.grad is not None and p.grad.data_ptr() >= b.data_ptr() for b in buckets.flat[:1] for p in buckets.buckets[0])
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01)          # the reference's optimiser settings
+    rm0 = model.sttmultires_unet.encoders.swin3d.patch_embed.head.norm_layer.norm_layer.running_mean.clone()
+    w0 = model.sttmultires_unet.preds[2].conv[0].weight.detach().clone()
+    losses = [train.train_step(model, opt, chunk, label, mask, buckets=buckets).item() for _ in range(10)]
+    print("losses", ["%.4f" % v for v in losses])
+    assert all(np.isfinite(losses)) and losses[-1] < 0.85 * losses[0] and losses[-1] < losses[-4]     # measured: 5.54 -> 3.78
+    assert not torch.equal(w0, model.sttmultires_unet.preds[2].conv[0].weight.detach())
+    assert not torch.equal(rm0, model.sttmultires_unet.encoders.swin3d.patch_embed.head.norm_layer.norm_layer.running_mean)
+    model.eval()
+    with torch.no_grad():
+        out = model(chunk)["flow"]
+    assert all(torch.isfinite(f).all() for f in out)
