@@ -2,6 +2,7 @@
 """Benchmark of the SDformerFlow forward hot path on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--neuron lif|psn] [--no-cpu] [--inflight F] [--eager]
+    python bench.py --train [--local-batch B] ...      (BASELINE configs[3], the training step; not the default workload)
 
 One "step" = one forward of MS_SpikingformerFlowNet_en4 over one synthetic 1 x 10 x 2 x 288 x 384 event
 voxel (BASELINE config 2) already resident in HBM.  For N > 1 the driver launches one process per GPU
@@ -158,8 +159,57 @@ def whole_job_rate(n_gpus, steps, dt):
     return n_gpus * steps / dt
 
 
+def main_train(args, world, rank, dev, dist, td):
+    """BASELINE configs[3] (not the default workload): supervised training step of MS_SpikingformerFlowNet_en4 - train-mode
+    forward, loss, backward, bucketed gradient all-reduce over RCCL (N > 1), clip, AdamW - on a local batch per GPU."""
+    from sdformerflow_amd import train
+    from sdformerflow_amd.harness import prepare_chunk
+    from sdformerflow_amd.synthetic import synth_label, synth_voxel
+    model, _ = build_model(args.neuron, dev)
+    model.train()
+    B = args.local_batch
+    chunk = prepare_chunk(synth_voxel(B, 10, 288, 384, seed=1238 + rank)).to(dev)
+    label, mask = (t.to(dev) for t in synth_label(B, 288, 384))
+    buckets = train.GradientBuckets(model.parameters())
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01)
+
+    def barrier():
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    losses = []
+    for _ in range(args.warmup):
+        train.train_step(model, opt, chunk, label, mask, buckets=buckets, dist=td if dist else None, world=world)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(train.train_step(model, opt, chunk, label, mask, buckets=buckets, dist=td if dist else None, world=world))
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, dev, dist)
+    losses = [float(v) for v in losses]
+    assert all(v == v and abs(v) != float("inf") for v in losses), "non-finite loss"
+    if rank == 0:
+        n_gpus = world if dist else args.gpus
+        print(json.dumps({
+            "metric": "training samples/sec (fwd+bwd+AdamW, 10-bin 288x384)", "value": n_gpus * B * args.steps / dt, "unit": "samples/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3]: MS_SpikingformerFlowNet_en4 supervised training step, local batch {B} per "
+                                   f"GPU (global {n_gpus * B}), neuron={args.neuron}, AdamW 1e-4 / wd 0.01 / clip 100; spiking neurons "
+                                   "forward + backward on HIP kernels, dense operators and their gradients on rocBLAS / MIOpen, "
+                                   f"{len(buckets.flat)} flat gradient buckets all-reduced over RCCL", "local_batch": B,
+                       "gradient_bytes": sum(b.numel() for b in buckets.flat) * 4},
+            "loss_first_last": [losses[0], losses[-1]], "peak_memory_gib": torch.cuda.max_memory_allocated() / 2 ** 30}))
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--train", action="store_true", help="BASELINE configs[3]: training step instead of the forward benchmark")
+    ap.add_argument("--local-batch", type=int, default=4, help="--train: samples per GPU and step")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
@@ -184,6 +234,9 @@ def main():
     local_rank %= ndev                                           # more ranks than visible GPUs: share (never silently fail)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    if args.train:
+        return main_train(args, world, rank, dev, dist, td if dist else None)
 
     model, sd = build_model(args.neuron, dev)
     chunk_cpu = synthetic_chunk()
