@@ -180,11 +180,12 @@ def main_train(args, world, rank, dev, dist, td):
 
     losses = []
     for _ in range(args.warmup):
-        train.train_step(model, opt, chunk, label, mask, buckets=buckets, dist=td if dist else None, world=world)
+        train.train_step(model, opt, chunk, label, mask, buckets=buckets, dist=td if dist else None, world=world, amp=args.amp)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses.append(train.train_step(model, opt, chunk, label, mask, buckets=buckets, dist=td if dist else None, world=world))
+        losses.append(train.train_step(model, opt, chunk, label, mask, buckets=buckets, dist=td if dist else None, world=world,
+                                       amp=args.amp))
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0, dev, dist)
     losses = [float(v) for v in losses]
@@ -194,7 +195,8 @@ def main_train(args, world, rank, dev, dist, td):
         print(json.dumps({
             "metric": "training samples/sec (fwd+bwd+AdamW, 10-bin 288x384)", "value": n_gpus * B * args.steps / dt, "unit": "samples/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 autocast (fp32 neurons, BN statistics, loss, AdamW)" if args.amp else "f32",
+            "data": "synthetic",
             "config": {"workload": f"BASELINE configs[3]: MS_SpikingformerFlowNet_en4 supervised training step, local batch {B} per "
                                    f"GPU (global {n_gpus * B}), neuron={args.neuron}, AdamW 1e-4 / wd 0.01 / clip 100; spiking neurons "
                                    "forward + backward on HIP kernels, dense operators and their gradients on rocBLAS / MIOpen, "
@@ -210,6 +212,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--train", action="store_true", help="BASELINE configs[3]: training step instead of the forward benchmark")
     ap.add_argument("--local-batch", type=int, default=4, help="--train: samples per GPU and step")
+    ap.add_argument("--amp", action="store_true", help="--train: bf16 autocast for the dense operators (the reference uses fp16 amp)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)

@@ -12,7 +12,8 @@ class LIFFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, tau, v_th, v_reset, detach_reset, alpha, kind):
-        x = x.contiguous()
+        ctx.in_dtype = x.dtype
+        x = x.float().contiguous()                  # under bf16 autocast the producer hands over bf16: the membrane is fp32
         ctx.save_for_backward(x)
         ctx.cfg = (tau, v_th, v_reset, detach_reset, alpha, kind)
         if kind == "if":
@@ -23,7 +24,8 @@ class LIFFunction(torch.autograd.Function):
     def backward(ctx, grad_spike):
         (x,) = ctx.saved_tensors
         tau, v_th, v_reset, detach_reset, alpha, kind = ctx.cfg
-        return hip.lif_bwd(x, grad_spike, tau, v_th, v_reset, detach_reset, alpha, kind), None, None, None, None, None, None
+        gx = hip.lif_bwd(x, grad_spike.float(), tau, v_th, v_reset, detach_reset, alpha, kind)
+        return gx.to(ctx.in_dtype), None, None, None, None, None, None
 
 
 class PSNFunction(torch.autograd.Function):
@@ -32,14 +34,15 @@ class PSNFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, b, alpha):
-        x = x.contiguous()
+        ctx.in_dtype = x.dtype
+        x = x.float().contiguous()
         ctx.save_for_backward(x, W, b)
         ctx.alpha = alpha
-        return hip.psn_fwd(x, W.detach(), b.detach(), torch.float32)
+        return hip.psn_fwd(x, W.detach().float(), b.detach().float(), torch.float32)
 
     @staticmethod
     def backward(ctx, grad_spike):
         x, W, b = ctx.saved_tensors
         need = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-        gx, gW, gb = hip.psn_bwd(x, W.detach(), b.detach(), grad_spike, ctx.alpha, need_param_grads=need)
-        return gx, gW, (gb.view_as(b) if gb is not None else None), None
+        gx, gW, gb = hip.psn_bwd(x, W.detach().float(), b.detach().float(), grad_spike.float(), ctx.alpha, need_param_grads=need)
+        return gx.to(ctx.in_dtype), gW, (gb.view_as(b) if gb is not None else None), None

@@ -251,8 +251,11 @@ class GradientBuckets:
 
 
 def train_step(model, optimizer, chunk, label, mask, buckets=None, dist=None, world=1, clip_grad=100.0, flow_scaling=1.0,
-               lambda_mod=1.0):
-    """One step of train_flow_parallel_supervised_SNN.py's loop body on this rank's micro-batch; returns the loss tensor."""
+               lambda_mod=1.0, amp=False):
+    """One step of train_flow_parallel_supervised_SNN.py's loop body on this rank's micro-batch; returns the loss tensor.
+    `amp`: the reference trains under `torch.cuda.amp.autocast` with fp16 + GradScaler (`optimizer.use_amp: true`,
+    :248, :314-331); here the same regions run under bf16 autocast (no scaler needed) - spikes are exact in bf16, the
+    membranes / neuron kernels, BatchNorm statistics, the loss and the optimiser stay fp32."""
     from .spikingjelly_compat import functional
     model.train()
     functional.reset_net(model)
@@ -260,8 +263,9 @@ def train_step(model, optimizer, chunk, label, mask, buckets=None, dist=None, wo
         buckets.zero()
     else:
         optimizer.zero_grad(set_to_none=True)
-    flows = forward_train(model, chunk)
-    loss = flow_loss_supervised(flows, label, mask, flow_scaling, lambda_mod)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        flows = forward_train(model, chunk)
+    loss = flow_loss_supervised([f.float() for f in flows], label, mask, flow_scaling, lambda_mod)
     loss.backward()
     if buckets is not None:
         buckets.all_reduce(dist, world)
