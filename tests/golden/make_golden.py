@@ -394,6 +394,26 @@ def gold_train_step():
     save("train_step", **out)
 
 
+def gold_ms_block_config5():
+    """The config-5 flavours of the block (BASELINE configs[4]): D = 20 frames with T = 20 neurons, and the large window
+    (2,15,15) with its 450-token positional encoding and shift (1,7,7) - pins the oracle's index arithmetic beyond (2,9,9)."""
+    out = {}
+    C, nH = 96, 3
+    for tag, kind, ws, (D, H, W), shift in (("w15_sw", "lif", (2, 15, 15), (6, 15, 33), (1, 7, 7)),
+                                            ("w15_w", "psn", (2, 15, 15), (4, 30, 15), (0, 0, 0)),
+                                            ("t20_sw", "lif", (2, 9, 9), (20, 9, 12), (1, 4, 4))):
+        blk = ref_swin.MS_Spiking_SwinTransformerBlock3D(C, (H, W), nH, window_size=ws, shift_size=shift, norm_layer="BN",
+                                                         **spk_kwargs(kind, D))
+        load_synth(blk)
+        x = rnd((1, D, H, W, C), 23, -0.5, 1.0)
+        Hp, Wp = -(-H // ws[1]) * ws[1], -(-W // ws[2]) * ws[2]
+        wsz, ssz = ref_ann.get_window_size((D, H, W), ws, shift)
+        mask = ref_swin.compute_mask(D, Hp, Wp, wsz, ssz, torch.device("cpu"))
+        out[f"{tag}_y"] = blk(x, mask)
+        out[f"{tag}_cfg"] = np.array([D, H, W, *ws, *shift])
+    save("ms_block_config5", **out)
+
+
 def gold_formats():
     """On-disk formats: the reference's `load_pretrained_interpolate` on seeded position tensors
     (window 9 -> 15, i.e. the large-window variant of BASELINE config 5) and its `DSECDatasetLite` read-back of the tiny
@@ -445,7 +465,7 @@ def gold_formats():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["neurons", "index_maps", "qk_attention", "sew_attention", "ann_attention",
-                             "ms_block", "end_to_end", "ann_end_to_end", "formats", "neuron_grads", "train_block", "train_step"]
+                             "ms_block", "end_to_end", "ann_end_to_end", "formats", "neuron_grads", "train_block", "train_step", "ms_block_config5"]
     for w in which:
         globals()["gold_" + w]()
 

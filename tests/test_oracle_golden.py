@@ -427,3 +427,20 @@ def test_oracle_train_step_matches_reference():
         tot += 1
         ok += abs(float(g.norm()) - r) <= 0.2 * r + 1e-12
     assert ok >= 0.9 * tot, (ok, tot)
+
+
+@pytest.mark.parametrize("tag,kind", [("w15_sw", "lif"), ("w15_w", "psn"), ("t20_sw", "lif")])
+def test_ms_block_config5_flavours_match_reference(tag, kind):
+    """BASELINE configs[4]: the large window (2,15,15) (450-token positional encoding, shift (1,7,7), padding 33 -> 45) and
+    D = T = 20 - the oracle's window / shift index arithmetic and neuron scan beyond the (2,9,9), T = 4 fixtures."""
+    g = gold("ms_block_config5")
+    D, H, W, w0, w1, w2, s0, s1, s2 = [int(v) for v in g[f"{tag}_cfg"]]
+    C, nH = 96, 3
+    shapes = block_shapes(C, nH, kind, D)
+    shapes["attn.positional_encoding"] = (1, nH, w0 * w1 * w2, C // nH)
+    sd = synth_state_dict(shapes)
+    x = rnd((1, D, H, W, C), 23, -0.5, 1.0)
+    y = O.ms_block(x, sd, "", nH, (w0, w1, w2), (s0, s1, s2), ncfg(kind, D))
+    ref = g[f"{tag}_y"]
+    bad = np.abs(y.numpy() - ref) > 1e-4 * np.abs(ref).mean()
+    assert bad.mean() <= 1e-4, bad.mean()           # a handful of spike flips at most (addmm vs the fixed fmaf order for psn)
