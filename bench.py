@@ -232,7 +232,9 @@ def main():
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
-        td.init_process_group("nccl")                            # RCCL over xGMI; used only for the timing barrier
+        # RCCL over xGMI (inference: timing barrier only; --train: the gradient all-reduce).  SDF_DIST_BACKEND=gloo lets the
+        # N > 1 code path be exercised with several ranks sharing one GPU, which RCCL refuses
+        td.init_process_group(os.environ.get("SDF_DIST_BACKEND", "nccl"))
     ndev = max(torch.cuda.device_count(), 1)
     local_rank %= ndev                                           # more ranks than visible GPUs: share (never silently fail)
     torch.cuda.set_device(local_rank)
