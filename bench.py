@@ -254,14 +254,16 @@ def main():
 
     with torch.no_grad():
         # single-stream latency of one forward (reported beside the throughput; not part of the timed region)
-        for _ in range(2):
+        for _ in range(5):                                       # first calls: library algorithm search, allocator growth
             model(chunk)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
+        lat = []
+        for _ in range(9):
+            t0 = time.perf_counter()
             model(chunk)
-        torch.cuda.synchronize()
-        latency_ms = (time.perf_counter() - t0) / 5 * 1e3
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t0) * 1e3)
+        latency_ms = sorted(lat)[len(lat) // 2]                      # median of 9 synchronous forwards
 
         # F independent forwards in flight: own stream, own static input, own graph (own activation memory)
         F_ = args.inflight

@@ -179,6 +179,61 @@ typedef struct SdfSpikeGemmDesc {
 
 int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream);
 
+/* The plain form of the spike GEMM the hot-path contract names: out[M,N] = fmaf(A W^T, bn_a[n], bn_b[n])
+ * with A (M,K) u8 spikes and W as planes (see above); a thin wrapper over sdf_spike_gemm_fwd. */
+int sdf_spike_gemm_bn_fwd(const uint8_t* A_spike, const uint16_t* W_planes, int nsplit, float acc_scale, const float* bn_a,
+                          const float* bn_b, float* out, int64_t M, int K, int N, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Window index table (row a4 / a6).  Replaces: F.pad to window multiples + torch.roll(-shift) + window_partition_v2 +
+ * the raw `.view(Wd, B_, Wh, Ww, C)` (reference Spiking_swin_transformer3D.py:789-804, :100-113) and, read backwards,
+ * window_reverse + roll(+shift) + crop (:810-820; swin_transformer3D_v2.py:52-65).
+ * map[(j*Wh*Ww) + tok] = flat (b, d, h, w) index of token `tok` of slice j, or -1 for padding; slice j = window*Wd + frame,
+ * windows ordered (b, d-block, h-block, w-block); attention step t' of window b' is slice t'*B_ + b'.  map holds
+ * B_*Wd*Wh*Ww int32 (device memory of the caller); *n_windows (host, optional) receives B_.  Built by a kernel on `stream`. */
+int sdf_window_slice_map(int32_t* map, int B, int D, int H, int W, int Wd, int Wh, int Ww, int shift_d, int shift_h, int shift_w,
+                         int64_t* n_windows, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Spiking QK window attention, whole (rows a5 + a6):  x += SSA(x) in place.
+ * Replaces: Spiking_SwinTransformerBlock3D.SSA + Spiking_QK_WindowAttention3D.forward + the shortcut add
+ * (reference Spiking_swin_transformer3D.py:781-821, :661-717, :840).  Four launches on `stream`:
+ *   xs = SN_proj(x gathered through slice_map)                                  (T', B_*N1, C) u8
+ *   q | k = SN_q/k( BN( xs [Wq;Wk]^T ) [+ positional_encoding on the k half] )  fused into the GEMM epilogue
+ *   E = k AND SN2_q( sum over each head's 32 channels of q )                    (token gate)
+ *   x[slice_map] += BN( Z Wp^T + b ),  Z = E read through the raw (B_,nH,T',N1,hd) head reshape (:709-710)
+ * Weights are planes from sdf_split_weight_*; BN as (alpha, beta) per channel.  Give EITHER the stacked projection
+ * (qk_*: planes [nsplit][2C][C], alpha / beta (2C), add (T', N1, 2C) with zeros in the q half, or NULL) - valid when the
+ * q and k neurons are parameter-free and equal - OR the separate q_* / k_* sets (PSN: each neuron owns a matrix).
+ * workspace: sdf_qk_attn_workspace_bytes(B_, T', N1, C) bytes, 256-byte aligned, caller-owned; gemm_workspace is the
+ * optional split-K scratch of sdf_spike_gemm_fwd.  C = nH * 32. */
+typedef struct SdfNeuronCfg {
+  int32_t kind;             /* SDF_LIF | SDF_PSN | SDF_IF */
+  float tau, v_th, v_reset;
+  int32_t soft_reset;
+  const float* psn_w;       /* (T,T), PSN only */
+  const float* psn_b;       /* (T)          */
+} SdfNeuronCfg;
+
+typedef struct SdfQkAttnDesc {
+  float* x;                 /* (B, D, H, W, C) fp32 channel-last, updated in place */
+  const int32_t* slice_map; /* sdf_window_slice_map */
+  int64_t B_;               /* windows */
+  int64_t x_rows;           /* B*D*H*W */
+  int32_t Tq, N1, C, nH;    /* window depth, Wh*Ww, channels, heads */
+  int32_t nsplit;
+  const uint16_t* qk_planes; const float* qk_alpha; const float* qk_beta; const float* qk_add; float qk_acc_scale;
+  const uint16_t* q_planes;  const float* q_alpha;  const float* q_beta;  float q_acc_scale;
+  const uint16_t* k_planes;  const float* k_alpha;  const float* k_beta;  const float* k_add; float k_acc_scale;
+  const uint16_t* p_planes;  const float* p_bias;   const float* p_alpha; const float* p_beta; float p_acc_scale;
+  SdfNeuronCfg sn_proj, sn_q, sn_k, sn2_q;
+  void* workspace;      int64_t workspace_bytes;
+  void* gemm_workspace; int64_t gemm_workspace_bytes;
+} SdfQkAttnDesc;
+
+int64_t sdf_qk_attn_workspace_bytes(int64_t B_, int Tq, int N1, int C);
+int sdf_qk_attn_fwd(const SdfQkAttnDesc* d, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Spike convolution (implicit GEMM):  out = epilogue( im2col(X) x W^T ) with X an NHWC u8 spike image batch.
  * Replaces: layer.Conv2d / nn.Conv2d / ConvTranspose2d on spikes + the SpikingNormLayer, shortcut add and

@@ -188,8 +188,7 @@ class MSFlowEngine:
     def _slice_map(self, B, D, H, W, ws, ss):
         key = ("win", B, D, H, W, ws, ss)
         if key not in self._maps:
-            src, B_ = window_slice_map(B, D, H, W, ws, ss)
-            self._maps[key] = (torch.from_numpy(src.reshape(-1)).to(self.device), B_)
+            self._maps[key] = hip.window_slice_map(B, D, H, W, ws, ss, self.device)        # built on the device, cached per shape
         return self._maps[key]
 
     def _merge_map(self, B, D, H, W):
@@ -303,29 +302,12 @@ class MSFlowEngine:
         ws, ss = get_window_size((D, H, W), blk.window_size, blk.shift_size)
         rowmap, B_ = self._slice_map(B, D, H, W, ws, ss)
         Tq, N1 = ws[0], ws[1] * ws[2]
-        rows = B_ * N1
-        n, M = rows * Cc, Tq * rows
-        dev = x.device
-        xs = torch.empty((M, Cc), dtype=torch.uint8, device=dev)
-        hip.neuron_fwd(x, xs, Tq, 1, n, 0, 0, 0, n, blk.sn_proj, rowmap=rowmap, rowlen=Cc)
-        # q = SN(BN(xs Wq^T)), k = SN(BN(xs Wk^T) + PE): GEMM with the neuron fused into its epilogue (u8 out)
+        # one C-ABI call: neuron over the gathered slices -> q|k spike GEMM (+BN, +PE, neurons fused) -> token gate ->
+        # projection spike GEMM through the head scramble with bias + BN + scatter + residual (csrc/qk_attn.hip)
         if blk.qk is not None:
-            qk = torch.empty((M, 2 * Cc), dtype=torch.uint8, device=dev)
-            hip.spike_gemm_sn(xs, blk.qk["Wp"], qk, 2 * Cc, Cc, Tq, rows, rows, 0, rows, blk.sn_q, alpha=blk.qk["alpha"],
-                              beta=blk.qk["beta"], add=blk.qk["add"], add_prows=N1)
-            hip.qk_gate(qk, qk[:, Cc:], xs, Tq, rows, Cc, blk.sn2_q, ldq=2 * Cc, ldk=2 * Cc)      # E overwrites xs
-            hip.spike_gemm(xs, blk.p.Wp, x, M, Cc, Cc, bias=blk.p.bias, alpha=blk.p.alpha, beta=blk.p.beta, resid=x,
-                           out_rowmap=rowmap, zg=(blk.nH, Tq, B_, N1))
-            return x
-        q = torch.empty((M, Cc), dtype=torch.uint8, device=dev)
-        hip.spike_gemm_sn(xs, blk.q.Wp, q, Cc, Cc, Tq, rows, rows, 0, rows, blk.sn_q, alpha=blk.q.alpha, beta=blk.q.beta)
-        k = torch.empty((M, Cc), dtype=torch.uint8, device=dev)
-        hip.spike_gemm_sn(xs, blk.k.Wp, k, Cc, Cc, Tq, rows, rows, 0, rows, blk.sn_k, alpha=blk.k.alpha, beta=blk.k.beta,
-                          add=blk.pe, add_prows=N1)
-        hip.qk_gate(q, k, xs, Tq, rows, Cc, blk.sn2_q)                                  # E overwrites xs
-        hip.spike_gemm(xs, blk.p.Wp, x, M, Cc, Cc, bias=blk.p.bias, alpha=blk.p.alpha, beta=blk.p.beta, resid=x,
-                       out_rowmap=rowmap, zg=(blk.nH, Tq, B_, N1))
-        return x
+            return hip.qk_attn(x, rowmap, B_, Tq, N1, blk.nH, blk.p, blk.sn_proj, blk.sn_q, blk.sn_k, blk.sn2_q, qk=blk.qk)
+        return hip.qk_attn(x, rowmap, B_, Tq, N1, blk.nH, blk.p, blk.sn_proj, blk.sn_q, blk.sn_k, blk.sn2_q,
+                           q_lin=blk.q, k_lin=blk.k, pe=blk.pe)
 
     def mlp(self, x, blk: _Block):
         """x (B,D,H,W,C) += MLP(x) over the true time axis D, in place (reference :164-181, :845)."""

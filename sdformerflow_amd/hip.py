@@ -20,7 +20,8 @@ KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
 
 EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
            "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd", "sdf_head_conv_sn_fwd",
-           "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes")
+           "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes",
+           "sdf_window_slice_map", "sdf_qk_attn_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd")
 
 
 class SdfError(RuntimeError):
@@ -90,6 +91,7 @@ def lib():
         for name in EXPORTS[1:]:
             getattr(_lib, name).restype = C.c_int
         _lib.sdf_psn_bwd_workspace_bytes.restype = C.c_int64
+        _lib.sdf_qk_attn_workspace_bytes.restype = C.c_int64
     return _lib
 
 
@@ -328,6 +330,74 @@ def qk_gate(q, k, e, Tq, rows, Cch, p: NeuronParams, ldq=None, ldk=None):
                                _stream())
     _check(rc, "sdf_qk_gate_strided_fwd")
     return e
+
+
+class NeuronCfg(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("tau", C.c_float), ("v_th", C.c_float), ("v_reset", C.c_float),
+                ("soft_reset", C.c_int32), ("psn_w", C.c_void_p), ("psn_b", C.c_void_p)]
+
+
+class QkAttnDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("slice_map", C.c_void_p), ("B_", C.c_int64), ("x_rows", C.c_int64),
+                ("Tq", C.c_int32), ("N1", C.c_int32), ("C", C.c_int32), ("nH", C.c_int32), ("nsplit", C.c_int32),
+                ("qk_planes", C.c_void_p), ("qk_alpha", C.c_void_p), ("qk_beta", C.c_void_p), ("qk_add", C.c_void_p),
+                ("qk_acc_scale", C.c_float),
+                ("q_planes", C.c_void_p), ("q_alpha", C.c_void_p), ("q_beta", C.c_void_p), ("q_acc_scale", C.c_float),
+                ("k_planes", C.c_void_p), ("k_alpha", C.c_void_p), ("k_beta", C.c_void_p), ("k_add", C.c_void_p),
+                ("k_acc_scale", C.c_float),
+                ("p_planes", C.c_void_p), ("p_bias", C.c_void_p), ("p_alpha", C.c_void_p), ("p_beta", C.c_void_p),
+                ("p_acc_scale", C.c_float),
+                ("sn_proj", NeuronCfg), ("sn_q", NeuronCfg), ("sn_k", NeuronCfg), ("sn2_q", NeuronCfg),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("gemm_workspace", C.c_void_p), ("gemm_workspace_bytes", C.c_int64)]
+
+
+def _ncfg(c, p: NeuronParams):
+    c.kind, c.tau, c.v_th = KIND[p.kind], p.tau, p.v_th
+    c.v_reset, c.soft_reset = (0.0 if p.v_reset is None else float(p.v_reset)), (1 if p.v_reset is None else 0)
+    c.psn_w, c.psn_b = _ptr(p.psn_w, torch.float32), _ptr(p.psn_b, torch.float32)
+
+
+def window_slice_map(B, D, H, W, ws, ss, device):
+    """sdf_window_slice_map: the int32 gather table of pad + roll + window_partition_v2, built on the device.
+    Returns (map (B_*Wd*Wh*Ww,), B_)."""
+    Wd, Wh, Ww = ws
+    B_ = B * -(-D // Wd) * -(-H // Wh) * -(-W // Ww)
+    m = torch.empty((B_ * Wd * Wh * Ww,), dtype=torch.int32, device=device)
+    nw = C.c_int64(0)
+    _check(lib().sdf_window_slice_map(C.c_void_p(m.data_ptr()), C.c_int(B), C.c_int(D), C.c_int(H), C.c_int(W), C.c_int(Wd),
+                                      C.c_int(Wh), C.c_int(Ww), C.c_int(ss[0]), C.c_int(ss[1]), C.c_int(ss[2]), C.byref(nw),
+                                      _stream()), "sdf_window_slice_map")
+    assert nw.value == B_
+    return m, B_
+
+
+def qk_attn(x, slice_map, B_, Tq, N1, nH, p_lin, sn_proj, sn_q, sn_k, sn2_q, qk=None, q_lin=None, k_lin=None, pe=None):
+    """sdf_qk_attn_fwd: x (B,D,H,W,C) fp32 channel-last += SSA(x), in place.  `qk` = {"Wp", "alpha", "beta", "add"} for the
+    stacked projection, or q_lin / k_lin (objects with Wp / alpha / beta) + pe for separate ones; p_lin has Wp / bias / alpha / beta."""
+    Cc = x.shape[-1]
+    d = QkAttnDesc()
+    d.x, d.slice_map = _ptr(x, torch.float32), _ptr(slice_map, torch.int32)
+    d.B_, d.x_rows, d.Tq, d.N1, d.C, d.nH = B_, x.numel() // Cc, Tq, N1, Cc, nH
+    d.nsplit = p_lin.Wp.shape[0]
+    if qk is not None:
+        d.qk_planes, d.qk_alpha, d.qk_beta = _ptr(qk["Wp"], torch.int16), _ptr(qk["alpha"], torch.float32), _ptr(qk["beta"], torch.float32)
+        d.qk_add, d.qk_acc_scale = _ptr(qk["add"], torch.float32), _acc_scale(qk["Wp"])
+    else:
+        d.q_planes, d.q_alpha, d.q_beta, d.q_acc_scale = _ptr(q_lin.Wp, torch.int16), _ptr(q_lin.alpha), _ptr(q_lin.beta), _acc_scale(q_lin.Wp)
+        d.k_planes, d.k_alpha, d.k_beta, d.k_acc_scale = _ptr(k_lin.Wp, torch.int16), _ptr(k_lin.alpha), _ptr(k_lin.beta), _acc_scale(k_lin.Wp)
+        d.k_add = _ptr(pe, torch.float32)
+    d.p_planes, d.p_bias, d.p_alpha, d.p_beta = _ptr(p_lin.Wp, torch.int16), _ptr(p_lin.bias), _ptr(p_lin.alpha), _ptr(p_lin.beta)
+    d.p_acc_scale = _acc_scale(p_lin.Wp)
+    for c, p in ((d.sn_proj, sn_proj), (d.sn_q, sn_q), (d.sn_k, sn_k), (d.sn2_q, sn2_q)):
+        _ncfg(c, p)
+    nbytes = lib().sdf_qk_attn_workspace_bytes(C.c_int64(B_), C.c_int(Tq), C.c_int(N1), C.c_int(Cc))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)          # intermediates: caller-owned, caching allocator
+    d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+    gws = workspace(x.device)
+    d.gemm_workspace, d.gemm_workspace_bytes = gws.data_ptr(), gws.numel()
+    _check(lib().sdf_qk_attn_fwd(C.byref(d), _stream()), "sdf_qk_attn_fwd")
+    return x
 
 
 def affine_resid(x, alpha, beta, Cch, inner, resid=None, out=None):

@@ -85,3 +85,14 @@ def test_argument_errors_are_reported_before_any_launch():
     d.mode, d.bias = 0, None
     assert lib.sdf_win_attn_fwd(C.byref(d), None) == E_NULL
     assert lib.sdf_spike_gemm_fwd(None, None) == E_NULL and lib.sdf_neuron_fwd(None, None) == E_NULL
+    assert lib.sdf_qk_attn_fwd(None, None) == E_NULL
+    q = hip.QkAttnDesc()
+    q.x, q.slice_map, q.workspace, q.p_planes, q.qk_planes = 0x10000, 0x10000, 0x10000, 0x10000, 0x10000
+    q.B_, q.Tq, q.N1, q.C, q.nH, q.workspace_bytes = 4, 2, 81, 100, 3, 1 << 30
+    assert lib.sdf_qk_attn_fwd(C.byref(q), None) == E_SHAPE     # C must be nH * 32
+    q.C, q.workspace_bytes = 96, 16
+    assert lib.sdf_qk_attn_fwd(C.byref(q), None) == E_SHAPE     # workspace smaller than sdf_qk_attn_workspace_bytes
+    lib.sdf_qk_attn_workspace_bytes.restype = C.c_int64
+    assert lib.sdf_qk_attn_workspace_bytes(C.c_int64(4), C.c_int(2), C.c_int(81), C.c_int(96)) == 62208 + 2 * 62208
+    assert lib.sdf_window_slice_map(None, 1, 2, 9, 9, 2, 9, 9, 0, 0, 0, None, None) == E_NULL
+    assert lib.sdf_window_slice_map(p, 1, 2, 9, 9, 0, 9, 9, 0, 0, 0, None, None) == E_SHAPE

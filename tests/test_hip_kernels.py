@@ -533,3 +533,83 @@ def test_neuron_modules_are_differentiable_on_the_gpu():
     for got, key in ((x.grad, "gx"), (p.spiking_neuron.weight.grad, "gW"), (p.spiking_neuron.bias.grad, "gb")):
         ref = torch.from_numpy(NG[f"psn_T{T}_{key}"])
         assert got.shape == ref.shape and (got.cpu() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item(), key
+
+
+# ------------------------------------------------------------------ the attention as one C-ABI call (SURVEY.md 8b sdf_qk_attn_fwd)
+@pytest.mark.parametrize("shape", [(1, 10, 72, 96, (2, 9, 9), (1, 4, 4)), (2, 4, 18, 21, (2, 9, 9), (0, 0, 0)),
+                                   (1, 5, 16, 24, (2, 8, 8), (1, 4, 4)), (1, 20, 30, 40, (2, 15, 15), (1, 7, 7))])
+def test_window_slice_map_built_on_the_device_equals_the_host_table(shape):
+    """sdf_window_slice_map (index arithmetic in a kernel) against the numpy table that tests/test_oracle_golden.py pins on
+    the reference's pad + roll + window_partition_v2 fixtures: bit-equal, padding rows -1."""
+    from sdformerflow_amd.STSwinNet_SNN.Spiking_swin_transformer3D import window_slice_map
+    B, D, H, W, ws, ss = shape
+    ref, B_ref = window_slice_map(B, D, H, W, ws, ss)
+    got, B_ = hip.window_slice_map(B, D, H, W, ws, ss, DEV)
+    assert B_ == B_ref and np.array_equal(got.cpu().numpy(), ref.reshape(-1))
+
+
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+def test_qk_attn_single_call_equals_its_four_launches(kind):
+    """sdf_qk_attn_fwd (neuron -> q|k GEMM -> gate -> projection GEMM inside the library) is bit-equal to the same four
+    entry points driven one by one from the host, for the stacked (lif) and the separate (psn) projection form; the block-level
+    parity against the oracle is tests/test_engine_gpu.py (the engine goes through this call)."""
+    import yaml
+    from sdformerflow_amd.engine import _Block
+    from sdformerflow_amd.STSwinNet_SNN import Spiking_swin_transformer3D as SW
+    from sdformerflow_amd.synthetic import synth_state_dict
+    kw = {"num_steps": 4, "v_reset": None, "v_th": 0.1, "neuron_type": kind, "surrogate_fun": "surrogate.ATan()", "tau": 2.0,
+          "detach_reset": True, "spike_norm": "BN"}
+    B, D, H, W, Cc, nH = 2, 4, 18, 21, 96, 3
+    m = SW.MS_Spiking_SwinTransformerBlock3D(Cc, (H, W), nH, window_size=(2, 9, 9), shift_size=(1, 4, 4), norm_layer="BN", **kw)
+    m.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}))
+    blk = _Block(m.to(DEV).eval(), torch.device(DEV), 2)
+    assert (blk.qk is not None) == (kind == "lif")
+    x0 = rnd((B, D, H, W, Cc), 31, -0.5, 1.0).to(DEV)
+    ws, ss = (2, 9, 9), (1, 4, 4)
+    rowmap, B_ = hip.window_slice_map(B, D, H, W, ws, ss, DEV)
+    Tq, N1 = 2, 81
+    rows = B_ * N1
+    M = Tq * rows
+    # (a) four launches from the host
+    xa = x0.clone()
+    xs = torch.empty((M, Cc), dtype=torch.uint8, device=DEV)
+    hip.neuron_fwd(xa, xs, Tq, 1, rows * Cc, 0, 0, 0, rows * Cc, blk.sn_proj, rowmap=rowmap, rowlen=Cc)
+    if blk.qk is not None:
+        qk = torch.empty((M, 2 * Cc), dtype=torch.uint8, device=DEV)
+        hip.spike_gemm_sn(xs, blk.qk["Wp"], qk, 2 * Cc, Cc, Tq, rows, rows, 0, rows, blk.sn_q, alpha=blk.qk["alpha"],
+                          beta=blk.qk["beta"], add=blk.qk["add"], add_prows=N1)
+        hip.qk_gate(qk, qk[:, Cc:], xs, Tq, rows, Cc, blk.sn2_q, ldq=2 * Cc, ldk=2 * Cc)
+    else:
+        q = torch.empty((M, Cc), dtype=torch.uint8, device=DEV)
+        k = torch.empty((M, Cc), dtype=torch.uint8, device=DEV)
+        hip.spike_gemm_sn(xs, blk.q.Wp, q, Cc, Cc, Tq, rows, rows, 0, rows, blk.sn_q, alpha=blk.q.alpha, beta=blk.q.beta)
+        hip.spike_gemm_sn(xs, blk.k.Wp, k, Cc, Cc, Tq, rows, rows, 0, rows, blk.sn_k, alpha=blk.k.alpha, beta=blk.k.beta,
+                          add=blk.pe, add_prows=N1)
+        hip.qk_gate(q, k, xs, Tq, rows, Cc, blk.sn2_q)
+    hip.spike_gemm(xs, blk.p.Wp, xa, M, Cc, Cc, bias=blk.p.bias, alpha=blk.p.alpha, beta=blk.p.beta, resid=xa, out_rowmap=rowmap,
+                   zg=(nH, Tq, B_, N1))
+    # (b) one call
+    xb = x0.clone()
+    if blk.qk is not None:
+        hip.qk_attn(xb, rowmap, B_, Tq, N1, nH, blk.p, blk.sn_proj, blk.sn_q, blk.sn_k, blk.sn2_q, qk=blk.qk)
+    else:
+        hip.qk_attn(xb, rowmap, B_, Tq, N1, nH, blk.p, blk.sn_proj, blk.sn_q, blk.sn_k, blk.sn2_q, q_lin=blk.q, k_lin=blk.k, pe=blk.pe)
+    torch.cuda.synchronize()
+    assert torch.equal(xa, xb) and not torch.equal(xa, x0)
+
+
+def test_spike_gemm_bn_plain_entry_point():
+    import ctypes as C
+    M, K, N = 4096, 96, 192
+    A = (torch.rand((M, K), device=DEV) < 0.3).to(torch.uint8)
+    Wf = torch.randn((N, K), device=DEV) * 0.1
+    Wp = hip.split_weight(Wf, 2)
+    a, b = torch.rand(N, device=DEV) + 0.5, torch.randn(N, device=DEV)
+    ref = torch.empty((M, N), device=DEV)
+    hip.spike_gemm(A, Wp, ref, M, N, K, alpha=a, beta=b)
+    out = torch.empty((M, N), device=DEV)
+    rc = hip.lib().sdf_spike_gemm_bn_fwd(C.c_void_p(A.data_ptr()), C.c_void_p(Wp.data_ptr()), C.c_int(2), C.c_float(Wp.sdf_acc_scale),
+                                         C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()),
+                                         C.c_int64(M), C.c_int(K), C.c_int(N), hip._stream())
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(out, ref)
