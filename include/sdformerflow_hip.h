@@ -235,6 +235,26 @@ int64_t sdf_qk_attn_workspace_bytes(int64_t B_, int Tq, int N1, int C);
 int sdf_qk_attn_fwd(const SdfQkAttnDesc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * MS MLP, whole (row a7):  x += BN2( SN2( BN1( SN1(x) W1^T ) ) W2^T )  in place on a (B, D, HW, C) fp32 buffer, neurons over
+ * the true time axis D.  Replaces: MS_Spiking_Mlp.forward + the block's second shortcut add (reference
+ * Spiking_swin_transformer3D.py:164-181, :845).  Three launches; the hidden (.., 4C) tensor only exists as 1-byte spikes.
+ * D in {2,4,5,10,20} (the fused-neuron epilogue); workspace: sdf_ms_mlp_workspace_bytes(B*D*HW, C, Ch), 256-byte aligned. */
+typedef struct SdfMsMlpDesc {
+  float* x;
+  int32_t B, D;
+  int64_t HW;
+  int32_t C, Ch, nsplit;
+  const uint16_t* fc1_planes; const float* fc1_alpha; const float* fc1_beta; float fc1_acc_scale;
+  const uint16_t* fc2_planes; const float* fc2_alpha; const float* fc2_beta; float fc2_acc_scale;
+  SdfNeuronCfg sn1, sn2;
+  void* workspace;      int64_t workspace_bytes;
+  void* gemm_workspace; int64_t gemm_workspace_bytes;
+} SdfMsMlpDesc;
+
+int64_t sdf_ms_mlp_workspace_bytes(int64_t tokens, int C, int Ch);
+int sdf_ms_mlp_fwd(const SdfMsMlpDesc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Spike convolution (implicit GEMM):  out = epilogue( im2col(X) x W^T ) with X an NHWC u8 spike image batch.
  * Replaces: layer.Conv2d / nn.Conv2d / ConvTranspose2d on spikes + the SpikingNormLayer, shortcut add and
  * Spiking_neuron around it in the patch embedding and the U-Net tail (reference Spiking_modules.py:339-347,

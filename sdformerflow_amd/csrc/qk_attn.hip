@@ -123,6 +123,47 @@ extern "C" int sdf_qk_attn_fwd(const SdfQkAttnDesc* d, void* stream) {
   return sdf_spike_gemm_fwd(&g, stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// MS MLP, whole (row a7): x += BN2(W2 SN2(BN1(W1 SN1(x))))  over the true time axis D of a (B, D, HW, C) buffer.
+extern "C" int64_t sdf_ms_mlp_workspace_bytes(int64_t tokens, int C, int Ch) {
+  if (tokens < 1 || C < 1 || Ch < 1) return 0;
+  return ((tokens * C + 255) / 256 * 256) + tokens * Ch;
+}
+
+extern "C" int sdf_ms_mlp_fwd(const SdfMsMlpDesc* d, void* stream) {
+  if (!d) return SDF_E_NULL;
+  if (!d->x || !d->fc1_planes || !d->fc2_planes || !d->workspace) return SDF_E_NULL;
+  if (d->B < 1 || d->D < 1 || d->HW < 1 || d->C < 32 || d->C % 32 || d->Ch < 32 || d->Ch % 32) return SDF_E_SHAPE;
+  const int64_t tokens = (int64_t)d->B * d->D * d->HW;
+  if (d->workspace_bytes < sdf_ms_mlp_workspace_bytes(tokens, d->C, d->Ch)) return SDF_E_SHAPE;
+  if (!sdf_aligned(d->workspace, 256)) return SDF_E_ALIGN;
+  const int C = d->C, Ch = d->Ch, D = d->D;
+  const int64_t hw = d->HW;
+  uint8_t* s1 = reinterpret_cast<uint8_t*>(d->workspace);
+  uint8_t* s2 = s1 + (tokens * C + 255) / 256 * 256;
+  // 1. sn1 over the D steps of every (b, hw, c)
+  SdfNeuronDesc n = {};
+  n.x = d->x; n.out = s1; n.T = D; n.out_dtype = SDF_U8;
+  n.nb = d->B; n.ni = hw * C; n.x_sb = (int64_t)D * hw * C; n.x_st = hw * C; n.o_sb = (int64_t)D * hw * C; n.o_st = hw * C;
+  fill_neuron(n, d->sn1);
+  int rc = sdf_neuron_fwd(&n, stream);
+  if (rc) return rc;
+  // 2. s2 = SN2(BN1(s1 W1^T)): neuron fused into the GEMM epilogue, the 4C hidden tensor never exists in fp32
+  SdfSpikeGemmDesc g = {};
+  g.A = s1; g.Wp = d->fc1_planes; g.out_spike = s2; g.M = tokens; g.N = Ch; g.K = C; g.lda = C; g.ldo = Ch; g.nsplit = d->nsplit;
+  g.acc_scale = d->fc1_acc_scale; g.alpha = d->fc1_alpha; g.beta = d->fc1_beta;
+  g.pos_count = (int64_t)d->B * hw; g.pos_inner = hw; g.pos_ostride = (int64_t)D * hw; g.t_stride = hw;
+  fill_gemm_neuron(g, d->sn2, D);
+  rc = sdf_spike_gemm_fwd(&g, stream);
+  if (rc) return rc;
+  // 3. x += BN2(s2 W2^T)
+  SdfSpikeGemmDesc h = {};
+  h.A = s2; h.Wp = d->fc2_planes; h.out = d->x; h.M = tokens; h.N = C; h.K = Ch; h.lda = Ch; h.ldo = C; h.nsplit = d->nsplit;
+  h.acc_scale = d->fc2_acc_scale; h.alpha = d->fc2_alpha; h.beta = d->fc2_beta; h.resid = d->x;
+  h.workspace = d->gemm_workspace; h.workspace_bytes = d->gemm_workspace_bytes;
+  return sdf_spike_gemm_fwd(&h, stream);
+}
+
 extern "C" int sdf_spike_gemm_bn_fwd(const uint8_t* A_spike, const uint16_t* W_planes, int nsplit, float acc_scale,
                                      const float* bn_a, const float* bn_b, float* out, int64_t M, int K, int N, void* stream) {
   SdfSpikeGemmDesc g = {};

@@ -312,18 +312,7 @@ class MSFlowEngine:
     def mlp(self, x, blk: _Block):
         """x (B,D,H,W,C) += MLP(x) over the true time axis D, in place (reference :164-181, :845)."""
         self._check_cl(x)
-        B, D, H, W, Cc = x.shape
-        ntok, hw = B * D * H * W, H * W
-        Ch = blk.fc1.N
-        dev = x.device
-        s1 = torch.empty((ntok, Cc), dtype=torch.uint8, device=dev)
-        hip.neuron_fwd(x, s1, D, B, hw * Cc, D * hw * Cc, hw * Cc, D * hw * Cc, hw * Cc, blk.sn1)
-        # s2 = SN(BN(s1 W1^T)) over the D time steps of every (b, h, w): fused GEMM + neuron, hidden never in fp32
-        s2 = torch.empty((ntok, Ch), dtype=torch.uint8, device=dev)
-        hip.spike_gemm_sn(s1, blk.fc1.Wp, s2, Ch, Cc, D, B * hw, hw, D * hw, hw, blk.sn2, alpha=blk.fc1.alpha,
-                          beta=blk.fc1.beta)
-        hip.spike_gemm(s2, blk.fc2.Wp, x, ntok, Cc, Ch, alpha=blk.fc2.alpha, beta=blk.fc2.beta, resid=x)
-        return x
+        return hip.ms_mlp(x, blk.fc1, blk.fc2, blk.sn1, blk.sn2)      # one C-ABI call (csrc/qk_attn.hip: sdf_ms_mlp_fwd)
 
     def swin_block(self, x, s, i):
         blk = self.stages[s][i]

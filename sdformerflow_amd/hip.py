@@ -21,7 +21,8 @@ KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
 EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
            "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd", "sdf_head_conv_sn_fwd",
            "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes",
-           "sdf_window_slice_map", "sdf_qk_attn_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd")
+           "sdf_window_slice_map", "sdf_qk_attn_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
+           "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes")
 
 
 class SdfError(RuntimeError):
@@ -92,6 +93,7 @@ def lib():
             getattr(_lib, name).restype = C.c_int
         _lib.sdf_psn_bwd_workspace_bytes.restype = C.c_int64
         _lib.sdf_qk_attn_workspace_bytes.restype = C.c_int64
+        _lib.sdf_ms_mlp_workspace_bytes.restype = C.c_int64
     return _lib
 
 
@@ -397,6 +399,34 @@ def qk_attn(x, slice_map, B_, Tq, N1, nH, p_lin, sn_proj, sn_q, sn_k, sn2_q, qk=
     gws = workspace(x.device)
     d.gemm_workspace, d.gemm_workspace_bytes = gws.data_ptr(), gws.numel()
     _check(lib().sdf_qk_attn_fwd(C.byref(d), _stream()), "sdf_qk_attn_fwd")
+    return x
+
+
+class MsMlpDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("B", C.c_int32), ("D", C.c_int32), ("HW", C.c_int64), ("C", C.c_int32), ("Ch", C.c_int32),
+                ("nsplit", C.c_int32),
+                ("fc1_planes", C.c_void_p), ("fc1_alpha", C.c_void_p), ("fc1_beta", C.c_void_p), ("fc1_acc_scale", C.c_float),
+                ("fc2_planes", C.c_void_p), ("fc2_alpha", C.c_void_p), ("fc2_beta", C.c_void_p), ("fc2_acc_scale", C.c_float),
+                ("sn1", NeuronCfg), ("sn2", NeuronCfg),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("gemm_workspace", C.c_void_p), ("gemm_workspace_bytes", C.c_int64)]
+
+
+def ms_mlp(x, fc1, fc2, sn1, sn2):
+    """sdf_ms_mlp_fwd: x (B,D,H,W,C) fp32 channel-last += MLP(x) over the time axis D, in place."""
+    B, D, H, W, Cc = x.shape
+    d = MsMlpDesc()
+    d.x, d.B, d.D, d.HW, d.C, d.Ch, d.nsplit = _ptr(x, torch.float32), B, D, H * W, Cc, fc1.N, fc1.Wp.shape[0]
+    d.fc1_planes, d.fc1_alpha, d.fc1_beta, d.fc1_acc_scale = _ptr(fc1.Wp, torch.int16), _ptr(fc1.alpha), _ptr(fc1.beta), _acc_scale(fc1.Wp)
+    d.fc2_planes, d.fc2_alpha, d.fc2_beta, d.fc2_acc_scale = _ptr(fc2.Wp, torch.int16), _ptr(fc2.alpha), _ptr(fc2.beta), _acc_scale(fc2.Wp)
+    _ncfg(d.sn1, sn1)
+    _ncfg(d.sn2, sn2)
+    nbytes = lib().sdf_ms_mlp_workspace_bytes(C.c_int64(B * D * H * W), C.c_int(Cc), C.c_int(fc1.N))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+    gws = workspace(x.device)
+    d.gemm_workspace, d.gemm_workspace_bytes = gws.data_ptr(), gws.numel()
+    _check(lib().sdf_ms_mlp_fwd(C.byref(d), _stream()), "sdf_ms_mlp_fwd")
     return x
 
 

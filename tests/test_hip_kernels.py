@@ -613,3 +613,29 @@ def test_spike_gemm_bn_plain_entry_point():
                                          C.c_int64(M), C.c_int(K), C.c_int(N), hip._stream())
     torch.cuda.synchronize()
     assert rc == 0 and torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+def test_ms_mlp_single_call_equals_its_three_launches(kind):
+    """sdf_ms_mlp_fwd against the same three entry points driven from the host (bit-equal); parity of the MLP against the
+    oracle is the teacher-forced block test of tests/test_engine_gpu.py, which goes through this call."""
+    from sdformerflow_amd.engine import _Block
+    from sdformerflow_amd.STSwinNet_SNN import Spiking_swin_transformer3D as SW
+    from sdformerflow_amd.synthetic import synth_state_dict
+    B, D, H, W, Cc = 2, 10, 9, 12, 96
+    kw = {"num_steps": D, "v_reset": None, "v_th": 0.1, "neuron_type": kind, "surrogate_fun": "surrogate.ATan()", "tau": 2.0,
+          "detach_reset": True, "spike_norm": "BN"}
+    m = SW.MS_Spiking_SwinTransformerBlock3D(Cc, (H, W), 3, window_size=(2, 9, 9), shift_size=(0, 0, 0), norm_layer="BN", **kw)
+    m.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}))
+    blk = _Block(m.to(DEV).eval(), torch.device(DEV), 2)
+    x0 = rnd((B, D, H, W, Cc), 33, -0.5, 1.0).to(DEV)
+    hw, ntok, Ch = H * W, B * D * H * W, 4 * Cc
+    xa = x0.clone()
+    s1 = torch.empty((ntok, Cc), dtype=torch.uint8, device=DEV)
+    hip.neuron_fwd(xa, s1, D, B, hw * Cc, D * hw * Cc, hw * Cc, D * hw * Cc, hw * Cc, blk.sn1)
+    s2 = torch.empty((ntok, Ch), dtype=torch.uint8, device=DEV)
+    hip.spike_gemm_sn(s1, blk.fc1.Wp, s2, Ch, Cc, D, B * hw, hw, D * hw, hw, blk.sn2, alpha=blk.fc1.alpha, beta=blk.fc1.beta)
+    hip.spike_gemm(s2, blk.fc2.Wp, xa, ntok, Cc, Ch, alpha=blk.fc2.alpha, beta=blk.fc2.beta, resid=xa)
+    xb = hip.ms_mlp(x0.clone(), blk.fc1, blk.fc2, blk.sn1, blk.sn2)
+    torch.cuda.synchronize()
+    assert torch.equal(xa, xb) and not torch.equal(xa, x0)
