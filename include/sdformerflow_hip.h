@@ -77,6 +77,18 @@ int sdf_psn_bwd(const float* x, const float* W, const float* b, const float* gra
                 float* grad_b, float* grad_h, void* workspace, int64_t workspace_bytes, int T, int64_t N, int surrogate,
                 float alpha, void* stream);
 
+/* Token gate of Spiking_QK_WindowAttention3D for the training path (reference Spiking_swin_transformer3D.py:687-694:
+ * `q.sum(-1)` over each head's 32 channels -> sn2_q over the T' steps -> `k.mul(...)`), fp32 spike tensors (T', rows, C):
+ *   forward   e = k * A,  A = SN2_q(head sums of q)
+ *   backward  grad_k = grad_e * A ;  grad_q = BPTT of SN2_q applied to sum_d(grad_e * k), broadcast over the head's channels
+ * LIF / IF gates (ATan surrogate, detach_reset as in sdf_lif_bwd); T' in {1, 2, 4}; C % 32 == 0; 16-byte aligned pointers.
+ * One launch each instead of the ~8 elementwise / reduction launches autograd runs for the composed expression. */
+int sdf_qk_gate_f32_fwd(const float* q, const float* k, float* e, int Tq, int64_t rows, int C, int kind, float tau, float v_th,
+                        int soft_reset, float v_reset, void* stream);
+int sdf_qk_gate_bwd(const float* q, const float* k, const float* grad_e, float* grad_q, float* grad_k, int Tq, int64_t rows, int C,
+                    int kind, float tau, float v_th, int soft_reset, float v_reset, int detach_reset, int surrogate, float alpha,
+                    void* stream);
+
 /* General neuron launch: strided / gathered input, fused eval-BatchNorm and additive prologue.
  * Replaces the reference idiom  SN( BN( y.permute(..) ).permute(..) [+ positional_encoding] )
  * (Spiking_swin_transformer3D.py:670-680, 168-174, 970) and the pad / roll / window_partition_v2

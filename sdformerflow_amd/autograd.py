@@ -46,3 +46,23 @@ class PSNFunction(torch.autograd.Function):
         need = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         gx, gW, gb = hip.psn_bwd(x, W.detach().float(), b.detach().float(), grad_spike.float(), ctx.alpha, need_param_grads=need)
         return gx.to(ctx.in_dtype), gW, (gb.view_as(b) if gb is not None else None), None
+
+
+class QKGateFunction(torch.autograd.Function):
+    """Token gate of the QK attention, e = k * SN2_q(sum of q over each head's channels), both directions one HIP launch
+    (reference Spiking_swin_transformer3D.py:687-694 under autograd); LIF / IF gates."""
+
+    @staticmethod
+    def forward(ctx, q, k, params, detach_reset, alpha):
+        ctx.in_dtype = q.dtype
+        q, k = q.float().contiguous(), k.float().contiguous()
+        ctx.save_for_backward(q, k)
+        ctx.cfg = (params, detach_reset, alpha)
+        return hip.qk_gate_f32(q, k, params)
+
+    @staticmethod
+    def backward(ctx, grad_e):
+        q, k = ctx.saved_tensors
+        params, detach_reset, alpha = ctx.cfg
+        gq, gk = hip.qk_gate_bwd(q, k, grad_e.float(), params, detach_reset, alpha)
+        return gq.to(ctx.in_dtype), gk.to(ctx.in_dtype), None, None, None

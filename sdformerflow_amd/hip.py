@@ -22,7 +22,7 @@ EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_s
            "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd", "sdf_head_conv_sn_fwd",
            "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes",
            "sdf_window_slice_map", "sdf_qk_attn_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
-           "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes")
+           "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd")
 
 
 class SdfError(RuntimeError):
@@ -428,6 +428,33 @@ def ms_mlp(x, fc1, fc2, sn1, sn2):
     d.gemm_workspace, d.gemm_workspace_bytes = gws.data_ptr(), gws.numel()
     _check(lib().sdf_ms_mlp_fwd(C.byref(d), _stream()), "sdf_ms_mlp_fwd")
     return x
+
+
+def qk_gate_f32(q, k, p: NeuronParams):
+    """sdf_qk_gate_f32_fwd: e = k * SN2_q(head sums of q) on fp32 spike tensors (Tq, rows, C) (training path)."""
+    q, k = q.contiguous(), k.contiguous()
+    Tq, Cc = q.shape[0], q.shape[-1]
+    e = torch.empty_like(k)
+    rc = lib().sdf_qk_gate_f32_fwd(C.c_void_p(_ptr(q, torch.float32)), C.c_void_p(_ptr(k, torch.float32)), C.c_void_p(_ptr(e)),
+                                   C.c_int(Tq), C.c_int64(q[0].numel() // Cc), C.c_int(Cc), C.c_int(KIND[p.kind]), C.c_float(p.tau),
+                                   C.c_float(p.v_th), C.c_int(1 if p.v_reset is None else 0),
+                                   C.c_float(0.0 if p.v_reset is None else p.v_reset), _stream())
+    _check(rc, "sdf_qk_gate_f32_fwd")
+    return e
+
+
+def qk_gate_bwd(q, k, grad_e, p: NeuronParams, detach_reset=True, alpha=2.0):
+    """sdf_qk_gate_bwd: (dL/dq, dL/dk) of the token gate."""
+    q, k, g = q.contiguous(), k.contiguous(), grad_e.contiguous()
+    Tq, Cc = q.shape[0], q.shape[-1]
+    gq, gk = torch.empty_like(q), torch.empty_like(k)
+    rc = lib().sdf_qk_gate_bwd(C.c_void_p(_ptr(q, torch.float32)), C.c_void_p(_ptr(k, torch.float32)), C.c_void_p(_ptr(g, torch.float32)),
+                               C.c_void_p(_ptr(gq)), C.c_void_p(_ptr(gk)), C.c_int(Tq), C.c_int64(q[0].numel() // Cc), C.c_int(Cc),
+                               C.c_int(KIND[p.kind]), C.c_float(p.tau), C.c_float(p.v_th), C.c_int(1 if p.v_reset is None else 0),
+                               C.c_float(0.0 if p.v_reset is None else p.v_reset), C.c_int(1 if detach_reset else 0), C.c_int(0),
+                               C.c_float(alpha), _stream())
+    _check(rc, "sdf_qk_gate_bwd")
+    return gq, gk
 
 
 def affine_resid(x, alpha, beta, Cch, inner, resid=None, out=None):

@@ -113,8 +113,13 @@ def qk_attention(x, attn):
     q = attn.sn_q(_bn_last(F.linear(xs, attn.linear_q.weight), attn.bn_q.norm_layer))
     k = _bn_last(F.linear(xs, attn.linear_k.weight), attn.bn_k.norm_layer)
     k = attn.sn_k(k + attn.positional_encoding.reshape(Tq, 1, N1, C))
-    a = attn.sn2_q(q.reshape(Tq, B_, N1, nH, hd).sum(-1))              # token gate per head: sum over the head's channels
-    e = k * a.repeat_interleave(hd, dim=-1)
+    gate = attn.sn2_q.spiking_neuron
+    if gate.kind in ("lif", "if") and hd == 32:                         # token gate, forward and backward one HIP launch each
+        from .autograd import QKGateFunction
+        e = QKGateFunction.apply(q, k, gate.params(), gate.detach_reset, getattr(gate.surrogate_function, "alpha", 2.0))
+    else:                                                               # PSN gate (learnable T' x T' matrix): composed path
+        a = attn.sn2_q(q.reshape(Tq, B_, N1, nH, hd).sum(-1))
+        e = k * a.repeat_interleave(hd, dim=-1)
     z = e.reshape(B_, nH, Tq, N1, hd).permute(2, 0, 3, 1, 4).reshape(Tq, B_, N1, C)     # the reference's raw head reshape
     return _bn_last(F.linear(z, attn.proj.weight, attn.proj.bias), attn.proj_bn.norm_layer)
 

@@ -639,3 +639,32 @@ def test_ms_mlp_single_call_equals_its_three_launches(kind):
     xb = hip.ms_mlp(x0.clone(), blk.fc1, blk.fc2, blk.sn1, blk.sn2)
     torch.cuda.synchronize()
     assert torch.equal(xa, xb) and not torch.equal(xa, x0)
+
+
+@pytest.mark.parametrize("Tq,detach,v_reset", [(2, True, None), (2, False, None), (2, True, 0.0), (4, True, None), (1, True, None)])
+def test_qk_gate_train_kernels_match_autograd_of_the_composed_expression(Tq, detach, v_reset):
+    """sdf_qk_gate_f32_fwd / sdf_qk_gate_bwd against torch autograd through the reference's expression
+    (`q.sum` per head -> neuron -> broadcast -> `k.mul`) with the CPU restatement of the neuron's backward: forward bit-equal
+    (head sums of spikes are exact integers), gradients to fp32 summation order."""
+    rows, Cc, nH = 4000 + 37, 96, 3
+    q = (torch.rand((Tq, rows, Cc)) < 0.35).float()
+    k = (torch.rand((Tq, rows, Cc)) < 0.3).float()
+    ge = torch.randn((Tq, rows, Cc))
+    p = hip.NeuronParams("lif", 2.0, 0.1 if v_reset is None else 3.0, v_reset)
+    # reference on the CPU: explicit chain, neuron backward from the oracle's restatement
+    s = q.reshape(Tq, rows, nH, 32).sum(-1)
+    _, A = BW.lif_forward_h(s, p.tau, p.v_th, v_reset)
+    e_ref = k * A.repeat_interleave(32, dim=-1)
+    gk_ref = ge * A.repeat_interleave(32, dim=-1)
+    gA = (ge * k).reshape(Tq, rows, nH, 32).sum(-1)
+    gs = BW.lif_backward(s, gA, p.tau, p.v_th, v_reset, detach, 2.0)
+    gq_ref = gs.repeat_interleave(32, dim=-1)
+    e = hip.qk_gate_f32(q.to(DEV), k.to(DEV), p)
+    gq, gk = hip.qk_gate_bwd(q.to(DEV), k.to(DEV), ge.to(DEV), p, detach, 2.0)
+    assert torch.equal(e.cpu(), e_ref) and torch.equal(gk.cpu(), gk_ref)
+    assert (gq.cpu() - gq_ref).abs().max().item() <= 1e-5 * gq_ref.abs().max().item()
+    # the autograd bridge
+    from sdformerflow_amd.autograd import QKGateFunction
+    qd, kd = q.to(DEV).requires_grad_(True), k.to(DEV).requires_grad_(True)
+    QKGateFunction.apply(qd, kd, p, detach, 2.0).backward(ge.to(DEV))
+    assert torch.equal(qd.grad, gq) and torch.equal(kd.grad, gk)
