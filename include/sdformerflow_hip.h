@@ -77,6 +77,21 @@ int sdf_psn_bwd(const float* x, const float* W, const float* b, const float* gra
                 float* grad_b, float* grad_h, void* workspace, int64_t workspace_bytes, int T, int64_t N, int surrogate,
                 float alpha, void* stream);
 
+/* Batch-statistics BatchNorm over the last dim of a channel-last (R, C) fp32 buffer, forward and backward (training form of
+ * the SpikingNormLayer "BN": spikingjelly layer.BatchNorm2d multi-step -> nn.BatchNorm2d on the view the reference makes with
+ * permute(0,1,4,2,3); Spiking_modules.py:101-146, Spiking_swin_transformer3D.py:172, 178, 673, 677, 714, 972) - no permute
+ * copies.  forward: y = (x - mean) * invstd * w + b with batch mean / biased variance (fp64 sums), save_mean / save_invstd (C)
+ * for the backward, running stats updated in place with momentum and the unbiased variance (pass NULL, NULL to skip).
+ * backward: grad_bias = sum gy, grad_weight = sum gy * xhat, grad_x = (gy - gb/R - xhat * gw/R) * invstd * w.
+ * C % 4 == 0; workspace: sdf_bn_train_workspace_bytes(R, C) bytes (8-byte aligned), caller-owned; deterministic reductions. */
+int64_t sdf_bn_train_workspace_bytes(int64_t R, int C);
+int sdf_bn_train_fwd(const float* x, const float* weight, const float* bias, float* y, float* save_mean, float* save_invstd,
+                     float* running_mean, float* running_var, int64_t R, int C, float eps, float momentum, void* workspace,
+                     int64_t workspace_bytes, void* stream);
+int sdf_bn_train_bwd(const float* x, const float* grad_y, const float* weight, const float* save_mean, const float* save_invstd,
+                     float* grad_x, float* grad_weight, float* grad_bias, int64_t R, int C, void* workspace, int64_t workspace_bytes,
+                     void* stream);
+
 /* Token gate of Spiking_QK_WindowAttention3D for the training path (reference Spiking_swin_transformer3D.py:687-694:
  * `q.sum(-1)` over each head's 32 channels -> sn2_q over the T' steps -> `k.mul(...)`), fp32 spike tensors (T', rows, C):
  *   forward   e = k * A,  A = SN2_q(head sums of q)

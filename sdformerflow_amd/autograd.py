@@ -66,3 +66,24 @@ class QKGateFunction(torch.autograd.Function):
         params, detach_reset, alpha = ctx.cfg
         gq, gk = hip.qk_gate_bwd(q, k, grad_e.float(), params, detach_reset, alpha)
         return gq.to(ctx.in_dtype), gk.to(ctx.in_dtype), None, None, None
+
+
+class BatchNormLastFunction(torch.autograd.Function):
+    """Batch-statistics BatchNorm over the last dim of a channel-last tensor (sdf_bn_train_fwd / _bwd): the training form of
+    the reference's `SpikingNormLayer("BN")(x.permute(0,1,4,2,3)).permute(...)` without the permute copies."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        ctx.in_dtype = x.dtype
+        x2 = x.float().contiguous().view(-1, x.shape[-1])
+        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        y, mean, invstd = hip.bn_train_fwd(x2, w, b, running_mean, running_var, momentum, eps)
+        ctx.save_for_backward(x2, w, mean, invstd)
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w, mean, invstd = ctx.saved_tensors
+        gx, gw, gb = hip.bn_train_bwd(x2, gy.float().contiguous().view(x2.shape), w, mean, invstd)
+        return gx.view(ctx.shape).to(ctx.in_dtype), gw, gb, None, None, None, None

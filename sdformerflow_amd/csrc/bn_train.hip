@@ -1,0 +1,199 @@
+// Batch-statistics BatchNorm over the LAST dim of a channel-last (R, C) fp32 buffer, forward and backward - the training
+// form of row a3 (reference: SpikingNormLayer "BN" in train mode = spikingjelly layer.BatchNorm2d multi-step ->
+// nn.BatchNorm2d on the (T*B, C, H, W) view the reference makes with `permute(0, 1, 4, 2, 3)`, Spiking_modules.py:101-146,
+// Spiking_swin_transformer3D.py:172, 178, 673, 677, 714, 972).  The library BatchNorm wants channels second: on this
+// framework's channel-last activations that costs a permute copy before and after every call and again in backward (240 of
+// the 453 copy launches of a training step).  Here the reduction runs down the rows of the (R, C) matrix in place.
+//   stats   : per-channel sum and sum of squares in fp64 (row-strided threads, LDS tree, per-block partials, fixed-order finish)
+//             -> mean, biased var, invstd = 1 / sqrt(var + eps); running_mean / running_var updated with the unbiased variance
+//   forward : y = (x - mean) * invstd * w + b                       (the operation order of ATen's CPU/GPU train kernels)
+//   backward: gb = sum gy, gw = sum gy * xhat;  gx = (gy - gb / R - xhat * gw / R) * invstd * w
+// All passes are HBM-bound streams of float4; nothing is saved by the forward except mean / invstd (2 C floats).
+#include "common.h"
+
+namespace {
+
+constexpr int BN_BLOCKS = 512;     // two workgroups per CU for the reductions
+
+struct BnParams {
+  const float* x; const float* gy; float* y; float* gx;
+  const float* w; const float* b;
+  const float* mean; const float* invstd;
+  double* partial;                 // [nblk][2][C]
+  int64_t R; int C;
+};
+
+// per-channel sums of (a, a*a) [stats] or (gy, gy * xhat) [backward] over a row-strided slice; partial[blk][0|1][c]
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(BnParams P) {
+  extern __shared__ double sm[];                                  // [RL][2][4 * QB]
+  const int Q = P.C / 4;                                          // channel quads
+  const int QB = Q < 64 ? Q : 64;                                 // quads per channel block
+  const int RL = 256 / QB;                                        // row lanes
+  const int cq = threadIdx.x % QB, rl = threadIdx.x / QB;
+  for (int q0 = 0; q0 < Q; q0 += QB) {
+    const int q = q0 + cq;
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    if (rl < RL && q < Q) {
+      float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
+      if (BWD) {
+        mu = *reinterpret_cast<const float4*>(P.mean + 4 * q);
+        is = *reinterpret_cast<const float4*>(P.invstd + 4 * q);
+      }
+      for (int64_t r = (int64_t)blockIdx.x * RL + rl; r < P.R; r += (int64_t)gridDim.x * RL) {
+        const float4 a = *reinterpret_cast<const float4*>(P.x + r * P.C + 4 * q);
+        if (!BWD) {
+          s0[0] += a.x; s0[1] += a.y; s0[2] += a.z; s0[3] += a.w;
+          s1[0] += (double)a.x * a.x; s1[1] += (double)a.y * a.y; s1[2] += (double)a.z * a.z; s1[3] += (double)a.w * a.w;
+        } else {
+          const float4 g = *reinterpret_cast<const float4*>(P.gy + r * P.C + 4 * q);
+          s0[0] += g.x; s0[1] += g.y; s0[2] += g.z; s0[3] += g.w;
+          s1[0] += (double)g.x * ((a.x - mu.x) * is.x); s1[1] += (double)g.y * ((a.y - mu.y) * is.y);
+          s1[2] += (double)g.z * ((a.z - mu.z) * is.z); s1[3] += (double)g.w * ((a.w - mu.w) * is.w);
+        }
+      }
+    }
+    __syncthreads();
+    if (rl < RL) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sm[(rl * 2 + 0) * 4 * QB + 4 * cq + j] = s0[j];
+        sm[(rl * 2 + 1) * 4 * QB + 4 * cq + j] = s1[j];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * 4 * QB; i += 256) {         // fixed-order sum over the row lanes
+      const int which = i / (4 * QB), c = i % (4 * QB);
+      if (4 * q0 + c < P.C) {
+        double t = 0;
+        for (int l = 0; l < RL; ++l) t += sm[(l * 2 + which) * 4 * QB + c];
+        P.partial[((int64_t)blockIdx.x * 2 + which) * P.C + 4 * q0 + c] = t;
+      }
+    }
+  }
+}
+
+// one workgroup per channel: strided fp64 sums of the per-block partials + a fixed-shape LDS tree (run-to-run bit-equal)
+template <bool BWD>
+__global__ __launch_bounds__(64) void bn_finish_kernel(const double* partial, int nblk, int C, int64_t R, float eps, float momentum,
+                                                       float* out0, float* out1, float* running_mean, float* running_var) {
+  __shared__ double sm[2][64];
+  const int c = blockIdx.x;
+  double s = 0, ss = 0;
+  for (int b = threadIdx.x; b < nblk; b += 64) { s += partial[((int64_t)b * 2) * C + c]; ss += partial[((int64_t)b * 2 + 1) * C + c]; }
+  sm[0][threadIdx.x] = s;
+  sm[1][threadIdx.x] = ss;
+  __syncthreads();
+  for (int o = 32; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) { sm[0][threadIdx.x] += sm[0][threadIdx.x + o]; sm[1][threadIdx.x] += sm[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  s = sm[0][0]; ss = sm[1][0];
+  if (BWD) {
+    out0[c] = (float)ss;                                          // grad_weight = sum gy * xhat
+    out1[c] = (float)s;                                           // grad_bias   = sum gy
+    return;
+  }
+  const double m = s / (double)R;
+  double var = ss / (double)R - m * m;
+  if (var < 0) var = 0;
+  out0[c] = (float)m;
+  out1[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+  }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_apply_kernel(BnParams P, const float* gw, const float* gb) {
+  const int Q = P.C / 4;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P.R * Q) return;
+  const int q = (int)(i % Q);
+  const float4 a = *reinterpret_cast<const float4*>(P.x + i * 4);
+  const float4 mu = *reinterpret_cast<const float4*>(P.mean + 4 * q), is = *reinterpret_cast<const float4*>(P.invstd + 4 * q);
+  const float4 w = *reinterpret_cast<const float4*>(P.w + 4 * q);
+  float4 o;
+  if (!BWD) {
+    const float4 b = *reinterpret_cast<const float4*>(P.b + 4 * q);
+    o.x = (a.x - mu.x) * is.x * w.x + b.x; o.y = (a.y - mu.y) * is.y * w.y + b.y;
+    o.z = (a.z - mu.z) * is.z * w.z + b.z; o.w = (a.w - mu.w) * is.w * w.w + b.w;
+    *reinterpret_cast<float4*>(P.y + i * 4) = o;
+  } else {
+    const float4 g = *reinterpret_cast<const float4*>(P.gy + i * 4);
+    const float4 sw = *reinterpret_cast<const float4*>(gw + 4 * q), sb = *reinterpret_cast<const float4*>(gb + 4 * q);
+    const float inv_r = 1.0f / (float)P.R;
+    o.x = (g.x - sb.x * inv_r - (a.x - mu.x) * is.x * (sw.x * inv_r)) * is.x * w.x;
+    o.y = (g.y - sb.y * inv_r - (a.y - mu.y) * is.y * (sw.y * inv_r)) * is.y * w.y;
+    o.z = (g.z - sb.z * inv_r - (a.z - mu.z) * is.z * (sw.z * inv_r)) * is.z * w.z;
+    o.w = (g.w - sb.w * inv_r - (a.w - mu.w) * is.w * (sw.w * inv_r)) * is.w * w.w;
+    *reinterpret_cast<float4*>(P.gx + i * 4) = o;
+  }
+}
+
+int nblocks(int64_t R, int C) {
+  const int QB = C / 4 < 64 ? C / 4 : 64, RL = 256 / QB;
+  const int64_t need = (R + RL - 1) / RL;
+  return (int)(need < BN_BLOCKS ? need : BN_BLOCKS);
+}
+
+size_t reduce_lds(int C) {
+  const int QB = C / 4 < 64 ? C / 4 : 64, RL = 256 / QB;
+  return (size_t)RL * 2 * 4 * QB * sizeof(double);
+}
+
+}  // namespace
+
+extern "C" int64_t sdf_bn_train_workspace_bytes(int64_t R, int C) {
+  if (R < 1 || C < 4 || C % 4) return 0;
+  return (int64_t)BN_BLOCKS * 2 * C * (int64_t)sizeof(double);
+}
+
+extern "C" int sdf_bn_train_fwd(const float* x, const float* weight, const float* bias, float* y, float* save_mean, float* save_invstd,
+                                float* running_mean, float* running_var, int64_t R, int C, float eps, float momentum, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
+  if (!x || !weight || !bias || !y || !save_mean || !save_invstd || !workspace) return SDF_E_NULL;
+  if (R < 1 || C < 4 || C % 4 || R * (int64_t)C >= (1LL << 40)) return SDF_E_SHAPE;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return SDF_E_NULL;
+  if (workspace_bytes < sdf_bn_train_workspace_bytes(R, C)) return SDF_E_SHAPE;
+  if (!sdf_aligned(x, 16) || !sdf_aligned(y, 16) || !sdf_aligned(weight, 16) || !sdf_aligned(bias, 16) || !sdf_aligned(save_mean, 16) ||
+      !sdf_aligned(save_invstd, 16) || !sdf_aligned(workspace, 8))
+    return SDF_E_ALIGN;
+  BnParams P = {};
+  P.x = x; P.y = y; P.w = weight; P.b = bias; P.mean = save_mean; P.invstd = save_invstd; P.partial = reinterpret_cast<double*>(workspace);
+  P.R = R; P.C = C;
+  hipStream_t s = sdf_stream(stream);
+  const int nblk = nblocks(R, C);
+  hipLaunchKernelGGL((bn_reduce_kernel<false>), dim3(nblk), dim3(256), reduce_lds(C), s, P);
+  hipLaunchKernelGGL((bn_finish_kernel<false>), dim3(C), dim3(64), 0, s, P.partial, nblk, C, R, eps, momentum, save_mean, save_invstd,
+                     running_mean, running_var);
+  hipLaunchKernelGGL((bn_apply_kernel<false>), dim3((unsigned)((R * (C / 4) + 255) / 256)), dim3(256), 0, s, P, nullptr, nullptr);
+  SDF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sdf_bn_train_bwd(const float* x, const float* grad_y, const float* weight, const float* save_mean, const float* save_invstd,
+                                float* grad_x, float* grad_weight, float* grad_bias, int64_t R, int C, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
+  if (!x || !grad_y || !weight || !save_mean || !save_invstd || !grad_x || !grad_weight || !grad_bias || !workspace) return SDF_E_NULL;
+  if (R < 1 || C < 4 || C % 4 || R * (int64_t)C >= (1LL << 40)) return SDF_E_SHAPE;
+  if (workspace_bytes < sdf_bn_train_workspace_bytes(R, C)) return SDF_E_SHAPE;
+  if (!sdf_aligned(x, 16) || !sdf_aligned(grad_y, 16) || !sdf_aligned(grad_x, 16) || !sdf_aligned(weight, 16) ||
+      !sdf_aligned(save_mean, 16) || !sdf_aligned(save_invstd, 16) || !sdf_aligned(grad_weight, 16) || !sdf_aligned(grad_bias, 16) ||
+      !sdf_aligned(workspace, 8))
+    return SDF_E_ALIGN;
+  BnParams P = {};
+  P.x = x; P.gy = grad_y; P.gx = grad_x; P.w = weight; P.mean = save_mean; P.invstd = save_invstd;
+  P.partial = reinterpret_cast<double*>(workspace); P.R = R; P.C = C;
+  hipStream_t s = sdf_stream(stream);
+  const int nblk = nblocks(R, C);
+  hipLaunchKernelGGL((bn_reduce_kernel<true>), dim3(nblk), dim3(256), reduce_lds(C), s, P);
+  hipLaunchKernelGGL((bn_finish_kernel<true>), dim3(C), dim3(64), 0, s, P.partial, nblk, C, R, 0.f, 0.f, grad_weight, grad_bias,
+                     nullptr, nullptr);
+  hipLaunchKernelGGL((bn_apply_kernel<true>), dim3((unsigned)((R * (C / 4) + 255) / 256)), dim3(256), 0, s, P, grad_weight, grad_bias);
+  SDF_LAUNCH_CHECK();
+  return 0;
+}

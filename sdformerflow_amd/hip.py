@@ -22,7 +22,8 @@ EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_s
            "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd", "sdf_head_conv_sn_fwd",
            "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes",
            "sdf_window_slice_map", "sdf_qk_attn_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
-           "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd")
+           "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd",
+           "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes")
 
 
 class SdfError(RuntimeError):
@@ -94,6 +95,7 @@ def lib():
         _lib.sdf_psn_bwd_workspace_bytes.restype = C.c_int64
         _lib.sdf_qk_attn_workspace_bytes.restype = C.c_int64
         _lib.sdf_ms_mlp_workspace_bytes.restype = C.c_int64
+        _lib.sdf_bn_train_workspace_bytes.restype = C.c_int64
     return _lib
 
 
@@ -428,6 +430,37 @@ def ms_mlp(x, fc1, fc2, sn1, sn2):
     d.gemm_workspace, d.gemm_workspace_bytes = gws.data_ptr(), gws.numel()
     _check(lib().sdf_ms_mlp_fwd(C.byref(d), _stream()), "sdf_ms_mlp_fwd")
     return x
+
+
+def bn_train_fwd(x2, weight, bias, running_mean, running_var, momentum, eps):
+    """sdf_bn_train_fwd on a contiguous (R, C) fp32 buffer: (y, save_mean, save_invstd); running stats updated in place."""
+    R, Cc = x2.shape
+    y = torch.empty_like(x2)
+    mean, invstd = torch.empty(Cc, dtype=torch.float32, device=x2.device), torch.empty(Cc, dtype=torch.float32, device=x2.device)
+    nbytes = lib().sdf_bn_train_workspace_bytes(C.c_int64(R), C.c_int(Cc))
+    ws = torch.empty((nbytes // 8,), dtype=torch.float64, device=x2.device)
+    rc = lib().sdf_bn_train_fwd(C.c_void_p(_ptr(x2, torch.float32)), C.c_void_p(_ptr(weight, torch.float32)),
+                                C.c_void_p(_ptr(bias, torch.float32)), C.c_void_p(_ptr(y)), C.c_void_p(_ptr(mean)), C.c_void_p(_ptr(invstd)),
+                                C.c_void_p(_ptr(running_mean, torch.float32)), C.c_void_p(_ptr(running_var, torch.float32)),
+                                C.c_int64(R), C.c_int(Cc), C.c_float(eps), C.c_float(momentum), C.c_void_p(ws.data_ptr()),
+                                C.c_int64(nbytes), _stream())
+    _check(rc, "sdf_bn_train_fwd")
+    return y, mean, invstd
+
+
+def bn_train_bwd(x2, grad_y, weight, mean, invstd):
+    """sdf_bn_train_bwd: (grad_x, grad_weight, grad_bias)."""
+    R, Cc = x2.shape
+    gx = torch.empty_like(x2)
+    gw, gb = torch.empty(Cc, dtype=torch.float32, device=x2.device), torch.empty(Cc, dtype=torch.float32, device=x2.device)
+    nbytes = lib().sdf_bn_train_workspace_bytes(C.c_int64(R), C.c_int(Cc))
+    ws = torch.empty((nbytes // 8,), dtype=torch.float64, device=x2.device)
+    rc = lib().sdf_bn_train_bwd(C.c_void_p(_ptr(x2, torch.float32)), C.c_void_p(_ptr(grad_y, torch.float32)),
+                                C.c_void_p(_ptr(weight, torch.float32)), C.c_void_p(_ptr(mean)), C.c_void_p(_ptr(invstd)),
+                                C.c_void_p(_ptr(gx)), C.c_void_p(_ptr(gw)), C.c_void_p(_ptr(gb)), C.c_int64(R), C.c_int(Cc),
+                                C.c_void_p(ws.data_ptr()), C.c_int64(nbytes), _stream())
+    _check(rc, "sdf_bn_train_bwd")
+    return gx, gw, gb
 
 
 def qk_gate_f32(q, k, p: NeuronParams):

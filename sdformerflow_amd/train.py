@@ -35,12 +35,12 @@ def _bn(x_nc, bn):
 
 
 def _bn_last(x, bn):
-    """(T, B, ..., C): the reference permutes channels to dim 2, flattens (T, B) and applies BatchNorm2d."""
-    C = x.shape[-1]
-    # (N, S, C) memory viewed as an (N, C, S, 1) channels_last tensor: BatchNorm's NHWC kernels take it as is - no permute
-    # copies on the way in or out (the reference's permute(0,1,4,2,3) materialises both)
-    x4 = x.reshape(x.shape[0] * x.shape[1], -1, C).permute(0, 2, 1).unsqueeze(-1)
-    return _bn(x4, bn).squeeze(-1).permute(0, 2, 1).reshape(x.shape)
+    """(T, B, ..., C) channel-last: the reference permutes channels to dim 2, flattens (T, B) and applies BatchNorm2d - the
+    same statistics are the column statistics of the (rows, C) matrix, taken in place by the HIP kernels (no permute copies)."""
+    from .autograd import BatchNormLastFunction
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return BatchNormLastFunction.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
 
 
 def _bn_ch2(x, bn):

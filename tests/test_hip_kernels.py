@@ -668,3 +668,31 @@ def test_qk_gate_train_kernels_match_autograd_of_the_composed_expression(Tq, det
     qd, kd = q.to(DEV).requires_grad_(True), k.to(DEV).requires_grad_(True)
     QKGateFunction.apply(qd, kd, p, detach, 2.0).backward(ge.to(DEV))
     assert torch.equal(qd.grad, gq) and torch.equal(kd.grad, gk)
+
+
+@pytest.mark.parametrize("R,Cc", [(5003, 96), (1237, 192), (40960, 384), (130, 3072), (7, 8)])
+def test_channel_last_train_batchnorm_matches_fp64_autograd(R, Cc):
+    """sdf_bn_train_fwd / _bwd (batch statistics down the rows of a channel-last matrix, fp64 sums) against the defining
+    formulas evaluated in fp64 under autograd (what nn.BatchNorm2d in train mode computes on the reference's permuted view):
+    output, running statistics, grad_x / grad_weight / grad_bias to 2e-6 of each tensor's scale; bit-equal run to run."""
+    from sdformerflow_amd.autograd import BatchNormLastFunction
+    g = torch.Generator().manual_seed(R + Cc)
+    x0 = (torch.randn((R, Cc), generator=g) * 1.5 + 0.3).to(DEV)
+    w0, b0 = (torch.rand(Cc, generator=g) + 0.5).to(DEV), torch.randn(Cc, generator=g).to(DEV)
+    gy = torch.randn((R, Cc), generator=g).to(DEV)
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x0, w0, b0))
+    m, v = xd.mean(0), xd.var(0, unbiased=False)
+    yd = (xd - m) / torch.sqrt(v + 1e-5) * wd + bd
+    yd.backward(gy.double())
+    ref = [yd.detach(), 0.1 * m.detach(), 0.9 + 0.1 * v.detach() * R / max(R - 1, 1), xd.grad, wd.grad, bd.grad]
+    outs = []
+    for _ in range(2):
+        x, w, b = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        rm, rv = torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV)
+        y = BatchNormLastFunction.apply(x.view(1, R, Cc), w, b, rm, rv, 0.1, 1e-5).view(R, Cc)
+        y.backward(gy)
+        outs.append([t.detach().clone() for t in (y, rm, rv, x.grad, w.grad, b.grad)])
+    for name, r, got, again in zip(("y", "running_mean", "running_var", "gx", "gw", "gb"), ref, *outs):
+        assert torch.equal(got, again), name
+        scale = r.abs().max().item() + 1e-12
+        assert (got.double() - r).abs().max().item() <= 2e-6 * scale, (name, (got.double() - r).abs().max().item(), scale)
