@@ -345,10 +345,23 @@ class MSFlowEngine:
                 feats.append(y)
         return feats
 
-    def _deconv_classes(self, i, B, D, h, w, cin_pad):
-        key = (i, B, D, h, w)
+    def _deconv_classes(self, i, B, D, h, w, cin_pad, wkey="ref", wuse=None):
+        key = (i, B, D, h, w, wkey)
         if key not in self._deconv:
-            self._deconv[key] = deconv_classes(self.decoders[i][0], B * D, h, w, cin_pad, self.nsplit, self.device)
+            self._deconv[key] = deconv_classes(self.decoders[i][0] if wuse is None else wuse, B * D, h, w, cin_pad, self.nsplit, self.device)
+        return self._deconv[key]
+
+    def _decoder_weight(self, i, wkey, C1, C2):
+        """ConvTranspose2d weight (Cin, Cout, 3, 3) of decoder i in the reference's input-channel order [pred | y | skip] ("ref")
+        or in the physical order of the concatenation-free path [y | skip | pred, 0, 0] ("perm")."""
+        wdec = self.decoders[i][0]
+        if wkey == "ref" or i == 0:
+            return wdec
+        key = ("wperm", i)
+        if key not in self._deconv:
+            n = wdec.shape[0] - C1 - C2                                   # prediction channels in front (2)
+            pad = torch.zeros((4 - n,) + tuple(wdec.shape[1:]), dtype=wdec.dtype, device=wdec.device)
+            self._deconv[key] = torch.cat([wdec[n:n + C1], wdec[n + C1:], wdec[:n], pad], 0).contiguous()
         return self._deconv[key]
 
     def unet_tail(self, feats):
@@ -361,28 +374,47 @@ class MSFlowEngine:
         for i in range(E):
             skip = feats[E - 1 - i]
             B, D, h, w, _ = skip.shape
-            parts = ([preds[-1]] if i > 0 else []) + [y, skip]          # skip_concat(pred, skip_concat(y, skip)) on channels
-            if any(p.shape[2:4] != (h, w) for p in parts):
-                parts = [F.pad(p, (0, 0, (w - p.shape[3]) // 2, w - p.shape[3] - (w - p.shape[3]) // 2,
-                                   (h - p.shape[2]) // 2, h - p.shape[2] - (h - p.shape[2]) // 2)) for p in parts]
-            cin = sum(p.shape[-1] for p in parts)
+            parts = ([preds[-1]] if i > 0 else []) + [y, skip]          # skip_concat(pred, skip_concat(y, skip)) on channels (:168-172)
             wdec, bn, sn = self.decoders[i]
             cout = wdec.shape[1]
             # small levels: ONE plain spike GEMM over the nine stacked tap matrices + a col2im pass fills the chip; the four
             # parity-class convolutions (no 9x intermediate) are kept where that intermediate would cost more than it saves
             as_gemm = B * D * h * w * 9 * cout * 4 <= 64 << 20
-            cp = _pad32(cin) if as_gemm else _pad16(cin)
-            cat = torch.zeros((B, D, h, w, cp), dtype=torch.float32, device=y.device) if cp != cin else None
-            if cat is None:
-                cat = torch.cat(parts, dim=-1)
+            same = all(p.shape[2:4] == (h, w) for p in parts)
+            if same:
+                # no concatenation: the decoder's neuron runs on each source and writes its spikes straight into that source's
+                # channel slice of the NHWC spike image (physical channel order [y | skip | prediction padded to 4]; the
+                # transposed-convolution weight rows are permuted to match once, at pack time)
+                C1, C2 = y.shape[-1], skip.shape[-1]
+                srcs = [(y, C1, C1), (skip, C2, C2)] + ([(preds[-1], 4, 32)] if i > 0 else [])     # (tensor, channels taken, pitch)
+                cin = C1 + C2 + (4 if i > 0 else 0)
+                cp = _pad32(cin) if as_gemm else _pad16(cin)
+                s = (torch.zeros if cp != cin else torch.empty)((B, D, h, w, cp), dtype=torch.uint8, device=y.device)
+                hw, c0 = h * w, 0
+                for src, take, pitch in srcs:
+                    for b in range(B):
+                        hip.neuron_fwd(src[b], s[b].view(-1)[c0:], D, hw, take, pitch, hw * pitch, cp, hw * cp, sn)
+                    c0 += take
+                wkey = "perm"
             else:
-                torch.cat(parts, dim=-1, out=cat[..., :cin])
-            s = self._neuron_bd(cat, sn)                                  # MS decoder: SN -> ConvT -> BN
+                parts = ([preds[-1][..., :self.preds[i - 1][3]]] if i > 0 else []) + [y, skip]
+                parts = [F.pad(p, (0, 0, (w - p.shape[3]) // 2, w - p.shape[3] - (w - p.shape[3]) // 2,
+                                   (h - p.shape[2]) // 2, h - p.shape[2] - (h - p.shape[2]) // 2)) for p in parts]
+                cin = sum(p.shape[-1] for p in parts)
+                cp = _pad32(cin) if as_gemm else _pad16(cin)
+                cat = torch.zeros((B, D, h, w, cp), dtype=torch.float32, device=y.device) if cp != cin else None
+                if cat is None:
+                    cat = torch.cat(parts, dim=-1)
+                else:
+                    torch.cat(parts, dim=-1, out=cat[..., :cin])
+                s = self._neuron_bd(cat, sn)                              # MS decoder: SN -> ConvT -> BN
+                wkey = "ref"
+            wuse = self._decoder_weight(i, wkey, y.shape[-1], skip.shape[-1])
             z = torch.empty((B, D, 2 * h, 2 * w, cout), dtype=torch.float32, device=y.device)
             if as_gemm:
-                key = ("taps", i, cp)
+                key = ("taps", i, cp, wkey)
                 if key not in self._deconv:
-                    self._deconv[key] = deconv_tap_weights(wdec, cp, self.nsplit)
+                    self._deconv[key] = deconv_tap_weights(wuse, cp, self.nsplit)
                 Y = torch.empty((B * D * h * w, 9 * cout), dtype=torch.float32, device=y.device)
                 hip.spike_gemm(s, self._deconv[key], Y, B * D * h * w, 9 * cout, cp)
                 hip.deconv_col2im(Y, B * D, h, w, cout, alpha=bn[0], beta=bn[1], out=z)
@@ -391,7 +423,7 @@ class MSFlowEngine:
             imgs = per = B * D
             while per * 4 * h * w * cout * 4 >= 1 << 31:
                 per = (per + 1) // 2
-            for cls in ([] if as_gemm else self._deconv_classes(i, B, D, h, w, cp)):
+            for cls in ([] if as_gemm else self._deconv_classes(i, B, D, h, w, cp, wkey, wuse)):
                 for i0 in range(0, imgs, per):
                     n = min(per, imgs - i0)
                     hip.spike_conv2d(s.view(imgs, h, w, cp)[i0:i0 + n], cls["Wp"], n, h, w, cp, h, w, cls["KH"], cls["KW"], 1,
@@ -401,9 +433,9 @@ class MSFlowEngine:
             sp = self._neuron_bd(z, psn)                                  # MS pred: SN -> conv1x1 (+bias), 2 outputs
             po = torch.empty((B * D * 4 * h * w, 32), dtype=torch.float32, device=y.device)
             hip.spike_gemm(sp, pw, po, po.shape[0], 32, cout, bias=pb)
-            preds.append(po.view(B, D, 2 * h, 2 * w, 32)[..., :nout])
+            preds.append(po.view(B, D, 2 * h, 2 * w, 32))                 # columns nout.. are exactly zero (zero weight rows, zero bias)
             y = z
-        return preds
+        return [p[..., :self.preds[0][3]] for p in preds]
 
     def forward(self, x):
         """(B,bins,2,H,W) fp32 on the GPU -> list of E flow maps (B,2,H,W) (reference :278-305)."""

@@ -376,3 +376,25 @@ def test_large_window_15x15_T20():
         b = model2(big)["flow"]
     assert all(f.shape == (1, 2, 480, 640) and torch.isfinite(f).all() for f in a)
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_unet_tail_with_mismatched_feature_sizes_takes_the_concat_path():
+    """Odd feature maps (19x25 -> 10x13 -> 5x7): the up-sampled stream (10x14) is larger than the skip (10x13), the reference's
+    skip_concat crops / pads it (models/model_util.py:14-19) - the engine's concatenation path (reference channel order);
+    equal sizes take the concatenation-free path, which the teacher-forced stage test covers.  Teacher-forced on synthetic
+    encoder features against the oracle's U-Net tail."""
+    from sdformerflow_amd.STSwinNet_SNN.Spiking_STSwinNet import MS_SpikingformerFlowNet
+    from sdformerflow_amd.synthetic import synth_uniform
+    model, sd, ocfg = build("lif", 144, 192, cls=MS_SpikingformerFlowNet)
+    n = ocfg["neuron"]
+    eng = model.to(DEV).engine()
+    feats = [synth_uniform((1, 10, h, w, c), 50 + i, -0.4, 0.9) for i, (h, w, c) in enumerate(((19, 25, 96), (10, 13, 192), (5, 7, 384)))]
+    report = []
+    with torch.no_grad():
+        preds = eng.unet_tail([f.contiguous().to(DEV) for f in feats])
+        ref = unet_tail_oracle([f.permute(1, 0, 4, 2, 3).contiguous() for f in feats], sd, n)
+    for i, (gp, rp) in enumerate(zip(preds, ref)):
+        assert gp.permute(1, 0, 4, 2, 3).shape == rp.shape
+        compare(f"unet.pred{i}", gp.permute(1, 0, 4, 2, 3), rp, report, 1e-1)
+    for name, rate, close in report:
+        print(f"odd sizes {name:12s} mismatch-rate {rate:.2e}  max-rel-dev-of-rest {close:.1e}")
