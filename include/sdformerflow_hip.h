@@ -92,6 +92,16 @@ int sdf_bn_train_bwd(const float* x, const float* grad_y, const float* weight, c
                      float* grad_x, float* grad_weight, float* grad_bias, int64_t R, int C, void* workspace, int64_t workspace_bytes,
                      void* stream);
 
+/* The same for an NCHW buffer (N, C, H, W), HW = H * W a multiple of 4, C <= 2048: the conv outputs of the patch embedding
+ * and the U-Net tail (layer.BatchNorm2d on (T*B, C, H, W), Spiking_modules.py:118, :291-296, :339-347, :467-474, :811-819,
+ * :906-933).  Same statistics / outputs / workspace size as the channel-last pair. */
+int sdf_bn_train_nchw_fwd(const float* x, const float* weight, const float* bias, float* y, float* save_mean, float* save_invstd,
+                          float* running_mean, float* running_var, int64_t N, int C, int HW, float eps, float momentum,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+int sdf_bn_train_nchw_bwd(const float* x, const float* grad_y, const float* weight, const float* save_mean,
+                          const float* save_invstd, float* grad_x, float* grad_weight, float* grad_bias, int64_t N, int C, int HW,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Token gate of Spiking_QK_WindowAttention3D for the training path (reference Spiking_swin_transformer3D.py:687-694:
  * `q.sum(-1)` over each head's 32 channels -> sn2_q over the T' steps -> `k.mul(...)`), fp32 spike tensors (T', rows, C):
  *   forward   e = k * A,  A = SN2_q(head sums of q)

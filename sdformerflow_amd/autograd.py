@@ -87,3 +87,23 @@ class BatchNormLastFunction(torch.autograd.Function):
         x2, w, mean, invstd = ctx.saved_tensors
         gx, gw, gb = hip.bn_train_bwd(x2, gy.float().contiguous().view(x2.shape), w, mean, invstd)
         return gx.view(ctx.shape).to(ctx.in_dtype), gw, gb, None, None, None, None
+
+
+class BatchNormNCHWFunction(torch.autograd.Function):
+    """Batch-statistics BatchNorm2d on an (N, C, H, W) tensor (sdf_bn_train_nchw_fwd / _bwd): the conv outputs of the patch
+    embedding and the U-Net tail in training mode."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        ctx.in_dtype = x.dtype
+        x4 = x.float().contiguous()
+        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        y, mean, invstd = hip.bn_train_nchw_fwd(x4, w, b, running_mean, running_var, momentum, eps)
+        ctx.save_for_backward(x4, w, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x4, w, mean, invstd = ctx.saved_tensors
+        gx, gw, gb = hip.bn_train_nchw_bwd(x4, gy.float().contiguous(), w, mean, invstd)
+        return gx.to(ctx.in_dtype), gw, gb, None, None, None, None

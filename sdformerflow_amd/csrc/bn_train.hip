@@ -20,7 +20,8 @@ struct BnParams {
   const float* w; const float* b;
   const float* mean; const float* invstd;
   double* partial;                 // [nblk][2][C]
-  int64_t R; int C;
+  int64_t R; int C;                // channel-last: R rows of C; NCHW: R = N * HW elements per channel
+  int64_t NB; int HW;              // NCHW only: N images, HW = H * W (HW % 4 == 0)
 };
 
 // per-channel sums of (a, a*a) [stats] or (gy, gy * xhat) [backward] over a row-strided slice; partial[blk][0|1][c]
@@ -134,6 +135,72 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnParams P, const float* 
   }
 }
 
+// ---- NCHW layout (the conv outputs of the patch embedding / U-Net: (T*B, C, H, W)) ----
+// reduce: a workgroup walks (image, channel) planes, sums each plane with float4 lanes + wave shuffles, and accumulates the
+// plane sums per channel in LDS; partial[blk][0|1][c] as in the channel-last kernel.
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_reduce_nchw_kernel(BnParams P) {
+  extern __shared__ double sm[];                                  // [2][C] + [4][2] scratch
+  double* acc = sm;
+  double* wsum = sm + 2 * P.C;
+  for (int i = threadIdx.x; i < 2 * P.C; i += 256) acc[i] = 0;
+  __syncthreads();
+  const int64_t planes = P.NB * P.C;
+  const int Q = P.HW / 4;
+  for (int64_t pl = blockIdx.x; pl < planes; pl += gridDim.x) {
+    const int c = (int)(pl % P.C);
+    const float* xp = P.x + pl * P.HW;
+    const float* gp = BWD ? P.gy + pl * P.HW : nullptr;
+    const float mu = BWD ? P.mean[c] : 0.f, is = BWD ? P.invstd[c] : 0.f;
+    double s0 = 0, s1 = 0;
+    for (int q = threadIdx.x; q < Q; q += 256) {
+      const float4 a = *reinterpret_cast<const float4*>(xp + 4 * q);
+      if (!BWD) {
+        s0 += ((double)a.x + a.y) + ((double)a.z + a.w);
+        s1 += ((double)a.x * a.x + (double)a.y * a.y) + ((double)a.z * a.z + (double)a.w * a.w);
+      } else {
+        const float4 g = *reinterpret_cast<const float4*>(gp + 4 * q);
+        s0 += ((double)g.x + g.y) + ((double)g.z + g.w);
+        s1 += ((double)g.x * ((a.x - mu) * is) + (double)g.y * ((a.y - mu) * is)) +
+              ((double)g.z * ((a.z - mu) * is) + (double)g.w * ((a.w - mu) * is));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { wsum[wave * 2] = s0; wsum[wave * 2 + 1] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      acc[c] += (wsum[0] + wsum[2]) + (wsum[4] + wsum[6]);
+      acc[P.C + c] += (wsum[1] + wsum[3]) + (wsum[5] + wsum[7]);
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < 2 * P.C; i += 256) P.partial[(int64_t)blockIdx.x * 2 * P.C + i] = acc[i];
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_apply_nchw_kernel(BnParams P, const float* gw, const float* gb) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;     // float4 index
+  const int Q = P.HW / 4;
+  if (i >= P.NB * P.C * Q) return;
+  const int c = (int)((i / Q) % P.C);
+  const float4 a = *reinterpret_cast<const float4*>(P.x + i * 4);
+  const float mu = P.mean[c], is = P.invstd[c], w = P.w[c];
+  float4 o;
+  if (!BWD) {
+    const float b = P.b[c];
+    o.x = (a.x - mu) * is * w + b; o.y = (a.y - mu) * is * w + b; o.z = (a.z - mu) * is * w + b; o.w = (a.w - mu) * is * w + b;
+    *reinterpret_cast<float4*>(P.y + i * 4) = o;
+  } else {
+    const float4 g = *reinterpret_cast<const float4*>(P.gy + i * 4);
+    const float inv_r = 1.0f / (float)P.R, sb = gb[c] * inv_r, sw = gw[c] * inv_r;
+    o.x = (g.x - sb - (a.x - mu) * is * sw) * is * w; o.y = (g.y - sb - (a.y - mu) * is * sw) * is * w;
+    o.z = (g.z - sb - (a.z - mu) * is * sw) * is * w; o.w = (g.w - sb - (a.w - mu) * is * sw) * is * w;
+    *reinterpret_cast<float4*>(P.gx + i * 4) = o;
+  }
+}
+
 int nblocks(int64_t R, int C) {
   const int QB = C / 4 < 64 ? C / 4 : 64, RL = 256 / QB;
   const int64_t need = (R + RL - 1) / RL;
@@ -194,6 +261,52 @@ extern "C" int sdf_bn_train_bwd(const float* x, const float* grad_y, const float
   hipLaunchKernelGGL((bn_finish_kernel<true>), dim3(C), dim3(64), 0, s, P.partial, nblk, C, R, 0.f, 0.f, grad_weight, grad_bias,
                      nullptr, nullptr);
   hipLaunchKernelGGL((bn_apply_kernel<true>), dim3((unsigned)((R * (C / 4) + 255) / 256)), dim3(256), 0, s, P, grad_weight, grad_bias);
+  SDF_LAUNCH_CHECK();
+  return 0;
+}
+
+// NCHW variants: x (N, C, H, W) contiguous, HW = H * W a multiple of 4; same statistics, same outputs, same workspace size.
+extern "C" int sdf_bn_train_nchw_fwd(const float* x, const float* weight, const float* bias, float* y, float* save_mean,
+                                     float* save_invstd, float* running_mean, float* running_var, int64_t N, int C, int HW, float eps,
+                                     float momentum, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!x || !weight || !bias || !y || !save_mean || !save_invstd || !workspace) return SDF_E_NULL;
+  if (N < 1 || C < 1 || HW < 4 || HW % 4 || N * (int64_t)C * HW >= (1LL << 40) || C > 2048) return SDF_E_SHAPE;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return SDF_E_NULL;
+  if (workspace_bytes < (int64_t)BN_BLOCKS * 2 * C * (int64_t)sizeof(double)) return SDF_E_SHAPE;
+  if (!sdf_aligned(x, 16) || !sdf_aligned(y, 16) || !sdf_aligned(workspace, 8)) return SDF_E_ALIGN;
+  BnParams P = {};
+  P.x = x; P.y = y; P.w = weight; P.b = bias; P.mean = save_mean; P.invstd = save_invstd; P.partial = reinterpret_cast<double*>(workspace);
+  P.R = N * HW; P.C = C; P.NB = N; P.HW = HW;
+  hipStream_t s = sdf_stream(stream);
+  const int64_t planes = N * C;
+  const int nblk = (int)(planes < BN_BLOCKS ? planes : BN_BLOCKS);
+  const size_t lds = (size_t)(2 * C + 8) * sizeof(double);
+  hipLaunchKernelGGL((bn_reduce_nchw_kernel<false>), dim3(nblk), dim3(256), lds, s, P);
+  hipLaunchKernelGGL((bn_finish_kernel<false>), dim3(C), dim3(64), 0, s, P.partial, nblk, C, P.R, eps, momentum, save_mean, save_invstd,
+                     running_mean, running_var);
+  hipLaunchKernelGGL((bn_apply_nchw_kernel<false>), dim3((unsigned)((N * C * (HW / 4) + 255) / 256)), dim3(256), 0, s, P, nullptr, nullptr);
+  SDF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sdf_bn_train_nchw_bwd(const float* x, const float* grad_y, const float* weight, const float* save_mean,
+                                     const float* save_invstd, float* grad_x, float* grad_weight, float* grad_bias, int64_t N, int C,
+                                     int HW, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!x || !grad_y || !weight || !save_mean || !save_invstd || !grad_x || !grad_weight || !grad_bias || !workspace) return SDF_E_NULL;
+  if (N < 1 || C < 1 || HW < 4 || HW % 4 || N * (int64_t)C * HW >= (1LL << 40) || C > 2048) return SDF_E_SHAPE;
+  if (workspace_bytes < (int64_t)BN_BLOCKS * 2 * C * (int64_t)sizeof(double)) return SDF_E_SHAPE;
+  if (!sdf_aligned(x, 16) || !sdf_aligned(grad_y, 16) || !sdf_aligned(grad_x, 16) || !sdf_aligned(workspace, 8)) return SDF_E_ALIGN;
+  BnParams P = {};
+  P.x = x; P.gy = grad_y; P.gx = grad_x; P.w = weight; P.mean = save_mean; P.invstd = save_invstd;
+  P.partial = reinterpret_cast<double*>(workspace); P.R = N * HW; P.C = C; P.NB = N; P.HW = HW;
+  hipStream_t s = sdf_stream(stream);
+  const int64_t planes = N * C;
+  const int nblk = (int)(planes < BN_BLOCKS ? planes : BN_BLOCKS);
+  const size_t lds = (size_t)(2 * C + 8) * sizeof(double);
+  hipLaunchKernelGGL((bn_reduce_nchw_kernel<true>), dim3(nblk), dim3(256), lds, s, P);
+  hipLaunchKernelGGL((bn_finish_kernel<true>), dim3(C), dim3(64), 0, s, P.partial, nblk, C, P.R, 0.f, 0.f, grad_weight, grad_bias, nullptr,
+                     nullptr);
+  hipLaunchKernelGGL((bn_apply_nchw_kernel<true>), dim3((unsigned)((N * C * (HW / 4) + 255) / 256)), dim3(256), 0, s, P, grad_weight, grad_bias);
   SDF_LAUNCH_CHECK();
   return 0;
 }

@@ -23,7 +23,7 @@ EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_s
            "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes",
            "sdf_window_slice_map", "sdf_qk_attn_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
            "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd",
-           "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes")
+           "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd")
 
 
 class SdfError(RuntimeError):
@@ -460,6 +460,40 @@ def bn_train_bwd(x2, grad_y, weight, mean, invstd):
                                 C.c_void_p(_ptr(gx)), C.c_void_p(_ptr(gw)), C.c_void_p(_ptr(gb)), C.c_int64(R), C.c_int(Cc),
                                 C.c_void_p(ws.data_ptr()), C.c_int64(nbytes), _stream())
     _check(rc, "sdf_bn_train_bwd")
+    return gx, gw, gb
+
+
+def bn_train_nchw_supported(x):
+    return x.dim() == 4 and (x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[1] <= 2048
+
+
+def bn_train_nchw_fwd(x, weight, bias, running_mean, running_var, momentum, eps):
+    """sdf_bn_train_nchw_fwd on a contiguous (N, C, H, W) fp32 buffer: (y, save_mean, save_invstd)."""
+    N, Cc, H, W = x.shape
+    y = torch.empty_like(x)
+    mean, invstd = torch.empty(Cc, dtype=torch.float32, device=x.device), torch.empty(Cc, dtype=torch.float32, device=x.device)
+    nbytes = lib().sdf_bn_train_workspace_bytes(C.c_int64(N * H * W), C.c_int((Cc + 3) // 4 * 4))
+    ws = torch.empty((nbytes // 8,), dtype=torch.float64, device=x.device)
+    rc = lib().sdf_bn_train_nchw_fwd(C.c_void_p(_ptr(x, torch.float32)), C.c_void_p(_ptr(weight, torch.float32)),
+                                     C.c_void_p(_ptr(bias, torch.float32)), C.c_void_p(_ptr(y)), C.c_void_p(_ptr(mean)),
+                                     C.c_void_p(_ptr(invstd)), C.c_void_p(_ptr(running_mean, torch.float32)),
+                                     C.c_void_p(_ptr(running_var, torch.float32)), C.c_int64(N), C.c_int(Cc), C.c_int(H * W),
+                                     C.c_float(eps), C.c_float(momentum), C.c_void_p(ws.data_ptr()), C.c_int64(nbytes), _stream())
+    _check(rc, "sdf_bn_train_nchw_fwd")
+    return y, mean, invstd
+
+
+def bn_train_nchw_bwd(x, grad_y, weight, mean, invstd):
+    N, Cc, H, W = x.shape
+    gx = torch.empty_like(x)
+    gw, gb = torch.empty(Cc, dtype=torch.float32, device=x.device), torch.empty(Cc, dtype=torch.float32, device=x.device)
+    nbytes = lib().sdf_bn_train_workspace_bytes(C.c_int64(N * H * W), C.c_int((Cc + 3) // 4 * 4))
+    ws = torch.empty((nbytes // 8,), dtype=torch.float64, device=x.device)
+    rc = lib().sdf_bn_train_nchw_bwd(C.c_void_p(_ptr(x, torch.float32)), C.c_void_p(_ptr(grad_y, torch.float32)),
+                                     C.c_void_p(_ptr(weight, torch.float32)), C.c_void_p(_ptr(mean)), C.c_void_p(_ptr(invstd)),
+                                     C.c_void_p(_ptr(gx)), C.c_void_p(_ptr(gw)), C.c_void_p(_ptr(gb)), C.c_int64(N), C.c_int(Cc),
+                                     C.c_int(H * W), C.c_void_p(ws.data_ptr()), C.c_int64(nbytes), _stream())
+    _check(rc, "sdf_bn_train_nchw_bwd")
     return gx, gw, gb
 
 

@@ -28,10 +28,13 @@ from . import hip
 
 # ---------------------------------------------------------------------------------------------- layers
 def _bn(x_nc, bn):
-    """Batch-statistics BatchNorm over dim 1 of (N, C, ...) with the module's parameters; running stats updated in place."""
+    """Batch-statistics BatchNorm over dim 1 of (N, C, H, W) with the module's parameters; running stats updated in place."""
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    return F.batch_norm(x_nc, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps)
+    if hip.bn_train_nchw_supported(x_nc):
+        from .autograd import BatchNormNCHWFunction
+        return BatchNormNCHWFunction.apply(x_nc, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+    return F.batch_norm(x_nc, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps)   # H*W % 4 != 0
 
 
 def _bn_last(x, bn):

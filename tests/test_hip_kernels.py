@@ -696,3 +696,30 @@ def test_channel_last_train_batchnorm_matches_fp64_autograd(R, Cc):
         assert torch.equal(got, again), name
         scale = r.abs().max().item() + 1e-12
         assert (got.double() - r).abs().max().item() <= 2e-6 * scale, (name, (got.double() - r).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("N,Cc,H,W", [(20, 48, 36, 48), (3, 96, 9, 12), (5, 768, 6, 6), (2, 2, 4, 4)])
+def test_nchw_train_batchnorm_matches_fp64_autograd(N, Cc, H, W):
+    """sdf_bn_train_nchw_fwd / _bwd against the defining formulas in fp64 under autograd (nn.BatchNorm2d in train mode)."""
+    from sdformerflow_amd.autograd import BatchNormNCHWFunction
+    g = torch.Generator().manual_seed(N * 1000 + Cc)
+    x0 = (torch.randn((N, Cc, H, W), generator=g) * 1.5 + 0.3).to(DEV)
+    w0, b0 = (torch.rand(Cc, generator=g) + 0.5).to(DEV), torch.randn(Cc, generator=g).to(DEV)
+    gy = torch.randn((N, Cc, H, W), generator=g).to(DEV)
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x0, w0, b0))
+    m, v = xd.mean((0, 2, 3)), xd.var((0, 2, 3), unbiased=False)
+    yd = (xd - m.view(1, -1, 1, 1)) / torch.sqrt(v.view(1, -1, 1, 1) + 1e-5) * wd.view(1, -1, 1, 1) + bd.view(1, -1, 1, 1)
+    yd.backward(gy.double())
+    R = N * H * W
+    ref = [yd.detach(), 0.1 * m.detach(), 0.9 + 0.1 * v.detach() * R / (R - 1), xd.grad, wd.grad, bd.grad]
+    outs = []
+    for _ in range(2):
+        x, w, b = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        rm, rv = torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV)
+        y = BatchNormNCHWFunction.apply(x, w, b, rm, rv, 0.1, 1e-5)
+        y.backward(gy)
+        outs.append([t.detach().clone() for t in (y, rm, rv, x.grad, w.grad, b.grad)])
+    for name, r, got, again in zip(("y", "running_mean", "running_var", "gx", "gw", "gb"), ref, *outs):
+        assert torch.equal(got, again), name
+        scale = r.abs().max().item() + 1e-12
+        assert (got.double() - r).abs().max().item() <= 2e-6 * scale, (name, (got.double() - r).abs().max().item(), scale)
