@@ -96,3 +96,28 @@ def test_argument_errors_are_reported_before_any_launch():
     assert lib.sdf_qk_attn_workspace_bytes(C.c_int64(4), C.c_int(2), C.c_int(81), C.c_int(96)) == 62208 + 2 * 62208
     assert lib.sdf_window_slice_map(None, 1, 2, 9, 9, 2, 9, 9, 0, 0, 0, None, None) == E_NULL
     assert lib.sdf_window_slice_map(p, 1, 2, 9, 9, 0, 9, 9, 0, 0, 0, None, None) == E_SHAPE
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under sdformerflow_amd/ (nor bench.py outside its cpu_baseline leg) may import
+    it, and there is no CPU fallback module to import instead."""
+    import ast
+    pkg = os.path.join(ROOT, "sdformerflow_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            tree = ast.parse(open(os.path.join(dirpath, f)).read())
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or ""]
+                assert not any(n == "oracle" or n.startswith("oracle.") for n in names), (f, names)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef):
+            uses = any(isinstance(n, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(n) for n in ast.walk(node))
+            assert not uses or node.name == "cpu_baseline", node.name
