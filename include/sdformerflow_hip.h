@@ -106,13 +106,17 @@ int sdf_bn_train_nchw_bwd(const float* x, const float* grad_y, const float* weig
  * `q.sum(-1)` over each head's 32 channels -> sn2_q over the T' steps -> `k.mul(...)`), fp32 spike tensors (T', rows, C):
  *   forward   e = k * A,  A = SN2_q(head sums of q)
  *   backward  grad_k = grad_e * A ;  grad_q = BPTT of SN2_q applied to sum_d(grad_e * k), broadcast over the head's channels
- * LIF / IF gates (ATan surrogate, detach_reset as in sdf_lif_bwd); T' in {1, 2, 4}; C % 32 == 0; 16-byte aligned pointers.
+ * LIF / IF / PSN gates (ATan surrogate; detach_reset as in sdf_lif_bwd); T' in {1, 2, 4}; C % 32 == 0; 16-byte aligned pointers.
+ * PSN: psn_w (T',T') / psn_b (T') in, grad_psn_w / grad_psn_b out, reduced deterministically through `workspace`
+ * (sdf_qk_gate_bwd_workspace_bytes); all five NULL otherwise.
  * One launch each instead of the ~8 elementwise / reduction launches autograd runs for the composed expression. */
 int sdf_qk_gate_f32_fwd(const float* q, const float* k, float* e, int Tq, int64_t rows, int C, int kind, float tau, float v_th,
-                        int soft_reset, float v_reset, void* stream);
+                        int soft_reset, float v_reset, const float* psn_w, const float* psn_b, void* stream);
+int64_t sdf_qk_gate_bwd_workspace_bytes(int Tq, int64_t rows, int C);
 int sdf_qk_gate_bwd(const float* q, const float* k, const float* grad_e, float* grad_q, float* grad_k, int Tq, int64_t rows, int C,
                     int kind, float tau, float v_th, int soft_reset, float v_reset, int detach_reset, int surrogate, float alpha,
-                    void* stream);
+                    const float* psn_w, const float* psn_b, float* grad_psn_w, float* grad_psn_b, void* workspace,
+                    int64_t workspace_bytes, void* stream);
 
 /* General neuron launch: strided / gathered input, fused eval-BatchNorm and additive prologue.
  * Replaces the reference idiom  SN( BN( y.permute(..) ).permute(..) [+ positional_encoding] )

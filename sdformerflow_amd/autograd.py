@@ -50,22 +50,27 @@ class PSNFunction(torch.autograd.Function):
 
 class QKGateFunction(torch.autograd.Function):
     """Token gate of the QK attention, e = k * SN2_q(sum of q over each head's channels), both directions one HIP launch
-    (reference Spiking_swin_transformer3D.py:687-694 under autograd); LIF / IF gates."""
+    (reference Spiking_swin_transformer3D.py:687-694 under autograd).  `psn_w` / `psn_b` are the gate's PSN parameters
+    (None for LIF / IF): their gradients come out of the same backward launch."""
 
     @staticmethod
-    def forward(ctx, q, k, params, detach_reset, alpha):
+    def forward(ctx, q, k, psn_w, psn_b, kind, tau, v_th, v_reset, detach_reset, alpha):
         ctx.in_dtype = q.dtype
         q, k = q.float().contiguous(), k.float().contiguous()
+        p = hip.NeuronParams(kind, tau, v_th, v_reset,
+                             psn_w=None if psn_w is None else psn_w.detach().float().contiguous(),
+                             psn_b=None if psn_b is None else psn_b.detach().float().reshape(-1).contiguous())
         ctx.save_for_backward(q, k)
-        ctx.cfg = (params, detach_reset, alpha)
-        return hip.qk_gate_f32(q, k, params)
+        ctx.cfg = (p, detach_reset, alpha, None if psn_b is None else psn_b.shape)
+        return hip.qk_gate_f32(q, k, p)
 
     @staticmethod
     def backward(ctx, grad_e):
         q, k = ctx.saved_tensors
-        params, detach_reset, alpha = ctx.cfg
-        gq, gk = hip.qk_gate_bwd(q, k, grad_e.float(), params, detach_reset, alpha)
-        return gq.to(ctx.in_dtype), gk.to(ctx.in_dtype), None, None, None
+        p, detach_reset, alpha, bshape = ctx.cfg
+        gq, gk, gW, gb = hip.qk_gate_bwd(q, k, grad_e.float(), p, detach_reset, alpha)
+        return (gq.to(ctx.in_dtype), gk.to(ctx.in_dtype), gW, None if gb is None else gb.view(bshape),
+                None, None, None, None, None, None)
 
 
 class BatchNormLastFunction(torch.autograd.Function):

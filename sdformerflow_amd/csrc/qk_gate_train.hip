@@ -8,8 +8,8 @@
 // Replaces, per block and direction, the chain reshape -> sum(-1) -> neuron -> repeat_interleave -> mul that autograd runs
 // as ~8 elementwise / reduction launches.  HBM-bound: 8 lanes own one (row, head) - a 128-byte line of each tensor per step -
 // and combine their partial sums with three xor shuffles; everything else is per-lane.  fp32 in / out so that the tensors
-// carry gradients (the inference kernel of qk_gate.hip moves bytes).  PSN gates (a learnable T' x T' matrix inside the gate)
-// stay on the composed path.
+// carry gradients (the inference kernel of qk_gate.hip moves bytes).  PSN gates carry a learnable T' x T' matrix and bias: their
+// gradients are reduced wave -> workgroup -> per-workgroup partials -> fixed-order finish (deterministic, no atomics).
 #include "common.h"
 
 namespace {
@@ -20,6 +20,8 @@ struct GateTrainParams {
   int64_t rows; int C; int G;
   int kind, soft, detach;
   float tau, inv_tau, v_th, v_reset, c_atan, half_alpha;
+  const float* psn_w; const float* psn_b;   // PSN gate: (T', T') and (T')
+  float* partial;                           // PSN backward: [nblk][T'*T' + T'] partial sums of dW | db
 };
 
 __device__ __forceinline__ float sum8(float v) {          // over the 8 lanes of one (row, head)
@@ -31,6 +33,17 @@ __device__ __forceinline__ float sum8(float v) {          // over the 8 lanes of
 
 template <int TQ>
 __device__ __forceinline__ void gate_neuron(const GateTrainParams& P, const float (&s)[TQ], float (&h)[TQ], float (&A)[TQ]) {
+  if (P.kind == SDF_PSN) {                                       // h = b + W s (the forward kernel's fma chain), A = (h >= 0)
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) {
+      float hh = P.psn_b[t];
+#pragma unroll
+      for (int k = 0; k < TQ; ++k) hh = __builtin_fmaf(P.psn_w[t * TQ + k], s[k], hh);
+      h[t] = hh;
+      A[t] = hh >= 0.f ? 1.f : 0.f;
+    }
+    return;
+  }
   const bool soft = P.soft != 0, reset0 = soft || P.v_reset == 0.f;
   float v = soft ? 0.f : P.v_reset;
 #pragma unroll
@@ -76,6 +89,54 @@ __global__ __launch_bounds__(256) void qk_gate_train_kernel(GateTrainParams P) {
 #pragma unroll
   for (int t = 0; t < TQ; ++t)
     gA[t] = sum8((gv[t].x * kv[t].x + gv[t].y * kv[t].y) + (gv[t].z * kv[t].z + gv[t].w * kv[t].w));
+  if (P.kind == SDF_PSN) {
+    // gh = gA * g'(h);  gs_k = sum_t W[t][k] gh_t;  dW[t][k] += gh_t s_k, db[t] += gh_t over all (row, head) pairs
+    float gh[TQ];
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) {
+      const float tt = P.c_atan * h[t], y = 1.f + tt * tt;
+      gh[t] = ((1.f / y) * P.half_alpha) * gA[t];
+    }
+#pragma unroll
+    for (int k = 0; k < TQ; ++k) {
+      float g = 0.f;
+#pragma unroll
+      for (int t = 0; t < TQ; ++t) g = __builtin_fmaf(P.psn_w[t * TQ + k], gh[t], g);
+      gs[k] = g;
+    }
+    if (live) {
+#pragma unroll
+      for (int t = 0; t < TQ; ++t) {
+        *reinterpret_cast<float4*>(P.gq + t * step + off) = make_float4(gs[t], gs[t], gs[t], gs[t]);
+        *reinterpret_cast<float4*>(P.gk + t * step + off) = make_float4(gv[t].x * A[t], gv[t].y * A[t], gv[t].z * A[t], gv[t].w * A[t]);
+      }
+    }
+    // parameter gradients: one lane per (row, head) contributes (all 8 hold the same sums); wave butterfly -> LDS -> partial
+    constexpr int NACC = TQ * TQ + TQ;
+    __shared__ float red[4][NACC];
+    const bool lead = live && (threadIdx.x & 7) == 0;
+    float acc[NACC];
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) {
+#pragma unroll
+      for (int k = 0; k < TQ; ++k) acc[t * TQ + k] = lead ? gh[t] * s[k] : 0.f;
+      acc[TQ * TQ + t] = lead ? gh[t] : 0.f;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) acc[a] += __shfl_xor(acc[a], o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) red[wave][a] = acc[a];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NACC)
+      P.partial[(int64_t)blockIdx.x * NACC + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    return;
+  }
   // BPTT through the gate neuron (the recurrence of neuron_bwd.hip on the TQ head sums)
   const bool soft = P.soft != 0;
   float gvm = 0.f;
@@ -111,13 +172,30 @@ __global__ __launch_bounds__(256) void qk_gate_train_kernel(GateTrainParams P) {
 
 int fill(GateTrainParams& P, int64_t rows, int C, int kind, float tau, float v_th, int soft_reset, float v_reset) {
   if (rows < 1 || C < 32 || C % 32 || rows * (int64_t)C >= (1LL << 40)) return SDF_E_SHAPE;
-  if (kind != SDF_LIF && kind != SDF_IF) return SDF_E_DTYPE;
+  if (kind != SDF_LIF && kind != SDF_IF && kind != SDF_PSN) return SDF_E_DTYPE;
   if (kind == SDF_LIF && !(tau > 1.f)) return SDF_E_SHAPE;
   P.rows = rows; P.C = C; P.G = C / 32; P.kind = kind; P.soft = soft_reset; P.tau = tau; P.v_th = v_th;
   P.v_reset = soft_reset ? 0.f : v_reset;
   int ex;
   P.inv_tau = (kind == SDF_LIF && frexpf(tau, &ex) == 0.5f) ? 1.0f / tau : 0.f;
   return 0;
+}
+
+// fixed-order sum of the per-workgroup partials (double accumulation, one thread per parameter-gradient entry group)
+__global__ __launch_bounds__(256) void gate_finish_kernel(const float* partial, int64_t nblk, int nacc, int tt, float* gW, float* gb) {
+  __shared__ double sm[256];
+  const int a = blockIdx.x;
+  double t = 0;
+  for (int64_t b = threadIdx.x; b < nblk; b += 256) t += partial[b * nacc + a];
+  sm[threadIdx.x] = t;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (a < tt * tt) gW[a] = (float)sm[0]; else gb[a - tt * tt] = (float)sm[0];
+  }
 }
 
 template <bool BWD>
@@ -137,20 +215,32 @@ int launch(const GateTrainParams& P, int Tq, hipStream_t s) {
 }  // namespace
 
 extern "C" int sdf_qk_gate_f32_fwd(const float* q, const float* k, float* e, int Tq, int64_t rows, int C, int kind, float tau,
-                                   float v_th, int soft_reset, float v_reset, void* stream) {
+                                   float v_th, int soft_reset, float v_reset, const float* psn_w, const float* psn_b, void* stream) {
   if (!q || !k || !e) return SDF_E_NULL;
+  if (kind == SDF_PSN && (!psn_w || !psn_b)) return SDF_E_NULL;
   if (!sdf_aligned(q, 16) || !sdf_aligned(k, 16) || !sdf_aligned(e, 16)) return SDF_E_ALIGN;
   GateTrainParams P = {};
   const int rc = fill(P, rows, C, kind, tau, v_th, soft_reset, v_reset);
   if (rc) return rc;
-  P.q = q; P.k = k; P.e = e;
+  P.q = q; P.k = k; P.e = e; P.psn_w = psn_w; P.psn_b = psn_b;
   return launch<false>(P, Tq, sdf_stream(stream));
+}
+
+extern "C" int64_t sdf_qk_gate_bwd_workspace_bytes(int Tq, int64_t rows, int C) {
+  if (Tq < 1 || rows < 1 || C < 32) return 0;
+  const int64_t nblk = (rows * (C / 32) * 8 + 255) / 256;
+  return nblk * (Tq * Tq + Tq) * (int64_t)sizeof(float);
 }
 
 extern "C" int sdf_qk_gate_bwd(const float* q, const float* k, const float* grad_e, float* grad_q, float* grad_k, int Tq,
                                int64_t rows, int C, int kind, float tau, float v_th, int soft_reset, float v_reset,
-                               int detach_reset, int surrogate, float alpha, void* stream) {
+                               int detach_reset, int surrogate, float alpha, const float* psn_w, const float* psn_b,
+                               float* grad_psn_w, float* grad_psn_b, void* workspace, int64_t workspace_bytes, void* stream) {
   if (!q || !k || !grad_e || !grad_q || !grad_k) return SDF_E_NULL;
+  if (kind == SDF_PSN) {
+    if (!psn_w || !psn_b || !grad_psn_w || !grad_psn_b || !workspace) return SDF_E_NULL;
+    if (workspace_bytes < sdf_qk_gate_bwd_workspace_bytes(Tq, rows, C) || !sdf_aligned(workspace, 4)) return SDF_E_SHAPE;
+  }
   if (surrogate != SDF_SURROGATE_ATAN) return SDF_E_DTYPE;
   if (!sdf_aligned(q, 16) || !sdf_aligned(k, 16) || !sdf_aligned(grad_e, 16) || !sdf_aligned(grad_q, 16) || !sdf_aligned(grad_k, 16))
     return SDF_E_ALIGN;
@@ -158,7 +248,14 @@ extern "C" int sdf_qk_gate_bwd(const float* q, const float* k, const float* grad
   const int rc = fill(P, rows, C, kind, tau, v_th, soft_reset, v_reset);
   if (rc) return rc;
   P.q = q; P.k = k; P.ge = grad_e; P.gq = grad_q; P.gk = grad_k; P.detach = detach_reset;
+  P.psn_w = psn_w; P.psn_b = psn_b; P.partial = reinterpret_cast<float*>(workspace);
   P.c_atan = (float)(3.14159265358979323846 / 2 * (double)alpha);
   P.half_alpha = (float)((double)alpha / 2);
-  return launch<true>(P, Tq, sdf_stream(stream));
+  const int rc2 = launch<true>(P, Tq, sdf_stream(stream));
+  if (rc2 || kind != SDF_PSN) return rc2;
+  const int64_t nblk = (rows * (C / 32) * 8 + 255) / 256;
+  const int nacc = Tq * Tq + Tq;
+  hipLaunchKernelGGL(gate_finish_kernel, dim3(nacc), dim3(256), 0, sdf_stream(stream), P.partial, nblk, nacc, Tq, grad_psn_w, grad_psn_b);
+  SDF_LAUNCH_CHECK();
+  return 0;
 }

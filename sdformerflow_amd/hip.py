@@ -22,7 +22,7 @@ EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_s
            "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd", "sdf_head_conv_sn_fwd",
            "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes",
            "sdf_window_slice_map", "sdf_qk_attn_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
-           "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd",
+           "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
            "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd")
 
 
@@ -96,6 +96,7 @@ def lib():
         _lib.sdf_qk_attn_workspace_bytes.restype = C.c_int64
         _lib.sdf_ms_mlp_workspace_bytes.restype = C.c_int64
         _lib.sdf_bn_train_workspace_bytes.restype = C.c_int64
+        _lib.sdf_qk_gate_bwd_workspace_bytes.restype = C.c_int64
     return _lib
 
 
@@ -505,23 +506,31 @@ def qk_gate_f32(q, k, p: NeuronParams):
     rc = lib().sdf_qk_gate_f32_fwd(C.c_void_p(_ptr(q, torch.float32)), C.c_void_p(_ptr(k, torch.float32)), C.c_void_p(_ptr(e)),
                                    C.c_int(Tq), C.c_int64(q[0].numel() // Cc), C.c_int(Cc), C.c_int(KIND[p.kind]), C.c_float(p.tau),
                                    C.c_float(p.v_th), C.c_int(1 if p.v_reset is None else 0),
-                                   C.c_float(0.0 if p.v_reset is None else p.v_reset), _stream())
+                                   C.c_float(0.0 if p.v_reset is None else p.v_reset), C.c_void_p(_ptr(p.psn_w, torch.float32)),
+                                   C.c_void_p(_ptr(p.psn_b, torch.float32)), _stream())
     _check(rc, "sdf_qk_gate_f32_fwd")
     return e
 
 
 def qk_gate_bwd(q, k, grad_e, p: NeuronParams, detach_reset=True, alpha=2.0):
-    """sdf_qk_gate_bwd: (dL/dq, dL/dk) of the token gate."""
+    """sdf_qk_gate_bwd: (dL/dq, dL/dk, dL/dW, dL/db) of the token gate (the last two only for a PSN gate, else None)."""
     q, k, g = q.contiguous(), k.contiguous(), grad_e.contiguous()
     Tq, Cc = q.shape[0], q.shape[-1]
+    rows = q[0].numel() // Cc
     gq, gk = torch.empty_like(q), torch.empty_like(k)
+    psn = p.kind == "psn"
+    gW = torch.empty((Tq, Tq), dtype=torch.float32, device=q.device) if psn else None
+    gb = torch.empty((Tq,), dtype=torch.float32, device=q.device) if psn else None
+    nbytes = lib().sdf_qk_gate_bwd_workspace_bytes(C.c_int(Tq), C.c_int64(rows), C.c_int(Cc)) if psn else 0
+    ws = torch.empty((max(nbytes, 4) // 4,), dtype=torch.float32, device=q.device) if psn else None
     rc = lib().sdf_qk_gate_bwd(C.c_void_p(_ptr(q, torch.float32)), C.c_void_p(_ptr(k, torch.float32)), C.c_void_p(_ptr(g, torch.float32)),
-                               C.c_void_p(_ptr(gq)), C.c_void_p(_ptr(gk)), C.c_int(Tq), C.c_int64(q[0].numel() // Cc), C.c_int(Cc),
+                               C.c_void_p(_ptr(gq)), C.c_void_p(_ptr(gk)), C.c_int(Tq), C.c_int64(rows), C.c_int(Cc),
                                C.c_int(KIND[p.kind]), C.c_float(p.tau), C.c_float(p.v_th), C.c_int(1 if p.v_reset is None else 0),
                                C.c_float(0.0 if p.v_reset is None else p.v_reset), C.c_int(1 if detach_reset else 0), C.c_int(0),
-                               C.c_float(alpha), _stream())
+                               C.c_float(alpha), C.c_void_p(_ptr(p.psn_w, torch.float32)), C.c_void_p(_ptr(p.psn_b, torch.float32)),
+                               C.c_void_p(_ptr(gW)), C.c_void_p(_ptr(gb)), C.c_void_p(_ptr(ws)), C.c_int64(nbytes), _stream())
     _check(rc, "sdf_qk_gate_bwd")
-    return gq, gk
+    return gq, gk, gW, gb
 
 
 def affine_resid(x, alpha, beta, Cch, inner, resid=None, out=None):

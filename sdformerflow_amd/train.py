@@ -117,10 +117,14 @@ def qk_attention(x, attn):
     k = _bn_last(F.linear(xs, attn.linear_k.weight), attn.bn_k.norm_layer)
     k = attn.sn_k(k + attn.positional_encoding.reshape(Tq, 1, N1, C))
     gate = attn.sn2_q.spiking_neuron
-    if gate.kind in ("lif", "if") and hd == 32:                         # token gate, forward and backward one HIP launch each
+    if hd == 32 and Tq in (1, 2, 4):                                    # token gate, forward and backward one HIP launch each
         from .autograd import QKGateFunction
-        e = QKGateFunction.apply(q, k, gate.params(), gate.detach_reset, getattr(gate.surrogate_function, "alpha", 2.0))
-    else:                                                               # PSN gate (learnable T' x T' matrix): composed path
+        alpha = getattr(gate.surrogate_function, "alpha", 2.0)
+        if gate.kind == "psn":
+            e = QKGateFunction.apply(q, k, gate.weight, gate.bias, "psn", 2.0, 0.0, None, True, alpha)
+        else:
+            e = QKGateFunction.apply(q, k, None, None, gate.kind, gate.tau, gate.v_threshold, gate.v_reset, gate.detach_reset, alpha)
+    else:                                                               # other head widths / window depths: composed expression
         a = attn.sn2_q(q.reshape(Tq, B_, N1, nH, hd).sum(-1))
         e = k * a.repeat_interleave(hd, dim=-1)
     z = e.reshape(B_, nH, Tq, N1, hd).permute(2, 0, 3, 1, 4).reshape(Tq, B_, N1, C)     # the reference's raw head reshape

@@ -660,14 +660,48 @@ def test_qk_gate_train_kernels_match_autograd_of_the_composed_expression(Tq, det
     gs = BW.lif_backward(s, gA, p.tau, p.v_th, v_reset, detach, 2.0)
     gq_ref = gs.repeat_interleave(32, dim=-1)
     e = hip.qk_gate_f32(q.to(DEV), k.to(DEV), p)
-    gq, gk = hip.qk_gate_bwd(q.to(DEV), k.to(DEV), ge.to(DEV), p, detach, 2.0)
+    gq, gk, _, _ = hip.qk_gate_bwd(q.to(DEV), k.to(DEV), ge.to(DEV), p, detach, 2.0)
     assert torch.equal(e.cpu(), e_ref) and torch.equal(gk.cpu(), gk_ref)
     assert (gq.cpu() - gq_ref).abs().max().item() <= 1e-5 * gq_ref.abs().max().item()
     # the autograd bridge
     from sdformerflow_amd.autograd import QKGateFunction
     qd, kd = q.to(DEV).requires_grad_(True), k.to(DEV).requires_grad_(True)
-    QKGateFunction.apply(qd, kd, p, detach, 2.0).backward(ge.to(DEV))
+    QKGateFunction.apply(qd, kd, None, None, "lif", p.tau, p.v_th, v_reset, detach, 2.0).backward(ge.to(DEV))
     assert torch.equal(qd.grad, gq) and torch.equal(kd.grad, gk)
+
+
+@pytest.mark.parametrize("Tq", [2, 4])
+def test_qk_gate_train_kernels_psn_gate_with_parameter_gradients(Tq):
+    """PSN gate (learnable T' x T' matrix + bias inside the gate): e, dL/dq, dL/dk, dL/dW, dL/db of the one-launch kernels against
+    torch autograd through the composed expression with the reference's surrogate; parameter gradients deterministic."""
+    from oracle import sdformer_oracle as O
+    rows, Cc, nH = 3000 + 11, 96, 3
+    g = torch.Generator().manual_seed(Tq)
+    q = (torch.rand((Tq, rows, Cc), generator=g) < 0.35).float()
+    k = (torch.rand((Tq, rows, Cc), generator=g) < 0.3).float()
+    ge = torch.randn((Tq, rows, Cc), generator=g)
+    W = (torch.randn((Tq, Tq), generator=g) * 0.3).requires_grad_(True)
+    b = torch.full((Tq, 1), -2.0).requires_grad_(True)
+    qr, kr = q.clone().requires_grad_(True), k.clone().requires_grad_(True)
+    s = qr.reshape(Tq, rows, nH, 32).sum(-1)
+    h = torch.addmm(b, W, s.flatten(1))
+    A = O._ATan.apply(h, 2.0).view(s.shape)
+    e_ref = kr * A.repeat_interleave(32, dim=-1)
+    e_ref.backward(ge)
+    from sdformerflow_amd.autograd import QKGateFunction
+    outs = []
+    for _ in range(2):
+        qd, kd = q.to(DEV).requires_grad_(True), k.to(DEV).requires_grad_(True)
+        Wd, bd = W.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+        e = QKGateFunction.apply(qd, kd, Wd, bd, "psn", 2.0, 0.0, None, True, 2.0)
+        e.backward(ge.to(DEV))
+        outs.append((e.detach(), qd.grad, kd.grad, Wd.grad, bd.grad))
+    assert all(torch.equal(a, c) for a, c in zip(*outs))
+    e, gq, gk, gW, gb = (t.cpu() for t in outs[0])
+    assert (e - e_ref.detach()).abs().mean().item() <= 1e-5                   # a head sum whose h is within rounding of 0 may flip
+    for name, got, ref in (("gq", gq, qr.grad), ("gk", gk, kr.grad), ("gW", gW, W.grad), ("gb", gb, b.grad)):
+        assert got.shape == ref.shape, name
+        assert (got - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-7, (name, (got - ref).abs().max().item())
 
 
 @pytest.mark.parametrize("R,Cc", [(5003, 96), (1237, 192), (40960, 384), (130, 3072), (7, 8)])
