@@ -235,6 +235,13 @@ int sdf_spike_gemm_bn_fwd(const uint8_t* A_spike, const uint16_t* W_planes, int 
 int sdf_window_slice_map(int32_t* map, int B, int D, int H, int W, int Wd, int Wh, int Ww, int shift_d, int shift_h, int shift_w,
                          int64_t* n_windows, void* stream);
 
+/* Rows of a channel-last fp32 buffer moved through that table - the training path's window partition / reverse with no
+ * materialised pad, roll, permute or crop:  gather  out[i,:] = map[i] >= 0 ? x[map[i],:] : 0   (M = map length rows out);
+ * scatter  out[map[i],:] = y[i,:] for map[i] >= 0 (rows of `out` that no entry names are left untouched - every valid source
+ * row occurs exactly once in a slice map, so each is the other's backward).  C % 4 == 0, 16-byte aligned. */
+int sdf_rows_gather_fwd(const float* x, const int32_t* map, float* out, int64_t M, int C, void* stream);
+int sdf_rows_scatter_fwd(const float* y, const int32_t* map, float* out, int64_t M, int C, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Spiking QK window attention, whole (rows a5 + a6):  x += SSA(x) in place.
  * Replaces: Spiking_SwinTransformerBlock3D.SSA + Spiking_QK_WindowAttention3D.forward + the shortcut add

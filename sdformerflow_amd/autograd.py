@@ -112,3 +112,40 @@ class BatchNormNCHWFunction(torch.autograd.Function):
         x4, w, mean, invstd = ctx.saved_tensors
         gx, gw, gb = hip.bn_train_nchw_bwd(x4, gy.float().contiguous(), w, mean, invstd)
         return gx.to(ctx.in_dtype), gw, gb, None, None, None, None
+
+
+class WindowGatherFunction(torch.autograd.Function):
+    """Window partition as a row gather through the slice map (pad + roll(-shift) + window_partition_v2 of the reference,
+    Spiking_swin_transformer3D.py:789-804, :100-113) - backward is the matching scatter."""
+
+    @staticmethod
+    def forward(ctx, x, row_map):
+        ctx.in_dtype, ctx.shape = x.dtype, x.shape
+        ctx.save_for_backward(row_map)
+        return hip.rows_gather(x.float().contiguous().view(-1, x.shape[-1]), row_map)
+
+    @staticmethod
+    def backward(ctx, g):
+        (row_map,) = ctx.saved_tensors
+        rows = 1
+        for d in ctx.shape[:-1]:
+            rows *= d
+        return hip.rows_scatter(g.float().contiguous(), row_map, rows).view(ctx.shape).to(ctx.in_dtype), None
+
+
+class WindowScatterFunction(torch.autograd.Function):
+    """Window reverse as a row scatter through the same map (window_reverse + roll(+shift) + crop, :810-820) - backward is the gather."""
+
+    @staticmethod
+    def forward(ctx, y2, row_map, out_shape):
+        ctx.in_dtype = y2.dtype
+        ctx.save_for_backward(row_map)
+        rows = 1
+        for d in out_shape[:-1]:
+            rows *= d
+        return hip.rows_scatter(y2.float().contiguous(), row_map, rows).view(out_shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (row_map,) = ctx.saved_tensors
+        return hip.rows_gather(g.float().contiguous().view(-1, g.shape[-1]), row_map).to(ctx.in_dtype), None, None

@@ -48,3 +48,49 @@ extern "C" int sdf_affine_resid_fwd(const float* x, const float* alpha, const fl
   SDF_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Window partition / reverse for the TRAINING path as index arithmetic (the inference path folds the same table into the
+// neuron kernel's gather and the GEMM's scatter): rows of a channel-last fp32 buffer moved through the int32 slice map of
+// sdf_window_slice_map - no materialised pad, roll, permute or crop (reference Spiking_swin_transformer3D.py:789-820).
+//   gather : out[i, :] = map[i] >= 0 ? x[map[i], :] : 0          (pad + roll(-shift) + window_partition_v2, and the
+//                                                                  backward of `scatter`)
+//   scatter: out[map[i], :] = y[i, :] for map[i] >= 0            (window_reverse + roll(+shift) + crop, and the backward
+//            of `gather`; every source row occurs exactly once in the map, so there is no accumulation and no atomic)
+namespace {
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void rows_move_kernel(const float* __restrict__ src, const int32_t* __restrict__ map,
+                                                        float* __restrict__ dst, int64_t M, int Q) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;     // float4 index into the (M, C) side
+  if (i >= M * Q) return;
+  const int64_t row = i / Q;
+  const int q = (int)(i - row * Q);
+  const int32_t m = map[row];
+  if (SCATTER) {
+    if (m >= 0) *reinterpret_cast<float4*>(dst + ((int64_t)m * Q + q) * 4) = *reinterpret_cast<const float4*>(src + i * 4);
+  } else {
+    *reinterpret_cast<float4*>(dst + i * 4) =
+        m >= 0 ? *reinterpret_cast<const float4*>(src + ((int64_t)m * Q + q) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+}  // namespace
+
+extern "C" int sdf_rows_gather_fwd(const float* x, const int32_t* map, float* out, int64_t M, int C, void* stream) {
+  if (!x || !map || !out) return SDF_E_NULL;
+  if (M < 1 || C < 4 || C % 4) return SDF_E_SHAPE;
+  if (!sdf_aligned(x, 16) || !sdf_aligned(out, 16)) return SDF_E_ALIGN;
+  hipLaunchKernelGGL((rows_move_kernel<false>), dim3((unsigned)((M * (C / 4) + 255) / 256)), dim3(256), 0, sdf_stream(stream), x, map,
+                     out, M, C / 4);
+  SDF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sdf_rows_scatter_fwd(const float* y, const int32_t* map, float* out, int64_t M, int C, void* stream) {
+  if (!y || !map || !out) return SDF_E_NULL;
+  if (M < 1 || C < 4 || C % 4) return SDF_E_SHAPE;
+  if (!sdf_aligned(y, 16) || !sdf_aligned(out, 16)) return SDF_E_ALIGN;
+  hipLaunchKernelGGL((rows_move_kernel<true>), dim3((unsigned)((M * (C / 4) + 255) / 256)), dim3(256), 0, sdf_stream(stream), y, map,
+                     out, M, C / 4);
+  SDF_LAUNCH_CHECK();
+  return 0;
+}

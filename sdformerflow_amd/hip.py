@@ -23,6 +23,7 @@ EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_s
            "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes",
            "sdf_window_slice_map", "sdf_qk_attn_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
            "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
+           "sdf_rows_gather_fwd", "sdf_rows_scatter_fwd",
            "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd")
 
 
@@ -496,6 +497,22 @@ def bn_train_nchw_bwd(x, grad_y, weight, mean, invstd):
                                      C.c_int(H * W), C.c_void_p(ws.data_ptr()), C.c_int64(nbytes), _stream())
     _check(rc, "sdf_bn_train_nchw_bwd")
     return gx, gw, gb
+
+
+def rows_gather(x2, row_map):
+    """sdf_rows_gather_fwd: (rows, C) fp32 -> (len(map), C), zero rows where the map is negative."""
+    out = torch.empty((row_map.numel(), x2.shape[1]), dtype=torch.float32, device=x2.device)
+    _check(lib().sdf_rows_gather_fwd(C.c_void_p(_ptr(x2, torch.float32)), C.c_void_p(_ptr(row_map, torch.int32)), C.c_void_p(_ptr(out)),
+                                     C.c_int64(row_map.numel()), C.c_int(x2.shape[1]), _stream()), "sdf_rows_gather_fwd")
+    return out
+
+
+def rows_scatter(y2, row_map, rows):
+    """sdf_rows_scatter_fwd: (len(map), C) fp32 -> (rows, C): out[map[i]] = y2[i]; rows nobody names are zero."""
+    out = torch.zeros((rows, y2.shape[1]), dtype=torch.float32, device=y2.device)
+    _check(lib().sdf_rows_scatter_fwd(C.c_void_p(_ptr(y2, torch.float32)), C.c_void_p(_ptr(row_map, torch.int32)), C.c_void_p(_ptr(out)),
+                                      C.c_int64(row_map.numel()), C.c_int(y2.shape[1]), _stream()), "sdf_rows_scatter_fwd")
+    return out
 
 
 def qk_gate_f32(q, k, p: NeuronParams):

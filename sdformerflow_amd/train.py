@@ -131,22 +131,22 @@ def qk_attention(x, attn):
     return _bn_last(F.linear(z, attn.proj.weight, attn.proj.bias), attn.proj_bn.norm_layer)
 
 
+_SLICE_MAPS = {}
+
+
 def ssa(x, blk):
-    """pad -> cyclic shift -> window_partition_v2 (raw view to (Wd, B_, Wh, Ww, C)) -> attention -> reverse -> crop."""
+    """Window partition -> attention -> window reverse, both as row moves through the int32 slice map (built on the device,
+    cached per shape): no materialised pad / roll / permute / crop in either direction of autograd."""
+    from .autograd import WindowGatherFunction, WindowScatterFunction
     B, D, H, W, C = x.shape
     (Wd, Wh, Ww), ss = get_window_size((D, H, W), blk.window_size, blk.shift_size)
-    pd, ph, pw = (Wd - D % Wd) % Wd, (Wh - H % Wh) % Wh, (Ww - W % Ww) % Ww
-    x = F.pad(x, (0, 0, 0, pw, 0, ph, 0, pd))
-    Dp, Hp, Wp = D + pd, H + ph, W + pw
-    if any(s > 0 for s in ss):
-        x = torch.roll(x, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
-    xw = x.view(B, Dp // Wd, Wd, Hp // Wh, Wh, Wp // Ww, Ww, C).permute(0, 1, 3, 5, 2, 4, 6, 7).contiguous()
-    B_ = B * (Dp // Wd) * (Hp // Wh) * (Wp // Ww)
-    y = qk_attention(xw.view(Wd, B_, Wh * Ww, C), blk.attn)              # raw view: step t' of window b' is slice t' B_ + b'
-    y = y.reshape(B, Dp // Wd, Hp // Wh, Wp // Ww, Wd, Wh, Ww, C).permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, Dp, Hp, Wp, C)
-    if any(s > 0 for s in ss):
-        y = torch.roll(y, shifts=ss, dims=(1, 2, 3))
-    return y[:, :D, :H, :W, :].contiguous()
+    key = (B, D, H, W, Wd, Wh, Ww, ss, str(x.device))
+    if key not in _SLICE_MAPS:
+        _SLICE_MAPS[key] = hip.window_slice_map(B, D, H, W, (Wd, Wh, Ww), ss, x.device)
+    row_map, B_ = _SLICE_MAPS[key]
+    xw = WindowGatherFunction.apply(x, row_map)                          # (Wd * B_ * Wh * Ww, C): step t' of window b' is slice t' B_ + b'
+    y = qk_attention(xw.view(Wd, B_, Wh * Ww, C), blk.attn)
+    return WindowScatterFunction.apply(y.reshape(-1, C), row_map, (B, D, H, W, C))
 
 
 def ms_mlp(x, mlp):

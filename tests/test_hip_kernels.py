@@ -757,3 +757,39 @@ def test_nchw_train_batchnorm_matches_fp64_autograd(N, Cc, H, W):
         assert torch.equal(got, again), name
         scale = r.abs().max().item() + 1e-12
         assert (got.double() - r).abs().max().item() <= 2e-6 * scale, (name, (got.double() - r).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 18, 21, (2, 9, 9), (1, 4, 4)), (1, 10, 24, 24, (2, 8, 8), (0, 0, 0)), (1, 6, 15, 33, (2, 15, 15), (1, 7, 7))])
+def test_window_gather_scatter_equal_the_reference_pad_roll_partition(shape):
+    """Training-path window partition / reverse as row moves through the slice map (sdf_rows_gather_fwd / _scatter_fwd) against
+    the reference's own sequence - F.pad, torch.roll(-shift), window_partition_v2's view / permute / raw view, and back
+    (window_reverse, roll(+shift), crop) - bit-equal in both directions of autograd."""
+    from sdformerflow_amd.autograd import WindowGatherFunction, WindowScatterFunction
+    import torch.nn.functional as F
+    B, D, H, W, ws, ss = shape
+    Cc = 32
+    Wd, Wh, Ww = ws
+    x0 = torch.randn((B, D, H, W, Cc), device=DEV)
+    gy = torch.randn((B, D, H, W, Cc), device=DEV)
+    # reference composition
+    xr = x0.clone().requires_grad_(True)
+    pd, ph, pw = (Wd - D % Wd) % Wd, (Wh - H % Wh) % Wh, (Ww - W % Ww) % Ww
+    xp = F.pad(xr, (0, 0, 0, pw, 0, ph, 0, pd))
+    Dp, Hp, Wp = D + pd, H + ph, W + pw
+    if any(ss):
+        xp = torch.roll(xp, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
+    xw = xp.view(B, Dp // Wd, Wd, Hp // Wh, Wh, Wp // Ww, Ww, Cc).permute(0, 1, 3, 5, 2, 4, 6, 7).contiguous()
+    B_ = B * (Dp // Wd) * (Hp // Wh) * (Wp // Ww)
+    win_ref = xw.view(Wd, B_, Wh * Ww, Cc)
+    back = (win_ref * 2.0).reshape(B, Dp // Wd, Hp // Wh, Wp // Ww, Wd, Wh, Ww, Cc).permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, Dp, Hp, Wp, Cc)
+    if any(ss):
+        back = torch.roll(back, shifts=ss, dims=(1, 2, 3))
+    y_ref = back[:, :D, :H, :W, :].contiguous()
+    y_ref.backward(gy)
+    # row moves
+    xm = x0.clone().requires_grad_(True)
+    row_map, B2 = hip.window_slice_map(B, D, H, W, ws, ss, DEV)
+    win = WindowGatherFunction.apply(xm, row_map).view(Wd, B2, Wh * Ww, Cc)
+    y = WindowScatterFunction.apply((win * 2.0).reshape(-1, Cc), row_map, (B, D, H, W, Cc))
+    y.backward(gy)
+    assert B2 == B_ and torch.equal(win, win_ref) and torch.equal(y, y_ref) and torch.equal(xm.grad, xr.grad)
