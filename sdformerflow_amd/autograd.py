@@ -149,3 +149,30 @@ class WindowScatterFunction(torch.autograd.Function):
     def backward(ctx, g):
         (row_map,) = ctx.saved_tensors
         return hip.rows_gather(g.float().contiguous().view(-1, g.shape[-1]), row_map).to(ctx.in_dtype), None, None
+
+
+class SpikeLinearFunction(torch.autograd.Function):
+    """Linear layer on a spike tensor in the training path: the FORWARD is the inference path's spike GEMM (binary activations
+    exact in 16 bits, fp32-grade weight planes re-split from the current weights, fp32 accumulate) and the activation is kept
+    for the backward as 1-byte spikes (a quarter of what autograd would hold); the backward's two dense products
+    (dX = dY W, dW = dY^T X) are library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, nsplit):
+        K, N = x.shape[-1], weight.shape[0]
+        xu8 = x.reshape(-1, K).to(torch.uint8)
+        planes = hip.split_weight(weight.detach().float().contiguous(), nsplit)
+        out = torch.empty((xu8.shape[0], N), dtype=torch.float32, device=x.device)
+        hip.spike_gemm(xu8, planes, out, xu8.shape[0], N, K, bias=None if bias is None else bias.detach().float().contiguous())
+        ctx.save_for_backward(xu8, weight)
+        ctx.has_bias, ctx.xshape, ctx.in_dtype = bias is not None, x.shape, x.dtype
+        return out.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        xu8, weight = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1]).float()
+        gx = (g2 @ weight.float()).view(ctx.xshape).to(ctx.in_dtype) if ctx.needs_input_grad[0] else None
+        gw = g2.t() @ xu8.float() if ctx.needs_input_grad[1] else None
+        gb = g2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None

@@ -27,6 +27,24 @@ from . import hip
 
 
 # ---------------------------------------------------------------------------------------------- layers
+# Forward of the Linear layers in the training path: 0 = library F.linear (default); 2 / 3 = the inference path's spike GEMM
+# with that many weight planes and the activation saved as 1-byte spikes.  Measured at local batch 4: same parity (block-level
+# gradients still equal the reference fixture element for element), 2.5 GiB less memory, but the step is SLOWER (fp32 123 ->
+# 130 ms: u8 conversion + per-step weight split + fp32 re-expansion in the backward; under bf16 autocast 95 -> 114 ms because
+# the backward products leave autocast) - so it stays off until the backward products are spike-aware too.
+SPIKE_LINEAR_PLANES = 0
+
+
+def _linear(x, lin):
+    """Linear on a SPIKE tensor (every Linear of the MS models is fed by a neuron or by the token gate): forward on the spike
+    GEMM kernel, spikes saved as bytes for the backward."""
+    K, N = lin.weight.shape[1], lin.weight.shape[0]
+    if SPIKE_LINEAR_PLANES and K % 32 == 0 and N % 32 == 0:
+        from .autograd import SpikeLinearFunction
+        return SpikeLinearFunction.apply(x, lin.weight, lin.bias, SPIKE_LINEAR_PLANES)
+    return F.linear(x, lin.weight, lin.bias)
+
+
 def _bn(x_nc, bn):
     """Batch-statistics BatchNorm over dim 1 of (N, C, H, W) with the module's parameters; running stats updated in place."""
     if bn.num_batches_tracked is not None:
@@ -113,8 +131,8 @@ def qk_attention(x, attn):
     nH = attn.num_heads
     hd = C // nH
     xs = attn.proj_sn(x)
-    q = attn.sn_q(_bn_last(F.linear(xs, attn.linear_q.weight), attn.bn_q.norm_layer))
-    k = _bn_last(F.linear(xs, attn.linear_k.weight), attn.bn_k.norm_layer)
+    q = attn.sn_q(_bn_last(_linear(xs, attn.linear_q), attn.bn_q.norm_layer))
+    k = _bn_last(_linear(xs, attn.linear_k), attn.bn_k.norm_layer)
     k = attn.sn_k(k + attn.positional_encoding.reshape(Tq, 1, N1, C))
     gate = attn.sn2_q.spiking_neuron
     if hd == 32 and Tq in (1, 2, 4):                                    # token gate, forward and backward one HIP launch each
@@ -128,7 +146,7 @@ def qk_attention(x, attn):
         a = attn.sn2_q(q.reshape(Tq, B_, N1, nH, hd).sum(-1))
         e = k * a.repeat_interleave(hd, dim=-1)
     z = e.reshape(B_, nH, Tq, N1, hd).permute(2, 0, 3, 1, 4).reshape(Tq, B_, N1, C)     # the reference's raw head reshape
-    return _bn_last(F.linear(z, attn.proj.weight, attn.proj.bias), attn.proj_bn.norm_layer)
+    return _bn_last(_linear(z, attn.proj), attn.proj_bn.norm_layer)
 
 
 _SLICE_MAPS = {}
@@ -150,8 +168,8 @@ def ssa(x, blk):
 
 
 def ms_mlp(x, mlp):
-    h = _bn_last(F.linear(mlp.sn1(x), mlp.fc1.weight, mlp.fc1.bias), mlp.bn1.norm_layer)
-    return _bn_last(F.linear(mlp.sn2(h), mlp.fc2.weight, mlp.fc2.bias), mlp.bn2.norm_layer)
+    h = _bn_last(_linear(mlp.sn1(x), mlp.fc1), mlp.bn1.norm_layer)
+    return _bn_last(_linear(mlp.sn2(h), mlp.fc2), mlp.bn2.norm_layer)
 
 
 def ms_block(x, blk, training=True):
@@ -165,7 +183,7 @@ def ms_patch_merge(x, pm):
         x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
     x = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
     x = pm.sn(x.permute(1, 0, 2, 3, 4).contiguous())
-    return _bn_last(F.linear(x, pm.reduction.weight), pm.norm.norm_layer).permute(1, 0, 2, 3, 4)
+    return _bn_last(_linear(x, pm.reduction), pm.norm.norm_layer).permute(1, 0, 2, 3, 4)
 
 
 def skip_concat_ch(x1, x2):
