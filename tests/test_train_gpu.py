@@ -138,3 +138,24 @@ def test_adamw_steps_reduce_the_loss_and_update_running_stats():
     with torch.no_grad():
         out = model(chunk)["flow"]
     assert all(torch.isfinite(f).all() for f in out)
+
+
+@pytest.mark.parametrize("planes", [2, 3])
+def test_optional_spike_gemm_forward_of_linear_layers(planes):
+    """train.SPIKE_LINEAR_PLANES (off by default): Linear on spikes through the inference spike GEMM under autograd - output
+    within the weight-plane truncation of F.linear, gradients equal to those of F.linear on the same spikes."""
+    from sdformerflow_amd.autograd import SpikeLinearFunction
+    x = (torch.rand((2, 500, 96), device=DEV) < 0.3).float()
+    lin = torch.nn.Linear(96, 192).to(DEV)
+    g = torch.randn((2, 500, 192), device=DEV)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.linear(xr, lin.weight, lin.bias)
+    yr.backward(g)
+    ref = (yr.detach(), xr.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    lin.zero_grad()
+    xs = x.clone().requires_grad_(True)
+    ys = SpikeLinearFunction.apply(xs, lin.weight, lin.bias, planes)
+    ys.backward(g)
+    assert (ys - ref[0]).abs().max().item() <= 2e-6 * ref[0].abs().max().item()
+    for got, r in ((xs.grad, ref[1]), (lin.weight.grad, ref[2]), (lin.bias.grad, ref[3])):
+        assert (got - r).abs().max().item() <= 1e-5 * r.abs().max().item()
