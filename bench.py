@@ -32,7 +32,11 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 PEAK_HBM_GBPS = 8000.0              # same guide: 8.0 TB/s spec (6.3 TB/s achievable)
-CONV_TRAFFIC_BYTES = (2 * 75516.1 + 104192.0) * 1024     # PMC, see roofline.traffic_source
+# HBM bytes per launch of the roofline shape from the PMC counters.  They cannot be read inside this process (rocprofv3 owns the
+# counters), so the figure is the one measured by tools/pmc_traffic.sh on the build named in CONV_TRAFFIC_SOURCE
+CONV_TRAFFIC_BYTES = (2 * 75516.1 + 104192.0) * 1024
+CONV_TRAFFIC_SOURCE = ("NOT measured in this run: profiles/r1m_pmc_traffic_conv.txt (round-1 build r1m), rocprofv3 --pmc FETCH_SIZE "
+                       "(x2, gfx950) and WRITE_SIZE in separate passes on this exact launch; algorithmic bytes 239.2e6")
 
 
 def build_model(kind, device):
@@ -48,69 +52,111 @@ def build_model(kind, device):
     return model.to(device), sd
 
 
-def synthetic_chunk():
+def synthetic_chunk(seed=1235):
     """Harness input prep of eval_DSEC_flow_SNN.py:179-205 on a seeded DSEC-like voxel."""
     from sdformerflow_amd.harness import prepare_chunk
     from sdformerflow_amd.synthetic import synth_voxel
-    return prepare_chunk(synth_voxel(1, 10, 288, 384, seed=1235))
+    return prepare_chunk(synth_voxel(1, 10, 288, 384, seed=seed))
 
 
-def time_dominant_kernels(model, iters=20):
-    """Live HIP-event timing (on the launch stream = torch's current stream, the one passed through the C ABI) of the
-    dominant kernel of the forward - the warp-specialised spike convolution on the patch-embedding res-block shape
-    (10 images of 144x192, 96 -> 96 channels, 3x3: 4 of the 26 convolution launches and ~0.8 ms of the step) - and of
-    the HBM-bound neuron update."""
+def _timed(fn, sets, iters):
+    """Average launch time of fn(set) cycling through `sets`, HIP events on the launch stream (= torch's current stream,
+    the one passed through the C ABI)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for i in range(max(3, len(sets))):
+        fn(sets[i % len(sets)])
+    e0.record()
+    for i in range(iters):
+        fn(sets[i % len(sets)])
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+L3_BYTES = 256 << 20                # Infinity Cache of the MI355X (MI355X_MICROARCH.md): replaying ONE working set smaller than
+                                    # this measures the L3-resident rate, not HBM - both figures are reported
+
+
+def time_dominant_kernels(model, iters=40):
+    """Live HIP-event timing of the dominant kernel of the forward - the ping-pong spike convolution on the patch-embedding
+    res-block shape (10 images of 144x192, 96 -> 96 channels, 3x3: 4 of the 26 convolution launches and ~0.8 ms of the step) -
+    and of the HBM-bound neuron update.  Each is timed twice: rotating through enough operand sets that consecutive launches
+    never find their operands in the 256 MiB Infinity Cache (> 2 x L3 between two uses of a set: the HBM figure, the one in
+    `achieved` / `frac`), and replaying one set (`l3_resident`, what round 1 reported)."""
     from sdformerflow_amd import hip
     eng = model.engine()
     dev = eng.device
     imgs, H, W, Cc = 10, 144, 192, 96
     rb = eng.pe_res[0]
-    x = (torch.rand((imgs, H, W, Cc), device=dev) < 0.3).to(torch.uint8)
-    out = torch.empty((imgs * H * W, Cc), device=dev)
-    resid = torch.rand((imgs * H * W, Cc), device=dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    set_bytes = imgs * H * W * Cc * (1 + 4 + 4)
+    nset = -(-3 * L3_BYTES // set_bytes)                          # 239 MB per set -> 4 sets = 956 MB in rotation
+    sets = [((torch.rand((imgs, H, W, Cc), device=dev) < 0.3).to(torch.uint8), torch.empty((imgs * H * W, Cc), device=dev),
+             torch.rand((imgs * H * W, Cc), device=dev)) for _ in range(nset)]
 
-    def conv():
-        hip.spike_conv2d(x, rb.w2, imgs, H, W, Cc, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=out, alpha=rb.bn2[0],
-                         beta=rb.bn2[1], resid=resid)
-    for _ in range(3):
-        conv()
-    e0.record()
-    for _ in range(iters):
-        conv()
-    e1.record()
-    torch.cuda.synchronize()
-    t_conv = e0.elapsed_time(e1) / iters * 1e-3
+    def conv(st):
+        hip.spike_conv2d(st[0], rb.w2, imgs, H, W, Cc, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=st[1], alpha=rb.bn2[0],
+                         beta=rb.bn2[1], resid=st[2])
+    t_conv = _timed(conv, sets, iters)
+    t_conv_l3 = _timed(conv, sets[:1], iters)
+    del sets
     flops = 2.0 * imgs * H * W * Cc * 9 * Cc                    # algorithmic: one multiply-add per (pixel, cout, tap, cin)
     ns = int(rb.w2.shape[0])
     gemm = {"kernel": f"sdfmm::spike_mm_pp_kernel<{ns},0,true> (3x3 spike conv 96->96 @ 10x144x192, BN + residual epilogue)",
             "bound": "mfma", "achieved": flops / t_conv / 1e12, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-            "us_per_launch": t_conv * 1e6, "traffic": CONV_TRAFFIC_BYTES if ns == 2 else None,
+            "us_per_launch": t_conv * 1e6, "operand_sets_in_rotation": nset, "rotation_bytes": nset * set_bytes,
+            "l3_resident": {"us_per_launch": t_conv_l3 * 1e6, "achieved": flops / t_conv_l3 / 1e12,
+                            "frac": flops / t_conv_l3 / 1e12 / PEAK_BF16_DENSE_TFLOPS},
+            "algorithmic_bytes": set_bytes + ns * Cc * 9 * Cc * 2,
+            "traffic": CONV_TRAFFIC_BYTES if ns == 2 else None,
             "traffic_unit": "bytes per launch (HBM read + write)",
-            "traffic_source": "profiles/r1m_pmc_traffic_conv.txt: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and WRITE_SIZE in separate "
-                              "passes on this exact launch; algorithmic bytes 239.2e6",
+            "traffic_source": CONV_TRAFFIC_SOURCE,
             "note": f"algorithmic flops (2 per multiply-add of the convolution); the kernel issues {ns} 16-bit MFMAs per product "
                     f"(fp32 weights carried as {ns} planes), i.e. {ns}x this on the matrix pipe; dense peak of the f16/bf16 MFMA"}
     gemm["frac"] = gemm["achieved"] / gemm["peak"]
+    gemm["frac_of_issued_mfma"] = ns * gemm["frac"]
     # neuron: T=10 over the stage-0 MLP hidden tensor shape (10 x 72*96*384 fp32 in, u8 out)
     blk = eng.stages[0][0]
     n = 72 * 96 * 384
-    xx = torch.rand((10, n), device=dev) - 0.3
-    s = torch.empty((10, n), dtype=torch.uint8, device=dev)
+    nset = -(-3 * L3_BYTES // (10 * n * 5))                       # 133 MB per set -> 7 sets
+    sets = [(torch.rand((10, n), device=dev) - 0.3, torch.empty((10, n), dtype=torch.uint8, device=dev)) for _ in range(nset)]
     p = blk.sn2
-    for _ in range(3):
-        hip.neuron_fwd(xx, s, 10, 1, n, 0, n, 0, n, p)
-    e0.record()
-    for _ in range(iters):
-        hip.neuron_fwd(xx, s, 10, 1, n, 0, n, 0, n, p)
-    e1.record()
-    torch.cuda.synchronize()
-    t_n = e0.elapsed_time(e1) / iters * 1e-3
+
+    def neur(st):
+        hip.neuron_fwd(st[0], st[1], 10, 1, n, 0, n, 0, n, p)
+    t_n = _timed(neur, sets, iters)
+    t_n_l3 = _timed(neur, sets[:1], iters)
+    del sets
     neuron = {"kernel": "neuron_kernel<10> (26.5 M neurons x T=10, f32 in / u8 out)", "bound": "hbm",
               "achieved": 10.0 * n * 5 / t_n / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "us_per_launch": t_n * 1e6,
+              "operand_sets_in_rotation": nset, "rotation_bytes": nset * 10 * n * 5,
+              "l3_resident": {"us_per_launch": t_n_l3 * 1e6, "achieved": 10.0 * n * 5 / t_n_l3 / 1e9,
+                              "frac": 10.0 * n * 5 / t_n_l3 / 1e9 / PEAK_HBM_GBPS},
               "traffic": None}
     neuron["frac"] = neuron["achieved"] / neuron["peak"]
     return gemm, neuron
+
+
+def time_swin_blocks(model, chunk, iters=10):
+    """The attention-GEMM roofline fraction of the metric: SURVEY.md 8(d)'s 183.7 GFLOP of the swin blocks' Linear layers
+    (q|k, proj, fc1, fc2, merge) per sample / the time of the swin stages themselves - the 12 blocks + 3 merges run alone on
+    one stream between two HIP events (this includes the blocks' fused epilogues, gather neurons and token gates, so it is a
+    lower bound of the GEMM launches' own rate; the per-launch split is in profiles/)."""
+    eng = model.engine()
+    with torch.no_grad():
+        y0 = eng.patch_embed(chunk)
+
+        def stages(_):
+            y = y0.clone()
+            for s, blocks in enumerate(eng.stages):
+                for i in range(len(blocks)):
+                    y = eng.swin_block(y, s, i)
+                if s < len(eng.merges):
+                    y = eng.patch_merge(y, s)
+        t = _timed(stages, [None], iters)
+    return {"flop": 183.7e9, "swin_stages_ms": t * 1e3, "tflops": 183.7e9 / t / 1e12,
+            "frac": 183.7e9 / t / (PEAK_BF16_DENSE_TFLOPS * 1e12),
+            "note": "183.7 GFLOP (SURVEY.md 8d) / time of the 12 swin blocks + 3 patch merges alone on one stream (HIP events); "
+                    "dense bf16 MFMA peak"}
 
 
 def cpu_baseline(kind, sd, chunk, budget_s=25.0):
@@ -187,14 +233,17 @@ def main_train(args, world, rank, dev, dist, td):
         losses.append(train.train_step(model, opt, chunk, label, mask, buckets=buckets, dist=td if dist else None, world=world,
                                        amp=args.amp))
     barrier()
-    dt = max_over_ranks(time.perf_counter() - t0, dev, dist)
+    dt_local = time.perf_counter() - t0
+    dt = max_over_ranks(dt_local, dev, dist)
+    ranks = gather_ranks(rank_record(rank, dev, B * args.steps, dt_local), dist, td)
     losses = [float(v) for v in losses]
     assert all(v == v and abs(v) != float("inf") for v in losses), "non-finite loss"
     if rank == 0:
-        n_gpus = world if dist else args.gpus
+        check_ranks(ranks, world, shared_ok=os.environ.get("SDF_DIST_BACKEND", "nccl") != "nccl")
+        n_gpus = world
         print(json.dumps({
             "metric": "training samples/sec (fwd+bwd+AdamW, 10-bin 288x384)", "value": n_gpus * B * args.steps / dt, "unit": "samples/s",
-            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": n_gpus, "world_size": world, "ranks": ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 autocast (fp32 neurons, BN statistics, loss, AdamW)" if args.amp else "f32",
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[3]: MS_SpikingformerFlowNet_en4 supervised training step, local batch {B} per "
@@ -208,43 +257,149 @@ def main_train(args, world, rank, dev, dist, td):
         td.destroy_process_group()
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process becomes the LAUNCHER.  It
+    starts N ranks (one per GPU) through torch.distributed.run as a CHILD process and exits with its code; it never makes
+    a GPU call itself (device_count() does not initialise the GPU on this image) and never exec()s."""
+    import subprocess
+    if os.environ.get("SDF_DIST_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < n:
+        sys.stderr.write(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} GPU(s) visible; refusing to report a "
+                         f"{n}-GPU number from fewer devices\n")
+        return 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def init_ranks(args):
+    """-> (world, rank, dev, dist, td).  The GPU count reported in the JSON is ALWAYS torch.distributed's world size (1 when
+    not distributed), never the --gpus flag; the flag must agree with it, and every rank must own a distinct GPU (except with
+    the explicit SDF_DIST_BACKEND=gloo test backend, where ranks may share a device or run the plumbing on the CPU)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("SDF_DIST_BACKEND", "nccl")
+    dist, td = world > 1, None
+    if dist:
+        import torch.distributed as td
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+        # RCCL over xGMI (inference: timing barrier + max only; --train: the gradient all-reduce)
+        td.init_process_group(backend)
+        world = td.get_world_size()
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but {world} rank(s) joined (WORLD_SIZE); refusing to print a line")
+    if args.plumbing:
+        return world, rank, torch.device("cpu"), dist, td
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py: {world} ranks but {ndev} visible GPU(s): one GPU per rank is required")
+    local_rank %= max(ndev, 1)                                   # only reachable with the gloo test backend
+    torch.cuda.set_device(local_rank)
+    return world, rank, torch.device("cuda", local_rank), dist, td
+
+
+def gather_ranks(info, dist, td):
+    """Every rank's {rank, device, ...} record on rank 0 (one all_gather_object; outside the timed region)."""
+    if not dist:
+        return [info]
+    out = [None] * td.get_world_size()
+    td.all_gather_object(out, info)
+    return out
+
+
+def rank_record(rank, dev, steps, dt_local):
+    rec = {"rank": rank, "host_pid": os.getpid(), "device": str(dev), "samples_per_s": steps / dt_local}
+    if dev.type == "cuda":
+        pr = torch.cuda.get_device_properties(dev)
+        rec["device_name"] = pr.name
+        rec["device_uuid"] = str(getattr(pr, "uuid", "")) or None
+        rec["pci_bus_id"] = getattr(pr, "pci_bus_id", None)
+    return rec
+
+
+def check_ranks(ranks, world, shared_ok):
+    """All `world` ranks reported, and (unless the gloo test backend shares devices on purpose) on distinct GPUs."""
+    assert sorted(r["rank"] for r in ranks) == list(range(world)), f"ranks missing: {[r['rank'] for r in ranks]} of {world}"
+    if not shared_ok:
+        ids = [(r.get("device_uuid") or r["device"]) for r in ranks]
+        assert len(set(ids)) == world, f"ranks share a GPU: {ids}"
+
+
+def main_plumbing(args, world, rank, dist, td):
+    """Launcher / rendezvous / barrier / max-over-ranks / rank-record plumbing without any GPU work (CPU test of the N > 1
+    path, tests/test_bench_launcher.py).  The line it prints is labelled as such and is not a benchmark result."""
+    dev = torch.device("cpu")
+    if dist:
+        td.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (rank + 1))
+    if dist:
+        td.barrier()
+    dt_local = time.perf_counter() - t0
+    dt = max_over_ranks(dt_local, dev, dist)
+    ranks = gather_ranks(rank_record(rank, dev, args.steps, dt_local), dist, td)
+    if rank == 0:
+        check_ranks(ranks, world, shared_ok=True)
+        print(json.dumps({"metric": "plumbing dry run (no GPU work, not a benchmark result)", "value": whole_job_rate(world, args.steps, dt),
+                          "unit": "sleeps/s", "n_gpus": world, "world_size": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "data": "none", "ranks": ranks}))
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--train", action="store_true", help="BASELINE configs[3]: training step instead of the forward benchmark")
     ap.add_argument("--local-batch", type=int, default=4, help="--train: samples per GPU and step")
     ap.add_argument("--amp", action="store_true", help="--train: bf16 autocast for the dense operators (the reference uses fp16 amp)")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 300 forwards / 10 training steps)")
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--neuron", default="lif", choices=["lif", "psn"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--inflight", type=int, default=3, help="independent forwards in flight per GPU (HIP streams)")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying HIP graphs")
+    ap.add_argument("--planes", type=int, default=2, choices=[1, 2, 3],
+                    help="16-bit weight planes of the spike GEMMs / convolutions: 2 = fp16 hi+lo (22 significand bits, the default "
+                         "parity mode), 3 = bf16 hi+mid+lo (the fp32 weight exactly), 1 = one bf16 plane (BASELINE configs[1]'s "
+                         "stated bf16 precision; a separately labelled throughput line, never the parity mode)")
+    ap.add_argument("--plumbing", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.inflight < 1:
         ap.error("--inflight must be >= 1")
+    if args.steps is None:
+        args.steps = 10 if args.train else 300
+    if args.warmup is None:
+        args.warmup = 2 if args.train else 6
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = world > 1
-    if dist:
-        import torch.distributed as td
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
-        # RCCL over xGMI (inference: timing barrier only; --train: the gradient all-reduce).  SDF_DIST_BACKEND=gloo lets the
-        # N > 1 code path be exercised with several ranks sharing one GPU, which RCCL refuses
-        td.init_process_group(os.environ.get("SDF_DIST_BACKEND", "nccl"))
-    ndev = max(torch.cuda.device_count(), 1)
-    local_rank %= ndev                                           # more ranks than visible GPUs: share (never silently fail)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    world, rank, dev, dist, td = init_ranks(args)
+    if args.plumbing:
+        return main_plumbing(args, world, rank, dist, td)
 
     if args.train:
-        return main_train(args, world, rank, dev, dist, td if dist else None)
+        return main_train(args, world, rank, dev, dist, td)
 
     model, sd = build_model(args.neuron, dev)
-    chunk_cpu = synthetic_chunk()
+    model.gemm_nsplit = args.planes
+    F_ = args.inflight
+    # every in-flight stream gets its OWN synthetic voxel (seed 1235 + j); stream 0's is the one the CPU baseline runs
+    chunks_cpu = [synthetic_chunk(1235 + j) for j in range(F_)]
+    chunk_cpu = chunks_cpu[0]
     chunk = chunk_cpu.to(dev)
 
     def barrier():
@@ -266,11 +421,11 @@ def main():
         latency_ms = sorted(lat)[len(lat) // 2]                      # median of 9 synchronous forwards
 
         # F independent forwards in flight: own stream, own static input, own graph (own activation memory)
-        F_ = args.inflight
         streams = [torch.cuda.Stream(device=dev) for _ in range(F_)]
-        inputs, outputs, graphs = [], [], []
-        for st in streams:
-            x = chunk.clone()
+        inputs, outputs, graphs, refs = [], [], [], []
+        for j, st in enumerate(streams):
+            x = chunks_cpu[j].to(dev)
+            refs.append([f.clone() for f in model(x)["flow"]])   # plain single-stream forward of this stream's voxel
             with torch.cuda.stream(st):
                 for _ in range(2):
                     o = model(x)                                 # also creates this stream's split-K workspace and plan caches
@@ -298,32 +453,39 @@ def main():
         for i in range(args.steps):
             step(i)
         barrier()
-        dt = time.perf_counter() - t0
-    out = outputs[0]
-    with torch.no_grad():
-        ref = model(chunk)
-    torch.cuda.synchronize()
-    assert all(torch.equal(a, b) for o in outputs for a, b in zip(o["flow"], ref["flow"])), "in-flight forwards differ from a plain one"
-    assert torch.isfinite(out["flow"][-1]).all()
-    dt = max_over_ranks(dt, dev, dist)
+        dt_local = time.perf_counter() - t0
+    for o, r in zip(outputs, refs):
+        assert all(torch.equal(a, b) for a, b in zip(o["flow"], r)), "an in-flight forward differs from the plain forward of its voxel"
+        assert torch.isfinite(o["flow"][-1]).all()
+    if F_ > 1:
+        assert not torch.equal(outputs[0]["flow"][-1], outputs[1]["flow"][-1]), "streams were meant to carry different voxels"
+    dt = max_over_ranks(dt_local, dev, dist)
+    ranks = gather_ranks(rank_record(rank, dev, args.steps, dt_local), dist, td)
 
     if rank == 0:
-        n_gpus = world if dist else args.gpus
+        check_ranks(ranks, world, shared_ok=os.environ.get("SDF_DIST_BACKEND", "nccl") != "nccl")
         gemm, neuron = time_dominant_kernels(model)
+        blocks = time_swin_blocks(model, chunk)
+        planes_txt = {1: "ONE bf16 weight plane (8 significand bits; throughput mode at BASELINE configs[1]'s stated precision, NOT the "
+                         "parity mode)",
+                      2: "2 fp16 weight planes hi+lo (22 of fp32's 24 significand bits; the default parity mode)",
+                      3: "3 bf16 weight planes hi+mid+lo (the fp32 weights exactly)"}[args.planes]
         res = {
-            "metric": "event-frames/sec fwd (1x10x2x288x384)", "value": whole_job_rate(n_gpus, args.steps, dt), "unit": "samples/s",
-            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "metric": "event-frames/sec fwd (1x10x2x288x384)", "value": whole_job_rate(world, args.steps, dt), "unit": "samples/s",
+            "n_gpus": world, "world_size": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "latency_ms_single_stream": latency_ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {1: "bf16", 2: "f16x2", 3: "f32"}[args.planes], "data": "synthetic",
+            "dtype_note": "binary u8 spikes x " + planes_txt + ", fp32 accumulate on the 16-bit MFMA pipe; membranes, BN, neurons fp32",
             "config": {"workload": "BASELINE configs[1]: MS_SpikingformerFlowNet_en4 forward, batch 1 per GPU, 10-bin 288x384 "
-                                   "voxel, neuron=" + args.neuron + f"; spike GEMMs and spike convolutions on 16-bit MFMA with "
-                                   f"{model.gemm_nsplit}-plane fp32-grade weights and fp32 accumulate; {args.inflight} independent forwards in flight "
+                                   "voxel, neuron=" + args.neuron + f"; {args.inflight} independent forwards (different voxels) in flight "
                                    f"per GPU on HIP streams ({'eager launches' if args.eager else 'HIP-graph replay'}); replicas per GPU",
-                       "in_flight": args.inflight, "hip_graph": not args.eager},
+                       "in_flight": args.inflight, "hip_graph": not args.eager, "weight_planes": args.planes},
+            "ranks": ranks,
             "roofline": gemm, "roofline_neuron": neuron,
-            "attention_gemm_roofline_frac": 183.7e9 / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12),
+            "attention_gemm_roofline_frac": blocks["frac"], "attention_gemm": blocks,
         }
-        if not args.no_cpu and n_gpus == 1:
+        if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.neuron, sd, chunk_cpu)
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
         print(json.dumps(res))

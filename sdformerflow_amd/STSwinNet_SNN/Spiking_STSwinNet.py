@@ -95,7 +95,7 @@ class MS_SpikingformerFlowNet(nn.Module):
                             "skip_type": "concat", "channel_multiplier": 2,
                             "use_upsample_conv": unet_kwargs.get("use_upsample_conv", True)})
         self.sttmultires_unet = MS_Spikingformer_MultiResUNet(unet_kwargs, dict(stt_kwargs))
-        self._engine = None
+        self._engine, self._stamp_tensors = None, None
         # Weight planes of the spike GEMMs / convolutions (binary spikes are exact in 16-bit floats, accumulation is fp32):
         #   2 = fp16 hi + lo of the power-of-two-scaled weight: 22 of the 24 significand bits at 2/3 of the matrix work.
         #       Measured against fp64 the layer outputs are as close as torch's own fp32 convolution, and every
@@ -123,14 +123,36 @@ class MS_SpikingformerFlowNet(nn.Module):
         return super().load_state_dict(*a, **k)
 
     def _apply(self, fn, *a, **k):
-        self._engine = None
+        self._engine, self._stamp_tensors = None, None
         return super()._apply(fn, *a, **k)
 
+    def _weights_stamp(self):
+        """Cheap version stamp of everything the packed engine copies: in-place updates (optimizer.step(), the train-mode
+        BN kernels' running statistics, load_state_dict's copy_()) bump a tensor's `_version`.  Host-side only (no device
+        sync, ~0.1 ms); the tensor list is cached and dropped whenever the tree is re-laid (`_apply`: .to() / .cuda())."""
+        if self._stamp_tensors is None:
+            self._stamp_tensors = list(self.parameters()) + list(self.buffers())
+        return (self.gemm_nsplit,) + tuple(t._version for t in self._stamp_tensors)
+
+    def invalidate_engine(self):
+        """For callers that swap tensors out behind the module's back (`p.data = ...`), which no version counter sees."""
+        self._engine, self._stamp_tensors = None, None
+
+    def train(self, mode=True):
+        """Entering training invalidates the packed inference plan (weights and BN statistics are about to change)."""
+        if mode:
+            self._engine = None
+        return super().train(mode)
+
     def engine(self):
-        """The packed HIP execution plan (rebuilt after weights move or change)."""
-        if self._engine is None:
+        """The packed HIP execution plan: split weight planes, folded eval-BN (alpha, beta), PSN matrices.  Rebuilt whenever
+        the weights moved or changed since it was packed - `load_state_dict`, `.to()`, `init_weights`, `train()`, and any
+        in-place update seen through the version stamp (eval -> train_step -> eval must not run on stale planes)."""
+        stamp = self._weights_stamp()
+        if self._engine is None or self._engine_stamp != stamp:
             from ..engine import MSFlowEngine
             self._engine = MSFlowEngine(self)
+            self._engine_stamp = stamp
         return self._engine
 
     def forward(self, x, log=False):

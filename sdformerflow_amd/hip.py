@@ -12,7 +12,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsdformerflow_hip.so")
+# SDF_HIP_LIB selects a DIAGNOSTIC build (tools/stamp_pp.sh, tools/gemm_ablate.sh build theirs beside the product library,
+# never over it); unset = the product library
+LIB_PATH = os.environ.get("SDF_HIP_LIB") or os.path.join(_HERE, "csrc", "libsdformerflow_hip.so")
 
 SDF_F32, SDF_U8 = 0, 1
 SDF_LIF, SDF_PSN, SDF_IF = 0, 1, 2

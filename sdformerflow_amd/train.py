@@ -230,8 +230,10 @@ def forward_train(model, x):
 
 
 # ---------------------------------------------------------------------------------------------- loss, step, all-reduce
-def flow_loss_supervised(pred_list, gt_flow, mask, flow_scaling=1.0, lambda_mod=1.0):
-    n = torch.sum(mask)
+def flow_loss_supervised(pred_list, gt_flow, mask, flow_scaling=1.0, lambda_mod=1.0, n_valid=None):
+    """Mean over predictions and samples of sum(EPE * mask) / (number of valid pixels) (reference loss/flow_supervised.py:85-102).
+    `n_valid` replaces the local count when the batch is sharded over ranks (see `global_valid_count`)."""
+    n = torch.sum(mask) if n_valid is None else n_valid
     cur = 0.0
     for pred in pred_list:
         flow = pred * flow_scaling
@@ -240,11 +242,32 @@ def flow_loss_supervised(pred_list, gt_flow, mask, flow_scaling=1.0, lambda_mod=
     return torch.mean(cur / len(pred_list))
 
 
+def global_valid_count(mask, dist=None, world=1):
+    """Valid pixels of the GLOBAL batch.  The reference trains under nn.DataParallel: the replicas' outputs are gathered and
+    the loss is taken on the whole batch, so every sample's error is divided by the valid-pixel count of the whole batch
+    (loss/flow_supervised.py:90, train_flow_parallel_supervised_SNN.py:139-143, :306-308).  With one process per GPU the
+    count is summed over the ranks (one scalar all-reduce, issued before the backward pass); together with the mean over
+    ranks of the gradients this reproduces the gathered-batch gradient exactly - normalising by the local count instead
+    makes the gradient ~world times larger."""
+    n = torch.sum(mask).float()
+    if dist is not None and world > 1:
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    return n
+
+
 class GradientBuckets:
     """Flat fp32 gradient buckets for the data-parallel step: the parameters' `.grad` are VIEWS into a few large
     contiguous buffers (default 64 MiB - ring all-reduce over xGMI is per-link bound, few large messages beat many small
-    ones; the whole en4 model is 220 MB = 4 buckets), so `all_reduce()` is one collective per bucket with no packing
-    copies, launched asynchronously bucket by bucket and waited once."""
+    ones; the whole en4 model is 220 MB = 4 buckets), so a bucket's all-reduce is one collective with no packing copies.
+
+    Overlap with backward: every parameter carries a post-accumulate-grad hook; when the last parameter of a bucket has
+    its gradient the bucket's all-reduce is launched asynchronously right there, inside `loss.backward()` (buckets are
+    filled in reverse parameter order = the order backward produces gradients, so the first collective leaves while most
+    of the backward pass is still to run).  `finish()` launches whatever is left - buckets holding a parameter that
+    received no gradient this step - waits for all, divides by world, and hands parameters that never received a
+    gradient to the optimiser as `.grad = None` (the reference leaves them None: no weight decay / moment updates on
+    the dead attn_sn weights).  Every rank launches the same collectives in the same order: completion order is a
+    property of the autograd graph, the left-overs go in bucket order."""
 
     def __init__(self, params, bucket_bytes=64 << 20):
         self.params = [p for p in params if p.requires_grad]
@@ -257,22 +280,70 @@ class GradientBuckets:
             cur_n += p.numel()
         if cur:
             self.buckets.append(cur)
-        self.flat = []
-        for b in self.buckets:
+        self.flat, self._views, self._bucket_of = [], {}, {}
+        for bi, b in enumerate(self.buckets):
             buf = torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device)
             off = 0
             for p in b:
-                p.grad = buf[off:off + p.numel()].view_as(p)
+                self._views[p] = buf[off:off + p.numel()].view_as(p)
+                self._bucket_of[p] = bi
+                p.grad = self._views[p]
                 off += p.numel()
+                p.register_post_accumulate_grad_hook(self._ready)
             self.flat.append(buf)
+        self._dist, self._world = None, 1
+        self._pending = [len(b) for b in self.buckets]
+        self._seen, self._works, self._launched = set(), [], set()
+        self.log = []                                                   # (event, bucket index, hooks fired so far): test hook
 
     def zero(self):
         for buf in self.flat:
             buf.zero_()
 
+    def begin(self, dist=None, world=1):
+        """Start of a step: zero the buckets, re-attach the `.grad` views, arm the hooks."""
+        self.zero()
+        for p, v in self._views.items():
+            p.grad = v
+        self._dist, self._world = (dist, world) if (dist is not None and world > 1) else (None, 1)
+        self._pending = [len(b) for b in self.buckets]
+        self._seen, self._works, self._launched, self.log = set(), [], set(), []
+
+    def _launch(self, bi):
+        self._launched.add(bi)
+        self.log.append(("all_reduce", bi, len(self._seen)))
+        if self._dist is not None:
+            self._works.append(self._dist.all_reduce(self.flat[bi], op=self._dist.ReduceOp.SUM, async_op=True))
+
+    def _ready(self, p):
+        if id(p) in self._seen:
+            return
+        self._seen.add(id(p))
+        if p.grad is not self._views[p]:                                # autograd replaced the view (first accumulation into None)
+            self._views[p].copy_(p.grad)
+            p.grad = self._views[p]
+        bi = self._bucket_of[p]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def finish(self):
+        """After backward: remaining buckets, wait, average, `.grad = None` for parameters without a gradient."""
+        for bi in range(len(self.buckets)):
+            if bi not in self._launched:
+                self._launch(bi)
+        for w in self._works:
+            w.wait()
+        if self._dist is not None:
+            for buf in self.flat:
+                buf.div_(self._world)
+        for p in self.params:
+            if id(p) not in self._seen:
+                p.grad = None
+        self._works = []
+
     def all_reduce(self, dist=None, world=1):
-        """Sum over ranks / world.  Parameters that received no gradient on any rank (the dead attn_sn of the PSN model)
-        contribute zeros on every rank alike."""
+        """Non-overlapped form (gradients already complete): sum over ranks / world, one collective per bucket."""
         if dist is None or world <= 1:
             return
         works = [dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True) for buf in self.flat]
@@ -284,7 +355,8 @@ class GradientBuckets:
 
 def train_step(model, optimizer, chunk, label, mask, buckets=None, dist=None, world=1, clip_grad=100.0, flow_scaling=1.0,
                lambda_mod=1.0, amp=False):
-    """One step of train_flow_parallel_supervised_SNN.py's loop body on this rank's micro-batch; returns the loss tensor.
+    """One step of train_flow_parallel_supervised_SNN.py's loop body (:233-336) on this rank's shard of the batch; returns the
+    loss tensor (this rank's samples' mean of err / n_global; the mean over ranks is the gathered-batch loss).
     `amp`: the reference trains under `torch.cuda.amp.autocast` with fp16 + GradScaler (`optimizer.use_amp: true`,
     :248, :314-331); here the same regions run under bf16 autocast (no scaler needed) - spikes are exact in bf16, the
     membranes / neuron kernels, BatchNorm statistics, the loss and the optimiser stay fp32."""
@@ -292,15 +364,17 @@ def train_step(model, optimizer, chunk, label, mask, buckets=None, dist=None, wo
     model.train()
     functional.reset_net(model)
     if buckets is not None:
-        buckets.zero()
+        buckets.begin(dist, world)
     else:
         optimizer.zero_grad(set_to_none=True)
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
         flows = forward_train(model, chunk)
-    loss = flow_loss_supervised([f.float() for f in flows], label, mask, flow_scaling, lambda_mod)
-    loss.backward()
+    n_valid = global_valid_count(mask, dist, world)
+    # local mean over B_local of err_i / n_global, times 1 / world from the gradient average = the gathered-batch mean
+    loss = flow_loss_supervised([f.float() for f in flows], label, mask, flow_scaling, lambda_mod, n_valid=n_valid)
+    loss.backward()                                                  # bucket all-reduces leave from the grad-ready hooks
     if buckets is not None:
-        buckets.all_reduce(dist, world)
+        buckets.finish()
     if clip_grad is not None:
         torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], clip_grad)
     optimizer.step()

@@ -1,0 +1,63 @@
+"""`python bench.py --gpus N` must START N ranks itself when it is not already running under torch.distributed.run, and the
+GPU count in its JSON line must be the number of ranks that joined - never the flag.  Run here end to end on the CPU with
+the explicit gloo test backend and the `--plumbing` dry run (launcher, rendezvous, barrier, max-over-ranks and the per-rank
+records are bench.py's own code paths; no GPU work, and the line says so)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(SDF_DIST_BACKEND="gloo", **(env_extra or {}))
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+
+
+def _line(out):
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (out.stdout[-2000:], out.stderr[-2000:])       # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_gpus_2_spawns_two_ranks_and_reports_them():
+    out = _run(["--gpus", "2", "--steps", "20", "--warmup", "1", "--plumbing"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = _line(out)
+    assert r["n_gpus"] == 2 and r["world_size"] == 2
+    assert sorted(x["rank"] for x in r["ranks"]) == [0, 1]
+    assert len({x["host_pid"] for x in r["ranks"]}) == 2                     # two real processes
+    # whole-job value = all ranks' steps / the SLOWEST rank's time (rank 1 sleeps twice as long per step)
+    slow = min(x["samples_per_s"] for x in r["ranks"])
+    assert abs(r["value"] - 2 * 20 / (r["ms_per_step"] * 20e-3)) < 1e-6 * r["value"]
+    assert r["value"] <= 2.0 * slow * 1.05
+    assert r["value"] < sum(x["samples_per_s"] for x in r["ranks"])           # not N x the fastest rank
+
+
+def test_single_process_line_reports_one_rank():
+    r = _line(_run(["--steps", "5", "--warmup", "0", "--plumbing"]))
+    assert r["n_gpus"] == 1 and r["world_size"] == 1 and [x["rank"] for x in r["ranks"]] == [0]
+
+
+def test_flag_that_disagrees_with_the_joined_ranks_is_refused():
+    """Started as ONE process that is told it is rank 0 of a world of 1 while --gpus says 8: no line, non-zero exit
+    (round 1 printed 8 x the single-GPU rate here)."""
+    out = _run(["--gpus", "8", "--steps", "5", "--plumbing"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"},
+               drop=("MASTER_ADDR", "MASTER_PORT"))
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_launcher_refuses_more_ranks_than_gpus_on_the_real_backend():
+    """Without the gloo test backend the launcher checks the visible device count BEFORE starting anything (this container
+    has no GPU): exit 2, no line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SDF_DIST_BACKEND")}
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "5"], capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    assert out.returncode == 2 and "refusing" in out.stderr

@@ -3,10 +3,10 @@
 # usage (on the GPU box): tools/stamp_pp.sh imgs H W Cin Cout stride nsplit [fused|resid]
 set -e
 cd "$(dirname "$0")/.."
-cp sdformerflow_amd/csrc/libsdformerflow_hip.so /tmp/lib_product.so
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-slp-vectorize -Wno-pass-failed -DSDF_STAMP -c sdformerflow_amd/csrc/spike_mm_pp.hip -o /tmp/pp_stamp.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o sdformerflow_amd/csrc/libsdformerflow_hip.so /tmp/pp_stamp.o $(ls sdformerflow_amd/csrc/obj/*.o | grep -v spike_mm_pp)
-python3 - "$@" <<'PY'
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libsdf_stamp.so /tmp/pp_stamp.o $(ls sdformerflow_amd/csrc/obj/*.o | grep -v spike_mm_pp)
+# the diagnostic library lives beside, not over, the product one
+SDF_HIP_LIB=/tmp/libsdf_stamp.so python3 - "$@" <<'PY'
 import ctypes, sys, os, torch
 sys.path.insert(0, os.getcwd())
 from sdformerflow_amd import hip
@@ -42,4 +42,3 @@ for g, o in ((0, 5), (1, 10)):
     nt = max(b[o + 4], 1)
     print(f"consumer group {g} wave 0: tiles {nt}; per tile: wait-full {b[o]/nt:.0f}  mfma {b[o+1]/nt:.0f}  epilogue {b[o+2]/nt:.0f}; total {b[o+3]} cycles")
 PY
-cp /tmp/lib_product.so sdformerflow_amd/csrc/libsdformerflow_hip.so
