@@ -55,7 +55,8 @@ def _np(sn_module, device):
 
 
 class _Block:
-    def __init__(self, blk, device, nsplit):
+    def __init__(self, blk, device, nsplit, name=""):
+        self.name = name
         a = blk.attn
         self.nH, self.window_size, self.shift_size = a.num_heads, blk.window_size, blk.shift_size
         self.q = _Lin(a.linear_q, a.bn_q.norm_layer, device, nsplit)
@@ -87,7 +88,8 @@ def _conv_planes(w, nsplit, cin_pad=None):
 class _ResBlock:
     """MS_ResBlock weights for the spike-convolution path (3x3, pad 1, NHWC)."""
 
-    def __init__(self, rb, device, nsplit):
+    def __init__(self, rb, device, nsplit, name=""):
+        self.name = name
         self.C = rb.conv1[0].weight.shape[0]
         self.w1, self.w2 = _conv_planes(rb.conv1[0].weight, nsplit), _conv_planes(rb.conv2[0].weight, nsplit)
         self.bn1, self.bn2 = bn_affine(rb.norm1.norm_layer, device), bn_affine(rb.norm2.norm_layer, device)
@@ -160,17 +162,19 @@ class MSFlowEngine:
         self.head_w_oihw = pe.head.conv[0].weight.detach().float().contiguous()
         self.head_bn, self.head_sn = bn_affine(pe.head.norm_layer.norm_layer, dev), _np(pe.head.sn, dev)
         self.conv_w, self.conv_bn = _conv_planes(pe.conv.conv[0].weight, ns), bn_affine(pe.conv.norm_layer.norm_layer, dev)
-        self.pe_res = [_ResBlock(rb, dev, ns) for rb in pe.residual_encoding.resblocks]
+        U = "sttmultires_unet."
+        self.pe_name = U + "encoders.swin3d.patch_embed."
+        self.pe_res = [_ResBlock(rb, dev, ns, self.pe_name + f"residual_encoding.resblocks.{i}.") for i, rb in enumerate(pe.residual_encoding.resblocks)]
         self.proj_res_w = pe.proj.conv_res.weight.detach().contiguous(memory_format=torch.channels_last)
         self.proj_w = _conv_planes(pe.proj.conv.weight, ns)
         self.proj_bn, self.proj_sn = bn_affine(pe.proj.norm_layer, dev), _np(pe.proj.sn, dev)
         self.stages, self.merges = [], []
-        for layer in sw.layers:
-            self.stages.append([_Block(b, dev, ns) for b in layer.swin_blocks])
+        for li, layer in enumerate(sw.layers):
+            self.stages.append([_Block(b, dev, ns, U + f"encoders.swin3d.layers.{li}.swin_blocks.{bi}.") for bi, b in enumerate(layer.swin_blocks)])
             if layer.downsample is not None:
                 d = layer.downsample
                 self.merges.append((_Lin(d.reduction, d.norm.norm_layer, dev, ns), _np(d.sn, dev)))
-        self.unet_res = [_ResBlock(rb, dev, ns) for rb in unet.resblocks]
+        self.unet_res = [_ResBlock(rb, dev, ns, U + f"resblocks.{i}.") for i, rb in enumerate(unet.resblocks)]
         self.decoders = [(d.deconv[0].weight.detach(), bn_affine(d.norm_layer.norm_layer, dev), _np(d.sn, dev)) for d in unet.decoders]
         # flow prediction = 1x1 convolution with 2 output channels on spikes: the spike GEMM with the weight rows padded
         # to one 32-column block (columns 2.. are zero and never read back)
@@ -183,6 +187,7 @@ class MSFlowEngine:
             bp[:w2.shape[0]] = p.conv[0].bias.detach().float()
             self.preds.append((hip.split_weight(wp, ns), bp, _np(p.sn, dev), w2.shape[0]))
         self._maps, self._deconv = {}, {}
+        self.tape = None            # parity tests set a list: every neuron layer's spikes are recorded (see _rec)
 
     # ------------------------------------------------------------------ helpers
     def _slice_map(self, B, D, H, W, ws, ss):
@@ -210,6 +215,13 @@ class MSFlowEngine:
         if x.dim() != 5 or not x.is_contiguous() or x.dtype != torch.float32:
             raise hip.SdfError(f"expected a contiguous fp32 (B,D,h,w,C) tensor, got shape {tuple(x.shape)} strides {x.stride()} "
                                f"{x.dtype}; call .contiguous() (the update is in place)")
+
+    def _rec(self, name, spikes, layout):
+        """Parity tape (tests only; `self.tape = []` switches it on, never during graph capture): a copy of the u8 spikes of
+        neuron layer `name` (the state_dict prefix of its Spiking_neuron); `layout` says how the copy maps onto the reference's
+        tensor at that call: "flat" = same memory order (reshape), "BDHWC->TBCHW" / "BDHWC->TBHWC" = permute."""
+        if self.tape is not None:
+            self.tape.append((name, spikes.clone(), layout))
 
     def _neuron_bd(self, x, p, bn=None, out_dtype=torch.uint8):
         """Neuron over D of a channel-last (B,D,h,w,C) activation, BN fused when given."""
@@ -250,11 +262,13 @@ class MSFlowEngine:
         B, D, h, w, _ = m.shape
         if s1 is None:
             s1 = self._neuron_bd(m, rb.sn1)
+        self._rec(rb.name + "sn1.spiking_neuron.", s1, "BDHWC->TBCHW")
         fus = self._fusable(B, D, h, w, rb.C)
         if fus:
             s2 = self._conv3x3(s1, rb.w1, rb.C, bn=rb.bn1, sn=rb.sn2)
         else:       # few rows (U-Net bottleneck): the fp32 epilogue can split K over the chip; neuron as its own launch
             s2 = self._neuron_bd(self._conv3x3(s1, rb.w1, rb.C), rb.sn2, bn=rb.bn1)
+        self._rec(rb.name + "sn2.spiking_neuron.", s2, "BDHWC->TBCHW")
         if next_sn is not None and fus:
             return self._conv3x3(s2, rb.w2, rb.C, bn=rb.bn2, resid=m, sn=next_sn, membrane=True)
         m2 = self._conv3x3(s2, rb.w2, rb.C, bn=rb.bn2, resid=m)
@@ -278,6 +292,7 @@ class MSFlowEngine:
         else:
             y = F.conv2d(xr.permute(0, 3, 1, 2), self.head_w, None, 1, 1).contiguous(memory_format=torch.channels_last)
             s = self._neuron_bd(y.permute(0, 2, 3, 1).view(B, T, H, W, -1), self.head_sn, bn=self.head_bn)
+        self._rec(self.pe_name + "head.sn.spiking_neuron.", s, "BDHWC->TBCHW")
         # every membrane of the patch embedding leaves its convolution together with the spikes of the neuron that reads it
         sns = [rb.sn1 for rb in self.pe_res] + [self.proj_sn]
         C0 = self.conv_w.shape[1]
@@ -291,6 +306,7 @@ class MSFlowEngine:
             m, s1 = self._resblock(m, rb, s1=s1, next_sn=sns[i + 1])
         # PED projection: 1x1 stride-2 shortcut on the (real-valued) membrane + SN -> conv3x3 s2 -> BN, summed in the epilogue
         Bm, Dm, h, w, Cc = m.shape
+        self._rec(self.pe_name + "proj.sn.spiking_neuron.", s1, "BDHWC->TBCHW")
         res = F.conv2d(m.view(B * T, h, w, Cc).permute(0, 3, 1, 2), self.proj_res_w, None, 2)
         res = res.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
         return self._conv3x3(s1, self.proj_w, self.proj_w.shape[1], stride=2, bn=self.proj_bn, resid=res)
@@ -304,15 +320,37 @@ class MSFlowEngine:
         Tq, N1 = ws[0], ws[1] * ws[2]
         # one C-ABI call: neuron over the gathered slices -> q|k spike GEMM (+BN, +PE, neurons fused) -> token gate ->
         # projection spike GEMM through the head scramble with bias + BN + scatter + residual (csrc/qk_attn.hip)
+        keep = None
+        if self.tape is not None:
+            # the slice spikes are overwritten by the gate inside the call: the tape runs the same kernel on the same input first
+            rows, keep = B_ * N1, []
+            xs = torch.empty((Tq, rows, Cc), dtype=torch.uint8, device=x.device)
+            hip.neuron_fwd(x, xs, Tq, 1, rows * Cc, 0, 0, 0, rows * Cc, blk.sn_proj, rowmap=rowmap, rowlen=Cc)
+            self._rec(blk.name + "attn.proj_sn.spiking_neuron.", xs, "flat")
         if blk.qk is not None:
-            return hip.qk_attn(x, rowmap, B_, Tq, N1, blk.nH, blk.p, blk.sn_proj, blk.sn_q, blk.sn_k, blk.sn2_q, qk=blk.qk)
-        return hip.qk_attn(x, rowmap, B_, Tq, N1, blk.nH, blk.p, blk.sn_proj, blk.sn_q, blk.sn_k, blk.sn2_q,
-                           q_lin=blk.q, k_lin=blk.k, pe=blk.pe)
+            hip.qk_attn(x, rowmap, B_, Tq, N1, blk.nH, blk.p, blk.sn_proj, blk.sn_q, blk.sn_k, blk.sn2_q, qk=blk.qk, keep_ws=keep)
+        else:
+            hip.qk_attn(x, rowmap, B_, Tq, N1, blk.nH, blk.p, blk.sn_proj, blk.sn_q, blk.sn_k, blk.sn2_q,
+                        q_lin=blk.q, k_lin=blk.k, pe=blk.pe, keep_ws=keep)
+        if keep:
+            M = Tq * B_ * N1
+            qk = keep[0][(M * Cc + 255) // 256 * 256:][:M * 2 * Cc]
+            q, k = (qk.view(M, 2 * Cc)[:, :Cc], qk.view(M, 2 * Cc)[:, Cc:]) if blk.qk is not None else (qk[:M * Cc], qk[M * Cc:])
+            self._rec(blk.name + "attn.sn_q.spiking_neuron.", q.reshape(Tq, B_ * N1, Cc), "flat")
+            self._rec(blk.name + "attn.sn_k.spiking_neuron.", k.reshape(Tq, B_ * N1, Cc), "flat")
+        return x
 
     def mlp(self, x, blk: _Block):
         """x (B,D,H,W,C) += MLP(x) over the true time axis D, in place (reference :164-181, :845)."""
         self._check_cl(x)
-        return hip.ms_mlp(x, blk.fc1, blk.fc2, blk.sn1, blk.sn2)      # one C-ABI call (csrc/qk_attn.hip: sdf_ms_mlp_fwd)
+        keep = [] if self.tape is not None else None
+        hip.ms_mlp(x, blk.fc1, blk.fc2, blk.sn1, blk.sn2, keep_ws=keep)      # one C-ABI call (csrc/qk_attn.hip: sdf_ms_mlp_fwd)
+        if keep:
+            B, D, H, W, Cc = x.shape
+            tok = B * D * H * W
+            self._rec(blk.name + "mlp.sn1.spiking_neuron.", keep[0][:tok * Cc].view(B, D, H, W, Cc), "BDHWC->TBHWC")
+            self._rec(blk.name + "mlp.sn2.spiking_neuron.", keep[0][(tok * Cc + 255) // 256 * 256:][:tok * blk.fc1.N].view(B, D, H, W, -1), "BDHWC->TBHWC")
+        return x
 
     def swin_block(self, x, s, i):
         blk = self.stages[s][i]
@@ -327,6 +365,7 @@ class MSFlowEngine:
         rows = B * H2 * W2
         sp = torch.empty((D * rows, 4 * Cc), dtype=torch.uint8, device=x.device)
         hip.neuron_fwd(x, sp, D, 1, rows * 4 * Cc, 0, 0, 0, rows * 4 * Cc, sn, rowmap=rowmap, rowlen=Cc)
+        self._rec(f"sttmultires_unet.encoders.swin3d.layers.{s}.downsample.sn.spiking_neuron.", sp.view(D, B, H2, W2, 4 * Cc), "flat")
         out = torch.empty((B, D, H2, W2, lin.N), dtype=torch.float32, device=x.device)
         hip.spike_gemm(sp, lin.Wp, out, D * rows, lin.N, 4 * Cc, alpha=lin.alpha, beta=lin.beta, out_rowmap=out_map)
         return out
@@ -396,6 +435,10 @@ class MSFlowEngine:
                         hip.neuron_fwd(src[b], s[b].view(-1)[c0:], D, hw, take, pitch, hw * pitch, cp, hw * cp, sn)
                     c0 += take
                 wkey = "perm"
+                if self.tape is not None:             # the reference's channel order is [prediction | y | skip]
+                    npred = self.preds[i - 1][3] if i > 0 else 0
+                    self._rec(f"sttmultires_unet.decoders.{i}.sn.spiking_neuron.",
+                              torch.cat([s[..., C1 + C2:C1 + C2 + npred], s[..., :C1 + C2]], -1), "BDHWC->TBCHW")
             else:
                 parts = ([preds[-1][..., :self.preds[i - 1][3]]] if i > 0 else []) + [y, skip]
                 parts = [F.pad(p, (0, 0, (w - p.shape[3]) // 2, w - p.shape[3] - (w - p.shape[3]) // 2,
@@ -409,6 +452,7 @@ class MSFlowEngine:
                     torch.cat(parts, dim=-1, out=cat[..., :cin])
                 s = self._neuron_bd(cat, sn)                              # MS decoder: SN -> ConvT -> BN
                 wkey = "ref"
+                self._rec(f"sttmultires_unet.decoders.{i}.sn.spiking_neuron.", s[..., :cin], "BDHWC->TBCHW")
             wuse = self._decoder_weight(i, wkey, y.shape[-1], skip.shape[-1])
             z = torch.empty((B, D, 2 * h, 2 * w, cout), dtype=torch.float32, device=y.device)
             if as_gemm:
@@ -431,6 +475,7 @@ class MSFlowEngine:
                                      out_rowmap=cls["rowmap"][:n * h * w])
             pw, pb, psn, nout = self.preds[i]
             sp = self._neuron_bd(z, psn)                                  # MS pred: SN -> conv1x1 (+bias), 2 outputs
+            self._rec(f"sttmultires_unet.preds.{i}.sn.spiking_neuron.", sp, "BDHWC->TBCHW")
             po = torch.empty((B * D * 4 * h * w, 32), dtype=torch.float32, device=y.device)
             hip.spike_gemm(sp, pw, po, po.shape[0], 32, cout, bias=pb)
             preds.append(po.view(B, D, 2 * h, 2 * w, 32))                 # columns nout.. are exactly zero (zero weight rows, zero bias)

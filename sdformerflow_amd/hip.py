@@ -380,7 +380,7 @@ def window_slice_map(B, D, H, W, ws, ss, device):
     return m, B_
 
 
-def qk_attn(x, slice_map, B_, Tq, N1, nH, p_lin, sn_proj, sn_q, sn_k, sn2_q, qk=None, q_lin=None, k_lin=None, pe=None):
+def qk_attn(x, slice_map, B_, Tq, N1, nH, p_lin, sn_proj, sn_q, sn_k, sn2_q, qk=None, q_lin=None, k_lin=None, pe=None, keep_ws=None):
     """sdf_qk_attn_fwd: x (B,D,H,W,C) fp32 channel-last += SSA(x), in place.  `qk` = {"Wp", "alpha", "beta", "add"} for the
     stacked projection, or q_lin / k_lin (objects with Wp / alpha / beta) + pe for separate ones; p_lin has Wp / bias / alpha / beta."""
     Cc = x.shape[-1]
@@ -405,6 +405,8 @@ def qk_attn(x, slice_map, B_, Tq, N1, nH, p_lin, sn_proj, sn_q, sn_k, sn2_q, qk=
     gws = workspace(x.device)
     d.gemm_workspace, d.gemm_workspace_bytes = gws.data_ptr(), gws.numel()
     _check(lib().sdf_qk_attn_fwd(C.byref(d), _stream()), "sdf_qk_attn_fwd")
+    if keep_ws is not None:
+        keep_ws.append(ws)                  # the call's intermediates (u8 spikes, layout: sdf_qk_attn_workspace_bytes) for the parity tape
     return x
 
 
@@ -418,7 +420,7 @@ class MsMlpDesc(C.Structure):
                 ("gemm_workspace", C.c_void_p), ("gemm_workspace_bytes", C.c_int64)]
 
 
-def ms_mlp(x, fc1, fc2, sn1, sn2):
+def ms_mlp(x, fc1, fc2, sn1, sn2, keep_ws=None):
     """sdf_ms_mlp_fwd: x (B,D,H,W,C) fp32 channel-last += MLP(x) over the time axis D, in place."""
     B, D, H, W, Cc = x.shape
     d = MsMlpDesc()
@@ -433,6 +435,8 @@ def ms_mlp(x, fc1, fc2, sn1, sn2):
     gws = workspace(x.device)
     d.gemm_workspace, d.gemm_workspace_bytes = gws.data_ptr(), gws.numel()
     _check(lib().sdf_ms_mlp_fwd(C.byref(d), _stream()), "sdf_ms_mlp_fwd")
+    if keep_ws is not None:
+        keep_ws.append(ws)
     return x
 
 

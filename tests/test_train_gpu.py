@@ -80,11 +80,14 @@ def test_train_mode_patch_merging_matches_reference_autograd():
     assert rate(pm.reduction.weight.grad, TB["merge_g/reduction.weight"]) <= 1e-3
 
 
-def small_model():
-    cfg = yaml.safe_load(open(CFG))
+def small_kwargs(cfg):
     cfg["model"]["spiking_neuron"] = dict(cfg["spiking_neuron"], neuron_type="lif")
     cfg["swin_transformer"].update(input_size=[144, 144], swin_depths=[2, 2, 6], swin_num_heads=[3, 6, 12], swin_out_indices=[0, 1, 2])
-    model = load_synth(MS_SpikingformerFlowNet(cfg["model"].copy(), cfg["swin_transformer"].copy()))
+    return cfg["model"].copy(), cfg["swin_transformer"].copy()
+
+
+def small_model():
+    model = load_synth(MS_SpikingformerFlowNet(*small_kwargs(yaml.safe_load(open(CFG)))))
     for m in model.modules():
         if hasattr(m, "drop_path_rate"):
             m.drop_path_rate = 0.0                                     # the fixture was made with DropPath = identity
@@ -159,3 +162,36 @@ def test_optional_spike_gemm_forward_of_linear_layers(planes):
     assert (ys - ref[0]).abs().max().item() <= 2e-6 * ref[0].abs().max().item()
     for got, r in ((xs.grad, ref[1]), (lin.weight.grad, ref[2]), (lin.bias.grad, ref[3])):
         assert (got - r).abs().max().item() <= 1e-5 * r.abs().max().item()
+
+
+def test_eval_after_training_uses_the_trained_weights_not_a_stale_engine():
+    """eval -> train_step -> eval (the normal train / validate loop): the packed inference engine caches split weight planes,
+    folded BN (alpha, beta) and PSN matrices; after a training step it must be rebuilt.  The second eval has to differ from
+    the first and equal what a freshly built model with the same state_dict gives."""
+    model, chunk, label, mask = small_model()
+    model.eval()
+    with torch.no_grad():
+        before = [f.clone() for f in model(chunk)["flow"]]
+    e0 = model.engine()
+    assert model.engine() is e0                                              # unchanged weights: the plan is reused
+    buckets = train.GradientBuckets(model.parameters())
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+    for _ in range(2):
+        train.train_step(model, opt, chunk, label, mask, buckets=buckets)
+    model.eval()
+    with torch.no_grad():
+        after = [f.clone() for f in model(chunk)["flow"]]
+    assert model.engine() is not e0
+    assert not any(torch.equal(a, b) for a, b in zip(before, after)), "validation ran on the pre-training weights"
+    cfg = yaml.safe_load(open(CFG))
+    fresh = type(model)(*small_kwargs(cfg))
+    fresh.load_state_dict(model.state_dict(), strict=True)
+    fresh = fresh.to(DEV).eval()
+    with torch.no_grad():
+        want = fresh(chunk)["flow"]
+    assert all(torch.equal(a, b) for a, b in zip(after, want))
+    # an in-place edit without train(): seen through the version stamp
+    with torch.no_grad():
+        model.sttmultires_unet.preds[2].conv[0].bias.add_(1.0)
+        moved = model(chunk)["flow"]
+    assert not torch.equal(moved[-1], after[-1])
