@@ -3,9 +3,9 @@
 
 The random-weight spiking net is chaotic (one flipped spike decorrelates everything downstream, shown
 CPU-vs-CPU in DESIGN.md), so parity is *teacher-forced*: every stage of the HIP engine is fed the
-oracle's input for that stage and must reproduce the oracle's output of that stage.  A stage output
-element counts as a mismatch when it differs by more than 1e-4 of the stage's mean magnitude (i.e. a
-spike flipped upstream inside the stage); everything else must agree to fp32 rounding.
+oracle's input for that stage, and inside the stage every neuron layer is checked by the spike-forced
+replay of tests/replay.py (0 decisions that the reference's own threshold margin does not explain; fp32
+outputs to 2e-5).  tests/test_replay_gpu.py makes the same statement for the free-running forward.
 """
 import os
 
@@ -63,52 +63,61 @@ def unet_tail_oracle(blocks, sd, n):
     return preds
 
 
-def compare(name, got, ref, report, max_rate):
-    got, ref = got.float().cpu(), ref.float()
-    scale = ref.abs().mean().item() + 1e-12
-    d = (got - ref).abs()
-    bad = d > 1e-4 * scale
-    rate = bad.float().mean().item()
-    close = d[~bad].max().item() / scale if (~bad).any() else 0.0
-    report.append((name, rate, close))
-    assert rate <= max_rate, (name, rate)
+def stage_replay(name, eng, gpu_call, oracle_call, report, tol=2e-5):
+    """One stage, teacher-forced on the oracle's input, checked layer by layer (tests/replay.py): every neuron layer inside
+    the stage is delta-consistent with the reference on the GPU's own upstream spikes - 0 unexplained decisions - and the
+    stage's fp32 output equals the replayed reference to `tol` of its largest magnitude.  (Round 1 bounded the RATE of
+    elements touched by a flip here: 2e-2 for the patch embedding, 1e-1 for the U-Net predictions.)"""
+    import replay
+    got, ref, rep = replay.run_part(eng, gpu_call, oracle_call)
+    summ = replay.summarise(rep)
+    got = got if isinstance(got, (list, tuple)) else [got]
+    ref = ref if isinstance(ref, (list, tuple)) else [ref]
+    dev = max(float((g.float().cpu() - r).abs().max() / r.abs().max()) for g, r in zip(got, ref))
+    report.append((name, summ, dev))
+    assert summ["unexplained"] == 0, (name, summ, [r for r in rep if r["forced"] and r["unexplained"]][:3])
+    assert dev <= tol, (name, dev)
+    return ref
+
+
+def teacher_forced_all(tag, eng, sd, ocfg, chunk, tail=True, stages=None):
+    """Every stage of the engine on the oracle's input for that stage, each checked layer by layer (stage_replay)."""
+    n, ws = ocfg["neuron"], tuple(ocfg["window_size"])
+    shift = tuple(w // 2 for w in ws)
+    p = "sttmultires_unet.encoders.swin3d."
+    report = []
+    # patch embedding: 7 convolutions + 6 neuron layers, every layer checked
+    ref = stage_replay("patch_embed", eng, lambda: eng.patch_embed(chunk.to(DEV)).permute(1, 0, 4, 2, 3),
+                       lambda: O.patch_embed(chunk, sd, p + "patch_embed.", n, ocfg["num_bins"]), report)[0]
+    y = ref.permute(1, 0, 3, 4, 2).contiguous()
+    feats, E = [], len(ocfg["depths"])
+    for s, (depth, nH) in enumerate(zip(ocfg["depths"], ocfg["num_heads"])):
+        if stages is not None and s >= stages:
+            break
+        for i in range(depth):
+            y = stage_replay(f"stage{s}.block{i}", eng, lambda: eng.swin_block(y.contiguous().to(DEV), s, i),
+                             lambda: O.ms_block(y, sd, p + f"layers.{s}.swin_blocks.{i}.", nH, ws, (0, 0, 0) if i % 2 == 0 else shift, n),
+                             report)[0]
+        feats.append(y.contiguous())
+        if s < E - 1:
+            y = stage_replay(f"stage{s}.merge", eng, lambda: eng.patch_merge(y.contiguous().to(DEV), s),
+                             lambda: O.ms_patch_merge(y, sd, p + f"layers.{s}.downsample.", n), report)[0]
+    if tail and stages is None:
+        # U-Net tail on the oracle's encoder features; compared on its per-scale predictions
+        O_feats = [f.permute(1, 0, 4, 2, 3).contiguous() for f in feats]
+        stage_replay("unet_tail", eng, lambda: [pp.permute(1, 0, 4, 2, 3) for pp in eng.unet_tail([f.contiguous().to(DEV) for f in feats])],
+                     lambda: unet_tail_oracle(O_feats, sd, n), report)
+    for name, summ, dev in report:
+        print(f"{tag:5s} {name:16s} layers {summ['layers_forced']:2d} flips {summ['flips']:4d} ambiguous {summ['ambiguous']:6d} of "
+              f"{summ['decisions']:10d} unexplained {summ['unexplained']} needed {summ['needed_ulps_max']:.1f} ulps; output max-dev {dev:.1e}")
+    return report
 
 
 @pytest.mark.parametrize("kind", ["lif", "psn"])
 def test_teacher_forced_stage_parity(kind):
     model, sd, ocfg = build(kind)
-    n = ocfg["neuron"]
     chunk = O.prepare_chunk(synth_voxel(1, 10, 288, 384, seed=1235))
-    p = "sttmultires_unet.encoders.swin3d."
-    eng = model.to(DEV).engine()
-    report = []
-    with torch.no_grad():
-        # patch embedding
-        ref = O.patch_embed(chunk, sd, p + "patch_embed.", n, 10)
-        compare("patch_embed", eng.patch_embed(chunk.to(DEV)), ref.permute(1, 0, 3, 4, 2), report, 2e-2)   # 7 convs + 6 neuron layers deep: flips compound inside the stage
-        y = ref.permute(1, 0, 3, 4, 2).contiguous()
-        ws, shift = (2, 9, 9), (1, 4, 4)
-        feats = []
-        for s, (depth, nH) in enumerate(zip(ocfg["depths"], ocfg["num_heads"])):
-            for i in range(depth):
-                ref = O.ms_block(y, sd, p + f"layers.{s}.swin_blocks.{i}.", nH, ws, (0, 0, 0) if i % 2 == 0 else shift, n)
-                got = eng.swin_block(y.contiguous().to(DEV), s, i)
-                compare(f"stage{s}.block{i}", got, ref, report, 1e-2)
-                y = ref
-            feats.append(y.contiguous())
-            if s < 3:
-                ref = O.ms_patch_merge(y, sd, p + f"layers.{s}.downsample.", n)
-                compare(f"stage{s}.merge", eng.patch_merge(y.contiguous().to(DEV), s), ref, report, 1e-3)
-                y = ref
-        # U-Net tail, teacher-forced on the oracle's encoder features; compared on its per-scale flow sums
-        preds = eng.unet_tail([f.contiguous().to(DEV) for f in feats])
-        O_feats = [f.permute(1, 0, 4, 2, 3).contiguous() for f in feats]
-        ref_preds = unet_tail_oracle(O_feats, sd, n)
-        for i, (gp, rp) in enumerate(zip(preds, ref_preds)):
-            compare(f"unet.pred{i}", gp.permute(1, 0, 4, 2, 3), rp, report, 1e-1)   # tiny maps: one flipped 768-ch spike touches a 6x6 patch (all T with PSN)
-    for name, rate, close in report:
-        print(f"{kind:4s} {name:16s} mismatch-rate {rate:.2e}  max-rel-dev-of-rest {close:.1e}")
-    assert all(torch.isfinite(pp).all() for pp in preds)
+    teacher_forced_all(kind, model.to(DEV).engine(), sd, ocfg, chunk)
 
 
 @pytest.mark.parametrize("kind", ["lif", "psn"])
@@ -130,7 +139,10 @@ def test_free_running_forward_statistics(kind):
         print(f"{kind} flow{i}: mean|ref| {r.abs().mean():.3f} mean|got| {g.abs().mean():.3f} mean-abs-dev/mean|ref| {rel:.3e}")
         assert abs(g.abs().mean().item() - r.abs().mean().item()) < 0.15 * r.abs().mean().item()
     print(f"{kind} AEE oracle {aee_ref:.5f} hip {aee_got:.5f} rel {abs(aee_got - aee_ref) / aee_ref:.2e}")
-    assert abs(aee_got - aee_ref) < 2e-3 * aee_ref     # north star: AEE within 1e-3 (measured 1.4e-4 .. 3.9e-4)
+    # a STATISTIC of two decorrelated flows against a random label (the label noise dominates it): kept as a sanity band only.
+    # The north star's "AEE within 1e-3 of reference" is asserted where it can be exact: tests/test_replay_gpu.py, on the same
+    # free-running forward, against the reference replayed on the GPU's own spikes
+    assert abs(aee_got - aee_ref) < 2e-3 * aee_ref
 
 
 def test_cpu_input_is_refused():
@@ -185,36 +197,13 @@ def test_batch2_three_encoder_model_teacher_forced():
     MS_SpikingformerFlowNet at 144x192: every stage must reproduce the oracle *at that batch size*."""
     from sdformerflow_amd.STSwinNet_SNN.Spiking_STSwinNet import MS_SpikingformerFlowNet
     model, sd, ocfg = build("lif", 144, 192, MS_SpikingformerFlowNet)
-    n = ocfg["neuron"]
     chunk = O.prepare_chunk(synth_voxel(2, 10, 144, 192, seed=77))
-    p = "sttmultires_unet.encoders.swin3d."
-    eng = model.to(DEV).engine()
-    report = []
+    teacher_forced_all("B=2", model.to(DEV).engine(), sd, ocfg, chunk)
     with torch.no_grad():
-        ref = O.patch_embed(chunk, sd, p + "patch_embed.", n, 10)
-        compare("patch_embed", eng.patch_embed(chunk.to(DEV)), ref.permute(1, 0, 3, 4, 2), report, 2e-2)
-        y = ref.permute(1, 0, 3, 4, 2).contiguous()
-        feats = []
-        for s_, (depth, nH) in enumerate(zip(ocfg["depths"], ocfg["num_heads"])):
-            for i in range(depth):
-                ref = O.ms_block(y, sd, p + f"layers.{s_}.swin_blocks.{i}.", nH, (2, 9, 9), (0, 0, 0) if i % 2 == 0 else (1, 4, 4), n)
-                compare(f"stage{s_}.block{i}", eng.swin_block(y.contiguous().to(DEV), s_, i), ref, report, 1e-2)
-                y = ref
-            feats.append(y.contiguous())
-            if s_ < 2:
-                ref = O.ms_patch_merge(y, sd, p + f"layers.{s_}.downsample.", n)
-                compare(f"stage{s_}.merge", eng.patch_merge(y.contiguous().to(DEV), s_), ref, report, 1e-3)
-                y = ref
-        preds = eng.unet_tail([f.contiguous().to(DEV) for f in feats])
-        ref_preds = unet_tail_oracle([f.permute(1, 0, 4, 2, 3).contiguous() for f in feats], sd, n)
-        for i, (gp, rp) in enumerate(zip(preds, ref_preds)):
-            compare(f"unet.pred{i}", gp.permute(1, 0, 4, 2, 3), rp, report, 1e-1)
         # and the two samples really are coupled: sample 0 of the batch differs from sample 0 run alone
         alone = O.forward_flownet(chunk[:1], sd, ocfg)[-1]
         both = O.forward_flownet(chunk, sd, ocfg)[-1][:1]
         assert (alone - both).abs().max() > 1e-3
-    for name, rate, close in report:
-        print(f"B=2 {name:16s} mismatch-rate {rate:.2e}  max-rel-dev-of-rest {close:.1e}")
     out = model(chunk.to(DEV))
     assert len(out["flow"]) == 3 and out["flow"][-1].shape == (2, 2, 144, 192)
 
@@ -222,23 +211,8 @@ def test_batch2_three_encoder_model_teacher_forced():
 def test_long_T20_stage_parity():
     """BASELINE configs[4] flavour: 20 bins / T = 20 (long LIF scan, T = 20 GEMM epilogue, unfused conv path)."""
     model, sd, ocfg = build("lif", 144, 192, T=20)
-    n = ocfg["neuron"]
     chunk = O.prepare_chunk(synth_voxel(1, 20, 144, 192, seed=78))
-    p = "sttmultires_unet.encoders.swin3d."
-    eng = model.to(DEV).engine()
-    report = []
-    with torch.no_grad():
-        ref = O.patch_embed(chunk, sd, p + "patch_embed.", n, 20)
-        compare("patch_embed", eng.patch_embed(chunk.to(DEV)), ref.permute(1, 0, 3, 4, 2), report, 2e-2)
-        y = ref.permute(1, 0, 3, 4, 2).contiguous()
-        for i in range(2):
-            r = O.ms_block(y, sd, p + f"layers.0.swin_blocks.{i}.", 3, (2, 9, 9), (0, 0, 0) if i % 2 == 0 else (1, 4, 4), n)
-            compare(f"stage0.block{i}", eng.swin_block(y.contiguous().to(DEV), 0, i), r, report, 1e-2)
-            y = r
-        r = O.ms_patch_merge(y, sd, p + "layers.0.downsample.", n)
-        compare("stage0.merge", eng.patch_merge(y.contiguous().to(DEV), 0), r, report, 1e-3)
-    for name, rate, close in report:
-        print(f"T=20 {name:16s} mismatch-rate {rate:.2e}  max-rel-dev-of-rest {close:.1e}")
+    teacher_forced_all("T=20", model.to(DEV).engine(), sd, ocfg, chunk, stages=1)
 
 
 def test_mdr_config_window8_T5_psn():
@@ -254,28 +228,12 @@ def test_mdr_config_window8_T5_psn():
     n = O.NeuronCfg("psn", cfg["spiking_neuron"]["v_th"], None, 2.0, 5)
     ocfg = {"neuron": n, "num_bins": 10, "window_size": (2, 8, 8), "depths": [2, 2, 6, 2], "num_heads": [3, 6, 12, 24]}
     chunk = O.prepare_chunk(synth_voxel(1, 10, 256, 256, seed=79))
-    p = "sttmultires_unet.encoders.swin3d."
-    eng = model.to(DEV).engine()
-    report = []
+    teacher_forced_all("MDR", model.to(DEV).engine(), sd, ocfg, chunk)
     with torch.no_grad():
-        ref = O.patch_embed(chunk, sd, p + "patch_embed.", n, 10)
-        compare("patch_embed", eng.patch_embed(chunk.to(DEV)), ref.permute(1, 0, 3, 4, 2), report, 2e-2)
-        y = ref.permute(1, 0, 3, 4, 2).contiguous()
-        for s_, (depth, nH) in enumerate(zip(ocfg["depths"], ocfg["num_heads"])):
-            for i in range(depth):
-                r = O.ms_block(y, sd, p + f"layers.{s_}.swin_blocks.{i}.", nH, (2, 8, 8), (0, 0, 0) if i % 2 == 0 else (1, 4, 4), n)
-                compare(f"stage{s_}.block{i}", eng.swin_block(y.contiguous().to(DEV), s_, i), r, report, 1e-2)
-                y = r
-            if s_ < 3:
-                r = O.ms_patch_merge(y, sd, p + f"layers.{s_}.downsample.", n)
-                compare(f"stage{s_}.merge", eng.patch_merge(y.contiguous().to(DEV), s_), r, report, 1e-3)
-                y = r
         refs = O.forward_flownet(chunk, sd, ocfg)
     out = model(chunk.to(DEV))["flow"]
     assert len(out) == 4 and all(torch.isfinite(f).all() for f in out)
     assert abs(out[-1].abs().mean().item() - refs[-1].abs().mean().item()) < 0.2 * refs[-1].abs().mean().item()
-    for name, rate, close in report:
-        print(f"MDR {name:16s} mismatch-rate {rate:.2e}  max-rel-dev-of-rest {close:.1e}")
 
 
 def test_forwards_in_flight_on_streams_and_graph_replay_are_bit_equal():
@@ -356,16 +314,8 @@ def test_large_window_15x15_T20():
     chunk = O.prepare_chunk(synth_voxel(1, 20, 120, 160, seed=81))
     p = "sttmultires_unet.encoders.swin3d."
     eng = model.engine()
-    report = []
-    with torch.no_grad():
-        ref = O.patch_embed(chunk, sd, p + "patch_embed.", n, 20)
-        y = ref.permute(1, 0, 3, 4, 2).contiguous()
-        for i in range(2):
-            r = O.ms_block(y, sd, p + f"layers.0.swin_blocks.{i}.", 3, (2, 15, 15), (0, 0, 0) if i % 2 == 0 else (1, 7, 7), n)
-            compare(f"stage0.block{i}", eng.swin_block(y.contiguous().to(DEV), 0, i), r, report, 1e-2)
-            y = r
-    for name, rate, close in report:
-        print(f"window15 {name:16s} mismatch-rate {rate:.2e}  max-rel-dev-of-rest {close:.1e}")
+    ocfg = {"neuron": n, "num_bins": 20, "window_size": (2, 15, 15), "depths": [2, 2, 6, 2], "num_heads": [3, 6, 12, 24]}
+    teacher_forced_all("win15", eng, sd, ocfg, chunk, stages=1)
     cfg["swin_transformer"].update(input_size=[480, 640])
     model2 = MS_SpikingformerFlowNet_en4(cfg["model"].copy(), cfg["swin_transformer"].copy())
     model2.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in model2.state_dict().items()}), strict=True)
@@ -390,11 +340,7 @@ def test_unet_tail_with_mismatched_feature_sizes_takes_the_concat_path():
     eng = model.to(DEV).engine()
     feats = [synth_uniform((1, 10, h, w, c), 50 + i, -0.4, 0.9) for i, (h, w, c) in enumerate(((19, 25, 96), (10, 13, 192), (5, 7, 384)))]
     report = []
-    with torch.no_grad():
-        preds = eng.unet_tail([f.contiguous().to(DEV) for f in feats])
-        ref = unet_tail_oracle([f.permute(1, 0, 4, 2, 3).contiguous() for f in feats], sd, n)
-    for i, (gp, rp) in enumerate(zip(preds, ref)):
-        assert gp.permute(1, 0, 4, 2, 3).shape == rp.shape
-        compare(f"unet.pred{i}", gp.permute(1, 0, 4, 2, 3), rp, report, 1e-1)
-    for name, rate, close in report:
-        print(f"odd sizes {name:12s} mismatch-rate {rate:.2e}  max-rel-dev-of-rest {close:.1e}")
+    O_feats = [f.permute(1, 0, 4, 2, 3).contiguous() for f in feats]
+    stage_replay("unet_tail(odd)", eng, lambda: [pp.permute(1, 0, 4, 2, 3) for pp in eng.unet_tail([f.contiguous().to(DEV) for f in feats])],
+                 lambda: unet_tail_oracle(O_feats, sd, n), report)
+    print("odd sizes", report[0][1], "output max-dev %.1e" % report[0][2])

@@ -54,7 +54,7 @@ def check(kind, B, size, seed, en4=True, planes=2, **kw):
         print(f"    {r['layer']:90s} flips {r['flips']:7d} ambiguous {r['ambiguous']:8d} of {r['n']:10d}  needed {r['needed_ulps']:.1f} ulps")
     assert summ["layers_free"] <= summ["layers_forced"] // 4, summ     # only the integer-input token gates (and dead attn_sn) run unforced
     assert summ["unexplained"] == 0, [r for r in report if r["forced"] and r["unexplained"]][:5]
-    assert summ["ambiguous"] <= 2e-3 * summ["decisions"], summ           # delta is tight: it covers a tiny part of the decisions
+    assert summ["ambiguous"] <= 2e-5 * summ["decisions"], summ           # delta is tight: it covers a tiny part of the decisions
     devs = []
     for g, r in zip(flows, ref):
         g = g.cpu()
@@ -91,8 +91,9 @@ def test_batch_of_two_three_encoders():
 
 
 def test_config5_shape_T20_odd_sizes():
-    """20 bins / T = 20, a size whose stage maps need padding and cropping (reduced from 480 x 640 so that the oracle finishes)."""
-    check("lif", 1, (240, 320), 91, T=20, bins=20)
+    """20 bins / T = 20, a width whose stage maps need padding and cropping (88 -> 90, 44 -> 45, 22 -> 27, 11 -> 18; reduced from
+    480 x 640 so that the oracle finishes in seconds; the smallest stage must still hold one 9 x 9 window, as in the reference)."""
+    check("lif", 1, (288, 352), 91, T=20, bins=20)
 
 
 def test_mdr_configuration_window8_T5_psn():
