@@ -34,9 +34,8 @@ PEAK_BF16_DENSE_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: ~2
 PEAK_HBM_GBPS = 8000.0              # same guide: 8.0 TB/s spec (6.3 TB/s achievable)
 # HBM bytes per launch of the roofline shape from the PMC counters.  They cannot be read inside this process (rocprofv3 owns the
 # counters), so the figure is the one measured by tools/pmc_traffic.sh on the build named in CONV_TRAFFIC_SOURCE
-CONV_TRAFFIC_BYTES = (2 * 75516.1 + 104192.0) * 1024
-CONV_TRAFFIC_SOURCE = ("NOT measured in this run: profiles/r1m_pmc_traffic_conv.txt (round-1 build r1m), rocprofv3 --pmc FETCH_SIZE "
-                       "(x2, gfx950) and WRITE_SIZE in separate passes on this exact launch; algorithmic bytes 239.2e6")
+CONV_TRAFFIC_BYTES = None
+CONV_TRAFFIC_SOURCE = "not measured yet for this build (tools/pmc_traffic.sh)"
 
 
 def build_model(kind, device):
@@ -78,42 +77,57 @@ L3_BYTES = 256 << 20                # Infinity Cache of the MI355X (MI355X_MICRO
 
 
 def time_dominant_kernels(model, iters=40):
-    """Live HIP-event timing of the dominant kernel of the forward - the ping-pong spike convolution on the patch-embedding
-    res-block shape (10 images of 144x192, 96 -> 96 channels, 3x3: 4 of the 26 convolution launches and ~0.8 ms of the step) -
-    and of the HBM-bound neuron update.  Each is timed twice: rotating through enough operand sets that consecutive launches
-    never find their operands in the 256 MiB Infinity Cache (> 2 x L3 between two uses of a set: the HBM figure, the one in
-    `achieved` / `frac`), and replaying one set (`l3_resident`, what round 1 reported)."""
+    """Live HIP-event timing of the dominant kernel of the forward - the 3x3 spike convolution of the patch embedding's
+    res-blocks (10 images of 144x192, 96 -> 96 channels) in the form the forward launches it: BN + identity stored as the fp32
+    membrane AND the next block's LIF over T=10 on it, one launch (MS_ResBlock conv2 + sn1; 2 of the forward's 5 big 3x3
+    launches, the other 3 differ only in the epilogue) - and of the HBM-bound neuron update.  Each is timed twice: rotating
+    through enough operand sets that consecutive launches never find their operands in the 256 MiB Infinity Cache (> 2 x L3
+    between two uses of a set: the HBM figure, the one in `achieved` / `frac`), and replaying one set (`l3_resident`, what
+    round 1 reported).  The plain fp32-epilogue launch of the same convolution (round 1's roofline shape) is reported beside it."""
     from sdformerflow_amd import hip
     eng = model.engine()
     dev = eng.device
     imgs, H, W, Cc = 10, 144, 192, 96
     rb = eng.pe_res[0]
-    set_bytes = imgs * H * W * Cc * (1 + 4 + 4)
-    nset = -(-3 * L3_BYTES // set_bytes)                          # 239 MB per set -> 4 sets = 956 MB in rotation
-    sets = [((torch.rand((imgs, H, W, Cc), device=dev) < 0.3).to(torch.uint8), torch.empty((imgs * H * W, Cc), device=dev),
-             torch.rand((imgs * H * W, Cc), device=dev)) for _ in range(nset)]
+    set_bytes = imgs * H * W * Cc * (1 + 4 + 4 + 1)
+    nset = -(-3 * L3_BYTES // set_bytes)                          # 265 MB per set -> 4 sets in rotation
+    sets = [((torch.rand((1, imgs, H, W, Cc), device=dev) < 0.3).to(torch.uint8), torch.rand((1, imgs, H, W, Cc), device=dev))
+            for _ in range(nset)]
+    sn = eng.pe_res[1].sn1
 
-    def conv(st):
-        hip.spike_conv2d(st[0], rb.w2, imgs, H, W, Cc, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=st[1], alpha=rb.bn2[0],
-                         beta=rb.bn2[1], resid=st[2])
-    t_conv = _timed(conv, sets, iters)
-    t_conv_l3 = _timed(conv, sets[:1], iters)
+    def conv_fused(st):
+        eng._conv3x3(st[0], rb.w2, Cc, bn=rb.bn2, resid=st[1], sn=sn, membrane=True)
+
+    def conv_f32(st):
+        eng._conv3x3(st[0], rb.w2, Cc, bn=rb.bn2, resid=st[1])
+    t_conv = _timed(conv_fused, sets, iters)
+    t_conv_l3 = _timed(conv_fused, sets[:1], iters)
+    t_f32 = _timed(conv_f32, sets, iters)
+    t_f32_l3 = _timed(conv_f32, sets[:1], iters)
     del sets
     flops = 2.0 * imgs * H * W * Cc * 9 * Cc                    # algorithmic: one multiply-add per (pixel, cout, tap, cin)
+    digits = getattr(rb.w2, "digits", None) is not None and sn.kind != "psn"
     ns = int(rb.w2.shape[0])
-    gemm = {"kernel": f"sdfmm::spike_mm_pp_kernel<{ns},0,true> (3x3 spike conv 96->96 @ 10x144x192, BN + residual epilogue)",
+    issued = 1.5 if digits else float(ns)                        # MFMA work per algorithmic flop on the 16-bit pipe's scale
+    kname = ("sdfmm::spike_conv_wres_i8_kernel<10,6,1> (weights resident in LDS as 3 int8 digit planes, halo tiles, LIF over T fused)"
+             if digits else f"sdfmm::spike_mm_pp_kernel<{ns},10,true> (streaming ping-pong kernel)")
+    gemm = {"kernel": kname + " - 3x3 spike conv 96->96 @ 10x144x192, BN + identity -> fp32 membrane + LIF(T=10) spikes",
             "bound": "mfma", "achieved": flops / t_conv / 1e12, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
             "us_per_launch": t_conv * 1e6, "operand_sets_in_rotation": nset, "rotation_bytes": nset * set_bytes,
             "l3_resident": {"us_per_launch": t_conv_l3 * 1e6, "achieved": flops / t_conv_l3 / 1e12,
                             "frac": flops / t_conv_l3 / 1e12 / PEAK_BF16_DENSE_TFLOPS},
-            "algorithmic_bytes": set_bytes + ns * Cc * 9 * Cc * 2,
-            "traffic": CONV_TRAFFIC_BYTES if ns == 2 else None,
-            "traffic_unit": "bytes per launch (HBM read + write)",
+            "fp32_epilogue_form": {"us_per_launch": t_f32 * 1e6, "achieved": flops / t_f32 / 1e12,
+                                   "frac": flops / t_f32 / 1e12 / PEAK_BF16_DENSE_TFLOPS, "l3_resident_us_per_launch": t_f32_l3 * 1e6,
+                                   "note": "the same convolution with the plain BN + residual fp32 epilogue (round 1's roofline shape)"},
+            "algorithmic_bytes": set_bytes + (3 if digits else 2 * ns) * Cc * 9 * Cc,
+            "traffic": CONV_TRAFFIC_BYTES, "traffic_unit": "bytes per launch (HBM read + write)",
             "traffic_source": CONV_TRAFFIC_SOURCE,
-            "note": f"algorithmic flops (2 per multiply-add of the convolution); the kernel issues {ns} 16-bit MFMAs per product "
-                    f"(fp32 weights carried as {ns} planes), i.e. {ns}x this on the matrix pipe; dense peak of the f16/bf16 MFMA"}
+            "note": "algorithmic flops (2 per multiply-add of the convolution) against the dense bf16/f16 MFMA peak.  The kernel issues "
+                    + ("3 int8 digit MFMAs (v_mfma_i32_32x32x32_i8, K = 32 in the cycles the 16-bit form needs for K = 16) per product: 1.5x "
+                       "the algorithmic work on the 16-bit pipe's scale" if digits else f"{ns} 16-bit MFMAs per product") +
+                    "; in-kernel clock under this load is 1.3-1.7 GHz, not the 2.4 GHz the peak assumes (profiles/r2_stamps_wres.txt)"}
     gemm["frac"] = gemm["achieved"] / gemm["peak"]
-    gemm["frac_of_issued_mfma"] = ns * gemm["frac"]
+    gemm["frac_of_issued_mfma"] = issued * gemm["frac"]
     # neuron: T=10 over the stage-0 MLP hidden tensor shape (10 x 72*96*384 fp32 in, u8 out)
     blk = eng.stages[0][0]
     n = 72 * 96 * 384

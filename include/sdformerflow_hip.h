@@ -216,7 +216,18 @@ typedef struct SdfSpikeGemmDesc {
   /* With out_rowmap: number of rows of out / resid (an upper bound of the scattered row indices + 1); 0 = unknown.
    * Lets the library pick kernels that address the output with 32-bit offsets. */
   int64_t out_rows;
+  /* nsplit == SDF_PLANES_I8X3 only (sdf_spike_conv2d_fwd, 3x3 / stride 1 / Cin 96 launches the weight-resident kernel takes):
+   * Wp is then int8_t[3][N][K] digit planes and col_scale[n] the power-of-two scale of output channel n, both made by
+   * sdf_split_weight_i8x3: w[n][k] = (d2*65536 + d1*256 + d0) * col_scale[n].  NULL otherwise. */
+  const float* col_scale;
 } SdfSpikeGemmDesc;
+
+#define SDF_PLANES_I8X3 4
+
+/* fp32 weights (N, K) -> three int8 digit planes [3][N][K] + per-row power-of-two scales: q = rint(w / s) with
+ * s = 2^(ceil(log2 max_k |w[n][k]|) - 22) (22 bits + sign against the row's largest weight), balanced base-256 digits.
+ * Spikes are int8 values already: the spike x weight dot product becomes three exact int32 MFMA sums. */
+int sdf_split_weight_i8x3(const float* W, int8_t* planes, float* col_scale, int N, int K, void* stream);
 
 int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream);
 

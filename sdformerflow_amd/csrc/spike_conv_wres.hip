@@ -1,0 +1,852 @@
+// Weight-resident 3x3 spike convolution for gfx950 (stride 1, pad 1, NHWC u8 spikes -> fp32 / spikes).
+//
+//   out[img, y, x, n] = epilogue( sum_{ky,kx,c} spike[img, y+ky-1, x+kx-1, c] * W[n, (ky*3+kx)*Cin + c] )
+//
+// The ping-pong kernel (spike_mm_pp.hip) streams BOTH operands through LDS for every 256 x 96 tile: 60 % of a stage's
+// bytes are weight planes that every tile re-fetches, and the im2col A operand is fetched 9 times.  Its producers, not
+// the matrix pipe, set the pace (profiles/r1m_stamps_conv.txt).  Here the roles are cut differently:
+//
+//   * a workgroup owns ONE 32-column block of the output for its whole life: that block's weights - every plane, the
+//     whole K = 9*Cin - are loaded into LDS once (2 planes x 32 x 864 fp16 = 110 KB) and stay there;
+//   * the activations of a tile of 8 x 16 output pixels enter LDS once as a 10 x 18 pixel HALO image (19 KB) instead
+//     of nine shifted copies: the nine taps are nine constant byte offsets into that image, folded into the
+//     immediate offsets of the fragment reads.  There is no im2col, no K ring, no producer role;
+//   * 8 wavefronts = 2 groups of 4.  A group owns one halo buffer and one tile at a time; each wave multiplies 32
+//     pixels x 32 columns x K (54 k-steps x planes of v_mfma_f32_32x32x16, fragments prefetched three k-steps ahead
+//     from LDS).  The groups run out of phase: one group's epilogue and halo refill overlap the other's MFMAs, and the
+//     two waves a SIMD hosts alternate on its matrix pipe;
+//   * the halo of step s+1 is requested from global memory BEFORE the MFMAs of step s and written to LDS after the
+//     epilogue of step s, so its latency is covered twice over.  Hand-over inside a group is two LDS counters
+//     (halo written / halo read), polled - no workgroup barrier in the steady state.
+//
+// Fused-neuron form (TT = T > 0): a work item is (column block, batch element, pixel tile) and the kernel walks the T
+// time steps of that tile in order, carrying the LIF / IF membrane of its 16 accumulator slots in registers; every
+// step's spikes (and optionally the fp32 membrane input = BN(conv) + residual) leave as soon as they exist.  No special
+// row order is needed for that - time is the loop, not a tile dimension.
+//
+// LDS layout is conflict-free by construction: pixel stride Cin + 8 bytes (an odd number of 8-byte units, so 32
+// consecutive pixels cover all 64 banks once for ds_read_b64), halo row pitch padded so that the second pixel row of a
+// wave continues that sequence; weight rows 2K + 16 bytes (4 x odd dwords: the 16 lanes of a ds_read_b128 group hit 16
+// distinct bank quads).
+// Compiled with -ffp-contract=off (the neuron arithmetic is the separately-rounded op sequence of neuron.hip).
+#include "spike_mm.h"
+
+#ifdef SDF_STAMP
+// diagnostic build only (tools/stamp_wres.sh): cycle accounting of wave 0 of each group of workgroup 0
+__device__ unsigned long long g_wres_stamp[32];
+#define STAMP(var) var = __builtin_readcyclecounter()
+#define STAMP_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(acc, a, b)
+#endif
+
+namespace sdfmm {
+namespace {
+
+constexpr int TH = 8, TW = 16;                  // output pixels of a tile: 4 waves x (2 rows x 16 pixels)
+constexpr int HH = TH + 2, HWID = TW + 2;       // halo image
+constexpr int NB = 32;                          // output columns of a workgroup
+constexpr uint32_t INV = 0x80000000u;
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)INV, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load16f(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+  const uint32_t x = v.x, y = v.y, z = v.z, w = v.w;
+  return make_float4(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z), __uint_as_float(w));
+}
+__device__ __forceinline__ void buf_store16f(__amdgpu_buffer_rsrc_t r, uint32_t off, float4 o) {
+  u32x4 v;
+  v.x = __float_as_uint(o.x); v.y = __float_as_uint(o.y); v.z = __float_as_uint(o.z); v.w = __float_as_uint(o.w);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+}
+__device__ __forceinline__ void wait_ge(uint32_t* p, uint32_t target) {
+  while (true) {
+    const uint32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if ((int32_t)(v - target) >= 0) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void signal(uint32_t* p, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// 8 spike bytes {0,1} -> 8 x 16-bit {0, 1.0}; the 24-bit multiply is a full-rate VALU op (the operands are 17 / 14 bits)
+template <int NSPLIT>
+__device__ __forceinline__ bf16x8 expand_spikes24(uint2 v) {
+  constexpr uint32_t ONE = NSPLIT == 2 ? 0x3C00u : 0x3F80u;
+  union { bf16x8 h; uint32_t u[4]; } r;
+  r.u[0] = __umul24(__builtin_amdgcn_perm(0u, v.x, 0x0c010c00u), ONE);
+  r.u[1] = __umul24(__builtin_amdgcn_perm(0u, v.x, 0x0c030c02u), ONE);
+  r.u[2] = __umul24(__builtin_amdgcn_perm(0u, v.y, 0x0c010c00u), ONE);
+  r.u[3] = __umul24(__builtin_amdgcn_perm(0u, v.y, 0x0c030c02u), ONE);
+  return r.h;
+}
+
+template <int CIN16>
+struct Geo {
+  static constexpr int CIN = 16 * CIN16;
+  static constexpr int K = 9 * CIN;
+  static constexpr int PS = CIN + 8;                                  // pixel stride in the halo image (bytes)
+  static constexpr int Q = PS / 8;                                    // odd
+  static constexpr int PAD = 8 * ((32 - (2 * Q) % 32) % 32);          // row pitch / 8 == 16 * Q (mod 32)
+  static constexpr int RPB = HWID * PS + PAD;                         // halo row pitch (bytes)
+  static constexpr int HALO = HH * RPB;
+  static constexpr int WP = 2 * K + 16;                               // weight row pitch (bytes): 4 x odd dwords
+  static constexpr int CHUNKS = HH * HWID * CIN16;                    // 16-byte pieces of a halo image
+  static constexpr int CPL = (CHUNKS + 255) / 256;                    // pieces per lane of a group
+  static_assert(Q % 2 == 1, "pixel stride must be an odd number of 8-byte units");
+  static_assert((WP / 4) % 8 == 4, "weight row pitch must be 4 x odd dwords");
+};
+
+template <int NSPLIT, int TT, int CIN16>
+__global__ __launch_bounds__(512) void spike_conv_wres_kernel(GemmParams P) {
+  using G = Geo<CIN16>;
+  constexpr bool SPIKE = TT > 0;
+  constexpr int T = SPIKE ? TT : 1;
+  constexpr int CIN = G::CIN, K = G::K, PS = G::PS, RPB = G::RPB, WP = G::WP;
+  constexpr int W_BYTES = NSPLIT * NB * WP;
+  constexpr int PAR = 3 * NB * 4;
+  static_assert(W_BYTES + 2 * G::HALO + PAR + 64 <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) uint8_t smem[W_BYTES + 2 * G::HALO + PAR + 64];
+  uint8_t* W_s = smem;
+  float* par_s = reinterpret_cast<float*>(smem + W_BYTES + 2 * G::HALO);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + W_BYTES + 2 * G::HALO + PAR);   // [g]: halo written, [2 + g]: halo read
+
+  const SdfSpikeGemmDesc& d = P.d;
+  const int H = P.cv.H, W = P.cv.W;                                   // == OH, OW (stride 1, pad 1)
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int grp = wave >> 2, cw = wave & 3;
+  const int gl = tid & 255;                                           // lane inside the group
+  const int N = d.N;
+  const float asc = P.acc_scale;
+  const bool soft = d.soft_reset != 0;
+  const bool has_res = d.resid != nullptr;
+  const bool memb = !SPIKE || d.out != nullptr;
+
+  // fused-neuron rows are (position, t) pairs, row(P, t) = (P / pos_inner) * pos_ostride + P % pos_inner + t * t_stride with
+  // every stride a whole number of images: batch element e = P / (H*W) starts at image (e / pm) * pso + e % pm, step t adds tstep
+  const int ohw = H * W;
+  const int pm = SPIKE ? (int)(d.pos_inner / ohw) : 1, pso = SPIKE ? (int)(d.pos_ostride / ohw) : 0;
+  const int tstep = SPIKE ? (int)(d.t_stride / ohw) : 0;
+
+  if (tid < 4) cnt[tid] = 0;
+
+  // work items: item = cb * tiles_m + rt, rt = (img or batch element) * tiles_img + tile; contiguous ranges per workgroup,
+  // workgroups dealt XCD-contiguously (neighbouring tiles share halo rows in one L2)
+  const int tiles_x = (W + TW - 1) / TW, tiles_img = tiles_x * ((H + TH - 1) / TH);
+  const int Gd = gridDim.x;
+  int wg = blockIdx.x;
+  if ((Gd & 7) == 0) wg = (wg & 7) * (Gd >> 3) + (wg >> 3);
+  const int nitems = P.ntiles;
+  const int base = nitems / Gd, rem = nitems % Gd;
+  const int t_begin = wg * base + (wg < rem ? wg : rem);
+  const int n_my = base + (wg < rem ? 1 : 0);
+
+  // this lane's pieces of a halo image: LDS offset, offset relative to the tile's origin pixel, and (dy, dx) for the bounds
+  uint32_t h_lds[G::CPL];
+  int h_rel[G::CPL], h_yx[G::CPL];
+#pragma unroll
+  for (int i = 0; i < G::CPL; ++i) {
+    const int c = gl + 256 * i;
+    const int cc = c < G::CHUNKS ? c : 0;
+    const int hy = cc / (HWID * CIN16), r = cc - hy * (HWID * CIN16);
+    const int px = r / CIN16, c16 = r - px * CIN16;
+    h_lds[i] = c < G::CHUNKS ? (uint32_t)(hy * RPB + px * PS + c16 * 16) : 0xFFFFFFFFu;
+    h_rel[i] = ((hy - 1) * W + (px - 1)) * CIN + c16 * 16;
+    h_yx[i] = ((hy - 1) << 16) | ((px - 1) & 0xFFFF);
+  }
+  const __amdgpu_buffer_rsrc_t A_rs = make_rsrc(d.A);
+  uint4 hreg[G::CPL];
+  auto halo_load = [&](int img, int y0, int x0) __attribute__((always_inline)) {
+    const uint32_t org = (uint32_t)(((img * H + y0) * W + x0) * CIN);
+#pragma unroll
+    for (int i = 0; i < G::CPL; ++i) {
+      const int yy = y0 + (h_yx[i] >> 16), xx = x0 + (int)(int16_t)(h_yx[i] & 0xFFFF);
+      const bool ok = h_lds[i] != 0xFFFFFFFFu && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(A_rs, ok ? org + (uint32_t)h_rel[i] : INV, 0, 0);
+      hreg[i] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+  };
+  uint8_t* H_s = smem + W_BYTES + grp * G::HALO;
+  auto halo_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < G::CPL; ++i) {
+      if (h_lds[i] != 0xFFFFFFFFu) {
+        uint2* p = reinterpret_cast<uint2*>(H_s + h_lds[i]);              // 8-byte aligned (pixel stride = 8 x odd)
+        p[0] = make_uint2(hreg[i].x, hreg[i].y);
+        p[1] = make_uint2(hreg[i].z, hreg[i].w);
+      }
+    }
+  };
+
+  // item -> (column block, image of step 0, tile origin)
+  auto item_decode = [&](int item, int& cb, int& img0, int& y0, int& x0) __attribute__((always_inline)) {
+    cb = item / P.tiles_m;
+    const int rt = item - cb * P.tiles_m;
+    const int im = rt / tiles_img, tl = rt - im * tiles_img;
+    const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
+    img0 = SPIKE ? (im / pm) * pso + im % pm : im; y0 = ty * TH; x0 = tx * TW;
+  };
+
+  // fragment addresses of this lane: 32 pixels of the wave (2 rows x 16) as MFMA rows, 32 weight rows as MFMA columns
+  int ln = lane;
+  asm volatile("" : "+v"(ln));
+  const int l31 = ln & 31, lh = ln >> 5;
+  const uint32_t a_lane = (uint32_t)((2 * cw + (l31 >> 4)) * RPB + (l31 & 15) * PS + 8 * lh);
+  const uint32_t w_lane = (uint32_t)(l31 * WP + 16 * lh);
+  const int qd = l31 >> 2, ql = l31 & 3;
+  const __amdgpu_buffer_rsrc_t out_rs = make_rsrc(d.out), res_rs = make_rsrc(d.resid), sp_rs = make_rsrc(d.out_spike);
+
+  uint32_t nstep = 0;                                                 // halo steps this group has been through
+  int seg_begin = 0;
+#ifdef SDF_STAMP
+  unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, a_issue = 0, a_wait = 0, a_mfma = 0, a_epi = 0, a_hand = 0, a_wload = 0;
+  const unsigned long long kstart = __builtin_readcyclecounter(), rstart = __builtin_amdgcn_s_memrealtime();
+#endif
+  while (seg_begin < n_my) {
+    // ---------------- a segment of items that share the column block: (re)load its weights ----------------
+    int cb, img0, y0, x0;
+    item_decode(t_begin + seg_begin, cb, img0, y0, x0);
+    int seg_end = (cb + 1) * P.tiles_m - t_begin;
+    if (seg_end > n_my) seg_end = n_my;
+    const int n0 = cb * NB;
+    STAMP(s0);
+    __syncthreads();                                                  // every wave is done with the previous block's weights
+    {
+      constexpr int KC8 = K / 8;                                       // 16-byte pieces per weight row
+      constexpr int WCH = NSPLIT * NB * KC8;
+      const __amdgpu_buffer_rsrc_t W_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(d.Wp), 0, NSPLIT * N * K * 2, 0x00020000);
+      // batches of 7 pieces per lane: all loads of a batch in flight before the first LDS write
+      constexpr int WB = 7, NBATCH = (WCH + 512 * WB - 1) / (512 * WB);
+#pragma unroll 1
+      for (int b = 0; b < NBATCH; ++b) {
+        u32x4 wv[WB];
+#pragma unroll
+        for (int i = 0; i < WB; ++i) {
+          const int c = tid + 512 * (b * WB + i);
+          const int cc = c < WCH ? c : 0;
+          const int row = cc / KC8, kc = cc - row * KC8;               // row = p * 32 + n
+          const int p = row / NB, n = row - p * NB;
+          wv[i] = __builtin_amdgcn_raw_buffer_load_b128(W_rs, c < WCH ? (uint32_t)(((p * N + n0 + n) * K + kc * 8) * 2) : INV, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WB; ++i) {
+          const int c = tid + 512 * (b * WB + i);
+          const int cc = c < WCH ? c : 0;
+          const int row = cc / KC8, kc = cc - row * KC8;
+          if (c < WCH) *reinterpret_cast<u32x4*>(W_s + row * WP + kc * 16) = wv[i];
+        }
+      }
+      if (tid < 3 * NB) {
+        const int which = tid / NB, n = tid - which * NB;
+        float v = which == 1 ? 1.f : 0.f;
+        if (which == 0 && d.bias) v = d.bias[n0 + n];
+        if (which == 1 && d.alpha) v = d.alpha[n0 + n];
+        if (which == 2 && d.alpha) v = d.beta[n0 + n];
+        par_s[tid] = v;
+      }
+    }
+    __syncthreads();
+    STAMP(s1); STAMP_ADD(a_wload, s0, s1);
+    const float4 bs4 = *reinterpret_cast<const float4*>(par_s + 4 * qd);
+    const float4 al4 = *reinterpret_cast<const float4*>(par_s + NB + 4 * qd);
+    const float4 be4 = *reinterpret_cast<const float4*>(par_s + 2 * NB + 4 * qd);
+
+    // ---------------- this group's items of the segment: seg_begin + grp, + 2, ... ----------------
+    int it = seg_begin + grp;
+    if (it < seg_end) {
+      item_decode(t_begin + it, cb, img0, y0, x0);
+      halo_load(img0, y0, x0);
+      if (nstep) wait_ge(&cnt[2 + grp], 4 * nstep);                   // previous halo fully read by the group
+      halo_store();
+      signal(&cnt[grp], lane);
+    }
+    for (; it < seg_end; it += 2) {
+      item_decode(t_begin + it, cb, img0, y0, x0);
+      float vmem[16];                                                 // LIF / IF membrane of the accumulator slots (transposed layout)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) vmem[e] = soft ? 0.f : d.v_reset;
+#pragma unroll 1
+      for (int t = 0; t < T; ++t) {
+        // request the NEXT step's halo now: its latency hides behind this step's MFMAs and epilogue
+        STAMP(s0);
+        bool have_next = true;
+        {
+          int ni = img0 + (t + 1) * tstep, ny = y0, nx = x0;
+          if (t + 1 == T) {
+            if (it + 2 < seg_end) { int ncb; item_decode(t_begin + it + 2, ncb, ni, ny, nx); }
+            else have_next = false;
+          }
+          if (have_next) halo_load(ni, ny, nx);
+        }
+        // rows of this step's epilogue, and its residual, requested before the MFMAs as well (in-order vmcnt: nothing the
+        // epilogue needs is younger than its own stores).  quad transpose: lane (qd, ql) ends with columns 4qd..4qd+3 of row
+        // rr = 8*q4 + 4*lh + ql of the wave's 32 pixels
+        const int img = img0 + t * tstep;
+        uint32_t rowoff[4];                                           // byte offset of (row, first column) in out / resid, or INV
+        uint32_t rowg[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int rr = 8 * q4 + 4 * lh + ql;
+          const int y = y0 + 2 * cw + (rr >> 4), x = x0 + (rr & 15);
+          const bool ok = y < H && x < W;
+          rowg[q4] = ok ? (uint32_t)((img * H + y) * W + x) : INV;
+          rowoff[q4] = ok ? rowg[q4] * (uint32_t)d.ldo * 4u + (uint32_t)(n0 + 4 * qd) * 4u : INV;
+        }
+        float4 rs[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) rs[q4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_res) {
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) rs[q4] = buf_load16f(res_rs, rowoff[q4]);
+        }
+        ++nstep;
+        STAMP(s1);
+        wait_ge(&cnt[grp], 4 * nstep);                                // this step's halo is in LDS (all four waves' pieces)
+        STAMP(s2);
+
+        // ------------------------------ MFMA phase: 54 k-steps x planes ------------------------------
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        constexpr int KS = 9 * CIN16;
+        constexpr int PF = 3;                                         // k-steps of fragments in flight
+        uint2 fa[PF + 1];
+        bf16x8 fb[PF + 1][NSPLIT];
+        auto frag = [&](int ks, int set) __attribute__((always_inline)) {
+          const int tap = ks / CIN16, c = ks - tap * CIN16;
+          const int ky = tap / 3, kx = tap - 3 * ky;
+          fa[set] = *reinterpret_cast<const uint2*>(H_s + a_lane + (ky * RPB + kx * PS + c * 16));
+#pragma unroll
+          for (int p = 0; p < NSPLIT; ++p)
+            fb[set][p] = *reinterpret_cast<const bf16x8*>(W_s + w_lane + (p * NB * WP + (tap * CIN + c * 16) * 2));
+        };
+#pragma unroll
+        for (int i = 0; i < PF; ++i) frag(i, i);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          if (ks + PF < KS) frag(ks + PF, (ks + PF) % (PF + 1));
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8 a = expand_spikes24<NSPLIT>(fa[ks % (PF + 1)]);
+#pragma unroll
+          for (int p = 0; p < NSPLIT; ++p) acc = mma<NSPLIT>(a, fb[ks % (PF + 1)][p], acc);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        signal(&cnt[2 + grp], lane);                                  // every fragment of this halo is in registers
+        STAMP(s3);
+
+        // ------------------------------ epilogue of this step ------------------------------
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          float v[4] = {acc[q4 * 4 + 0], acc[q4 * 4 + 1], acc[q4 * 4 + 2], acc[q4 * 4 + 3]};
+          quad_transpose(v, ql);
+          float4 o = make_float4(v[0] * asc, v[1] * asc, v[2] * asc, v[3] * asc);
+          if (!SPIKE) { o.x += bs4.x; o.y += bs4.y; o.z += bs4.z; o.w += bs4.w; }
+          o.x = __builtin_fmaf(o.x, al4.x, be4.x); o.y = __builtin_fmaf(o.y, al4.y, be4.y);
+          o.z = __builtin_fmaf(o.z, al4.z, be4.z); o.w = __builtin_fmaf(o.w, al4.w, be4.w);
+          o.x += rs[q4].x; o.y += rs[q4].y; o.z += rs[q4].z; o.w += rs[q4].w;
+          if (memb) buf_store16f(out_rs, rowoff[q4], o);
+          if (SPIKE) {
+            const float xs[4] = {o.x, o.y, o.z, o.w};
+            uint32_t pk = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float& vm = vmem[q4 * 4 + j];
+              float hcur;
+              if (d.sn_kind == SDF_IF) {
+                hcur = vm + xs[j];
+              } else {
+                const float dl = (soft || d.v_reset == 0.f) ? (xs[j] - vm) : (xs[j] - (vm - d.v_reset));
+                hcur = vm + ((P.inv_tau != 0.f) ? dl * P.inv_tau : dl / d.tau);
+              }
+              const float s = (hcur - d.v_th >= 0.f) ? 1.f : 0.f;
+              vm = soft ? (hcur - s * d.v_th) : ((1.f - s) * hcur + s * d.v_reset);
+              pk |= ((__float_as_uint(s) >> 29) & 1u) << (8 * j);     // 1.0f has bit 29 set
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(pk, sp_rs, rowg[q4] != INV ? rowg[q4] * (uint32_t)N + (uint32_t)(n0 + 4 * qd) : INV, 0, 0);
+          }
+        }
+        // ------------------------------ hand the next halo over ------------------------------
+        STAMP(s4);
+        if (have_next) {
+          wait_ge(&cnt[2 + grp], 4 * nstep);                          // all four waves have this step's fragments in registers
+          halo_store();
+          signal(&cnt[grp], lane);
+        }
+        STAMP(s5);
+        STAMP_ADD(a_issue, s0, s1); STAMP_ADD(a_wait, s1, s2); STAMP_ADD(a_mfma, s2, s3); STAMP_ADD(a_epi, s3, s4); STAMP_ADD(a_hand, s4, s5);
+      }
+    }
+    seg_begin = seg_end;
+  }
+#ifdef SDF_STAMP
+  if (blockIdx.x == 0 && (tid == 0 || tid == 256)) {
+    unsigned long long* o = g_wres_stamp + (tid ? 16 : 0);
+    o[0] = a_issue; o[1] = a_wait; o[2] = a_mfma; o[3] = a_epi; o[4] = a_hand; o[5] = a_wload; o[6] = nstep;
+    o[7] = __builtin_readcyclecounter() - kstart; o[8] = __builtin_amdgcn_s_memrealtime() - rstart;
+  }
+#endif
+}
+
+// =========================================================================================================
+// int8 digit form (nsplit == SDF_PLANES_I8X3): the weight of output channel n is the fixed-point number
+//   w = (d2 * 65536 + d1 * 256 + d0) * col_scale[n],  d0, d1 in [-128, 127], |d2| <= 64, col_scale[n] a power of two
+// (sdf_split_weight_i8x3: 22 bits + sign against the channel's largest weight).  Spike bytes {0, 1} ARE int8 values, so
+// the fragment a lane reads from the halo image is the MFMA operand as it stands - no expansion to 16-bit floats, no VALU
+// work in the main loop - and v_mfma_i32_32x32x32_i8 covers K = 32 in the cycles the fp16 form needs for K = 16: three
+// digit MFMAs per 32 channels instead of four plane MFMAs.  The three int32 dot products are exact (order-independent,
+// bit-reproducible); they meet in fp32 as fma(acc2, 65536, fma(acc1, 256, acc0)) * col_scale.
+// Tiles are 16 x 16 pixels here (the digit planes leave room for two 37 KB halo images): a wave owns 64 pixels = two MFMA
+// row blocks that share every weight fragment.
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(16))) int i32x16;
+
+template <int CIN16, int RB>
+struct GeoI8 {
+  static constexpr int TH8 = 8 * RB, TW8 = 16, HH8 = TH8 + 2, HW8 = 18;   // RB row blocks of 32 pixels per wave
+  static constexpr int CIN = 16 * CIN16;
+  static constexpr int K = 9 * CIN;
+  static constexpr int PS = CIN + 16;                                 // pixel stride: 4 x odd dwords (16-byte fragment reads)
+  static constexpr int RPB = (HW8 * PS + 255) / 256 * 256;            // halo row pitch: a whole number of bank rounds
+  static constexpr int HALO = HH8 * RPB;
+  static constexpr int WP = K + 16;                                   // digit-plane row pitch (bytes): 4 x odd dwords
+  static constexpr int RCH = HW8 * CIN16;                             // 16-byte pieces of a halo row (108): one per lane of a half group
+  static constexpr int CPL = (HH8 + 1) / 2;                           // pieces per lane: two halo rows per pass of the group's 256 lanes
+  static_assert(RCH <= 128, "a halo row must fit the 128 lanes of a half group");
+  static_assert((PS / 4) % 8 == 4 && (WP / 4) % 8 == 4, "pitches must be 4 x odd dwords");
+  static_assert(CIN % 32 == 0, "K steps of 32 must not straddle taps");
+};
+
+template <int TT, int CIN16, int RB>
+__global__ __launch_bounds__(512) void spike_conv_wres_i8_kernel(GemmParams P, const float* __restrict__ col_scale) {
+  using G = GeoI8<CIN16, RB>;
+  constexpr bool SPIKE = TT > 0;
+  constexpr int T = SPIKE ? TT : 1;
+  constexpr int CIN = G::CIN, K = G::K, PS = G::PS, RPB = G::RPB, WP = G::WP, TH8 = G::TH8, TW8 = G::TW8;
+  constexpr int W_BYTES = 3 * NB * WP;
+  constexpr int PAR = 2 * NB * 4;
+  static_assert(W_BYTES + 2 * G::HALO + PAR + 64 <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) uint8_t smem[W_BYTES + 2 * G::HALO + PAR + 64];
+  uint8_t* W_s = smem;
+  float* par_s = reinterpret_cast<float*>(smem + W_BYTES + 2 * G::HALO);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + W_BYTES + 2 * G::HALO + PAR);
+
+  const SdfSpikeGemmDesc& d = P.d;
+  const int H = P.cv.H, W = P.cv.W;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int grp = wave >> 2, cw = wave & 3;
+  const int gl = tid & 255;
+  const int N = d.N;
+  const bool has_res = d.resid != nullptr;
+  const bool memb = !SPIKE || d.out != nullptr;
+  const int ohw = H * W;
+  const int pm = SPIKE ? (int)(d.pos_inner / ohw) : 1, pso = SPIKE ? (int)(d.pos_ostride / ohw) : 0;
+  const int tstep = SPIKE ? (int)(d.t_stride / ohw) : 0;
+  // the shipped neuron (LIF, soft reset, tau a power of two) gets a straight-line body; anything else the general one
+  const bool lif_fast = SPIKE && d.sn_kind == SDF_LIF && d.soft_reset != 0 && P.inv_tau != 0.f;
+  const bool soft = d.soft_reset != 0;
+
+  if (tid < 4) cnt[tid] = 0;
+
+  const int tiles_x = (W + TW8 - 1) / TW8, tiles_img = tiles_x * ((H + TH8 - 1) / TH8);
+  const int Gd = gridDim.x;
+  int wg = blockIdx.x;
+  if ((Gd & 7) == 0) wg = (wg & 7) * (Gd >> 3) + (wg >> 3);
+  const int nitems = P.ntiles;
+  const int base = nitems / Gd, rem = nitems % Gd;
+  const int t_begin = wg * base + (wg < rem ? wg : rem);
+  const int n_my = base + (wg < rem ? 1 : 0);
+
+  // halo image: pass i of the group's 256 lanes moves halo rows 2i and 2i+1, lane (half, j) the j-th 16-byte piece of its row
+  const int hhalf = gl >> 7, hj = gl & 127;
+  const bool hj_ok = hj < G::RCH;
+  const int hpx = (hj_ok ? hj : 0) / CIN16, hc16 = (hj_ok ? hj : 0) - hpx * CIN16;
+  const uint32_t h_lds0 = (uint32_t)(hhalf * RPB + hpx * PS + hc16 * 16);
+  const int h_rel0 = ((hhalf - 1) * W + (hpx - 1)) * CIN + hc16 * 16;
+  const __amdgpu_buffer_rsrc_t A_rs = make_rsrc(d.A);
+  u32x4 hreg[G::CPL];
+  auto halo_load = [&](int img, int y0, int x0) __attribute__((always_inline)) {
+    const uint32_t org = (uint32_t)(((img * H + y0) * W + x0) * CIN) + (uint32_t)h_rel0;
+    const bool xok = hj_ok && (unsigned)(x0 + hpx - 1) < (unsigned)W;
+#pragma unroll
+    for (int i = 0; i < G::CPL; ++i) {
+      const int hy = 2 * i + hhalf;
+      const bool ok = xok && hy < G::HH8 && (unsigned)(y0 + hy - 1) < (unsigned)H;
+      hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(A_rs, ok ? org + (uint32_t)(2 * i * W * CIN) : INV, 0, 0);
+    }
+  };
+  uint8_t* H_s = smem + W_BYTES + grp * G::HALO;
+  auto halo_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < G::CPL; ++i)
+      if (hj_ok && 2 * i + hhalf < G::HH8) *reinterpret_cast<u32x4*>(H_s + h_lds0 + 2 * i * RPB) = hreg[i];
+  };
+  auto item_decode = [&](int item, int& cb, int& img0, int& y0, int& x0) __attribute__((always_inline)) {
+    cb = item / P.tiles_m;
+    const int rt = item - cb * P.tiles_m;
+    const int im = rt / tiles_img, tl = rt - im * tiles_img;
+    const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
+    img0 = SPIKE ? (im / pm) * pso + im % pm : im; y0 = ty * TH8; x0 = tx * TW8;
+  };
+
+  int ln = lane;
+  asm volatile("" : "+v"(ln));
+  const int l31 = ln & 31, lh = ln >> 5;
+  const uint32_t a_lane = (uint32_t)((2 * RB * cw + (l31 >> 4)) * RPB + (l31 & 15) * PS + 16 * lh);      // + 2*rb rows
+  const uint32_t w_lane = (uint32_t)(l31 * WP + 16 * lh);
+  const int qd = l31 >> 2, ql = l31 & 3;
+  const __amdgpu_buffer_rsrc_t out_rs = make_rsrc(d.out), res_rs = make_rsrc(d.resid), sp_rs = make_rsrc(d.out_spike);
+
+  uint32_t nstep = 0;
+  int seg_begin = 0;
+#ifdef SDF_STAMP
+  unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, a_issue = 0, a_wait = 0, a_mfma = 0, a_epi = 0, a_hand = 0, a_wload = 0;
+  const unsigned long long kstart = __builtin_readcyclecounter(), rstart = __builtin_amdgcn_s_memrealtime();
+#endif
+  while (seg_begin < n_my) {
+    int cb, img0, y0, x0;
+    item_decode(t_begin + seg_begin, cb, img0, y0, x0);
+    int seg_end = (cb + 1) * P.tiles_m - t_begin;
+    if (seg_end > n_my) seg_end = n_my;
+    const int n0 = cb * NB;
+    STAMP(s0);
+    __syncthreads();
+    {
+      constexpr int KC16 = K / 16;                                     // 16-byte pieces per digit-plane row
+      constexpr int WCH = 3 * NB * KC16;
+      const __amdgpu_buffer_rsrc_t W_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(d.Wp), 0, 3 * N * K, 0x00020000);
+      constexpr int WB = 6, NBATCH = (WCH + 512 * WB - 1) / (512 * WB);
+#pragma unroll 1
+      for (int b = 0; b < NBATCH; ++b) {
+        u32x4 wv[WB];
+#pragma unroll
+        for (int i = 0; i < WB; ++i) {
+          const int c = tid + 512 * (b * WB + i);
+          const int cc = c < WCH ? c : 0;
+          const int row = cc / KC16, kc = cc - row * KC16;             // row = digit * 32 + n
+          const int dg = row / NB, n = row - dg * NB;
+          wv[i] = __builtin_amdgcn_raw_buffer_load_b128(W_rs, c < WCH ? (uint32_t)((dg * N + n0 + n) * K + kc * 16) : INV, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WB; ++i) {
+          const int c = tid + 512 * (b * WB + i);
+          const int cc = c < WCH ? c : 0;
+          const int row = cc / KC16, kc = cc - row * KC16;
+          if (c < WCH) *reinterpret_cast<u32x4*>(W_s + row * WP + kc * 16) = wv[i];
+        }
+      }
+      // BN folded with the channel's digit scale: fma(D * s, alpha, beta) == fma(D, s * alpha, beta) exactly (s is a power of two)
+      if (tid < 2 * NB) {
+        const int which = tid / NB, n = tid - which * NB;
+        const float sc = col_scale[n0 + n];
+        par_s[tid] = which == 0 ? (d.alpha ? d.alpha[n0 + n] * sc : sc) : (d.alpha ? d.beta[n0 + n] : 0.f);
+      }
+    }
+    __syncthreads();
+    STAMP(s1); STAMP_ADD(a_wload, s0, s1);
+    const float4 al4 = *reinterpret_cast<const float4*>(par_s + 4 * qd);
+    const float4 be4 = *reinterpret_cast<const float4*>(par_s + NB + 4 * qd);
+
+    int it = seg_begin + grp;
+    if (it < seg_end) {
+      item_decode(t_begin + it, cb, img0, y0, x0);
+      halo_load(img0, y0, x0);
+      if (nstep) wait_ge(&cnt[2 + grp], 4 * nstep);
+      halo_store();
+      signal(&cnt[grp], lane);
+    }
+    for (; it < seg_end; it += 2) {
+      item_decode(t_begin + it, cb, img0, y0, x0);
+      float vmem[SPIKE ? 16 * RB : 1];
+      if (SPIKE) {
+#pragma unroll
+        for (int e = 0; e < 16 * RB; ++e) vmem[e] = soft ? 0.f : d.v_reset;
+      }
+#pragma unroll 1
+      for (int t = 0; t < T; ++t) {
+        STAMP(s0);
+        // rows of this step's epilogue; the fp32 epilogue requests its residual now, ahead of the MFMAs (in-order vmcnt:
+        // nothing the epilogue waits for is younger than its own stores)
+        const int img = img0 + t * tstep;
+        // quad transpose in the epilogue: lane (qd, ql) ends with columns 4qd..4qd+3 of pixel rr = 8*q4 + 4*lh + ql of a row
+        // block's 32 -> 16-byte loads / stores (dword-per-slot accesses measured slower: 4 x the memory instructions)
+        const uint32_t ld4 = (uint32_t)d.ldo * 4u, col4 = (uint32_t)(n0 + 4 * qd) * 4u;
+        const int ybase = y0 + 2 * RB * cw, xbase = x0 + 4 * lh + ql;
+        const uint32_t g00 = (uint32_t)((img * H + ybase) * W + xbase);
+        auto row_g = [&](int rb, int q4) __attribute__((always_inline)) -> uint32_t {     // global row (img, y, x), or INV outside the image
+          const int yo = 2 * rb + (q4 >> 1), xo = 8 * (q4 & 1);       // rr = 8*q4 + 4*lh + ql: row rr >> 4, column rr & 15
+          return (ybase + yo < H && xbase + xo < W) ? g00 + (uint32_t)(yo * W + xo) : INV;
+        };
+        auto rowoff = [&](int rb, int q4) __attribute__((always_inline)) -> uint32_t {
+          const uint32_t g = row_g(rb, q4);
+          return g != INV ? g * ld4 + col4 : INV;
+        };
+        float4 rs[RB][4];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) rs[rb][q4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto load_res = [&]() __attribute__((always_inline)) {
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) rs[rb][q4] = buf_load16f(res_rs, rowoff(rb, q4));
+        };
+        constexpr bool RES_EARLY = !SPIKE || RB == 1;               // registers allow it: the residual's latency hides behind the MFMAs
+        if (RES_EARLY && has_res) load_res();
+        ++nstep;
+        STAMP(s1);
+        wait_ge(&cnt[grp], 4 * nstep);
+        STAMP(s2);
+
+        // ------------------------------ MFMA phase: 27 K-steps of 32 x 3 digits x RB row blocks ------------------------------
+        i32x16 acc[3][RB];
+#pragma unroll
+        for (int dg = 0; dg < 3; ++dg)
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[dg][rb][e] = 0;
+        constexpr int KS = 9 * (CIN / 32);
+        constexpr int PF = RB == 1 ? 2 : 1;
+        i32x4 fa[PF + 1][RB], fb[PF + 1][3];
+        auto frag = [&](int ks, int set) __attribute__((always_inline)) {
+          constexpr int C32 = CIN / 32;
+          const int tap = ks / C32, c = ks - tap * C32;
+          const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb)
+            fa[set][rb] = *reinterpret_cast<const i32x4*>(H_s + a_lane + ((2 * rb + ky) * RPB + kx * PS + c * 32));
+#pragma unroll
+          for (int dg = 0; dg < 3; ++dg)
+            fb[set][dg] = *reinterpret_cast<const i32x4*>(W_s + w_lane + (dg * NB * WP + tap * CIN + c * 32));
+        };
+#pragma unroll
+        for (int i = 0; i < PF; ++i) frag(i, i);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          if (ks + PF < KS) frag(ks + PF, (ks + PF) % (PF + 1));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int dg = 0; dg < 3; ++dg)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+              acc[dg][rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks % (PF + 1)][rb], fb[ks % (PF + 1)][dg], acc[dg][rb], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        signal(&cnt[2 + grp], lane);
+        STAMP(s3);
+
+        // ------------------------------ epilogue: RB row blocks of 32 pixels ------------------------------
+        if (!RES_EARLY && has_res) load_res();
+        // the NEXT step's halo is requested here: its latency hides behind this epilogue and, beyond it, behind the other
+        // group's MFMAs; its registers are not live across this group's own MFMA phase
+        bool have_next = true;
+        {
+          int ni = img0 + (t + 1) * tstep, ny = y0, nx = x0;
+          if (t + 1 == T) {
+            if (it + 2 < seg_end) { int ncb; item_decode(t_begin + it + 2, ncb, ni, ny, nx); }
+            else have_next = false;
+          }
+          if (have_next) halo_load(ni, ny, nx);
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            __builtin_amdgcn_sched_barrier(0);                          // keep the batches apart: bounded live ranges, no spills
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              // exact integer dot products -> one fp32 number: the two low digits meet as integers (< 2^26), the high one in the fma
+              const int e = q4 * 4 + j;
+              const int lo = acc[1][rb][e] * 256 + acc[0][rb][e];
+              v[j] = __builtin_fmaf((float)acc[2][rb][e], 65536.f, (float)lo);
+            }
+            quad_transpose(v, ql);
+            float4 o;
+            o.x = __builtin_fmaf(v[0], al4.x, be4.x) + rs[rb][q4].x; o.y = __builtin_fmaf(v[1], al4.y, be4.y) + rs[rb][q4].y;
+            o.z = __builtin_fmaf(v[2], al4.z, be4.z) + rs[rb][q4].z; o.w = __builtin_fmaf(v[3], al4.w, be4.w) + rs[rb][q4].w;
+            if (memb) buf_store16f(out_rs, rowoff(rb, q4), o);
+            if (SPIKE) {
+              const float xs[4] = {o.x, o.y, o.z, o.w};
+              uint32_t pk = 0;
+              if (lif_fast) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  float& vm = vmem[rb * 16 + q4 * 4 + j];
+                  const float hcur = vm + (xs[j] - vm) * P.inv_tau;
+                  const float sp = (hcur - d.v_th >= 0.f) ? 1.f : 0.f;
+                  vm = hcur - sp * d.v_th;
+                  pk |= ((__float_as_uint(sp) >> 29) & 1u) << (8 * j);   // 1.0f has bit 29 set
+                }
+              } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  float& vm = vmem[rb * 16 + q4 * 4 + j];
+                  float hcur;
+                  if (d.sn_kind == SDF_IF) {
+                    hcur = vm + xs[j];
+                  } else {
+                    const float dl = (soft || d.v_reset == 0.f) ? (xs[j] - vm) : (xs[j] - (vm - d.v_reset));
+                    hcur = vm + ((P.inv_tau != 0.f) ? dl * P.inv_tau : dl / d.tau);
+                  }
+                  const float sp = (hcur - d.v_th >= 0.f) ? 1.f : 0.f;
+                  vm = soft ? (hcur - sp * d.v_th) : ((1.f - sp) * hcur + sp * d.v_reset);
+                  pk |= ((__float_as_uint(sp) >> 29) & 1u) << (8 * j);
+                }
+              }
+              const uint32_t g = row_g(rb, q4);
+              __builtin_amdgcn_raw_buffer_store_b32(pk, sp_rs, g != INV ? g * (uint32_t)N + (uint32_t)(n0 + 4 * qd) : INV, 0, 0);
+            }
+          }
+        }
+        STAMP(s4);
+        if (have_next) {
+          wait_ge(&cnt[2 + grp], 4 * nstep);
+          halo_store();
+          signal(&cnt[grp], lane);
+        }
+        STAMP(s5);
+        STAMP_ADD(a_issue, s0, s1); STAMP_ADD(a_wait, s1, s2); STAMP_ADD(a_mfma, s2, s3); STAMP_ADD(a_epi, s3, s4); STAMP_ADD(a_hand, s4, s5);
+      }
+    }
+    seg_begin = seg_end;
+  }
+#ifdef SDF_STAMP
+  if (blockIdx.x == 0 && (tid == 0 || tid == 256)) {
+    unsigned long long* o = g_wres_stamp + (tid ? 16 : 0);
+    o[0] = a_issue; o[1] = a_wait; o[2] = a_mfma; o[3] = a_epi; o[4] = a_hand; o[5] = a_wload; o[6] = nstep;
+    o[7] = __builtin_readcyclecounter() - kstart; o[8] = __builtin_amdgcn_s_memrealtime() - rstart;
+  }
+#endif
+}
+
+template <int NSPLIT, int TT>
+int launch_c(const GemmParams& P, dim3 grid, hipStream_t s) {
+  switch (P.cv.Cin) {
+    case 96: hipLaunchKernelGGL((spike_conv_wres_kernel<NSPLIT, TT, 6>), grid, dim3(512), 0, s, P); return 0;
+    default: return SDF_E_SHAPE;
+  }
+}
+
+}  // namespace
+
+// true when the weight-resident kernel has an instantiation for this convolution and the launch is big enough to use it
+bool spike_conv_wres_supports(const GemmParams& P, bool any_size) {
+  const SdfSpikeGemmDesc& d = P.d;
+  const ConvGeom& c = P.cv;
+  if (c.Cin != 96 || c.KWc != 3 || d.K != 9 * c.Cin || c.sy != 1 || c.sx != 1 || c.H != c.OH || c.W != c.OW) return false;
+  if (c.dy[0] != -1 || c.dy[1] != 0 || c.dy[2] != 1 || c.dx[0] != -1 || c.dx[1] != 0 || c.dx[2] != 1) return false;
+  if (d.N % NB || (d.nsplit != 1 && d.nsplit != 2 && d.nsplit != SDF_PLANES_I8X3) || d.out_rowmap || d.add || d.zg_nH > 0) return false;
+  if (d.nsplit == SDF_PLANES_I8X3 && (!d.col_scale || d.bias)) return false;
+  if (d.sn_T != 0 && d.sn_T != 10) return false;
+  const int64_t imgs = d.M / ((int64_t)c.OH * c.OW);
+  if (d.sn_T > 0) {
+    if (d.sn_kind == SDF_PSN || d.bias) return false;
+    if (d.nsplit != SDF_PLANES_I8X3 && !any_size) return false;     // 16-bit planes: the fused form measured slower than the streaming kernel
+    // positions must enumerate whole images, time steps and outer blocks must be whole images apart
+    const int64_t ohw = (int64_t)c.OH * c.OW;
+    if (d.pos_inner % ohw || d.pos_ostride % ohw || d.t_stride % ohw || d.pos_count % ohw || d.t_stride == 0) return false;
+    if (imgs % d.sn_T) return false;
+  }
+  if (d.ldo % 4 || (d.out && !sdf_aligned(d.out, 16)) || (d.resid && !sdf_aligned(d.resid, 16))) return false;
+  const int64_t lim = (int64_t)1 << 31;
+  if (imgs * c.H * c.W * c.Cin >= lim || d.M * d.ldo * 4 >= lim || d.M * d.N >= lim) return false;
+  const int64_t tiles = imgs * ((c.OH + TH - 1) / TH) * ((c.OW + TW - 1) / TW) / (d.sn_T > 0 ? d.sn_T : 1);
+  return any_size || tiles * (d.N / NB) >= 512;                                  // two rounds of the chip at least: below that the split-K paths win
+}
+
+int launch_spike_conv_wres(const GemmParams& Pin, hipStream_t s) {
+  GemmParams P = Pin;
+  const SdfSpikeGemmDesc& d = P.d;
+  const ConvGeom& c = P.cv;
+  const int64_t imgs = d.M / ((int64_t)c.OH * c.OW);
+  const int T = d.sn_T > 0 ? d.sn_T : 1;
+  // digit-plane kernel: 16 x 16 pixel tiles (two row blocks per wave share every weight fragment) when that still leaves every
+  // half workgroup several items, 8 x 16 otherwise (fused-neuron items are T steps long: few and coarse at batch 1)
+  int th = TH;
+  if (d.nsplit == SDF_PLANES_I8X3) {
+    const int64_t items16 = (imgs / T) * ((c.OH + 15) / 16) * ((c.OW + TW - 1) / TW) * (d.N / NB);
+    const char* erb = getenv("SDF_CONV_WRES_RB");                     // tuning override
+    th = (erb ? erb[0] == '2' : items16 >= 2048) ? 16 : 8;
+  }
+  P.tiles_m = (int)((imgs / T) * ((c.OH + th - 1) / th) * ((c.OW + TW - 1) / TW));   // fused: imgs / T = pos_count / (OH*OW) batch elements
+  P.tiles_n = d.N / NB;
+  P.ntiles = P.tiles_m * P.tiles_n;
+  P.ksplit = 1; P.spc = 0; P.partial = nullptr;
+  const int G = P.ntiles < 256 ? P.ntiles : 256;
+  dim3 grid((unsigned)G);
+  int rc;
+  if (d.nsplit == SDF_PLANES_I8X3) {
+    if (c.Cin != 96) return SDF_E_SHAPE;
+    if (d.sn_T == 0 && th == 16) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 6, 2>), grid, dim3(512), 0, s, P, d.col_scale);
+    else if (d.sn_T == 0) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 6, 1>), grid, dim3(512), 0, s, P, d.col_scale);
+    else if (th == 16) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 2>), grid, dim3(512), 0, s, P, d.col_scale);
+    else hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 1>), grid, dim3(512), 0, s, P, d.col_scale);
+    rc = 0;
+  } else if (d.sn_T == 0) rc = d.nsplit == 1 ? launch_c<1, 0>(P, grid, s) : launch_c<2, 0>(P, grid, s);
+  else rc = d.nsplit == 1 ? launch_c<1, 10>(P, grid, s) : launch_c<2, 10>(P, grid, s);
+  if (rc) return rc;
+  hipError_t e = hipGetLastError();
+  return e != hipSuccess ? (int)e : 0;
+}
+
+}  // namespace sdfmm
+
+namespace {
+// one workgroup per weight row: row maximum -> power-of-two scale -> balanced base-256 digits of rint(w / scale)
+__global__ __launch_bounds__(256) void split_weight_i8x3_kernel(const float* __restrict__ W, int8_t* __restrict__ planes,
+                                                                float* __restrict__ col_scale, int N, int K) {
+  __shared__ float red[256];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  float mx = 0.f;
+  for (int k = tid; k < K; k += 256) mx = fmaxf(mx, fabsf(W[(int64_t)n * K + k]));
+  red[tid] = mx;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (tid < s2) red[tid] = fmaxf(red[tid], red[tid + s2]);
+    __syncthreads();
+  }
+  mx = red[0];
+  int ex = 0;
+  if (mx > 0.f && mx < 3.0e38f) frexpf(mx, &ex);                       // mx = f * 2^ex, f in [0.5, 1): mx < 2^ex
+  if (ex < -100) ex = -100;
+  const float scale = ldexpf(1.f, ex - 22);
+  if (tid == 0) col_scale[n] = scale;
+  const float inv = ldexpf(1.f, 22 - ex);
+  for (int k = tid; k < K; k += 256) {
+    int q = (int)rintf(W[(int64_t)n * K + k] * inv);                  // |q| <= 2^22
+    const int d0 = ((q + 128) & 255) - 128;
+    q = (q - d0) >> 8;
+    const int d1 = ((q + 128) & 255) - 128;
+    const int d2 = (q - d1) >> 8;                                     // |d2| <= 64
+    planes[((int64_t)0 * N + n) * K + k] = (int8_t)d0;
+    planes[((int64_t)1 * N + n) * K + k] = (int8_t)d1;
+    planes[((int64_t)2 * N + n) * K + k] = (int8_t)d2;
+  }
+}
+}  // namespace
+
+extern "C" int sdf_split_weight_i8x3(const float* W, int8_t* planes, float* col_scale, int N, int K, void* stream) {
+  if (!W || !planes || !col_scale) return SDF_E_NULL;
+  if (N < 1 || K < 1) return SDF_E_SHAPE;
+  hipLaunchKernelGGL(split_weight_i8x3_kernel, dim3((unsigned)N), dim3(256), 0, sdf_stream(stream), W, planes, col_scale, N, K);
+  SDF_LAUNCH_CHECK();
+  return 0;
+}
+
+#ifdef SDF_STAMP
+extern "C" int sdf_debug_read_stamps_wres(unsigned long long* host32) {
+  return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(g_wres_stamp), 32 * sizeof(unsigned long long));
+}
+#endif

@@ -550,17 +550,19 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
   if (spike ? !d->out_spike : !d->out) return SDF_E_NULL;
   if (c->H < 1 || c->W < 1 || c->H > 32767 || c->W > 32767 || c->OH < 1 || c->OW < 1) return SDF_E_SHAPE;
   if (c->Cin < 48 || c->Cin % 16 || c->KH < 1 || c->KH > 3 || c->KW < 1 || c->KW > 3 || c->sy < 1 || c->sx < 1) return SDF_E_SHAPE;
-  if (d->K != c->KH * c->KW * c->Cin || d->N % 96 || d->M % ((int64_t)c->OH * c->OW) || d->M >= (1LL << 31)) return SDF_E_SHAPE;
+  if (d->K != c->KH * c->KW * c->Cin || d->N % 32 || d->M % ((int64_t)c->OH * c->OW) || d->M >= (1LL << 31)) return SDF_E_SHAPE;
   if ((d->M / ((int64_t)c->OH * c->OW)) * c->H * c->W >= (1LL << 31)) return SDF_E_SHAPE;
-  if (d->nsplit < 1 || d->nsplit > 3) return SDF_E_DTYPE;
-  if (!sdf_scale_ok(d)) return SDF_E_DTYPE;
+  const bool i8x3 = d->nsplit == SDF_PLANES_I8X3;                 // int8 digit planes: only the weight-resident kernel reads them
+  if (!i8x3 && (d->nsplit < 1 || d->nsplit > 3)) return SDF_E_DTYPE;
+  if (!i8x3 && !sdf_scale_ok(d)) return SDF_E_DTYPE;
+  if (i8x3 && !d->col_scale) return SDF_E_NULL;
   if (d->alpha && !d->beta) return SDF_E_NULL;
   if (d->zg_nH > 0) return SDF_E_SHAPE;
   GemmParams P;
   P.d = *d;
   P.d.lda = 0;
   P.inv_tau = 0.f;
-  P.acc_scale = sdf_acc_scale(d);
+  P.acc_scale = i8x3 ? 1.f : sdf_acc_scale(d);
   if (spike) {
     if (d->sn_T != 10 || d->pos_count < 1 || d->pos_inner < 1 || d->pos_count * d->sn_T != d->M) return SDF_E_SHAPE;
     if (d->sn_kind != SDF_LIF && d->sn_kind != SDF_PSN && d->sn_kind != SDF_IF) return SDF_E_DTYPE;
@@ -579,6 +581,10 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
   cv.KWc = c->KW;
   cv.kw_mul = c->KW == 1 ? 32 : (c->KW == 2 ? 16 : 11);
   for (int i = 0; i < 3; ++i) { cv.dy[i] = c->dy[i]; cv.dx[i] = c->dx[i]; }
+  // 3x3 / stride 1 on 96 channels with enough tiles to fill the chip: weights resident in LDS, halo tiles instead of im2col
+  const char* ewr = getenv("SDF_CONV_WRES");                  // A/B override: 0 = always the streaming kernels below, 2 = at any size
+  if (!(ewr && ewr[0] == '0') && spike_conv_wres_supports(P, i8x3 || (ewr && ewr[0] == '2'))) return launch_spike_conv_wres(P, sdf_stream(stream));
+  if (i8x3) return SDF_E_SHAPE;                                 // digit planes have no streaming-kernel form: the caller packs per shape
   // 256 x 96 tiles, producer waves do the im2col addressing; the ping-pong kernel overlaps epilogues with the MFMAs
   const char* e = getenv("SDF_CONV_PP");                      // tuning override: 0 = barrier-synchronised kernel
   if (spike_mm_pp_supports(P, true) && !(e && e[0] == '0')) return launch_spike_mm_pp(P, true, sdf_stream(stream));
@@ -608,6 +614,7 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
       return 0;
     }
   }
+  if (d->N % 96) return SDF_E_SHAPE;                              // the streaming kernels work on 96-column blocks
   if (d->nsplit == 2 || (spike && d->out)) return SDF_E_DTYPE;   // only the ping-pong kernel has these
   return launch_spike_mm_ws(P, true, sdf_stream(stream));
 }

@@ -106,6 +106,10 @@ int launch_spike_mm_ws(const GemmParams& P, bool conv, hipStream_t s);
 // ping-pong kernel (spike_mm_pp.hip): same tiles, consumer groups alternate tiles so epilogues overlap the MFMAs
 bool spike_mm_pp_supports(const GemmParams& P, bool conv);
 int launch_spike_mm_pp(const GemmParams& P, bool conv, hipStream_t s);
+// weight-resident 3x3 / stride-1 spike convolution (spike_conv_wres.hip): one 32-column block's weights stay in LDS, the
+// activations enter as halo tiles (no im2col); `supports` is false for shapes it has no instantiation for
+bool spike_conv_wres_supports(const GemmParams& P, bool any_size);
+int launch_spike_conv_wres(const GemmParams& P, hipStream_t s);
 // split-K planning (fills ksplit / spc / partial from the descriptor's workspace) and the k-ordered second pass
 void plan_splitk(GemmParams& P, int kc);
 int launch_splitk_reduce(const GemmParams& P, hipStream_t s);

@@ -85,6 +85,14 @@ def _conv_planes(w, nsplit, cin_pad=None):
     return hip.pack_conv_weight(w.detach().float(), nsplit, cin_pad)
 
 
+def _conv_digits(w, nsplit):
+    """int8 digit planes of a 3x3 convolution on 96 input channels (what the weight-resident kernel reads for large launches,
+    csrc/spike_conv_wres.hip); None where that kernel has no instantiation or the exact 3-plane / 1-plane modes were asked for."""
+    if nsplit != 2 or w.shape[1] != 96 or tuple(w.shape[2:]) != (3, 3) or w.shape[0] % 32:
+        return None
+    return hip.pack_conv_weight_i8x3(w.detach().float())
+
+
 class _ResBlock:
     """MS_ResBlock weights for the spike-convolution path (3x3, pad 1, NHWC)."""
 
@@ -92,6 +100,7 @@ class _ResBlock:
         self.name = name
         self.C = rb.conv1[0].weight.shape[0]
         self.w1, self.w2 = _conv_planes(rb.conv1[0].weight, nsplit), _conv_planes(rb.conv2[0].weight, nsplit)
+        self.w1.digits, self.w2.digits = _conv_digits(rb.conv1[0].weight, nsplit), _conv_digits(rb.conv2[0].weight, nsplit)
         self.bn1, self.bn2 = bn_affine(rb.norm1.norm_layer, device), bn_affine(rb.norm2.norm_layer, device)
         self.sn1, self.sn2 = _np(rb.sn1, device), _np(rb.sn2, device)
 
@@ -239,6 +248,11 @@ class MSFlowEngine:
         B, D, h, w, Cin = s.shape
         oh, ow = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
         a, b = bn if bn is not None else (None, None)
+        # large 3x3 / stride-1 launches on 96 channels: int8 digit planes, weights resident in LDS (csrc/spike_conv_wres.hip)
+        digits = getattr(Wp, "digits", None)
+        if digits is not None and (sn is None or (sn.kind != "psn" and D == 10)) and \
+                hip.conv_wres_applicable(B * D, h, w, Cin, Cout, stride, D if sn is not None else 1):
+            Wp = digits                                               # (the kernel's fused form: LIF / IF over T = 10)
         if sn is None:
             out = torch.empty((B, D, oh, ow, Cout), dtype=torch.float32, device=s.device)
             hip.spike_conv2d(s, Wp, B * D, h, w, Cin, oh, ow, 3, 3, stride, (-1, 0, 1), (-1, 0, 1), out=out, alpha=a, beta=b,

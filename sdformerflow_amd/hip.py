@@ -26,7 +26,7 @@ EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_s
            "sdf_window_slice_map", "sdf_qk_attn_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
            "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
            "sdf_rows_gather_fwd", "sdf_rows_scatter_fwd",
-           "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd")
+           "sdf_split_weight_i8x3", "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd")
 
 
 class SdfError(RuntimeError):
@@ -58,7 +58,8 @@ class SpikeGemmDesc(C.Structure):
                 ("psn_w", C.c_void_p), ("psn_b", C.c_void_p),
                 ("pos_count", C.c_int64), ("pos_inner", C.c_int64), ("pos_ostride", C.c_int64), ("t_stride", C.c_int64),
                 ("add", C.c_void_p), ("add_prows", C.c_int64), ("out_spike", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("acc_scale", C.c_float), ("out_rows", C.c_int64)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("acc_scale", C.c_float), ("out_rows", C.c_int64),
+                ("col_scale", C.c_void_p)]
 
 
 class SpikeConvDesc(C.Structure):
@@ -279,8 +280,42 @@ def split_weight(W, nsplit=3):
     return planes
 
 
+PLANES_I8X3 = 4
+
+
+def split_weight_i8x3(W):
+    """fp32 weight (N, K) -> int8 digit planes (3, N, K) + per-row power-of-two scales (attribute `sdf_col_scale`):
+    w = (d2*65536 + d1*256 + d0) * scale (sdf_split_weight_i8x3).  Only the weight-resident 3x3 convolution reads this format."""
+    W = W.contiguous()
+    N, K = W.shape
+    planes = torch.empty((3, N, K), dtype=torch.int8, device=W.device)
+    scale = torch.empty((N,), dtype=torch.float32, device=W.device)
+    _check(lib().sdf_split_weight_i8x3(C.c_void_p(_ptr(W, torch.float32)), C.c_void_p(planes.data_ptr()), C.c_void_p(scale.data_ptr()),
+                                       C.c_int(N), C.c_int(K), _stream()), "sdf_split_weight_i8x3")
+    planes.sdf_col_scale = scale
+    return planes
+
+
+def conv_wres_applicable(imgs, H, W, Cin, Cout, stride, T=1):
+    """Mirror of the library's dispatch rule (csrc/spike_conv_wres.hip: spike_conv_wres_supports): 3x3 / stride 1 / 96 input
+    channels, output columns in blocks of 32, and enough 8 x 16 pixel tiles (x T steps each when the neuron is fused) to give
+    every half workgroup of the chip work - below that the streaming kernels' split-K wins."""
+    if Cin != 96 or stride != 1 or Cout % 32:
+        return False
+    if imgs * H * W * max(Cout * 4, Cin) >= 1 << 31:             # the kernel addresses its operands with 31-bit byte offsets
+        return False
+    tiles = (imgs // T) * (-(-H // 8)) * (-(-W // 16))
+    return tiles * (Cout // 32) >= 512
+
+
+def pack_conv_weight_i8x3(w):
+    """Conv2d weight (Cout, Cin, KH, KW) fp32 -> int8 digit planes (3, Cout, KH*KW*Cin), K in (ky, kx, cin) order."""
+    Cout, Cin, KH, KW = w.shape
+    return split_weight_i8x3(w.detach().float().permute(0, 2, 3, 1).reshape(Cout, KH * KW * Cin))
+
+
 def _acc_scale(Wp):
-    if Wp.shape[0] != 2:
+    if Wp.dtype == torch.int8 or Wp.shape[0] != 2:
         return 0.0
     if not hasattr(Wp, "sdf_acc_scale"):
         raise SdfError("fp16 weight planes without their scale: use the tensor returned by split_weight(W, 2) as is")
@@ -609,9 +644,13 @@ def spike_conv2d(x, Wp, imgs, H, W, Cin, OH, OW, KH, KW, stride, dy, dx, out=Non
     fp32 epilogue -> `out` (rows, Cout); fused neuron (sn, sn_T=10, pos=(count, inner, ostride, t_stride)) -> `out_spike`."""
     d = SpikeConvDesc()
     g = d.g
-    g.A, g.Wp = _ptr(x, torch.uint8), _ptr(Wp, torch.int16)
+    g.A, g.Wp = _ptr(x, torch.uint8), _ptr(Wp)
     g.M, g.N, g.K = imgs * OH * OW, Wp.shape[1], KH * KW * Cin
     g.lda, g.ldo, g.nsplit, g.acc_scale = 0, Wp.shape[1], Wp.shape[0], _acc_scale(Wp)
+    if Wp.dtype == torch.int8:                                    # digit planes (split_weight_i8x3)
+        g.nsplit, g.col_scale = PLANES_I8X3, _ptr(Wp.sdf_col_scale, torch.float32)
+    elif Wp.dtype != torch.int16:
+        raise SdfError(f"weight planes must be int16 (16-bit float planes) or int8 (digit planes), got {Wp.dtype}")
     g.alpha, g.beta = _ptr(alpha, torch.float32), _ptr(beta, torch.float32)
     g.resid, g.out_rowmap = _ptr(resid, torch.float32), _ptr(out_rowmap, torch.int32)
     if out_rowmap is not None and out is not None:
