@@ -11,13 +11,15 @@ Forward runs on the HIP engine; there is no CPU fallback (it raises on CPU tenso
 import torch
 import torch.nn as nn
 
-from .Spiking_modules import MS_ResBlock, MS_SpikingPredLayer, MS_SpikingTransposeDecoderLayer
+from .Spiking_modules import (MS_ResBlock, MS_SpikingPredLayer, MS_SpikingTransposeDecoderLayer, SEWResBlock, SpikingPredLayer,
+                              SpikingTransposeDecoderLayer)
 from .Spiking_submodules import IFNode
-from .Spiking_swin_transformer3D import MS_Spiking_SwinTransformer3D_v2
+from .Spiking_swin_transformer3D import MS_Spiking_SwinTransformer3D_v2, Spiking_SwinTransformer3D_v2
 
 
 class MS_spiking_former_encoder(nn.Module):
     """reference Spiking_STSwinNet.py:8-88."""
+    swin_type = MS_Spiking_SwinTransformer3D_v2
 
     def __init__(self, arc_type="swinv2", patch_embed_type="PatchEmbedLocal", img_size=(240, 320), patch_size=(32, 2, 2),
                  in_chans=128, embed_dim=96, depths=(2, 2, 6), num_heads=(3, 6, 12), window_size=(2, 7, 7),
@@ -26,7 +28,7 @@ class MS_spiking_former_encoder(nn.Module):
         super().__init__()
         self.num_encoders = len(depths)
         self.out_channels = [embed_dim * 2 ** i for i in range(self.num_encoders)]
-        self.swin3d = MS_Spiking_SwinTransformer3D_v2(
+        self.swin3d = self.swin_type(
             arc_type=arc_type, embed_type=patch_embed_type, img_size=img_size, patch_size=patch_size, in_chans=in_chans,
             embed_dim=embed_dim, depths=depths, num_heads=num_heads, window_size=window_size,
             pretrained_window_size=pretrained_window_size, mlp_ratio=mlp_ratio, drop_rate=0.0, attn_drop_rate=0.0,
@@ -34,9 +36,15 @@ class MS_spiking_former_encoder(nn.Module):
             **spiking_kwargs)
 
 
+class spiking_former_encoder(MS_spiking_former_encoder):
+    """SEW encoder (reference Spiking_STSwinNet.py:8-86)."""
+    swin_type = Spiking_SwinTransformer3D_v2
+
+
 class MS_Spikingformer_MultiResUNet(nn.Module):
     """Spiking U-Net: swin encoder, 2 MS res-blocks, transposed-conv decoders with per-scale flow predictions
     (reference Spiking_STSwinNet.py:90-252, SNN_models.py:118-164)."""
+    encoder_block, res_type, transpose_type, pred_type = MS_spiking_former_encoder, MS_ResBlock, MS_SpikingTransposeDecoderLayer, MS_SpikingPredLayer
 
     def __init__(self, unet_kwargs, stt_kwargs):
         super().__init__()
@@ -61,15 +69,15 @@ class MS_Spikingformer_MultiResUNet(nn.Module):
         self.encoder_input_sizes = [self.base_num_channels] + self.encoder_output_sizes[:-1]
         self.max_num_channels = self.encoder_output_sizes[-1]
         kw = self.spiking_kwargs
-        self.resblocks = nn.ModuleList([MS_ResBlock(self.max_num_channels, self.max_num_channels, connect_function="ADD", **kw)
+        self.resblocks = nn.ModuleList([self.res_type(self.max_num_channels, self.max_num_channels, connect_function="ADD", **kw)
                                         for _ in range(self.num_residual_blocks)])
         self.decoders = nn.ModuleList()
         for i, (cin, cout) in enumerate(zip(reversed(self.encoder_output_sizes), reversed(self.encoder_input_sizes))):
-            self.decoders.append(MS_SpikingTransposeDecoderLayer(2 * cin + (0 if i == 0 else self.num_output_channels), cout,
+            self.decoders.append(self.transpose_type(2 * cin + (0 if i == 0 else self.num_output_channels), cout,
                                                                  kernel_size=self.kernel_size, scale=2, **kw))
-        self.preds = nn.ModuleList([MS_SpikingPredLayer(c, self.num_output_channels, 1, **kw)
+        self.preds = nn.ModuleList([self.pred_type(c, self.num_output_channels, 1, **kw)
                                     for c in reversed(self.encoder_input_sizes)])
-        self.encoders = MS_spiking_former_encoder(
+        self.encoders = self.encoder_block(
             arc_type=stt_kwargs["use_arc"][0], patch_embed_type=stt_kwargs["use_arc"][1], img_size=self.input_size,
             patch_size=[int(i) for i in stt_kwargs["swin_patch_size"]], in_chans=self.num_bins_events,
             embed_dim=self.base_num_channels, depths=self.depths, num_heads=self.num_heads, window_size=self.window_size,
@@ -78,10 +86,43 @@ class MS_Spikingformer_MultiResUNet(nn.Module):
             pol_in_channel=False, **kw)
         self.preds_out = nn.ModuleList([IFNode(v_threshold=float("inf"), v_reset=0.0) for _ in range(self.num_encoders)])
 
+    def record_flops(self):
+        """Analytic MAC record of the reference (Spiking_STSwinNet.py:211-237)."""
+        rec = {"en": self.encoders.swin3d.record_flops()}
+        H, W = self.encoders.swin3d.patch_embed.patches_resolution
+        H, W = H // 2 ** (self.num_encoders - 1), W // 2 ** (self.num_encoders - 1)
+        C = self.max_num_channels
+        for i in range(self.num_residual_blocks):
+            rec[f"res{i}conv0"] = rec[f"res{i}conv1"] = C * C * 9 * H * W
+        for i, (cin, cout) in enumerate(zip(reversed(self.encoder_output_sizes), reversed(self.encoder_input_sizes))):
+            H, W = 2 * H, 2 * W
+            rec[f"decoder{i}"] = (2 * cin + (0 if i == 0 else self.num_output_channels)) * cout * H * W * self.kernel_size ** 2
+            rec[f"pred{i}"] = cout * self.num_output_channels * H * W
+        return rec
+
+    def flops(self):
+        """reference :184-209: encoder + res-blocks + decoders + predictions, one MAC per BN output element."""
+        f = self.encoders.swin3d.flops()
+        H, W = self.encoders.swin3d.patch_embed.patches_resolution
+        H, W = H // 2 ** (self.num_encoders - 1), W // 2 ** (self.num_encoders - 1)
+        f += 2 * self.max_num_channels ** 2 * 9 * H * W * self.num_residual_blocks
+        for i, (cin, cout) in enumerate(zip(reversed(self.encoder_output_sizes), reversed(self.encoder_input_sizes))):
+            H, W = 2 * H, 2 * W
+            f += (2 * cin + (0 if i == 0 else self.num_output_channels)) * cout * H * W * self.kernel_size ** 2 + cout * H * W
+            f += cout * self.num_output_channels * H * W + self.num_output_channels * H * W
+        return f
+
+
+class Spikingformer_MultiResUNet(MS_Spikingformer_MultiResUNet):
+    """SEW U-Net (reference Spiking_STSwinNet.py:90-182; SNN_models.py:12-32): SEW encoder, SEW res-blocks, transposed-conv
+    decoders with the neuron after the norm, plain 1x1 predictions."""
+    encoder_block, res_type, transpose_type, pred_type = spiking_former_encoder, SEWResBlock, SpikingTransposeDecoderLayer, SpikingPredLayer
+
 
 class MS_SpikingformerFlowNet(nn.Module):
     """MS-shortcut SDformerFlow, 3 encoders (reference Spiking_STSwinNet.py:313-317)."""
     num_en = 3
+    unet_type = MS_Spikingformer_MultiResUNet
 
     def __init__(self, unet_kwargs, stt_kwargs):
         super().__init__()
@@ -94,7 +135,7 @@ class MS_SpikingformerFlowNet(nn.Module):
         unet_kwargs.update({"num_encoders": self.num_en, "num_residual_blocks": 2, "num_output_channels": 2,
                             "skip_type": "concat", "channel_multiplier": 2,
                             "use_upsample_conv": unet_kwargs.get("use_upsample_conv", True)})
-        self.sttmultires_unet = MS_Spikingformer_MultiResUNet(unet_kwargs, dict(stt_kwargs))
+        self.sttmultires_unet = self.unet_type(unet_kwargs, dict(stt_kwargs))
         self._engine, self._stamp_tensors = None, None
         # Weight planes of the spike GEMMs / convolutions (binary spikes are exact in 16-bit floats, accumulation is fp32):
         #   2 = fp16 hi + lo of the power-of-two-scaled weight: 22 of the 24 significand bits at 2/3 of the matrix work.
@@ -150,10 +191,21 @@ class MS_SpikingformerFlowNet(nn.Module):
         in-place update seen through the version stamp (eval -> train_step -> eval must not run on stale planes)."""
         stamp = self._weights_stamp()
         if self._engine is None or self._engine_stamp != stamp:
-            from ..engine import MSFlowEngine
-            self._engine = MSFlowEngine(self)
+            self._engine = self._make_engine()
             self._engine_stamp = stamp
         return self._engine
+
+    def _make_engine(self):
+        from ..engine import MSFlowEngine
+        return MSFlowEngine(self)
+
+    def flops(self):
+        """reference :307-308."""
+        return self.sttmultires_unet.flops()
+
+    def record_flops(self):
+        """reference :310-311."""
+        return self.sttmultires_unet.record_flops()
 
     def forward(self, x, log=False):
         if self.training:                     # train-mode forward under autograd (batch-stat BN, HIP neurons both ways)
@@ -169,3 +221,19 @@ class MS_SpikingformerFlowNet(nn.Module):
 class MS_SpikingformerFlowNet_en4(MS_SpikingformerFlowNet):
     """MS-shortcut SDformerFlow, 4 encoders - the shipped model (reference :319-325)."""
     num_en = 4
+
+
+class SpikingformerFlowNet(MS_SpikingformerFlowNet):
+    """SEW-shortcut SDformerFlow, 3 encoders (reference Spiking_STSwinNet.py:254-311): the stream between blocks carries sums
+    of spikes.  Inference runs on `engine_sew.SEWFlowEngine`; training of this family is not built."""
+    num_en = 3
+    unet_type = Spikingformer_MultiResUNet
+
+    def _make_engine(self):
+        from ..engine_sew import SEWFlowEngine
+        return SEWFlowEngine(self)
+
+    def forward(self, x, log=False):
+        if self.training:
+            raise NotImplementedError("the SEW family is forward-only here (the training path covers the shipped MS models)")
+        return super().forward(x, log)

@@ -149,6 +149,22 @@ class MS_PED_Spiking_PatchEmbed_Conv_sfn(nn.Module):
         self.proj = SpikingPEDLayer(embed_dim, embed_dim, 3, tuple(patch_size[2:]), 1, norm=spike_norm,
                                     patch_resolution=self.patches_resolution, **kw)
 
+    def record_flops(self):
+        """reference :1816-1840."""
+        E, (H, W), (ph, pw) = self.embed_dim, self.image_size, self.patches_resolution
+        rec = {"head": self.num_ch * E // 2 * 9 * H * W,
+               "conv": E // 2 * E * self.first_conv_k * self.first_conv_k * H * W // 4}
+        for i in range(self.num_res):
+            rec[f"res{i}_conv0"] = rec[f"res{i}_conv1"] = E * E * 9 * H * W // 4
+        rec["proj"] = E * E * 9 * ph * pw
+        return rec
+
+    def flops(self):
+        """reference :1795-1814: the convolutions above plus one MAC per BN output element."""
+        E, (H, W), (ph, pw) = self.embed_dim, self.image_size, self.patches_resolution
+        bn = E // 2 * H * W + E * H * W + self.num_res * 2 * E * H * W // 4 + E * ph * pw
+        return sum(self.record_flops().values()) + bn
+
 
 class MS_SpikingTransposeDecoderLayer(nn.Module):
     """SN -> ConvTranspose 3x3 s2 -> BN (reference :397-474)."""
@@ -172,4 +188,23 @@ class MS_SpikingPredLayer(nn.Module):
         super().__init__()
         self.norm = None
         self.sn = Spiking_neuron(**_neuron_kwargs(spiking_kwargs))
+        self.conv = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size, stride, kernel_size // 2, bias=True))
+
+
+# ---------------------------------------------------------------------------------------------- SEW family (reference :827-878, :397-456, :571-603)
+class SEWResBlock(MS_ResBlock):
+    """conv-BN-SN-conv-BN-SN + identity (spike-element-wise ADD; reference :827-878).  Same parameters as `MS_ResBlock`; the
+    order of neuron and convolution differs, which the SEW engine schedules."""
+
+
+class SpikingTransposeDecoderLayer(MS_SpikingTransposeDecoderLayer):
+    """ConvTranspose 3x3 s2 -> BN -> SN (reference :397-456): the neuron comes last."""
+
+
+class SpikingPredLayer(nn.Module):
+    """Plain conv1x1 (+bias) flow prediction on spikes (reference :571-603): no neuron of its own."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, **spiking_kwargs):
+        super().__init__()
+        self.norm = None
         self.conv = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size, stride, kernel_size // 2, bias=True))

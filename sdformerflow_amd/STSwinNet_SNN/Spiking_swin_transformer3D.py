@@ -80,6 +80,16 @@ class Spiking_QK_WindowAttention3D(nn.Module):
         self.proj_bn = SpikingNormLayer(dim, self.window_size[0], norm, spiking_kwargs["v_th"])
         self.proj_sn = Spiking_neuron(**kw)
 
+    def flops(self, N):
+        """MACs of one window of N tokens.  The reference class has no `flops()` (its model-level `flops()` raises for the
+        shipped MS model); counted here like its SEW sibling (:377-392) with what this attention really
+        does: q and k projections, the projection, their norms - the token gate is additions and a compare, no MACs."""
+        return N * self.dim * self.dim * 2 + N * self.dim * 2 + N * self.dim * self.dim + N * self.dim
+
+    def record_flops(self, nW, N):
+        d = nW * N * self.dim * self.dim
+        return {"q": d, "k": d, "attn": 0, "proj": d}
+
 
 class Spiking_BN_WindowAttention3D(nn.Module):
     """SEW spiking window attention, swinv1 branch (reference :184-370): spike q,k,v, (q*scale) k^T + table bias
@@ -139,6 +149,17 @@ class Spiking_BN_WindowAttention3D(nn.Module):
             hip.neuron_fwd(y, out, Tq, 1, n, 0, n, 0, n, _np(self.proj_sn, dev), alpha=a, beta=b, Cch=C, inner=1)
             return out.view(B_, N, C), None
 
+    def flops(self, N):
+        """MACs of one window of N tokens (reference :377-392)."""
+        f = N * self.dim * self.dim * 3 + N * self.dim * 3
+        f += 2 * self.num_heads * N * (self.dim // self.num_heads) * N
+        return f + N * self.dim * self.dim + N * self.dim
+
+    def record_flops(self, nW, N):
+        """reference :394-411."""
+        d = nW * N * self.dim * self.dim
+        return {"q": d, "k": d, "v": d, "attn": 2 * nW * self.num_heads * N * (self.dim // self.num_heads) * N, "proj": d}
+
 
 class MS_Spiking_Mlp(nn.Module):
     """SN -> fc1 -> BN -> SN -> fc2 -> BN (reference :115-181)."""
@@ -159,6 +180,7 @@ class MS_Spiking_Mlp(nn.Module):
 
 class MS_Spiking_SwinTransformerBlock3D(nn.Module):
     """x += SSA(x); x += MLP(x) with membrane shortcuts (reference :720-895)."""
+    attn_module, mlp_module = None, None                  # set below the class bodies (MS: QK attention + MS MLP)
 
     def __init__(self, dim, input_resolution, num_heads, window_size=(2, 7, 7), pretrained_window_size=(0, 0, 0),
                  shift_size=(0, 0, 0), mlp_ratio=4.0, version="swinv1", qkv_bias=True, qk_scale=None, drop=0.0, attn_drop=0.0,
@@ -170,9 +192,24 @@ class MS_Spiking_SwinTransformerBlock3D(nn.Module):
         self.dim, self.input_resolution, self.num_heads = dim, input_resolution, num_heads
         self.window_size, self.shift_size, self.mlp_ratio = tuple(window_size), tuple(shift_size), mlp_ratio
         self.norm_layer, self.drop_path_rate, self.cnf = norm_layer, drop_path, "ADD"
-        self.attn = Spiking_QK_WindowAttention3D(dim, self.window_size, pretrained_window_size, num_heads, version, qkv_bias,
-                                                 qk_scale, attn_drop, drop, norm=norm_layer, **spiking_kwargs)
-        self.mlp = MS_Spiking_Mlp(dim, int(dim * mlp_ratio), norm_layer=norm_layer, drop=drop, **spiking_kwargs)
+        self.attn = self.attn_module(dim, self.window_size, pretrained_window_size, num_heads, version, qkv_bias,
+                                     qk_scale, attn_drop, drop, norm=norm_layer, **spiking_kwargs)
+        self.mlp = self.mlp_module(dim, int(dim * mlp_ratio), norm_layer=norm_layer, drop=drop, **spiking_kwargs)
+
+    def flops(self):
+        """Analytic MAC count of the reference (:849-866); the reference's MS block raises here because its QK attention has no
+        `flops()` - this build counts that attention's three Linear layers the way the SEW attention counts its own."""
+        H, W = self.input_resolution
+        nW = H * W // self.window_size[1] // self.window_size[2]
+        f = nW * self.attn.flops(self.window_size[0] * self.window_size[1] * self.window_size[2])
+        f += 2 * H * W * self.dim * self.dim * self.mlp_ratio
+        return f + H * W * self.dim * self.mlp_ratio + H * W * self.dim
+
+    def record_flops(self):
+        H, W = self.input_resolution
+        nW = H * W // self.window_size[1] // self.window_size[2]
+        return {"attn": self.attn.record_flops(nW, self.window_size[0] * self.window_size[1] * self.window_size[2]),
+                "mlp0": H * W * self.dim * self.dim * self.mlp_ratio, "mlp1": H * W * self.dim * self.dim * self.mlp_ratio}
 
 
 class MS_SpikingPatchMerging(nn.Module):
@@ -185,9 +222,19 @@ class MS_SpikingPatchMerging(nn.Module):
         self.norm = SpikingNormLayer(2 * dim, spiking_kwargs["num_steps"], norm_layer, spiking_kwargs["v_th"])
         self.sn = Spiking_neuron(**_neuron_kwargs(spiking_kwargs))
 
+    def flops(self):
+        """reference :936-941."""
+        H, W = self.input_resolution
+        return (H // 2) * (W // 2) * 4 * self.dim * 2 * self.dim + (H // 2) * (W // 2) * self.dim // 2
+
+    def record_flops(self):
+        H, W = self.input_resolution
+        return (H // 2) * (W // 2) * 4 * self.dim * 2 * self.dim
+
 
 class MS_Spiking_Swin_BasicLayer(nn.Module):
     """One stage: `depth` blocks alternating W-MSA / SW-MSA + optional patch merging (reference :995-1129)."""
+    swin_block_type = MS_Spiking_SwinTransformerBlock3D
 
     def __init__(self, dim, input_resolution, depth, num_heads, window_size=(1, 7, 7), pretrained_window_size=(1, 7, 7),
                  mlp_ratio=4.0, version="swinv1", qkv_bias=False, qk_scale=None, drop=0.0, attn_drop=0.0, drop_path=0.0,
@@ -197,16 +244,27 @@ class MS_Spiking_Swin_BasicLayer(nn.Module):
         self.window_size = tuple(window_size)
         self.shift_size = tuple(i // 2 for i in window_size)
         self.swin_blocks = nn.ModuleList([
-            MS_Spiking_SwinTransformerBlock3D(
+            self.swin_block_type(
                 dim, input_resolution, num_heads, self.window_size, pretrained_window_size,
                 (0, 0, 0) if i % 2 == 0 else self.shift_size, mlp_ratio, version, qkv_bias, qk_scale, drop, attn_drop,
                 drop_path[i] if isinstance(drop_path, list) else drop_path, norm_layer=norm_layer, **spiking_kwargs)
             for i in range(depth)])
         self.downsample = downsample(input_resolution, dim=dim, norm_layer=norm_layer, **spiking_kwargs) if downsample else None
 
+    def flops(self):
+        """reference :1109-1115."""
+        return sum(b.flops() for b in self.swin_blocks) + (self.downsample.flops() if self.downsample is not None else 0)
+
+    def record_flops(self):
+        rec = {f"block{i}": b.record_flops() for i, b in enumerate(self.swin_blocks)}
+        if self.downsample is not None:
+            rec["downsample"] = self.downsample.record_flops()
+        return rec
+
 
 class MS_Spiking_SwinTransformer3D_v2(nn.Module):
     """Backbone: patch embedding + stages (reference :1132-1292)."""
+    swin_layer_type, downsample_layer_type = MS_Spiking_Swin_BasicLayer, MS_SpikingPatchMerging
 
     def __init__(self, pretrained=None, pretrained2d=False, arc_type="swinv1", embed_type="PatchEmbedLocal", img_size=(320, 480),
                  patch_size=(4, 4, 4), in_chans=3, embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24),
@@ -225,9 +283,46 @@ class MS_Spiking_SwinTransformer3D_v2(nn.Module):
         dpr = [float(v) for v in np.linspace(0, drop_path_rate, sum(depths))]
         self.layers = nn.ModuleList()
         for i in range(self.num_layers):
-            self.layers.append(MS_Spiking_Swin_BasicLayer(
+            self.layers.append(self.swin_layer_type(
                 int(embed_dim * 2 ** i), (self.patches_resolution[0] // 2 ** i, self.patches_resolution[1] // 2 ** i), depths[i],
                 num_heads[i], window_size, pretrained_window_size, mlp_ratio, arc_type, qkv_bias, qk_scale, drop_rate,
                 attn_drop_rate, dpr[sum(depths[:i]):sum(depths[:i + 1])], norm_layer,
-                MS_SpikingPatchMerging if i < self.num_layers - 1 else None, use_checkpoint, **spiking_kwargs))
+                self.downsample_layer_type if i < self.num_layers - 1 else None, use_checkpoint, **spiking_kwargs))
         self.num_features = [int(embed_dim * 2 ** i) for i in range(self.num_layers)]
+
+    def flops(self):
+        """reference :1266-1274: patch embedding + stages."""
+        return self.patch_embed.flops() + sum(layer.flops() for layer in self.layers)
+
+    def record_flops(self):
+        rec = {"patch_embed": self.patch_embed.record_flops()}
+        for i, layer in enumerate(self.layers):
+            rec[f"layer{i}"] = layer.record_flops()
+        return rec
+
+
+MS_Spiking_SwinTransformerBlock3D.attn_module = Spiking_QK_WindowAttention3D
+MS_Spiking_SwinTransformerBlock3D.mlp_module = MS_Spiking_Mlp
+
+
+# ---------------------------------------------------------------------------------------------- SEW family (reference :115-162, :720-886, :898-950)
+class Spiking_Mlp(MS_Spiking_Mlp):
+    """fc1 -> BN -> SN -> fc2 -> BN -> SN (reference :115-162); same parameters as the MS variant, the SEW engine orders them."""
+
+
+class Spiking_SwinTransformerBlock3D(MS_Spiking_SwinTransformerBlock3D):
+    """x = SSA(x) + x; x = MLP(x) + x with spike-element-wise ADD shortcuts (reference :720-886)."""
+    attn_module, mlp_module = Spiking_BN_WindowAttention3D, Spiking_Mlp
+
+
+class SpikingPatchMerging(MS_SpikingPatchMerging):
+    """2x2 gather -> Linear 4C->2C -> BN -> SN (reference :898-950)."""
+
+
+class Spiking_Swin_BasicLayer(MS_Spiking_Swin_BasicLayer):
+    swin_block_type = Spiking_SwinTransformerBlock3D
+
+
+class Spiking_SwinTransformer3D_v2(MS_Spiking_SwinTransformer3D_v2):
+    """SEW backbone (reference :1132-1285)."""
+    swin_layer_type, downsample_layer_type = Spiking_Swin_BasicLayer, SpikingPatchMerging

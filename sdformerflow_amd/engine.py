@@ -177,6 +177,12 @@ class MSFlowEngine:
         self.proj_res_w = pe.proj.conv_res.weight.detach().contiguous(memory_format=torch.channels_last)
         self.proj_w = _conv_planes(pe.proj.conv.weight, ns)
         self.proj_bn, self.proj_sn = bn_affine(pe.proj.norm_layer, dev), _np(pe.proj.sn, dev)
+        self._maps, self._deconv = {}, {}
+        self.tape = None            # parity tests set a list: every neuron layer's spikes are recorded (see _rec)
+        self._init_stages(model, unet, sw, dev, ns, U)
+
+    def _init_stages(self, model, unet, sw, dev, ns, U):
+        """Everything behind the patch embedding (the SEW engine packs its own: engine_sew.SEWFlowEngine)."""
         self.stages, self.merges = [], []
         for li, layer in enumerate(sw.layers):
             self.stages.append([_Block(b, dev, ns, U + f"encoders.swin3d.layers.{li}.swin_blocks.{bi}.") for bi, b in enumerate(layer.swin_blocks)])
@@ -195,8 +201,6 @@ class MSFlowEngine:
             bp = torch.zeros(32, dtype=torch.float32, device=dev)
             bp[:w2.shape[0]] = p.conv[0].bias.detach().float()
             self.preds.append((hip.split_weight(wp, ns), bp, _np(p.sn, dev), w2.shape[0]))
-        self._maps, self._deconv = {}, {}
-        self.tape = None            # parity tests set a list: every neuron layer's spikes are recorded (see _rec)
 
     # ------------------------------------------------------------------ helpers
     def _slice_map(self, B, D, H, W, ws, ss):

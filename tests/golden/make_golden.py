@@ -248,6 +248,43 @@ def gold_end_to_end():
                 f.write(f"{k} {'x'.join(map(str, v.shape))}\n")
 
 
+# ------------------------------------------------------------------ 7b. SEW model family end to end
+def gold_sew_end_to_end():
+    """`SpikingformerFlowNet` (SEW shortcuts, 3 encoders) at 144 x 192, lif and psn: flow maps at native resolution, the AEE
+    tuple, the firing rate of every neuron layer in call order, and the state_dict schema."""
+    from models.STSwinNet_SNN.Spiking_STSwinNet import SpikingformerFlowNet
+    out = {}
+    for kind in ("lif", "psn"):
+        config = en4_config(kind)
+        config["swin_transformer"].update(input_size=[144, 192], swin_depths=[2, 2, 6], swin_num_heads=[3, 6, 12], swin_out_indices=[0, 1, 2])
+        model = SpikingformerFlowNet(config["model"].copy(), config["swin_transformer"].copy())
+        load_synth(model)
+        rates, hooks = [], []
+        for name, mod in model.named_modules():
+            if name.endswith("spiking_neuron"):
+                hooks.append(mod.register_forward_hook(lambda m, i, o, name=name: rates.append((name, float(o.mean())))))
+        vox = synth_voxel(1, 10, 144, 192, seed=1234 + 7)
+        chunk = torch.cat((torch.relu(vox).unsqueeze(2), torch.relu(-vox).unsqueeze(2)), dim=2)
+        lo, hi = chunk[chunk != 0].min(), chunk[chunk != 0].max()
+        chunk[chunk != 0] = (chunk[chunk != 0] - lo) / (hi - lo)
+        functional.reset_net(model)
+        res = model(chunk)
+        for h in hooks:
+            h.remove()
+        for i, f in enumerate(res["flow"]):
+            s = f.shape[-1] // (24 * 2 ** i)
+            out[f"{kind}_flow{i}"] = f[:, :, ::s, ::s].contiguous()
+        label, mask = synth_label(1, 144, 192)
+        m = AEE(res["flow"][-1], label, mask, 1)()
+        out[f"{kind}_aee"] = np.array([float(v.reshape(-1)[0]) for v in m])
+        out[f"{kind}_rates"] = np.array([r for _, r in rates], dtype=np.float32)
+        out[f"{kind}_rate_names"] = np.array([n for n, _ in rates])
+        with open(os.path.join(HERE, f"state_schema_sew_{kind}.txt"), "w") as f:
+            for k, v in model.state_dict().items():
+                f.write(f"{k} {'x'.join(map(str, v.shape))}\n")
+    save("sew_end_to_end", **out)
+
+
 # ------------------------------------------------------------------ 8. ANN STTFlowNet end to end (BASELINE config 3 family)
 def gold_ann_end_to_end():
     from models.STSwinNet.STSwinNet import STTFlowNet, STTFlowNet_4en
@@ -465,7 +502,7 @@ def gold_formats():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["neurons", "index_maps", "qk_attention", "sew_attention", "ann_attention",
-                             "ms_block", "end_to_end", "ann_end_to_end", "formats", "neuron_grads", "train_block", "train_step", "ms_block_config5"]
+                             "ms_block", "end_to_end", "sew_end_to_end", "ann_end_to_end", "formats", "neuron_grads", "train_block", "train_step", "ms_block_config5"]
     for w in which:
         globals()["gold_" + w]()
 
