@@ -98,3 +98,33 @@ def test_config5_shape_T20_odd_sizes():
 
 def test_mdr_configuration_window8_T5_psn():
     check("psn", 1, (256, 256), 92, en4=False, T=5, window=(2, 8, 8))
+
+
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+def test_sew_family_free_running_forward(kind):
+    """`SpikingformerFlowNet` (SEW shortcuts: the stream carries sums of spikes; dense library GEMMs / convolutions where a
+    layer reads it, spike kernels where a layer reads spikes, the fused SEW window-attention kernel with the shift mask) -
+    the same statement as for the MS models: every neuron layer delta-consistent, flows equal to the replayed reference."""
+    from sdformerflow_amd.STSwinNet_SNN.Spiking_STSwinNet import SpikingformerFlowNet
+    cfg = yaml.safe_load(open(CFG))
+    cfg["model"]["spiking_neuron"] = dict(cfg["spiking_neuron"], neuron_type=kind)
+    cfg["swin_transformer"].update(input_size=[144, 192], swin_depths=[2, 2, 6], swin_num_heads=[3, 6, 12], swin_out_indices=[0, 1, 2])
+    model = SpikingformerFlowNet(cfg["model"].copy(), cfg["swin_transformer"].copy())
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()
+                           if not k.endswith(("relative_position_index",))})
+    model.load_state_dict(sd, strict=False)
+    model = model.eval().to(DEV)
+    sd = {k: v for k, v in model.state_dict().items()}
+    sd = {k: v.cpu() for k, v in sd.items() if not k.endswith("num_batches_tracked")}
+    ocfg = {"neuron": O.NeuronCfg(kind, 0.1, None, 2.0, 10), "num_bins": 10, "window_size": (2, 9, 9), "depths": [2, 2, 6],
+            "num_heads": [3, 6, 12]}
+    chunk = harness.prepare_chunk(synth_voxel(1, 10, 144, 192, seed=1234 + 7))
+    flows, ref, report = replay.run(model.engine(), chunk.to(DEV), chunk, sd, lambda c: O.forward_sew_flownet(c, sd, ocfg))
+    summ = replay.summarise(report)
+    print(f"SEW {kind}: {summ}")
+    assert summ["layers_forced"] == 75 and summ["layers_free"] == 0 and summ["unexplained"] == 0, summ
+    devs = [float((g.cpu() - r).abs().max() / r.abs().max()) for g, r in zip(flows, ref)]
+    print("    flows vs replayed reference:", ["%.1e" % d for d in devs])
+    assert max(devs) <= FLOW_TOL, devs
+    out = model(chunk.to(DEV))
+    assert out["attn"] is None and all(torch.equal(a, b) for a, b in zip(out["flow"], flows))
