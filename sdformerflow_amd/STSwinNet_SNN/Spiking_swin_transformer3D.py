@@ -80,6 +80,10 @@ class Spiking_QK_WindowAttention3D(nn.Module):
         self.proj_bn = SpikingNormLayer(dim, self.window_size[0], norm, spiking_kwargs["v_th"])
         self.proj_sn = Spiking_neuron(**kw)
 
+    def forward(self, x, mask=None):
+        from ..module_forward import qk_attention_forward
+        return qk_attention_forward(self, x, mask)
+
     def flops(self, N):
         """MACs of one window of N tokens.  The reference class has no `flops()` (its model-level `flops()` raises for the
         shipped MS model); counted here like its SEW sibling (:377-392) with what this attention really
@@ -128,15 +132,14 @@ class Spiking_BN_WindowAttention3D(nn.Module):
             Tq, B_, Wh, Ww, C = x.shape
             N1, dev, nsplit = Wh * Ww, x.device, 2
             M, n = Tq * B_ * N1, B_ * N1 * C
-            xs = x.reshape(M, C).to(torch.uint8).contiguous()               # SEW blocks feed spikes
-            f = torch.empty((M, C), dtype=torch.float32, device=dev)
+            xs = x.reshape(M, C).float().contiguous()                       # the SEW stream carries SUMS of spikes: dense projections
             spk = {}
             for name in ("q", "k", "v"):
                 lin, bn, sn = getattr(self, f"linear_{name}"), getattr(self, f"bn_{name}"), getattr(self, f"sn_{name}")
                 a, b = bn_affine(bn.norm_layer, dev)
-                hip.spike_gemm(xs, hip.split_weight(lin.weight.detach().float(), nsplit), f, M, C, C, alpha=a, beta=b)
+                f = torch.mm(xs, lin.weight.detach().float().t())
                 spk[name] = torch.empty((M, C), dtype=torch.uint8, device=dev)
-                hip.neuron_fwd(f, spk[name], Tq, 1, n, 0, n, 0, n, _np(sn, dev))
+                hip.neuron_fwd(f, spk[name], Tq, 1, n, 0, n, 0, n, _np(sn, dev), alpha=a, beta=b, Cch=C, inner=1)
             N = Tq * N1
             idx = self.relative_position_index[:N, :N].reshape(-1)
             bias = self.relative_position_bias_table.detach()[idx].reshape(N, N, -1).permute(2, 0, 1).contiguous()
@@ -177,6 +180,10 @@ class MS_Spiking_Mlp(nn.Module):
         self.bn2 = SpikingNormLayer(out_features, spiking_kwargs["num_steps"], spiking_kwargs["spike_norm"], spiking_kwargs["v_th"])
         self.sn2 = Spiking_neuron(**kw)
 
+    def forward(self, x):
+        from ..module_forward import ms_mlp_forward
+        return ms_mlp_forward(self, x)
+
 
 class MS_Spiking_SwinTransformerBlock3D(nn.Module):
     """x += SSA(x); x += MLP(x) with membrane shortcuts (reference :720-895)."""
@@ -195,6 +202,10 @@ class MS_Spiking_SwinTransformerBlock3D(nn.Module):
         self.attn = self.attn_module(dim, self.window_size, pretrained_window_size, num_heads, version, qkv_bias,
                                      qk_scale, attn_drop, drop, norm=norm_layer, **spiking_kwargs)
         self.mlp = self.mlp_module(dim, int(dim * mlp_ratio), norm_layer=norm_layer, drop=drop, **spiking_kwargs)
+
+    def forward(self, x, mask_matrix=None, return_attention=False):
+        from ..module_forward import ms_block_forward
+        return ms_block_forward(self, x, mask_matrix, return_attention)
 
     def flops(self):
         """Analytic MAC count of the reference (:849-866); the reference's MS block raises here because its QK attention has no
@@ -221,6 +232,10 @@ class MS_SpikingPatchMerging(nn.Module):
         self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
         self.norm = SpikingNormLayer(2 * dim, spiking_kwargs["num_steps"], norm_layer, spiking_kwargs["v_th"])
         self.sn = Spiking_neuron(**_neuron_kwargs(spiking_kwargs))
+
+    def forward(self, x):
+        from ..module_forward import ms_patch_merging_forward
+        return ms_patch_merging_forward(self, x)
 
     def flops(self):
         """reference :936-941."""
@@ -309,14 +324,26 @@ MS_Spiking_SwinTransformerBlock3D.mlp_module = MS_Spiking_Mlp
 class Spiking_Mlp(MS_Spiking_Mlp):
     """fc1 -> BN -> SN -> fc2 -> BN -> SN (reference :115-162); same parameters as the MS variant, the SEW engine orders them."""
 
+    def forward(self, x):
+        from ..module_forward import sew_mlp_forward
+        return sew_mlp_forward(self, x)
+
 
 class Spiking_SwinTransformerBlock3D(MS_Spiking_SwinTransformerBlock3D):
     """x = SSA(x) + x; x = MLP(x) + x with spike-element-wise ADD shortcuts (reference :720-886)."""
     attn_module, mlp_module = Spiking_BN_WindowAttention3D, Spiking_Mlp
 
+    def forward(self, x, mask_matrix=None, return_attention=False):
+        from ..module_forward import sew_block_forward
+        return sew_block_forward(self, x, mask_matrix, return_attention)
+
 
 class SpikingPatchMerging(MS_SpikingPatchMerging):
     """2x2 gather -> Linear 4C->2C -> BN -> SN (reference :898-950)."""
+
+    def forward(self, x):
+        from ..module_forward import sew_patch_merging_forward
+        return sew_patch_merging_forward(self, x)
 
 
 class Spiking_Swin_BasicLayer(MS_Spiking_Swin_BasicLayer):

@@ -155,6 +155,17 @@ def deconv_tap_weights(w, cin_pad, nsplit):
 
 
 class MSFlowEngine:
+    @classmethod
+    def bare(cls, device, nsplit=2):
+        """An engine without a model: the helpers (index maps, kernels, tape) for module-level `forward()` calls - the
+        block-level classes of the module tree pack themselves and run through the same methods the model does."""
+        e = cls.__new__(cls)
+        if torch.device(device).type != "cuda":
+            raise hip.SdfError("module forwards run on the MI355X HIP engine only (no CPU fallback): move the module and its input to 'cuda'")
+        hip.lib()
+        e.device, e.nsplit, e._maps, e._deconv, e.tape, e._masks = torch.device(device), nsplit, {}, {}, None, {}
+        return e
+
     def __init__(self, model):
         self.device = next(model.parameters()).device
         if self.device.type != "cuda":
@@ -374,9 +385,9 @@ class MSFlowEngine:
         blk = self.stages[s][i]
         return self.mlp(self.attention(x, blk), blk)
 
-    def patch_merge(self, x, s):
+    def patch_merge(self, x, s, packed=None):
         """(B,D,H,W,C) -> (B,D,H/2,W/2,2C) (reference :952-974)."""
-        lin, sn = self.merges[s]
+        lin, sn = self.merges[s] if packed is None else packed
         self._check_cl(x)
         B, D, H, W, Cc = x.shape
         rowmap, H2, W2, out_map = self._merge_map(B, D, H, W)

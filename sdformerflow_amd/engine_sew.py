@@ -127,9 +127,9 @@ class SEWFlowEngine(MSFlowEngine):
         x = self.attention(x, blk) + x                                            # SEW ADD (:840)
         return self.mlp(x, blk) + x                                               # (:845)
 
-    def patch_merge(self, x, s):
+    def patch_merge(self, x, s, packed=None):
         """2x2 gather -> Linear -> BN -> SN (reference :914-934): spikes (B,D,H/2,W/2,2C) fp32."""
-        w_t, bn, sn = self.merges[s]
+        w_t, bn, sn = self.merges[s] if packed is None else packed
         self._check_cl(x)
         B, D, H, W, Cc = x.shape
         rowmap, H2, W2, _ = self._merge_map(B, D, H, W)
