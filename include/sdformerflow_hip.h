@@ -444,6 +444,13 @@ typedef struct SdfWinAttnDesc {
   const float* scale;       /* (nH) */
   const float* bias;        /* (nH,N,N) */
   const float* mask;        /* (nW,N,N) or NULL */
+  /* ANN mode, optional in-kernel windowing (replaces F.pad + torch.roll + window_partition in front of the attention and
+   * window_reverse + roll back + crop behind it, reference swin_transformer3D_v2.py:286-310): row_map[b_*N + n] = row of
+   * token n of window b_ in the un-partitioned (rows, 3C) qkv buffer and (rows, C) output buffer (the table of
+   * sdf_window_slice_map), or -1 for a padding token; a padding token's q | k | v is pad_qkv (3C floats: what the qkv
+   * Linear makes of a zero row, i.e. its bias) and its output row is dropped.  NULL = q and out are window-major. */
+  const int32_t* row_map;
+  const float* pad_qkv;
 } SdfWinAttnDesc;
 
 int sdf_win_attn_fwd(const SdfWinAttnDesc* d, void* stream);

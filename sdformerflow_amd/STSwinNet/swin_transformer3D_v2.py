@@ -3,6 +3,7 @@
 `WindowAttention3D` :87-205, whose score / bias / mask / softmax / .V core runs in one fused MFMA kernel
 (csrc/win_attn.hip) and whose two projections are plain library GEMMs (rocBLAS through torch)."""
 import math
+import os
 from functools import lru_cache
 
 import numpy as np
@@ -98,6 +99,16 @@ class WindowAttention3D(nn.Module):
             o = hip.win_attn_ann(qkv, scale, self.position_bias(), None if mask is None else mask.contiguous(), self.num_heads)
             return self.proj(o), None
 
+    def forward_rows(self, y2, row_map, B_, mask):
+        """Attention on un-partitioned rows y2 (rows, C): windows are formed by `row_map` inside the kernel -> (rows, C)."""
+        with torch.no_grad():
+            qkv = self.qkv(y2).contiguous()
+            pad = self.qkv.bias.detach().float().contiguous() if self.qkv.bias is not None else torch.zeros(3 * self.dim, device=y2.device)
+            scale = torch.clamp(self.logit_scale, max=math.log(1.0 / 0.01)).exp().reshape(-1).contiguous()
+            N = self.window_size[0] * self.window_size[1] * self.window_size[2]
+            o = hip.win_attn_ann_windowed(qkv, row_map, B_, N, pad, scale, self.position_bias(), mask, self.num_heads)
+            return self.proj(o)
+
 
 class Mlp(nn.Module):
     """fc1 -> GELU -> fc2 (reference :15-34; dropout is identity in eval)."""
@@ -125,24 +136,35 @@ class SwinTransformerBlock3D(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
+    _maps = {}
+
     def forward(self, x, mask_matrix=None):
+        """forward_part1 + forward_part2 (reference :272-313).  The reference pads, rolls and partitions LN(x) into windows and
+        reverses all of that behind the attention (:286-310); here the qkv projection runs on the un-partitioned rows and the
+        attention kernel reads / writes them through the slice map (index arithmetic inside the kernel, nothing materialised):
+        the projection is row-wise, so it commutes with the permutation; a padding token is a zero row, whose q | k | v is the
+        qkv bias.  `SDF_ATTN_MATERIALISE=1` keeps the reference's sequence as the A/B path."""
         B, D, H, W, C = x.shape
         ws, ss = get_window_size((D, H, W), self.window_size, self.shift_size)
         y = self.norm1(x)
-        pd, pb, pr = (-D) % ws[0], (-H) % ws[1], (-W) % ws[2]
-        y = F.pad(y, (0, 0, 0, pr, 0, pb, 0, pd))
-        Dp, Hp, Wp = y.shape[1:4]
+        Dp, Hp, Wp = D + (-D) % ws[0], H + (-H) % ws[1], W + (-W) % ws[2]
         shifted = any(s > 0 for s in ss)
-        if shifted:
-            y = torch.roll(y, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
-            mask = mask_matrix if mask_matrix is not None else compute_mask(Dp, Hp, Wp, ws, ss, x.device)
+        mask = (mask_matrix if mask_matrix is not None else compute_mask(Dp, Hp, Wp, ws, ss, x.device)) if shifted else None
+        if os.environ.get("SDF_ATTN_MATERIALISE") == "1" or self.training:
+            y = F.pad(y, (0, 0, 0, Wp - W, 0, Hp - H, 0, Dp - D))
+            if shifted:
+                y = torch.roll(y, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
+            a, _ = self.attn(window_partition(y, ws), mask)
+            a = window_reverse(a, ws, B, Dp, Hp, Wp)
+            if shifted:
+                a = torch.roll(a, shifts=ss, dims=(1, 2, 3))
+            x = x + a[:, :D, :H, :W]
         else:
-            mask = None
-        a, _ = self.attn(window_partition(y, ws), mask)
-        a = window_reverse(a, ws, B, Dp, Hp, Wp)
-        if shifted:
-            a = torch.roll(a, shifts=ss, dims=(1, 2, 3))
-        x = x + a[:, :D, :H, :W]
+            key = (B, D, H, W, ws, ss, str(x.device))
+            if key not in SwinTransformerBlock3D._maps:
+                SwinTransformerBlock3D._maps[key] = hip.window_slice_map(B, D, H, W, ws, ss, x.device)
+            row_map, B_ = SwinTransformerBlock3D._maps[key]
+            x = x + self.attn.forward_rows(y.reshape(-1, C), row_map, B_, None if mask is None else mask.contiguous()).view(B, D, H, W, C)
         return x + self.mlp(self.norm2(x))
 
 

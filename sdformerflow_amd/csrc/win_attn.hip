@@ -30,6 +30,15 @@ struct AttnParams {
   SdfWinAttnDesc d;
 };
 
+// ANN mode: first float of the q | k | v row of token r of window b.  With a row map the window partition (pad, roll, reshape)
+// is this lookup; a padding token reads the qkv Linear's image of a zero row.
+__device__ __forceinline__ const float* qkv_row(const SdfWinAttnDesc& d, int b, int r, int C) {
+  const float* q = reinterpret_cast<const float*>(d.q);
+  if (!d.row_map) return q + ((int64_t)b * d.N + r) * 3 * C;
+  const int row = d.row_map[(int64_t)b * d.N + r];
+  return row >= 0 ? q + (int64_t)row * 3 * C : d.pad_qkv;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void win_attn_kernel(AttnParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -51,7 +60,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(AttnParams P) {
     for (int i = 0; i < 8; ++i) qv[i] = kv[i] = vv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < N) {
       if (MODE == SDF_ATTN_ANN) {
-        const float* base = reinterpret_cast<const float*>(d.q) + ((int64_t)b * N + r) * 3 * C + g * HD;
+        const float* base = qkv_row(d, b, r, C) + g * HD;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           qv[i] = *reinterpret_cast<const float4*>(base + 4 * i);
@@ -203,7 +212,9 @@ __global__ __launch_bounds__(256) void win_attn_kernel(AttnParams P) {
       if (i < N) {
         int64_t off;
         if (MODE == SDF_ATTN_ANN) {
-          off = ((int64_t)b * N + i) * C + g * HD;                           // (attn@v).transpose(1,2).reshape(B_,N,C)
+          const int64_t orow = d.row_map ? d.row_map[(int64_t)b * N + i] : (int64_t)b * N + i;
+          if (orow < 0) continue;                                            // padding token: cropped away by the reference
+          off = orow * C + g * HD;                                           // (attn@v).transpose(1,2).reshape(B_,N,C) [+ window reverse]
         } else {
           const int t = i / d.N1, n1 = i - t * d.N1;                         // (B_,nH,T',N1,hd) -> (T',B_,N1,C)
           off = (((int64_t)t * d.B_ + b) * d.N1 + n1) * C + g * HD;
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
     for (int i = 0; i < 8; ++i) qr[i] = 0.f;
     if (MODE == SDF_ATTN_ANN) {
       if (qi < N) {
-        const float* base = reinterpret_cast<const float*>(d.q) + ((int64_t)b * N + qi) * 3 * C + g * HD + 8 * lg;
+        const float* base = qkv_row(d, b, qi, C) + g * HD + 8 * lg;
         const float4 a = *reinterpret_cast<const float4*>(base), c = *reinterpret_cast<const float4*>(base + 4);
         qr[0] = a.x; qr[1] = a.y; qr[2] = a.z; qr[3] = a.w; qr[4] = c.x; qr[5] = c.y; qr[6] = c.z; qr[7] = c.w;
       }
@@ -316,7 +327,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
       kq[it] = vq[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r < N) {
         if (MODE == SDF_ATTN_ANN) {
-          const float* base = reinterpret_cast<const float*>(d.q) + ((int64_t)b * N + r) * 3 * C + g * HD + 4 * piece;
+          const float* base = qkv_row(d, b, r, C) + g * HD + 4 * piece;
           kq[it] = *reinterpret_cast<const float4*>(base + C);
           vq[it] = *reinterpret_cast<const float4*>(base + 2 * C);
         } else {
@@ -473,7 +484,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
       if (i < N) {
         int64_t off;
         if (MODE == SDF_ATTN_ANN) {
-          off = ((int64_t)b * N + i) * C + g * HD;
+          const int64_t orow = d.row_map ? d.row_map[(int64_t)b * N + i] : (int64_t)b * N + i;   // window reverse + roll back + crop
+          if (orow < 0) continue;
+          off = orow * C + g * HD;
         } else {
           const int t = i / d.N1, n1 = i - t * d.N1;
           off = (((int64_t)t * d.B_ + b) * d.N1 + n1) * C + g * HD;
@@ -507,6 +520,7 @@ extern "C" int sdf_win_attn_fwd(const SdfWinAttnDesc* d, void* stream) {
   if (d->hd != HD || d->B_ < 1 || d->nH < 1 || d->N < 1 || d->N > 16 * NT_MAX) return SDF_E_SHAPE;
   if (d->mask && (d->nW < 1 || d->B_ % d->nW)) return SDF_E_SHAPE;
   if (d->mode == SDF_ATTN_SEW && (d->Tq < 1 || d->N1 < 1 || d->Tq * d->N1 != d->N)) return SDF_E_SHAPE;
+  if (d->row_map && (d->mode != SDF_ATTN_ANN || !d->pad_qkv)) return SDF_E_NULL;   // windowing through the map: ANN form, needs the pad row
   if (!sdf_aligned(d->q, d->mode == SDF_ATTN_ANN ? 16 : 4) || !sdf_aligned(d->out, 4)) return SDF_E_ALIGN;
   AttnParams P;
   P.d = *d;

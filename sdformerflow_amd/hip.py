@@ -79,7 +79,7 @@ class WinAttnDesc(C.Structure):
     _fields_ = [("mode", C.c_int32), ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("out", C.c_void_p),
                 ("B_", C.c_int32), ("nW", C.c_int32), ("nH", C.c_int32), ("N", C.c_int32), ("hd", C.c_int32),
                 ("Tq", C.c_int32), ("N1", C.c_int32),
-                ("scale", C.c_void_p), ("bias", C.c_void_p), ("mask", C.c_void_p)]
+                ("scale", C.c_void_p), ("bias", C.c_void_p), ("mask", C.c_void_p), ("row_map", C.c_void_p), ("pad_qkv", C.c_void_p)]
 
 
 _lib = None
@@ -600,6 +600,21 @@ def affine_resid(x, alpha, beta, Cch, inner, resid=None, out=None):
                                     C.c_void_p(_ptr(out, torch.float32)), C.c_int64(x.numel()), C.c_int(Cch),
                                     C.c_int64(inner), _stream())
     _check(rc, "sdf_affine_resid_fwd")
+    return out
+
+
+def win_attn_ann_windowed(qkv, row_map, B_, N, pad_qkv, scale, bias, mask, nH):
+    """The same with the window partition / reverse INSIDE the kernel: qkv (rows, 3C) fp32 in the activation's own row order,
+    row_map (B_*N,) int32 from `window_slice_map` (pad + roll + partition; -1 = padding token, which reads `pad_qkv` (3C) and
+    writes nothing) -> (rows, C) in the activation's row order (window reverse + roll back + crop), untouched rows zero."""
+    rows, C3 = qkv.shape
+    out = torch.zeros((rows, C3 // 3), dtype=torch.float32, device=qkv.device)
+    d = WinAttnDesc()
+    d.mode, d.q, d.k, d.v, d.out = 0, _ptr(qkv, torch.float32), _ptr(qkv), _ptr(qkv), _ptr(out)
+    d.B_, d.nW, d.nH, d.N, d.hd = B_, (mask.shape[0] if mask is not None else 1), nH, N, C3 // 3 // nH
+    d.scale, d.bias, d.mask = _ptr(scale, torch.float32), _ptr(bias, torch.float32), _ptr(mask, torch.float32)
+    d.row_map, d.pad_qkv = _ptr(row_map, torch.int32), _ptr(pad_qkv, torch.float32)
+    _check(lib().sdf_win_attn_fwd(C.byref(d), _stream()), "sdf_win_attn_fwd")
     return out
 
 

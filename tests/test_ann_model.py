@@ -90,3 +90,29 @@ def test_sttflownet_4en_matches_oracle():
     for i, (a, b) in enumerate(zip(got, ref)):
         d = (a.cpu() - b).abs().max().item()
         assert d <= 1e-3 * b.abs().mean().item(), (i, d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift", [(0, 0, 0), (1, 4, 4)])
+def test_window_partition_inside_the_attention_kernel_equals_the_materialised_sequence(shift):
+    """`SwinTransformerBlock3D.forward` reads / writes the attention's rows through the slice map inside the kernel; the
+    reference's pad + roll + window_partition ... window_reverse + roll + crop sequence (swin_transformer3D_v2.py:286-310) is
+    kept as the `SDF_ATTN_MATERIALISE=1` A/B path.  Odd sizes (padding tokens read the qkv bias and write nothing), shift with
+    mask, batch 2; equal up to the library GEMM's row-count-dependent rounding (the projections run on different row orders)."""
+    from sdformerflow_amd.STSwinNet.swin_transformer3D_v2 import SwinTransformerBlock3D
+    from sdformerflow_amd.synthetic import synth_uniform as rnd
+    blk = SwinTransformerBlock3D(96, 3, window_size=(2, 9, 9), shift_size=shift, qkv_bias=True)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in blk.state_dict().items()
+                           if not k.endswith(("relative_position_index", "relative_coords_table"))})
+    blk.load_state_dict(sd, strict=False)
+    blk = blk.to("cuda:0").eval()
+    x = rnd((2, 3, 20, 25, 96), 61, -1.0, 1.0).to("cuda:0")              # D = 3 -> 4, H = 20 -> 27, W = 25 -> 27 padded
+    with torch.no_grad():
+        fused = blk(x)
+        os.environ["SDF_ATTN_MATERIALISE"] = "1"
+        try:
+            ref = blk(x)
+        finally:
+            os.environ.pop("SDF_ATTN_MATERIALISE", None)
+    assert fused.shape == ref.shape == x.shape
+    assert (fused - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
