@@ -180,6 +180,52 @@ __global__ __launch_bounds__(256) void neuron_kernel(NeuronParams P) {
   }
 }
 
+// One neuron per lane, any N: the contiguous (T, N) entry points use it when N is not a multiple of 4 (rows of such a
+// buffer are not 16-byte aligned, so the streaming kernel's float4 accesses do not apply).  Same op sequence.
+__global__ __launch_bounds__(256) void neuron_scalar_kernel(const float* __restrict__ x, void* __restrict__ out, float* __restrict__ v_last,
+                                                            int T, int64_t N, int kind, float tau, float inv_tau, float v_th,
+                                                            float v_reset, int soft_i, int out_dtype, const float* __restrict__ psn_w,
+                                                            const float* __restrict__ psn_b) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const bool soft = soft_i != 0;
+  auto put = [&](int t, float sp) {
+    if (out_dtype == SDF_F32) reinterpret_cast<float*>(out)[(int64_t)t * N + n] = sp;
+    else reinterpret_cast<uint8_t*>(out)[(int64_t)t * N + n] = sp != 0.f ? 1 : 0;
+  };
+  if (kind == SDF_PSN) {
+    for (int t = 0; t < T; ++t) {
+      float h = psn_b[t];
+      for (int k = 0; k < T; ++k) h = __builtin_fmaf(psn_w[t * T + k], x[(int64_t)k * N + n], h);
+      put(t, h >= 0.f ? 1.f : 0.f);
+    }
+    return;
+  }
+  const bool reset0 = soft || v_reset == 0.f;
+  float v = soft ? 0.f : v_reset;
+  for (int t = 0; t < T; ++t) {
+    const float xt = x[(int64_t)t * N + n];
+    const float h = kind == SDF_IF ? v + xt : lif_charge(v, xt, tau, inv_tau, v_reset, reset0);
+    put(t, fire_reset(v, h, v_th, v_reset, soft));
+  }
+  if (v_last) v_last[n] = v;
+}
+
+int launch_scalar(const float* x, void* spike, float* v_last, int T, int64_t N, int kind, float tau, float v_th, int soft_reset,
+                  float v_reset, int spike_dtype, const float* W, const float* b, void* stream) {
+  if (!x || !spike) return SDF_E_NULL;
+  if (T < 1 || N < 1) return SDF_E_SHAPE;
+  if (spike_dtype != SDF_F32 && spike_dtype != SDF_U8) return SDF_E_DTYPE;
+  if (kind == SDF_PSN && (!W || !b)) return SDF_E_NULL;
+  if (kind == SDF_LIF && !(tau > 1.f)) return SDF_E_SHAPE;
+  int ex;
+  const float inv_tau = (kind == SDF_LIF && frexpf(tau, &ex) == 0.5f) ? 1.0f / tau : 0.f;
+  hipLaunchKernelGGL(neuron_scalar_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, sdf_stream(stream), x, spike, v_last, T, N,
+                     kind, tau, inv_tau, v_th, v_reset, soft_reset, spike_dtype, W, b);
+  SDF_LAUNCH_CHECK();
+  return 0;
+}
+
 int validate(const SdfNeuronDesc& d) {
   if (!d.x || !d.out) return SDF_E_NULL;
   if (d.T < 1 || d.nb < 1 || d.ni < 4) return SDF_E_SHAPE;
@@ -238,6 +284,7 @@ extern "C" int sdf_neuron_fwd(const SdfNeuronDesc* dp, void* stream) {
 
 extern "C" int sdf_lif_fwd(const float* x, void* spike, float* v_last, int T, int64_t N, float tau, float v_th,
                            int soft_reset, float v_reset, int spike_dtype, void* stream) {
+  if (N % 4) return launch_scalar(x, spike, v_last, T, N, SDF_LIF, tau, v_th, soft_reset, v_reset, spike_dtype, nullptr, nullptr, stream);
   SdfNeuronDesc d = {};
   d.x = x; d.out = spike; d.v_last = v_last; d.T = T; d.out_dtype = spike_dtype;
   d.nb = 1; d.ni = N; d.x_sb = 0; d.x_st = N; d.o_sb = 0; d.o_st = N;
@@ -247,6 +294,8 @@ extern "C" int sdf_lif_fwd(const float* x, void* spike, float* v_last, int T, in
 
 extern "C" int sdf_psn_fwd(const float* x, const float* W, const float* b, void* spike, int T, int64_t N,
                            int spike_dtype, void* stream) {
+  if (N % 4 || (T != 1 && T != 2 && T != 4 && T != 5 && T != 8 && T != 10 && T != 16 && T != 20))
+    return launch_scalar(x, spike, nullptr, T, N, SDF_PSN, 2.f, 0.f, 1, 0.f, spike_dtype, W, b, stream);
   SdfNeuronDesc d = {};
   d.x = x; d.out = spike; d.T = T; d.out_dtype = spike_dtype;
   d.nb = 1; d.ni = N; d.x_sb = 0; d.x_st = N; d.o_sb = 0; d.o_st = N;

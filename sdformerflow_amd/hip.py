@@ -187,11 +187,8 @@ def _unpad4(out, info):
 
 
 def lif_fwd(x, tau=2.0, v_th=1.0, v_reset=None, out_dtype=torch.float32, return_v=False):
-    """Multi-step LIF over dim 0 of a contiguous tensor (sdf_lif_fwd)."""
-    (x,), info = _pad4(x)
-    if info is not None:
-        out = lif_fwd(x, tau, v_th, v_reset, out_dtype, return_v)
-        return (_unpad4(out[0], info), out[1][:info[1]].reshape(info[0][1:])) if return_v else _unpad4(out, info)
+    """Multi-step LIF over dim 0 of a contiguous tensor (sdf_lif_fwd; any per-step size - the library handles N % 4 != 0)."""
+    x = x.contiguous()
     T, N = x.shape[0], x[0].numel()
     out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     v = torch.empty(x.shape[1:], dtype=torch.float32, device=x.device) if return_v else None
@@ -245,10 +242,8 @@ def psn_bwd(x, W, b, grad_spike, alpha=2.0, need_param_grads=True):
 
 
 def psn_fwd(x, W, b, out_dtype=torch.float32):
-    """Parallel spiking neuron over dim 0 of a contiguous tensor (sdf_psn_fwd)."""
-    (x,), info = _pad4(x)
-    if info is not None:
-        return _unpad4(psn_fwd(x, W, b, out_dtype), info)
+    """Parallel spiking neuron over dim 0 of a contiguous tensor (sdf_psn_fwd; any per-step size)."""
+    x = x.contiguous()
     T, N = x.shape[0], x[0].numel()
     out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     rc = lib().sdf_psn_fwd(C.c_void_p(_ptr(x, torch.float32)), C.c_void_p(_ptr(W.contiguous(), torch.float32)),

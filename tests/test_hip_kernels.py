@@ -31,6 +31,20 @@ def test_lif_bit_exact(T, v_reset):
         assert torch.equal(v.cpu(), vref)
 
 
+@pytest.mark.parametrize("N", [1, 3, 243, 2 * 5 * 81 * 3 + 1])
+def test_lif_and_psn_any_per_step_size_through_the_c_abi(N):
+    """sdf_lif_fwd / sdf_psn_fwd with N % 4 != 0 (e.g. the (T', B_, 81, nH) token gate): served by the library itself - a C
+    caller needs no padding; bit-equal to the C oracle, spikes and final membrane."""
+    for T in (2, 7, 10):
+        x = rnd((T, N), 300 + N + T, -0.3, 0.6)
+        for v_reset in (None, 0.05):
+            ref, vref = R.neuron_ref(x, "lif", 2.0, 0.1, v_reset, return_aux=True)
+            s, v = hip.lif_fwd(x.to(DEV), 2.0, 0.1, v_reset, torch.uint8, return_v=True)
+            assert torch.equal(s.cpu().float(), ref) and torch.equal(v.cpu(), vref)
+        W, b = rnd((T, T), 5 + T, -0.5, 0.5) + 0.5 * torch.eye(T), torch.full((T, 1), -0.1)
+        assert torch.equal(hip.psn_fwd(x.to(DEV), W.to(DEV), b.to(DEV)).cpu(), R.neuron_ref(x, "psn", psn_w=W, psn_b=b))
+
+
 def test_lif_non_power_of_two_tau():
     x = neuron_input(10)
     ref = R.neuron_ref(x, "lif", 3.0, 0.1, None)
