@@ -34,8 +34,11 @@ PEAK_BF16_DENSE_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: ~2
 PEAK_HBM_GBPS = 8000.0              # same guide: 8.0 TB/s spec (6.3 TB/s achievable)
 # HBM bytes per launch of the roofline shape from the PMC counters.  They cannot be read inside this process (rocprofv3 owns the
 # counters), so the figure is the one measured by tools/pmc_traffic.sh on the build named in CONV_TRAFFIC_SOURCE
-CONV_TRAFFIC_BYTES = None
-CONV_TRAFFIC_SOURCE = "not measured yet for this build (tools/pmc_traffic.sh)"
+CONV_TRAFFIC_BYTES = (2 * 95125.3 + 129600.0) * 1024        # digit-plane kernel, fused LIF + membrane form
+CONV_TRAFFIC_SOURCE = ("NOT measured in this run: profiles/r2e_pmc_traffic_conv_fused_membrane.txt (round-2 build r2e, tools/pmc_traffic.sh "
+                       "fusedm i8x3): rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and WRITE_SIZE in separate passes on this exact launch = "
+                       "185.8 MB read + 126.6 MB written; algorithmic 265.7 MB (26.5 spikes in + 106.2 residual + 106.2 membrane + 26.5 spikes "
+                       "out + 0.3 weights): 1.18x - the spike image is read once per 32-column block (3x) plus the halo rows")
 
 
 def build_model(kind, device):
@@ -120,7 +123,7 @@ def time_dominant_kernels(model, iters=40):
                                    "frac": flops / t_f32 / 1e12 / PEAK_BF16_DENSE_TFLOPS, "l3_resident_us_per_launch": t_f32_l3 * 1e6,
                                    "note": "the same convolution with the plain BN + residual fp32 epilogue (round 1's roofline shape)"},
             "algorithmic_bytes": set_bytes + (3 if digits else 2 * ns) * Cc * 9 * Cc,
-            "traffic": CONV_TRAFFIC_BYTES, "traffic_unit": "bytes per launch (HBM read + write)",
+            "traffic": CONV_TRAFFIC_BYTES if digits else None, "traffic_unit": "bytes per launch (HBM read + write)",
             "traffic_source": CONV_TRAFFIC_SOURCE,
             "note": "algorithmic flops (2 per multiply-add of the convolution) against the dense bf16/f16 MFMA peak.  The kernel issues "
                     + ("3 int8 digit MFMAs (v_mfma_i32_32x32x32_i8, K = 32 in the cycles the 16-bit form needs for K = 16) per product: 1.5x "
