@@ -98,13 +98,18 @@ def time_dominant_kernels(model, iters=40):
             for _ in range(nset)]
     sn = eng.pe_res[1].sn1
 
-    def conv_fused(st):
+    def conv_fusedm(st):                                          # res-block conv2: membrane + the next block's spikes
         eng._conv3x3(st[0], rb.w2, Cc, bn=rb.bn2, resid=st[1], sn=sn, membrane=True)
+
+    def conv_fused(st):                                           # res-block conv1: BN -> LIF spikes only
+        eng._conv3x3(st[0], rb.w1, Cc, bn=rb.bn1, sn=rb.sn2)
 
     def conv_f32(st):
         eng._conv3x3(st[0], rb.w2, Cc, bn=rb.bn2, resid=st[1])
-    t_conv = _timed(conv_fused, sets, iters)
-    t_conv_l3 = _timed(conv_fused, sets[:1], iters)
+    t_m, t_m_l3 = _timed(conv_fusedm, sets, iters), _timed(conv_fusedm, sets[:1], iters)
+    t_s, t_s_l3 = _timed(conv_fused, sets, iters), _timed(conv_fused, sets[:1], iters)
+    # the forward launches this kernel four times on this shape: twice in each form -> its average launch duration
+    t_conv, t_conv_l3 = (t_m + t_s) / 2, (t_m_l3 + t_s_l3) / 2
     t_f32 = _timed(conv_f32, sets, iters)
     t_f32_l3 = _timed(conv_f32, sets[:1], iters)
     del sets
@@ -114,21 +119,26 @@ def time_dominant_kernels(model, iters=40):
     issued = 1.5 if digits else float(ns)                        # MFMA work per algorithmic flop on the 16-bit pipe's scale
     kname = ("sdfmm::spike_conv_wres_i8_kernel<10,6,1> (weights resident in LDS as 3 int8 digit planes, halo tiles, LIF over T fused)"
              if digits else f"sdfmm::spike_mm_pp_kernel<{ns},10,true> (streaming ping-pong kernel)")
-    gemm = {"kernel": kname + " - 3x3 spike conv 96->96 @ 10x144x192, BN + identity -> fp32 membrane + LIF(T=10) spikes",
+    gemm = {"kernel": kname + " - 3x3 spike conv 96->96 @ 10x144x192; average over the forward's four launches of it on this shape "
+                              "(2 x BN -> LIF(T=10) spikes, 2 x BN + identity -> fp32 membrane + LIF spikes)",
             "bound": "mfma", "achieved": flops / t_conv / 1e12, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
             "us_per_launch": t_conv * 1e6, "operand_sets_in_rotation": nset, "rotation_bytes": nset * set_bytes,
             "l3_resident": {"us_per_launch": t_conv_l3 * 1e6, "achieved": flops / t_conv_l3 / 1e12,
                             "frac": flops / t_conv_l3 / 1e12 / PEAK_BF16_DENSE_TFLOPS},
+            "forms": {"spikes_only": {"us_per_launch": t_s * 1e6, "frac": flops / t_s / 1e12 / PEAK_BF16_DENSE_TFLOPS,
+                                      "l3_resident_us_per_launch": t_s_l3 * 1e6},
+                      "membrane_and_spikes": {"us_per_launch": t_m * 1e6, "frac": flops / t_m / 1e12 / PEAK_BF16_DENSE_TFLOPS,
+                                              "l3_resident_us_per_launch": t_m_l3 * 1e6}},
             "fp32_epilogue_form": {"us_per_launch": t_f32 * 1e6, "achieved": flops / t_f32 / 1e12,
                                    "frac": flops / t_f32 / 1e12 / PEAK_BF16_DENSE_TFLOPS, "l3_resident_us_per_launch": t_f32_l3 * 1e6,
                                    "note": "the same convolution with the plain BN + residual fp32 epilogue (round 1's roofline shape)"},
             "algorithmic_bytes": set_bytes + (3 if digits else 2 * ns) * Cc * 9 * Cc,
             "traffic": CONV_TRAFFIC_BYTES if digits else None, "traffic_unit": "bytes per launch (HBM read + write)",
-            "traffic_source": CONV_TRAFFIC_SOURCE,
+            "traffic_source": CONV_TRAFFIC_SOURCE + " (the membrane + spikes form; the spikes-only form writes 106 MB less)",
             "note": "algorithmic flops (2 per multiply-add of the convolution) against the dense bf16/f16 MFMA peak.  The kernel issues "
                     + ("3 int8 digit MFMAs (v_mfma_i32_32x32x32_i8, K = 32 in the cycles the 16-bit form needs for K = 16) per product: 1.5x "
                        "the algorithmic work on the 16-bit pipe's scale" if digits else f"{ns} 16-bit MFMAs per product") +
-                    "; in-kernel clock under this load is 1.3-1.7 GHz, not the 2.4 GHz the peak assumes (profiles/r2_stamps_wres.txt)"}
+                    "; in-kernel clock under this load is 1.3-1.7 GHz, not the 2.4 GHz the peak assumes (profiles/r2e_stamps_wres.txt)"}
     gemm["frac"] = gemm["achieved"] / gemm["peak"]
     gemm["frac_of_issued_mfma"] = issued * gemm["frac"]
     # neuron: T=10 over the stage-0 MLP hidden tensor shape (10 x 72*96*384 fp32 in, u8 out)
