@@ -425,19 +425,20 @@ struct GeoI8 {
   static_assert(CIN % 32 == 0, "K steps of 32 must not straddle taps");
 };
 
-template <int TT, int CIN16, int RB>
-__global__ __launch_bounds__(512) void spike_conv_wres_i8_kernel(GemmParams P, const float* __restrict__ col_scale) {
+template <int TT, int CIN16, int RB, int NGRP>
+__global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmParams P, const float* __restrict__ col_scale) {
   using G = GeoI8<CIN16, RB>;
   constexpr bool SPIKE = TT > 0;
   constexpr int T = SPIKE ? TT : 1;
   constexpr int CIN = G::CIN, K = G::K, PS = G::PS, RPB = G::RPB, WP = G::WP, TH8 = G::TH8, TW8 = G::TW8;
   constexpr int W_BYTES = 3 * NB * WP;
   constexpr int PAR = 2 * NB * 4;
-  static_assert(W_BYTES + 2 * G::HALO + PAR + 64 <= 160 * 1024, "LDS budget");
-  __shared__ __attribute__((aligned(16))) uint8_t smem[W_BYTES + 2 * G::HALO + PAR + 64];
+  constexpr int NT = 256 * NGRP;                                      // NGRP groups of 4 waves, one halo buffer each
+  static_assert(W_BYTES + NGRP * G::HALO + PAR + 64 <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) uint8_t smem[W_BYTES + NGRP * G::HALO + PAR + 64];
   uint8_t* W_s = smem;
-  float* par_s = reinterpret_cast<float*>(smem + W_BYTES + 2 * G::HALO);
-  uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + W_BYTES + 2 * G::HALO + PAR);
+  float* par_s = reinterpret_cast<float*>(smem + W_BYTES + NGRP * G::HALO);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + W_BYTES + NGRP * G::HALO + PAR);   // [g]: halo written, [NGRP + g]: halo read
 
   const SdfSpikeGemmDesc& d = P.d;
   const int H = P.cv.H, W = P.cv.W;
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(512) void spike_conv_wres_i8_kernel(GemmParams P, c
   const bool lif_fast = SPIKE && d.sn_kind == SDF_LIF && d.soft_reset != 0 && P.inv_tau != 0.f;
   const bool soft = d.soft_reset != 0;
 
-  if (tid < 4) cnt[tid] = 0;
+  if (tid < 2 * NGRP) cnt[tid] = 0;
 
   const int tiles_x = (W + TW8 - 1) / TW8, tiles_img = tiles_x * ((H + TH8 - 1) / TH8);
   const int Gd = gridDim.x;
@@ -524,13 +525,13 @@ __global__ __launch_bounds__(512) void spike_conv_wres_i8_kernel(GemmParams P, c
       constexpr int KC16 = K / 16;                                     // 16-byte pieces per digit-plane row
       constexpr int WCH = 3 * NB * KC16;
       const __amdgpu_buffer_rsrc_t W_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(d.Wp), 0, 3 * N * K, 0x00020000);
-      constexpr int WB = 6, NBATCH = (WCH + 512 * WB - 1) / (512 * WB);
+      constexpr int WB = 6, NBATCH = (WCH + NT * WB - 1) / (NT * WB);
 #pragma unroll 1
       for (int b = 0; b < NBATCH; ++b) {
         u32x4 wv[WB];
 #pragma unroll
         for (int i = 0; i < WB; ++i) {
-          const int c = tid + 512 * (b * WB + i);
+          const int c = tid + NT * (b * WB + i);
           const int cc = c < WCH ? c : 0;
           const int row = cc / KC16, kc = cc - row * KC16;             // row = digit * 32 + n
           const int dg = row / NB, n = row - dg * NB;
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(512) void spike_conv_wres_i8_kernel(GemmParams P, c
         }
 #pragma unroll
         for (int i = 0; i < WB; ++i) {
-          const int c = tid + 512 * (b * WB + i);
+          const int c = tid + NT * (b * WB + i);
           const int cc = c < WCH ? c : 0;
           const int row = cc / KC16, kc = cc - row * KC16;
           if (c < WCH) *reinterpret_cast<u32x4*>(W_s + row * WP + kc * 16) = wv[i];
@@ -560,11 +561,11 @@ __global__ __launch_bounds__(512) void spike_conv_wres_i8_kernel(GemmParams P, c
     if (it < seg_end) {
       item_decode(t_begin + it, cb, img0, y0, x0);
       halo_load(img0, y0, x0);
-      if (nstep) wait_ge(&cnt[2 + grp], 4 * nstep);
+      if (nstep) wait_ge(&cnt[NGRP + grp], 4 * nstep);
       halo_store();
       signal(&cnt[grp], lane);
     }
-    for (; it < seg_end; it += 2) {
+    for (; it < seg_end; it += NGRP) {
       item_decode(t_begin + it, cb, img0, y0, x0);
       float vmem[SPIKE ? 16 * RB : 1];
       if (SPIKE) {
@@ -617,7 +618,7 @@ __global__ __launch_bounds__(512) void spike_conv_wres_i8_kernel(GemmParams P, c
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[dg][rb][e] = 0;
         constexpr int KS = 9 * (CIN / 32);
-        constexpr int PF = RB == 1 ? 2 : 1;
+        constexpr int PF = (RB == 1 && NGRP == 2) ? 2 : 1;              // three groups live on 168 registers
         i32x4 fa[PF + 1][RB], fb[PF + 1][3];
         auto frag = [&](int ks, int set) __attribute__((always_inline)) {
           constexpr int C32 = CIN / 32;
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(512) void spike_conv_wres_i8_kernel(GemmParams P, c
               acc[dg][rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks % (PF + 1)][rb], fb[ks % (PF + 1)][dg], acc[dg][rb], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
-        signal(&cnt[2 + grp], lane);
+        signal(&cnt[NGRP + grp], lane);
         STAMP(s3);
 
         // ------------------------------ epilogue: RB row blocks of 32 pixels ------------------------------
@@ -654,7 +655,7 @@ __global__ __launch_bounds__(512) void spike_conv_wres_i8_kernel(GemmParams P, c
         {
           int ni = img0 + (t + 1) * tstep, ny = y0, nx = x0;
           if (t + 1 == T) {
-            if (it + 2 < seg_end) { int ncb; item_decode(t_begin + it + 2, ncb, ni, ny, nx); }
+            if (it + NGRP < seg_end) { int ncb; item_decode(t_begin + it + NGRP, ncb, ni, ny, nx); }
             else have_next = false;
           }
           if (have_next) halo_load(ni, ny, nx);
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(512) void spike_conv_wres_i8_kernel(GemmParams P, c
         }
         STAMP(s4);
         if (have_next) {
-          wait_ge(&cnt[2 + grp], 4 * nstep);
+          wait_ge(&cnt[NGRP + grp], 4 * nstep);
           halo_store();
           signal(&cnt[grp], lane);
         }
@@ -789,10 +790,16 @@ int launch_spike_conv_wres(const GemmParams& Pin, hipStream_t s) {
   int rc;
   if (d.nsplit == SDF_PLANES_I8X3) {
     if (c.Cin != 96) return SDF_E_SHAPE;
-    if (d.sn_T == 0 && th == 16) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 6, 2>), grid, dim3(512), 0, s, P, d.col_scale);
-    else if (d.sn_T == 0) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 6, 1>), grid, dim3(512), 0, s, P, d.col_scale);
-    else if (th == 16) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 2>), grid, dim3(512), 0, s, P, d.col_scale);
-    else hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 1>), grid, dim3(512), 0, s, P, d.col_scale);
+    // fused-neuron items are T steps long and their epilogue (neuron + two stores) outweighs their MFMAs: with few of them
+    // (batch 1: 648 on this shape) THREE groups of waves per workgroup - 768 slots, one item each, the matrix pipe shared
+    // three ways - instead of two groups with one or two items each
+    const char* eg = getenv("SDF_CONV_WRES_GROUPS");                   // tuning override: 2 or 3
+    const bool g3 = d.sn_T > 0 && th == 8 && (eg ? eg[0] == '3' : true);
+    if (d.sn_T == 0 && th == 16) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 6, 2, 2>), grid, dim3(512), 0, s, P, d.col_scale);
+    else if (d.sn_T == 0) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 6, 1, 2>), grid, dim3(512), 0, s, P, d.col_scale);
+    else if (th == 16) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 2, 2>), grid, dim3(512), 0, s, P, d.col_scale);
+    else if (g3) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 1, 3>), grid, dim3(768), 0, s, P, d.col_scale);
+    else hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 1, 2>), grid, dim3(512), 0, s, P, d.col_scale);
     rc = 0;
   } else if (d.sn_T == 0) rc = d.nsplit == 1 ? launch_c<1, 0>(P, grid, s) : launch_c<2, 0>(P, grid, s);
   else rc = d.nsplit == 1 ? launch_c<1, 10>(P, grid, s) : launch_c<2, 10>(P, grid, s);
