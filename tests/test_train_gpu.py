@@ -68,7 +68,9 @@ def test_train_mode_block_matches_reference_autograd(tag, kind):
     worst = max(report.values())
     print(f"train block {tag}: mismatch rates y {report['y']:.2e} gx {report['gx']:.2e} worst {worst:.2e} "
           f"({max(report, key=report.get)})")
-    assert report["y"] <= 1e-2 and report["gx"] <= 2e-2 and worst <= 5e-2, report
+    # measured on every box so far: 0 mismatching elements in y, gx and every parameter gradient; the bounds leave room for a
+    # handful of spikes flipped by another box's library-GEMM heuristics (one flipped spike touches ~1e-4 of a tensor here)
+    assert report["y"] <= 2e-3 and report["gx"] <= 5e-3 and worst <= 1e-2, report
 
 
 def test_train_mode_patch_merging_matches_reference_autograd():
