@@ -7,9 +7,12 @@ Turns the module tree (state_dict holder) into a flat schedule of C-ABI kernel l
   * pad + roll + window_partition_v2 (+ the raw .view) and window_reverse + roll + crop become one int32
     row map per (shape, shift), used as a gather by the neuron kernel and as a scatter by the GEMM epilogue
   * the residual adds of the block happen in the GEMM epilogues, in place, on the (B,D,H,W,C) activation
-  * spikes travel as 1 byte between kernels (fp32 only where a MIOpen convolution consumes them)
+  * spikes travel as 1 byte between kernels
+  * the convolutions either side of the swin stages (patch embedding, U-Net tail: SURVEY.md 8f rows 1-2) are implicit-GEMM
+    spike convolutions with the BN / residual / neuron epilogues fused; the large 96-channel 3x3 launches take int8 digit
+    planes and the weight-resident kernel (csrc/spike_conv_wres.hip); only the 1x1 PED shortcut on the fp32 membrane is MIOpen
+  * `tape` (tests only) keeps every neuron layer's spikes for the spike-forced oracle replay (tests/replay.py)
 
-Convolutions (patch embedding, U-Net tail: SURVEY.md 8f rows 1-2) are stock ATen/MIOpen calls for now.
 Reference schedule being replaced: models/STSwinNet_SNN/Spiking_STSwinNet.py:161-182,278-305 and the
 call tree of SURVEY.md 3.2.  No CPU fallback: everything here raises off-GPU.
 """
