@@ -117,7 +117,8 @@ def time_dominant_kernels(model, iters=40):
     digits = getattr(rb.w2, "digits", None) is not None and sn.kind != "psn"
     ns = int(rb.w2.shape[0])
     issued = 1.5 if digits else float(ns)                        # MFMA work per algorithmic flop on the 16-bit pipe's scale
-    kname = ("sdfmm::spike_conv_wres_i8_kernel<10,6,1> (weights resident in LDS as 3 int8 digit planes, halo tiles, LIF over T fused)"
+    kname = ("sdfmm::spike_conv_wres_i8_kernel<10,6,1,3> (weights resident in LDS as 3 int8 digit planes, halo tiles, LIF over T fused, "
+             "3 wave groups per workgroup)"
              if digits else f"sdfmm::spike_mm_pp_kernel<{ns},10,true> (streaming ping-pong kernel)")
     gemm = {"kernel": kname + " - 3x3 spike conv 96->96 @ 10x144x192; average over the forward's four launches of it on this shape "
                               "(2 x BN -> LIF(T=10) spikes, 2 x BN + identity -> fp32 membrane + LIF spikes)",
