@@ -268,6 +268,13 @@ class MSFlowEngine:
         a, b = bn if bn is not None else (None, None)
         # large 3x3 / stride-1 launches on 96 channels: int8 digit planes, weights resident in LDS (csrc/spike_conv_wres.hip)
         digits = getattr(Wp, "digits", None)
+        if digits is not None and sn is not None and (sn.kind == "psn" or D != 10) and \
+                hip.conv_wres_applicable(B * D, h, w, Cin, Cout, stride, 1):
+            # the digit kernel's fused form is LIF / IF over T = 10; other neurons (the shipped PSN) take its fp32 form and
+            # the neuron kernel behind it - still ahead of the streaming kernel's fused epilogue (profiles/r2j_psn.txt)
+            m = self._conv3x3(s, Wp, Cout, stride, bn=bn, resid=resid if membrane else None)
+            sp = self._neuron_bd(m, sn)
+            return (m, sp) if membrane else sp
         if digits is not None and (sn is None or (sn.kind != "psn" and D == 10)) and \
                 hip.conv_wres_applicable(B * D, h, w, Cin, Cout, stride, D if sn is not None else 1):
             Wp = digits                                               # (the kernel's fused form: LIF / IF over T = 10)
