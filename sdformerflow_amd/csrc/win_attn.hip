@@ -398,8 +398,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
         }
       }
     };
+#ifdef SDF_ATTN_NOSTRIP
+    // timing experiment only (tools/attn_strip_cost.sh): what do the bias / mask strip loads from L2 cost?  (wrong results)
+#pragma unroll
+    for (int jt = 0; jt < NTC; ++jt) { bb[jt] = u32x4{0u, 0u, 0u, 0u}; mm[jt] = u32x4{0u, 0u, 0u, 0u}; }
+#else
     load_strip(bias_rs, bb);
     if (HAS_MASK) load_strip(mask_rs, mm);
+#endif
     // ---- S^T = K Q^T ----
     f32x4 st[NTC];
 #pragma unroll
