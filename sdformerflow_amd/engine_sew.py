@@ -7,8 +7,9 @@ layers that read it see small non-negative numbers, not spikes: those products (
 reduction, the first convolution of a res-block, the transposed convolutions) are dense fp32 library calls (rocBLAS /
 MIOpen through torch - plain library GEMMs / convolutions), everything that reads spikes (fc2, the second res-block
 convolution, the flow predictions) runs on the spike kernels, every BatchNorm is folded into the neuron kernel that
-follows it, the score / bias / mask / .V core is the fused window-attention kernel (csrc/win_attn.hip, SEW mode), and window
-partition / reverse are row moves through the slice map (no materialised pad / roll / permute / crop).
+follows it, the score / bias / mask / .V core is the fused window-attention kernel (csrc/win_attn.hip, SEW mode); the window
+partition is the row map the q / k / v neuron kernel gathers through (the projections run on un-partitioned rows), the window
+reverse a row scatter through the same map (no materialised pad / roll / permute / crop).
 No CPU fallback: everything here raises off-GPU."""
 from __future__ import annotations
 
@@ -100,10 +101,17 @@ class SEWFlowEngine(MSFlowEngine):
         rowmap, B_ = self._slice_map(B, D, H, W, ws, ss)
         Tq, N1 = ws[0], ws[1] * ws[2]
         M = Tq * B_ * N1
-        xw = hip.rows_gather(x.view(-1, Cc), rowmap)                              # window partition (+ pad, roll): (T'*B_*N1, C)
+        # q / k / v: the projection is row-wise, so it runs on the un-partitioned rows; pad + roll + window_partition_v2 (and its raw
+        # (T', B_, ...) view) are the row map the neuron kernel gathers through - nothing is materialised.  A padding token reads
+        # zeros: BN(Linear(0)) = beta, as in the reference (the projections carry no bias)
+        x2 = x.view(-1, Cc)
         spk = {}
         for n, w in (("q", blk.wq), ("k", blk.wk), ("v", blk.wv)):
-            spk[n] = self._sn_rows(torch.mm(xw, w), Tq, blk.sn[n], blk.bn[n], blk.name + f"attn.sn_{n}.spiking_neuron.", torch.uint8)
+            y = torch.mm(x2, w)
+            spk[n] = torch.empty((M, Cc), dtype=torch.uint8, device=x.device)
+            hip.neuron_fwd(y, spk[n], Tq, 1, M // Tq * Cc, 0, 0, 0, M // Tq * Cc, blk.sn[n], rowmap=rowmap, rowlen=Cc,
+                           alpha=blk.bn[n][0], beta=blk.bn[n][1], Cch=Cc, inner=1)
+            self._rec(blk.name + f"attn.sn_{n}.spiking_neuron.", spk[n], "flat")
         mask = self._mask(D, H, W, ws, ss) if any(s > 0 for s in ss) else None
         z = hip.win_attn_sew(spk["q"], spk["k"], spk["v"], blk.scale, blk.bias(Tq * N1), mask, blk.nH, Tq, B_, N1)
         y = torch.addmm(blk.bp, z.view(M, Cc), blk.wp_t)
