@@ -457,6 +457,31 @@ typedef struct SdfWinAttnDesc {
 
 int sdf_win_attn_fwd(const SdfWinAttnDesc* d, void* stream);
 
+/* ---- dense 3x3 convolution of real-valued activations (ANN patch embedding, BASELINE config 3) ----------------------
+ * Replaces the library convolutions of reference models/STSwinNet/PatchEmbed.py:166-196 (`PatchEmbedLocal`: head Conv2d +
+ * four `ResidualBlock`s, models/submodules.py:160-229) together with their BatchNorm2d (eval: folded to alpha / beta), residual
+ * add and ReLU:  out = act(alpha[n] * conv3x3(x, w)[n] + beta[n] (+ resid)), stride 1, zero padding 1.
+ * Activations are "planes": [imgs][ceil(C/16)][H][W] records of 64 bytes, a record = 4 pieces of { 4 x fp16 hi, 4 x fp16 lo }
+ * for 16 channels (value = hi + lo, 22 significant bits; sdf_pack_planes / sdf_unpack_planes convert from / to NCHW fp32).
+ * w: fp16 planes [2][N][K] with w = plane0 + plane1, K = 9 * 16 * cin_records ordered (record, ky, kx, channel in record);
+ * channels beyond Cin carry zero weights.  N % 32 == 0; cin_records in {1, 6}; every tensor below 2^31 bytes. */
+typedef struct SdfDenseConvDesc {
+  const void* x;            /* planes [imgs][cin_records][H][W][64 B] */
+  const uint16_t* w;        /* fp16 planes [2][N][K] */
+  const float* alpha;       /* (N) or NULL = 1 */
+  const float* beta;        /* (N) or NULL = 0 */
+  const void* resid;        /* planes [imgs][N/16][H][W][64 B] or NULL */
+  void* out;                /* planes [imgs][N/16][H][W][64 B], or fp32 NHWC (imgs,H,W,N) when out_f32 */
+  int32_t imgs, H, W, cin_records, N;
+  int32_t relu;             /* max(., 0) after the residual add */
+  int32_t out_f32;
+} SdfDenseConvDesc;
+
+int sdf_dense_conv3x3_fwd(const SdfDenseConvDesc* d, void* stream);
+/* x (imgs,C,H,W) fp32 -> planes (channels C .. 16*ceil(C/16)-1 zero) and back */
+int sdf_pack_planes(const float* x, void* planes, int imgs, int C, int H, int W, void* stream);
+int sdf_unpack_planes(const void* planes, float* x, int imgs, int C, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,8 +1,14 @@
 """ANN patch embedding on the path of BASELINE config 3 (mirror of reference models/STSwinNet/PatchEmbed.py:104-196,
 `PatchEmbedLocal`): per temporal chunk, Conv2d head -> 4 BatchNorm residual blocks -> strided Conv2d projection.
-Dense fp32 convolutions: MIOpen through torch (library convolutions, not a hot op of this framework)."""
+The nine stride-1 convolutions (60 % of config 3 on the library's fp32 Winograd kernel) run on this framework's dense
+convolution (csrc/dense_conv_wres.hip: two fp16 planes per operand, BatchNorm / residual / ReLU in the epilogue, activations
+kept as hi + lo planes between the layers); the stride-4 projection stays a library convolution on the channels-last result."""
+import os
+
 import torch
 import torch.nn as nn
+
+from .. import hip
 
 
 class ResidualBlock(nn.Module):
@@ -54,7 +60,38 @@ class PatchEmbedLocal(nn.Module):
         self.residual_encoding = _ResidualEncoding(embed_dim)
         self.proj = nn.Conv2d(embed_dim, embed_dim, 3, self.patch_size[1:], 1)
 
+    def _packed(self):
+        """fp16 weight planes and folded eval-BatchNorm (alpha, beta) of the stride-1 convolutions, rebuilt when a tensor changes."""
+        tensors = list(self.head.parameters()) + list(self.residual_encoding.parameters()) + list(self.residual_encoding.buffers())
+        stamp = tuple((t.data_ptr(), t._version) for t in tensors)
+        if getattr(self, "_pk_stamp", None) != stamp:
+            def fold(bn):
+                a = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
+                return a.contiguous(), (bn.bias.detach().float() - bn.running_mean.float() * a).contiguous()
+            pk = [(hip.pack_dense_conv_weight(self.head.weight), None, self.head.bias.detach().float().contiguous())]
+            for i in range(1, 5):
+                rb = getattr(self.residual_encoding, f"resblock{i}")
+                pk.append((hip.pack_dense_conv_weight(rb.conv1.weight),) + fold(rb.bn1))
+                pk.append((hip.pack_dense_conv_weight(rb.conv2.weight),) + fold(rb.bn2))
+            self._pk, self._pk_stamp = pk, stamp
+        return self._pk
+
+    def _encode_planes(self, x):
+        """head + residual encoding of (imgs, C, H, W) fp32 -> (imgs, H, W, embed_dim) fp32, channels last."""
+        pk = self._packed()
+        a = hip.dense_conv3x3(hip.pack_planes(x), *pk[0])
+        for i in range(4):
+            y = hip.dense_conv3x3(a, *pk[1 + 2 * i], None, True)
+            a = hip.dense_conv3x3(y, *pk[2 + 2 * i], a, True, i == 3)
+        return a
+
     def forward(self, x):
         T, B = x.shape[:2]
-        y = self.proj(self.residual_encoding(self.head(x.flatten(0, 1))))            # the T chunks share every weight
+        x = x.flatten(0, 1)                                                           # the T chunks share every weight
+        imgs, C, H, W = x.shape
+        if (not self.training and x.is_cuda and os.environ.get("SDF_DENSE_CONV", "1") != "0"
+                and hip.dense_conv_applicable(imgs, H, W, C, self.embed_dim) and C <= 16 and self.embed_dim == 96):
+            y = self.proj(self._encode_planes(x).permute(0, 3, 1, 2)).contiguous()
+        else:
+            y = self.proj(self.residual_encoding(self.head(x)))
         return y.view(T, B, *y.shape[1:]).permute(1, 2, 0, 3, 4)

@@ -26,7 +26,8 @@ EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_s
            "sdf_window_slice_map", "sdf_qk_attn_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
            "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
            "sdf_rows_gather_fwd", "sdf_rows_scatter_fwd",
-           "sdf_split_weight_i8x3", "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd")
+           "sdf_split_weight_i8x3", "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd",
+           "sdf_dense_conv3x3_fwd", "sdf_pack_planes", "sdf_unpack_planes")
 
 
 class SdfError(RuntimeError):
@@ -80,6 +81,12 @@ class WinAttnDesc(C.Structure):
                 ("B_", C.c_int32), ("nW", C.c_int32), ("nH", C.c_int32), ("N", C.c_int32), ("hd", C.c_int32),
                 ("Tq", C.c_int32), ("N1", C.c_int32),
                 ("scale", C.c_void_p), ("bias", C.c_void_p), ("mask", C.c_void_p), ("row_map", C.c_void_p), ("pad_qkv", C.c_void_p)]
+
+
+class DenseConvDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("alpha", C.c_void_p), ("beta", C.c_void_p), ("resid", C.c_void_p),
+                ("out", C.c_void_p), ("imgs", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("cin_records", C.c_int32),
+                ("N", C.c_int32), ("relu", C.c_int32), ("out_f32", C.c_int32)]
 
 
 _lib = None
@@ -635,6 +642,68 @@ def win_attn_sew(q, k, v, scale, bias, mask, nH, Tq, B_, N1):
     d.Tq, d.N1 = Tq, N1
     d.scale, d.bias, d.mask = _ptr(scale, torch.float32), _ptr(bias, torch.float32), _ptr(mask, torch.float32)
     _check(lib().sdf_win_attn_fwd(C.byref(d), _stream()), "sdf_win_attn_fwd")
+    return out
+
+
+# ---- dense 3x3 convolution of real-valued activations (ANN patch embedding; csrc/dense_conv_wres.hip) ----
+def pack_planes(x):
+    """(imgs, C, H, W) fp32 -> activation planes (imgs, ceil(C/16), H, W, 32) fp16: per pixel and 16 channels four pieces of
+    {4 x hi, 4 x lo}, value = hi + lo (sdf_pack_planes)."""
+    x = x.contiguous()
+    imgs, Cc, H, W = x.shape
+    planes = torch.empty((imgs, -(-Cc // 16), H, W, 32), dtype=torch.float16, device=x.device)
+    _check(lib().sdf_pack_planes(C.c_void_p(_ptr(x, torch.float32)), C.c_void_p(planes.data_ptr()), C.c_int(imgs), C.c_int(Cc),
+                                 C.c_int(H), C.c_int(W), _stream()), "sdf_pack_planes")
+    return planes
+
+
+def unpack_planes(planes, Cc):
+    """activation planes -> (imgs, Cc, H, W) fp32 (sdf_unpack_planes)."""
+    imgs, nch, H, W, _ = planes.shape
+    x = torch.empty((imgs, Cc, H, W), dtype=torch.float32, device=planes.device)
+    _check(lib().sdf_unpack_planes(C.c_void_p(_ptr(planes, torch.float16)), C.c_void_p(x.data_ptr()), C.c_int(imgs), C.c_int(Cc),
+                                   C.c_int(H), C.c_int(W), _stream()), "sdf_unpack_planes")
+    return x
+
+
+def pack_dense_conv_weight(w):
+    """Conv2d weight (Cout, Cin, 3, 3) fp32 -> fp16 planes (2, Cout, 9 * 16 * ceil(Cin/16)), w = plane0 + plane1, K ordered
+    (16-channel record, ky, kx, channel in record); channels beyond Cin are zero."""
+    Cout, Cin, KH, KW = w.shape
+    if (KH, KW) != (3, 3):
+        raise SdfError("dense_conv3x3 takes 3x3 kernels")
+    rec = -(-Cin // 16)
+    wp = torch.zeros((Cout, rec * 16, 3, 3), dtype=torch.float32, device=w.device)
+    wp[:, :Cin] = w.detach().float()
+    wk = wp.view(Cout, rec, 16, 3, 3).permute(0, 1, 3, 4, 2).reshape(Cout, rec * 144)
+    hi = wk.half()
+    lo = (wk - hi.float()).half()
+    return torch.stack([hi, lo]).contiguous()
+
+
+def dense_conv_applicable(imgs, H, W, Cin, Cout):
+    """Shapes sdf_dense_conv3x3_fwd has an instantiation for (Cin <= 16 or Cin == 96, Cout in blocks of 32, 31-bit offsets)."""
+    rec = -(-Cin // 16)
+    return rec in (1, 6) and Cout % 32 == 0 and imgs * H * W * max(rec * 64, Cout * 4) < 1 << 31
+
+
+def dense_conv3x3(xp, wplanes, alpha=None, beta=None, resid=None, relu=False, out_f32=False):
+    """out = act(alpha * conv3x3(x, w) + beta (+ resid)), stride 1, zero padding 1 (sdf_dense_conv3x3_fwd).  xp / resid / the result
+    are activation planes; out_f32 returns (imgs, H, W, N) fp32 (channels last) instead."""
+    imgs, rec, H, W, _ = xp.shape
+    N = wplanes.shape[1]
+    if wplanes.shape[2] != rec * 144:
+        raise SdfError(f"weight planes of K = {wplanes.shape[2]} against {rec} activation records")
+    if resid is not None and tuple(resid.shape) != (imgs, N // 16, H, W, 32):
+        raise SdfError("residual planes must have the output's shape")
+    out = (torch.empty((imgs, H, W, N), dtype=torch.float32, device=xp.device) if out_f32 else
+           torch.empty((imgs, N // 16, H, W, 32), dtype=torch.float16, device=xp.device))
+    d = DenseConvDesc()
+    d.x, d.w = _ptr(xp, torch.float16), _ptr(wplanes, torch.float16)
+    d.alpha, d.beta = _ptr(alpha, torch.float32), _ptr(beta, torch.float32)
+    d.resid, d.out = _ptr(resid, torch.float16), out.data_ptr()
+    d.imgs, d.H, d.W, d.cin_records, d.N, d.relu, d.out_f32 = imgs, H, W, rec, N, int(relu), int(out_f32)
+    _check(lib().sdf_dense_conv3x3_fwd(C.byref(d), _stream()), "sdf_dense_conv3x3_fwd")
     return out
 
 
