@@ -12,33 +12,51 @@
 // fp32 - so no layer pays a conversion pass and BatchNorm (folded to alpha / beta), the residual add and the ReLU never
 // touch memory on their own.
 //
-// Same division of labour as spike_conv_wres.hip: a workgroup owns one 32-column block of the output and keeps that block's
-// weights - both planes, the whole K = 9 * Cin - in LDS (2 x 32 x 864 fp16 = 110 KB); activations enter as halo images
-// (10 x 18 pixels for a tile of 8 x 16 outputs), the nine taps are nine constant offsets into the image.  A halo image of all
-// 96 channels in two planes would be 69 KB, so the image is cut by CHANNEL: one step = 16 input channels (15 KB image, 9 taps x 3
-// MFMAs per wave), the accumulators stay in registers across the steps of a tile and the epilogue runs after the last one.
-// 8 wavefronts = 2 groups of 4; a group owns one halo image, the next image is requested from memory before the MFMAs of the
-// current one and written after them, the two groups run out of phase (LDS counters, no workgroup barrier in the steady state).
+// A workgroup keeps the weights of one 32-column block of the output - both planes, the whole K = 9 * Cin - in LDS
+// (2 x 32 x 864 fp16 = 110 KB), as spike_conv_wres.hip does.  The activations are handled per WAVE: each of the 8 wavefronts
+// owns a tile of 4 x 8 output pixels (its 32 MFMA rows) and a private 6 x 10 pixel halo image of it in LDS; the nine taps are
+// nine constant offsets into that image.  An image of all 96 channels in two planes would not fit beside the weights, so it is
+// cut by CHANNEL: one step = 16 input channels (5 KB image, 9 taps x 3 MFMAs), the accumulators stay in registers across the
+// steps of a tile and the epilogue runs after the last one.  Nothing is shared between waves but the weights, so the steady
+// state has no barrier, no counter and no polling: a wave requests the image of step s + 2 from memory, multiplies step s, and
+// writes the image of step s + 1 behind its own last fragment reads (a wave's LDS operations execute in order); the two waves
+// a SIMD hosts fill each other's gaps on the matrix pipe.  (The first version shared a 10 x 18 image between four waves: two
+// LDS hand-overs per step cost as much as the step's 27 MFMAs - profiles/r2l_stamps_dense.txt.)
+// The N / 32 workgroups that serve the column blocks of one tile range sit on one XCD and walk the range side by side: its
+// activations leave HBM once (column blocks as an outer loop over the tensor read 2.7 x the algorithmic bytes, r2l_pmc_dense.txt).
+// The weights are the MFMA's ROW operand and the pixels its column operand, so a lane's accumulator quads are four consecutive
+// channels of one pixel - a 16-byte piece of the output as it stands, no transpose in the epilogue.
 //
 // Activation layout ("planes", sdf_pack_planes): [img][Cin/16][H][W] records of 64 bytes = 4 x { 4 x fp16 hi, 4 x fp16 lo } for
 // 16 channels: a 16-byte piece is four channels complete, which is what one lane holds after the epilogue's quad transpose
 // (one 16-byte store per four channels) and what the halo loader splits into the hi and lo halves of the LDS pixel record.
-// LDS is conflict-free by construction: pixel stride 80 bytes (16-byte slots 5 apart), row pitch a multiple of 256 bytes, so
-// the 16 lanes of every ds_read_b128 group cover the 16 slots of a bank row once; weight rows 2K + 16 bytes (4 x odd dwords).
+// LDS is conflict-free by construction: pixel stride 80 bytes (16-byte slots 5 apart: 8 pixels of a row take slots
+// {0,5,10,15,4,9,14,3}), row pitch 128 (mod 256) bytes, so the 16 lanes of every ds_read_b128 group (two half rows of two
+// tile rows) cover the 16 slots of a bank row once; weight rows 2K + 16 bytes (4 x odd dwords).
 #include "spike_mm.h"
+
+#ifdef SDF_STAMP
+// diagnostic build only (tools/stamp_dense.sh): cycle accounting of wave 0 of each group of workgroup 0
+__device__ unsigned long long g_dense_stamp[32];
+#define STAMP(var) var = __builtin_readcyclecounter()
+#define STAMP_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(acc, a, b)
+#endif
 
 namespace sdfmm {
 namespace {
 
-constexpr int TH = 8, TW = 16;                  // output pixels of a tile: 4 waves x (2 rows x 16 pixels)
-constexpr int HH = TH + 2, HWID = TW + 2;       // halo image
-constexpr int NB = 32;                          // output columns of a workgroup
+constexpr int TH = 4, TW = 8;                   // output pixels of a wave's tile: 32 MFMA rows = 4 rows x 8 pixels
+constexpr int HH = TH + 2, HWID = TW + 2;       // its halo image
+constexpr int NB = 32;                          // output columns of a workgroup pass
 constexpr int REC = 64;                         // bytes of a pixel record in memory (16 channels, hi + lo)
 constexpr int PS = 80;                          // pixel stride in the halo image: 32 B hi, 32 B lo, 16 B pad
-constexpr int RPB = 1536;                       // halo row pitch: 18 * 80 = 1440 -> next multiple of 256
-constexpr int HALO = HH * RPB;
-constexpr int PIECES = HH * HWID * 4;           // 16-byte pieces of a halo image
-constexpr int CPL = (PIECES + 255) / 256;       // pieces per lane of a group
+constexpr int RPB = 896;                        // halo row pitch: 10 * 80 = 800 -> 128 (mod 256), see the bank note above
+constexpr int HALO = HH * RPB;                  // 5376 bytes per wave
+constexpr int PIECES = HH * HWID * 4;           // 16-byte pieces of a halo image (240)
+constexpr int CPL = (PIECES + 63) / 64;         // pieces per lane
 constexpr uint32_t INV = 0x80000000u;
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -46,50 +64,34 @@ typedef __attribute__((ext_vector_type(2))) _Float16 h2;
 
 struct DenseParams {
   SdfDenseConvDesc d;
-  int tiles_m, ntiles;
+  int wtiles;                                   // wave tiles of the whole output: imgs * ceil(H/4) * ceil(W/8)
+  int ranges;                                   // contiguous tile ranges; each is served by N / 32 workgroups, one per column block
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)INV, 0x00020000);
 }
-__device__ __forceinline__ void wait_ge(uint32_t* p, uint32_t target) {
-  while (true) {
-    const uint32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    if ((int32_t)(v - target) >= 0) break;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ void signal(uint32_t* p, int lane) {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 
-// fp32 -> (hi, lo) fp16 pair, round to nearest; values beyond the fp16 range saturate instead of becoming infinities
-__device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
-  x = __builtin_fminf(__builtin_fmaxf(x, -65000.f), 65000.f);
-  hi = (_Float16)x;
-  lo = (_Float16)(x - (float)hi);
-}
-__device__ __forceinline__ uint32_t pack2(_Float16 a, _Float16 b) {
-  h2 v; v.x = a; v.y = b;
-  return __builtin_bit_cast(uint32_t, v);
-}
-__device__ __forceinline__ float2 unpack2(uint32_t u) {
-  const h2 v = __builtin_bit_cast(h2, u);
-  return make_float2((float)v.x, (float)v.y);
-}
-// one 16-byte piece {hi0..3, lo0..3} <-> four fp32 values
+typedef __attribute__((ext_vector_type(2))) float f2;
+// four fp32 values -> one 16-byte piece {hi0..3, lo0..3}: hi = fp16(x), lo = fp16(x - hi), both round to nearest
+// (v_cvt_pk_f16_f32); values beyond the fp16 range saturate instead of becoming infinities
 __device__ __forceinline__ u32x4 piece_from(float4 o) {
-  _Float16 h[4], l[4];
-  split_f16(o.x, h[0], l[0]); split_f16(o.y, h[1], l[1]); split_f16(o.z, h[2], l[2]); split_f16(o.w, h[3], l[3]);
+  f2 a, b;
+  a.x = __builtin_amdgcn_fmed3f(o.x, -65000.f, 65000.f); a.y = __builtin_amdgcn_fmed3f(o.y, -65000.f, 65000.f);
+  b.x = __builtin_amdgcn_fmed3f(o.z, -65000.f, 65000.f); b.y = __builtin_amdgcn_fmed3f(o.w, -65000.f, 65000.f);
+  const h2 ha = __builtin_convertvector(a, h2), hb = __builtin_convertvector(b, h2);
+  f2 ra, rb;
+  ra.x = a.x - (float)ha.x; ra.y = a.y - (float)ha.y; rb.x = b.x - (float)hb.x; rb.y = b.y - (float)hb.y;
+  const h2 la = __builtin_convertvector(ra, h2), lb = __builtin_convertvector(rb, h2);
   u32x4 v;
-  v.x = pack2(h[0], h[1]); v.y = pack2(h[2], h[3]); v.z = pack2(l[0], l[1]); v.w = pack2(l[2], l[3]);
+  v.x = __builtin_bit_cast(uint32_t, ha); v.y = __builtin_bit_cast(uint32_t, hb);
+  v.z = __builtin_bit_cast(uint32_t, la); v.w = __builtin_bit_cast(uint32_t, lb);
   return v;
 }
 __device__ __forceinline__ float4 piece_to(u32x4 v) {
-  const float2 h01 = unpack2(v.x), h23 = unpack2(v.y), l01 = unpack2(v.z), l23 = unpack2(v.w);
-  return make_float4(h01.x + l01.x, h01.y + l01.y, h23.x + l23.x, h23.y + l23.y);
+  const h2 ha = __builtin_bit_cast(h2, (uint32_t)v.x), hb = __builtin_bit_cast(h2, (uint32_t)v.y);
+  const h2 la = __builtin_bit_cast(h2, (uint32_t)v.z), lb = __builtin_bit_cast(h2, (uint32_t)v.w);
+  return make_float4((float)ha.x + (float)la.x, (float)ha.y + (float)la.y, (float)hb.x + (float)lb.x, (float)hb.y + (float)lb.y);
 }
 
 template <int CCH>
@@ -99,42 +101,81 @@ __global__ __launch_bounds__(512) void dense_conv_wres_kernel(DenseParams P) {
   constexpr int W_BYTES = 2 * NB * WP;
   constexpr int PAR = 2 * NB * 4;
   static_assert((WP / 4) % 8 == 4, "weight row pitch must be 4 x odd dwords");
-  static_assert(W_BYTES + 2 * HALO + PAR + 64 <= 160 * 1024, "LDS budget");
-  __shared__ __attribute__((aligned(16))) uint8_t smem[W_BYTES + 2 * HALO + PAR + 64];
+  static_assert(W_BYTES + 8 * HALO + PAR <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) uint8_t smem[W_BYTES + 8 * HALO + PAR];
   uint8_t* W_s = smem;
-  float* par_s = reinterpret_cast<float*>(smem + W_BYTES + 2 * HALO);
-  uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + W_BYTES + 2 * HALO + PAR);     // [g]: halo written, [2 + g]: halo read
+  float* par_s = reinterpret_cast<float*>(smem + W_BYTES + 8 * HALO);
 
   const SdfDenseConvDesc& d = P.d;
   const int H = d.H, W = d.W, N = d.N;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int grp = wave >> 2, cw = wave & 3;
-  const int gl = tid & 255;                                           // lane inside the group
   const bool has_res = d.resid != nullptr;
   const bool relu = d.relu != 0, out_f32 = d.out_f32 != 0;
   const int nch = N >> 4;                                             // channel records of the output / residual planes
+  const int ncb = N / NB;
 
-  if (tid < 4) cnt[tid] = 0;
+  // workgroup -> (tile range, column block).  The ncb workgroups of a range run side by side on ONE XCD, so the activations
+  // they all read come out of HBM once and out of that L2 afterwards (column blocks as an outer loop over the whole tensor read
+  // 2.7 x the algorithmic bytes, profiles/r2l_pmc_dense.txt).  Full grid: workgroup p sits on XCD p % 8 as its (p / 8)-th.
+  int range, cb;
+  if (gridDim.x == 256 && ncb <= 32) {
+    const int x = blockIdx.x & 7, k = blockIdx.x >> 3, m = 32 / ncb;   // m whole groups per XCD, the rest pooled across XCDs
+    if (k < m * ncb) { range = x * m + k / ncb; cb = k % ncb; }
+    else { const int e = x * (32 - m * ncb) + (k - m * ncb); range = 8 * m + e / ncb; cb = e % ncb; }
+  } else {
+    range = blockIdx.x / ncb; cb = blockIdx.x % ncb;
+  }
+  if (range >= P.ranges) return;
+  const int n0 = cb * NB;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, tiles_img = tiles_x * tiles_y;
+  const int base = P.wtiles / P.ranges, rem = P.wtiles % P.ranges;
+  const int t_begin = range * base + (range < rem ? range : rem);
+  const int n_my = base + (range < rem ? 1 : 0);
 
-  // work items: item = cb * tiles_m + rt, rt = img * tiles_img + tile; contiguous ranges per workgroup, workgroups dealt
-  // XCD-contiguously (neighbouring tiles share halo rows in one L2)
-  const int tiles_x = (W + TW - 1) / TW, tiles_img = tiles_x * ((H + TH - 1) / TH);
-  const int Gd = gridDim.x;
-  int wg = blockIdx.x;
-  if ((Gd & 7) == 0) wg = (wg & 7) * (Gd >> 3) + (wg >> 3);
-  const int nitems = P.ntiles;
-  const int base = nitems / Gd, rem = nitems % Gd;
-  const int t_begin = wg * base + (wg < rem ? wg : rem);
-  const int n_my = base + (wg < rem ? 1 : 0);
+  // ---------------- the column block's weights, once ----------------
+  {
+    constexpr int KC8 = K / 8;                                         // 16-byte pieces per weight row
+    constexpr int WCH = 2 * NB * KC8;
+    const __amdgpu_buffer_rsrc_t W_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(d.w), 0, 2 * N * K * 2, 0x00020000);
+    constexpr int WB = 7, NBATCH = (WCH + 512 * WB - 1) / (512 * WB);   // batches of 7 pieces per lane in flight
+#pragma unroll 1
+    for (int b = 0; b < NBATCH; ++b) {
+      u32x4 wv[WB];
+#pragma unroll
+      for (int i = 0; i < WB; ++i) {
+        const int c = tid + 512 * (b * WB + i);
+        const int cc = c < WCH ? c : 0;
+        const int row = cc / KC8, kc = cc - row * KC8;                 // row = p * 32 + n
+        const int p = row / NB, n = row - p * NB;
+        wv[i] = __builtin_amdgcn_raw_buffer_load_b128(W_rs, c < WCH ? (uint32_t)(((p * N + n0 + n) * K + kc * 8) * 2) : INV, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < WB; ++i) {
+        const int c = tid + 512 * (b * WB + i);
+        const int cc = c < WCH ? c : 0;
+        const int row = cc / KC8, kc = cc - row * KC8;
+        if (c < WCH) *reinterpret_cast<u32x4*>(W_s + row * WP + kc * 16) = wv[i];
+      }
+    }
+    if (tid < 2 * NB) {
+      const int which = tid / NB, n = tid - which * NB;
+      float v = which == 0 ? 1.f : 0.f;
+      if (which == 0 && d.alpha) v = d.alpha[n0 + n];
+      if (which == 1 && d.beta) v = d.beta[n0 + n];
+      par_s[tid] = v;
+    }
+  }
+  __syncthreads();
 
-  // this lane's pieces of a halo image: LDS offset of the hi half, byte offset relative to the tile's origin record, (dy, dx)
+  // this lane's pieces of its wave's halo image: LDS offset of the hi half, byte offset relative to the tile's origin record,
+  // (dy, dx).  Lanes without a fourth piece request a copy of their third and write nothing.
   uint32_t h_lds[CPL];
   int h_rel[CPL], h_yx[CPL];
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
-    const int c = gl + 256 * i;
-    const int cc = c < PIECES ? c : 0;
+    const int c = lane + 64 * i;
+    const int cc = c < PIECES ? c : c - 64;
     const int hy = cc / (HWID * 4), r = cc - hy * (HWID * 4);
     const int px = r >> 2, j = r & 3;
     h_lds[i] = c < PIECES ? (uint32_t)(hy * RPB + px * PS + 8 * j) : 0xFFFFFFFFu;
@@ -142,203 +183,187 @@ __global__ __launch_bounds__(512) void dense_conv_wres_kernel(DenseParams P) {
     h_yx[i] = ((hy - 1) << 16) | ((px - 1) & 0xFFFF);
   }
   const __amdgpu_buffer_rsrc_t A_rs = make_rsrc(d.x);
-  u32x4 hreg[CPL];
-  auto halo_load = [&](int img, int ch, int y0, int x0) __attribute__((always_inline)) {
+  // two register sets: the halo of step s + 2 is requested at the start of step s and written to LDS at the end of step s + 1
+  // (a step is ~0.5 us of MFMAs, a load under a full chip takes longer than that)
+  u32x4 hreg[2][CPL];
+  auto halo_load = [&](u32x4 (&hr)[CPL], int img, int ch, int y0, int x0) __attribute__((always_inline)) {
     const uint32_t org = (uint32_t)((((img * CCH + ch) * H + y0) * W + x0) * REC);
+    if (y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= H && x0 + TW + 1 <= W) {  // interior tile: every halo pixel exists
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-      const int yy = y0 + (h_yx[i] >> 16), xx = x0 + (int)(int16_t)(h_yx[i] & 0xFFFF);
-      const bool ok = h_lds[i] != 0xFFFFFFFFu && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-      hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(A_rs, ok ? org + (uint32_t)h_rel[i] : INV, 0, 0);
+      for (int i = 0; i < CPL; ++i) hr[i] = __builtin_amdgcn_raw_buffer_load_b128(A_rs, org + (uint32_t)h_rel[i], 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int yy = y0 + (h_yx[i] >> 16), xx = x0 + (int)(int16_t)(h_yx[i] & 0xFFFF);
+        const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        hr[i] = __builtin_amdgcn_raw_buffer_load_b128(A_rs, ok ? org + (uint32_t)h_rel[i] : INV, 0, 0);
+      }
     }
   };
-  uint8_t* H_s = smem + W_BYTES + grp * HALO;
-  auto halo_store = [&]() __attribute__((always_inline)) {
+  uint8_t* H_s = smem + W_BYTES + wave * HALO;                        // this wave's own image: no other wave reads or writes it
+  auto halo_store = [&](const u32x4 (&hr)[CPL]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
       if (h_lds[i] != 0xFFFFFFFFu) {
-        *reinterpret_cast<uint2*>(H_s + h_lds[i]) = make_uint2(hreg[i].x, hreg[i].y);          // 4 x hi
-        *reinterpret_cast<uint2*>(H_s + h_lds[i] + 32) = make_uint2(hreg[i].z, hreg[i].w);     // 4 x lo
+        *reinterpret_cast<uint2*>(H_s + h_lds[i]) = make_uint2(hr[i].x, hr[i].y);          // 4 x hi
+        *reinterpret_cast<uint2*>(H_s + h_lds[i] + 32) = make_uint2(hr[i].z, hr[i].w);     // 4 x lo
       }
     }
   };
 
-  auto item_decode = [&](int item, int& cb, int& img, int& y0, int& x0) __attribute__((always_inline)) {
-    cb = item / P.tiles_m;
-    const int rt = item - cb * P.tiles_m;
-    img = rt / tiles_img;
-    const int tl = rt - img * tiles_img;
-    const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
-    y0 = ty * TH; x0 = tx * TW;
+  // a position in the walk over (image, tile row, tile column); the tiles of a wave are eight apart.  (Handing the tiles out
+  // through an LDS counter instead measured no faster - the waves of a workgroup already finish together.)
+  struct Pos { int img, ty, tx; };
+  auto pos_of = [&](int tile) __attribute__((always_inline)) {
+    Pos p;
+    p.img = tile / tiles_img;
+    const int tl = tile - p.img * tiles_img;
+    p.ty = tl / tiles_x; p.tx = tl - p.ty * tiles_x;
+    return p;
+  };
+  auto advance8 = [&](Pos& p) __attribute__((always_inline)) {
+    p.tx += 8;
+    while (p.tx >= tiles_x) { p.tx -= tiles_x; ++p.ty; }
+    while (p.ty >= tiles_y) { p.ty -= tiles_y; ++p.img; }
   };
 
-  // fragment addresses of this lane: 32 pixels of the wave (2 rows x 16) as MFMA rows, 32 weight rows as MFMA columns
+  // fragment addresses of this lane.  The WEIGHTS are the MFMA's row operand and the wave's 32 pixels (4 rows x 8) its column
+  // operand: accumulator slots 4q..4q+3 of a lane are then output channels 8q + 4*(lane / 32) + 0..3 of pixel lane % 32 -
+  // four consecutive channels, i.e. one 16-byte piece of the planes (or of an fp32 channels-last row) with no transpose.
   int ln = lane;
   asm volatile("" : "+v"(ln));
   const int l31 = ln & 31, lh = ln >> 5;
-  const uint32_t a_lane = (uint32_t)((2 * cw + (l31 >> 4)) * RPB + (l31 & 15) * PS + 16 * lh);
+  const uint32_t a_lane = (uint32_t)((l31 >> 3) * RPB + (l31 & 7) * PS + 16 * lh);
   const uint32_t w_lane = (uint32_t)(l31 * WP + 16 * lh);
-  const int qd = l31 >> 2, ql = l31 & 3;
   const __amdgpu_buffer_rsrc_t out_rs = make_rsrc(d.out), res_rs = make_rsrc(d.resid);
 
-  uint32_t nstep = 0;                                                 // halo steps this group has been through
-  int seg_begin = 0;
-  while (seg_begin < n_my) {
-    // ---------------- a segment of items that share the column block: (re)load its weights ----------------
-    int cb, img, y0, x0;
-    item_decode(t_begin + seg_begin, cb, img, y0, x0);
-    int seg_end = (cb + 1) * P.tiles_m - t_begin;
-    if (seg_end > n_my) seg_end = n_my;
-    const int n0 = cb * NB;
-    __syncthreads();                                                  // every wave is done with the previous block's weights
-    {
-      constexpr int KC8 = K / 8;                                       // 16-byte pieces per weight row
-      constexpr int WCH = 2 * NB * KC8;
-      const __amdgpu_buffer_rsrc_t W_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(d.w), 0, 2 * N * K * 2, 0x00020000);
-      constexpr int WB = 7, NBATCH = (WCH + 512 * WB - 1) / (512 * WB);   // batches of 7 pieces per lane in flight
-#pragma unroll 1
-      for (int b = 0; b < NBATCH; ++b) {
-        u32x4 wv[WB];
-#pragma unroll
-        for (int i = 0; i < WB; ++i) {
-          const int c = tid + 512 * (b * WB + i);
-          const int cc = c < WCH ? c : 0;
-          const int row = cc / KC8, kc = cc - row * KC8;               // row = p * 32 + n
-          const int p = row / NB, n = row - p * NB;
-          wv[i] = __builtin_amdgcn_raw_buffer_load_b128(W_rs, c < WCH ? (uint32_t)(((p * N + n0 + n) * K + kc * 8) * 2) : INV, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < WB; ++i) {
-          const int c = tid + 512 * (b * WB + i);
-          const int cc = c < WCH ? c : 0;
-          const int row = cc / KC8, kc = cc - row * KC8;
-          if (c < WCH) *reinterpret_cast<u32x4*>(W_s + row * WP + kc * 16) = wv[i];
-        }
-      }
-      if (tid < 2 * NB) {
-        const int which = tid / NB, n = tid - which * NB;
-        float v = which == 0 ? 1.f : 0.f;
-        if (which == 0 && d.alpha) v = d.alpha[n0 + n];
-        if (which == 1 && d.beta) v = d.beta[n0 + n];
-        par_s[tid] = v;
-      }
+#ifdef SDF_STAMP
+  unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, a_issue = 0, a_mfma = 0, a_epi = 0, a_store = 0, nstep = 0;
+  const unsigned long long kstart = __builtin_readcyclecounter(), rstart = __builtin_amdgcn_s_memrealtime();
+#endif
+  // ---------------- this wave's tiles of the range: wave, wave + 8, ...; steps = tiles x channel records ----------------
+  const int my_items = n_my > wave ? (n_my - wave + 7) / 8 : 0;
+  const int S = my_items * CCH;
+  Pos pc = pos_of(t_begin + wave);                                     // position of the step being multiplied
+  Pos pp = pc;                                                         // position / record / count of the next step to REQUEST
+  int chp = 0, sp = 0;
+  auto request = [&](u32x4 (&hr)[CPL]) __attribute__((always_inline)) {
+    if (sp < S) {
+      halo_load(hr, pp.img, chp, pp.ty * TH, pp.tx * TW);
+      ++sp;
+      if (++chp == CCH) { chp = 0; advance8(pp); }
     }
-    __syncthreads();
-    const float4 al4 = *reinterpret_cast<const float4*>(par_s + 4 * qd);
-    const float4 be4 = *reinterpret_cast<const float4*>(par_s + NB + 4 * qd);
-
-    // ---------------- this group's items of the segment: seg_begin + grp, + 2, ... ----------------
-    int it = seg_begin + grp;
-    if (it < seg_end) {
-      item_decode(t_begin + it, cb, img, y0, x0);
-      halo_load(img, 0, y0, x0);
-      if (nstep) wait_ge(&cnt[2 + grp], 4 * nstep);                   // previous halo fully read by the group
-      halo_store();
-      signal(&cnt[grp], lane);
-    }
-    for (; it < seg_end; it += 2) {
-      item_decode(t_begin + it, cb, img, y0, x0);
-      f32x16 acc;
+  };
+  if (S > 0) {
+    request(hreg[0]);
+    halo_store(hreg[0]);
+    request(hreg[1]);
+  }
+  f32x16 acc;
+  uint32_t pixoff = INV, pixres = INV;                                // byte offset of this lane's pixel in out / resid (first piece), or INV
+  u32x4 rs[4];
+  int ch = 0;
+  // one step: request step s + 2 into `hnew`, multiply step s, then write step s + 1 (requested a step ago, in `hold`)
+  auto step = [&](int s, u32x4 (&hnew)[CPL], const u32x4 (&hold)[CPL]) __attribute__((always_inline)) {
+    STAMP(s0);
+    request(hnew);
+    if (ch == 0) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-      uint32_t rowoff[4];                                             // byte offset of (pixel, first channel of the lane) in out, or INV
-      uint32_t resoff[4];
-      u32x4 rs[4];
-#pragma unroll 1
-      for (int ch = 0; ch < CCH; ++ch) {
-        // request the NEXT step's halo now: its latency hides behind this step's MFMAs
-        bool have_next = true;
-        {
-          int ni = img, nc = ch + 1, ny = y0, nx = x0;
-          if (nc == CCH) {
-            nc = 0;
-            if (it + 2 < seg_end) { int ncb; item_decode(t_begin + it + 2, ncb, ni, ny, nx); }
-            else have_next = false;
-          }
-          if (have_next) halo_load(ni, nc, ny, nx);
-        }
-        if (ch == CCH - 1) {
-          // rows of the epilogue and its residual, requested before the last MFMAs.  quad transpose: lane (qd, ql) ends with
-          // columns 4qd..4qd+3 of row rr = 8*q4 + 4*lh + ql of the wave's 32 pixels
+    }
+    if (ch == CCH - 1) {
+      // the epilogue's addresses and its residual, requested before the last MFMAs: piece q of the lane = channels
+      // n0 + 8q + 4*lh .. + 3 = record 2cb + (q >> 1), piece 2(q & 1) + lh of that record
+      const int img = pc.img;
+      const int y = pc.ty * TH + (l31 >> 3), x = pc.tx * TW + (l31 & 7);
+      const bool ok = y < H && x < W;
+      const uint32_t pix = (uint32_t)((img * H + y) * W + x);
+      pixres = ok ? (uint32_t)(img * nch + 2 * cb) * (uint32_t)(H * W) * REC + (uint32_t)(y * W + x) * REC + (uint32_t)lh * 16u : INV;
+      pixoff = !ok ? INV : out_f32 ? pix * (uint32_t)N * 4u + (uint32_t)(n0 + 4 * lh) * 4u : pixres;
 #pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const int rr = 8 * q4 + 4 * lh + ql;
-            const int y = y0 + 2 * cw + (rr >> 4), x = x0 + (rr & 15);
-            const bool ok = y < H && x < W;
-            const uint32_t rec = (uint32_t)(((img * nch + 2 * cb + (qd >> 2)) * H + y) * W + x) * REC + (uint32_t)(qd & 3) * 16u;
-            resoff[q4] = ok ? rec : INV;
-            rowoff[q4] = !ok ? INV : out_f32 ? (uint32_t)((img * H + y) * W + x) * (uint32_t)N * 4u + (uint32_t)(n0 + 4 * qd) * 4u : rec;
-            rs[q4] = u32x4{0u, 0u, 0u, 0u};
-          }
-          if (has_res) {
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) rs[q4] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, resoff[q4], 0, 0);
-          }
-        }
-        ++nstep;
-        wait_ge(&cnt[grp], 4 * nstep);                                // this step's halo is in LDS (all four waves' pieces)
-
-        // ------------------------------ MFMA phase: 9 taps x 3 products ------------------------------
-        constexpr int PF = 3;                                         // taps of fragments in flight
-        bf16x8 fa[PF + 1][2], fb[PF + 1][2];
-        const uint32_t w_step = w_lane + (uint32_t)ch * (9 * 32);
-        auto frag = [&](int tap, int set) __attribute__((always_inline)) {
-          const int ky = tap / 3, kx = tap - 3 * ky;
-          fa[set][0] = *reinterpret_cast<const bf16x8*>(H_s + a_lane + (ky * RPB + kx * PS));
-          fa[set][1] = *reinterpret_cast<const bf16x8*>(H_s + a_lane + (ky * RPB + kx * PS + 32));
-          fb[set][0] = *reinterpret_cast<const bf16x8*>(W_s + w_step + tap * 32);
-          fb[set][1] = *reinterpret_cast<const bf16x8*>(W_s + w_step + (NB * WP + tap * 32));
-        };
-#pragma unroll
-        for (int i = 0; i < PF; ++i) frag(i, i);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          if (tap + PF < 9) frag(tap + PF, (tap + PF) % (PF + 1));
-          __builtin_amdgcn_sched_barrier(0);
-          const int s = tap % (PF + 1);
-          acc = mma<2>(fa[s][1], fb[s][0], acc);                      // small terms first
-          acc = mma<2>(fa[s][0], fb[s][1], acc);
-          acc = mma<2>(fa[s][0], fb[s][0], acc);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        signal(&cnt[2 + grp], lane);                                  // every fragment of this halo is in registers
-
-        // ------------------------------ epilogue after the last channel step ------------------------------
-        if (ch == CCH - 1) {
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            float v[4] = {acc[q4 * 4 + 0], acc[q4 * 4 + 1], acc[q4 * 4 + 2], acc[q4 * 4 + 3]};
-            quad_transpose(v, ql);
-            float4 o;
-            o.x = __builtin_fmaf(v[0], al4.x, be4.x); o.y = __builtin_fmaf(v[1], al4.y, be4.y);
-            o.z = __builtin_fmaf(v[2], al4.z, be4.z); o.w = __builtin_fmaf(v[3], al4.w, be4.w);
-            if (has_res) {
-              const float4 r = piece_to(rs[q4]);
-              o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-            }
-            if (relu) {
-              o.x = __builtin_fmaxf(o.x, 0.f); o.y = __builtin_fmaxf(o.y, 0.f);
-              o.z = __builtin_fmaxf(o.z, 0.f); o.w = __builtin_fmaxf(o.w, 0.f);
-            }
-            u32x4 st;
-            if (out_f32) {
-              st.x = __float_as_uint(o.x); st.y = __float_as_uint(o.y); st.z = __float_as_uint(o.z); st.w = __float_as_uint(o.w);
-            } else {
-              st = piece_from(o);
-            }
-            __builtin_amdgcn_raw_buffer_store_b128(st, out_rs, rowoff[q4], 0, 0);
-          }
-        }
-        // ------------------------------ hand the next halo over ------------------------------
-        if (have_next) {
-          wait_ge(&cnt[2 + grp], 4 * nstep);                          // all four waves have this step's fragments in registers
-          halo_store();
-          signal(&cnt[grp], lane);
-        }
+      for (int q = 0; q < 4; ++q) {
+        rs[q] = u32x4{0u, 0u, 0u, 0u};
+        if (has_res) rs[q] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, ok ? pixres + (uint32_t)((q >> 1) * H * W * REC + (q & 1) * 32) : INV, 0, 0);
       }
     }
-    seg_begin = seg_end;
+    STAMP(s1);
+
+    // ------------------------------ MFMA phase: 9 taps x 3 products ------------------------------
+    constexpr int PF = 3;                                             // taps of fragments in flight
+    bf16x8 fa[PF + 1][2], fb[PF + 1][2];
+    const uint32_t w_step = w_lane + (uint32_t)ch * (9 * 32);
+    auto frag = [&](int tap, int set) __attribute__((always_inline)) {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      fa[set][0] = *reinterpret_cast<const bf16x8*>(H_s + a_lane + (ky * RPB + kx * PS));
+      fa[set][1] = *reinterpret_cast<const bf16x8*>(H_s + a_lane + (ky * RPB + kx * PS + 32));
+      fb[set][0] = *reinterpret_cast<const bf16x8*>(W_s + w_step + tap * 32);
+      fb[set][1] = *reinterpret_cast<const bf16x8*>(W_s + w_step + (NB * WP + tap * 32));
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) frag(i, i);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap + PF < 9) frag(tap + PF, (tap + PF) % (PF + 1));
+      __builtin_amdgcn_sched_barrier(0);
+      const int f = tap % (PF + 1);
+      acc = mma<2>(fb[f][0], fa[f][1], acc);                          // w_hi * a_lo: small terms first
+      acc = mma<2>(fb[f][1], fa[f][0], acc);                          // w_lo * a_hi
+      acc = mma<2>(fb[f][0], fa[f][0], acc);                          // w_hi * a_hi
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    STAMP(s2);
+    // the next image goes into LDS behind this step's last fragment reads (a wave's LDS operations execute in order)
+    if (s + 1 < S) halo_store(hold);
+    STAMP(s3);
+
+    // ------------------------------ epilogue after the last channel step ------------------------------
+    if (ch == CCH - 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 al4 = *reinterpret_cast<const float4*>(par_s + 8 * q + 4 * lh);
+        const float4 be4 = *reinterpret_cast<const float4*>(par_s + NB + 8 * q + 4 * lh);
+        float4 o;
+        o.x = __builtin_fmaf(acc[q * 4 + 0], al4.x, be4.x); o.y = __builtin_fmaf(acc[q * 4 + 1], al4.y, be4.y);
+        o.z = __builtin_fmaf(acc[q * 4 + 2], al4.z, be4.z); o.w = __builtin_fmaf(acc[q * 4 + 3], al4.w, be4.w);
+        if (has_res) {
+          const float4 r = piece_to(rs[q]);
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (relu) {
+          o.x = __builtin_fmaxf(o.x, 0.f); o.y = __builtin_fmaxf(o.y, 0.f);
+          o.z = __builtin_fmaxf(o.z, 0.f); o.w = __builtin_fmaxf(o.w, 0.f);
+        }
+        u32x4 st;
+        uint32_t off;
+        if (out_f32) {
+          st.x = __float_as_uint(o.x); st.y = __float_as_uint(o.y); st.z = __float_as_uint(o.z); st.w = __float_as_uint(o.w);
+          off = pixoff + (uint32_t)(q * 32);
+        } else {
+          st = piece_from(o);
+          off = pixoff + (uint32_t)((q >> 1) * H * W * REC + (q & 1) * 32);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(st, out_rs, pixoff != INV ? off : INV, 0, 0);
+      }
+    }
+    if (++ch == CCH) { ch = 0; advance8(pc); }
+    STAMP(s4);
+    STAMP_ADD(a_issue, s0, s1); STAMP_ADD(a_mfma, s1, s2); STAMP_ADD(a_store, s2, s3); STAMP_ADD(a_epi, s3, s4);
+#ifdef SDF_STAMP
+    ++nstep;
+#endif
+  };
+#pragma unroll 1
+  for (int s = 0; s < S; s += 2) {
+    step(s, hreg[0], hreg[1]);
+    if (s + 1 < S) step(s + 1, hreg[1], hreg[0]);
   }
+#ifdef SDF_STAMP
+  if (blockIdx.x == 0 && (tid == 0 || tid == 256)) {
+    unsigned long long* o = g_dense_stamp + (tid ? 16 : 0);
+    o[0] = a_issue; o[1] = 0; o[2] = a_mfma; o[3] = a_epi; o[4] = 0; o[5] = a_store; o[6] = nstep;
+    o[7] = __builtin_readcyclecounter() - kstart; o[8] = __builtin_amdgcn_s_memrealtime() - rstart;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -397,15 +422,24 @@ extern "C" int sdf_dense_conv3x3_fwd(const SdfDenseConvDesc* d, void* stream) {
   if (px * d->cin_records * REC >= lim || px * d->N * 4 >= lim) return SDF_E_SHAPE;   // 31-bit buffer offsets
   DenseParams P;
   P.d = *d;
-  P.tiles_m = (int)((int64_t)d->imgs * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW));
-  P.ntiles = P.tiles_m * (d->N / NB);
-  const int G = P.ntiles < 256 ? P.ntiles : 256;
+  P.wtiles = (int)((int64_t)d->imgs * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW));
+  const int ncb = d->N / NB;
+  if (ncb > 32) return SDF_E_SHAPE;
+  const int want = (P.wtiles + 7) / 8;                                 // a workgroup wants at least one tile per wave
+  P.ranges = want < 256 / ncb ? want : 256 / ncb;
+  const int G = P.ranges == 256 / ncb ? 256 : P.ranges * ncb;
   hipStream_t s = sdf_stream(stream);
   if (d->cin_records == 1) hipLaunchKernelGGL((dense_conv_wres_kernel<1>), dim3(G), dim3(512), 0, s, P);
   else hipLaunchKernelGGL((dense_conv_wres_kernel<6>), dim3(G), dim3(512), 0, s, P);
   SDF_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef SDF_STAMP
+extern "C" int sdf_debug_read_stamps_dense(unsigned long long* host32) {
+  return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(g_dense_stamp), 32 * sizeof(unsigned long long));
+}
+#endif
 
 static int planes_grid(int64_t total) {
   const int64_t b = (total + 255) / 256;

@@ -1,0 +1,21 @@
+#!/usr/bin/env bash
+# PMC counters of the dense 3x3 convolution (own --pmc passes; HBM bytes as MI355X_MICROARCH.md prescribes: FETCH_SIZE x2 on gfx950).
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/pmc_dense
+for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_INSTS_SMEM" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
+  timeout 120 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_dense -- python3 tools/dense_conv_one.py "$@" > /dev/null 2>&1 < /dev/null
+done
+python3 - <<PY
+import csv, glob, collections
+acc = collections.defaultdict(list)
+for f in glob.glob("gpurun_out/pmc_dense/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "dense_conv_wres" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k in sorted(acc):
+    v = acc[k]
+    print(f"{k:32s} {sum(v)/len(v):16.0f}  (n={len(v)})")
+PY
