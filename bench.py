@@ -164,6 +164,52 @@ def time_dominant_kernels(model, iters=40):
     return gemm, neuron
 
 
+def time_config3(iters=10):
+    """BASELINE configs[2] beside the headline: the ANN STTFlowNet (STT_voxel config: 20 bins, patch (10,4,4), window (2,9,9)) at
+    batch 8, 288 x 384, synthetic weights and voxels - ms per batch, samples/s - and its dominant kernel, the dense 3x3
+    convolution of the patch embedding on two fp16 planes per operand (csrc/dense_conv_wres.hip), timed with HIP events on the
+    launch stream on config 3's own shape (16 images x 96 channels x 288 x 384, BatchNorm + residual + ReLU in the epilogue)."""
+    import yaml
+    from sdformerflow_amd import hip
+    from sdformerflow_amd.STSwinNet import STSwinNet
+    from sdformerflow_amd.synthetic import synth_state_dict, synth_voxel
+    B, H, W = 8, 288, 384
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "sdformerflow_amd", "configs", "train_DSEC_supervised_STT_voxel.yml")))
+    net = STSwinNet.STTFlowNet(dict(cfg["model"], spiking_neuron=None), dict(cfg["swin_transformer"], input_size=[H, W])).eval()
+    skip = ("relative_position_index", "relative_coords_table", "num_batches_tracked")
+    net.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items() if not k.endswith(skip)}), strict=False)
+    net = net.to("cuda")
+    vox = synth_voxel(B, 20, H, W, seed=1237).to("cuda")
+    with torch.no_grad():
+        for _ in range(3):
+            flow = net(vox, None)["flow"]
+        assert all(torch.isfinite(f).all() for f in flow)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            net(vox, None)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+    g = torch.Generator().manual_seed(0)
+    sets = []
+    for _ in range(2):                                             # 2 x (0.68 GB in + 0.68 GB residual + 0.68 GB out) > 3 x the Infinity Cache
+        xp = hip.pack_planes(torch.randn(2 * B, 96, H, W, generator=g).cuda())
+        rp = hip.pack_planes(torch.randn(2 * B, 96, H, W, generator=g).cuda())
+        sets.append((xp, rp))
+    wp = hip.pack_dense_conv_weight((torch.randn(96, 96, 3, 3, generator=g) / 30).cuda())
+    al, be = (0.5 + torch.rand(96, generator=g)).cuda(), torch.randn(96, generator=g).cuda()
+    t = _timed(lambda s_: hip.dense_conv3x3(s_[0], wp, al, be, s_[1], True), sets, 20)
+    flop = 2 * B * H * W * 96 * 864 * 2
+    del sets
+    return {"workload": "BASELINE configs[2]: STTFlowNet (ANN) forward, batch 8, 20-bin 288x384 voxel, fp32 activations", "samples_per_s": B / dt,
+            "ms_per_batch": dt * 1e3, "dtype": "f32 as f16x2 (hi + lo planes of both operands, three products, fp32 accumulate)",
+            "roofline": {"kernel": "dense_conv_wres_kernel<6> (16 x 96 x 288 x 384, 3x3, BN + residual + ReLU fused)", "bound": "mfma",
+                         "achieved": flop / t / 1e12, "executed_on_pipe": 3 * flop / t / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": flop / t / 1e12 / 2500.0, "frac_executed": 3 * flop / t / 1e12 / 2500.0, "us_per_launch": t * 1e6,
+                         "algorithmic_flop_per_launch": flop, "operand_sets_in_rotation": 2, "traffic": 1.89e9 + 0.66e9,
+                         "traffic_note": "HBM bytes per launch from profiles/r2m_pmc_dense.txt (FETCH_SIZE x 2 + WRITE_SIZE); algorithmic 2.04e9"}}
+
+
 def time_swin_blocks(model, chunk, iters=10):
     """The attention-GEMM roofline fraction of the metric: SURVEY.md 8(d)'s 183.7 GFLOP of the swin blocks' Linear layers
     (q|k, proj, fc1, fc2, merge) per sample / the time of the swin stages themselves - the 12 blocks + 3 merges run alone on
@@ -398,6 +444,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--neuron", default="lif", choices=["lif", "psn"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-config3", action="store_true", help="skip the BASELINE configs[2] (ANN, batch 8) side measurement")
     ap.add_argument("--inflight", type=int, default=3, help="independent forwards in flight per GPU (HIP streams)")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying HIP graphs")
     ap.add_argument("--planes", type=int, default=2, choices=[1, 2, 3],
@@ -513,6 +560,8 @@ def main():
             "roofline": gemm, "roofline_neuron": neuron,
             "attention_gemm_roofline_frac": blocks["frac"], "attention_gemm": blocks,
         }
+        if not args.no_config3 and world == 1:
+            res["config3_ann"] = time_config3()
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.neuron, sd, chunk_cpu)
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]

@@ -116,3 +116,36 @@ def test_window_partition_inside_the_attention_kernel_equals_the_materialised_se
             os.environ.pop("SDF_ATTN_MATERIALISE", None)
     assert fused.shape == ref.shape == x.shape
     assert (fused - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_config3_batch8_dense_convolution_path(monkeypatch):
+    """BASELINE configs[2] at full size (batch 8, 20 bins, 288 x 384): the patch embedding's stride-1 convolutions on this
+    framework's dense convolution (two fp16 planes per operand, csrc/dense_conv_wres.hip) against (a) the CPU oracle on the first
+    and last sample and (b) the same network with the library's fp32 convolutions on the whole batch - the 1e-3 bound of the north
+    star, and in practice four orders closer to the library path than that."""
+    from oracle import sdformer_oracle as O
+    net = build("STTFlowNet", (288, 384)).eval()
+    sd = load_synth(net)
+    vox = synth_voxel(8, 20, 288, 384, seed=1237)
+    cfg = {"num_bins": 20, "patch_size": (10, 4, 4), "window_size": (2, 9, 9), "depths": [2, 2, 6], "num_heads": [3, 6, 12]}
+    net = net.cuda()
+    net.norm_input = False
+    calls = []
+    from sdformerflow_amd import hip
+    real = hip.dense_conv3x3
+    monkeypatch.setattr(hip, "dense_conv3x3", lambda *a, **k: (calls.append(a[0].shape), real(*a, **k))[1])
+    got = [f.cpu() for f in net(vox.cuda(), None)["flow"]]
+    assert len(calls) == 9 and all(c[0] == 16 for c in calls), calls          # head + 8 residual-block convolutions, 16 images each
+    monkeypatch.setenv("SDF_DENSE_CONV", "0")
+    lib = [f.cpu() for f in net(vox.cuda(), None)["flow"]]
+    assert len(calls) == 9
+    for i, (a, b) in enumerate(zip(got, lib)):
+        d = (a - b).abs().max().item()
+        assert d <= 2e-5 * b.abs().mean().item(), (i, d, b.abs().mean().item())
+    for n in (0, 7):
+        with torch.no_grad():
+            ref = O.forward_sttflownet(vox[n:n + 1], sd, cfg)
+        for i, (a, b) in enumerate(zip(got, ref)):
+            d = (a[n:n + 1] - b).abs().max().item()
+            assert d <= 1e-3 * b.abs().mean().item(), (n, i, d)
