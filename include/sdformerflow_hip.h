@@ -475,12 +475,19 @@ typedef struct SdfDenseConvDesc {
   int32_t imgs, H, W, cin_records, N;
   int32_t relu;             /* max(., 0) after the residual add */
   int32_t out_f32;
+  int32_t x_records;        /* records per image of the tensor x points into when x is a channel slice of a wider planes tensor
+                             * (x = base + first_record * H * W * 64 bytes); 0 = cin_records.  Wide convolutions are chains of
+                             * slices: out_k = conv(slice_k) + out_{k-1} through `resid`, the last link carries beta and relu */
 } SdfDenseConvDesc;
 
 int sdf_dense_conv3x3_fwd(const SdfDenseConvDesc* d, void* stream);
 /* x (imgs,C,H,W) fp32 -> planes (channels C .. 16*ceil(C/16)-1 zero) and back */
 int sdf_pack_planes(const float* x, void* planes, int imgs, int C, int H, int W, void* stream);
 int sdf_unpack_planes(const void* planes, float* x, int imgs, int C, int H, int W, void* stream);
+/* bilinear x2 upsampling (align_corners false; reference models/submodules.py:117-157 `UpsampleConvLayer`) of x (imgs,C,h,w) fp32
+ * with element strides (sn,sc,sh,sw), written as records rec0 .. rec0+ceil(C/16)-1 of planes [imgs][rec_total][2h][2w] */
+int sdf_pack_planes_up2(const float* x, void* planes, int imgs, int C, int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                        int rec0, int rec_total, void* stream);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,8 @@
 The window-attention core (section 8 row a10) is this framework's fused HIP kernel; the dense glue around it
 (LayerNorm, Linear, GELU, fp32 convolutions, bilinear upsampling) is library work through torch on the GPU.
 Forward-only: the modules refuse training mode and CPU tensors (no fallback path)."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -26,7 +28,63 @@ class ConvLayer(nn.Module):
 
 
 class UpsampleConvLayer(ConvLayer):
-    """bilinear x2 (align_corners False) -> conv2d -> relu (reference models/submodules.py:117-157)."""
+    """bilinear x2 (align_corners False) -> conv2d -> relu (reference models/submodules.py:117-157).
+    `forward_parts` is the same layer on the channel concatenation of `parts` without materialising it: each part is upsampled
+    straight into its records of one activation-planes tensor (sdf_pack_planes_up2) and the 3x3 convolution runs on this
+    framework's dense convolution as a chain of 96-channel slices (hip.dense_conv3x3_wide); `order` says where each part's
+    channels sit in the layer's weight (the reference concatenates [prediction, features, skip], the planes hold the
+    2-channel prediction last so that every slice starts on a 16-channel record)."""
+
+    def parts_plan(self, parts, order):
+        """Record layout of the parts, or None when this layer / these shapes have no dense-convolution form."""
+        conv = self.conv2d
+        if (self.training or conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.out_channels % 32 or self.activation != "relu"
+                or os.environ.get("SDF_DENSE_CONV", "1") == "0" or not all(p.is_cuda and p.dtype == torch.float32 for p in parts)):
+            return None
+        if any(p.shape[1] % 16 for p in parts[:-1]):
+            return None
+        recs = [-(-p.shape[1] // 16) for p in parts]
+        slices = hip.dense_conv_slices(sum(recs))
+        imgs, _, h, w = parts[0].shape
+        if slices is None or not hip.dense_conv_applicable(imgs, 2 * h, 2 * w, 96, conv.out_channels) \
+                or imgs * 4 * h * w * sum(recs) * 64 >= 1 << 31:
+            return None
+        return recs, slices
+
+    def _packed(self, parts, order, recs, slices):
+        conv = self.conv2d
+        stamp = (conv.weight.data_ptr(), conv.weight._version, conv.bias.data_ptr(), conv.bias._version, tuple(order), tuple(recs))
+        if getattr(self, "_pk_stamp", None) != stamp:
+            w = conv.weight.detach().float()
+            start = [0] * len(parts)                                   # first weight channel of each part: `order` lists the parts as the
+            c = 0                                                      # reference concatenates them
+            for i in order:
+                start[i] = c
+                c += parts[i].shape[1]
+            cols = []
+            for i, p in enumerate(parts):
+                blk = w[:, start[i]:start[i] + p.shape[1]]
+                pad = recs[i] * 16 - p.shape[1]
+                cols.append(F.pad(blk, (0, 0, 0, 0, 0, pad)) if pad else blk)
+            wr = torch.cat(cols, dim=1)                                # weight in the planes' channel order, parts padded to whole records
+            self._pk = [((r0, n), hip.pack_dense_conv_weight(wr[:, 16 * r0:16 * (r0 + n)])) for r0, n in slices]
+            self._pk_bias = conv.bias.detach().float().contiguous()
+            self._pk_stamp = stamp
+        return self._pk, self._pk_bias
+
+    def forward_parts(self, parts, order):
+        plan = self.parts_plan(parts, order)
+        if plan is None:
+            return self.forward(torch.cat([parts[i] for i in order], dim=1))
+        recs, slices = plan
+        imgs, _, h, w = parts[0].shape
+        planes = torch.empty((imgs, sum(recs), 2 * h, 2 * w, 32), dtype=torch.float16, device=parts[0].device)
+        r0 = 0
+        for p, r in zip(parts, recs):
+            hip.pack_planes_up2(p, planes, r0)
+            r0 += r
+        wsl, bias = self._packed(parts, order, recs, slices)
+        return hip.dense_conv3x3_wide(planes, wsl, bias, True, True).permute(0, 3, 1, 2)     # (imgs, Cout, 2h, 2w), channels last
 
     def forward(self, x):
         return super().forward(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False))
@@ -89,10 +147,9 @@ class STT_MultiResUNet(nn.Module):
             y = rb(y)
         preds = []
         for i, (dec, pred) in enumerate(zip(self.decoders, self.preds)):
-            y = torch.cat([y, blocks[self.num_encoders - 1 - i]], dim=1)
-            if i > 0:
-                y = torch.cat([preds[-1], y], dim=1)
-            y = dec(y)
+            # the reference concatenates [previous prediction, features, skip] (models/STSwinNet/STSwinNet.py:259-283)
+            parts = [y, blocks[self.num_encoders - 1 - i]] + ([preds[-1]] if i > 0 else [])
+            y = dec.forward_parts(parts, [2, 0, 1] if i > 0 else [0, 1])
             preds.append(pred(y))
         return preds, None
 

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(512) void dense_conv_wres_kernel(DenseParams P) {
   const bool relu = d.relu != 0, out_f32 = d.out_f32 != 0;
   const int nch = N >> 4;                                             // channel records of the output / residual planes
   const int ncb = N / NB;
+  const int xrec = d.x_records > 0 ? d.x_records : CCH;               // records per image of the tensor x is a slice of
 
   // workgroup -> (tile range, column block).  The ncb workgroups of a range run side by side on ONE XCD, so the activations
   // they all read come out of HBM once and out of that L2 afterwards (column blocks as an outer loop over the whole tensor read
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(512) void dense_conv_wres_kernel(DenseParams P) {
   // (a step is ~0.5 us of MFMAs, a load under a full chip takes longer than that)
   u32x4 hreg[2][CPL];
   auto halo_load = [&](u32x4 (&hr)[CPL], int img, int ch, int y0, int x0) __attribute__((always_inline)) {
-    const uint32_t org = (uint32_t)((((img * CCH + ch) * H + y0) * W + x0) * REC);
+    const uint32_t org = (uint32_t)((((img * xrec + ch) * H + y0) * W + x0) * REC);
     if (y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= H && x0 + TW + 1 <= W) {  // interior tile: every halo pixel exists
 #pragma unroll
       for (int i = 0; i < CPL; ++i) hr[i] = __builtin_amdgcn_raw_buffer_load_b128(A_rs, org + (uint32_t)h_rel[i], 0, 0);
@@ -408,6 +409,45 @@ __global__ __launch_bounds__(256) void unpack_planes_kernel(const u32x4* __restr
   }
 }
 
+// Bilinear x2 upsampling (align_corners false: F.interpolate(scale_factor=2, mode="bilinear"), reference models/submodules.py:117-157
+// `UpsampleConvLayer`) of an (imgs, C, h, w) fp32 tensor with arbitrary strides, written as records rec0 .. of planes
+// [imgs][rec_total][2h][2w]: output pixel 2k takes 0.25 / 0.75 of inputs k-1 / k, pixel 2k+1 takes 0.75 / 0.25 of k / k+1,
+// indices clamped to the image.  One thread per (output pixel, 4-channel piece).
+__global__ __launch_bounds__(256) void pack_planes_up2_kernel(const float* __restrict__ x, u32x4* __restrict__ planes, int imgs, int C,
+                                                              int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int rec0,
+                                                              int rec_total) {
+  const int H = 2 * h, W = 2 * w, nch = (C + 15) / 16;
+  const int64_t hw = (int64_t)H * W;
+  const int64_t total = (int64_t)imgs * nch * 4 * hw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t pix = i % hw;
+    const int64_t r = i / hw;
+    const int j = (int)(r & 3);
+    const int64_t ic = r >> 2;
+    const int img = (int)(ic / nch), rec = (int)(ic - (int64_t)img * nch);
+    const int oy = (int)(pix / W), ox = (int)(pix - (int64_t)oy * W);
+    const int ky = oy >> 1, kx = ox >> 1;
+    const int y0 = (oy & 1) ? ky : (ky > 0 ? ky - 1 : 0), y1 = (oy & 1) ? (ky + 1 < h ? ky + 1 : h - 1) : ky;
+    const int x0 = (ox & 1) ? kx : (kx > 0 ? kx - 1 : 0), x1 = (ox & 1) ? (kx + 1 < w ? kx + 1 : w - 1) : kx;
+    const float wy1 = (oy & 1) ? 0.25f : (ky > 0 ? 0.75f : 0.f), wx1 = (ox & 1) ? 0.25f : (kx > 0 ? 0.75f : 0.f);
+    const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = rec * 16 + 4 * j + e;
+      float o = 0.f;
+      if (c < C) {
+        const float* b = x + img * sn + c * sc;
+        const float top = wx0 * b[y0 * sh + x0 * sw] + wx1 * b[y0 * sh + x1 * sw];
+        const float bot = wx0 * b[y1 * sh + x0 * sw] + wx1 * b[y1 * sh + x1 * sw];
+        o = wy0 * top + wy1 * bot;
+      }
+      v[e] = o;
+    }
+    planes[(((int64_t)img * rec_total + rec0 + rec) * hw + pix) * 4 + j] = piece_from(make_float4(v[0], v[1], v[2], v[3]));
+  }
+}
+
 }  // namespace
 }  // namespace sdfmm
 
@@ -418,8 +458,9 @@ extern "C" int sdf_dense_conv3x3_fwd(const SdfDenseConvDesc* d, void* stream) {
   if (d->cin_records != 1 && d->cin_records != 6) return SDF_E_SHAPE;            // instantiated: Cin <= 16 (head), Cin = 96
   if (!sdf_aligned(d->x, 16) || !sdf_aligned(d->w, 16) || !sdf_aligned(d->out, 16) || (d->resid && !sdf_aligned(d->resid, 16)))
     return SDF_E_ALIGN;
+  if (d->x_records != 0 && d->x_records < d->cin_records) return SDF_E_SHAPE;
   const int64_t lim = (int64_t)1 << 31, px = (int64_t)d->imgs * d->H * d->W;
-  if (px * d->cin_records * REC >= lim || px * d->N * 4 >= lim) return SDF_E_SHAPE;   // 31-bit buffer offsets
+  if (px * (d->x_records > 0 ? d->x_records : d->cin_records) * REC >= lim || px * d->N * 4 >= lim) return SDF_E_SHAPE;   // 31-bit buffer offsets
   DenseParams P;
   P.d = *d;
   P.wtiles = (int)((int64_t)d->imgs * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW));
@@ -454,6 +495,19 @@ extern "C" int sdf_pack_planes(const float* x, void* planes, int imgs, int C, in
   const int64_t total = (int64_t)imgs * nch * 4 * H * W;
   hipLaunchKernelGGL(sdfmm::pack_planes_kernel, dim3(planes_grid(total)), dim3(256), 0, sdf_stream(stream), x,
                      reinterpret_cast<sdfmm::u32x4*>(planes), imgs, C, nch, H, W);
+  SDF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sdf_pack_planes_up2(const float* x, void* planes, int imgs, int C, int h, int w, int64_t sn, int64_t sc, int64_t sh,
+                                   int64_t sw, int rec0, int rec_total, void* stream) {
+  if (!x || !planes) return SDF_E_NULL;
+  const int nch = (C + 15) / 16;
+  if (imgs <= 0 || C <= 0 || h <= 0 || w <= 0 || rec0 < 0 || rec0 + nch > rec_total) return SDF_E_SHAPE;
+  if (!sdf_aligned(planes, 16)) return SDF_E_ALIGN;
+  const int64_t total = (int64_t)imgs * nch * 4 * (2 * h) * (2 * w);
+  hipLaunchKernelGGL(sdfmm::pack_planes_up2_kernel, dim3(planes_grid(total)), dim3(256), 0, sdf_stream(stream), x,
+                     reinterpret_cast<sdfmm::u32x4*>(planes), imgs, C, h, w, sn, sc, sh, sw, rec0, rec_total);
   SDF_LAUNCH_CHECK();
   return 0;
 }

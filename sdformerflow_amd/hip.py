@@ -27,7 +27,7 @@ EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_s
            "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
            "sdf_rows_gather_fwd", "sdf_rows_scatter_fwd",
            "sdf_split_weight_i8x3", "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd",
-           "sdf_dense_conv3x3_fwd", "sdf_pack_planes", "sdf_unpack_planes")
+           "sdf_dense_conv3x3_fwd", "sdf_pack_planes", "sdf_unpack_planes", "sdf_pack_planes_up2")
 
 
 class SdfError(RuntimeError):
@@ -86,7 +86,7 @@ class WinAttnDesc(C.Structure):
 class DenseConvDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("alpha", C.c_void_p), ("beta", C.c_void_p), ("resid", C.c_void_p),
                 ("out", C.c_void_p), ("imgs", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("cin_records", C.c_int32),
-                ("N", C.c_int32), ("relu", C.c_int32), ("out_f32", C.c_int32)]
+                ("N", C.c_int32), ("relu", C.c_int32), ("out_f32", C.c_int32), ("x_records", C.c_int32)]
 
 
 _lib = None
@@ -666,6 +666,22 @@ def unpack_planes(planes, Cc):
     return x
 
 
+def pack_planes_up2(x, planes=None, rec0=0):
+    """Bilinear x2 upsampling (F.interpolate(scale_factor=2, mode="bilinear", align_corners=False)) of x (imgs, C, h, w) fp32 - any
+    strides, e.g. a channels-last view - straight into activation planes at twice the size; with `planes` / `rec0` it fills records
+    rec0 .. of an existing (imgs, R, 2h, 2w, 32) tensor, which is how a channel concatenation is assembled (sdf_pack_planes_up2)."""
+    imgs, Cc, h, w = x.shape
+    if planes is None:
+        planes = torch.empty((imgs, -(-Cc // 16), 2 * h, 2 * w, 32), dtype=torch.float16, device=x.device)
+    if tuple(planes.shape[2:]) != (2 * h, 2 * w, 32) or planes.shape[0] != imgs or not planes.is_contiguous():
+        raise SdfError("planes must be a contiguous (imgs, R, 2h, 2w, 32) tensor")
+    sn, sc, sh, sw = x.stride()
+    _check(lib().sdf_pack_planes_up2(C.c_void_p(_ptr(x, torch.float32)), C.c_void_p(_ptr(planes, torch.float16)), C.c_int(imgs),
+                                     C.c_int(Cc), C.c_int(h), C.c_int(w), C.c_int64(sn), C.c_int64(sc), C.c_int64(sh), C.c_int64(sw),
+                                     C.c_int(rec0), C.c_int(planes.shape[1]), _stream()), "sdf_pack_planes_up2")
+    return planes
+
+
 def pack_dense_conv_weight(w):
     """Conv2d weight (Cout, Cin, 3, 3) fp32 -> fp16 planes (2, Cout, 9 * 16 * ceil(Cin/16)), w = plane0 + plane1, K ordered
     (16-channel record, ky, kx, channel in record); channels beyond Cin are zero."""
@@ -681,6 +697,24 @@ def pack_dense_conv_weight(w):
     return torch.stack([hi, lo]).contiguous()
 
 
+def dense_conv_slices(records):
+    """Record ranges [(first, count)] a convolution over `records` input records is chained from: sixes, then at most one single."""
+    six, one = divmod(records, 6)
+    if one > 1:
+        return None
+    return [(6 * i, 6) for i in range(six)] + ([(6 * six, 1)] if one else [])
+
+
+def dense_conv3x3_wide(xp, wslices, beta=None, relu=False, out_f32=False):
+    """3x3 convolution over any record count `dense_conv_slices` can cut: link k multiplies records [first, first + count) with its own
+    weight planes and adds the previous link's result (`resid`); the last link adds beta, applies relu and picks the output format."""
+    out = None
+    for k, ((r0, n), wp) in enumerate(wslices):
+        last = k == len(wslices) - 1
+        out = dense_conv3x3(xp[:, r0:r0 + n], wp, None, beta if last else None, out, relu and last, out_f32 and last)
+    return out
+
+
 def dense_conv_applicable(imgs, H, W, Cin, Cout):
     """Shapes sdf_dense_conv3x3_fwd has an instantiation for (Cin <= 16 or Cin == 96, Cout in blocks of 32, 31-bit offsets)."""
     rec = -(-Cin // 16)
@@ -694,12 +728,16 @@ def dense_conv3x3(xp, wplanes, alpha=None, beta=None, resid=None, relu=False, ou
     N = wplanes.shape[1]
     if wplanes.shape[2] != rec * 144:
         raise SdfError(f"weight planes of K = {wplanes.shape[2]} against {rec} activation records")
+    # a channel slice xp = full[:, r0:r0 + rec] of a wider contiguous planes tensor is addressed in place
+    if xp.stride()[1:] != (H * W * 32, W * 32, 32, 1) or xp.stride(0) % (H * W * 32) or xp.stride(0) < rec * H * W * 32:
+        raise SdfError("activation planes must be contiguous or a record slice of a contiguous planes tensor")
+    x_records = xp.stride(0) // (H * W * 32)
     if resid is not None and tuple(resid.shape) != (imgs, N // 16, H, W, 32):
         raise SdfError("residual planes must have the output's shape")
     out = (torch.empty((imgs, H, W, N), dtype=torch.float32, device=xp.device) if out_f32 else
            torch.empty((imgs, N // 16, H, W, 32), dtype=torch.float16, device=xp.device))
     d = DenseConvDesc()
-    d.x, d.w = _ptr(xp, torch.float16), _ptr(wplanes, torch.float16)
+    d.x, d.w, d.x_records = _ptr(xp, torch.float16), _ptr(wplanes, torch.float16), x_records
     d.alpha, d.beta = _ptr(alpha, torch.float32), _ptr(beta, torch.float32)
     d.resid, d.out = _ptr(resid, torch.float16), out.data_ptr()
     d.imgs, d.H, d.W, d.cin_records, d.N, d.relu, d.out_f32 = imgs, H, W, rec, N, int(relu), int(out_f32)

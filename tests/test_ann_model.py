@@ -136,10 +136,12 @@ def test_config3_batch8_dense_convolution_path(monkeypatch):
     real = hip.dense_conv3x3
     monkeypatch.setattr(hip, "dense_conv3x3", lambda *a, **k: (calls.append(a[0].shape), real(*a, **k))[1])
     got = [f.cpu() for f in net(vox.cuda(), None)["flow"]]
-    assert len(calls) == 9 and all(c[0] == 16 for c in calls), calls          # head + 8 residual-block convolutions, 16 images each
+    # head + 8 residual-block convolutions on 16 images (batch x 2 temporal chunks); the three decoders' 768 / 386 / 194-channel
+    # convolutions as chains of 8 / 5 / 3 slices on 8 images
+    assert [c[0] for c in calls] == [16] * 9 + [8] * 16 and [c[1] for c in calls[9:]] == [6] * 8 + [6] * 4 + [1] + [6] * 2 + [1], calls
     monkeypatch.setenv("SDF_DENSE_CONV", "0")
     lib = [f.cpu() for f in net(vox.cuda(), None)["flow"]]
-    assert len(calls) == 9
+    assert len(calls) == 25
     for i, (a, b) in enumerate(zip(got, lib)):
         d = (a - b).abs().max().item()
         assert d <= 2e-5 * b.abs().mean().item(), (i, d, b.abs().mean().item())

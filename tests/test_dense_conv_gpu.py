@@ -95,3 +95,43 @@ def test_rejects_unsupported_shapes():
     w = hip.pack_dense_conv_weight(torch.randn(48, 16, 3, 3).cuda())     # 48 output channels: not a multiple of 32
     with pytest.raises(hip.SdfError):
         hip.dense_conv3x3(x, w)
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_pack_planes_up2_is_bilinear_interpolation(channels_last):
+    """sdf_pack_planes_up2 = F.interpolate(scale_factor=2, mode="bilinear", align_corners=False) written as planes, for any input
+    strides, into a record range of a wider tensor (reference models/submodules.py:117-157)."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(2, 32, 9, 13, generator=g).cuda()
+    b = torch.randn(2, 2, 9, 13, generator=g).cuda()
+    if channels_last:
+        a = a.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    planes = torch.zeros((2, 3, 18, 26, 32), dtype=torch.float16, device="cuda")
+    hip.pack_planes_up2(a, planes, 0)
+    hip.pack_planes_up2(b, planes, 2)
+    got = hip.unpack_planes(planes, 48)
+    ref = F.interpolate(torch.cat([a, b], 1), scale_factor=2, mode="bilinear", align_corners=False)
+    # the planes keep 22 bits of each value; the interpolation itself rounds like torch's up to the order of its four products
+    assert torch.all((got[:, :34] - ref).abs() <= ref.abs() * 2.0 ** -21 + 1e-6)
+    assert torch.count_nonzero(got[:, 34:]) == 0
+
+
+@pytest.mark.parametrize("Cin,Cout", [(194, 96), (386, 96), (768, 192)])
+def test_wide_convolution_as_a_chain_of_slices(Cin, Cout):
+    """The decoders' convolutions (194, 386, 768 input channels) as chains of 96-channel slices plus one 16-channel record."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(Cin)
+    x = torch.randn(2, Cin, 12, 20, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)).cuda()
+    bias = torch.randn(Cout, generator=g).cuda()
+    xp = hip.pack_planes(x)
+    slices = hip.dense_conv_slices(xp.shape[1])
+    assert slices is not None and sum(n for _, n in slices) == xp.shape[1]
+    wpad = F.pad(w, (0, 0, 0, 0, 0, xp.shape[1] * 16 - Cin))
+    wsl = [((r0, n), hip.pack_dense_conv_weight(wpad[:, 16 * r0:16 * (r0 + n)])) for r0, n in slices]
+    y = hip.dense_conv3x3_wide(xp, wsl, bias, True, True).permute(0, 3, 1, 2)
+    ref = torch.relu(F.conv2d(x.double().cpu(), w.double().cpu(), bias.double().cpu(), 1, 1))
+    err = (y.double().cpu() - ref).abs().max().item()
+    assert err <= 4e-6 * ref.abs().max().item(), (err, ref.abs().max().item())
+    assert hip.dense_conv_slices(8) is None                            # 6 + 2: no chain of sixes and one single
