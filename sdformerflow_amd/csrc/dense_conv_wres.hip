@@ -412,18 +412,22 @@ __global__ __launch_bounds__(256) void unpack_planes_kernel(const u32x4* __restr
 // Bilinear x2 upsampling (align_corners false: F.interpolate(scale_factor=2, mode="bilinear"), reference models/submodules.py:117-157
 // `UpsampleConvLayer`) of an (imgs, C, h, w) fp32 tensor with arbitrary strides, written as records rec0 .. of planes
 // [imgs][rec_total][2h][2w]: output pixel 2k takes 0.25 / 0.75 of inputs k-1 / k, pixel 2k+1 takes 0.75 / 0.25 of k / k+1,
-// indices clamped to the image.  One thread per (output pixel, 4-channel piece).
+// indices clamped to the image.
+template <bool CL>
 __global__ __launch_bounds__(256) void pack_planes_up2_kernel(const float* __restrict__ x, u32x4* __restrict__ planes, int imgs, int C,
                                                               int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int rec0,
                                                               int rec_total) {
+  // CL (channel stride 1, C % 4 == 0): one thread per (pixel, piece), pieces fastest - four 16-byte loads, one 16-byte store,
+  // both contiguous across the wave.  Otherwise one thread per (pixel, record), pixels fastest: every scalar load is contiguous
+  // across the wave and a thread writes its record's 64 bytes whole.
   const int H = 2 * h, W = 2 * w, nch = (C + 15) / 16;
   const int64_t hw = (int64_t)H * W;
-  const int64_t total = (int64_t)imgs * nch * 4 * hw;
+  const int64_t total = (int64_t)imgs * nch * hw * (CL ? 4 : 1);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t pix = i % hw;
-    const int64_t r = i / hw;
-    const int j = (int)(r & 3);
-    const int64_t ic = r >> 2;
+    int64_t pix, ic;
+    int j0 = 0;
+    if (CL) { j0 = (int)(i & 3); pix = (i >> 2) % hw; ic = (i >> 2) / hw; }
+    else { pix = i % hw; ic = i / hw; }
     const int img = (int)(ic / nch), rec = (int)(ic - (int64_t)img * nch);
     const int oy = (int)(pix / W), ox = (int)(pix - (int64_t)oy * W);
     const int ky = oy >> 1, kx = ox >> 1;
@@ -431,20 +435,39 @@ __global__ __launch_bounds__(256) void pack_planes_up2_kernel(const float* __res
     const int x0 = (ox & 1) ? kx : (kx > 0 ? kx - 1 : 0), x1 = (ox & 1) ? (kx + 1 < w ? kx + 1 : w - 1) : kx;
     const float wy1 = (oy & 1) ? 0.25f : (ky > 0 ? 0.75f : 0.f), wx1 = (ox & 1) ? 0.25f : (kx > 0 ? 0.75f : 0.f);
     const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = rec * 16 + 4 * j + e;
-      float o = 0.f;
+    const int64_t o00 = y0 * sh + x0 * sw, o01 = y0 * sh + x1 * sw, o10 = y1 * sh + x0 * sw, o11 = y1 * sh + x1 * sw;
+    u32x4* dst = planes + (((int64_t)img * rec_total + rec0 + rec) * hw + pix) * 4;
+    const float* bimg = x + img * sn;
+    if (CL) {
+      const int c = rec * 16 + 4 * j0;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c < C) {
-        const float* b = x + img * sn + c * sc;
-        const float top = wx0 * b[y0 * sh + x0 * sw] + wx1 * b[y0 * sh + x1 * sw];
-        const float bot = wx0 * b[y1 * sh + x0 * sw] + wx1 * b[y1 * sh + x1 * sw];
-        o = wy0 * top + wy1 * bot;
+        const float* b = bimg + c;
+        const float4 a00 = *reinterpret_cast<const float4*>(b + o00), a01 = *reinterpret_cast<const float4*>(b + o01);
+        const float4 a10 = *reinterpret_cast<const float4*>(b + o10), a11 = *reinterpret_cast<const float4*>(b + o11);
+        o.x = wy0 * (wx0 * a00.x + wx1 * a01.x) + wy1 * (wx0 * a10.x + wx1 * a11.x);
+        o.y = wy0 * (wx0 * a00.y + wx1 * a01.y) + wy1 * (wx0 * a10.y + wx1 * a11.y);
+        o.z = wy0 * (wx0 * a00.z + wx1 * a01.z) + wy1 * (wx0 * a10.z + wx1 * a11.z);
+        o.w = wy0 * (wx0 * a00.w + wx1 * a01.w) + wy1 * (wx0 * a10.w + wx1 * a11.w);
       }
-      v[e] = o;
+      dst[j0] = piece_from(o);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = rec * 16 + 4 * j + e;
+          float o = 0.f;
+          if (c < C) {
+            const float* b = bimg + c * sc;
+            o = wy0 * (wx0 * b[o00] + wx1 * b[o01]) + wy1 * (wx0 * b[o10] + wx1 * b[o11]);
+          }
+          v[e] = o;
+        }
+        dst[j] = piece_from(make_float4(v[0], v[1], v[2], v[3]));
+      }
     }
-    planes[(((int64_t)img * rec_total + rec0 + rec) * hw + pix) * 4 + j] = piece_from(make_float4(v[0], v[1], v[2], v[3]));
   }
 }
 
@@ -505,9 +528,14 @@ extern "C" int sdf_pack_planes_up2(const float* x, void* planes, int imgs, int C
   const int nch = (C + 15) / 16;
   if (imgs <= 0 || C <= 0 || h <= 0 || w <= 0 || rec0 < 0 || rec0 + nch > rec_total) return SDF_E_SHAPE;
   if (!sdf_aligned(planes, 16)) return SDF_E_ALIGN;
-  const int64_t total = (int64_t)imgs * nch * 4 * (2 * h) * (2 * w);
-  hipLaunchKernelGGL(sdfmm::pack_planes_up2_kernel, dim3(planes_grid(total)), dim3(256), 0, sdf_stream(stream), x,
-                     reinterpret_cast<sdfmm::u32x4*>(planes), imgs, C, h, w, sn, sc, sh, sw, rec0, rec_total);
+  const bool cl = sc == 1 && C % 4 == 0 && sn % 4 == 0 && sh % 4 == 0 && sw % 4 == 0 && sdf_aligned(x, 16);
+  const int64_t total = (int64_t)imgs * nch * (2 * h) * (2 * w) * (cl ? 4 : 1);
+  if (cl)
+    hipLaunchKernelGGL(sdfmm::pack_planes_up2_kernel<true>, dim3(planes_grid(total)), dim3(256), 0, sdf_stream(stream), x,
+                       reinterpret_cast<sdfmm::u32x4*>(planes), imgs, C, h, w, sn, sc, sh, sw, rec0, rec_total);
+  else
+    hipLaunchKernelGGL(sdfmm::pack_planes_up2_kernel<false>, dim3(planes_grid(total)), dim3(256), 0, sdf_stream(stream), x,
+                       reinterpret_cast<sdfmm::u32x4*>(planes), imgs, C, h, w, sn, sc, sh, sw, rec0, rec_total);
   SDF_LAUNCH_CHECK();
   return 0;
 }
