@@ -13,15 +13,17 @@
 // touch memory on their own.
 //
 // A workgroup keeps the weights of one 32-column block of the output - both planes, the whole K = 9 * Cin - in LDS
-// (2 x 32 x 864 fp16 = 110 KB), as spike_conv_wres.hip does.  The activations are handled per WAVE: each of the 8 wavefronts
-// owns a tile of 4 x 8 output pixels (its 32 MFMA rows) and a private 6 x 10 pixel halo image of it in LDS; the nine taps are
-// nine constant offsets into that image.  An image of all 96 channels in two planes would not fit beside the weights, so it is
-// cut by CHANNEL: one step = 16 input channels (5 KB image, 9 taps x 3 MFMAs), the accumulators stay in registers across the
-// steps of a tile and the epilogue runs after the last one.  Nothing is shared between waves but the weights, so the steady
-// state has no barrier, no counter and no polling: a wave requests the image of step s + 2 from memory, multiplies step s, and
-// writes the image of step s + 1 behind its own last fragment reads (a wave's LDS operations execute in order); the two waves
-// a SIMD hosts fill each other's gaps on the matrix pipe.  (The first version shared a 10 x 18 image between four waves: two
-// LDS hand-overs per step cost as much as the step's 27 MFMAs - profiles/r2l_stamps_dense.txt.)
+// (2 x 32 x 864 fp16 = 110 KB), as spike_conv_wres.hip does.  The activations are handled per WAVE: each of the 12 wavefronts
+// (three per SIMD) owns a tile of 4 x 8 output pixels (its 32 MFMA columns) and a private 6 x 10 pixel halo image of it in
+// LDS; the nine taps are nine constant offsets into that image.  An image of all 96 channels in two planes would not fit beside
+// the weights, so it is cut by CHANNEL: one step = 16 input channels (3.75 KB image, 9 taps x 3 MFMAs), the accumulators stay in
+// registers across the steps of a tile and the epilogue runs after the last one.  Nothing is shared between waves but the
+// weights, so the steady state has no barrier, no counter and no polling: a wave requests the image of step s + 2 from memory,
+// multiplies step s, and writes the image of step s + 1 behind its own last fragment reads (a wave's LDS operations execute in
+// order); the waves a SIMD hosts fill each other's gaps on the matrix pipe.  (The first version shared a 10 x 18 image between
+// four waves: two LDS hand-overs per step cost as much as the step's 27 MFMAs - profiles/r2l_stamps_dense.txt.  Eight waves
+// with padded 80-byte pixel records ran the pipe 56 % busy at 1.71 GHz, twelve with the swizzled 64-byte records below 63 %
+// at 1.59 GHz: busy x clock is what the chip's power limit fixes, r2m / r2p_pmc_dense.txt.)
 // The N / 32 workgroups that serve the column blocks of one tile range sit on one XCD and walk the range side by side: its
 // activations leave HBM once (column blocks as an outer loop over the tensor read 2.7 x the algorithmic bytes, r2l_pmc_dense.txt).
 // The weights are the MFMA's ROW operand and the pixels its column operand, so a lane's accumulator quads are four consecutive
@@ -30,9 +32,10 @@
 // Activation layout ("planes", sdf_pack_planes): [img][Cin/16][H][W] records of 64 bytes = 4 x { 4 x fp16 hi, 4 x fp16 lo } for
 // 16 channels: a 16-byte piece is four channels complete, which is what one lane holds after the epilogue's quad transpose
 // (one 16-byte store per four channels) and what the halo loader splits into the hi and lo halves of the LDS pixel record.
-// LDS is conflict-free by construction: pixel stride 80 bytes (16-byte slots 5 apart: 8 pixels of a row take slots
-// {0,5,10,15,4,9,14,3}), row pitch 128 (mod 256) bytes, so the 16 lanes of every ds_read_b128 group (two half rows of two
-// tile rows) cover the 16 slots of a bank row once; weight rows 2K + 16 bytes (4 x odd dwords).
+// LDS is conflict-free by construction without padding: a pixel record is 64 bytes = four 16-byte slots (hi 0-7, hi 8-15,
+// lo 0-7, lo 8-15) stored at slot ^ (halo row & 3).  The 16 lanes of a ds_read_b128 group are four 4-pixel row segments on four
+// consecutive halo rows; four consecutive pixels cover the four 64-byte quarters of a 256-byte bank row, and the four rows put
+// the slot they all ask for at four different places of its quarter.  Weight rows are 2K + 16 bytes (4 x odd dwords).
 #include "spike_mm.h"
 
 #ifdef SDF_STAMP
@@ -52,9 +55,11 @@ constexpr int TH = 4, TW = 8;                   // output pixels of a wave's til
 constexpr int HH = TH + 2, HWID = TW + 2;       // its halo image
 constexpr int NB = 32;                          // output columns of a workgroup pass
 constexpr int REC = 64;                         // bytes of a pixel record in memory (16 channels, hi + lo)
-constexpr int PS = 80;                          // pixel stride in the halo image: 32 B hi, 32 B lo, 16 B pad
-constexpr int RPB = 896;                        // halo row pitch: 10 * 80 = 800 -> 128 (mod 256), see the bank note above
-constexpr int HALO = HH * RPB;                  // 5376 bytes per wave
+constexpr int NW = 12;                          // wavefronts of a workgroup: three per SIMD
+constexpr int PS = 64;                          // pixel stride in the halo image: 4 slots of 16 B = hi 0-7, hi 8-15, lo 0-7, lo 8-15,
+                                                // stored at slot ^ (halo row & 3) - see the bank note above
+constexpr int RPB = HWID * PS;                  // halo row pitch (640 bytes)
+constexpr int HALO = HH * RPB;                  // 3840 bytes per wave
 constexpr int PIECES = HH * HWID * 4;           // 16-byte pieces of a halo image (240)
 constexpr int CPL = (PIECES + 63) / 64;         // pieces per lane
 constexpr uint32_t INV = 0x80000000u;
@@ -95,16 +100,16 @@ __device__ __forceinline__ float4 piece_to(u32x4 v) {
 }
 
 template <int CCH>
-__global__ __launch_bounds__(512) void dense_conv_wres_kernel(DenseParams P) {
+__global__ __launch_bounds__(64 * NW) void dense_conv_wres_kernel(DenseParams P) {
   constexpr int K = 9 * 16 * CCH;
   constexpr int WP = 2 * K + 16;                                      // weight row pitch (bytes): 4 x odd dwords
   constexpr int W_BYTES = 2 * NB * WP;
   constexpr int PAR = 2 * NB * 4;
   static_assert((WP / 4) % 8 == 4, "weight row pitch must be 4 x odd dwords");
-  static_assert(W_BYTES + 8 * HALO + PAR <= 160 * 1024, "LDS budget");
-  __shared__ __attribute__((aligned(16))) uint8_t smem[W_BYTES + 8 * HALO + PAR];
+  static_assert(W_BYTES + NW * HALO + PAR <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) uint8_t smem[W_BYTES + NW * HALO + PAR];
   uint8_t* W_s = smem;
-  float* par_s = reinterpret_cast<float*>(smem + W_BYTES + 8 * HALO);
+  float* par_s = reinterpret_cast<float*>(smem + W_BYTES + NW * HALO);
 
   const SdfDenseConvDesc& d = P.d;
   const int H = d.H, W = d.W, N = d.N;
@@ -139,13 +144,14 @@ __global__ __launch_bounds__(512) void dense_conv_wres_kernel(DenseParams P) {
     constexpr int KC8 = K / 8;                                         // 16-byte pieces per weight row
     constexpr int WCH = 2 * NB * KC8;
     const __amdgpu_buffer_rsrc_t W_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(d.w), 0, 2 * N * K * 2, 0x00020000);
-    constexpr int WB = 7, NBATCH = (WCH + 512 * WB - 1) / (512 * WB);   // batches of 7 pieces per lane in flight
+    constexpr int NT = 64 * NW;
+    constexpr int WB = 7, NBATCH = (WCH + NT * WB - 1) / (NT * WB);     // batches of 7 pieces per lane in flight
 #pragma unroll 1
     for (int b = 0; b < NBATCH; ++b) {
       u32x4 wv[WB];
 #pragma unroll
       for (int i = 0; i < WB; ++i) {
-        const int c = tid + 512 * (b * WB + i);
+        const int c = tid + NT * (b * WB + i);
         const int cc = c < WCH ? c : 0;
         const int row = cc / KC8, kc = cc - row * KC8;                 // row = p * 32 + n
         const int p = row / NB, n = row - p * NB;
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(512) void dense_conv_wres_kernel(DenseParams P) {
       }
 #pragma unroll
       for (int i = 0; i < WB; ++i) {
-        const int c = tid + 512 * (b * WB + i);
+        const int c = tid + NT * (b * WB + i);
         const int cc = c < WCH ? c : 0;
         const int row = cc / KC8, kc = cc - row * KC8;
         if (c < WCH) *reinterpret_cast<u32x4*>(W_s + row * WP + kc * 16) = wv[i];
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(512) void dense_conv_wres_kernel(DenseParams P) {
     const int cc = c < PIECES ? c : c - 64;
     const int hy = cc / (HWID * 4), r = cc - hy * (HWID * 4);
     const int px = r >> 2, j = r & 3;
-    h_lds[i] = c < PIECES ? (uint32_t)(hy * RPB + px * PS + 8 * j) : 0xFFFFFFFFu;
+    h_lds[i] = c < PIECES ? (uint32_t)(hy * RPB + px * PS + (((j >> 1) ^ (hy & 3)) << 4) + 8 * (j & 1)) : 0xFFFFFFFFu;
     h_rel[i] = ((hy - 1) * W + (px - 1)) * REC + 16 * j;
     h_yx[i] = ((hy - 1) << 16) | ((px - 1) & 0xFFFF);
   }
@@ -207,12 +213,12 @@ __global__ __launch_bounds__(512) void dense_conv_wres_kernel(DenseParams P) {
     for (int i = 0; i < CPL; ++i) {
       if (h_lds[i] != 0xFFFFFFFFu) {
         *reinterpret_cast<uint2*>(H_s + h_lds[i]) = make_uint2(hr[i].x, hr[i].y);          // 4 x hi
-        *reinterpret_cast<uint2*>(H_s + h_lds[i] + 32) = make_uint2(hr[i].z, hr[i].w);     // 4 x lo
+        *reinterpret_cast<uint2*>(H_s + (h_lds[i] ^ 32u)) = make_uint2(hr[i].z, hr[i].w);  // 4 x lo: slot ^ 2
       }
     }
   };
 
-  // a position in the walk over (image, tile row, tile column); the tiles of a wave are eight apart.  (Handing the tiles out
+  // a position in the walk over (image, tile row, tile column); the tiles of a wave are NW apart.  (Handing the tiles out
   // through an LDS counter instead measured no faster - the waves of a workgroup already finish together.)
   struct Pos { int img, ty, tx; };
   auto pos_of = [&](int tile) __attribute__((always_inline)) {
@@ -222,8 +228,8 @@ __global__ __launch_bounds__(512) void dense_conv_wres_kernel(DenseParams P) {
     p.ty = tl / tiles_x; p.tx = tl - p.ty * tiles_x;
     return p;
   };
-  auto advance8 = [&](Pos& p) __attribute__((always_inline)) {
-    p.tx += 8;
+  auto advance = [&](Pos& p) __attribute__((always_inline)) {
+    p.tx += NW;
     while (p.tx >= tiles_x) { p.tx -= tiles_x; ++p.ty; }
     while (p.ty >= tiles_y) { p.ty -= tiles_y; ++p.img; }
   };
@@ -234,7 +240,10 @@ __global__ __launch_bounds__(512) void dense_conv_wres_kernel(DenseParams P) {
   int ln = lane;
   asm volatile("" : "+v"(ln));
   const int l31 = ln & 31, lh = ln >> 5;
-  const uint32_t a_lane = (uint32_t)((l31 >> 3) * RPB + (l31 & 7) * PS + 16 * lh);
+  // hi fragment of tap row ky: slot lh ^ ((tile row + ky) & 3) of the lane's pixel record; the lo fragment is that address ^ 32
+  uint32_t a_row[3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) a_row[ky] = (uint32_t)(((l31 >> 3) + ky) * RPB + (l31 & 7) * PS + ((lh ^ (((l31 >> 3) + ky) & 3)) << 4));
   const uint32_t w_lane = (uint32_t)(l31 * WP + 16 * lh);
   const __amdgpu_buffer_rsrc_t out_rs = make_rsrc(d.out), res_rs = make_rsrc(d.resid);
 
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(512) void dense_conv_wres_kernel(DenseParams P) {
   const unsigned long long kstart = __builtin_readcyclecounter(), rstart = __builtin_amdgcn_s_memrealtime();
 #endif
   // ---------------- this wave's tiles of the range: wave, wave + 8, ...; steps = tiles x channel records ----------------
-  const int my_items = n_my > wave ? (n_my - wave + 7) / 8 : 0;
+  const int my_items = n_my > wave ? (n_my - wave + NW - 1) / NW : 0;
   const int S = my_items * CCH;
   Pos pc = pos_of(t_begin + wave);                                     // position of the step being multiplied
   Pos pp = pc;                                                         // position / record / count of the next step to REQUEST
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(512) void dense_conv_wres_kernel(DenseParams P) {
     if (sp < S) {
       halo_load(hr, pp.img, chp, pp.ty * TH, pp.tx * TW);
       ++sp;
-      if (++chp == CCH) { chp = 0; advance8(pp); }
+      if (++chp == CCH) { chp = 0; advance(pp); }
     }
   };
   if (S > 0) {
@@ -290,13 +299,13 @@ __global__ __launch_bounds__(512) void dense_conv_wres_kernel(DenseParams P) {
     STAMP(s1);
 
     // ------------------------------ MFMA phase: 9 taps x 3 products ------------------------------
-    constexpr int PF = 3;                                             // taps of fragments in flight
+    constexpr int PF = 2;                                             // taps of fragments in flight
     bf16x8 fa[PF + 1][2], fb[PF + 1][2];
     const uint32_t w_step = w_lane + (uint32_t)ch * (9 * 32);
     auto frag = [&](int tap, int set) __attribute__((always_inline)) {
       const int ky = tap / 3, kx = tap - 3 * ky;
-      fa[set][0] = *reinterpret_cast<const bf16x8*>(H_s + a_lane + (ky * RPB + kx * PS));
-      fa[set][1] = *reinterpret_cast<const bf16x8*>(H_s + a_lane + (ky * RPB + kx * PS + 32));
+      fa[set][0] = *reinterpret_cast<const bf16x8*>(H_s + a_row[ky] + kx * PS);
+      fa[set][1] = *reinterpret_cast<const bf16x8*>(H_s + (a_row[ky] ^ 32u) + kx * PS);
       fb[set][0] = *reinterpret_cast<const bf16x8*>(W_s + w_step + tap * 32);
       fb[set][1] = *reinterpret_cast<const bf16x8*>(W_s + w_step + (NB * WP + tap * 32));
     };
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(512) void dense_conv_wres_kernel(DenseParams P) {
         __builtin_amdgcn_raw_buffer_store_b128(st, out_rs, pixoff != INV ? off : INV, 0, 0);
       }
     }
-    if (++ch == CCH) { ch = 0; advance8(pc); }
+    if (++ch == CCH) { ch = 0; advance(pc); }
     STAMP(s4);
     STAMP_ADD(a_issue, s0, s1); STAMP_ADD(a_mfma, s1, s2); STAMP_ADD(a_store, s2, s3); STAMP_ADD(a_epi, s3, s4);
 #ifdef SDF_STAMP
@@ -489,12 +498,12 @@ extern "C" int sdf_dense_conv3x3_fwd(const SdfDenseConvDesc* d, void* stream) {
   P.wtiles = (int)((int64_t)d->imgs * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW));
   const int ncb = d->N / NB;
   if (ncb > 32) return SDF_E_SHAPE;
-  const int want = (P.wtiles + 7) / 8;                                 // a workgroup wants at least one tile per wave
+  const int want = (P.wtiles + NW - 1) / NW;                           // a workgroup wants at least one tile per wave
   P.ranges = want < 256 / ncb ? want : 256 / ncb;
   const int G = P.ranges == 256 / ncb ? 256 : P.ranges * ncb;
   hipStream_t s = sdf_stream(stream);
-  if (d->cin_records == 1) hipLaunchKernelGGL((dense_conv_wres_kernel<1>), dim3(G), dim3(512), 0, s, P);
-  else hipLaunchKernelGGL((dense_conv_wres_kernel<6>), dim3(G), dim3(512), 0, s, P);
+  if (d->cin_records == 1) hipLaunchKernelGGL((dense_conv_wres_kernel<1>), dim3(G), dim3(64 * NW), 0, s, P);
+  else hipLaunchKernelGGL((dense_conv_wres_kernel<6>), dim3(G), dim3(64 * NW), 0, s, P);
   SDF_LAUNCH_CHECK();
   return 0;
 }
