@@ -489,6 +489,24 @@ int sdf_unpack_planes(const void* planes, float* x, int imgs, int C, int H, int 
 int sdf_pack_planes_up2(const float* x, void* planes, int imgs, int C, int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
                         int rec0, int rec_total, void* stream);
 
+/* ---- Linear layer on real-valued activations (ANN swin blocks, BASELINE config 3) --------------------------------
+ * Replaces F.linear (+ F.gelu, + the residual add) of reference models/STSwinNet/swin_transformer3D_v2.py:176-202
+ * (`WindowAttention3D`: qkv, proj), :15-34 (`Mlp`: fc1 -> GELU -> fc2) and :272-313 (the block's two shortcut adds):
+ *   out[m, n] = act(sum_k a[m, k] * w[n, k] + bias[n]) (+ resid[m, n]),  act = erf-form GELU when `gelu`, else identity.
+ * a, resid, out: fp32 row-major (M, K) / (M, N); out may alias resid.  w: fp16 planes [2][N][K], w = plane0 + plane1
+ * (hi = fp16(w), lo = fp16(w - hi)).  N % 96 == 0, K % 32 == 0, every tensor below 2^31 bytes. */
+typedef struct SdfDenseLinearDesc {
+  const float* a;
+  const uint16_t* w;
+  const float* bias;        /* (N) or NULL */
+  const float* resid;       /* (M, N) or NULL */
+  float* out;
+  int32_t M, N, K;
+  int32_t gelu;
+} SdfDenseLinearDesc;
+
+int sdf_dense_linear_fwd(const SdfDenseLinearDesc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,7 +1,8 @@
 """ANN video-swin-v2 pieces on the hot path (mirror of reference models/STSwinNet/swin_transformer3D_v2.py):
 `window_partition` :37-49, `window_reverse` :52-65, `get_window_size` :68-81, `compute_mask` :409-421 and the cosine
 `WindowAttention3D` :87-205, whose score / bias / mask / softmax / .V core runs in one fused MFMA kernel
-(csrc/win_attn.hip) and whose two projections are plain library GEMMs (rocBLAS through torch)."""
+(csrc/win_attn.hip) and whose projections - like the Mlp's - run on this framework's Linear kernel (csrc/dense_linear.hip:
+two fp16 planes per operand, bias / GELU / shortcut add in the epilogue; `SDF_DENSE_LINEAR=0` keeps the library GEMMs)."""
 import math
 import os
 from functools import lru_cache
@@ -13,6 +14,25 @@ import torch.nn.functional as F
 
 from .. import hip
 from ..STSwinNet_SNN.Spiking_swin_transformer3D import get_window_size  # noqa: F401  (same function, one definition)
+
+
+def linear_rows(lin, a, gelu=False, resid=None):
+    """act(lin(a)) (+ resid) on rows a (M, K) fp32: one launch of sdf_dense_linear_fwd when the layer has a kernel form (eval, GPU,
+    N % 96 == 0, K % 32 == 0), the library's F.linear / F.gelu / add otherwise.  The fp16 weight planes are made once per
+    parameter version."""
+    M, K = a.shape
+    N = lin.out_features
+    if (not lin.training and a.is_cuda and a.dtype == torch.float32 and os.environ.get("SDF_DENSE_LINEAR", "1") != "0"
+            and hip.dense_linear_applicable(M, N, K)):
+        stamp = (lin.weight.data_ptr(), lin.weight._version)
+        if getattr(lin, "_pk_stamp", None) != stamp:
+            lin._pk, lin._pk_stamp = hip.pack_dense_linear_weight(lin.weight), stamp
+        bias = lin.bias.detach() if lin.bias is not None else None
+        return hip.dense_linear(a.contiguous(), lin._pk, bias, gelu, resid)
+    y = F.linear(a, lin.weight, lin.bias)
+    if gelu:
+        y = F.gelu(y)
+    return y if resid is None else resid + y
 
 
 def window_partition(x, window_size):
@@ -99,15 +119,16 @@ class WindowAttention3D(nn.Module):
             o = hip.win_attn_ann(qkv, scale, self.position_bias(), None if mask is None else mask.contiguous(), self.num_heads)
             return self.proj(o), None
 
-    def forward_rows(self, y2, row_map, B_, mask):
-        """Attention on un-partitioned rows y2 (rows, C): windows are formed by `row_map` inside the kernel -> (rows, C)."""
+    def forward_rows(self, y2, row_map, B_, mask, resid=None):
+        """Attention on un-partitioned rows y2 (rows, C): windows are formed by `row_map` inside the kernel -> (rows, C),
+        plus `resid` (the block's shortcut, added in the projection's epilogue)."""
         with torch.no_grad():
-            qkv = self.qkv(y2).contiguous()
+            qkv = linear_rows(self.qkv, y2)
             pad = self.qkv.bias.detach().float().contiguous() if self.qkv.bias is not None else torch.zeros(3 * self.dim, device=y2.device)
             scale = torch.clamp(self.logit_scale, max=math.log(1.0 / 0.01)).exp().reshape(-1).contiguous()
             N = self.window_size[0] * self.window_size[1] * self.window_size[2]
             o = hip.win_attn_ann_windowed(qkv, row_map, B_, N, pad, scale, self.position_bias(), mask, self.num_heads)
-            return self.proj(o)
+            return linear_rows(self.proj, o, False, resid)
 
 
 class Mlp(nn.Module):
@@ -118,8 +139,12 @@ class Mlp(nn.Module):
         self.fc1 = nn.Linear(in_features, hidden_features or in_features)
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
 
-    def forward(self, x):
-        return self.fc2(F.gelu(self.fc1(x)))
+    def forward(self, x, resid=None):
+        """fc2(gelu(fc1(x))) (+ resid): GELU rides in fc1's epilogue, the shortcut in fc2's."""
+        shp = x.shape
+        h = linear_rows(self.fc1, x.reshape(-1, shp[-1]), True)
+        y = linear_rows(self.fc2, h, False, None if resid is None else resid.reshape(-1, resid.shape[-1]))
+        return y.view(*shp[:-1], y.shape[-1])
 
 
 class SwinTransformerBlock3D(nn.Module):
@@ -164,8 +189,9 @@ class SwinTransformerBlock3D(nn.Module):
             if key not in SwinTransformerBlock3D._maps:
                 SwinTransformerBlock3D._maps[key] = hip.window_slice_map(B, D, H, W, ws, ss, x.device)
             row_map, B_ = SwinTransformerBlock3D._maps[key]
-            x = x + self.attn.forward_rows(y.reshape(-1, C), row_map, B_, None if mask is None else mask.contiguous()).view(B, D, H, W, C)
-        return x + self.mlp(self.norm2(x))
+            x = self.attn.forward_rows(y.reshape(-1, C), row_map, B_, None if mask is None else mask.contiguous(),
+                                       x.reshape(-1, C)).view(B, D, H, W, C)
+        return self.mlp(self.norm2(x), x)
 
 
 class PatchMerging(nn.Module):
@@ -181,7 +207,8 @@ class PatchMerging(nn.Module):
         if H % 2 or W % 2:
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
         x = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
-        return self.reduction(self.norm(x))
+        y = self.norm(x)
+        return linear_rows(self.reduction, y.reshape(-1, y.shape[-1])).view(*y.shape[:-1], -1)
 
 
 class Swin_BasicLayer(nn.Module):

@@ -27,7 +27,7 @@ EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_s
            "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
            "sdf_rows_gather_fwd", "sdf_rows_scatter_fwd",
            "sdf_split_weight_i8x3", "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd",
-           "sdf_dense_conv3x3_fwd", "sdf_pack_planes", "sdf_unpack_planes", "sdf_pack_planes_up2")
+           "sdf_dense_conv3x3_fwd", "sdf_pack_planes", "sdf_unpack_planes", "sdf_pack_planes_up2", "sdf_dense_linear_fwd")
 
 
 class SdfError(RuntimeError):
@@ -87,6 +87,11 @@ class DenseConvDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("alpha", C.c_void_p), ("beta", C.c_void_p), ("resid", C.c_void_p),
                 ("out", C.c_void_p), ("imgs", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("cin_records", C.c_int32),
                 ("N", C.c_int32), ("relu", C.c_int32), ("out_f32", C.c_int32), ("x_records", C.c_int32)]
+
+
+class DenseLinearDesc(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("resid", C.c_void_p), ("out", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("gelu", C.c_int32)]
 
 
 _lib = None
@@ -742,6 +747,36 @@ def dense_conv3x3(xp, wplanes, alpha=None, beta=None, resid=None, relu=False, ou
     d.resid, d.out = _ptr(resid, torch.float16), out.data_ptr()
     d.imgs, d.H, d.W, d.cin_records, d.N, d.relu, d.out_f32 = imgs, H, W, rec, N, int(relu), int(out_f32)
     _check(lib().sdf_dense_conv3x3_fwd(C.byref(d), _stream()), "sdf_dense_conv3x3_fwd")
+    return out
+
+
+# ---- Linear layer on real-valued activations (ANN swin blocks; csrc/dense_linear.hip) ----
+def pack_dense_linear_weight(w):
+    """Linear weight (N, K) fp32 -> fp16 planes (2, N, K): hi = fp16(w), lo = fp16(w - hi)."""
+    w = w.detach().float()
+    hi = w.half()
+    return torch.stack([hi, (w - hi.float()).half()]).contiguous()
+
+
+def dense_linear_applicable(M, N, K):
+    return N % 96 == 0 and K % 32 == 0 and M * max(N, K) * 4 < 1 << 31
+
+
+def dense_linear(a, wplanes, bias=None, gelu=False, resid=None, out=None):
+    """out = act(a @ w.T + bias) (+ resid) for a (M, K) fp32, w as fp16 planes (2, N, K) (sdf_dense_linear_fwd); `out` may be
+    `resid` (in-place shortcut add)."""
+    M, K = a.shape
+    N = wplanes.shape[1]
+    if wplanes.shape[2] != K or not a.is_contiguous():
+        raise SdfError("dense_linear needs a contiguous (M, K) activation and (2, N, K) weight planes")
+    if resid is not None and (tuple(resid.shape) != (M, N) or not resid.is_contiguous()):
+        raise SdfError("residual must be a contiguous (M, N) tensor")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    d = DenseLinearDesc()
+    d.a, d.w, d.bias, d.resid, d.out = _ptr(a, torch.float32), _ptr(wplanes, torch.float16), _ptr(bias, torch.float32), _ptr(resid, torch.float32), _ptr(out, torch.float32)
+    d.M, d.N, d.K, d.gelu = M, N, K, int(gelu)
+    _check(lib().sdf_dense_linear_fwd(C.byref(d), _stream()), "sdf_dense_linear_fwd")
     return out
 
 
