@@ -507,6 +507,10 @@ typedef struct SdfDenseLinearDesc {
 
 int sdf_dense_linear_fwd(const SdfDenseLinearDesc* d, void* stream);
 
+/* nn.LayerNorm over the last dim of x (rows, C) fp32, elementwise affine (reference models/STSwinNet/swin_transformer3D_v2.py:
+ * `norm1` / `norm2` of the blocks :231-233, `PatchMerging.norm` :356, the per-stage output norms :622-624).  C % 4 == 0, C <= 2048. */
+int sdf_layer_norm_fwd(const float* x, const float* gamma, const float* beta, float* out, int64_t rows, int C, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

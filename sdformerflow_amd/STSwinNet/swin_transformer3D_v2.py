@@ -35,6 +35,15 @@ def linear_rows(lin, a, gelu=False, resid=None):
     return y if resid is None else resid + y
 
 
+def layer_norm(ln, x):
+    """nn.LayerNorm `ln` on x (..., C): the HIP kernel in eval on the GPU (one read, one write), torch otherwise."""
+    C = x.shape[-1]
+    if (not ln.training and x.is_cuda and x.dtype == torch.float32 and ln.elementwise_affine and ln.bias is not None and C % 4 == 0
+            and C <= 2048 and os.environ.get("SDF_LAYER_NORM", "1") != "0"):
+        return hip.layer_norm(x.contiguous(), ln.weight.detach(), ln.bias.detach(), ln.eps)
+    return ln(x)
+
+
 def window_partition(x, window_size):
     """(B,D,H,W,C) -> (B*nW, Wd*Wh*Ww, C), windows ordered (b, d-block, h-block, w-block)."""
     B, D, H, W, C = x.shape
@@ -171,7 +180,7 @@ class SwinTransformerBlock3D(nn.Module):
         qkv bias.  `SDF_ATTN_MATERIALISE=1` keeps the reference's sequence as the A/B path."""
         B, D, H, W, C = x.shape
         ws, ss = get_window_size((D, H, W), self.window_size, self.shift_size)
-        y = self.norm1(x)
+        y = layer_norm(self.norm1, x)
         Dp, Hp, Wp = D + (-D) % ws[0], H + (-H) % ws[1], W + (-W) % ws[2]
         shifted = any(s > 0 for s in ss)
         mask = (mask_matrix if mask_matrix is not None else compute_mask(Dp, Hp, Wp, ws, ss, x.device)) if shifted else None
@@ -191,7 +200,7 @@ class SwinTransformerBlock3D(nn.Module):
             row_map, B_ = SwinTransformerBlock3D._maps[key]
             x = self.attn.forward_rows(y.reshape(-1, C), row_map, B_, None if mask is None else mask.contiguous(),
                                        x.reshape(-1, C)).view(B, D, H, W, C)
-        return self.mlp(self.norm2(x), x)
+        return self.mlp(layer_norm(self.norm2, x), x)
 
 
 class PatchMerging(nn.Module):
@@ -207,7 +216,7 @@ class PatchMerging(nn.Module):
         if H % 2 or W % 2:
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
         x = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
-        y = self.norm(x)
+        y = layer_norm(self.norm, x)
         return linear_rows(self.reduction, y.reshape(-1, y.shape[-1])).view(*y.shape[:-1], -1)
 
 
@@ -254,5 +263,5 @@ class SwinTransformer3D_v2(nn.Module):
         for i, layer in enumerate(self.layers):
             o, x = layer(x)
             if i in self.out_indices:
-                outs.append(getattr(self, f"norm{i}")(o).permute(0, 4, 1, 2, 3))
+                outs.append(layer_norm(getattr(self, f"norm{i}"), o).permute(0, 4, 1, 2, 3))
         return outs

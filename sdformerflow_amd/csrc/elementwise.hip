@@ -94,3 +94,81 @@ extern "C" int sdf_rows_scatter_fwd(const float* y, const int32_t* map, float* o
   SDF_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim of (rows, C) fp32 (nn.LayerNorm of the ANN swin blocks, reference
+// models/STSwinNet/swin_transformer3D_v2.py:231-233, 272, 312, 356, 622-624): L lanes per row hold the row in registers (V float4
+// each), mean and centred variance by xor shuffles inside the L lanes, one read and one write of the tensor.
+namespace {
+template <int L, int V>
+__global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ out, int64_t rows, int C,
+                                                         float eps) {
+  const int sub = threadIdx.x % L;
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / L;
+  if (row >= rows) return;                                            // whole L-lane groups leave together (256 % L == 0)
+  const float* xr = x + row * C;
+  float4 v[V];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = (i * L + sub) * 4;
+    v[i] = c < C ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+#pragma unroll
+  for (int m = L / 2; m >= 1; m >>= 1) s += __shfl_xor(s, m, L);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = (i * L + sub) * 4;
+    if (c < C) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+#pragma unroll
+  for (int m = L / 2; m >= 1; m >>= 1) q += __shfl_xor(q, m, L);
+  const float rstd = 1.f / sqrtf(q / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = (i * L + sub) * 4;
+    if (c < C) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x; o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z; o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      *reinterpret_cast<float4*>(out + row * C + c) = o;
+    }
+  }
+}
+
+template <int L>
+int launch_layer_norm(const float* x, const float* g, const float* b, float* out, int64_t rows, int C, float eps, hipStream_t s) {
+  const int V = (C + 4 * L - 1) / (4 * L);
+  const dim3 grid((unsigned)((rows * L + 255) / 256));
+  switch (V) {
+    case 1: hipLaunchKernelGGL((layer_norm_kernel<L, 1>), grid, dim3(256), 0, s, x, g, b, out, rows, C, eps); break;
+    case 2: hipLaunchKernelGGL((layer_norm_kernel<L, 2>), grid, dim3(256), 0, s, x, g, b, out, rows, C, eps); break;
+    case 3: hipLaunchKernelGGL((layer_norm_kernel<L, 3>), grid, dim3(256), 0, s, x, g, b, out, rows, C, eps); break;
+    case 4: hipLaunchKernelGGL((layer_norm_kernel<L, 4>), grid, dim3(256), 0, s, x, g, b, out, rows, C, eps); break;
+    case 5: case 6: hipLaunchKernelGGL((layer_norm_kernel<L, 6>), grid, dim3(256), 0, s, x, g, b, out, rows, C, eps); break;
+    case 7: case 8: hipLaunchKernelGGL((layer_norm_kernel<L, 8>), grid, dim3(256), 0, s, x, g, b, out, rows, C, eps); break;
+    default: return SDF_E_SHAPE;
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" int sdf_layer_norm_fwd(const float* x, const float* gamma, const float* beta, float* out, int64_t rows, int C, float eps,
+                                  void* stream) {
+  if (!x || !gamma || !beta || !out) return SDF_E_NULL;
+  if (rows <= 0 || C <= 0 || C % 4 || C > 2048) return SDF_E_SHAPE;
+  if (!sdf_aligned(x, 16) || !sdf_aligned(out, 16) || !sdf_aligned(gamma, 16) || !sdf_aligned(beta, 16)) return SDF_E_ALIGN;
+  const int rc = C <= 512 ? launch_layer_norm<16>(x, gamma, beta, out, rows, C, eps, sdf_stream(stream))
+                          : launch_layer_norm<64>(x, gamma, beta, out, rows, C, eps, sdf_stream(stream));
+  if (rc) return rc;
+  SDF_LAUNCH_CHECK();
+  return 0;
+}

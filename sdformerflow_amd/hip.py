@@ -27,7 +27,7 @@ EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_s
            "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
            "sdf_rows_gather_fwd", "sdf_rows_scatter_fwd",
            "sdf_split_weight_i8x3", "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd",
-           "sdf_dense_conv3x3_fwd", "sdf_pack_planes", "sdf_unpack_planes", "sdf_pack_planes_up2", "sdf_dense_linear_fwd")
+           "sdf_dense_conv3x3_fwd", "sdf_pack_planes", "sdf_unpack_planes", "sdf_pack_planes_up2", "sdf_dense_linear_fwd", "sdf_layer_norm_fwd")
 
 
 class SdfError(RuntimeError):
@@ -777,6 +777,18 @@ def dense_linear(a, wplanes, bias=None, gelu=False, resid=None, out=None):
     d.a, d.w, d.bias, d.resid, d.out = _ptr(a, torch.float32), _ptr(wplanes, torch.float16), _ptr(bias, torch.float32), _ptr(resid, torch.float32), _ptr(out, torch.float32)
     d.M, d.N, d.K, d.gelu = M, N, K, int(gelu)
     _check(lib().sdf_dense_linear_fwd(C.byref(d), _stream()), "sdf_dense_linear_fwd")
+    return out
+
+
+def layer_norm(x, gamma, beta, eps):
+    """LayerNorm over the last dim of a contiguous fp32 tensor (sdf_layer_norm_fwd)."""
+    Cc = x.shape[-1]
+    if not x.is_contiguous():
+        raise SdfError("layer_norm needs a contiguous tensor")
+    out = torch.empty_like(x)
+    _check(lib().sdf_layer_norm_fwd(C.c_void_p(_ptr(x, torch.float32)), C.c_void_p(_ptr(gamma, torch.float32)), C.c_void_p(_ptr(beta, torch.float32)),
+                                    C.c_void_p(out.data_ptr()), C.c_int64(x.numel() // Cc), C.c_int(Cc), C.c_float(eps), _stream()),
+           "sdf_layer_norm_fwd")
     return out
 
 

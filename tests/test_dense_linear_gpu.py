@@ -53,3 +53,15 @@ def test_in_place_shortcut_and_rejections():
         hip.dense_linear(a, hip.pack_dense_linear_weight(torch.randn(64, 96).cuda()))          # N % 96
     with pytest.raises(hip.SdfError):
         hip.dense_linear(torch.randn(10, 48).cuda(), hip.pack_dense_linear_weight(torch.randn(96, 48).cuda()))   # K % 32
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 96), (333, 192), (100, 384), (64, 768), (17, 1536), (5, 100), (9, 2048)])
+def test_layer_norm_matches_torch(rows, C):
+    """sdf_layer_norm_fwd against nn.LayerNorm in fp64 (reference swin_transformer3D_v2.py: norm1 / norm2 / PatchMerging.norm / norm{i})."""
+    from sdformerflow_amd import hip
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 3 + 1.5).cuda()
+    w, b = (0.5 + torch.rand(C, generator=g)).cuda(), torch.randn(C, generator=g).cuda()
+    y = hip.layer_norm(x, w, b, 1e-5)
+    ref = F.layer_norm(x.double().cpu(), (C,), w.double().cpu(), b.double().cpu(), 1e-5)
+    assert (y.double().cpu() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
