@@ -503,6 +503,12 @@ typedef struct SdfDenseLinearDesc {
   float* out;
   int32_t M, N, K;
   int32_t gelu;
+  /* convolution form (cv_C > 0; all zero = plain Linear): `a` is a channels-last image (imgs, cv_H, cv_W, cv_C) fp32 and row m =
+   * (img, oy, ox) gathers the 3x3 / pad 1 / stride cv_stride neighbourhood, K = 9 * cv_C ordered (ky, kx, c) - the strided
+   * projection of reference models/STSwinNet/PatchEmbed.py:191 (`PatchEmbedLocal.proj`).  cv_OH / cv_OW = (H - 1) / stride + 1;
+   * out_T > 1 writes image t * B + b of the input as image b * out_T + t of the output ((T,B) -> (B,T): the layout the swin
+   * stages consume).  No residual in this form. */
+  int32_t cv_H, cv_W, cv_C, cv_stride, cv_OH, cv_OW, out_T;
 } SdfDenseLinearDesc;
 
 int sdf_dense_linear_fwd(const SdfDenseLinearDesc* d, void* stream);

@@ -76,6 +76,14 @@ class PatchEmbedLocal(nn.Module):
             self._pk, self._pk_stamp = pk, stamp
         return self._pk
 
+    def _packed_proj(self):
+        w = self.proj.weight
+        stamp = (w.data_ptr(), w._version)
+        if getattr(self, "_pkp_stamp", None) != stamp:
+            self._pkp = hip.pack_dense_linear_weight(w.detach().float().permute(0, 2, 3, 1).reshape(w.shape[0], -1))
+            self._pkp_stamp = stamp
+        return self._pkp
+
     def _encode_planes(self, x):
         """head + residual encoding of (imgs, C, H, W) fp32 -> (imgs, H, W, embed_dim) fp32, channels last."""
         pk = self._packed()
@@ -91,7 +99,15 @@ class PatchEmbedLocal(nn.Module):
         imgs, C, H, W = x.shape
         if (not self.training and x.is_cuda and os.environ.get("SDF_DENSE_CONV", "1") != "0"
                 and hip.dense_conv_applicable(imgs, H, W, C, self.embed_dim) and C <= 16 and self.embed_dim == 96):
-            y = self.proj(self._encode_planes(x).permute(0, 3, 1, 2)).contiguous()
+            a = self._encode_planes(x)                                                # (imgs, H, W, C) channels last
+            st = self.proj.stride
+            if st[0] == st[1] and self.embed_dim % 32 == 0 and self.proj.bias is not None:
+                # the strided projection as a GEMM over gathered rows; images leave (b, t)-major, channels last: the returned
+                # (B, C, T, h, w) is a view of exactly the (B, T, h, w, C) buffer the swin stages ask for (their permute + contiguous
+                # is then free)
+                y = hip.dense_conv3x3_strided(a, self._packed_proj(), self.proj.bias.detach().float(), st[0], T)
+                return y.view(B, T, *y.shape[1:]).permute(0, 4, 1, 2, 3)
+            y = self.proj(a.permute(0, 3, 1, 2)).contiguous()
         else:
             y = self.proj(self.residual_encoding(self.head(x)))
         return y.view(T, B, *y.shape[1:]).permute(1, 2, 0, 3, 4)

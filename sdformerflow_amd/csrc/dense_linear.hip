@@ -64,16 +64,32 @@ __global__ __launch_bounds__(256) void dense_linear_kernel(LinearParams P) {
   const int tn = blockIdx.x % P.tiles_n, tm = blockIdx.x / P.tiles_n;   // column tiles fastest: the A tile is shared through L2
   const int m0 = tm * BM, n0 = tn * BN;
 
-  const __amdgpu_buffer_rsrc_t A_rs = rsrc(d.a, (uint32_t)M * (uint32_t)K * 4u);
+  // convolution form: row m = (img, oy, ox) of a 3x3 / pad 1 / stride cv_stride convolution over a channels-last fp32 image,
+  // k = (ky * 3 + kx) * C + c: a chunk of 32 k is 128 contiguous bytes of one tap (C % 32 == 0), zero outside the image
+  const bool conv = d.cv_C > 0;
+  const int cvH = d.cv_H, cvW = d.cv_W, cvC = d.cv_C, ohw = d.cv_OH * d.cv_OW;
+  const __amdgpu_buffer_rsrc_t A_rs = rsrc(d.a, conv ? (uint32_t)(M / ohw) * (uint32_t)(cvH * cvW) * (uint32_t)cvC * 4u
+                                                     : (uint32_t)M * (uint32_t)K * 4u);
   const __amdgpu_buffer_rsrc_t W_rs = rsrc(d.w, 2u * (uint32_t)N * (uint32_t)K * 2u);
 
   // loader pieces of this thread.  A: 128 rows x 8 float4 per chunk, 4 per thread; W: 2 planes x 96 rows x 4 sixteen-byte pieces, 3 per thread
   uint32_t a_off[4], a_lds[4], w_off[3], w_lds[3];
+  int a_y[4], a_x[4];                                                  // convolution form: input row / column of tap (0, 0)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int p = tid + 256 * i, row = p >> 3, c4 = p & 7;
-    a_off[i] = m0 + row < M ? (uint32_t)((m0 + row) * K + c4 * 4) * 4u : INV;
     a_lds[i] = (uint32_t)(row * RS + c4 * 8);
+    a_y[i] = a_x[i] = 0;
+    if (!conv) {
+      a_off[i] = m0 + row < M ? (uint32_t)((m0 + row) * K + c4 * 4) * 4u : INV;
+    } else if (m0 + row < M) {
+      const int img = (m0 + row) / ohw, pix = (m0 + row) - img * ohw;
+      const int oy = pix / d.cv_OW, ox = pix - oy * d.cv_OW;
+      a_y[i] = oy * d.cv_stride - 1; a_x[i] = ox * d.cv_stride - 1;
+      a_off[i] = (uint32_t)(img * cvH * cvW * cvC + c4 * 4) * 4u;       // image base + the piece's channel offset
+    } else {
+      a_off[i] = INV;
+    }
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -83,8 +99,18 @@ __global__ __launch_bounds__(256) void dense_linear_kernel(LinearParams P) {
   }
   u32x4 areg[4], wreg[3];
   auto request = [&](int kc) __attribute__((always_inline)) {
+    if (conv) {
+      const int tap = (kc * KC) / cvC, c0 = kc * KC - tap * cvC, ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) areg[i] = __builtin_amdgcn_raw_buffer_load_b128(A_rs, a_off[i] != INV ? a_off[i] + (uint32_t)kc * (KC * 4) : INV, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+        const bool ok = a_off[i] != INV && (unsigned)iy < (unsigned)cvH && (unsigned)ix < (unsigned)cvW;
+        areg[i] = __builtin_amdgcn_raw_buffer_load_b128(A_rs, ok ? a_off[i] + (uint32_t)((iy * cvW + ix) * cvC + c0) * 4u : INV, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) areg[i] = __builtin_amdgcn_raw_buffer_load_b128(A_rs, a_off[i] != INV ? a_off[i] + (uint32_t)kc * (KC * 4) : INV, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(W_rs, w_off[i] + (uint32_t)kc * (KC * 2), 0, 0);
   };
@@ -142,7 +168,12 @@ __global__ __launch_bounds__(256) void dense_linear_kernel(LinearParams P) {
   }
 
   // epilogue: accumulator quad q of block j = columns n0 + 32j + 8q + 4lh .. + 3 of row m0 + 32*wave + l31
-  const int m = m0 + wave * 32 + l31;
+  int m = m0 + wave * 32 + l31;
+  const bool m_ok = m < M;
+  if (conv && d.out_T > 1 && m_ok) {                                   // images arrive (t, b)-major and leave (b, t)-major
+    const int img = m / ohw, pix = m - img * ohw, nb = (M / ohw) / d.out_T;
+    m = ((img % nb) * d.out_T + img / nb) * ohw + pix;
+  }
   const __amdgpu_buffer_rsrc_t C_rs = rsrc(d.out, (uint32_t)M * (uint32_t)N * 4u);
   const __amdgpu_buffer_rsrc_t R_rs = rsrc(d.resid, (uint32_t)M * (uint32_t)N * 4u);
   const bool gelu = d.gelu != 0, has_res = d.resid != nullptr;
@@ -151,7 +182,7 @@ __global__ __launch_bounds__(256) void dense_linear_kernel(LinearParams P) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = n0 + 32 * j + 8 * q + 4 * lh;
-      const uint32_t off = m < M ? (uint32_t)(m * N + n) * 4u : INV;
+      const uint32_t off = m_ok ? (uint32_t)(m * N + n) * 4u : INV;
       float4 o = make_float4(acc[j][4 * q + 0], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
       if (d.bias) {
         const float4 b = *reinterpret_cast<const float4*>(d.bias + n);
@@ -174,8 +205,16 @@ __global__ __launch_bounds__(256) void dense_linear_kernel(LinearParams P) {
 extern "C" int sdf_dense_linear_fwd(const SdfDenseLinearDesc* d, void* stream) {
   if (!d || !d->a || !d->w || !d->out) return SDF_E_NULL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->N % BN || d->K % KC) return SDF_E_SHAPE;
+  if (d->cv_C > 0) {
+    if (d->cv_C % KC || d->K != 9 * d->cv_C || d->cv_H <= 0 || d->cv_W <= 0 || d->cv_stride <= 0 || d->cv_OH <= 0 || d->cv_OW <= 0) return SDF_E_SHAPE;
+    if (d->cv_OH != (d->cv_H - 1) / d->cv_stride + 1 || d->cv_OW != (d->cv_W - 1) / d->cv_stride + 1) return SDF_E_SHAPE;   // 3x3, pad 1
+    if (d->M % (d->cv_OH * d->cv_OW) || d->resid) return SDF_E_SHAPE;
+    const int imgs = d->M / (d->cv_OH * d->cv_OW);
+    if (d->out_T > 1 && imgs % d->out_T) return SDF_E_SHAPE;
+    if ((int64_t)imgs * d->cv_H * d->cv_W * d->cv_C * 4 >= ((int64_t)1 << 31)) return SDF_E_SHAPE;
+  }
   const int64_t lim = (int64_t)1 << 31;
-  if ((int64_t)d->M * d->K * 4 >= lim || (int64_t)d->M * d->N * 4 >= lim || (int64_t)d->N * d->K * 4 >= lim) return SDF_E_SHAPE;
+  if ((d->cv_C == 0 && (int64_t)d->M * d->K * 4 >= lim) || (int64_t)d->M * d->N * 4 >= lim || (int64_t)d->N * d->K * 4 >= lim) return SDF_E_SHAPE;
   if (!sdf_aligned(d->a, 16) || !sdf_aligned(d->w, 16) || !sdf_aligned(d->out, 16) || (d->resid && !sdf_aligned(d->resid, 16)) ||
       (d->bias && !sdf_aligned(d->bias, 16)))
     return SDF_E_ALIGN;

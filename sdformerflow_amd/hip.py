@@ -91,7 +91,9 @@ class DenseConvDesc(C.Structure):
 
 class DenseLinearDesc(C.Structure):
     _fields_ = [("a", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("resid", C.c_void_p), ("out", C.c_void_p),
-                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("gelu", C.c_int32)]
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("gelu", C.c_int32),
+                ("cv_H", C.c_int32), ("cv_W", C.c_int32), ("cv_C", C.c_int32), ("cv_stride", C.c_int32), ("cv_OH", C.c_int32),
+                ("cv_OW", C.c_int32), ("out_T", C.c_int32)]
 
 
 _lib = None
@@ -789,6 +791,24 @@ def layer_norm(x, gamma, beta, eps):
     _check(lib().sdf_layer_norm_fwd(C.c_void_p(_ptr(x, torch.float32)), C.c_void_p(_ptr(gamma, torch.float32)), C.c_void_p(_ptr(beta, torch.float32)),
                                     C.c_void_p(out.data_ptr()), C.c_int64(x.numel() // Cc), C.c_int(Cc), C.c_float(eps), _stream()),
            "sdf_layer_norm_fwd")
+    return out
+
+
+def dense_conv3x3_strided(x_cl, wplanes, bias, stride, out_T=0):
+    """3x3 / pad 1 / stride `stride` convolution of a channels-last fp32 image x_cl (imgs, H, W, C) as a GEMM over gathered rows
+    (sdf_dense_linear_fwd, convolution form) -> (imgs, OH, OW, N) fp32 channels last; with out_T = T the images, (t, b)-major on the
+    way in, leave (b, t)-major.  wplanes = pack_dense_linear_weight(w.permute(0, 2, 3, 1).reshape(N, 9 * C))."""
+    imgs, H, W, Cc = x_cl.shape
+    N = wplanes.shape[1]
+    if wplanes.shape[2] != 9 * Cc or not x_cl.is_contiguous():
+        raise SdfError("dense_conv3x3_strided needs a contiguous (imgs, H, W, C) image and (2, N, 9C) weight planes")
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.empty((imgs, OH, OW, N), dtype=torch.float32, device=x_cl.device)
+    d = DenseLinearDesc()
+    d.a, d.w, d.bias, d.resid, d.out = _ptr(x_cl, torch.float32), _ptr(wplanes, torch.float16), _ptr(bias, torch.float32), None, _ptr(out)
+    d.M, d.N, d.K, d.gelu = imgs * OH * OW, N, 9 * Cc, 0
+    d.cv_H, d.cv_W, d.cv_C, d.cv_stride, d.cv_OH, d.cv_OW, d.out_T = H, W, Cc, stride, OH, OW, out_T
+    _check(lib().sdf_dense_linear_fwd(C.byref(d), _stream()), "sdf_dense_linear_fwd")
     return out
 
 

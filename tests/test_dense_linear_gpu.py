@@ -65,3 +65,22 @@ def test_layer_norm_matches_torch(rows, C):
     y = hip.layer_norm(x, w, b, 1e-5)
     ref = F.layer_norm(x.double().cpu(), (C,), w.double().cpu(), b.double().cpu(), 1e-5)
     assert (y.double().cpu() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("imgs,H,W,C,N,stride,T", [(4, 24, 32, 96, 96, 4, 2), (2, 17, 21, 32, 192, 2, 0), (6, 12, 12, 64, 96, 1, 3)])
+def test_strided_convolution_as_gathered_gemm(imgs, H, W, C, N, stride, T):
+    """The convolution form of sdf_dense_linear_fwd (PatchEmbedLocal.proj, reference models/STSwinNet/PatchEmbed.py:191) against
+    F.conv2d in fp64, including the (T, B) -> (B, T) image order of the output."""
+    from sdformerflow_amd import hip
+    g = torch.Generator().manual_seed(imgs * H + C)
+    x = torch.randn(imgs, C, H, W, generator=g).cuda()
+    w = (torch.randn(N, C, 3, 3, generator=g) / (3 * C ** 0.5)).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    wp = hip.pack_dense_linear_weight(w.permute(0, 2, 3, 1).reshape(N, -1))
+    y = hip.dense_conv3x3_strided(x.permute(0, 2, 3, 1).contiguous(), wp, b, stride, T)
+    ref = F.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), stride, 1).permute(0, 2, 3, 1)
+    if T:
+        ref = ref.reshape(T, imgs // T, *ref.shape[1:]).transpose(0, 1).reshape(ref.shape)
+    assert y.shape == ref.shape
+    err = (y.double().cpu() - ref).abs().max().item()
+    assert err <= 4e-6 * ref.abs().max().item(), (err, ref.abs().max().item())
