@@ -119,13 +119,23 @@ class WindowAttention3D(nn.Module):
         b = tab[self.relative_position_index.view(-1)].view(N, N, -1).permute(2, 0, 1)
         return (16 * torch.sigmoid(b)).contiguous()
 
+    def _bias_and_scale(self):
+        """(position bias (nH, N, N), clamped exp logit scale (nH,)): functions of the parameters alone, so in eval they are computed
+        once per parameter version instead of once per forward (ten cpb_mlp evaluations per config-3 forward otherwise)."""
+        ps = list(self.cpb_mlp.parameters()) + [self.logit_scale]
+        stamp = tuple((p.data_ptr(), p._version) for p in ps)
+        if self.training or getattr(self, "_bs_stamp", None) != stamp:
+            scale = torch.clamp(self.logit_scale, max=math.log(1.0 / 0.01)).exp().reshape(-1).contiguous()
+            self._bs, self._bs_stamp = (self.position_bias(), scale), stamp
+        return self._bs
+
     def forward(self, x, mask=None):
         if self.training:
             raise NotImplementedError("forward-only (SURVEY.md section 8f row 3 covers the backward kernels)")
         with torch.no_grad():
             qkv = self.qkv(x).contiguous()
-            scale = torch.clamp(self.logit_scale, max=math.log(1.0 / 0.01)).exp().reshape(-1).contiguous()
-            o = hip.win_attn_ann(qkv, scale, self.position_bias(), None if mask is None else mask.contiguous(), self.num_heads)
+            bias, scale = self._bias_and_scale()
+            o = hip.win_attn_ann(qkv, scale, bias, None if mask is None else mask.contiguous(), self.num_heads)
             return self.proj(o), None
 
     def forward_rows(self, y2, row_map, B_, mask, resid=None):
@@ -134,9 +144,9 @@ class WindowAttention3D(nn.Module):
         with torch.no_grad():
             qkv = linear_rows(self.qkv, y2)
             pad = self.qkv.bias.detach().float().contiguous() if self.qkv.bias is not None else torch.zeros(3 * self.dim, device=y2.device)
-            scale = torch.clamp(self.logit_scale, max=math.log(1.0 / 0.01)).exp().reshape(-1).contiguous()
+            bias, scale = self._bias_and_scale()
             N = self.window_size[0] * self.window_size[1] * self.window_size[2]
-            o = hip.win_attn_ann_windowed(qkv, row_map, B_, N, pad, scale, self.position_bias(), mask, self.num_heads)
+            o = hip.win_attn_ann_windowed(qkv, row_map, B_, N, pad, scale, bias, mask, self.num_heads)
             return linear_rows(self.proj, o, False, resid)
 
 
