@@ -159,3 +159,34 @@ def test_config3_batch8_dense_convolution_path(monkeypatch):
         for i, (a, b) in enumerate(zip(got, ref)):
             d = (a[n:n + 1] - b).abs().max().item()
             assert d <= 1e-3 * b.abs().mean().item(), (n, i, d)
+
+
+@pytest.mark.gpu
+def test_patch_embedding_and_decoder_modules_match_their_library_forms(monkeypatch):
+    """Module level: `PatchEmbedLocal` (dense convolutions + gathered-row projection) and `UpsampleConvLayer.forward_parts` (fused
+    upsample-packing + slice chain) against the same modules on the library's fp32 convolutions, fed the same tensors."""
+    from sdformerflow_amd.STSwinNet.PatchEmbed import PatchEmbedLocal
+    from sdformerflow_amd.STSwinNet.STSwinNet import UpsampleConvLayer
+    g = torch.Generator().manual_seed(21)
+    pe = PatchEmbedLocal((48, 64), (10, 4, 4), 20, 96).eval()
+    with torch.no_grad():
+        for p in pe.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.05 if p.dim() > 1 else 0.2) + (1.0 if p.dim() == 1 and p.shape[0] == 96 else 0.0))
+        for n, b in pe.named_buffers():
+            if n.endswith("running_var"):
+                b.copy_(0.5 + torch.rand(b.shape, generator=g))
+            elif n.endswith("running_mean"):
+                b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+    pe = pe.cuda()
+    x = torch.randn(2, 3, 10, 48, 64, generator=g).cuda()
+    dec = UpsampleConvLayer(2 * 96 + 2, 96, 3).eval().cuda()
+    parts = [torch.randn(3, 96, 12, 16, generator=g).cuda(), torch.randn(3, 96, 12, 16, generator=g).cuda(), torch.randn(3, 2, 12, 16, generator=g).cuda()]
+    with torch.no_grad():
+        y = pe(x)
+        z = dec.forward_parts(parts, [2, 0, 1])
+        monkeypatch.setenv("SDF_DENSE_CONV", "0")
+        y_lib = pe(x)
+        z_lib = dec.forward_parts(parts, [2, 0, 1])
+    assert y.shape == y_lib.shape == (3, 96, 2, 12, 16) and z.shape == z_lib.shape == (3, 96, 24, 32)
+    assert (y - y_lib).abs().max().item() <= 2e-5 * y_lib.abs().max().item()
+    assert (z - z_lib).abs().max().item() <= 2e-5 * z_lib.abs().max().item()
