@@ -504,6 +504,275 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// win_attn_tiled_f16_kernel: the ANN arithmetic of win_attn_tiled_kernel on the 16-bit matrix pipe.  Every fp32 operand is
+// the sum of two fp16 numbers (x = hi + lo, hi = fp16(x), lo = fp16(x - hi): 22 significant bits) and every product is three
+// MFMAs (hi*hi + lo*hi + hi*lo, fp32 accumulation): K Q^T is 3 x v_mfma_f32_16x16x32_f16 per 16 x 16 score tile (the whole
+// head dimension in one instruction) instead of 8 x v_mfma_f32_16x16x4_f32, P V is 2 x 3 x v_mfma_f32_16x16x16_f16 instead
+// of 8 - 96 matrix-pipe cycles per tile pair instead of 512.  The register choreography is unchanged: S^T = K Q^T leaves
+// keys 4*(lane/16) + 0..3 of query lane%16 in a lane's accumulator, which is exactly the A operand layout of the 16-key P V
+// step (split into hi / lo on the spot), so the probabilities never touch LDS.  K rows live in LDS as two fp16 planes
+// (80-byte rows: conflict-free ds_read_b128 over 16 consecutive keys), V transposed as [key quad][dim]{4 x hi, 4 x lo}
+// (one ds_read_b128 per P V B operand, 512-byte key-quad pitch: conflict-free).
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+constexpr int KRS = 80;                // K row pitch in bytes: 32 fp16 + 16 pad
+
+// four fp32 -> four hi and four lo fp16 (round to nearest; saturating at the fp16 range)
+__device__ __forceinline__ void split4_f16(float x, float y, float z, float w, uint2& hi, uint2& lo) {
+  f32x2 a, b;
+  a.x = __builtin_amdgcn_fmed3f(x, -65000.f, 65000.f); a.y = __builtin_amdgcn_fmed3f(y, -65000.f, 65000.f);
+  b.x = __builtin_amdgcn_fmed3f(z, -65000.f, 65000.f); b.y = __builtin_amdgcn_fmed3f(w, -65000.f, 65000.f);
+  const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
+  f32x2 ra, rb;
+  ra.x = a.x - (float)ha.x; ra.y = a.y - (float)ha.y; rb.x = b.x - (float)hb.x; rb.y = b.y - (float)hb.y;
+  const f16x2 la = __builtin_convertvector(ra, f16x2), lb = __builtin_convertvector(rb, f16x2);
+  hi = make_uint2(__builtin_bit_cast(uint32_t, ha), __builtin_bit_cast(uint32_t, hb));
+  lo = make_uint2(__builtin_bit_cast(uint32_t, la), __builtin_bit_cast(uint32_t, lb));
+}
+
+template <int NTC, bool HAS_MASK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WPE, 4))) void win_attn_tiled_f16_kernel(AttnParams P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const SdfWinAttnDesc& d = P.d;
+  constexpr int NP = NTC * 16;
+  const int N = d.N;
+  uint8_t* Khi = reinterpret_cast<uint8_t*>(lds);                  // [NP][KRS]
+  uint8_t* Klo = Khi + NP * KRS;
+  uint8_t* Vt2 = Klo + NP * KRS;                                   // [NP / 4][HD][16 B]
+
+  const int total = gridDim.x, per_xcd = total >> 3;               // workgroup -> (window, head): as win_attn_tiled_kernel
+  int L = blockIdx.x;
+  if (L < per_xcd * 8) L = (L & 7) * per_xcd + (L >> 3);
+  const int share = (d.B_ / d.nW) * d.nH;
+  const int w = L / share, rest = L - w * share;
+  const int bc = rest / d.nH, g = rest - bc * d.nH;
+  const int b = bc * d.nW + w;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int C = d.nH * HD;
+
+  auto load_q = [&](int qt, float (&qr)[8]) __attribute__((always_inline)) {
+    const int qi = qt * 16 + l15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qr[i] = 0.f;
+    if (qi < N) {
+      const float* base = qkv_row(d, b, qi, C) + g * HD + 8 * lg;
+      const float4 a = *reinterpret_cast<const float4*>(base), c = *reinterpret_cast<const float4*>(base + 4);
+      qr[0] = a.x; qr[1] = a.y; qr[2] = a.z; qr[3] = a.w; qr[4] = c.x; qr[5] = c.y; qr[6] = c.z; qr[7] = c.w;
+    }
+  };
+  const int wv = (wave + L) & 3;
+  float qnext[8];
+  load_q(wv, qnext);
+
+  float warm = 0.f;
+  if (HAS_MASK) {
+    const float* mw = d.mask + (int64_t)(b % d.nW) * N * N;
+    for (int i = tid * 32; i < N * N; i += 256 * 32) warm += mw[i];
+  }
+  // ---- stage K (normalised, hi / lo planes) and V (transposed by key quads): a unit = (key quad, 4 dims), 8 units per quad ----
+  {
+    constexpr int UNITS = (NP / 4) * 8, IT = (UNITS + 255) / 256;
+    float4 kq[IT][4], vq[IT][4];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int u = tid + 256 * it, kgp = u >> 3, piece = u & 7;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * kgp + j;
+        kq[it][j] = vq[it][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u < UNITS && r < N) {
+          const float* base = qkv_row(d, b, r, C) + g * HD + 4 * piece;
+          kq[it][j] = *reinterpret_cast<const float4*>(base + C);
+          vq[it][j] = *reinterpret_cast<const float4*>(base + 2 * C);
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int u = tid + 256 * it, kgp = u >> 3, piece = u & 7;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float4 kv = kq[it][j];                                     // F.normalize(k, dim=-1): the key's 8 units are neighbouring lanes
+        float sk = kv.x * kv.x + kv.y * kv.y + kv.z * kv.z + kv.w * kv.w;
+        sk += __shfl_xor(sk, 1);
+        sk += __shfl_xor(sk, 2);
+        sk += __shfl_xor(sk, 4);
+        const float ik = 1.f / fmaxf(sqrtf(sk), 1e-12f);
+        uint2 hi, lo;
+        split4_f16(kv.x * ik, kv.y * ik, kv.z * ik, kv.w * ik, hi, lo);
+        if (u < UNITS) {
+          *reinterpret_cast<uint2*>(Khi + (4 * kgp + j) * KRS + 8 * piece) = hi;
+          *reinterpret_cast<uint2*>(Klo + (4 * kgp + j) * KRS + 8 * piece) = lo;
+        }
+      }
+      if (u < UNITS) {
+        const float vx[4][4] = {{vq[it][0].x, vq[it][1].x, vq[it][2].x, vq[it][3].x}, {vq[it][0].y, vq[it][1].y, vq[it][2].y, vq[it][3].y},
+                                {vq[it][0].z, vq[it][1].z, vq[it][2].z, vq[it][3].z}, {vq[it][0].w, vq[it][1].w, vq[it][2].w, vq[it][3].w}};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                              // dim 4*piece + c: its four keys, hi then lo
+          uint2 hi, lo;
+          split4_f16(vx[c][0], vx[c][1], vx[c][2], vx[c][3], hi, lo);
+          *reinterpret_cast<uint4*>(Vt2 + ((kgp * HD) + 4 * piece + c) * 16) = make_uint4(hi.x, hi.y, lo.x, lo.y);
+        }
+      }
+    }
+  }
+  asm volatile("" ::"v"(warm));
+  __syncthreads();
+
+  const float ls = d.scale[g];
+  const uint32_t tbytes = (uint32_t)N * (uint32_t)N * 4u;
+  const __amdgpu_buffer_rsrc_t bias_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.bias + (int64_t)g * N * N), 0, (int)tbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mask_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(HAS_MASK ? d.mask + (int64_t)(b % d.nW) * N * N : d.bias), 0, HAS_MASK ? (int)tbytes : 0, 0x00020000);
+
+  for (int qt = wv; qt < NTC; qt += 4) {
+    if (qt * 16 >= N) break;
+    const int qi = qt * 16 + l15;
+    float qreg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qreg[i] = qnext[i];
+    {                                                              // F.normalize(q, dim=-1)
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ss += qreg[i] * qreg[i];
+      ss += __shfl_xor(ss, 16);
+      ss += __shfl_xor(ss, 32);
+      const float iq = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) qreg[i] *= iq;
+    }
+    if (qt + 4 < NTC) load_q(qt + 4, qnext);
+    uint2 qh0, ql0, qh1, ql1;
+    split4_f16(qreg[0], qreg[1], qreg[2], qreg[3], qh0, ql0);
+    split4_f16(qreg[4], qreg[5], qreg[6], qreg[7], qh1, ql1);
+    const f16x8 q_hi = __builtin_bit_cast(f16x8, make_uint4(qh0.x, qh0.y, qh1.x, qh1.y));
+    const f16x8 q_lo = __builtin_bit_cast(f16x8, make_uint4(ql0.x, ql0.y, ql1.x, ql1.y));
+
+    u32x4 bb[NTC], mm[NTC];
+    const uint32_t rowoff = (uint32_t)qi * (uint32_t)N * 4u;
+    auto load_strip = [&](const __amdgpu_buffer_rsrc_t& rs, u32x4 (&dst)[NTC]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int jt = 0; jt < NTC; ++jt) {
+        const int kb = jt * 16 + 4 * lg;
+        if (jt < NTC - 1) {
+          dst[jt] = __builtin_amdgcn_raw_buffer_load_b128(rs, qi < N ? rowoff + (uint32_t)kb * 4u : INV_OFF, 0, 0);
+        } else {
+          const uint32_t o0 = (qi < N && kb < N) ? rowoff + (uint32_t)kb * 4u : INV_OFF;
+          const uint32_t o1 = (qi < N && kb + 2 < N) ? rowoff + (uint32_t)kb * 4u + 8u : INV_OFF;
+          const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(rs, o0, 0, 0);
+          const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(rs, o1, 0, 0);
+          dst[jt] = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+      }
+    };
+    load_strip(bias_rs, bb);
+    if (HAS_MASK) load_strip(mask_rs, mm);
+    // ---- S^T = K Q^T: three 16x16x32 products per key tile ----
+    f32x4 st[NTC];
+#pragma unroll
+    for (int jt = 0; jt < NTC; ++jt) {
+      const int kj = jt * 16 + l15;
+      const f16x8 k_hi = *reinterpret_cast<const f16x8*>(Khi + kj * KRS + 16 * lg);
+      const f16x8 k_lo = *reinterpret_cast<const f16x8*>(Klo + kj * KRS + 16 * lg);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, q_lo, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_lo, q_hi, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, q_hi, acc, 0, 0, 0);
+      st[jt] = acc;
+    }
+#pragma unroll
+    for (int jt = 0; jt < NTC; ++jt) {
+      const int kb = jt * 16 + 4 * lg;
+      const uint32_t b0 = bb[jt].x, b1 = bb[jt].y, b2 = bb[jt].z, b3 = bb[jt].w;
+      float s0 = st[jt][0] * ls + __uint_as_float(b0), s1 = st[jt][1] * ls + __uint_as_float(b1);
+      float s2 = st[jt][2] * ls + __uint_as_float(b2), s3 = st[jt][3] * ls + __uint_as_float(b3);
+      if (HAS_MASK) {
+        const uint32_t m0 = mm[jt].x, m1 = mm[jt].y, m2 = mm[jt].z, m3 = mm[jt].w;
+        s0 += __uint_as_float(m0); s1 += __uint_as_float(m1); s2 += __uint_as_float(m2); s3 += __uint_as_float(m3);
+      }
+      if (jt == NTC - 1) {
+        s0 = (kb + 0 < N) ? s0 : -INFINITY; s1 = (kb + 1 < N) ? s1 : -INFINITY;
+        s2 = (kb + 2 < N) ? s2 : -INFINITY; s3 = (kb + 3 < N) ? s3 : -INFINITY;
+      }
+      st[jt][0] = s0; st[jt][1] = s1; st[jt][2] = s2; st[jt][3] = s3;
+    }
+    {
+      float m = -INFINITY;
+#pragma unroll
+      for (int jt = 0; jt < NTC; ++jt) m = fmaxf(fmaxf(fmaxf(m, st[jt][0]), fmaxf(st[jt][1], st[jt][2])), st[jt][3]);
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      const float L2E = 1.4426950408889634f, mneg = -m * L2E;
+      float sum = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < NTC; ++jt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(st[jt][r], L2E, mneg));
+          st[jt][r] = e;
+          sum += e;
+        }
+      }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      const float inv = 1.f / sum;
+#pragma unroll
+      for (int jt = 0; jt < NTC; ++jt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[jt][r] *= inv;
+      }
+    }
+    // ---- O = P V: the lane's four probabilities of key tile jt are the A operand (keys 16 jt + 4 lg + 0..3) ----
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jt = 0; jt < NTC; ++jt) {
+      uint2 ph, pl;
+      split4_f16(st[jt][0], st[jt][1], st[jt][2], st[jt][3], ph, pl);
+      const f16x4 p_hi = __builtin_bit_cast(f16x4, ph), p_lo = __builtin_bit_cast(f16x4, pl);
+      const uint4 v0 = *reinterpret_cast<const uint4*>(Vt2 + (((4 * jt + lg) * HD) + l15) * 16);
+      const uint4 v1 = *reinterpret_cast<const uint4*>(Vt2 + (((4 * jt + lg) * HD) + 16 + l15) * 16);
+      const f16x4 v0h = __builtin_bit_cast(f16x4, make_uint2(v0.x, v0.y)), v0l = __builtin_bit_cast(f16x4, make_uint2(v0.z, v0.w));
+      const f16x4 v1h = __builtin_bit_cast(f16x4, make_uint2(v1.x, v1.y)), v1l = __builtin_bit_cast(f16x4, make_uint2(v1.z, v1.w));
+      o0 = __builtin_amdgcn_mfma_f32_16x16x16f16(p_lo, v0h, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x16f16(p_lo, v1h, o1, 0, 0, 0);
+      o0 = __builtin_amdgcn_mfma_f32_16x16x16f16(p_hi, v0l, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x16f16(p_hi, v1l, o1, 0, 0, 0);
+      o0 = __builtin_amdgcn_mfma_f32_16x16x16f16(p_hi, v0h, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x16f16(p_hi, v1h, o1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = qt * 16 + 4 * lg + r;
+      if (i < N) {
+        const int64_t orow = d.row_map ? d.row_map[(int64_t)b * N + i] : (int64_t)b * N + i;   // window reverse + roll back + crop
+        if (orow < 0) continue;
+        const int64_t off = orow * C + g * HD;
+        d.out[off + l15] = o0[r];
+        d.out[off + 16 + l15] = o1[r];
+      }
+    }
+  }
+}
+
+template <int NTC>
+int launch_tiled_f16(const AttnParams& P, hipStream_t s) {
+  constexpr size_t lds = (size_t)(2 * NTC * 16 * KRS + (NTC * 4) * HD * 16);
+  dim3 grid((unsigned)(P.d.B_ * P.d.nH)), block(256);
+  if (P.d.mask) {
+    hipLaunchKernelGGL((win_attn_tiled_f16_kernel<NTC, true>), grid, block, lds, s, P);
+  } else {
+    hipLaunchKernelGGL((win_attn_tiled_f16_kernel<NTC, false>), grid, block, lds, s, P);
+  }
+  SDF_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int MODE, int NTC>
 int launch_tiled(const AttnParams& P, hipStream_t s) {
   constexpr size_t lds = (size_t)(NTC * 16 * LDW + HD * (NTC * 16 + 4)) * sizeof(float);
@@ -540,6 +809,11 @@ extern "C" int sdf_win_attn_fwd(const SdfWinAttnDesc* d, void* stream) {
   if (d->N % 2 == 0 && (int64_t)d->N * d->N * 4 < (1LL << 31) && !(ge && ge[0] == '1')) {
     const int nt = (d->N + 15) / 16;                         // compiled tile counts: windows (2,8,8) and (2,9,9)
     if (d->mode == SDF_ATTN_ANN) {
+      const char* f32 = getenv("SDF_ATTN_F32");              // A/B override: 1 = the fp32-pipe kernel
+      if (!(f32 && f32[0] == '1')) {
+        if (nt == 8) return launch_tiled_f16<8>(P, s);
+        if (nt == 11) return launch_tiled_f16<11>(P, s);
+      }
       if (nt == 8) return launch_tiled<SDF_ATTN_ANN, 8>(P, s);
       if (nt == 11) return launch_tiled<SDF_ATTN_ANN, 11>(P, s);
     } else {

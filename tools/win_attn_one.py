@@ -33,7 +33,14 @@ e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / reps * 1e3
 fl = 4.0 * N * N * 32 * B_ * nH                         # QK^T + P.V, SURVEY.md 8(d): 3.36 MFLOP per (window, head)
 NT = (N + 15) // 16
-mf = B_ * nH * NT * NT * 16                             # v_mfma_f32_16x16x4_f32 issued: 8 per S tile + 8 per P.V tile pair
-floor_us = mf * 32 / 4 / 256 / 2400.0                   # 32 cyc/SIMD each, 4 SIMDs x 256 CUs, 2.4 GHz
+f16 = mode == "ann" and N % 2 == 0 and NT in (8, 11) and os.environ.get("SDF_ATTN_F32") != "1" and os.environ.get("SDF_ATTN_GENERIC") != "1"
+if f16:
+    # three v_mfma_f32_16x16x32_f16 (16 cycles) per S tile + six v_mfma_f32_16x16x16_f16 (8 cycles) per P.V tile pair
+    cyc = B_ * nH * NT * NT * (3 * 16 + 6 * 8)
+    what = "hi/lo fp16 planes, three products: 9 MFMAs per tile pair on the 16-bit pipe"
+else:
+    cyc = B_ * nH * NT * NT * 16 * 32                  # v_mfma_f32_16x16x4_f32 (32 cycles): 8 per S tile + 8 per P.V tile pair
+    what = "16 fp32 MFMAs per tile pair"
+floor_us = cyc / 4 / 256 / 2400.0                       # 4 SIMDs x 256 CUs, 2.4 GHz
 print(f"win_attn {mode} B_={B_} nH={nH} N={N} {'mask' if mask is not None else 'no mask'}: {us:.1f} us  {fl/us/1e6:.1f} TFLOP/s algorithmic = {100*fl/us/1e6/157.3:.1f} % of the "
-      f"157.3 TF fp32-MFMA peak; {mf} MFMAs issued -> pipe floor {floor_us:.1f} us, MFMA-pipe utilisation {100*floor_us/us:.1f} %")
+      f"157.3 TF fp32-MFMA peak; {what} -> pipe floor {floor_us:.1f} us, MFMA-pipe utilisation {100*floor_us/us:.1f} %")
