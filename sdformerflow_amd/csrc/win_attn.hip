@@ -533,7 +533,7 @@ __device__ __forceinline__ void split4_f16(float x, float y, float z, float w, u
   lo = make_uint2(__builtin_bit_cast(uint32_t, la), __builtin_bit_cast(uint32_t, lb));
 }
 
-template <int NTC, bool HAS_MASK>
+template <int MODE, int NTC, bool HAS_MASK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WPE, 4))) void win_attn_tiled_f16_kernel(AttnParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const SdfWinAttnDesc& d = P.d;
@@ -559,9 +559,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
 #pragma unroll
     for (int i = 0; i < 8; ++i) qr[i] = 0.f;
     if (qi < N) {
-      const float* base = qkv_row(d, b, qi, C) + g * HD + 8 * lg;
-      const float4 a = *reinterpret_cast<const float4*>(base), c = *reinterpret_cast<const float4*>(base + 4);
-      qr[0] = a.x; qr[1] = a.y; qr[2] = a.z; qr[3] = a.w; qr[4] = c.x; qr[5] = c.y; qr[6] = c.z; qr[7] = c.w;
+      if (MODE == SDF_ATTN_ANN) {
+        const float* base = qkv_row(d, b, qi, C) + g * HD + 8 * lg;
+        const float4 a = *reinterpret_cast<const float4*>(base), c = *reinterpret_cast<const float4*>(base + 4);
+        qr[0] = a.x; qr[1] = a.y; qr[2] = a.z; qr[3] = a.w; qr[4] = c.x; qr[5] = c.y; qr[6] = c.z; qr[7] = c.w;
+      } else {                                                     // binary q: 0 / 1 (the scale multiplies the exact count afterwards)
+        const uint8_t* qp = reinterpret_cast<const uint8_t*>(d.q) + (((int64_t)b * d.nH + g) * N + qi) * HD + 8 * lg;
+        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(qp), w1 = *reinterpret_cast<const uint32_t*>(qp + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          qr[i] = ((w0 >> (8 * i)) & 0xff) ? 1.f : 0.f;
+          qr[4 + i] = ((w1 >> (8 * i)) & 0xff) ? 1.f : 0.f;
+        }
+      }
     }
   };
   const int wv = (wave + L) & 3;
@@ -585,9 +595,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
         const int r = 4 * kgp + j;
         kq[it][j] = vq[it][j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (u < UNITS && r < N) {
-          const float* base = qkv_row(d, b, r, C) + g * HD + 4 * piece;
-          kq[it][j] = *reinterpret_cast<const float4*>(base + C);
-          vq[it][j] = *reinterpret_cast<const float4*>(base + 2 * C);
+          if (MODE == SDF_ATTN_ANN) {
+            const float* base = qkv_row(d, b, r, C) + g * HD + 4 * piece;
+            kq[it][j] = *reinterpret_cast<const float4*>(base + C);
+            vq[it][j] = *reinterpret_cast<const float4*>(base + 2 * C);
+          } else {
+            const int64_t off = (((int64_t)b * d.nH + g) * N + r) * HD + 4 * piece;
+            const uint32_t wk = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(d.k) + off);
+            const uint32_t wv = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(d.v) + off);
+            kq[it][j] = make_float4((float)(wk & 0xff), (float)((wk >> 8) & 0xff), (float)((wk >> 16) & 0xff), (float)(wk >> 24));
+            vq[it][j] = make_float4((float)(wv & 0xff), (float)((wv >> 8) & 0xff), (float)((wv >> 16) & 0xff), (float)(wv >> 24));
+          }
         }
       }
     }
@@ -596,12 +614,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
       const int u = tid + 256 * it, kgp = u >> 3, piece = u & 7;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float4 kv = kq[it][j];                                     // F.normalize(k, dim=-1): the key's 8 units are neighbouring lanes
-        float sk = kv.x * kv.x + kv.y * kv.y + kv.z * kv.z + kv.w * kv.w;
-        sk += __shfl_xor(sk, 1);
-        sk += __shfl_xor(sk, 2);
-        sk += __shfl_xor(sk, 4);
-        const float ik = 1.f / fmaxf(sqrtf(sk), 1e-12f);
+        float4 kv = kq[it][j];
+        float ik = 1.f;
+        if (MODE == SDF_ATTN_ANN) {                                // F.normalize(k, dim=-1): the key's 8 units are neighbouring lanes
+          float sk = kv.x * kv.x + kv.y * kv.y + kv.z * kv.z + kv.w * kv.w;
+          sk += __shfl_xor(sk, 1);
+          sk += __shfl_xor(sk, 2);
+          sk += __shfl_xor(sk, 4);
+          ik = 1.f / fmaxf(sqrtf(sk), 1e-12f);
+        }
         uint2 hi, lo;
         split4_f16(kv.x * ik, kv.y * ik, kv.z * ik, kv.w * ik, hi, lo);
         if (u < UNITS) {
@@ -624,7 +645,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
   asm volatile("" ::"v"(warm));
   __syncthreads();
 
-  const float ls = d.scale[g];
+  const float ls = d.scale[g];                          // ANN: logit scale on cosines; SEW: q's scale on the exact spike count
   const uint32_t tbytes = (uint32_t)N * (uint32_t)N * 4u;
   const __amdgpu_buffer_rsrc_t bias_rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.bias + (int64_t)g * N * N), 0, (int)tbytes, 0x00020000);
@@ -637,7 +658,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
     float qreg[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) qreg[i] = qnext[i];
-    {                                                              // F.normalize(q, dim=-1)
+    if (MODE == SDF_ATTN_ANN) {                                    // F.normalize(q, dim=-1)
       float ss = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) ss += qreg[i] * qreg[i];
@@ -681,8 +702,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
       const f16x8 k_hi = *reinterpret_cast<const f16x8*>(Khi + kj * KRS + 16 * lg);
       const f16x8 k_lo = *reinterpret_cast<const f16x8*>(Klo + kj * KRS + 16 * lg);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, q_lo, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_lo, q_hi, acc, 0, 0, 0);
+      if (MODE == SDF_ATTN_ANN) {                                  // binary operands have no lo halves: one exact product
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, q_lo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_lo, q_hi, acc, 0, 0, 0);
+      }
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, q_hi, acc, 0, 0, 0);
       st[jt] = acc;
     }
@@ -697,12 +720,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
         s0 += __uint_as_float(m0); s1 += __uint_as_float(m1); s2 += __uint_as_float(m2); s3 += __uint_as_float(m3);
       }
       if (jt == NTC - 1) {
-        s0 = (kb + 0 < N) ? s0 : -INFINITY; s1 = (kb + 1 < N) ? s1 : -INFINITY;
-        s2 = (kb + 2 < N) ? s2 : -INFINITY; s3 = (kb + 3 < N) ? s3 : -INFINITY;
+        const float NEG = (MODE == SDF_ATTN_ANN) ? -INFINITY : 0.f;
+        s0 = (kb + 0 < N) ? s0 : NEG; s1 = (kb + 1 < N) ? s1 : NEG;
+        s2 = (kb + 2 < N) ? s2 : NEG; s3 = (kb + 3 < N) ? s3 : NEG;
       }
       st[jt][0] = s0; st[jt][1] = s1; st[jt][2] = s2; st[jt][3] = s3;
     }
-    {
+    if (MODE == SDF_ATTN_ANN) {
       float m = -INFINITY;
 #pragma unroll
       for (int jt = 0; jt < NTC; ++jt) m = fmaxf(fmaxf(fmaxf(m, st[jt][0]), fmaxf(st[jt][1], st[jt][2])), st[jt][3]);
@@ -741,8 +765,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
       const f16x4 v1h = __builtin_bit_cast(f16x4, make_uint2(v1.x, v1.y)), v1l = __builtin_bit_cast(f16x4, make_uint2(v1.z, v1.w));
       o0 = __builtin_amdgcn_mfma_f32_16x16x16f16(p_lo, v0h, o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_16x16x16f16(p_lo, v1h, o1, 0, 0, 0);
-      o0 = __builtin_amdgcn_mfma_f32_16x16x16f16(p_hi, v0l, o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_16x16x16f16(p_hi, v1l, o1, 0, 0, 0);
+      if (MODE == SDF_ATTN_ANN) {                                  // binary v has no lo half
+        o0 = __builtin_amdgcn_mfma_f32_16x16x16f16(p_hi, v0l, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x16f16(p_hi, v1l, o1, 0, 0, 0);
+      }
       o0 = __builtin_amdgcn_mfma_f32_16x16x16f16(p_hi, v0h, o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_16x16x16f16(p_hi, v1h, o1, 0, 0, 0);
     }
@@ -750,9 +776,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
     for (int r = 0; r < 4; ++r) {
       const int i = qt * 16 + 4 * lg + r;
       if (i < N) {
-        const int64_t orow = d.row_map ? d.row_map[(int64_t)b * N + i] : (int64_t)b * N + i;   // window reverse + roll back + crop
-        if (orow < 0) continue;
-        const int64_t off = orow * C + g * HD;
+        int64_t off;
+        if (MODE == SDF_ATTN_ANN) {
+          const int64_t orow = d.row_map ? d.row_map[(int64_t)b * N + i] : (int64_t)b * N + i;   // window reverse + roll back + crop
+          if (orow < 0) continue;
+          off = orow * C + g * HD;
+        } else {
+          const int t = i / d.N1, n1 = i - t * d.N1;
+          off = (((int64_t)t * d.B_ + b) * d.N1 + n1) * C + g * HD;
+        }
         d.out[off + l15] = o0[r];
         d.out[off + 16 + l15] = o1[r];
       }
@@ -760,14 +792,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
   }
 }
 
-template <int NTC>
+template <int MODE, int NTC>
 int launch_tiled_f16(const AttnParams& P, hipStream_t s) {
   constexpr size_t lds = (size_t)(2 * NTC * 16 * KRS + (NTC * 4) * HD * 16);
   dim3 grid((unsigned)(P.d.B_ * P.d.nH)), block(256);
   if (P.d.mask) {
-    hipLaunchKernelGGL((win_attn_tiled_f16_kernel<NTC, true>), grid, block, lds, s, P);
+    hipLaunchKernelGGL((win_attn_tiled_f16_kernel<MODE, NTC, true>), grid, block, lds, s, P);
   } else {
-    hipLaunchKernelGGL((win_attn_tiled_f16_kernel<NTC, false>), grid, block, lds, s, P);
+    hipLaunchKernelGGL((win_attn_tiled_f16_kernel<MODE, NTC, false>), grid, block, lds, s, P);
   }
   SDF_LAUNCH_CHECK();
   return 0;
@@ -808,15 +840,16 @@ extern "C" int sdf_win_attn_fwd(const SdfWinAttnDesc* d, void* stream) {
   const char* ge = getenv("SDF_ATTN_GENERIC");                 // A/B override: 1 = always the general kernel
   if (d->N % 2 == 0 && (int64_t)d->N * d->N * 4 < (1LL << 31) && !(ge && ge[0] == '1')) {
     const int nt = (d->N + 15) / 16;                         // compiled tile counts: windows (2,8,8) and (2,9,9)
+    const char* f32 = getenv("SDF_ATTN_F32");                // A/B override: 1 = the fp32-pipe kernels
+    const bool pipe16 = !(f32 && f32[0] == '1');
     if (d->mode == SDF_ATTN_ANN) {
-      const char* f32 = getenv("SDF_ATTN_F32");              // A/B override: 1 = the fp32-pipe kernel
-      if (!(f32 && f32[0] == '1')) {
-        if (nt == 8) return launch_tiled_f16<8>(P, s);
-        if (nt == 11) return launch_tiled_f16<11>(P, s);
-      }
+      if (pipe16 && nt == 8) return launch_tiled_f16<SDF_ATTN_ANN, 8>(P, s);
+      if (pipe16 && nt == 11) return launch_tiled_f16<SDF_ATTN_ANN, 11>(P, s);
       if (nt == 8) return launch_tiled<SDF_ATTN_ANN, 8>(P, s);
       if (nt == 11) return launch_tiled<SDF_ATTN_ANN, 11>(P, s);
     } else {
+      if (pipe16 && nt == 8) return launch_tiled_f16<SDF_ATTN_SEW, 8>(P, s);
+      if (pipe16 && nt == 11) return launch_tiled_f16<SDF_ATTN_SEW, 11>(P, s);
       if (nt == 8) return launch_tiled<SDF_ATTN_SEW, 8>(P, s);
       if (nt == 11) return launch_tiled<SDF_ATTN_SEW, 11>(P, s);
     }

@@ -33,11 +33,14 @@ e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / reps * 1e3
 fl = 4.0 * N * N * 32 * B_ * nH                         # QK^T + P.V, SURVEY.md 8(d): 3.36 MFLOP per (window, head)
 NT = (N + 15) // 16
-f16 = mode == "ann" and N % 2 == 0 and NT in (8, 11) and os.environ.get("SDF_ATTN_F32") != "1" and os.environ.get("SDF_ATTN_GENERIC") != "1"
-if f16:
+f16 = N % 2 == 0 and NT in (8, 11) and os.environ.get("SDF_ATTN_F32") != "1" and os.environ.get("SDF_ATTN_GENERIC") != "1"
+if f16 and mode == "ann":
     # three v_mfma_f32_16x16x32_f16 (16 cycles) per S tile + six v_mfma_f32_16x16x16_f16 (8 cycles) per P.V tile pair
     cyc = B_ * nH * NT * NT * (3 * 16 + 6 * 8)
     what = "hi/lo fp16 planes, three products: 9 MFMAs per tile pair on the 16-bit pipe"
+elif f16:
+    cyc = B_ * nH * NT * NT * (1 * 16 + 4 * 8)           # binary q / k / v: one exact product for S, P = hi + lo against binary v
+    what = "binary operands exact in fp16: 5 MFMAs per tile pair on the 16-bit pipe"
 else:
     cyc = B_ * nH * NT * NT * 16 * 32                  # v_mfma_f32_16x16x4_f32 (32 cycles): 8 per S tile + 8 per P.V tile pair
     what = "16 fp32 MFMAs per tile pair"
