@@ -1,0 +1,12 @@
+#!/usr/bin/env python3
+"""Three eager single-stream forwards of BASELINE config 2 (for the rocprofv3 --pmc passes of tools/pmc_forward.sh)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+dev = torch.device("cuda:0")
+model, sd = bench.build_model("lif", dev)
+x = bench.synthetic_chunk().to(dev)
+with torch.no_grad():
+    for _ in range(3):
+        model(x)
+torch.cuda.synchronize()
