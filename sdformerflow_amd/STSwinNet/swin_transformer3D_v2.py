@@ -190,6 +190,11 @@ class SwinTransformerBlock3D(nn.Module):
         qkv bias.  `SDF_ATTN_MATERIALISE=1` keeps the reference's sequence as the A/B path."""
         B, D, H, W, C = x.shape
         ws, ss = get_window_size((D, H, W), self.window_size, self.shift_size)
+        if tuple(ws) != tuple(self.window_size):
+            # the reference clamps the window to the feature map (:277) and then fails to add its (N, N) position bias, built for
+            # the nominal window, to the smaller scores (:190, RuntimeError); the same input is refused here, not mis-addressed
+            raise RuntimeError(f"feature map {(D, H, W)} is smaller than the window {self.window_size}: the relative position bias of "
+                               "WindowAttention3D is defined for the nominal window only (reference swin_transformer3D_v2.py:184-190)")
         y = layer_norm(self.norm1, x)
         Dp, Hp, Wp = D + (-D) % ws[0], H + (-H) % ws[1], W + (-W) % ws[2]
         shifted = any(s > 0 for s in ss)

@@ -190,3 +190,15 @@ def test_patch_embedding_and_decoder_modules_match_their_library_forms(monkeypat
     assert y.shape == y_lib.shape == (3, 96, 2, 12, 16) and z.shape == z_lib.shape == (3, 96, 24, 32)
     assert (y - y_lib).abs().max().item() <= 2e-5 * y_lib.abs().max().item()
     assert (z - z_lib).abs().max().item() <= 2e-5 * z_lib.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_feature_map_smaller_than_the_window_is_refused_like_the_reference():
+    """At 96 x 128 the third stage is 6 x 8 tokens, smaller than the (2, 9, 9) window: the reference clamps the window and then
+    raises when it adds the 162 x 162 position bias (swin_transformer3D_v2.py:190); this build raises too (it used to run the
+    attention kernel past its row map)."""
+    net = build("STTFlowNet", (96, 128)).eval()
+    load_synth(net)
+    net = net.cuda()
+    with pytest.raises(RuntimeError, match="smaller than the window"):
+        net(synth_voxel(1, 20, 96, 128, seed=5).cuda(), None)
