@@ -355,6 +355,11 @@ class MSFlowEngine:
         self._check_cl(x)
         B, D, H, W, Cc = x.shape
         ws, ss = get_window_size((D, H, W), blk.window_size, blk.shift_size)
+        if tuple(ws) != tuple(blk.window_size):
+            # the reference clamps the window (:786) and then cannot view its positional encoding, sized for the nominal window, as
+            # (T', 1, Wh, Ww, C) (:678, RuntimeError); refused here as well instead of reading the table with the wrong pitch
+            raise hip.SdfError(f"feature map {(D, H, W)} is smaller than the window {tuple(blk.window_size)}: the positional encoding of "
+                               "Spiking_QK_WindowAttention3D is defined for the nominal window only (reference Spiking_swin_transformer3D.py:678)")
         rowmap, B_ = self._slice_map(B, D, H, W, ws, ss)
         Tq, N1 = ws[0], ws[1] * ws[2]
         # one C-ABI call: neuron over the gathered slices -> q|k spike GEMM (+BN, +PE, neurons fused) -> token gate ->

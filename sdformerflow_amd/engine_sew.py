@@ -98,6 +98,11 @@ class SEWFlowEngine(MSFlowEngine):
         self._check_cl(x)
         B, D, H, W, Cc = x.shape
         ws, ss = get_window_size((D, H, W), blk.window_size, blk.shift_size)
+        if tuple(ws) != tuple(blk.window_size):
+            # the reference clamps the window and then cannot add its (N, N) relative-position table, indexed for the nominal
+            # window, to the smaller scores (Spiking_swin_transformer3D.py:345-350, RuntimeError); refused here as well
+            raise hip.SdfError(f"feature map {(D, H, W)} is smaller than the window {tuple(blk.window_size)}: the relative position bias of "
+                               "Spiking_BN_WindowAttention3D is defined for the nominal window only")
         rowmap, B_ = self._slice_map(B, D, H, W, ws, ss)
         Tq, N1 = ws[0], ws[1] * ws[2]
         M = Tq * B_ * N1

@@ -344,3 +344,15 @@ def test_unet_tail_with_mismatched_feature_sizes_takes_the_concat_path():
     stage_replay("unet_tail(odd)", eng, lambda: [pp.permute(1, 0, 4, 2, 3) for pp in eng.unet_tail([f.contiguous().to(DEV) for f in feats])],
                  lambda: unet_tail_oracle(O_feats, sd, n), report)
     print("odd sizes", report[0][1], "output max-dev %.1e" % report[0][2])
+
+
+def test_feature_map_smaller_than_the_window_is_refused():
+    """At 96 x 128 the third stage of the en4 model is 6 x 8 tokens, smaller than the (2, 9, 9) window: the reference clamps the
+    window (Spiking_swin_transformer3D.py:786) and then fails to view its positional encoding as (T', 1, Wh, Ww, C) (:678); the
+    engine refuses the input as well instead of reading the table with the wrong pitch."""
+    from sdformerflow_amd import hip
+    from sdformerflow_amd.harness import prepare_chunk
+    model, _, _ = build("lif", 96, 128)
+    x = prepare_chunk(synth_voxel(1, 10, 96, 128, seed=3)).to("cuda:0")
+    with pytest.raises(hip.SdfError, match="smaller than the window"):
+        model.to("cuda:0")(x)
