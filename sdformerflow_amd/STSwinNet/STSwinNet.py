@@ -90,6 +90,12 @@ class UpsampleConvLayer(ConvLayer):
         return super().forward(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False))
 
 
+def _fit_to(x1, ref):
+    """x1 (B, C, h, w) centre-padded (cropped where negative) to ref's spatial size: the ZeroPad2d of `skip_concat`."""
+    dY, dX = ref.shape[-2] - x1.shape[-2], ref.shape[-1] - x1.shape[-1]
+    return F.pad(x1, (dX // 2, dX - dX // 2, dY // 2, dY - dY // 2)) if dY or dX else x1
+
+
 class STT_encoder(nn.Module):
     """Swin backbone + one 1x1 projection per (stage, time block) whose outputs are concatenated along channels."""
 
@@ -148,7 +154,10 @@ class STT_MultiResUNet(nn.Module):
         preds = []
         for i, (dec, pred) in enumerate(zip(self.decoders, self.preds)):
             # the reference concatenates [previous prediction, features, skip] (models/STSwinNet/STSwinNet.py:259-283)
-            parts = [y, blocks[self.num_encoders - 1 - i]] + ([preds[-1]] if i > 0 else [])
+            # with `skip_concat` (models/model_util.py:14-19): what is concatenated in front of the skip is centre-padded - cropped
+            # where the difference is negative - to the skip's size (odd feature sizes)
+            skip = blocks[self.num_encoders - 1 - i]
+            parts = [_fit_to(y, skip), skip] + ([_fit_to(preds[-1], skip)] if i > 0 else [])
             y = dec.forward_parts(parts, [2, 0, 1] if i > 0 else [0, 1])
             preds.append(pred(y))
         return preds, None

@@ -309,6 +309,22 @@ def gold_ann_end_to_end():
             fh.write(f"{k} {'x'.join(map(str, v.shape))}\n")
 
 
+def gold_ann_odd_size():
+    """STTFlowNet at 150 x 200: stage sizes 38 x 50, 19 x 25, 10 x 13 - every decoder output is one larger than its skip, which
+    `skip_concat` (models/model_util.py:14-19) crops.  Flows subsampled 4 x (the finest prediction lives at 76 x 100 before upsampling)."""
+    from models.STSwinNet.STSwinNet import STTFlowNet
+    cfg = YAMLParser("/root/reference/configs/train_DSEC_supervised_STT_voxel.yml")
+    config = cfg.combine_entries(cfg.config)
+    config["swin_transformer"]["input_size"] = [150, 200]
+    model = STTFlowNet(config["model"].copy(), config["swin_transformer"].copy())
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()
+              if not k.endswith(("relative_position_index", "relative_coords_table"))}
+    model.load_state_dict(synth_state_dict(shapes), strict=False)
+    model.eval()
+    res = model(synth_voxel(1, 20, 150, 200, seed=9), None)
+    save("ann_odd_size", **{f"flow{i}": f[:, :, ::2, ::2].contiguous() for i, f in enumerate(res["flow"])})
+
+
 def gold_neuron_grads():
     """Gradients through the reference's own `Spiking_neuron` factory (Spiking_modules.py:26-99): autograd over the
     spikingjelly-stub LIFNode (torch backend) and the in-tree PSN, ATan surrogate, seeded x and upstream gradient."""
@@ -502,7 +518,7 @@ def gold_formats():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["neurons", "index_maps", "qk_attention", "sew_attention", "ann_attention",
-                             "ms_block", "end_to_end", "sew_end_to_end", "ann_end_to_end", "formats", "neuron_grads", "train_block", "train_step", "ms_block_config5"]
+                             "ms_block", "end_to_end", "sew_end_to_end", "ann_end_to_end", "ann_odd_size", "formats", "neuron_grads", "train_block", "train_step", "ms_block_config5"]
     for w in which:
         globals()["gold_" + w]()
 

@@ -202,3 +202,23 @@ def test_feature_map_smaller_than_the_window_is_refused_like_the_reference():
     net = net.cuda()
     with pytest.raises(RuntimeError, match="smaller than the window"):
         net(synth_voxel(1, 20, 96, 128, seed=5).cuda(), None)
+
+
+@pytest.mark.gpu
+def test_odd_feature_sizes_follow_skip_concat():
+    """150 x 200: the stage sizes are 38 x 50, 19 x 25, 10 x 13, so every decoder output is one larger than its skip and
+    `skip_concat` (models/model_util.py:14-19, used at models/STSwinNet/STSwinNet.py:277-279) crops it before the concatenation."""
+    from oracle import sdformer_oracle as O
+    net = build("STTFlowNet", (150, 200)).eval()
+    sd = load_synth(net)
+    vox = synth_voxel(1, 20, 150, 200, seed=9)
+    cfg = {"num_bins": 20, "patch_size": (10, 4, 4), "window_size": (2, 9, 9), "depths": [2, 2, 6], "num_heads": [3, 6, 12]}
+    with torch.no_grad():
+        ref = O.forward_sttflownet(vox, sd, cfg)
+    net = net.cuda()
+    net.norm_input = False
+    got = net(vox.cuda(), None)["flow"]
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert a.shape == b.shape
+        d = (a.cpu() - b).abs().max().item()
+        assert d <= 1e-3 * b.abs().mean().item(), (i, d)

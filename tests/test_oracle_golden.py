@@ -268,6 +268,27 @@ def test_ann_sttflownet_end_to_end_matches_reference():
         assert d.max() <= 1e-3 * np.abs(ref).mean(), (i, d.max(), np.abs(ref).mean())      # north-star bound (ANN is not chaotic)
 
 
+def test_ann_sttflownet_at_odd_feature_sizes_matches_reference():
+    """150 x 200 (stage sizes 38 x 50, 19 x 25, 10 x 13): the decoders' `skip_concat` crops the upsampled features to the skip's
+    size (models/model_util.py:14-19); fixture from the real reference (make_golden.py `ann_odd_size`)."""
+    g = gold("ann_odd_size")
+    shapes = {}
+    with open(os.path.join(G, "state_schema_sttflownet.txt")) as f:
+        for line in f:
+            name, _, shp = line.strip().partition(" ")
+            shapes[name] = tuple(int(v) for v in shp.split("x")) if shp else ()
+    sd = synth_state_dict({k: v for k, v in shapes.items()
+                           if not k.endswith(("relative_position_index", "relative_coords_table", "num_batches_tracked"))})
+    cfg = {"num_bins": 20, "patch_size": (10, 4, 4), "window_size": (2, 9, 9), "depths": [2, 2, 6], "num_heads": [3, 6, 12]}
+    with torch.no_grad():
+        flows = O.forward_sttflownet(synth_voxel(1, 20, 150, 200, seed=9), sd, cfg)
+    for i, f in enumerate(flows):
+        ref = g[f"flow{i}"]
+        assert tuple(f.shape) == (1, 2, 150, 200)
+        d = np.abs(f[:, :, ::2, ::2].numpy() - ref)
+        assert d.max() <= 1e-3 * np.abs(ref).mean(), (i, d.max(), np.abs(ref).mean())
+
+
 # ------------------------------------------------------------------ neuron backward (training path, SURVEY.md 8f rank 3)
 NG = np.load(os.path.join(os.path.dirname(__file__), "golden", "neuron_grads.npz"))
 LIF_GRAD_CASES = [("soft_detach", None, True, 2.0), ("soft_nodetach", None, False, 2.0), ("hard_detach", 0.0, True, 2.0),
