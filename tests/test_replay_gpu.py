@@ -128,3 +128,9 @@ def test_sew_family_free_running_forward(kind):
     assert max(devs) <= FLOW_TOL, devs
     out = model(chunk.to(DEV))
     assert out["attn"] is None and all(torch.equal(a, b) for a, b in zip(out["flow"], flows))
+
+
+def test_odd_feature_sizes_three_encoders():
+    """150 x 200: stage maps 38 x 50, 19 x 25, 10 x 13 - the transposed-convolution decoders overshoot their skips by one pixel and
+    `skip_concat` (models/model_util.py:14-19) crops them; padded windows at every stage."""
+    check("lif", 1, (150, 200), 93, en4=False)
