@@ -96,6 +96,31 @@ def test_argument_errors_are_reported_before_any_launch():
     assert lib.sdf_qk_attn_workspace_bytes(C.c_int64(4), C.c_int(2), C.c_int(81), C.c_int(96)) == 62208 + 2 * 62208
     assert lib.sdf_window_slice_map(None, 1, 2, 9, 9, 2, 9, 9, 0, 0, 0, None, None) == E_NULL
     assert lib.sdf_window_slice_map(p, 1, 2, 9, 9, 0, 9, 9, 0, 0, 0, None, None) == E_SHAPE
+    # dense kernels of the ANN path (round 2)
+    assert lib.sdf_dense_conv3x3_fwd(None, None) == E_NULL and lib.sdf_dense_linear_fwd(None, None) == E_NULL
+    dc = hip.DenseConvDesc()
+    dc.x, dc.w, dc.out = 0x10000, 0x10000, 0x10000
+    dc.imgs, dc.H, dc.W, dc.cin_records, dc.N = 2, 16, 16, 6, 48
+    assert lib.sdf_dense_conv3x3_fwd(C.byref(dc), None) == E_SHAPE        # output columns come in blocks of 32
+    dc.N, dc.cin_records = 96, 2
+    assert lib.sdf_dense_conv3x3_fwd(C.byref(dc), None) == E_SHAPE        # instantiated for 1 and 6 input records
+    dc.cin_records, dc.x_records = 6, 3
+    assert lib.sdf_dense_conv3x3_fwd(C.byref(dc), None) == E_SHAPE        # a slice cannot be wider than the tensor it is cut from
+    dc.x_records, dc.imgs, dc.H, dc.W = 0, 64, 288, 384
+    assert lib.sdf_dense_conv3x3_fwd(C.byref(dc), None) == E_SHAPE        # 31-bit offsets
+    dc.imgs, dc.x = 2, 0x10004
+    assert lib.sdf_dense_conv3x3_fwd(C.byref(dc), None) == E_ALIGN
+    dl = hip.DenseLinearDesc()
+    dl.a, dl.w, dl.out, dl.M, dl.N, dl.K = 0x10000, 0x10000, 0x10000, 100, 64, 96
+    assert lib.sdf_dense_linear_fwd(C.byref(dl), None) == E_SHAPE         # N % 96
+    dl.N, dl.K = 96, 48
+    assert lib.sdf_dense_linear_fwd(C.byref(dl), None) == E_SHAPE         # K % 32
+    dl.K, dl.cv_C, dl.cv_H, dl.cv_W, dl.cv_stride, dl.cv_OH, dl.cv_OW = 9 * 32, 32, 8, 8, 4, 2, 3
+    assert lib.sdf_dense_linear_fwd(C.byref(dl), None) == E_SHAPE         # OW must be (W - 1) / stride + 1
+    assert lib.sdf_pack_planes(None, p, 1, 16, 4, 4, None) == E_NULL and lib.sdf_pack_planes(p, p, 1, 0, 4, 4, None) == E_SHAPE
+    assert lib.sdf_pack_planes_up2(p, p, 1, 16, 4, 4, C.c_int64(256), C.c_int64(16), C.c_int64(4), C.c_int64(1), 1, 1, None) == E_SHAPE   # records past the tensor
+    assert lib.sdf_layer_norm_fwd(p, p, p, p, C.c_int64(8), 98, C.c_float(1e-5), None) == E_SHAPE      # C % 4
+    assert lib.sdf_layer_norm_fwd(p, p, p, odd, C.c_int64(8), 96, C.c_float(1e-5), None) == E_ALIGN
 
 
 def test_product_never_imports_the_oracle():
