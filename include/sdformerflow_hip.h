@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SDF_VERSION 100
+#define SDF_VERSION 101
 
 enum { SDF_F32 = 0, SDF_U8 = 1 };
 enum { SDF_LIF = 0, SDF_PSN = 1, SDF_IF = 2 };
@@ -298,8 +298,10 @@ int sdf_qk_attn_fwd(const SdfQkAttnDesc* d, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * MS MLP, whole (row a7):  x += BN2( SN2( BN1( SN1(x) W1^T ) ) W2^T )  in place on a (B, D, HW, C) fp32 buffer, neurons over
  * the true time axis D.  Replaces: MS_Spiking_Mlp.forward + the block's second shortcut add (reference
- * Spiking_swin_transformer3D.py:164-181, :845).  Three launches; the hidden (.., 4C) tensor only exists as 1-byte spikes.
- * D in {2,4,5,10,20} (the fused-neuron epilogue); workspace: sdf_ms_mlp_workspace_bytes(B*D*HW, C, Ch), 256-byte aligned. */
+ * Spiking_swin_transformer3D.py:164-181, :845).  ONE launch (csrc/ms_mlp_fused.hip: SN1, fc1, BN1, SN2, fc2, BN2 and the
+ * shortcut on a tile of positions x all D steps; neither spike tensor leaves the compute unit) for C in {96, 192},
+ * D in {5,10,20}, Ch % 96 == 0; otherwise three launches with the hidden (.., 4C) tensor as 1-byte spikes in `workspace`
+ * (D in {2,4,5,10,20}, the fused-neuron GEMM epilogue).  workspace: sdf_ms_mlp_workspace_bytes(B*D*HW, C, Ch), 256-byte aligned. */
 typedef struct SdfMsMlpDesc {
   float* x;
   int32_t B, D;
@@ -310,7 +312,14 @@ typedef struct SdfMsMlpDesc {
   SdfNeuronCfg sn1, sn2;
   void* workspace;      int64_t workspace_bytes;
   void* gemm_workspace; int64_t gemm_workspace_bytes;
+  int32_t flags;        /* SDF_MLP_* bits */
 } SdfMsMlpDesc;
+
+enum {
+  SDF_MLP_KEEP_SPIKES = 1,   /* leave SN1's and SN2's spikes in `workspace` (u8 [tokens][C], then [tokens][Ch] at the next 256-byte
+                                boundary): what the three-launch form always does; the one-launch form only on request */
+  SDF_MLP_THREE_LAUNCHES = 2 /* never take the one-launch kernel (A/B reference; same as SDF_MLP_FUSED=0 in the environment) */
+};
 
 int64_t sdf_ms_mlp_workspace_bytes(int64_t tokens, int C, int Ch);
 int sdf_ms_mlp_fwd(const SdfMsMlpDesc* d, void* stream);

@@ -9,7 +9,8 @@
 //                          term) and the q / k neurons fused -> token gate (group sums, sn2_q, AND) -> projection spike
 //                          GEMM reading through the head scramble, bias + BN + scatter + residual in its epilogue.
 // The intermediates (three u8 spike tensors) live in the caller's workspace; nothing is allocated here.
-#include "common.h"
+#include "spike_mm.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -141,6 +142,14 @@ extern "C" int sdf_ms_mlp_fwd(const SdfMsMlpDesc* d, void* stream) {
   const int64_t hw = d->HW;
   uint8_t* s1 = reinterpret_cast<uint8_t*>(d->workspace);
   uint8_t* s2 = s1 + (tokens * C + 255) / 256 * 256;
+  // one launch where the kernel has an instantiation (SDF_MLP_FUSED=0 / SDF_MLP_THREE_LAUNCHES: the A/B reference below)
+  {
+    const char* e = getenv("SDF_MLP_FUSED");
+    if (!(d->flags & SDF_MLP_THREE_LAUNCHES) && !(e && e[0] == '0') && sdfmm::ms_mlp_fused_supports(d)) {
+      const bool keep = (d->flags & SDF_MLP_KEEP_SPIKES) != 0;
+      return sdfmm::launch_ms_mlp_fused(d, keep ? s1 : nullptr, keep ? s2 : nullptr, sdf_stream(stream));
+    }
+  }
   // 1. sn1 over the D steps of every (b, hw, c)
   SdfNeuronDesc n = {};
   n.x = d->x; n.out = s1; n.T = D; n.out_dtype = SDF_U8;

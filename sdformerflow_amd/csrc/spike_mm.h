@@ -110,6 +110,9 @@ int launch_spike_mm_pp(const GemmParams& P, bool conv, hipStream_t s);
 // activations enter as halo tiles (no im2col); `supports` is false for shapes it has no instantiation for
 bool spike_conv_wres_supports(const GemmParams& P, bool any_size);
 int launch_spike_conv_wres(const GemmParams& P, hipStream_t s);
+// MS MLP as one launch (ms_mlp_fused.hip); keep_s1 / keep_s2: optional u8 copies of the SN1 / SN2 spikes (parity tape)
+bool ms_mlp_fused_supports(const SdfMsMlpDesc* d);
+int launch_ms_mlp_fused(const SdfMsMlpDesc* d, uint8_t* keep_s1, uint8_t* keep_s2, hipStream_t s);
 // split-K planning (fills ksplit / spc / partial from the descriptor's workspace) and the k-ordered second pass
 void plan_splitk(GemmParams& P, int kc);
 int launch_splitk_reduce(const GemmParams& P, hipStream_t s);

@@ -461,11 +461,15 @@ class MsMlpDesc(C.Structure):
                 ("fc2_planes", C.c_void_p), ("fc2_alpha", C.c_void_p), ("fc2_beta", C.c_void_p), ("fc2_acc_scale", C.c_float),
                 ("sn1", NeuronCfg), ("sn2", NeuronCfg),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-                ("gemm_workspace", C.c_void_p), ("gemm_workspace_bytes", C.c_int64)]
+                ("gemm_workspace", C.c_void_p), ("gemm_workspace_bytes", C.c_int64), ("flags", C.c_int32)]
 
 
-def ms_mlp(x, fc1, fc2, sn1, sn2, keep_ws=None):
-    """sdf_ms_mlp_fwd: x (B,D,H,W,C) fp32 channel-last += MLP(x) over the time axis D, in place."""
+MLP_KEEP_SPIKES, MLP_THREE_LAUNCHES = 1, 2
+
+
+def ms_mlp(x, fc1, fc2, sn1, sn2, keep_ws=None, three_launches=False):
+    """sdf_ms_mlp_fwd: x (B,D,H,W,C) fp32 channel-last += MLP(x) over the time axis D, in place.  `keep_ws` (a list) receives
+    the workspace with the SN1 / SN2 spikes (parity tape); `three_launches` selects the unfused A/B reference."""
     B, D, H, W, Cc = x.shape
     d = MsMlpDesc()
     d.x, d.B, d.D, d.HW, d.C, d.Ch, d.nsplit = _ptr(x, torch.float32), B, D, H * W, Cc, fc1.N, fc1.Wp.shape[0]
@@ -478,6 +482,7 @@ def ms_mlp(x, fc1, fc2, sn1, sn2, keep_ws=None):
     d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
     gws = workspace(x.device)
     d.gemm_workspace, d.gemm_workspace_bytes = gws.data_ptr(), gws.numel()
+    d.flags = (MLP_KEEP_SPIKES if keep_ws is not None else 0) | (MLP_THREE_LAUNCHES if three_launches else 0)
     _check(lib().sdf_ms_mlp_fwd(C.byref(d), _stream()), "sdf_ms_mlp_fwd")
     if keep_ws is not None:
         keep_ws.append(ws)

@@ -631,7 +631,7 @@ def test_spike_gemm_bn_plain_entry_point():
 
 @pytest.mark.parametrize("kind", ["lif", "psn"])
 def test_ms_mlp_single_call_equals_its_three_launches(kind):
-    """sdf_ms_mlp_fwd against the same three entry points driven from the host (bit-equal); parity of the MLP against the
+    """sdf_ms_mlp_fwd (three-launch form) against the same three entry points driven from the host (bit-equal); parity of the MLP against the
     oracle is the teacher-forced block test of tests/test_engine_gpu.py, which goes through this call."""
     from sdformerflow_amd.engine import _Block
     from sdformerflow_amd.STSwinNet_SNN import Spiking_swin_transformer3D as SW
@@ -650,7 +650,7 @@ def test_ms_mlp_single_call_equals_its_three_launches(kind):
     s2 = torch.empty((ntok, Ch), dtype=torch.uint8, device=DEV)
     hip.spike_gemm_sn(s1, blk.fc1.Wp, s2, Ch, Cc, D, B * hw, hw, D * hw, hw, blk.sn2, alpha=blk.fc1.alpha, beta=blk.fc1.beta)
     hip.spike_gemm(s2, blk.fc2.Wp, xa, ntok, Cc, Ch, alpha=blk.fc2.alpha, beta=blk.fc2.beta, resid=xa)
-    xb = hip.ms_mlp(x0.clone(), blk.fc1, blk.fc2, blk.sn1, blk.sn2)
+    xb = hip.ms_mlp(x0.clone(), blk.fc1, blk.fc2, blk.sn1, blk.sn2, three_launches=True)   # (the one-launch form: tests/test_ms_mlp_fused_gpu.py)
     torch.cuda.synchronize()
     assert torch.equal(xa, xb) and not torch.equal(xa, x0)
 

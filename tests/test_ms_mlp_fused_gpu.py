@@ -1,0 +1,114 @@
+"""GPU parity of the one-launch MS MLP (csrc/ms_mlp_fused.hip) through the C ABI `sdf_ms_mlp_fwd`.
+
+The MLP is x += BN2(SN2(BN1(SN1(x) W1^T)) W2^T) (reference Spiking_swin_transformer3D.py:164-181, :845).  Its three
+arithmetic steps are checked one by one, each on the kernel's OWN upstream spikes (teacher forcing, as tests/replay.py does
+for whole models), so that every statement is exact:
+  * SN1 spikes: bit-equal to the C oracle neuron on x;
+  * SN2 spikes: delta-consistent with the oracle neuron on the fp64 pre-activation BN1(s1 W1^T) - 0 decisions that the
+    reference's own threshold margin (16 ulp of max(rms, v_th)) does not explain;
+  * output: x + BN2(s2 W2^T) in fp64, to 1e-5 of the output range.
+And against the three-launch form of the same entry point (the A/B reference)."""
+import pytest
+import torch
+
+from oracle import neuron_ref as R
+from oracle import sdformer_oracle as O
+from sdformerflow_amd import hip
+from sdformerflow_amd.synthetic import synth_uniform as rnd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class _L:
+    def __init__(self, W, alpha, beta, ns):
+        self.N, self.K = W.shape
+        self.Wp = hip.split_weight(W.to(DEV).contiguous(), ns)
+        self.alpha, self.beta, self.bias = alpha.to(DEV).contiguous(), beta.to(DEV).contiguous(), None
+
+
+def _case(B, D, H, W, Cc, kind, ns, seed=0):
+    Ch = 4 * Cc
+    x0 = rnd((B, D, H, W, Cc), 900 + seed, -0.5, 1.0)
+    W1, W2 = rnd((Ch, Cc), 901 + seed, -0.3, 0.3), rnd((Cc, Ch), 902 + seed, -0.1, 0.1)
+    a1, b1 = rnd((Ch,), 903 + seed, 0.5, 1.5), rnd((Ch,), 904 + seed, -0.2, 0.2)
+    a2, b2 = rnd((Cc,), 905 + seed, 0.5, 1.5), rnd((Cc,), 906 + seed, -0.2, 0.2)
+    Wn = rnd((D, D), 907 + seed, -0.5, 0.5) + 0.5 * torch.eye(D)
+    bn = torch.full((D,), -0.1)
+    p = hip.NeuronParams(kind, 2.0, 0.1, None, Wn.to(DEV), bn.to(DEV))
+    return x0, W1, W2, a1, b1, a2, b2, Wn, bn, p, _L(W1, a1, b1, ns), _L(W2, a2, b2, ns)
+
+
+def _weff(Wp):
+    """The fp64 value of the weight the planes carry (what the kernel multiplies by, exactly)."""
+    if Wp.shape[0] == 2:
+        return Wp.cpu().view(torch.float16).double().sum(0) * Wp.sdf_acc_scale
+    return Wp.cpu().view(torch.bfloat16).double().sum(0)
+
+
+def _spikes_of(ws, ntok, Cc, Ch):
+    s1 = ws[:ntok * Cc].view(ntok, Cc)
+    s2 = ws[(ntok * Cc + 255) // 256 * 256:][:ntok * Ch].view(ntok, Ch)
+    return s1, s2
+
+
+@pytest.mark.parametrize("ns", [2, 3, 1])
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+@pytest.mark.parametrize("B,D,H,W,Cc", [(2, 10, 9, 12, 96), (1, 10, 7, 5, 192), (1, 20, 5, 9, 96), (3, 5, 6, 7, 96),
+                                        (1, 20, 3, 7, 192)])
+def test_ms_mlp_one_launch_steps_against_the_oracle(B, D, H, W, Cc, kind, ns):
+    if ns != 2 and (kind == "psn" or D != 10):
+        pytest.skip("plane formats 1 / 3 are covered on the shipped T = 10 LIF shapes")
+    x0, W1, W2, a1, b1, a2, b2, Wn, bn, p, fc1, fc2 = _case(B, D, H, W, Cc, kind, ns)
+    Ch, ntok = 4 * Cc, B * D * H * W
+    keep = []
+    xg = hip.ms_mlp(x0.to(DEV).clone(), fc1, fc2, p, p, keep_ws=keep)
+    torch.cuda.synchronize()
+    s1g, s2g = (t.cpu() for t in _spikes_of(keep[0], ntok, Cc, Ch))
+    # (a) SN1 over D: bit-exact
+    xt = x0.permute(1, 0, 2, 3, 4).contiguous()                                               # (D,B,H,W,C)
+    s1r = R.neuron_ref(xt, kind, 2.0, 0.1, None, psn_w=Wn, psn_b=bn).permute(1, 0, 2, 3, 4).reshape(ntok, Cc)
+    assert torch.equal(s1g.float(), s1r), "SN1 spikes differ from the oracle"
+    assert 0.03 < s1r.mean() < 0.97
+    # (b) SN2 on the kernel's own s1: every decision explained by the reference's margin
+    W1e, W2e = _weff(fc1.Wp), _weff(fc2.Wp)                                                     # 2 planes: 22 bits; 1 plane: bf16(W); 3: W
+    assert (W1e - W1.double()).abs().max() <= {1: 2.0 ** -8, 2: 2.0 ** -22, 3: 0.0}[ns] * 0.3
+    h = (s1g.double() @ W1e.t()) * a1.double() + b1.double()                                   # (ntok, Ch) rows (b,t,hw)
+    ht = h.view(B, D, H * W, Ch).permute(1, 0, 2, 3).float().contiguous()
+    got = s2g.view(B, D, H * W, Ch).permute(1, 0, 2, 3).float().contiguous()
+    ncfg = O.NeuronCfg(kind, 0.1, None, 2.0, D)
+    delta = 16 * 2.0 ** -23 * max(float(ht.pow(2).mean().sqrt()), 0.1)                         # 16 ulp, as tests/replay.py
+    rep = O.delta_consistent(ht, got, ncfg, {"w.weight": Wn, "w.bias": bn.view(-1, 1)}, "w.", delta)
+    assert rep["unexplained"] == 0, rep
+    assert rep["flips"] <= 2e-4 * got.numel(), rep
+    assert 0.03 < got.mean() < 0.97
+    # (c) fc2 + BN2 + shortcut on the kernel's own s2
+    ref = x0.reshape(ntok, Cc).double() + (s2g.double() @ W2e.t()) * a2.double() + b2.double()
+    err = (xg.cpu().reshape(ntok, Cc).double() - ref).abs().max().item()
+    assert err <= 1e-5 * ref.abs().max().item(), err
+
+
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+@pytest.mark.parametrize("B,D,H,W,Cc", [(2, 10, 9, 12, 96), (1, 10, 18, 24, 192), (1, 20, 6, 8, 96)])
+def test_ms_mlp_one_launch_against_three_launches(B, D, H, W, Cc, kind):
+    """Same entry point, both forms: SN1 spikes bit-equal; SN2 spikes may differ where the two accumulation orders round a
+    pre-activation to different sides of the threshold (rate bound), the outputs agree wherever the hidden spikes do."""
+    x0, W1, W2, a1, b1, a2, b2, Wn, bn, p, fc1, fc2 = _case(B, D, H, W, Cc, kind, 2, seed=50)
+    Ch, ntok = 4 * Cc, B * D * H * W
+    ka, kb = [], []
+    xa = hip.ms_mlp(x0.to(DEV).clone(), fc1, fc2, p, p, keep_ws=ka)
+    xb = hip.ms_mlp(x0.to(DEV).clone(), fc1, fc2, p, p, keep_ws=kb, three_launches=True)
+    torch.cuda.synchronize()
+    s1a, s2a = _spikes_of(ka[0], ntok, Cc, Ch)
+    s1b, s2b = _spikes_of(kb[0], ntok, Cc, Ch)
+    assert torch.equal(s1a, s1b)
+    diff = (s2a != s2b)
+    assert diff.float().mean().item() <= 1e-4
+    same_rows = ~diff.any(dim=1)
+    assert same_rows.float().mean().item() > 0.9
+    d = (xa.view(ntok, Cc) - xb.view(ntok, Cc)).abs()
+    assert d[same_rows].max().item() <= 2e-5 * xb.abs().max().item()
+    # without the tape the one-launch form writes nothing but x and is bit-equal to itself with the tape
+    xc = hip.ms_mlp(x0.to(DEV).clone(), fc1, fc2, p, p)
+    torch.cuda.synchronize()
+    assert torch.equal(xa, xc) and not torch.equal(xa, x0.to(DEV))
