@@ -421,6 +421,37 @@ int sdf_flow_out_fwd(const float* pred, float* out, int B, int D, int h, int w, 
                      float scale_y, float scale_x, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Flow-prediction head of one U-Net level, one launch (csrc/pred_head.hip):
+ *   p[t] = conv1x1(SN_pred(z)[t]) + bias (2 outputs; MS_SpikingPredLayer, reference Spiking_modules.py:605-640),
+ *   flow = nearest upsampling by whole factors (H / h, W / w) of sum_t p[t] (reference Spiking_STSwinNet.py:289-303), and - the
+ *   next decoder level reads cat(p, z, skip) behind its own neuron (Spiking_STSwinNet.py:168-172, Spiking_modules.py:467-474) -
+ *   the spike bytes of SN_next(z) / SN_next(p) written into their channel slices of that level's NHWC u8 spike image.
+ * Replaces sdf_neuron_fwd + sdf_spike_gemm_fwd (2 columns padded to 32) + sdf_flow_out_fwd of this level and two
+ * sdf_neuron_fwd launches (+ the zero fill of the image's padding channels) of the next one; z is read once.
+ *   z (B, D, h*w, Cin) fp32 channel-last; Cin in {96, 192, 384}; D in {5, 10, 20} (PSN: D <= 10); wgt (2, Cin) fp32; bias (2) or NULL
+ *   pred (B, D, h*w, 4) fp32 = (p0, p1, 0, 0) or NULL;  flow (B, 2, H, W) fp32 or NULL (H % h == 0, W % w == 0)
+ *   next_spikes (B, D, h*w, next_ld) u8 or NULL: bytes [next_z_off, +Cin) = SN_next(z), [next_pred_off, +4) = SN_next(p) (channels
+ *     2, 3 zero), [next_zero_off, +next_zero_len) zeroed (the image's padding channels); all offsets / lengths multiples of 4
+ *   keep_spikes (B, D, h*w, Cin) u8 or NULL: SN_pred(z) (parity tape).  Anything else returns SDF_E_SHAPE: the caller keeps the
+ *   three-launch form. */
+typedef struct SdfPredHeadDesc {
+  const float* z;
+  int32_t B, D, h, w, Cin;
+  SdfNeuronCfg sn_pred;
+  const float* wgt;                 /* (2, Cin) fp32 */
+  const float* bias;
+  float* pred;
+  float* flow;
+  int32_t H, W;
+  uint8_t* next_spikes;
+  int32_t next_ld, next_z_off, next_pred_off, next_zero_off, next_zero_len;
+  SdfNeuronCfg sn_next;
+  uint8_t* keep_spikes;
+} SdfPredHeadDesc;
+
+int sdf_pred_head_fwd(const SdfPredHeadDesc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Eval BatchNorm affine (+ residual):  out = fmaf(x, alpha[c], beta[c]) (+ resid), c = (i/inner) % C.
  * Replaces: SpikingNormLayer after a convolution and the membrane (MS) shortcut add
  * (reference Spiking_modules.py:922-926, 816-818).  n % 4 == 0; inner % 4 == 0 or (inner == 1, C % 4 == 0).

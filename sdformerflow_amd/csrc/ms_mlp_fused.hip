@@ -83,40 +83,6 @@ __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
                                                    __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, b), c, 0, 0, 0);
 }
 
-// neuron over the T values a lane holds.  NK (compile time, both neurons of an MLP share it): 0 = the shipped LIF (soft reset,
-// tau a power of two: straight-line body), 1 = PSN (the k-ordered fmaf chain of neuron.hip), 2 = any other LIF / IF setting
-template <int NK, int T>
-__device__ __forceinline__ void neuron_T(const float (&xs)[T], float (&sp)[T], const SdfNeuronCfg& n, float inv_tau) {
-  if constexpr (NK == 1) {
-    // the row loop is kept rolled (one row of T coefficients in scalar registers at a time); decisions travel as a bit mask
-    uint32_t m = 0;
-#pragma unroll 1
-    for (int t = 0; t < T; ++t) {
-      const float* w = n.psn_w + t * T;
-      float hh = n.psn_b[t];
-#pragma unroll
-      for (int k = 0; k < T; ++k) hh = __builtin_fmaf(w[k], xs[k], hh);
-      m |= (hh >= 0.f ? 1u : 0u) << t;
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t) sp[t] = ((m >> t) & 1u) ? 1.f : 0.f;
-  } else if constexpr (NK == 0) {
-    // h = v + (x - v) / tau; s = (h - v_th >= 0); v = h - s * v_th: with s in {0, 1} the last line is h - v_th (the difference the
-    // comparison already holds) or h itself, bit for bit
-    float v = 0.f;
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const float hcur = v + (xs[t] - v) * inv_tau;
-      const float dth = hcur - n.v_th;
-      const bool fire = dth >= 0.f;
-      sp[t] = fire ? 1.f : 0.f;
-      v = fire ? dth : hcur;
-    }
-  } else {
-    lif_steps<T>(xs, sp, n.kind, n.soft_reset != 0, n.v_reset, n.v_th, n.tau, inv_tau);
-  }
-}
-
 template <int NSPLIT, int T, int C16, int CG, int NB1, int RG, int TEAMS>
 struct MlpGeo {
   static constexpr int C = 16 * C16, NB2 = C16 / CG, CH = 16 * NB1 * CG;
@@ -466,16 +432,6 @@ __global__ __launch_bounds__(64 * RG * CG * TEAMS, (MlpGeo<NSPLIT, T, C16, CG, N
 #endif
 }
 
-float inv_tau_of(const SdfNeuronCfg& n) {
-  int ex;
-  return (n.kind == SDF_LIF && frexpf(n.tau, &ex) == 0.5f) ? 1.0f / n.tau : 0.f;
-}
-
-int neuron_class(const SdfNeuronCfg& n) {
-  if (n.kind == SDF_PSN) return 1;
-  return (n.kind == SDF_LIF && n.soft_reset != 0 && inv_tau_of(n) != 0.f) ? 0 : 2;
-}
-
 template <int NSPLIT, int T, int C16, int CG, int NB1, int RG, int TEAMS>
 int launch_one(const MlpFusedParams& P, hipStream_t s) {
   using G = MlpGeo<NSPLIT, T, C16, CG, NB1, RG, TEAMS>;
@@ -534,12 +490,15 @@ bool ms_mlp_fused_supports(const SdfMsMlpDesc* d) {
   if (d->Ch % 192 || d->nsplit < 1 || d->nsplit > 3) return false;
   if (d->nsplit != 2 && d->D != 10) return false;
   if (neuron_class(d->sn1) != neuron_class(d->sn2)) return false;
-  if (neuron_class(d->sn1) == 1 && d->D > 10) return false;           // PSN over T = 20: 400 coefficients do not fit the scalar registers     // (every shipped configuration builds both from one neuron setting)
+  if (neuron_class(d->sn1) == 1 && d->D > 10) return false;           // PSN over T = 20: 400 coefficients do not fit the scalar registers
   for (const SdfNeuronCfg* n : {&d->sn1, &d->sn2}) {
     if (n->kind != SDF_LIF && n->kind != SDF_IF && n->kind != SDF_PSN) return false;
     if (n->kind == SDF_PSN && (!n->psn_w || !n->psn_b)) return false;
     if (n->kind == SDF_LIF && !(n->tau > 1.f)) return false;
   }
+  // C = 192 (stage 1): a work item streams 1.2 MB of weights for 8 positions; with few positions (batch 1 at 288 x 384: 1 728) the
+  // three-launch form is as fast (measured 65 us both), from a few thousand on the one-launch form wins (config 5: -30 %)
+  if (d->C == 192 && (int64_t)d->B * d->HW < 4096 && !getenv("SDF_MLP_FUSED_ANY")) return false;
   if (!sdf_aligned(d->x, 16) || !sdf_aligned(d->fc1_planes, 16) || !sdf_aligned(d->fc2_planes, 16)) return false;
   if (!d->fc1_alpha || !d->fc1_beta || !d->fc2_alpha || !d->fc2_beta) return false;
   if (!sdf_aligned(d->fc2_alpha, 16) || !sdf_aligned(d->fc2_beta, 16)) return false;

@@ -1,6 +1,7 @@
 // Shared definitions of the spike matrix-multiply kernels (spike_gemm.hip, spike_mm_ws.hip).
 #pragma once
 #include "common.h"
+#include <math.h>
 
 namespace sdfmm {
 
@@ -79,6 +80,50 @@ __device__ __forceinline__ void lif_steps(const float (&xs)[T], float (&sp)[T], 
     sp[t] = (hcur - v_th >= 0.f) ? 1.f : 0.f;
     v = soft ? (hcur - sp[t] * v_th) : ((1.f - sp[t]) * hcur + sp[t] * v_reset);
   }
+}
+
+// neuron over the T values a lane holds.  NK (compile time, both neurons of an MLP share it): 0 = the shipped LIF (soft reset,
+// tau a power of two: straight-line body), 1 = PSN (the k-ordered fmaf chain of neuron.hip), 2 = any other LIF / IF setting
+template <int NK, int T>
+__device__ __forceinline__ void neuron_T(const float (&xs)[T], float (&sp)[T], const SdfNeuronCfg& n, float inv_tau) {
+  if constexpr (NK == 1) {
+    // the row loop is kept rolled (one row of T coefficients in scalar registers at a time); decisions travel as a bit mask
+    uint32_t m = 0;
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+      const float* w = n.psn_w + t * T;
+      float hh = n.psn_b[t];
+#pragma unroll
+      for (int k = 0; k < T; ++k) hh = __builtin_fmaf(w[k], xs[k], hh);
+      m |= (hh >= 0.f ? 1u : 0u) << t;
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) sp[t] = ((m >> t) & 1u) ? 1.f : 0.f;
+  } else if constexpr (NK == 0) {
+    // h = v + (x - v) / tau; s = (h - v_th >= 0); v = h - s * v_th: with s in {0, 1} the last line is h - v_th (the difference the
+    // comparison already holds) or h itself, bit for bit
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const float hcur = v + (xs[t] - v) * inv_tau;
+      const float dth = hcur - n.v_th;
+      const bool fire = dth >= 0.f;
+      sp[t] = fire ? 1.f : 0.f;
+      v = fire ? dth : hcur;
+    }
+  } else {
+    lif_steps<T>(xs, sp, n.kind, n.soft_reset != 0, n.v_reset, n.v_th, n.tau, inv_tau);
+  }
+}
+
+// host side: 1 / tau where that is exact (tau a power of two; 0 = divide), and the compile-time class of a neuron setting
+static inline float inv_tau_of(const SdfNeuronCfg& n) {
+  int ex;
+  return (n.kind == SDF_LIF && frexpf(n.tau, &ex) == 0.5f) ? 1.0f / n.tau : 0.f;
+}
+static inline int neuron_class(const SdfNeuronCfg& n) {
+  if (n.kind == SDF_PSN) return 1;
+  return (n.kind == SDF_LIF && n.soft_reset != 0 && inv_tau_of(n) != 0.f) ? 0 : 2;
 }
 
 // 4x4 transpose inside every quad of lanes (two DPP butterflies): in: lane q holds v[j] = X[row j][col q];

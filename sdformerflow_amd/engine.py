@@ -214,7 +214,8 @@ class MSFlowEngine:
             wp[:w2.shape[0]] = w2
             bp = torch.zeros(32, dtype=torch.float32, device=dev)
             bp[:w2.shape[0]] = p.conv[0].bias.detach().float()
-            self.preds.append((hip.split_weight(wp, ns), bp, _np(p.sn, dev), w2.shape[0]))
+            self.preds.append((hip.split_weight(wp, ns), bp, _np(p.sn, dev), w2.shape[0], w2.to(dev).contiguous(),
+                               p.conv[0].bias.detach().float().to(dev).contiguous()))
 
     # ------------------------------------------------------------------ helpers
     def _slice_map(self, B, D, H, W, ws, ss):
@@ -447,34 +448,46 @@ class MSFlowEngine:
             self._deconv[key] = torch.cat([wdec[n:n + C1], wdec[n + C1:], wdec[:n], pad], 0).contiguous()
         return self._deconv[key]
 
-    def unet_tail(self, feats):
+    def _decoder_geometry(self, i, B, D, h, w, cin):
+        """(as_gemm, padded channel count of the NHWC spike image) of decoder level i on an (h, w) input with cin channels.
+        Small levels: ONE plain spike GEMM over the nine stacked tap matrices + a col2im pass fills the chip; the four parity-class
+        convolutions (no 9x intermediate) are kept where that intermediate would cost more than it saves."""
+        cout = self.decoders[i][0].shape[1]
+        as_gemm = B * D * h * w * 9 * cout * 4 <= 64 << 20
+        return as_gemm, (_pad32(cin) if as_gemm else _pad16(cin))
+
+    def unet_tail(self, feats, out_size=None):
         """res-blocks + decoders + per-scale predictions on channel-last (B,D,h,w,C) features
-        (reference Spiking_STSwinNet.py:161-182)."""
+        (reference Spiking_STSwinNet.py:161-182).  Returns the per-scale predictions (B,D,h',w',2) fp32; with `out_size` = (H, W)
+        the flow maps (time sum + nearest upsampling, reference :289-303) of the levels whose prediction head ran as one launch
+        are left in `self._flows` (None where the three-launch form ran: forward() calls sdf_flow_out_fwd for those)."""
         y = feats[-1]
         for rb in self.unet_res:
             y = self._resblock(y, rb)
         preds, E = [], len(feats)
+        self._flows = [None] * E
+        carried = None          # this level's spike image with the [y | prediction] slices already written by the previous level's head
         for i in range(E):
             skip = feats[E - 1 - i]
             B, D, h, w, _ = skip.shape
-            parts = ([preds[-1]] if i > 0 else []) + [y, skip]          # skip_concat(pred, skip_concat(y, skip)) on channels (:168-172)
+            # skip_concat(pred, skip_concat(y, skip)) on channels (:168-172); the prediction has y's size (both come from z)
             wdec, bn, sn = self.decoders[i]
             cout = wdec.shape[1]
-            # small levels: ONE plain spike GEMM over the nine stacked tap matrices + a col2im pass fills the chip; the four
-            # parity-class convolutions (no 9x intermediate) are kept where that intermediate would cost more than it saves
-            as_gemm = B * D * h * w * 9 * cout * 4 <= 64 << 20
-            same = all(p.shape[2:4] == (h, w) for p in parts)
+            same = tuple(y.shape[2:4]) == (h, w)
             if same:
                 # no concatenation: the decoder's neuron runs on each source and writes its spikes straight into that source's
                 # channel slice of the NHWC spike image (physical channel order [y | skip | prediction padded to 4]; the
                 # transposed-convolution weight rows are permuted to match once, at pack time)
                 C1, C2 = y.shape[-1], skip.shape[-1]
-                srcs = [(y, C1, C1), (skip, C2, C2)] + ([(preds[-1], 4, 32)] if i > 0 else [])     # (tensor, channels taken, pitch)
                 cin = C1 + C2 + (4 if i > 0 else 0)
-                cp = _pad32(cin) if as_gemm else _pad16(cin)
-                s = (torch.zeros if cp != cin else torch.empty)((B, D, h, w, cp), dtype=torch.uint8, device=y.device)
-                hw, c0 = h * w, 0
-                for src, take, pitch in srcs:
+                as_gemm, cp = self._decoder_geometry(i, B, D, h, w, cin)
+                if carried is not None:
+                    s, srcs, c0 = carried, [(skip, C2, C2)], C1          # [y | . | prediction | zeros] came from the level above
+                else:
+                    s = (torch.zeros if cp != cin else torch.empty)((B, D, h, w, cp), dtype=torch.uint8, device=y.device)
+                    srcs, c0 = [(y, C1, C1), (skip, C2, C2)] + ([(preds[-1], 4, preds[-1].shape[-1])] if i > 0 else []), 0
+                hw = h * w
+                for src, take, pitch in srcs:                             # (tensor, channels taken, pitch)
                     for b in range(B):
                         hip.neuron_fwd(src[b], s[b].view(-1)[c0:], D, hw, take, pitch, hw * pitch, cp, hw * cp, sn)
                     c0 += take
@@ -488,7 +501,7 @@ class MSFlowEngine:
                 parts = [F.pad(p, (0, 0, (w - p.shape[3]) // 2, w - p.shape[3] - (w - p.shape[3]) // 2,
                                    (h - p.shape[2]) // 2, h - p.shape[2] - (h - p.shape[2]) // 2)) for p in parts]
                 cin = sum(p.shape[-1] for p in parts)
-                cp = _pad32(cin) if as_gemm else _pad16(cin)
+                as_gemm, cp = self._decoder_geometry(i, B, D, h, w, cin)
                 cat = torch.zeros((B, D, h, w, cp), dtype=torch.float32, device=y.device) if cp != cin else None
                 if cat is None:
                     cat = torch.cat(parts, dim=-1)
@@ -497,6 +510,7 @@ class MSFlowEngine:
                 s = self._neuron_bd(cat, sn)                              # MS decoder: SN -> ConvT -> BN
                 wkey = "ref"
                 self._rec(f"sttmultires_unet.decoders.{i}.sn.spiking_neuron.", s[..., :cin], "BDHWC->TBCHW")
+            carried = None
             wuse = self._decoder_weight(i, wkey, y.shape[-1], skip.shape[-1])
             z = torch.empty((B, D, 2 * h, 2 * w, cout), dtype=torch.float32, device=y.device)
             if as_gemm:
@@ -517,14 +531,37 @@ class MSFlowEngine:
                     hip.spike_conv2d(s.view(imgs, h, w, cp)[i0:i0 + n], cls["Wp"], n, h, w, cp, h, w, cls["KH"], cls["KW"], 1,
                                      cls["dy"], cls["dx"], out=z.view(imgs, 4 * h * w, cout)[i0:i0 + n], alpha=bn[0], beta=bn[1],
                                      out_rowmap=cls["rowmap"][:n * h * w])
-            pw, pb, psn, nout = self.preds[i]
-            sp = self._neuron_bd(z, psn)                                  # MS pred: SN -> conv1x1 (+bias), 2 outputs
-            self._rec(f"sttmultires_unet.preds.{i}.sn.spiking_neuron.", sp, "BDHWC->TBCHW")
-            po = torch.empty((B * D * 4 * h * w, 32), dtype=torch.float32, device=y.device)
-            hip.spike_gemm(sp, pw, po, po.shape[0], 32, cout, bias=pb)
-            preds.append(po.view(B, D, 2 * h, 2 * w, 32))                 # columns nout.. are exactly zero (zero weight rows, zero bias)
+            pw, pb, psn, nout, w2, b2 = self.preds[i]
+            H2, W2 = 2 * h, 2 * w
+            nxt_skip = feats[E - 2 - i] if i + 1 < E else None
+            fs = out_size if out_size is not None and out_size[0] % H2 == 0 and out_size[1] % W2 == 0 else None
+            if nout == 2 and hip.pred_head_supported(D, cout, fs[0] if fs else H2, fs[1] if fs else W2, H2, W2, psn,
+                                                      self.decoders[i + 1][2] if nxt_skip is not None else None) \
+                    and B * D * H2 * W2 * max(cout, 16) * 4 < 1 << 40:
+                # MS pred: SN -> conv1x1 (+bias), 2 outputs, its time sum + upsampling, and the next level's [y | prediction]
+                # spikes - one launch, z read once (csrc/pred_head.hip)
+                nxt = None
+                if nxt_skip is not None and tuple(nxt_skip.shape[2:4]) == (H2, W2):
+                    C1n, C2n = cout, nxt_skip.shape[-1]
+                    cin_n = C1n + C2n + 4
+                    _, cp_n = self._decoder_geometry(i + 1, B, D, H2, W2, cin_n)
+                    carried = torch.empty((B, D, H2, W2, cp_n), dtype=torch.uint8, device=y.device)
+                    nxt = (carried, self.decoders[i + 1][2], 0, C1n + C2n, (cin_n, cp_n - cin_n))
+                pred, flow, sp = hip.pred_head(z, w2, b2, psn, fs[0] if fs else None, fs[1] if fs else None,
+                                               want_pred=self.tape is not None or fs is None or (i + 1 < E and nxt is None),
+                                               nxt=nxt, keep=self.tape is not None)
+                if sp is not None:
+                    self._rec(f"sttmultires_unet.preds.{i}.sn.spiking_neuron.", sp, "BDHWC->TBCHW")
+                self._flows[i] = flow
+                preds.append(pred)
+            else:
+                sp = self._neuron_bd(z, psn)                              # MS pred: SN -> conv1x1 (+bias), 2 outputs
+                self._rec(f"sttmultires_unet.preds.{i}.sn.spiking_neuron.", sp, "BDHWC->TBCHW")
+                po = torch.empty((B * D * 4 * h * w, 32), dtype=torch.float32, device=y.device)
+                hip.spike_gemm(sp, pw, po, po.shape[0], 32, cout, bias=pb)
+                preds.append(po.view(B, D, 2 * h, 2 * w, 32))             # columns nout.. are exactly zero (zero weight rows, zero bias)
             y = z
-        return [p[..., :self.preds[0][3]] for p in preds]
+        return [None if p is None else p[..., :self.preds[0][3]] for p in preds]
 
     def forward(self, x):
         """(B,bins,2,H,W) fp32 on the GPU -> list of E flow maps (B,2,H,W) (reference :278-305)."""
@@ -532,6 +569,6 @@ class MSFlowEngine:
             raise hip.SdfError("input must be a GPU tensor (no CPU fallback)")
         x = x.float().contiguous()
         H, W = x.shape[-2:]
-        preds = self.unet_tail(self.encoder(x))
-        # sum over time + nearest upsampling to the input size, one small kernel per scale
-        return [hip.flow_out(p, H, W, H / p.shape[2], W / p.shape[3]) for p in preds]
+        preds = self.unet_tail(self.encoder(x), out_size=(H, W))
+        # sum over time + nearest upsampling to the input size: done by the prediction head's launch, else one small kernel per scale
+        return [f if f is not None else hip.flow_out(p, H, W, H / p.shape[2], W / p.shape[3]) for p, f in zip(preds, self._flows)]

@@ -163,8 +163,9 @@ class SEWFlowEngine(MSFlowEngine):
         self._rec(rb.name + "sn2.spiking_neuron.", s2.to(torch.uint8), "BDHWC->TBCHW")
         return s2 + x
 
-    def unet_tail(self, feats):
+    def unet_tail(self, feats, out_size=None):
         """SEW res-blocks + decoders (ConvT -> BN -> SN) + plain 1x1 predictions (reference Spiking_STSwinNet.py:161-182)."""
+        self._flows = [None] * len(feats)                                          # (flow read-out: sdf_flow_out_fwd per scale in forward())
         y = feats[-1]
         for rb in self.unet_res:
             y = self._sew_resblock(y, rb)

@@ -24,7 +24,7 @@ EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_s
            "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd", "sdf_head_conv_sn_fwd",
            "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes",
            "sdf_window_slice_map", "sdf_qk_attn_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
-           "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
+           "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_pred_head_fwd", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
            "sdf_rows_gather_fwd", "sdf_rows_scatter_fwd",
            "sdf_split_weight_i8x3", "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd",
            "sdf_dense_conv3x3_fwd", "sdf_pack_planes", "sdf_unpack_planes", "sdf_pack_planes_up2", "sdf_dense_linear_fwd", "sdf_layer_norm_fwd")
@@ -894,6 +894,48 @@ def flow_out(pred, H, W, scale_y, scale_x):
                                   C.c_int(w), C.c_int64(pred.stride(3)), C.c_int(Cc), C.c_int(H), C.c_int(W), C.c_float(scale_y),
                                   C.c_float(scale_x), _stream()), "sdf_flow_out_fwd")
     return out
+
+
+class PredHeadDesc(C.Structure):
+    _fields_ = [("z", C.c_void_p), ("B", C.c_int32), ("D", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("Cin", C.c_int32),
+                ("sn_pred", NeuronCfg), ("wgt", C.c_void_p), ("bias", C.c_void_p), ("pred", C.c_void_p), ("flow", C.c_void_p),
+                ("H", C.c_int32), ("W", C.c_int32), ("next_spikes", C.c_void_p), ("next_ld", C.c_int32), ("next_z_off", C.c_int32),
+                ("next_pred_off", C.c_int32), ("next_zero_off", C.c_int32), ("next_zero_len", C.c_int32), ("sn_next", NeuronCfg),
+                ("keep_spikes", C.c_void_p)]
+
+
+def pred_head_supported(D, Cin, H, W, h, w, sn, sn_next=None):
+    """Mirror of sdf_pred_head_fwd's shape rules (csrc/pred_head.hip): the caller keeps the three-launch form otherwise."""
+    if Cin not in (96, 192, 384) or D not in (5, 10, 20) or H % h or W % w:
+        return False
+    if sn.kind == "psn" and D > 10:
+        return False
+    return sn_next is None or sn_next.kind == sn.kind or {sn.kind, sn_next.kind} <= {"lif", "if"}
+
+
+def pred_head(z, wgt, bias, sn, H, W, want_pred=True, nxt=None, keep=False):
+    """sdf_pred_head_fwd: z (B,D,h,w,Cin) fp32 channel-last -> (pred (B,D,h,w,4) fp32 or None, flow (B,2,H,W) fp32, spikes of
+    SN_pred(z) (B,D,h,w,Cin) u8 if `keep`).  `nxt` = (spike image (B,D,h,w,ld) u8 of the next decoder level, its neuron,
+    offset of z's slice, offset of the prediction's 4-wide slice, (offset, length) of the padding channels to zero)."""
+    B, D, h, w, Cin = z.shape
+    d = PredHeadDesc()
+    d.z, d.B, d.D, d.h, d.w, d.Cin = _ptr(z, torch.float32), B, D, h, w, Cin
+    _ncfg(d.sn_pred, sn)
+    d.wgt, d.bias = _ptr(wgt, torch.float32), _ptr(bias, torch.float32)
+    pred = torch.empty((B, D, h, w, 4), dtype=torch.float32, device=z.device) if want_pred else None
+    flow = torch.empty((B, 2, H, W), dtype=torch.float32, device=z.device) if H is not None else None
+    d.pred, d.flow, d.H, d.W = _ptr(pred), _ptr(flow), H or 0, W or 0
+    if nxt is not None:
+        img, sn_next, z_off, p_off, (zero_off, zero_len) = nxt
+        if img.dtype != torch.uint8 or not img.is_contiguous() or tuple(img.shape[:4]) != (B, D, h, w):
+            raise SdfError("the next level's spike image must be a contiguous (B,D,h,w,ld) u8 tensor")
+        d.next_spikes, d.next_ld, d.next_z_off, d.next_pred_off = img.data_ptr(), img.shape[4], z_off, p_off
+        d.next_zero_off, d.next_zero_len = zero_off, zero_len
+        _ncfg(d.sn_next, sn_next)
+    sp = torch.empty((B, D, h, w, Cin), dtype=torch.uint8, device=z.device) if keep else None
+    d.keep_spikes = _ptr(sp)
+    _check(lib().sdf_pred_head_fwd(C.byref(d), _stream()), "sdf_pred_head_fwd")
+    return pred, flow, sp
 
 
 def deconv_col2im(Y, imgs, H, W, Cout, alpha=None, beta=None, out=None):

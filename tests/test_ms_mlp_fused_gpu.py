@@ -8,6 +8,8 @@ for whole models), so that every statement is exact:
     reference's own threshold margin (16 ulp of max(rms, v_th)) does not explain;
   * output: x + BN2(s2 W2^T) in fp64, to 1e-5 of the output range.
 And against the three-launch form of the same entry point (the A/B reference)."""
+import os
+
 import pytest
 import torch
 
@@ -18,6 +20,7 @@ from sdformerflow_amd.synthetic import synth_uniform as rnd
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+os.environ["SDF_MLP_FUSED_ANY"] = "1"          # small C = 192 cases take the one-launch kernel too (the dispatcher would not)
 
 
 class _L:

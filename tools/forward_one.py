@@ -7,6 +7,6 @@ dev = torch.device("cuda:0")
 model, sd = bench.build_model("lif", dev)
 x = bench.synthetic_chunk().to(dev)
 with torch.no_grad():
-    for _ in range(3):
+    for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
         model(x)
 torch.cuda.synchronize()
