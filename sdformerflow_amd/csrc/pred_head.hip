@@ -40,12 +40,22 @@ __global__ __launch_bounds__(256) void pred_head_kernel(PredParams P) {
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t][0] = acc[t][1] = 0.f;
   const bool to_next = d.next_spikes != nullptr, keep = d.keep_spikes != nullptr;
-#pragma unroll 1
+  // all three quads' loads are requested up front where the registers allow it (T <= 10: 30 x 16 bytes in flight per lane): the
+  // small levels are a few hundred waves, each of which would otherwise pay the memory latency three times in a row
+  constexpr bool AHEAD = T <= 10;
+  float4 vall[AHEAD ? 3 : 1][T];
+  if (AHEAD) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int t = 0; t < T; ++t) vall[AHEAD ? i : 0][t] = *reinterpret_cast<const float4*>(d.z + (row0 + t * HW) * Cin + 4 * (g + LPP * i));
+  }
+#pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int c = 4 * (g + LPP * i);
     float4 v[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) v[t] = *reinterpret_cast<const float4*>(d.z + (row0 + t * HW) * Cin + c);
+    for (int t = 0; t < T; ++t) v[t] = AHEAD ? vall[AHEAD ? i : 0][t] : *reinterpret_cast<const float4*>(d.z + (row0 + t * HW) * Cin + c);
     const float4 w0 = *reinterpret_cast<const float4*>(d.wgt + c), w1 = *reinterpret_cast<const float4*>(d.wgt + Cin + c);
     uint32_t pk[T], pk2[T];
 #pragma unroll

@@ -515,14 +515,25 @@ void plan_splitk(GemmParams& P, int kc) {
   P.spc = S;
   P.partial = nullptr;
   if (d.sn_T == 0 && P.ntiles <= 128 && S >= 4 && d.workspace) {
-    int ks = (256 + P.ntiles - 1) / P.ntiles;
-    if (const char* e = getenv("SDF_KSPLIT_MULT")) ks *= atoi(e) > 0 ? atoi(e) : 1;   // tuning override: oversubscribe the chip
-    if (ks > S / 2) ks = S / 2;
-    if (ks > 32) ks = 32;
-    while (ks > 1 && (int64_t)ks * d.M * d.N * 4 > d.workspace_bytes) --ks;
-    if (ks > 1 && sdf_aligned(d.workspace, 16)) {
-      P.ksplit = ks;
-      P.spc = (S + ks - 1) / ks;
+    // K chunks per tile: the count that minimises (rounds of the 256 workgroups) x (stages per item + a fixed per-item cost of
+    // about three stages: prologue, epilogue, partial store).  Round 2 took ceil(256 / tiles), which on 40 tiles is 7 chunks =
+    // 280 items = TWO rounds of 16 stages where 6 chunks = 240 items run ONE round of 18 (U-Net res-blocks: 49 -> 3x us).
+    int kmax = S / 2 < 32 ? S / 2 : 32;
+    if (const char* e = getenv("SDF_KSPLIT_MULT")) {                // tuning override: the old rule, oversubscribed
+      int ks = (256 + P.ntiles - 1) / P.ntiles * (atoi(e) > 0 ? atoi(e) : 1);
+      kmax = ks < kmax ? ks : kmax;
+    }
+    int best = 1;
+    int64_t best_cost = -1;
+    for (int ks = 1; ks <= kmax; ++ks) {
+      if ((int64_t)ks * d.M * d.N * 4 > d.workspace_bytes) break;
+      const int64_t rounds = ((int64_t)P.ntiles * ks + 255) / 256, spc = (S + ks - 1) / ks;
+      const int64_t cost = rounds * (spc + 3);
+      if (best_cost < 0 || cost < best_cost || (getenv("SDF_KSPLIT_MULT") && ks == kmax)) { best_cost = cost; best = ks; }
+    }
+    if (best > 1 && sdf_aligned(d.workspace, 16)) {
+      P.ksplit = best;
+      P.spc = (S + best - 1) / best;
       P.partial = reinterpret_cast<float*>(d.workspace);
     }
   }
