@@ -340,13 +340,44 @@ def free_port():
     return port
 
 
+def count_gpus_without_hip(topology="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs this process could use, counted WITHOUT any HIP / HSA call (the launcher must never initialise the GPU: it starts
+    the ranks as children): KFD topology nodes with SIMDs (CPU nodes have simd_count 0), narrowed by the *_VISIBLE_DEVICES
+    lists when they are plain index lists.  None when the topology cannot be read - then the ranks verify (init_ranks)."""
+    if not os.path.isdir("/sys/class/kfd") and topology.startswith("/sys/class/kfd"):
+        return 0                                                 # no amdgpu compute driver at all: no GPU to give a rank
+    try:
+        nodes = sorted(os.listdir(topology), key=lambda v: int(v) if v.isdigit() else 1 << 30)
+    except OSError:
+        return None
+    n = 0
+    for node in nodes:
+        try:
+            props = dict(ln.split(None, 1) for ln in open(os.path.join(topology, node, "properties")) if " " in ln.strip())
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    if n == 0:
+        return None                                              # unreadable / masked topology (containers): let the ranks verify
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [t for t in v.split(",") if t.strip() != ""]
+            if all(t.strip().isdigit() for t in ids):
+                n = min(n, len(ids))
+    return n
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process becomes the LAUNCHER.  It
     starts N ranks (one per GPU) through torch.distributed.run as a CHILD process and exits with its code; it never makes
-    a GPU call itself (device_count() does not initialise the GPU on this image) and never exec()s."""
+    a GPU call itself - the device count comes from the KFD topology in sysfs, not from HIP (torch's own device count falls
+    back to hipGetDeviceCount without amdsmi) - and never exec()s.  Every rank then proves its own GPU (init_ranks)."""
     import subprocess
-    if os.environ.get("SDF_DIST_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < n:
-        sys.stderr.write(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} GPU(s) visible; refusing to report a "
+    have = count_gpus_without_hip() if os.environ.get("SDF_DIST_BACKEND", "nccl") == "nccl" else None
+    if have is not None and have < n:
+        sys.stderr.write(f"bench.py: --gpus {n} but only {have} GPU(s) visible; refusing to report a "
                          f"{n}-GPU number from fewer devices\n")
         return 2
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))

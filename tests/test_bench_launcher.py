@@ -61,3 +61,22 @@ def test_launcher_refuses_more_ranks_than_gpus_on_the_real_backend():
         import pytest
         pytest.skip("needs a box with fewer than 2 GPUs")
     assert out.returncode == 2 and "refusing" in out.stderr
+
+
+def test_launcher_counts_gpus_from_the_kfd_topology_without_hip(tmp_path, monkeypatch):
+    """The device count the launcher refuses on comes from sysfs (KFD topology nodes with SIMDs), never from a HIP call."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for i, simd in enumerate([0, 0, 256, 256, 256]):                          # two CPU nodes, three GPUs
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {8 if simd == 0 else 0}\nsimd_count {simd}\ngfx_target_version {90500 if simd else 0}\n")
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert bench.count_gpus_without_hip(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.count_gpus_without_hip(str(tmp_path)) == 2
+    assert bench.count_gpus_without_hip(str(tmp_path / "missing")) is None        # unreadable: the ranks verify themselves
+    src = open(BENCH).read()
+    body = src[src.index("def launch_ranks"):src.index("def init_ranks")]
+    assert "torch.cuda" not in body                                               # the launcher makes no torch.cuda call at all
