@@ -518,6 +518,9 @@ typedef struct SdfDenseConvDesc {
   int32_t x_records;        /* records per image of the tensor x points into when x is a channel slice of a wider planes tensor
                              * (x = base + first_record * H * W * 64 bytes); 0 = cin_records.  Wide convolutions are chains of
                              * slices: out_k = conv(slice_k) + out_{k-1} through `resid`, the last link carries beta and relu */
+  float acc_scale;          /* the planes hold scale * w (scale a power of two chosen at pack time so that max|w| fills the fp16
+                             * range: small weights keep their 22 bits instead of sinking into fp16 subnormals); the accumulator is
+                             * multiplied by acc_scale = 1 / scale (folded into alpha: exact).  0 = 1 */
 } SdfDenseConvDesc;
 
 int sdf_dense_conv3x3_fwd(const SdfDenseConvDesc* d, void* stream);
@@ -534,7 +537,9 @@ int sdf_pack_planes_up2(const float* x, void* planes, int imgs, int C, int h, in
  * (`WindowAttention3D`: qkv, proj), :15-34 (`Mlp`: fc1 -> GELU -> fc2) and :272-313 (the block's two shortcut adds):
  *   out[m, n] = act(sum_k a[m, k] * w[n, k] + bias[n]) (+ resid[m, n]),  act = erf-form GELU when `gelu`, else identity.
  * a, resid, out: fp32 row-major (M, K) / (M, N); out may alias resid.  w: fp16 planes [2][N][K], w = plane0 + plane1
- * (hi = fp16(w), lo = fp16(w - hi)).  N % 96 == 0, K % 32 == 0, every tensor below 2^31 bytes. */
+ * (hi = fp16(s w), lo = fp16(s w - hi), s = 1 / acc_scale).  N % 96 == 0, K % 32 == 0, every tensor below 2^31 bytes.
+ * Activations are split into hi + lo fp16 in the loader: a value beyond the fp16 range (|x| > 65504) or a NaN becomes inf / NaN
+ * and the affected outputs come out NaN - it is never silently replaced by a finite number. */
 typedef struct SdfDenseLinearDesc {
   const float* a;
   const uint16_t* w;
@@ -549,6 +554,8 @@ typedef struct SdfDenseLinearDesc {
    * out_T > 1 writes image t * B + b of the input as image b * out_T + t of the output ((T,B) -> (B,T): the layout the swin
    * stages consume).  No residual in this form. */
   int32_t cv_H, cv_W, cv_C, cv_stride, cv_OH, cv_OW, out_T;
+  float acc_scale;          /* 1 / (power-of-two scale the weight planes were packed with); multiplies the accumulator before the
+                             * bias (exact).  0 = 1 */
 } SdfDenseLinearDesc;
 
 int sdf_dense_linear_fwd(const SdfDenseLinearDesc* d, void* stream);

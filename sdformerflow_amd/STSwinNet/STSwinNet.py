@@ -186,6 +186,16 @@ class STTFlowNet(nn.Module):
     def reset_states(self):
         pass
 
+    def invalidate_engine(self):
+        """Drop every packed-weight cache of the tree (fp16 planes of the Linear / convolution layers, position bias).  The caches
+        re-pack by themselves on (data_ptr, version) changes; writes through `p.data.copy_()` (EMA swaps) bump neither - call this."""
+        from .swin_transformer3D_v2 import SwinTransformerBlock3D
+        for m in self.modules():
+            for name in ("_pk_stamp", "_pkp_stamp", "_bs_stamp"):
+                if hasattr(m, name):
+                    setattr(m, name, None)
+        SwinTransformerBlock3D._maps.clear()
+
     @staticmethod
     def normalize(x):
         nz = x != 0

@@ -180,7 +180,8 @@ class SwinTransformerBlock3D(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
-    _maps = {}
+    _maps = {}             # (B, D, H, W, window, shift, device) -> device row map, shared by the blocks of a process; LRU-bounded
+    _MAPS_MAX = 32
 
     def forward(self, x, mask_matrix=None):
         """forward_part1 + forward_part2 (reference :272-313).  The reference pads, rolls and partitions LN(x) into windows and
@@ -210,9 +211,14 @@ class SwinTransformerBlock3D(nn.Module):
             x = x + a[:, :D, :H, :W]
         else:
             key = (B, D, H, W, ws, ss, str(x.device))
-            if key not in SwinTransformerBlock3D._maps:
-                SwinTransformerBlock3D._maps[key] = hip.window_slice_map(B, D, H, W, ws, ss, x.device)
-            row_map, B_ = SwinTransformerBlock3D._maps[key]
+            maps = SwinTransformerBlock3D._maps
+            if key not in maps:
+                while len(maps) >= SwinTransformerBlock3D._MAPS_MAX:      # bounded: evaluation sweeps over many input sizes
+                    maps.pop(next(iter(maps)))                          # must not grow GPU memory without limit (oldest first)
+                maps[key] = hip.window_slice_map(B, D, H, W, ws, ss, x.device)
+            else:
+                maps[key] = maps.pop(key)                               # most recently used last
+            row_map, B_ = maps[key]
             x = self.attn.forward_rows(y.reshape(-1, C), row_map, B_, None if mask is None else mask.contiguous(),
                                        x.reshape(-1, C)).view(B, D, H, W, C)
         return self.mlp(layer_norm(self.norm2, x), x)

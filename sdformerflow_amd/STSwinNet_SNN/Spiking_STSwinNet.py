@@ -173,7 +173,10 @@ class MS_SpikingformerFlowNet(nn.Module):
         sync, ~0.1 ms); the tensor list is cached and dropped whenever the tree is re-laid (`_apply`: .to() / .cuda())."""
         if self._stamp_tensors is None:
             self._stamp_tensors = list(self.parameters()) + list(self.buffers())
-        return (self.gemm_nsplit,) + tuple(t._version for t in self._stamp_tensors)
+        # (data_ptr, version): `p.data = other` moves the pointer, in-place updates bump the version.  What NO stamp can see: writes
+        # through `p.data.copy_()` / `p.data.mul_()` (EMA weight swaps) and a Parameter OBJECT replaced in a submodule - call
+        # invalidate_engine() after those (INTEGRATION.md).
+        return (self.gemm_nsplit,) + tuple((t.data_ptr(), t._version) for t in self._stamp_tensors)
 
     def invalidate_engine(self):
         """For callers that swap tensors out behind the module's back (`p.data = ...`), which no version counter sees."""

@@ -79,11 +79,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
 
 typedef __attribute__((ext_vector_type(2))) float f2;
 // four fp32 values -> one 16-byte piece {hi0..3, lo0..3}: hi = fp16(x), lo = fp16(x - hi), both round to nearest
-// (v_cvt_pk_f16_f32); values beyond the fp16 range saturate instead of becoming infinities
+// (v_cvt_pk_f16_f32); a value beyond the fp16 range becomes inf / NaN and stays visible downstream (no silent clamp)
 __device__ __forceinline__ u32x4 piece_from(float4 o) {
   f2 a, b;
-  a.x = __builtin_amdgcn_fmed3f(o.x, -65000.f, 65000.f); a.y = __builtin_amdgcn_fmed3f(o.y, -65000.f, 65000.f);
-  b.x = __builtin_amdgcn_fmed3f(o.z, -65000.f, 65000.f); b.y = __builtin_amdgcn_fmed3f(o.w, -65000.f, 65000.f);
+  a.x = o.x; a.y = o.y;
+  b.x = o.z; b.y = o.w;
   const h2 ha = __builtin_convertvector(a, h2), hb = __builtin_convertvector(b, h2);
   f2 ra, rb;
   ra.x = a.x - (float)ha.x; ra.y = a.y - (float)ha.y; rb.x = b.x - (float)hb.x; rb.y = b.y - (float)hb.y;
@@ -167,8 +167,9 @@ __global__ __launch_bounds__(64 * NW) void dense_conv_wres_kernel(DenseParams P)
     }
     if (tid < 2 * NB) {
       const int which = tid / NB, n = tid - which * NB;
-      float v = which == 0 ? 1.f : 0.f;
-      if (which == 0 && d.alpha) v = d.alpha[n0 + n];
+      const float asc = d.acc_scale != 0.f ? d.acc_scale : 1.f;          // 1 / weight scale, a power of two: folds into alpha exactly
+      float v = which == 0 ? asc : 0.f;
+      if (which == 0 && d.alpha) v = d.alpha[n0 + n] * asc;
       if (which == 1 && d.beta) v = d.beta[n0 + n];
       par_s[tid] = v;
     }

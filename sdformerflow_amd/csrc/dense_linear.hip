@@ -16,6 +16,7 @@
 // F.gelu) and the residual are applied on 16-byte pieces and stored as such.  LDS rows are 64 data bytes + 16 pad (slots 5
 // apart: conflict-free ds_read_b128 over 16 consecutive rows).
 #include "common.h"
+#include <math.h>
 
 namespace {
 
@@ -43,8 +44,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, uint32_t b
 // four fp32 values -> {hi0..3} and {lo0..3} as two 8-byte words
 __device__ __forceinline__ void split4(u32x4 v, uint2& hi, uint2& lo) {
   f2 a, b;
-  a.x = __builtin_amdgcn_fmed3f(__uint_as_float(v.x), -65000.f, 65000.f); a.y = __builtin_amdgcn_fmed3f(__uint_as_float(v.y), -65000.f, 65000.f);
-  b.x = __builtin_amdgcn_fmed3f(__uint_as_float(v.z), -65000.f, 65000.f); b.y = __builtin_amdgcn_fmed3f(__uint_as_float(v.w), -65000.f, 65000.f);
+  // no clamp: a value beyond the fp16 range converts to inf, its residual to -inf / NaN, and the products to NaN - an
+  // out-of-range or NaN activation shows in the output instead of being replaced by a finite number
+  a.x = __uint_as_float(v.x); a.y = __uint_as_float(v.y);
+  b.x = __uint_as_float(v.z); b.y = __uint_as_float(v.w);
   const h2 ha = __builtin_convertvector(a, h2), hb = __builtin_convertvector(b, h2);
   f2 ra, rb;
   ra.x = a.x - (float)ha.x; ra.y = a.y - (float)ha.y; rb.x = b.x - (float)hb.x; rb.y = b.y - (float)hb.y;
@@ -177,13 +180,14 @@ __global__ __launch_bounds__(256) void dense_linear_kernel(LinearParams P) {
   const __amdgpu_buffer_rsrc_t C_rs = rsrc(d.out, (uint32_t)M * (uint32_t)N * 4u);
   const __amdgpu_buffer_rsrc_t R_rs = rsrc(d.resid, (uint32_t)M * (uint32_t)N * 4u);
   const bool gelu = d.gelu != 0, has_res = d.resid != nullptr;
+  const float asc = d.acc_scale != 0.f ? d.acc_scale : 1.f;             // 1 / weight scale (a power of two)
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = n0 + 32 * j + 8 * q + 4 * lh;
       const uint32_t off = m_ok ? (uint32_t)(m * N + n) * 4u : INV;
-      float4 o = make_float4(acc[j][4 * q + 0], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+      float4 o = make_float4(acc[j][4 * q + 0] * asc, acc[j][4 * q + 1] * asc, acc[j][4 * q + 2] * asc, acc[j][4 * q + 3] * asc);
       if (d.bias) {
         const float4 b = *reinterpret_cast<const float4*>(d.bias + n);
         o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
@@ -205,6 +209,10 @@ __global__ __launch_bounds__(256) void dense_linear_kernel(LinearParams P) {
 extern "C" int sdf_dense_linear_fwd(const SdfDenseLinearDesc* d, void* stream) {
   if (!d || !d->a || !d->w || !d->out) return SDF_E_NULL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->N % BN || d->K % KC) return SDF_E_SHAPE;
+  if (d->acc_scale != 0.f) {
+    int ex;
+    if (!(d->acc_scale > 0.f) || frexpf(d->acc_scale, &ex) != 0.5f) return SDF_E_DTYPE;      // a power of two (exact rescaling)
+  }
   if (d->cv_C > 0) {
     if (d->cv_C % KC || d->K != 9 * d->cv_C || d->cv_H <= 0 || d->cv_W <= 0 || d->cv_stride <= 0 || d->cv_OH <= 0 || d->cv_OW <= 0) return SDF_E_SHAPE;
     if (d->cv_OH != (d->cv_H - 1) / d->cv_stride + 1 || d->cv_OW != (d->cv_W - 1) / d->cv_stride + 1) return SDF_E_SHAPE;   // 3x3, pad 1

@@ -520,11 +520,11 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 constexpr int KRS = 80;                // K row pitch in bytes: 32 fp16 + 16 pad
 
-// four fp32 -> four hi and four lo fp16 (round to nearest; saturating at the fp16 range)
+// four fp32 -> four hi and four lo fp16 (round to nearest; beyond the fp16 range: inf / NaN, visible in the output)
 __device__ __forceinline__ void split4_f16(float x, float y, float z, float w, uint2& hi, uint2& lo) {
   f32x2 a, b;
-  a.x = __builtin_amdgcn_fmed3f(x, -65000.f, 65000.f); a.y = __builtin_amdgcn_fmed3f(y, -65000.f, 65000.f);
-  b.x = __builtin_amdgcn_fmed3f(z, -65000.f, 65000.f); b.y = __builtin_amdgcn_fmed3f(w, -65000.f, 65000.f);
+  a.x = x; a.y = y;
+  b.x = z; b.y = w;
   const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
   f32x2 ra, rb;
   ra.x = a.x - (float)ha.x; ra.y = a.y - (float)ha.y; rb.x = b.x - (float)hb.x; rb.y = b.y - (float)hb.y;
@@ -745,13 +745,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
       }
       sum += __shfl_xor(sum, 16);
       sum += __shfl_xor(sum, 32);
-      const float inv = 1.f / sum;
+      // probabilities leave as 2^10 p: a p of 1/162 keeps its 22 bits in hi + lo instead of a subnormal lo half; the factor
+      // comes off the finished product (both exact: powers of two)
+      const float inv = (1.f / sum) * 1024.f;
 #pragma unroll
       for (int jt = 0; jt < NTC; ++jt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) st[jt][r] *= inv;
       }
     }
+    constexpr float OSC = MODE == SDF_ATTN_ANN ? 0.0009765625f : 1.f;
     // ---- O = P V: the lane's four probabilities of key tile jt are the A operand (keys 16 jt + 4 lg + 0..3) ----
     f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -785,8 +788,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
           const int t = i / d.N1, n1 = i - t * d.N1;
           off = (((int64_t)t * d.B_ + b) * d.N1 + n1) * C + g * HD;
         }
-        d.out[off + l15] = o0[r];
-        d.out[off + 16 + l15] = o1[r];
+        d.out[off + l15] = o0[r] * OSC;
+        d.out[off + 16 + l15] = o1[r] * OSC;
       }
     }
   }

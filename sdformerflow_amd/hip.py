@@ -86,14 +86,14 @@ class WinAttnDesc(C.Structure):
 class DenseConvDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("alpha", C.c_void_p), ("beta", C.c_void_p), ("resid", C.c_void_p),
                 ("out", C.c_void_p), ("imgs", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("cin_records", C.c_int32),
-                ("N", C.c_int32), ("relu", C.c_int32), ("out_f32", C.c_int32), ("x_records", C.c_int32)]
+                ("N", C.c_int32), ("relu", C.c_int32), ("out_f32", C.c_int32), ("x_records", C.c_int32), ("acc_scale", C.c_float)]
 
 
 class DenseLinearDesc(C.Structure):
     _fields_ = [("a", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("resid", C.c_void_p), ("out", C.c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("gelu", C.c_int32),
                 ("cv_H", C.c_int32), ("cv_W", C.c_int32), ("cv_C", C.c_int32), ("cv_stride", C.c_int32), ("cv_OH", C.c_int32),
-                ("cv_OW", C.c_int32), ("out_T", C.c_int32)]
+                ("cv_OW", C.c_int32), ("out_T", C.c_int32), ("acc_scale", C.c_float)]
 
 
 _lib = None
@@ -309,6 +309,8 @@ def conv_wres_applicable(imgs, H, W, Cin, Cout, stride, T=1):
     """Mirror of the library's dispatch rule (csrc/spike_conv_wres.hip: spike_conv_wres_supports): 3x3 / stride 1 / 96 input
     channels, output columns in blocks of 32, and enough 8 x 16 pixel tiles (x T steps each when the neuron is fused) to give
     every half workgroup of the chip work - below that the streaming kernels' split-K wins."""
+    if os.environ.get("SDF_CONV_WRES", "") == "0":             # the library's A/B override: always the streaming kernels (which
+        return False                                             # do not read digit planes: the caller must keep its 16-bit planes)
     if Cin != 96 or stride != 1 or Cout % 32:
         return False
     if imgs * H * W * max(Cout * 4, Cin) >= 1 << 31:             # the kernel addresses its operands with 31-bit byte offsets
@@ -704,9 +706,7 @@ def pack_dense_conv_weight(w):
     wp = torch.zeros((Cout, rec * 16, 3, 3), dtype=torch.float32, device=w.device)
     wp[:, :Cin] = w.detach().float()
     wk = wp.view(Cout, rec, 16, 3, 3).permute(0, 1, 3, 4, 2).reshape(Cout, rec * 144)
-    hi = wk.half()
-    lo = (wk - hi.float()).half()
-    return torch.stack([hi, lo]).contiguous()
+    return _f16_planes(wk)
 
 
 def dense_conv_slices(records):
@@ -753,16 +753,31 @@ def dense_conv3x3(xp, wplanes, alpha=None, beta=None, resid=None, relu=False, ou
     d.alpha, d.beta = _ptr(alpha, torch.float32), _ptr(beta, torch.float32)
     d.resid, d.out = _ptr(resid, torch.float16), out.data_ptr()
     d.imgs, d.H, d.W, d.cin_records, d.N, d.relu, d.out_f32 = imgs, H, W, rec, N, int(relu), int(out_f32)
+    d.acc_scale = getattr(wplanes, "sdf_acc_scale", 1.0)
     _check(lib().sdf_dense_conv3x3_fwd(C.byref(d), _stream()), "sdf_dense_conv3x3_fwd")
     return out
 
 
 # ---- Linear layer on real-valued activations (ANN swin blocks; csrc/dense_linear.hip) ----
-def pack_dense_linear_weight(w):
-    """Linear weight (N, K) fp32 -> fp16 planes (2, N, K): hi = fp16(w), lo = fp16(w - hi)."""
+def _f16_planes(w):
+    """fp32 (N, K) -> fp16 planes (2, N, K) of s * w: hi = fp16(s w), lo = fp16(s w - hi), s the power of two that puts max|w| in
+    [2^14, 2^15) - every weight within 2^-13 of the largest keeps 22 significant bits (unscaled, a weight of 0.02 has an fp16-subnormal
+    lo half and keeps 19).  1 / s travels with the tensor as `sdf_acc_scale`; the kernels multiply the accumulator by it (exact)."""
+    import math
     w = w.detach().float()
-    hi = w.half()
-    return torch.stack([hi, (w - hi.float()).half()]).contiguous()
+    mx = float(w.abs().max()) if w.numel() else 0.0
+    scale = 2.0 ** (14 - math.floor(math.log2(mx))) if mx > 0 and math.isfinite(mx) else 1.0
+    scale = min(max(scale, 2.0 ** -100), 2.0 ** 100)
+    ws = w * scale
+    hi = ws.half()
+    planes = torch.stack([hi, (ws - hi.float()).half()]).contiguous()
+    planes.sdf_acc_scale = 1.0 / scale
+    return planes
+
+
+def pack_dense_linear_weight(w):
+    """Linear weight (N, K) fp32 -> scaled fp16 planes (2, N, K) (see _f16_planes)."""
+    return _f16_planes(w)
 
 
 def dense_linear_applicable(M, N, K):
@@ -783,6 +798,7 @@ def dense_linear(a, wplanes, bias=None, gelu=False, resid=None, out=None):
     d = DenseLinearDesc()
     d.a, d.w, d.bias, d.resid, d.out = _ptr(a, torch.float32), _ptr(wplanes, torch.float16), _ptr(bias, torch.float32), _ptr(resid, torch.float32), _ptr(out, torch.float32)
     d.M, d.N, d.K, d.gelu = M, N, K, int(gelu)
+    d.acc_scale = getattr(wplanes, "sdf_acc_scale", 1.0)
     _check(lib().sdf_dense_linear_fwd(C.byref(d), _stream()), "sdf_dense_linear_fwd")
     return out
 
@@ -813,6 +829,7 @@ def dense_conv3x3_strided(x_cl, wplanes, bias, stride, out_T=0):
     d.a, d.w, d.bias, d.resid, d.out = _ptr(x_cl, torch.float32), _ptr(wplanes, torch.float16), _ptr(bias, torch.float32), None, _ptr(out)
     d.M, d.N, d.K, d.gelu = imgs * OH * OW, N, 9 * Cc, 0
     d.cv_H, d.cv_W, d.cv_C, d.cv_stride, d.cv_OH, d.cv_OW, d.out_T = H, W, Cc, stride, OH, OW, out_T
+    d.acc_scale = getattr(wplanes, "sdf_acc_scale", 1.0)
     _check(lib().sdf_dense_linear_fwd(C.byref(d), _stream()), "sdf_dense_linear_fwd")
     return out
 

@@ -10,11 +10,14 @@ def test_conv_weight_planes_reconstruct_the_weight_in_record_tap_channel_order()
     w = torch.randn(32, 21, 3, 3, generator=g) * 0.05
     p = hip.pack_dense_conv_weight(w)
     assert p.shape == (2, 32, 2 * 144) and p.dtype == torch.float16
-    full = (p[0].float() + p[1].float()).view(32, 2, 3, 3, 16)           # (n, record, ky, kx, channel in record)
+    sc = p.sdf_acc_scale                                                     # planes hold w / sc, sc a power of two
+    assert 2.0 ** 14 <= float(w.abs().max()) / sc < 2.0 ** 15
+    full = ((p[0].double() + p[1].double()) * sc).view(32, 2, 3, 3, 16)      # (n, record, ky, kx, channel in record)
     back = full.permute(0, 1, 4, 2, 3).reshape(32, 32, 3, 3)
-    assert torch.all((back[:, :21] - w).abs() <= w.abs() * 2.0 ** -21 + 2.0 ** -24)
+    # 22 significant bits for EVERY weight down to 2^-13 of the largest (no fp16-subnormal lo halves: ADVICE r2)
+    assert torch.all((back[:, :21] - w.double()).abs() <= w.double().abs() * 2.0 ** -21 + float(w.abs().max()) * 2.0 ** -38)
     assert torch.count_nonzero(back[:, 21:]) == 0                            # padding channels carry zero weights
-    hi = w.half().float()                                                    # plane 0 is the fp16 rounding of the weight
+    hi = (w / sc).half().float()                                             # plane 0 is the fp16 rounding of the scaled weight
     assert torch.equal(p[0].view(32, 2, 3, 3, 16).permute(0, 1, 4, 2, 3).reshape(32, 32, 3, 3)[:, :21].float(), hi)
 
 
@@ -23,8 +26,13 @@ def test_linear_weight_planes():
     w = torch.randn(96, 64, generator=g)
     p = hip.pack_dense_linear_weight(w)
     assert p.shape == (2, 96, 64)
-    assert torch.equal(p[0].float(), w.half().float())
-    assert torch.all((p[0].float() + p[1].float() - w).abs() <= w.abs() * 2.0 ** -21 + 2.0 ** -24)
+    sc = p.sdf_acc_scale
+    assert torch.equal(p[0].float(), (w / sc).half().float())
+    assert torch.all(((p[0].double() + p[1].double()) * sc - w.double()).abs() <= w.double().abs() * 2.0 ** -21 + float(w.abs().max()) * 2.0 ** -38)
+    small = torch.full((96, 64), 1e-3)
+    small[0, 0] = 0.5                                                        # a weight 500x below the largest keeps its bits
+    q = hip.pack_dense_linear_weight(small)
+    assert abs(float((q[0, 5, 5].double() + q[1, 5, 5].double()) * q.sdf_acc_scale) - 1e-3) <= 1e-3 * 2.0 ** -21
 
 
 def test_slice_plan_and_applicability():
