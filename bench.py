@@ -210,6 +210,120 @@ def time_config3(iters=10):
                          "traffic_note": "HBM bytes per launch from profiles/r2p_pmc_dense.txt (FETCH_SIZE x 2 + WRITE_SIZE); algorithmic 2.04e9"}}
 
 
+def inflight_rate(model, chunks_cpu, dev, F_, steps, warmup=6):
+    """samples/s of `steps` batch-1 forwards dealt round-robin over F_ streams, each replaying its own HIP graph (the headline's
+    timed region without the multi-rank plumbing), and the median latency of a synchronous forward."""
+    with torch.no_grad():
+        x0 = chunks_cpu[0].to(dev)
+        for _ in range(3):
+            model(x0)
+        torch.cuda.synchronize()
+        lat = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            model(x0)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t0) * 1e3)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(F_)]
+        graphs, keep = [], []
+        for j, st in enumerate(streams):
+            x = chunks_cpu[j].to(dev)
+            with torch.cuda.stream(st):
+                for _ in range(2):
+                    model(x)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                o = model(x)
+            graphs.append(g)
+            keep.append((x, o))
+        torch.cuda.synchronize()
+        for i in range(warmup):
+            with torch.cuda.stream(streams[i % F_]):
+                graphs[i % F_].replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            with torch.cuda.stream(streams[i % F_]):
+                graphs[i % F_].replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert all(torch.isfinite(o["flow"][-1]).all() for _, o in keep)
+    return {"samples_per_s": steps / dt, "ms_per_step": dt / steps * 1e3, "latency_ms_single_stream": sorted(lat)[len(lat) // 2],
+            "steps": steps, "in_flight": F_}
+
+
+def side_measurements(args, dev, chunks_cpu):
+    """The other modes / BASELINE configurations beside the headline, each a short run of the same code paths (the default line's
+    own configuration is never changed by them): the exact 3-plane and the 1-plane bf16 weight modes, the shipped PSN neuron,
+    BASELINE configs[4] (20 bins / T = 20, 480 x 640, batch 4) and one configs[3] training step at local batch 4 on this GPU."""
+    from sdformerflow_amd import train
+    from sdformerflow_amd.harness import prepare_chunk
+    from sdformerflow_amd.synthetic import synth_label, synth_voxel
+    out = {}
+    for name, kind, planes in (("planes3_exact_fp32_weights", "lif", 3), ("planes1_bf16_weights", "lif", 1), ("neuron_psn", "psn", 2)):
+        m, _ = build_model(kind, dev)
+        m.gemm_nsplit = planes
+        r = inflight_rate(m, chunks_cpu, dev, args.inflight, 90)
+        r["workload"] = f"configs[1] forward, neuron={kind}, weight planes={planes} ({ {1: 'one bf16', 2: 'fp16 hi+lo', 3: 'bf16 hi+mid+lo = fp32 exactly'}[planes] })"
+        out[name] = r
+        del m
+        torch.cuda.empty_cache()
+    # configs[4]: long-T / large-map stress, one stream (at batch 4 the launches fill the chip on their own)
+    import yaml
+    from sdformerflow_amd.STSwinNet_SNN.Spiking_STSwinNet import MS_SpikingformerFlowNet_en4
+    from sdformerflow_amd.synthetic import synth_state_dict
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "sdformerflow_amd", "configs", "train_DSEC_supervised_SDformerFlow_en4.yml")))
+    cfg["model"]["spiking_neuron"] = dict(cfg["spiking_neuron"], neuron_type="lif", num_steps=20)
+    cfg["model"].update(num_bins=20)
+    cfg["swin_transformer"].update(input_size=[480, 640])
+    try:
+        m5 = MS_SpikingformerFlowNet_en4(cfg["model"].copy(), cfg["swin_transformer"].copy())
+        m5.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in m5.state_dict().items()}), strict=True)
+        m5 = m5.eval().to(dev)
+        x5 = prepare_chunk(synth_voxel(4, 20, 480, 640, seed=1239)).to(dev)
+        with torch.no_grad():
+            for _ in range(2):
+                o = m5(x5)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                o = m5(x5)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 5
+        assert torch.isfinite(o["flow"][-1]).all()
+        out["config5_T20_480x640_batch4"] = {"workload": "BASELINE configs[4]: en4 forward, 20 bins / T = 20, 480x640, batch 4, neuron=lif, one stream (eager)",
+                                             "samples_per_s": 4 / dt, "ms_per_batch": dt * 1e3}
+        del m5, x5, o
+    except Exception as e:                                         # a side line must never take the headline down with it
+        out["config5_T20_480x640_batch4"] = {"error": repr(e)[:300]}
+    torch.cuda.empty_cache()
+    try:
+        m4, _ = build_model("lif", dev)
+        m4.train()
+        B = 4
+        chunk = prepare_chunk(synth_voxel(B, 10, 288, 384, seed=1238)).to(dev)
+        label, mask = (t.to(dev) for t in synth_label(B, 288, 384))
+        buckets = train.GradientBuckets(m4.parameters())
+        opt = torch.optim.AdamW(m4.parameters(), lr=1e-4, weight_decay=0.01)
+        for _ in range(2):
+            train.train_step(m4, opt, chunk, label, mask, buckets=buckets, dist=None, world=1, amp=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        losses = [float(train.train_step(m4, opt, chunk, label, mask, buckets=buckets, dist=None, world=1, amp=False)) for _ in range(4)]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 4
+        assert all(v == v and abs(v) != float("inf") for v in losses)
+        out["config4_train_step_1gpu"] = {"workload": "BASELINE configs[3] on ONE GPU: supervised training step (train-mode forward, loss, backward, clip, AdamW), "
+                                                      "local batch 4, fp32, no collective at world size 1",
+                                          "samples_per_s": B / dt, "ms_per_step": dt * 1e3, "loss_first_last": [losses[0], losses[-1]]}
+        del m4, opt, buckets
+    except Exception as e:
+        out["config4_train_step_1gpu"] = {"error": repr(e)[:300]}
+    torch.cuda.empty_cache()
+    return out
+
+
 def time_swin_blocks(model, chunk, iters=10):
     """The attention-GEMM roofline fraction of the metric: SURVEY.md 8(d)'s 183.7 GFLOP of the swin blocks' Linear layers
     (q|k, proj, fc1, fc2, merge) per sample / the time of the swin stages themselves - the 12 blocks + 3 merges run alone on
@@ -476,6 +590,7 @@ def main():
     ap.add_argument("--neuron", default="lif", choices=["lif", "psn"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-config3", action="store_true", help="skip the BASELINE configs[2] (ANN, batch 8) side measurement")
+    ap.add_argument("--no-sides", action="store_true", help="skip the other side measurements (weight-plane modes, PSN, configs[3] / [4])")
     ap.add_argument("--inflight", type=int, default=3, help="independent forwards in flight per GPU (HIP streams)")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying HIP graphs")
     ap.add_argument("--planes", type=int, default=2, choices=[1, 2, 3],
@@ -593,6 +708,10 @@ def main():
         }
         if not args.no_config3 and world == 1:
             res["config3_ann"] = time_config3()
+        if not args.no_sides and world == 1 and args.planes == 2 and args.neuron == "lif":
+            del model
+            torch.cuda.empty_cache()
+            res["side_measurements"] = side_measurements(args, dev, chunks_cpu)
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.neuron, sd, chunk_cpu)
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]

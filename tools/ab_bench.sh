@@ -9,5 +9,5 @@ pick='import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print("%8.1f samples/s  %.3f ms/step  latency %.3f ms  swin stages %.3f ms" % (d["value"], d["ms_per_step"], d["latency_ms_single_stream"], d["attention_gemm"]["swin_stages_ms"]))'
 for i in $(seq $N); do
   echo -n "base : "; (cd .ab_base && python3 bench.py --no-cpu "$@" 2>/dev/null | python3 -c "$pick")
-  echo -n "this : "; python3 bench.py --no-cpu "$@" 2>/dev/null | python3 -c "$pick"
+  echo -n "this : "; python3 bench.py --no-cpu --no-sides "$@" 2>/dev/null | python3 -c "$pick"
 done
