@@ -447,6 +447,95 @@ def gold_train_step():
     save("train_step", **out)
 
 
+def gold_train_step_forced():
+    """The oracle's TRAIN mode pinned EXACTLY on the reference (the free-running comparison of `train_step` is only a statistic:
+    the net is chaotic).  The reference's train-mode forward + backward runs with forward hooks that keep every neuron layer's
+    spikes; the oracle then runs its own train-mode forward + backward with those spikes FORCED (`oracle.NEURON_FORCE`: value of
+    the spike = the reference's, gradient = the surrogate's at the oracle's membrane, reset following the forced decision), so the
+    two compute graphs carry identical spike trains and differ by floating-point rounding only.  Stored: per parameter
+    max|g_oracle - g_reference| / max|g_reference|, the loss pair, and per neuron layer the number of the reference's decisions the
+    oracle's own pre-activation would have taken differently (`delta_consistent`: all within 16 ulp of the threshold).  lif and psn."""
+    from models.STSwinNet_SNN.Spiking_STSwinNet import MS_SpikingformerFlowNet
+    from loss.flow_supervised import flow_loss_supervised
+    from oracle import sdformer_oracle as O
+    out = {}
+    for kind in ("lif", "psn"):
+        config = en4_config(kind)
+        config["swin_transformer"].update(input_size=[144, 144], swin_depths=[2, 2, 6], swin_num_heads=[3, 6, 12], swin_out_indices=[0, 1, 2])
+        with torch.enable_grad():
+            model = MS_SpikingformerFlowNet(config["model"].copy(), config["swin_transformer"].copy())
+            load_synth(model)
+            model.train()
+            _no_drop_path(model)
+            functional.reset_net(model)
+            tape = {}
+            hooks = [m.register_forward_hook(lambda mod, inp, o, n=n: tape.__setitem__(n + ".", o.detach().clone()))
+                     for n, m in model.named_modules() if n.endswith(".spiking_neuron")]
+            vox = synth_voxel(2, 10, 144, 144, seed=1234 + 4)
+            chunk = torch.cat((torch.relu(vox).unsqueeze(2), torch.relu(-vox).unsqueeze(2)), dim=2)
+            lo, hi = chunk[chunk != 0].min(), chunk[chunk != 0].max()
+            chunk[chunk != 0] = (chunk[chunk != 0] - lo) / (hi - lo)
+            label, mask = synth_label(2, 144, 144)
+            res = model(chunk)
+            loss = flow_loss_supervised(config, "cpu")(res["flow"], label, mask, gamma=None)
+            loss.backward()
+            for h in hooks:
+                h.remove()
+            ref_grads = {n: (p.grad.clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+            # ---- the oracle on the same weights / inputs with the reference's spikes forced
+            sd0 = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.endswith("num_batches_tracked")}
+        # (running statistics were updated in place by the reference's forward: the oracle needs the values BEFORE it - regenerate)
+        shapes = {k: tuple(v.shape) for k, v in sd0.items()}
+        sd = synth_state_dict(shapes, 0, -0.1)
+        sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) else v.clone())
+              for k, v in sd.items()}
+        ocfg = {"neuron": O.NeuronCfg(kind, 0.1, None, 2.0, 10), "num_bins": 10, "window_size": (2, 9, 9), "depths": [2, 2, 6],
+                "num_heads": [3, 6, 12]}
+        report, used = [], set()
+
+        def force(prefix, x, kind=kind, sd=sd):
+            got = tape.get(prefix)
+            if got is None:
+                return None                                             # the integer-input token gate: never taped, computed freely
+            used.add(prefix)
+            xd = x.detach()
+            delta = 16 * 2.0 ** -23 * max(float(xd.pow(2).mean().sqrt()), 0.1)
+            r = O.delta_consistent(xd, got.reshape(xd.shape), ocfg["neuron"], {k: v.detach() for k, v in sd.items()}, prefix, delta)
+            report.append((prefix, r["flips"], r["unexplained"], r["n"]))
+            return got.reshape(x.shape)
+
+        O.TRAIN, O.NEURON_FORCE = O.TrainCtx(), force
+        try:
+            with torch.enable_grad():
+                flows = O.forward_flownet(chunk, sd, ocfg)
+                oloss = O.flow_loss_supervised(flows, label, mask, 1.0, 1.0)
+                oloss.backward()
+        finally:
+            O.TRAIN, O.NEURON_FORCE = None, None
+        names, rel = [], []
+        for n, g in ref_grads.items():
+            og = sd[n].grad
+            names.append(n)
+            if g is None or float(g.abs().max()) == 0.0:
+                assert og is None or float(og.abs().max()) == 0.0, n
+                rel.append(-1.0)
+            elif n.endswith("attn.proj.bias"):
+                # a bias in front of a batch-statistics BatchNorm: its true gradient is zero, both sides hold rounding noise -
+                # measured against the scale of the same layer's weight gradient
+                rel.append(float((og - g).abs().max() / ref_grads[n[:-4] + "weight"].abs().max()))
+            else:
+                rel.append(float((og - g).abs().max() / g.abs().max()))
+        worst = max(rel)
+        print(f"  train_step_forced[{kind}]: loss reference {float(loss):.8f} oracle {float(oloss):.8f}; {len(used)} layers forced, "
+              f"{sum(r[1] for r in report)} decisions differ, {sum(r[2] for r in report)} unexplained of {sum(r[3] for r in report)}; "
+              f"worst parameter-gradient deviation {worst:.2e} ({names[int(np.argmax(rel))]})")
+        out[f"{kind}_loss"] = np.array([float(loss), float(oloss)])
+        out[f"{kind}_grad_names"], out[f"{kind}_grad_rel"] = np.array(names), np.array(rel, dtype=np.float64)
+        out[f"{kind}_layers"] = np.array([r[0] for r in report])
+        out[f"{kind}_flips_unexplained_n"] = np.array([[r[1], r[2], r[3]] for r in report], dtype=np.int64)
+    save("train_step_forced", **out)
+
+
 def gold_ms_block_config5():
     """The config-5 flavours of the block (BASELINE configs[4]): D = 20 frames with T = 20 neurons, and the large window
     (2,15,15) with its 450-token positional encoding and shift (1,7,7) - pins the oracle's index arithmetic beyond (2,9,9)."""
@@ -518,7 +607,7 @@ def gold_formats():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["neurons", "index_maps", "qk_attention", "sew_attention", "ann_attention",
-                             "ms_block", "end_to_end", "sew_end_to_end", "ann_end_to_end", "ann_odd_size", "formats", "neuron_grads", "train_block", "train_step", "ms_block_config5"]
+                             "ms_block", "end_to_end", "sew_end_to_end", "ann_end_to_end", "ann_odd_size", "formats", "neuron_grads", "train_block", "train_step", "train_step_forced", "ms_block_config5"]
     for w in which:
         globals()["gold_" + w]()
 

@@ -450,6 +450,25 @@ def test_oracle_train_step_matches_reference():
     assert ok >= 0.9 * tot, (ok, tot)
 
 
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+def test_oracle_train_mode_is_pinned_exactly_by_the_spike_forced_reference_run(kind):
+    """`train_step_forced.npz` (tests/golden/make_golden.py `gold_train_step_forced`, needs /root/reference) is the record of the
+    oracle's TRAIN-mode forward + backward run with the REAL reference's spikes forced into every neuron layer: both graphs then
+    carry identical spike trains, so unlike the free-running statistic above the comparison is exact - loss to 1e-7, every
+    parameter gradient to 5e-5 of its largest element, and every decision in which the oracle's own pre-activation would have
+    differed from the reference's explained by a 16-ulp threshold margin (0 unexplained).  The same forced run against the GPU's
+    spikes is tests/test_train_gpu.py::test_whole_model_train_step_spike_forced_gradient_parity."""
+    F_ = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_step_forced.npz"))
+    lr, lo = (float(v) for v in F_[f"{kind}_loss"])
+    assert abs(lr - lo) <= 1e-7 * abs(lr)
+    fun = F_[f"{kind}_flips_unexplained_n"]
+    assert len(fun) == 78 and int(fun[:, 1].sum()) == 0                         # 78 forced neuron layers, nothing unexplained
+    assert int(fun[:, 0].sum()) <= 1e-6 * int(fun[:, 2].sum())                  # a handful of 188 M decisions sit on the threshold
+    rel = F_[f"{kind}_grad_rel"]
+    live = rel[rel >= 0]
+    assert len(live) >= 200 and float(live.max()) <= 5e-5, float(live.max())
+
+
 @pytest.mark.parametrize("tag,kind", [("w15_sw", "lif"), ("w15_w", "psn"), ("t20_sw", "lif")])
 def test_ms_block_config5_flavours_match_reference(tag, kind):
     """BASELINE configs[4]: the large window (2,15,15) (450-token positional encoding, shift (1,7,7), padding 33 -> 45) and
