@@ -34,11 +34,17 @@ PEAK_BF16_DENSE_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: ~2
 PEAK_HBM_GBPS = 8000.0              # same guide: 8.0 TB/s spec (6.3 TB/s achievable)
 # HBM bytes per launch of the roofline shape from the PMC counters.  They cannot be read inside this process (rocprofv3 owns the
 # counters), so the figure is the one measured by tools/pmc_traffic.sh on the build named in CONV_TRAFFIC_SOURCE
-CONV_TRAFFIC_BYTES = (2 * 95125.3 + 129600.0) * 1024        # digit-plane kernel, fused LIF + membrane form
-CONV_TRAFFIC_SOURCE = ("NOT measured in this run: profiles/r2e_pmc_traffic_conv_fused_membrane.txt (round-2 build r2e, tools/pmc_traffic.sh "
-                       "fusedm i8x3): rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and WRITE_SIZE in separate passes on this exact launch = "
-                       "185.8 MB read + 126.6 MB written; algorithmic 265.7 MB (26.5 spikes in + 106.2 residual + 106.2 membrane + 26.5 spikes "
-                       "out + 0.3 weights): 1.18x - the spike image is read once per 32-column block (3x) plus the halo rows")
+# (round 3: profiles/r3g_pmc_kernels.txt, the shipped three-group kernel; both epilogue forms, since `roofline` averages over them)
+CONV_TRAFFIC_KIB = {"membrane_and_spikes": (95362.0, 131136.0), "spikes_only": (42605.0, 27456.0)}     # (FETCH_SIZE, WRITE_SIZE) KiB / launch
+CONV_TRAFFIC_BYTES = sum(2 * f + w for f, w in CONV_TRAFFIC_KIB.values()) / 2 * 1024                 # FETCH_SIZE x 2: gfx950 correction
+CONV_ALGORITHMIC_BYTES = {"membrane_and_spikes": 10 * 144 * 192 * 96 * (1 + 4 + 4 + 1) + 3 * 96 * 864,
+                          "spikes_only": 10 * 144 * 192 * 96 * (1 + 1) + 3 * 96 * 864}
+CONV_TRAFFIC_SOURCE = ("NOT measured in this run (rocprofv3 owns the counters): profiles/r3g_pmc_kernels.txt (round-3 tree, tools/pmc_kernels.sh: "
+                       "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes on this exact launch, gfx950 x2 read "
+                       "correction, KiB = 1024 B): membrane + spikes form 195.3 MB read + 134.3 MB written against 265.7 MB algorithmic "
+                       "(1.24x: the 26.5 MB spike image is read once per 32-column block, 3x, plus halo rows; the write side is exact); "
+                       "spikes-only form 87.3 + 28.1 MB against 53.4 MB (2.2x, the same 3x image reads); `traffic` is their mean, as "
+                       "`achieved` is the mean over the forward's two launches of each form")
 
 
 def build_model(kind, device):
@@ -133,13 +139,17 @@ def time_dominant_kernels(model, iters=40):
             "fp32_epilogue_form": {"us_per_launch": t_f32 * 1e6, "achieved": flops / t_f32 / 1e12,
                                    "frac": flops / t_f32 / 1e12 / PEAK_BF16_DENSE_TFLOPS, "l3_resident_us_per_launch": t_f32_l3 * 1e6,
                                    "note": "the same convolution with the plain BN + residual fp32 epilogue (round 1's roofline shape)"},
-            "algorithmic_bytes": set_bytes + (3 if digits else 2 * ns) * Cc * 9 * Cc,
-            "traffic": CONV_TRAFFIC_BYTES if digits else None, "traffic_unit": "bytes per launch (HBM read + write)",
-            "traffic_source": CONV_TRAFFIC_SOURCE + " (the membrane + spikes form; the spikes-only form writes 106 MB less)",
+            "algorithmic_bytes": sum(CONV_ALGORITHMIC_BYTES.values()) / 2,
+            "traffic": CONV_TRAFFIC_BYTES if digits else None, "traffic_unit": "bytes per launch (HBM read + write), mean of the two forms",
+            "traffic_over_algorithmic": CONV_TRAFFIC_BYTES / (sum(CONV_ALGORITHMIC_BYTES.values()) / 2) if digits else None,
+            "traffic_source": CONV_TRAFFIC_SOURCE,
+            "pmc": "profiles/r3g_pmc_kernels.txt: 683 MFMA and 5 600 VALU instructions per wave (8.2 VALU per MFMA), "
+                   "SQ_VALU_MFMA_BUSY_CYCLES = 34-38 % of the kernel's cycles per SIMD at an effective 2.2 GHz, LDS bank conflicts 6 % of "
+                   "LDS cycles: the kernel is bound by its epilogue's vector instructions, not by the matrix pipe",
             "note": "algorithmic flops (2 per multiply-add of the convolution) against the dense bf16/f16 MFMA peak.  The kernel issues "
                     + ("3 int8 digit MFMAs (v_mfma_i32_32x32x32_i8, K = 32 in the cycles the 16-bit form needs for K = 16) per product: 1.5x "
                        "the algorithmic work on the 16-bit pipe's scale" if digits else f"{ns} 16-bit MFMAs per product") +
-                    "; in-kernel clock under this load is 1.3-1.7 GHz, not the 2.4 GHz the peak assumes (profiles/r2e_stamps_wres.txt)"}
+                    "; the matrix pipe is busy 34-38 % of the kernel's cycles (PMC, profiles/r3g_pmc_kernels.txt)"}
     gemm["frac"] = gemm["achieved"] / gemm["peak"]
     gemm["frac_of_issued_mfma"] = issued * gemm["frac"]
     # neuron: T=10 over the stage-0 MLP hidden tensor shape (10 x 72*96*384 fp32 in, u8 out)
