@@ -30,6 +30,7 @@
 // LDS rows are padded (A 18-dword stride for ds_read_b64, W 36-dword stride for ds_read_b128): conflict-free.
 // Compiled with -ffp-contract=off (the neuron arithmetic is the separately-rounded op sequence of neuron.hip).
 #include "spike_mm.h"
+#include <stdlib.h>
 #include <type_traits>
 
 #ifdef SDF_STAMP
@@ -667,7 +668,20 @@ int launch_spike_mm_pp(const GemmParams& Pin, bool conv, hipStream_t s) {
   P.ntiles = P.tiles_m * P.tiles_n;
   plan_splitk(P, KC);
   const int nitems = P.ntiles * P.ksplit;
-  const int G = nitems < 256 ? nitems : 256;
+  // one workgroup per compute unit (the kernel fills a CU's registers and LDS).  With more than 256 items the grid is sized for
+  // EQUAL rounds - 288 items: 144 workgroups x 2 items, not 256 of which 32 run a second item while 224 compute units idle:
+  // same duration, and the other in-flight forwards' kernels get the compute units this launch does not need
+  // A workgroup's two consumer groups alternate items, so a workgroup wants an EVEN number of items: with one item per workgroup
+  // half of its matrix-pipe time is idle.  SDF_PP_PAIR=0: the round-2 rule (one item per workgroup up to 256 workgroups).
+  static const bool pair = !(getenv("SDF_PP_PAIR") && getenv("SDF_PP_PAIR")[0] == '0');
+  int G;
+  if (pair && nitems >= 16) {
+    const int rounds = (nitems + 511) / 512;                     // items per workgroup = 2 * rounds
+    G = (nitems + 2 * rounds - 1) / (2 * rounds);
+  } else {
+    const int rounds = (nitems + 255) / 256;
+    G = (nitems + rounds - 1) / rounds;
+  }
   dim3 grid((unsigned)G);
   int rc;
   if (conv)
