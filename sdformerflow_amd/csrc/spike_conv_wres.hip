@@ -504,7 +504,10 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
   const int l31 = ln & 31, lh = ln >> 5;
   const uint32_t a_lane = (uint32_t)((2 * RB * cw + (l31 >> 4)) * RPB + (l31 & 15) * PS + 16 * lh);      // + 2*rb rows
   const uint32_t w_lane = (uint32_t)(l31 * WP + 16 * lh);
-  const int qd = l31 >> 2, ql = l31 & 3;
+  // The WEIGHT digits are the MFMA's row operand and the pixels its column operand: the accumulator then holds, per lane, pixel
+  // l31 of the row block and in registers 4 q4 .. 4 q4 + 3 the four CONSECUTIVE channels n0 + 8 q4 + 4 lh + 0..3 - one 16-byte
+  // piece of the fp32 row and one dword of the spike row, with no quad transpose in front of the stores (round 2 had the
+  // operands the other way round and spent about 40 vector instructions per accumulator quad on the transpose).
   const __amdgpu_buffer_rsrc_t out_rs = make_rsrc(d.out), res_rs = make_rsrc(d.resid), sp_rs = make_rsrc(d.out_spike);
 
   uint32_t nstep = 0;
@@ -554,8 +557,6 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
     }
     __syncthreads();
     STAMP(s1); STAMP_ADD(a_wload, s0, s1);
-    const float4 al4 = *reinterpret_cast<const float4*>(par_s + 4 * qd);
-    const float4 be4 = *reinterpret_cast<const float4*>(par_s + NB + 4 * qd);
 
     int it = seg_begin + grp;
     if (it < seg_end) {
@@ -578,18 +579,16 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
         // rows of this step's epilogue; the fp32 epilogue requests its residual now, ahead of the MFMAs (in-order vmcnt:
         // nothing the epilogue waits for is younger than its own stores)
         const int img = img0 + t * tstep;
-        // quad transpose in the epilogue: lane (qd, ql) ends with columns 4qd..4qd+3 of pixel rr = 8*q4 + 4*lh + ql of a row
-        // block's 32 -> 16-byte loads / stores (dword-per-slot accesses measured slower: 4 x the memory instructions)
-        const uint32_t ld4 = (uint32_t)d.ldo * 4u, col4 = (uint32_t)(n0 + 4 * qd) * 4u;
-        const int ybase = y0 + 2 * RB * cw, xbase = x0 + 4 * lh + ql;
+        // this lane's pixel of row block rb: (ybase + 2 rb, xbase); its accumulator quad q4 = channels n0 + 8 q4 + 4 lh + 0..3
+        const uint32_t ld4 = (uint32_t)d.ldo * 4u, col4 = (uint32_t)(n0 + 4 * lh) * 4u;
+        const int ybase = y0 + 2 * RB * cw + (l31 >> 4), xbase = x0 + (l31 & 15);
         const uint32_t g00 = (uint32_t)((img * H + ybase) * W + xbase);
         auto row_g = [&](int rb, int q4) __attribute__((always_inline)) -> uint32_t {     // global row (img, y, x), or INV outside the image
-          const int yo = 2 * rb + (q4 >> 1), xo = 8 * (q4 & 1);       // rr = 8*q4 + 4*lh + ql: row rr >> 4, column rr & 15
-          return (ybase + yo < H && xbase + xo < W) ? g00 + (uint32_t)(yo * W + xo) : INV;
+          return (ybase + 2 * rb < H && xbase < W) ? g00 + (uint32_t)(2 * rb * W) : INV;
         };
         auto rowoff = [&](int rb, int q4) __attribute__((always_inline)) -> uint32_t {
           const uint32_t g = row_g(rb, q4);
-          return g != INV ? g * ld4 + col4 : INV;
+          return g != INV ? g * ld4 + col4 + (uint32_t)(32 * q4) : INV;
         };
         float4 rs[RB][4];
 #pragma unroll
@@ -641,7 +640,7 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
           for (int dg = 0; dg < 3; ++dg)
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
-              acc[dg][rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks % (PF + 1)][rb], fb[ks % (PF + 1)][dg], acc[dg][rb], 0, 0, 0);
+              acc[dg][rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[ks % (PF + 1)][dg], fa[ks % (PF + 1)][rb], acc[dg][rb], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         signal(&cnt[NGRP + grp], lane);
@@ -673,7 +672,8 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
               const int lo = acc[1][rb][e] * 256 + acc[0][rb][e];
               v[j] = __builtin_fmaf((float)acc[2][rb][e], 65536.f, (float)lo);
             }
-            quad_transpose(v, ql);
+            const float4 al4 = *reinterpret_cast<const float4*>(par_s + 8 * q4 + 4 * lh);
+            const float4 be4 = *reinterpret_cast<const float4*>(par_s + NB + 8 * q4 + 4 * lh);
             float4 o;
             o.x = __builtin_fmaf(v[0], al4.x, be4.x) + rs[rb][q4].x; o.y = __builtin_fmaf(v[1], al4.y, be4.y) + rs[rb][q4].y;
             o.z = __builtin_fmaf(v[2], al4.z, be4.z) + rs[rb][q4].z; o.w = __builtin_fmaf(v[3], al4.w, be4.w) + rs[rb][q4].w;
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
                 }
               }
               const uint32_t g = row_g(rb, q4);
-              __builtin_amdgcn_raw_buffer_store_b32(pk, sp_rs, g != INV ? g * (uint32_t)N + (uint32_t)(n0 + 4 * qd) : INV, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(pk, sp_rs, g != INV ? g * (uint32_t)N + (uint32_t)(n0 + 8 * q4 + 4 * lh) : INV, 0, 0);
             }
           }
         }
