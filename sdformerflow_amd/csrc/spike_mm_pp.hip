@@ -386,8 +386,13 @@ __global__ __launch_bounds__(768) void spike_mm_pp_kernel(GemmParams P) {
         if (p == 0) { a0 = expand_spikes<NSPLIT>(fa[ks & 1][0]); a1 = expand_spikes<NSPLIT>(fa[ks & 1][1]); }
 #pragma unroll
         for (int nb = 0; nb < 3; ++nb) {
-          acc[0][nb] = mma<NSPLIT>(a0, fb[u & 1][nb], acc[0][nb]);
-          acc[1][nb] = mma<NSPLIT>(a1, fb[u & 1][nb], acc[1][nb]);
+          if (SPIKE) {                                             // rows = (position, t) slots of a lane: the neuron runs on registers
+            acc[0][nb] = mma<NSPLIT>(a0, fb[u & 1][nb], acc[0][nb]);
+            acc[1][nb] = mma<NSPLIT>(a1, fb[u & 1][nb], acc[1][nb]);
+          } else {                                                 // fp32 epilogue: weights as the row operand - accumulator quads are
+            acc[0][nb] = mma<NSPLIT>(fb[u & 1][nb], a0, acc[0][nb]);   // four consecutive columns of one output row (no transpose)
+            acc[1][nb] = mma<NSPLIT>(fb[u & 1][nb], a1, acc[1][nb]);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -403,50 +408,45 @@ __global__ __launch_bounds__(768) void spike_mm_pp_kernel(GemmParams P) {
     const int cb = t / P.tiles_m, rt = t - cb * P.tiles_m;
     const int n0 = cb * BN;
     if (!SPIKE) {
-      // Each lane ends up with 4 consecutive columns of one row (quad transpose) -> 16-byte loads / stores.
+      // The weights were the MFMA's row operand: lane (l31, lh) holds output row l31 of each of its two row blocks and, in
+      // accumulator quad q4 of column block nb, the four consecutive columns n0 + 32 nb + 8 q4 + 4 lh + 0..3 -> 16-byte loads /
+      // stores with no transpose (round 2 multiplied the other way round and transposed 24 quads per tile).
       // vmcnt counts loads AND stores in order on CDNA4, so a load placed between stores makes its s_waitcnt drain
-      // the stores in front of it.  Hence: per 32-column block, ALL parameter / residual loads are issued and waited
-      // for (pinned in straight-line code) before its first store - three drain points per tile - and there are no
-      // per-lane "load or constant" selects (hipcc branches around those and waits).  Column-block-outer keeps the
-      // live set (96 accumulators + 12 parameters + 32 residuals) inside the 168 registers of a 3-waves-per-SIMD kernel.
-      const int qd = l31 >> 2, ql = l31 & 3;
-      const int mrow0 = rt * BM + cw * 64 + 4 * lh + ql;         // + rb*32 + 8*q4
+      // the stores in front of it.  Hence: per batch, ALL residual loads are issued and waited for (pinned in straight-line
+      // code) before its first store, and there are no per-lane "load or constant" selects (hipcc branches around those and waits).
+      const int mrow0 = rt * BM + cw * 64 + l31;                 // + rb*32
       const bool has_map = d.out_rowmap != nullptr, has_res = d.resid != nullptr;
       if (ksplit > 1) {
         // split-K: raw fp32 partial sums; scale / bias / BN / residual / scatter happen in splitk_reduce_kernel
         float* pbase = P.partial + (int64_t)kc * d.M * N;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < 2; ++rb) {
+          const int m = mrow0 + rb * 32;
+          float* op = pbase + (int64_t)m * N + n0 + 4 * lh;
 #pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const int m = mrow0 + rb * 32 + 8 * q4;
-            float* op = pbase + (int64_t)m * N + n0 + 4 * qd;
+          for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
-            for (int nb = 0; nb < 3; ++nb) {
-              float v[4] = {acc[rb][nb][q4 * 4 + 0], acc[rb][nb][q4 * 4 + 1], acc[rb][nb][q4 * 4 + 2], acc[rb][nb][q4 * 4 + 3]};
-              quad_transpose(v, ql);
-              if (m < (int)d.M) *reinterpret_cast<float4*>(op + nb * 32) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-          }
+            for (int q4 = 0; q4 < 4; ++q4)
+              if (m < (int)d.M)
+                *reinterpret_cast<float4*>(op + nb * 32 + 8 * q4) =
+                    make_float4(acc[rb][nb][q4 * 4 + 0], acc[rb][nb][q4 * 4 + 1], acc[rb][nb][q4 * 4 + 2], acc[rb][nb][q4 * 4 + 3]);
+        }
       } else {
-        // byte offset of each of this lane's 8 rows in out / resid, or INV (row past M, or dropped by the row map)
+        // byte offset of each of this lane's 2 rows in out / resid, or INV (row past M, or dropped by the row map)
         const uint32_t ldo4 = (uint32_t)d.ldo * 4u;
-        uint32_t dstm[2][4];
+        uint32_t dstm[2];
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const int m = mrow0 + rb * 32 + 8 * q4;
-            int r = m;
-            if (has_map) r = d.out_rowmap[m < (int)d.M ? m : 0];
-            dstm[rb][q4] = (m < (int)d.M && r >= 0) ? (uint32_t)r * ldo4 : INV;
-          }
-        auto dst = [&](int rb, int q4) __attribute__((always_inline)) -> uint32_t { return dstm[rb][q4]; };
+        for (int rb = 0; rb < 2; ++rb) {
+          const int m = mrow0 + rb * 32;
+          int r = m;
+          if (has_map) r = d.out_rowmap[m < (int)d.M ? m : 0];
+          dstm[rb] = (m < (int)d.M && r >= 0) ? (uint32_t)r * ldo4 : INV;
+        }
         {
-        // Six batches (column block nb, row block rb) of 4 rows x 4 columns per lane.  The residual loads of batch
+        // Six batches (column block nb, row block rb) of 4 quads per lane.  The residual loads of batch
         // k + 1 are issued BEFORE the stores of batch k: vmcnt retires in order, so waiting for them never waits for a
         // store, and one memory round trip overlaps the next.  Bias / alpha / beta of the tile's 96 columns are parked
-        // in a private LDS strip (lgkmcnt, not vmcnt, and 12 instead of 36 live registers).
+        // in a private LDS strip (lgkmcnt, not vmcnt).
         float* par_s = reinterpret_cast<float*>(smem + NSLOT * BUF + STG + DEC) + wave * (3 * BN);
         {
           const int c4 = ln < 24 ? ln : 0;                        // 24 lanes x 4 columns per parameter
@@ -462,12 +462,12 @@ __global__ __launch_bounds__(768) void spike_mm_pp_kernel(GemmParams P) {
         const __amdgpu_buffer_rsrc_t res_rs = make_rsrc(d.resid), out_rs = make_rsrc(d.out);   // offsets < 2^31: launcher
         float4 rs[2][4];
         auto load_rs = [&](int nb, int rb, float4 (&rr)[4]) __attribute__((always_inline)) {
-          const uint32_t cb4 = (uint32_t)(n0 + nb * 32 + 4 * qd) * 4u;
+          const uint32_t cb4 = (uint32_t)(n0 + nb * 32 + 4 * lh) * 4u;
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) rr[q4] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (has_res) {
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) rr[q4] = buf_load16f(res_rs, dst(rb, q4) + cb4);      // INV + cb4 stays out of range
+            for (int q4 = 0; q4 < 4; ++q4) rr[q4] = buf_load16f(res_rs, dstm[rb] + cb4 + 32u * q4);      // INV + ... stays out of range
           }
         };
         load_rs(0, 0, rs[0]);
@@ -478,23 +478,22 @@ __global__ __launch_bounds__(768) void spike_mm_pp_kernel(GemmParams P) {
           __builtin_amdgcn_sched_barrier(0);                    // keep the batches apart: bounded live ranges, no spills
           if (k + 1 < 6) load_rs((k + 1) >> 1, (k + 1) & 1, rs[(k + 1) & 1]);
           __builtin_amdgcn_sched_barrier(0);
-          const float4 bs = *reinterpret_cast<const float4*>(par_s + nb * 32 + 4 * qd);
-          const float4 al = *reinterpret_cast<const float4*>(par_s + BN + nb * 32 + 4 * qd);
-          const float4 be = *reinterpret_cast<const float4*>(par_s + 2 * BN + nb * 32 + 4 * qd);
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) asm volatile("" :: "v"(rs[k & 1][q4].x), "v"(rs[k & 1][q4].w));    // waits pinned here
-          const uint32_t cb4 = (uint32_t)(n0 + nb * 32 + 4 * qd) * 4u;
+          const uint32_t cb4 = (uint32_t)(n0 + nb * 32 + 4 * lh) * 4u;
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {
-            float v[4] = {acc[rb][nb][q4 * 4 + 0], acc[rb][nb][q4 * 4 + 1], acc[rb][nb][q4 * 4 + 2], acc[rb][nb][q4 * 4 + 3]};
-            quad_transpose(v, ql);
-            float4 o = make_float4(v[0] * asc, v[1] * asc, v[2] * asc, v[3] * asc);
+            const float4 bs = *reinterpret_cast<const float4*>(par_s + nb * 32 + 8 * q4 + 4 * lh);
+            const float4 al = *reinterpret_cast<const float4*>(par_s + BN + nb * 32 + 8 * q4 + 4 * lh);
+            const float4 be = *reinterpret_cast<const float4*>(par_s + 2 * BN + nb * 32 + 8 * q4 + 4 * lh);
+            float4 o = make_float4(acc[rb][nb][q4 * 4 + 0] * asc, acc[rb][nb][q4 * 4 + 1] * asc, acc[rb][nb][q4 * 4 + 2] * asc,
+                                   acc[rb][nb][q4 * 4 + 3] * asc);
             o.x += bs.x; o.y += bs.y; o.z += bs.z; o.w += bs.w;
             o.x = __builtin_fmaf(o.x, al.x, be.x); o.y = __builtin_fmaf(o.y, al.y, be.y);
             o.z = __builtin_fmaf(o.z, al.z, be.z); o.w = __builtin_fmaf(o.w, al.w, be.w);
             const float4 r = rs[k & 1][q4];
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-            buf_store16f(out_rs, dst(rb, q4) + cb4, o);
+            buf_store16f(out_rs, dstm[rb] + cb4 + 32u * q4, o);
           }
         }
         }
