@@ -785,24 +785,36 @@ int launch_spike_conv_wres(const GemmParams& Pin, hipStream_t s) {
   P.tiles_n = d.N / NB;
   P.ntiles = P.tiles_m * P.tiles_n;
   P.ksplit = 1; P.spc = 0; P.partial = nullptr;
-  const int G = P.ntiles < 256 ? P.ntiles : 256;
-  dim3 grid((unsigned)G);
+  int G = P.ntiles < 256 ? P.ntiles : 256;
   int rc;
   if (d.nsplit == SDF_PLANES_I8X3) {
     if (c.Cin != 96) return SDF_E_SHAPE;
+    {
+      // a workgroup's wave groups take its items in turn: give every workgroup a whole number of items per group and size the
+      // grid for equal rounds (648 fused items, 3 groups: 216 workgroups x 3 items instead of 256 of which 120 leave a group
+      // idle) - same duration, and the compute units this launch does not need go to the other in-flight forwards' kernels
+      const char* eg0 = getenv("SDF_CONV_WRES_GROUPS");
+      const int ng = (d.sn_T > 0 && th == 8 && (eg0 ? eg0[0] == '3' : true)) ? 3 : 2;
+      const int rounds = (P.ntiles + 256 * ng - 1) / (256 * ng), per = ng * rounds;
+      if (P.ntiles >= 64) G = (P.ntiles + per - 1) / per;
+    }
     // fused-neuron items are T steps long and their epilogue (neuron + two stores) outweighs their MFMAs: with few of them
     // (batch 1: 648 on this shape) THREE groups of waves per workgroup - 768 slots, one item each, the matrix pipe shared
     // three ways - instead of two groups with one or two items each
     const char* eg = getenv("SDF_CONV_WRES_GROUPS");                   // tuning override: 2 or 3
     const bool g3 = d.sn_T > 0 && th == 8 && (eg ? eg[0] == '3' : true);
+    const dim3 grid((unsigned)G);
     if (d.sn_T == 0 && th == 16) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 6, 2, 2>), grid, dim3(512), 0, s, P, d.col_scale);
     else if (d.sn_T == 0) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 6, 1, 2>), grid, dim3(512), 0, s, P, d.col_scale);
     else if (th == 16) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 2, 2>), grid, dim3(512), 0, s, P, d.col_scale);
     else if (g3) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 1, 3>), grid, dim3(768), 0, s, P, d.col_scale);
     else hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 1, 2>), grid, dim3(512), 0, s, P, d.col_scale);
     rc = 0;
-  } else if (d.sn_T == 0) rc = d.nsplit == 1 ? launch_c<1, 0>(P, grid, s) : launch_c<2, 0>(P, grid, s);
-  else rc = d.nsplit == 1 ? launch_c<1, 10>(P, grid, s) : launch_c<2, 10>(P, grid, s);
+  } else {
+    const dim3 grid((unsigned)G);
+    if (d.sn_T == 0) rc = d.nsplit == 1 ? launch_c<1, 0>(P, grid, s) : launch_c<2, 0>(P, grid, s);
+    else rc = d.nsplit == 1 ? launch_c<1, 10>(P, grid, s) : launch_c<2, 10>(P, grid, s);
+  }
   if (rc) return rc;
   hipError_t e = hipGetLastError();
   return e != hipSuccess ? (int)e : 0;
