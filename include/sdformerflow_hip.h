@@ -158,6 +158,9 @@ typedef struct SdfNeuronDesc {
 } SdfNeuronDesc;
 
 int sdf_neuron_fwd(const SdfNeuronDesc* d, void* stream);
+/* n independent neuron calls as ONE launch when they share T in {2, 4, 5, 10, 20} and n <= 6 (otherwise one launch each): the
+ * U-Net decoders' skip inputs - four small tensors that each paid a launch of their own (reference Spiking_modules.py:467-474). */
+int sdf_neuron_multi_fwd(const SdfNeuronDesc* descs, int n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Spike GEMM:  out[M,N] = epilogue( A[M,K] (binary, u8) x W[N,K]^T ).
@@ -395,9 +398,32 @@ typedef struct SdfHeadConvDesc {
   int32_t soft_reset;
   const float* psn_w;
   const float* psn_b;
+  /* strided input (all zero = the packed NHWC layout above): element (b, t, y, x, ci) of the input is
+   * x[b * x_sb + t * x_st + y * x_sy + x * x_sx + x_sc[ci]] - the event voxel (B, bins, 2, H, W) is then read IN PLACE
+   * (reference patch embedding :1775-1784: time step t takes bin t of each polarity; channel ci = (bin group, polarity)),
+   * no re-layout copies in front of the kernel */
+  int64_t x_sb, x_st, x_sy, x_sx;
+  int64_t x_sc[4];
 } SdfHeadConvDesc;
 
 int sdf_head_conv_sn_fwd(const SdfHeadConvDesc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 1x1 strided convolution of a real-valued fp32 NHWC image on the exact fp32 matrix pipe (csrc/pointwise_conv.hip):
+ *   out[img, oy, ox, n] = sum_c x[img, oy*stride, ox*stride, c] * w[n, c] (+ bias[n])
+ * Replaces SpikingPEDLayer.conv_res - the membrane shortcut of the stride-2 patch-embedding projection, the one layer of the
+ * SNN forward that reads a membrane instead of spikes (reference Spiking_modules.py:772-826).
+ *   x (imgs, H, W, Cin) fp32; w (N, Cin) fp32 (the module's (N, Cin, 1, 1)); out (imgs, OH, OW, N) fp32, OH = (H-1)/stride + 1.
+ * Built for Cin = 96, N in {96, 192}; anything else returns SDF_E_SHAPE and the caller keeps its library convolution. */
+typedef struct SdfPointwiseConvDesc {
+  const float* x;
+  const float* w;
+  const float* bias;        /* (N) or NULL */
+  float* out;
+  int32_t imgs, H, W, Cin, N, stride, OH, OW;
+} SdfPointwiseConvDesc;
+
+int sdf_pointwise_conv_f32_fwd(const SdfPointwiseConvDesc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * col2im + eval BatchNorm of a ConvTranspose2d(k=3, s=2, p=1, output_padding=1) on spikes whose nine per-tap products were

@@ -37,12 +37,14 @@ __global__ __launch_bounds__(256) void head_conv_sn_kernel(HeadParams P) {
   const int Cout = 16 * CPT;
 
   // ---- stage the patch (zero outside the image) ----
+  const bool strided = d.x_sy != 0;
   for (int i = tid; i < T * 3 * COLS * CIN; i += 256) {
     const int ci = i % CIN, c = (i / CIN) % COLS, r = (i / (CIN * COLS)) % 3, t = i / (CIN * COLS * 3);
     const int yy = y + r - 1, xx = x0 + c - 1;
     float v = 0.f;
     if ((unsigned)yy < (unsigned)d.H && (unsigned)xx < (unsigned)d.W)
-      v = d.x[((((int64_t)b * T + t) * d.H + yy) * d.W + xx) * CIN + ci];
+      v = strided ? d.x[(int64_t)b * d.x_sb + (int64_t)t * d.x_st + (int64_t)yy * d.x_sy + (int64_t)xx * d.x_sx + d.x_sc[ci]]
+                  : d.x[((((int64_t)b * T + t) * d.H + yy) * d.W + xx) * CIN + ci];
     (&xs_s[0][0][0][0])[i] = v;
   }
   // ---- this lane's weights: w[cout][cin][ky][kx] (the module's own layout) ----

@@ -72,8 +72,7 @@ __device__ __forceinline__ float4 prologue(const NeuronParams& P, float4 x, int 
 
 // T is a compile-time constant (register-resident x) when TT > 0, else runtime (streaming, LIF/IF only).
 template <int TT>
-__global__ __launch_bounds__(256) void neuron_kernel(NeuronParams P) {
-  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void neuron_body(const NeuronParams& P, int64_t q) {
   if (q >= P.quads) return;
   const int T = TT > 0 ? TT : P.d.T;
   const int64_t e = q * 4;
@@ -180,6 +179,33 @@ __global__ __launch_bounds__(256) void neuron_kernel(NeuronParams P) {
   }
 }
 
+template <int TT>
+__global__ __launch_bounds__(256) void neuron_kernel(NeuronParams P) {
+  neuron_body<TT>(P, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+// Several independent neuron calls of the same T as ONE launch (the decoders' skip inputs: four small tensors, each a launch of
+// its own before): workgroup ranges are dealt to the descriptors by `first[]`
+constexpr int MULTI_MAX = 6;
+struct NeuronMulti {
+  NeuronParams p[MULTI_MAX];
+  int first[MULTI_MAX + 1];       // first workgroup of descriptor i; first[n] = grid size
+  int n;
+};
+
+template <int TT>
+__global__ __launch_bounds__(256) void neuron_multi_kernel(NeuronMulti M) {
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < MULTI_MAX; ++k)
+    if (k < M.n && (int)blockIdx.x >= M.first[k]) i = k;
+  i = __builtin_amdgcn_readfirstlane(i);
+  // (select by a chain of wave-uniform compares: an indexed copy of a by-value struct would live in scratch)
+#define SDF_MULTI_CASE(k) if (i == k) { neuron_body<TT>(M.p[k], (int64_t)((int)blockIdx.x - M.first[k]) * 256 + threadIdx.x); return; }
+  SDF_MULTI_CASE(0) SDF_MULTI_CASE(1) SDF_MULTI_CASE(2) SDF_MULTI_CASE(3) SDF_MULTI_CASE(4) SDF_MULTI_CASE(5)
+#undef SDF_MULTI_CASE
+}
+
 // One neuron per lane, any N: the contiguous (T, N) entry points use it when N is not a multiple of 4 (rows of such a
 // buffer are not 16-byte aligned, so the streaming kernel's float4 accesses do not apply).  Same op sequence.
 __global__ __launch_bounds__(256) void neuron_scalar_kernel(const float* __restrict__ x, void* __restrict__ out, float* __restrict__ v_last,
@@ -278,6 +304,52 @@ extern "C" int sdf_neuron_fwd(const SdfNeuronDesc* dp, void* stream) {
       hipLaunchKernelGGL(neuron_kernel<0>, grid, block, 0, s, P);
   }
 #undef SDF_T_CASE
+  SDF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sdf_neuron_multi_fwd(const SdfNeuronDesc* descs, int n, void* stream) {
+  if (!descs) return SDF_E_NULL;
+  if (n < 1) return SDF_E_SHAPE;
+  if (n == 1) return sdf_neuron_fwd(descs, stream);
+  const int T = descs[0].T;
+  bool one = n <= MULTI_MAX && (T == 2 || T == 4 || T == 5 || T == 10 || T == 20);
+  for (int i = 0; i < n; ++i) {
+    const int rc = validate(descs[i]);
+    if (rc) return rc;
+    one = one && descs[i].T == T;
+  }
+  if (!one) {                                                    // mixed T or more than MULTI_MAX descriptors: one launch each
+    for (int i = 0; i < n; ++i) {
+      const int rc = sdf_neuron_fwd(descs + i, stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  NeuronMulti M;
+  M.n = n;
+  int64_t wgs = 0;
+  for (int i = 0; i < n; ++i) {
+    NeuronParams& P = M.p[i];
+    P.d = descs[i];
+    P.quads = descs[i].nb * descs[i].ni / 4;
+    P.rows = descs[i].rowmap ? descs[i].nb * descs[i].ni / descs[i].rowlen : 0;
+    int ex;
+    P.inv_tau = (descs[i].kind == SDF_LIF && frexpf(descs[i].tau, &ex) == 0.5f) ? 1.0f / descs[i].tau : 0.f;
+    M.first[i] = (int)wgs;
+    wgs += (P.quads + 255) / 256;
+    if (wgs >= (1LL << 31)) return SDF_E_SHAPE;
+  }
+  for (int i = n; i <= MULTI_MAX; ++i) M.first[i] = (int)wgs;
+  dim3 grid((unsigned)wgs), block(256);
+  hipStream_t s = sdf_stream(stream);
+  switch (T) {
+    case 2: hipLaunchKernelGGL(neuron_multi_kernel<2>, grid, block, 0, s, M); break;
+    case 4: hipLaunchKernelGGL(neuron_multi_kernel<4>, grid, block, 0, s, M); break;
+    case 5: hipLaunchKernelGGL(neuron_multi_kernel<5>, grid, block, 0, s, M); break;
+    case 10: hipLaunchKernelGGL(neuron_multi_kernel<10>, grid, block, 0, s, M); break;
+    default: hipLaunchKernelGGL(neuron_multi_kernel<20>, grid, block, 0, s, M); break;
+  }
   SDF_LAUNCH_CHECK();
   return 0;
 }

@@ -189,6 +189,8 @@ class MSFlowEngine:
         self.pe_name = U + "encoders.swin3d.patch_embed."
         self.pe_res = [_ResBlock(rb, dev, ns, self.pe_name + f"residual_encoding.resblocks.{i}.") for i, rb in enumerate(pe.residual_encoding.resblocks)]
         self.proj_res_w = pe.proj.conv_res.weight.detach().contiguous(memory_format=torch.channels_last)
+        self.proj_res_w2 = pe.proj.conv_res.weight.detach().float().reshape(pe.proj.conv_res.weight.shape[0], -1).contiguous()
+        self.proj_res_b = None if pe.proj.conv_res.bias is None else pe.proj.conv_res.bias.detach().float().contiguous()
         self.proj_w = _conv_planes(pe.proj.conv.weight, ns)
         self.proj_bn, self.proj_sn = bn_affine(pe.proj.norm_layer, dev), _np(pe.proj.sn, dev)
         self._maps, self._deconv = {}, {}
@@ -317,19 +319,22 @@ class MSFlowEngine:
     # ------------------------------------------------------------------ stages (each usable stand-alone in tests)
     def patch_embed(self, x):
         """(B,bins,2,H,W) -> membrane (B,D,H/4,W/4,C), channel-last (reference Spiking_modules.py:1770-1790)."""
+        xv = x                                                   # the voxel as handed over (the kernel reads its first num_bins bins in place)
         if x.size(1) > self.num_bins:
             x = x[:, :self.num_bins]
         B, T = x.shape[0], self.num_steps
         H, W = x.shape[-2:]
         num_ch = self.num_bins * 2 // T
-        ev = x.permute(0, 2, 3, 4, 1)                                                     # (B,2,H,W,bins)
-        xr = torch.stack([ev[:, i % 2, :, :, (i // 2) * T:(i // 2 + 1) * T] for i in range(num_ch)], -1)   # (B,H,W,T,ch)
-        xr = xr.permute(0, 3, 1, 2, 4).contiguous().view(B * T, H, W, num_ch)               # NHWC, image = (b,t)
-        # head: real-valued 2-channel input -> conv + BN + SN as one kernel (shapes outside its build: library convolution,
-        # then BN + SN fused in the neuron kernel)
-        if hip.head_conv_sn_supported(T, H, W, num_ch, self.head_w_oihw.shape[0]):
-            s = hip.head_conv_sn(xr, self.head_w_oihw, B, T, H, W, self.head_sn, alpha=self.head_bn[0], beta=self.head_bn[1])
+        # head: real-valued 2-channel input -> conv + BN + SN as one kernel that reads the voxel in place (channel ci of step t is
+        # polarity ci % 2 of bin (ci // 2) * T + t; shapes outside its build: re-layout + library convolution, then BN + SN
+        # fused in the neuron kernel)
+        if hip.head_conv_sn_supported(T, H, W, num_ch, self.head_w_oihw.shape[0]) and xv.is_contiguous():
+            s = hip.head_conv_sn(xv, self.head_w_oihw, B, T, H, W, self.head_sn, alpha=self.head_bn[0], beta=self.head_bn[1],
+                                 voxel_bins=xv.shape[1])
         else:
+            ev = x.permute(0, 2, 3, 4, 1)                                                 # (B,2,H,W,bins)
+            xr = torch.stack([ev[:, i % 2, :, :, (i // 2) * T:(i // 2 + 1) * T] for i in range(num_ch)], -1)   # (B,H,W,T,ch)
+            xr = xr.permute(0, 3, 1, 2, 4).contiguous().view(B * T, H, W, num_ch)           # NHWC, image = (b,t)
             y = F.conv2d(xr.permute(0, 3, 1, 2), self.head_w, None, 1, 1).contiguous(memory_format=torch.channels_last)
             s = self._neuron_bd(y.permute(0, 2, 3, 1).view(B, T, H, W, -1), self.head_sn, bn=self.head_bn)
         self._rec(self.pe_name + "head.sn.spiking_neuron.", s, "BDHWC->TBCHW")
@@ -347,8 +352,11 @@ class MSFlowEngine:
         # PED projection: 1x1 stride-2 shortcut on the (real-valued) membrane + SN -> conv3x3 s2 -> BN, summed in the epilogue
         Bm, Dm, h, w, Cc = m.shape
         self._rec(self.pe_name + "proj.sn.spiking_neuron.", s1, "BDHWC->TBCHW")
-        res = F.conv2d(m.view(B * T, h, w, Cc).permute(0, 3, 1, 2), self.proj_res_w, None, 2)
-        res = res.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        if hip.pointwise_conv_supported(Cc, self.proj_res_w2.shape[0]):                # exact fp32 MFMA (csrc/pointwise_conv.hip)
+            res = hip.pointwise_conv_f32(m.view(B * T, h, w, Cc), self.proj_res_w2, 2, self.proj_res_b)
+        else:
+            res = F.conv2d(m.view(B * T, h, w, Cc).permute(0, 3, 1, 2), self.proj_res_w, self.proj_res_b, 2)
+            res = res.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
         return self._conv3x3(s1, self.proj_w, self.proj_w.shape[1], stride=2, bn=self.proj_bn, resid=res)
 
     def attention(self, x, blk: _Block):
@@ -456,6 +464,41 @@ class MSFlowEngine:
         as_gemm = B * D * h * w * 9 * cout * 4 <= 64 << 20
         return as_gemm, (_pad32(cin) if as_gemm else _pad16(cin))
 
+    def _prepare_decoder_images(self, feats, y0, out_size):
+        """NHWC u8 spike images of every decoder level with the skip slices written by one multi-descriptor neuron launch, or None
+        when the pyramid is not regular / a level's head has no one-launch kernel (the per-level path handles those)."""
+        E = len(feats)
+        if out_size is None or E < 2 or E > 6 or feats[0].shape[0] != 1:
+            return None
+        B, D, h0, w0, _ = feats[-1].shape
+        if tuple(y0.shape[2:4]) != (h0, w0):
+            return None
+        imgs, calls, c1 = [], [], y0.shape[-1]
+        for i in range(E):
+            skip = feats[E - 1 - i]
+            h, w = h0 << i, w0 << i
+            if tuple(skip.shape[2:4]) != (h, w):
+                return None
+            wdec, bn, sn = self.decoders[i]
+            cout = wdec.shape[1]
+            pw, pb, psn, nout, w2, b2 = self.preds[i]
+            ok = nout == 2 and out_size[0] % (2 * h) == 0 and out_size[1] % (2 * w) == 0 and \
+                hip.pred_head_supported(D, cout, out_size[0], out_size[1], 2 * h, 2 * w, psn, self.decoders[i + 1][2] if i + 1 < E else None)
+            if not ok:
+                return None
+            C2 = skip.shape[-1]
+            cin = c1 + C2 + (4 if i > 0 else 0)
+            _, cp = self._decoder_geometry(i, B, D, h, w, cin)
+            img = torch.empty((B, D, h, w, cp), dtype=torch.uint8, device=y0.device)
+            if i == 0 and cp != cin:
+                img[..., cin:].zero_()                                  # (levels >= 1: zeroed by the head of the level above)
+            hw = h * w
+            calls.append((skip[0], img[0].view(-1)[c1:], D, hw, C2, C2, hw * C2, cp, hw * cp, sn))
+            imgs.append(img)
+            c1 = cout
+        hip.neuron_multi_fwd(calls)
+        return imgs
+
     def unet_tail(self, feats, out_size=None):
         """res-blocks + decoders + per-scale predictions on channel-last (B,D,h,w,C) features
         (reference Spiking_STSwinNet.py:161-182).  Returns the per-scale predictions (B,D,h',w',2) fp32; with `out_size` = (H, W)
@@ -467,6 +510,10 @@ class MSFlowEngine:
         preds, E = [], len(feats)
         self._flows = [None] * E
         carried = None          # this level's spike image with the [y | prediction] slices already written by the previous level's head
+        # Regular pyramid (every level twice the size of the one before, every prediction head on its one-launch kernel): the
+        # spike images of ALL levels are laid out now and the decoders' neuron on the four skip tensors - four small launches
+        # before - is ONE launch (sdf_neuron_multi_fwd); the [y | prediction] slices arrive from the level above's head.
+        ready = self._prepare_decoder_images(feats, y, out_size) if self.tape is None else None
         for i in range(E):
             skip = feats[E - 1 - i]
             B, D, h, w, _ = skip.shape
@@ -481,7 +528,10 @@ class MSFlowEngine:
                 C1, C2 = y.shape[-1], skip.shape[-1]
                 cin = C1 + C2 + (4 if i > 0 else 0)
                 as_gemm, cp = self._decoder_geometry(i, B, D, h, w, cin)
-                if carried is not None:
+                if ready is not None:
+                    s, c0 = ready[i], 0                                   # skip slice (and padding) already in place; level 0 takes y now
+                    srcs = [(y, C1, C1)] if i == 0 else []
+                elif carried is not None:
                     s, srcs, c0 = carried, [(skip, C2, C2)], C1          # [y | . | prediction | zeros] came from the level above
                 else:
                     s = (torch.zeros if cp != cin else torch.empty)((B, D, h, w, cp), dtype=torch.uint8, device=y.device)
@@ -545,7 +595,7 @@ class MSFlowEngine:
                     C1n, C2n = cout, nxt_skip.shape[-1]
                     cin_n = C1n + C2n + 4
                     _, cp_n = self._decoder_geometry(i + 1, B, D, H2, W2, cin_n)
-                    carried = torch.empty((B, D, H2, W2, cp_n), dtype=torch.uint8, device=y.device)
+                    carried = ready[i + 1] if ready is not None else torch.empty((B, D, H2, W2, cp_n), dtype=torch.uint8, device=y.device)
                     nxt = (carried, self.decoders[i + 1][2], 0, C1n + C2n, (cin_n, cp_n - cin_n))
                 pred, flow, sp = hip.pred_head(z, w2, b2, psn, fs[0] if fs else None, fs[1] if fs else None,
                                                want_pred=self.tape is not None or fs is None or (i + 1 < E and nxt is None),

@@ -24,7 +24,7 @@ EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_s
            "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd", "sdf_head_conv_sn_fwd",
            "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes",
            "sdf_window_slice_map", "sdf_qk_attn_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
-           "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_pred_head_fwd", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
+           "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_pred_head_fwd", "sdf_pointwise_conv_f32_fwd", "sdf_neuron_multi_fwd", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
            "sdf_rows_gather_fwd", "sdf_rows_scatter_fwd",
            "sdf_split_weight_i8x3", "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd",
            "sdf_dense_conv3x3_fwd", "sdf_pack_planes", "sdf_unpack_planes", "sdf_pack_planes_up2", "sdf_dense_linear_fwd", "sdf_layer_norm_fwd")
@@ -73,7 +73,8 @@ class HeadConvDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("alpha", C.c_void_p), ("beta", C.c_void_p), ("out", C.c_void_p),
                 ("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
                 ("sn_kind", C.c_int32), ("tau", C.c_float), ("v_th", C.c_float), ("v_reset", C.c_float),
-                ("soft_reset", C.c_int32), ("psn_w", C.c_void_p), ("psn_b", C.c_void_p)]
+                ("soft_reset", C.c_int32), ("psn_w", C.c_void_p), ("psn_b", C.c_void_p),
+                ("x_sb", C.c_int64), ("x_st", C.c_int64), ("x_sy", C.c_int64), ("x_sx", C.c_int64), ("x_sc", C.c_int64 * 4)]
 
 
 class WinAttnDesc(C.Structure):
@@ -163,9 +164,8 @@ class NeuronParams:
         self.psn_w, self.psn_b = psn_w, psn_b
 
 
-def neuron_fwd(x, out, T, nb, ni, x_sb, x_st, o_sb, o_st, p: NeuronParams, rowmap=None, rowlen=0,
-               alpha=None, beta=None, Cch=0, inner=1, add=None, add_st=0, add_period=0, v_last=None):
-    """sdf_neuron_fwd: see include/sdformerflow_hip.h for the addressing contract."""
+def _neuron_desc(x, out, T, nb, ni, x_sb, x_st, o_sb, o_st, p: NeuronParams, rowmap=None, rowlen=0,
+                 alpha=None, beta=None, Cch=0, inner=1, add=None, add_st=0, add_period=0, v_last=None):
     d = NeuronDesc()
     d.x, d.out, d.v_last = _ptr(x, torch.float32), _ptr(out), _ptr(v_last, torch.float32)
     d.T = T
@@ -181,8 +181,21 @@ def neuron_fwd(x, out, T, nb, ni, x_sb, x_st, o_sb, o_st, p: NeuronParams, rowma
     d.v_reset = 0.0 if p.v_reset is None else float(p.v_reset)
     d.soft_reset = 1 if p.v_reset is None else 0
     d.psn_w, d.psn_b = _ptr(p.psn_w, torch.float32), _ptr(p.psn_b, torch.float32)
+    return d
+
+
+def neuron_fwd(x, out, T, nb, ni, x_sb, x_st, o_sb, o_st, p: NeuronParams, rowmap=None, rowlen=0,
+               alpha=None, beta=None, Cch=0, inner=1, add=None, add_st=0, add_period=0, v_last=None):
+    """sdf_neuron_fwd: see include/sdformerflow_hip.h for the addressing contract."""
+    d = _neuron_desc(x, out, T, nb, ni, x_sb, x_st, o_sb, o_st, p, rowmap, rowlen, alpha, beta, Cch, inner, add, add_st, add_period, v_last)
     _check(lib().sdf_neuron_fwd(C.byref(d), _stream()), "sdf_neuron_fwd")
     return out
+
+
+def neuron_multi_fwd(calls):
+    """sdf_neuron_multi_fwd: `calls` = argument tuples of neuron_fwd; one launch when they share T and are at most six."""
+    descs = (NeuronDesc * len(calls))(*[_neuron_desc(*c) for c in calls])
+    _check(lib().sdf_neuron_multi_fwd(descs, C.c_int(len(calls)), _stream()), "sdf_neuron_multi_fwd")
 
 
 def _pad4(*ts):
@@ -884,13 +897,22 @@ def head_conv_sn_supported(T, H, W, Cin, Cout):
     return (Cin, Cout) in ((2, 32), (2, 48), (2, 64), (4, 48)) and T in (5, 10, 20) and W % 16 == 0
 
 
-def head_conv_sn(x, w, B, T, H, W, p: NeuronParams, alpha=None, beta=None):
-    """sdf_head_conv_sn_fwd: x (B*T,H,W,Cin) fp32 NHWC, w (Cout,Cin,3,3) fp32 -> u8 spikes (B,T,H,W,Cout)."""
+def head_conv_sn(x, w, B, T, H, W, p: NeuronParams, alpha=None, beta=None, voxel_bins=None):
+    """sdf_head_conv_sn_fwd: x (B*T,H,W,Cin) fp32 NHWC, w (Cout,Cin,3,3) fp32 -> u8 spikes (B,T,H,W,Cout).
+    With `voxel_bins`, x is the event voxel (B, bins, 2, H, W) itself, read in place through strides: input channel ci of time
+    step t is polarity ci % 2 of bin (ci // 2) * T + t (reference patch embedding, Spiking_modules.py:1775-1784)."""
     Cout, Cin = w.shape[0], w.shape[1]
     if not x.is_contiguous() or not w.is_contiguous():
-        raise SdfError("head_conv_sn needs contiguous NHWC input and OIHW weights")
+        raise SdfError("head_conv_sn needs a contiguous input and OIHW weights")
     out = torch.empty((B, T, H, W, Cout), dtype=torch.uint8, device=x.device)
     d = HeadConvDesc()
+    if voxel_bins is not None:
+        if tuple(x.shape) != (B, voxel_bins, 2, H, W) or Cin * T > 2 * voxel_bins or Cin > 4:
+            raise SdfError(f"voxel {tuple(x.shape)} does not hold {Cin} channels x {T} steps")
+        hw = H * W
+        d.x_sb, d.x_st, d.x_sy, d.x_sx = voxel_bins * 2 * hw, 2 * hw, W, 1
+        for ci in range(Cin):
+            d.x_sc[ci] = (ci // 2) * T * 2 * hw + (ci % 2) * hw
     d.x, d.w, d.out = _ptr(x, torch.float32), _ptr(w, torch.float32), _ptr(out, torch.uint8)
     d.alpha, d.beta = _ptr(alpha, torch.float32), _ptr(beta, torch.float32)
     d.B, d.T, d.H, d.W, d.Cin, d.Cout = B, T, H, W, Cin, Cout
@@ -910,6 +932,30 @@ def flow_out(pred, H, W, scale_y, scale_x):
     _check(lib().sdf_flow_out_fwd(C.c_void_p(_ptr(pred, torch.float32)), C.c_void_p(out.data_ptr()), C.c_int(B), C.c_int(D), C.c_int(h),
                                   C.c_int(w), C.c_int64(pred.stride(3)), C.c_int(Cc), C.c_int(H), C.c_int(W), C.c_float(scale_y),
                                   C.c_float(scale_x), _stream()), "sdf_flow_out_fwd")
+    return out
+
+
+class PointwiseConvDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("imgs", C.c_int32), ("H", C.c_int32),
+                ("W", C.c_int32), ("Cin", C.c_int32), ("N", C.c_int32), ("stride", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32)]
+
+
+def pointwise_conv_supported(Cin, N):
+    return Cin == 96 and N in (96, 192)
+
+
+def pointwise_conv_f32(x, w, stride, bias=None):
+    """sdf_pointwise_conv_f32_fwd: x (imgs,H,W,Cin) fp32 NHWC, w (N,Cin) fp32 -> (imgs,OH,OW,N) fp32, exact fp32 MFMA."""
+    imgs, H, W, Cin = x.shape
+    N = w.shape[0]
+    if not x.is_contiguous() or not w.is_contiguous() or tuple(w.shape) != (N, Cin):
+        raise SdfError("pointwise_conv_f32 needs a contiguous NHWC image and an (N, Cin) weight")
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.empty((imgs, OH, OW, N), dtype=torch.float32, device=x.device)
+    d = PointwiseConvDesc()
+    d.x, d.w, d.bias, d.out = _ptr(x, torch.float32), _ptr(w, torch.float32), _ptr(bias, torch.float32), out.data_ptr()
+    d.imgs, d.H, d.W, d.Cin, d.N, d.stride, d.OH, d.OW = imgs, H, W, Cin, N, stride, OH, OW
+    _check(lib().sdf_pointwise_conv_f32_fwd(C.byref(d), _stream()), "sdf_pointwise_conv_f32_fwd")
     return out
 
 

@@ -381,6 +381,12 @@ def test_head_conv_bn_neuron(kind, B, T, H, W, Cout):
     rate = (out.cpu().float() != ref).float().mean().item()
     assert rate <= 2e-4, rate
     assert 0.03 < ref.mean() < 0.97
+    # the same input as the event voxel (B, bins, 2, H, W) read IN PLACE through strides (bins = T here, plus two spare bins the
+    # kernel must not touch): bit-equal to the packed NHWC launch
+    vox = torch.full((B, T + 2, 2, H, W), 7.0)
+    vox[:, :T] = x.view(B, T, H, W, 2).permute(0, 1, 4, 2, 3)
+    out2 = hip.head_conv_sn(vox.to(DEV), w.to(DEV), B, T, H, W, p, alpha=alpha.to(DEV), beta=beta.to(DEV), voxel_bins=T + 2)
+    assert torch.equal(out2, out)
 
 
 @pytest.mark.parametrize("h,w,H,W", [(9, 12, 288, 384), (36, 48, 288, 384), (5, 7, 20, 28)])
@@ -807,3 +813,19 @@ def test_window_gather_scatter_equal_the_reference_pad_roll_partition(shape):
     y = WindowScatterFunction.apply((win * 2.0).reshape(-1, Cc), row_map, (B, D, H, W, Cc))
     y.backward(gy)
     assert B2 == B_ and torch.equal(win, win_ref) and torch.equal(y, y_ref) and torch.equal(xm.grad, xr.grad)
+
+
+@pytest.mark.parametrize("imgs,H,W,N,stride", [(3, 10, 14, 96, 2), (2, 9, 7, 192, 2), (1, 6, 5, 96, 1)])
+def test_pointwise_conv_f32_exact_matrix_pipe(imgs, H, W, N, stride):
+    """1x1 strided convolution of a real-valued membrane on the fp32 MFMA (SpikingPEDLayer.conv_res, Spiking_modules.py:819)
+    against fp64: fp32 products and sums, so the error is that of an fp32 dot product of 96 terms."""
+    x = rnd((imgs, H, W, 96), 140, -2.0, 2.0)
+    w = rnd((N, 96), 141, -0.3, 0.3)
+    b = rnd((N,), 142, -0.1, 0.1)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double().view(N, 96, 1, 1), b.double(), stride).permute(0, 2, 3, 1)
+    got = hip.pointwise_conv_f32(x.to(DEV), w.to(DEV), stride, b.to(DEV)).cpu()
+    assert got.shape == ref.shape
+    assert (got.double() - ref).abs().max() <= 2e-6 * ref.abs().max()
+    got0 = hip.pointwise_conv_f32(x.to(DEV), w.to(DEV), stride).cpu()
+    assert (got0.double() - (ref - b.double())).abs().max() <= 2e-6 * ref.abs().max()
+    assert not hip.pointwise_conv_supported(64, 96)

@@ -62,6 +62,10 @@ def check(kind, B, size, seed, en4=True, planes=2, **kw):
         devs.append(float((g - r).abs().max() / r.abs().max()))
     print(f"    flows vs replayed reference: max-abs-dev / max|flow| per scale {['%.1e' % d for d in devs]}")
     assert max(devs) <= FLOW_TOL, devs
+    # the plain forward (no tape: one-launch kernels write nothing but their outputs, the decoders' skip inputs go through one
+    # multi-descriptor neuron launch) is bit-equal to the taped one that was just replayed
+    plain = model(chunk.to(DEV))["flow"]
+    assert all(torch.equal(a, b) for a, b in zip(plain, flows)), "the untaped forward differs from the taped one"
     return flows, ref, summ
 
 
