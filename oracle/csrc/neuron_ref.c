@@ -31,6 +31,8 @@ void ref_lif(const float* x, float* s, float* v_last, int T, int64_t N, float ta
       float h;
       if (is_if) {
         h = v + xi;
+      } else if (tau < 1.f) {     /* ParametricLIFNode: tau carries k = sigmoid(w), the charge multiplies (Spiking_modules.py:75-82) */
+        h = (soft || v_reset == 0.f) ? v + (xi - v) * tau : v + (xi - (v - v_reset)) * tau;
       } else if (soft || v_reset == 0.f) {
         h = v + (xi - v) / tau;
       } else {

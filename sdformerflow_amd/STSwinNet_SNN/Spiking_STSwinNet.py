@@ -214,11 +214,10 @@ class MS_SpikingformerFlowNet(nn.Module):
         if self.training:                     # train-mode forward under autograd (batch-stat BN, HIP neurons both ways)
             from ..train import forward_train
             return {"flow": forward_train(self, x), "attn": None}
-        if log:
-            raise NotImplementedError("attention-score logging (attn_sn, dead on the forward path) is not built")
         with torch.no_grad():
-            flows = self.engine().forward(x)
-        return {"flow": flows, "attn": None}
+            scores = [] if log else None          # reference :283-284; see engine.forward for what the reference's own chain does
+            flows = self.engine().forward(x, scores)
+        return {"flow": flows, "attn": scores}
 
 
 class MS_SpikingformerFlowNet_en4(MS_SpikingformerFlowNet):
@@ -239,4 +238,7 @@ class SpikingformerFlowNet(MS_SpikingformerFlowNet):
     def forward(self, x, log=False):
         if self.training:
             raise NotImplementedError("the SEW family is forward-only here (the training path covers the shipped MS models)")
+        if log:
+            raise NotImplementedError("SEW attention maps (B_, nH, N, N) live in registers of the fused window-attention kernel and "
+                                      "are never materialised; log=True is built for the MS (QK token-gate) family")
         return super().forward(x, log)

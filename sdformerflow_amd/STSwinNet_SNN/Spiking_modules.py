@@ -6,7 +6,7 @@ which fuses BN into the neuron kernels and never materialises the reference's pe
 """
 import torch.nn as nn
 
-from .Spiking_submodules import LIFNode, IFNode, PSN
+from .Spiking_submodules import LIFNode, IFNode, PSN, ParametricLIFNode, SLTTLIFNode, GatedLIFNode
 
 
 class _Surrogate:
@@ -25,7 +25,9 @@ surrogate = _Surrogate
 
 
 class Spiking_neuron(nn.Module):
-    """reference Spiking_modules.py:26-99 - the `neuron_type` switch; lif / if / psn are HIP-backed."""
+    """reference Spiking_modules.py:26-99 - the `neuron_type` switch.  lif / if / psn / plif / SLTTlif run on the HIP kernels
+    (plif: the multiplicative charge through the `tau` field; SLTTlif: LIF forward); glif is torch element-wise ops on the
+    tensor's device (module-level only - the fused engines refuse it)."""
 
     def __init__(self, num_steps, spike_norm=None, neuron_type="plif", v_th=1.0, v_reset=0, surrogate_fun="surrogate.ATan()",
                  tau=2.0, detach_reset=True):
@@ -38,9 +40,17 @@ class Spiking_neuron(nn.Module):
             self.spiking_neuron = IFNode(v_threshold=v_th, v_reset=v_reset, surrogate_function=fn, detach_reset=detach_reset)
         elif neuron_type == "psn":
             self.spiking_neuron = PSN(T=num_steps, surrogate_function=fn)
+        elif neuron_type == "SLTTlif":
+            self.spiking_neuron = SLTTLIFNode(tau=tau, v_threshold=v_th, v_reset=v_reset, surrogate_function=fn,
+                                              detach_reset=detach_reset)
+        elif neuron_type == "plif":
+            self.spiking_neuron = ParametricLIFNode(init_tau=tau, v_threshold=v_th, v_reset=v_reset, surrogate_function=fn,
+                                                    detach_reset=detach_reset)
+        elif neuron_type == "glif":
+            self.spiking_neuron = GatedLIFNode(T=num_steps, init_v_subreset=None, init_tau=0.25, init_v_threshold=0.5,
+                                               init_conduct=0.5, surrogate_function=fn)
         else:
-            raise NotImplementedError(f"neuron_type {neuron_type!r}: only lif / if / psn have a HIP kernel "
-                                      "(plif, glif, SLTTlif are outside SURVEY.md section 8)")
+            raise ValueError(f"neuron type {neuron_type!r} not in the list (lif, if, plif, SLTTlif, glif, psn)")
 
     def forward(self, x):
         return self.spiking_neuron(x)

@@ -11,4 +11,15 @@
   } while (0)
 
 static inline hipStream_t sdf_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+#include <math.h>
+// LIF time constant as the C ABI carries it.  tau > 1: spikingjelly's LIFNode, v += (x - v) / tau - the reciprocal is used where it is
+// exact (tau a power of two; 0 = divide).  0 < tau < 1: the multiplicative form v += (x - v) * tau of ParametricLIFNode, whose
+// multiplier k = sigmoid(w) the caller passes as `tau` (reference Spiking_modules.py:75-82; spikingjelly neuron.ParametricLIFNode).
+static inline bool sdf_tau_ok(int kind, float tau) { return kind != SDF_LIF || tau > 1.f || (tau > 0.f && tau < 1.f); }
+static inline float sdf_inv_tau(int kind, float tau) {
+  if (kind != SDF_LIF) return 0.f;
+  if (tau > 0.f && tau < 1.f) return tau;
+  int ex;
+  return frexpf(tau, &ex) == 0.5f ? 1.0f / tau : 0.f;
+}
 static inline bool sdf_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }

@@ -172,12 +172,11 @@ extern "C" int sdf_head_conv_sn_fwd(const SdfHeadConvDesc* d, void* stream) {
   if (d->alpha && !d->beta) return SDF_E_NULL;
   if (d->sn_kind != SDF_LIF && d->sn_kind != SDF_PSN && d->sn_kind != SDF_IF) return SDF_E_DTYPE;
   if (d->sn_kind == SDF_PSN && (!d->psn_w || !d->psn_b)) return SDF_E_NULL;
-  if (d->sn_kind == SDF_LIF && !(d->tau > 1.f)) return SDF_E_SHAPE;
+  if (!sdf_tau_ok(d->sn_kind, d->tau)) return SDF_E_SHAPE;
   if (!sdf_aligned(d->out, 16)) return SDF_E_ALIGN;
   HeadParams P;
   P.d = *d;
-  int ex;
-  P.inv_tau = (d->sn_kind == SDF_LIF && frexpf(d->tau, &ex) == 0.5f) ? 1.0f / d->tau : 0.f;
+  P.inv_tau = sdf_inv_tau(d->sn_kind, d->tau);
   const int64_t tiles = (int64_t)d->B * d->H * (d->W / 16);
   if (tiles >= (1LL << 31)) return SDF_E_SHAPE;
   dim3 grid((unsigned)tiles);

@@ -494,7 +494,7 @@ bool ms_mlp_fused_supports(const SdfMsMlpDesc* d) {
   for (const SdfNeuronCfg* n : {&d->sn1, &d->sn2}) {
     if (n->kind != SDF_LIF && n->kind != SDF_IF && n->kind != SDF_PSN) return false;
     if (n->kind == SDF_PSN && (!n->psn_w || !n->psn_b)) return false;
-    if (n->kind == SDF_LIF && !(n->tau > 1.f)) return false;
+    if (!sdf_tau_ok(n->kind, n->tau)) return false;
   }
   // C = 192 (stage 1): a work item streams 1.2 MB of weights for 8 positions; with few positions (batch 1 at 288 x 384: 1 728) the
   // three-launch form is as fast (measured 65 us both), from a few thousand on the one-launch form wins (config 5: -30 %)

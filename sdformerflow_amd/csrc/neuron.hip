@@ -243,9 +243,8 @@ int launch_scalar(const float* x, void* spike, float* v_last, int T, int64_t N, 
   if (T < 1 || N < 1) return SDF_E_SHAPE;
   if (spike_dtype != SDF_F32 && spike_dtype != SDF_U8) return SDF_E_DTYPE;
   if (kind == SDF_PSN && (!W || !b)) return SDF_E_NULL;
-  if (kind == SDF_LIF && !(tau > 1.f)) return SDF_E_SHAPE;
-  int ex;
-  const float inv_tau = (kind == SDF_LIF && frexpf(tau, &ex) == 0.5f) ? 1.0f / tau : 0.f;
+  if (!sdf_tau_ok(kind, tau)) return SDF_E_SHAPE;
+  const float inv_tau = sdf_inv_tau(kind, tau);
   hipLaunchKernelGGL(neuron_scalar_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, sdf_stream(stream), x, spike, v_last, T, N,
                      kind, tau, inv_tau, v_th, v_reset, soft_reset, spike_dtype, W, b);
   SDF_LAUNCH_CHECK();
@@ -274,7 +273,7 @@ int validate(const SdfNeuronDesc& d) {
   if (d.kind == SDF_PSN) {
     if (!d.psn_w || !d.psn_b) return SDF_E_NULL;
     if (d.v_last) return SDF_E_SHAPE;
-  } else if (d.kind == SDF_LIF && !(d.tau > 1.f)) {
+  } else if (!sdf_tau_ok(d.kind, d.tau)) {
     return SDF_E_SHAPE;
   }
   if (d.v_last && !sdf_aligned(d.v_last, 16)) return SDF_E_ALIGN;
@@ -291,9 +290,7 @@ extern "C" int sdf_neuron_fwd(const SdfNeuronDesc* dp, void* stream) {
   P.d = *dp;
   P.quads = dp->nb * dp->ni / 4;
   P.rows = dp->rowmap ? dp->nb * dp->ni / dp->rowlen : 0;
-  int ex;
-  float m = frexpf(dp->tau, &ex);
-  P.inv_tau = (dp->kind == SDF_LIF && m == 0.5f) ? 1.0f / dp->tau : 0.f;
+  P.inv_tau = sdf_inv_tau(dp->kind, dp->tau);
   dim3 grid((unsigned)((P.quads + 255) / 256)), block(256);
   hipStream_t s = sdf_stream(stream);
 #define SDF_T_CASE(TT) case TT: hipLaunchKernelGGL(neuron_kernel<TT>, grid, block, 0, s, P); break;
@@ -334,8 +331,7 @@ extern "C" int sdf_neuron_multi_fwd(const SdfNeuronDesc* descs, int n, void* str
     P.d = descs[i];
     P.quads = descs[i].nb * descs[i].ni / 4;
     P.rows = descs[i].rowmap ? descs[i].nb * descs[i].ni / descs[i].rowlen : 0;
-    int ex;
-    P.inv_tau = (descs[i].kind == SDF_LIF && frexpf(descs[i].tau, &ex) == 0.5f) ? 1.0f / descs[i].tau : 0.f;
+    P.inv_tau = sdf_inv_tau(descs[i].kind, descs[i].tau);
     M.first[i] = (int)wgs;
     wgs += (P.quads + 255) / 256;
     if (wgs >= (1LL << 31)) return SDF_E_SHAPE;

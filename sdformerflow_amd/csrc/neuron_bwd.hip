@@ -246,7 +246,7 @@ extern "C" int sdf_lif_bwd(const float* x, const float* grad_spike, float* grad_
   if (N < 4 || N % 4) return SDF_E_SHAPE;
   if (kind != SDF_LIF && kind != SDF_IF) return SDF_E_DTYPE;
   if (surrogate != SDF_SURROGATE_ATAN) return SDF_E_DTYPE;
-  if (kind == SDF_LIF && !(tau > 1.f)) return SDF_E_SHAPE;
+  if (kind == SDF_LIF && !(tau > 1.f)) return SDF_E_SHAPE;        // the multiplicative (PLIF) form has no backward here
   if (!sdf_aligned(x, 16) || !sdf_aligned(grad_spike, 16) || !sdf_aligned(grad_x, 16)) return SDF_E_ALIGN;
   BwdParams P = {};
   P.x = x; P.gs = grad_spike; P.gx = grad_x; P.N = N; P.T = T; P.kind = kind; P.soft = soft_reset; P.detach = detach_reset;

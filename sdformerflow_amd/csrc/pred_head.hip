@@ -175,7 +175,7 @@ bool same_neuron(const SdfNeuronCfg& a, const SdfNeuronCfg& b) {
 int check_neuron(const SdfNeuronCfg& n) {
   if (n.kind != SDF_LIF && n.kind != SDF_PSN && n.kind != SDF_IF) return SDF_E_DTYPE;
   if (n.kind == SDF_PSN && (!n.psn_w || !n.psn_b)) return SDF_E_NULL;
-  if (n.kind == SDF_LIF && !(n.tau > 1.f)) return SDF_E_SHAPE;
+  if (!sdf_tau_ok(n.kind, n.tau)) return SDF_E_SHAPE;
   return 0;
 }
 }  // namespace

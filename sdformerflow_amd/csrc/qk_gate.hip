@@ -92,14 +92,13 @@ extern "C" int sdf_qk_gate_strided_fwd(const uint8_t* q, const uint8_t* k, uint8
   if (ldq < C || ldk < C || ldq % 16 || ldk % 16) return SDF_E_SHAPE;
   if (kind != SDF_LIF && kind != SDF_PSN && kind != SDF_IF) return SDF_E_DTYPE;
   if (kind == SDF_PSN && (!psn_w || !psn_b)) return SDF_E_NULL;
-  if (kind == SDF_LIF && !(tau > 1.f)) return SDF_E_SHAPE;
+  if (!sdf_tau_ok(kind, tau)) return SDF_E_SHAPE;
   if (!sdf_aligned(q, 16) || !sdf_aligned(k, 16) || !sdf_aligned(e, 16)) return SDF_E_ALIGN;
   GateParams P;
   P.q = q; P.k = k; P.e = e; P.Tq = Tq; P.rows = rows; P.C = C; P.G = C / 32;
   P.ldq = ldq; P.ldk = ldk;
   P.kind = kind; P.tau = tau; P.v_th = v_th; P.v_reset = v_reset; P.soft = soft_reset;
-  int ex;
-  P.inv_tau = (kind == SDF_LIF && frexpf(tau, &ex) == 0.5f) ? 1.0f / tau : 0.f;
+  P.inv_tau = sdf_inv_tau(kind, tau);
   P.psn_w = psn_w; P.psn_b = psn_b;
   int64_t n = rows * P.G;
   hipLaunchKernelGGL(qk_gate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sdf_stream(stream), P);

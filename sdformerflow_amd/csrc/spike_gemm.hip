@@ -465,12 +465,11 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
     if (d->pos_count < 1 || d->pos_inner < 1 || d->pos_count * d->sn_T != d->M) return SDF_E_SHAPE;
     if (d->sn_kind != SDF_LIF && d->sn_kind != SDF_PSN && d->sn_kind != SDF_IF) return SDF_E_DTYPE;
     if (d->sn_kind == SDF_PSN && (!d->psn_w || !d->psn_b)) return SDF_E_NULL;
-    if (d->sn_kind == SDF_LIF && !(d->tau > 1.f)) return SDF_E_SHAPE;
+    if (!sdf_tau_ok(d->sn_kind, d->tau)) return SDF_E_SHAPE;
     if (d->add && d->add_prows < 1) return SDF_E_SHAPE;
     if (d->zg_nH > 0 || d->out_rowmap || d->resid || d->bias) return SDF_E_SHAPE;   // F32-only features
     if (!sdf_aligned(d->out_spike, 16) || d->N % 16) return SDF_E_ALIGN;
-    int ex;
-    if (d->sn_kind == SDF_LIF && frexpf(d->tau, &ex) == 0.5f) P.inv_tau = 1.0f / d->tau;
+    P.inv_tau = sdf_inv_tau(d->sn_kind, d->tau);
   } else if (d->zg_nH > 0) {
     if (d->K != d->zg_nH * 32 || d->zg_T < 1 || d->zg_B < 1 || d->zg_N1 < 1) return SDF_E_SHAPE;
     if ((int64_t)d->zg_T * d->zg_B * d->zg_N1 != d->M) return SDF_E_SHAPE;
@@ -567,13 +566,12 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
     if (d->sn_T != 10 || d->pos_count < 1 || d->pos_inner < 1 || d->pos_count * d->sn_T != d->M) return SDF_E_SHAPE;
     if (d->sn_kind != SDF_LIF && d->sn_kind != SDF_PSN && d->sn_kind != SDF_IF) return SDF_E_DTYPE;
     if (d->sn_kind == SDF_PSN && (!d->psn_w || !d->psn_b)) return SDF_E_NULL;
-    if (d->sn_kind == SDF_LIF && !(d->tau > 1.f)) return SDF_E_SHAPE;
+    if (!sdf_tau_ok(d->sn_kind, d->tau)) return SDF_E_SHAPE;
     if (d->out_rowmap || d->bias || d->add) return SDF_E_SHAPE;
     if (d->resid && !d->out) return SDF_E_NULL;                   // a residual only exists for the membrane output
     if (d->out && (d->ldo < d->N || !sdf_aligned(d->out, 4))) return SDF_E_SHAPE;
     if (!sdf_aligned(d->out_spike, 16)) return SDF_E_ALIGN;
-    int ex;
-    if (d->sn_kind == SDF_LIF && frexpf(d->tau, &ex) == 0.5f) P.inv_tau = 1.0f / d->tau;
+    P.inv_tau = sdf_inv_tau(d->sn_kind, d->tau);
   }
   if (!sdf_aligned(d->A, 16) || !sdf_aligned(d->Wp, 16)) return SDF_E_ALIGN;
   ConvGeom& cv = P.cv;

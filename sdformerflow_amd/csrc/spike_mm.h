@@ -118,8 +118,7 @@ __device__ __forceinline__ void neuron_T(const float (&xs)[T], float (&sp)[T], c
 
 // host side: 1 / tau where that is exact (tau a power of two; 0 = divide), and the compile-time class of a neuron setting
 static inline float inv_tau_of(const SdfNeuronCfg& n) {
-  int ex;
-  return (n.kind == SDF_LIF && frexpf(n.tau, &ex) == 0.5f) ? 1.0f / n.tau : 0.f;
+  return sdf_inv_tau(n.kind, n.tau);
 }
 static inline int neuron_class(const SdfNeuronCfg& n) {
   if (n.kind == SDF_PSN) return 1;

@@ -51,16 +51,33 @@ class _Lin:
 def _np(sn_module, device):
     """NeuronParams of a Spiking_neuron wrapper, PSN weights moved to the device."""
     n = sn_module.spiking_neuron
+    if n.kind not in hip.KIND:
+        raise hip.SdfError(f"neuron {type(n).__name__}: no fused kernel (lif / if / psn / plif / SLTTlif have one); it only runs as a "
+                           "stand-alone module (reference Spiking_modules.py:84-92)")
     if n.kind == "psn":
         return hip.NeuronParams("psn", psn_w=n.weight.detach().float().to(device).contiguous(),
                                 psn_b=n.bias.detach().float().reshape(-1).to(device).contiguous())
     return hip.NeuronParams(n.kind, n.tau, n.v_threshold, n.v_reset)
 
 
+def attention_score(e, sn, nH, Tq, B_, N1):
+    """`attn = self.attn_sn(x)` of `Spiking_QK_WindowAttention3D.forward` (reference Spiking_swin_transformer3D.py:709-711) from the
+    gated spikes e (T', B_*N1, C) u8 of one block: the head scramble Z[t,b,n,g,d] = E_flat[((((b nH + g) T' + t) N1 + n) hd + d] as a
+    re-layout (diagnostic path: the score is dead on the forward path, :715-716), then the neuron kernel over T'.
+    -> (T', B_, N1, C) fp32 spikes."""
+    Cc = e.shape[-1]
+    z = e.reshape(B_, nH, Tq, N1, Cc // nH).permute(2, 0, 3, 1, 4).reshape(Tq, B_ * N1 * Cc).float().contiguous()
+    out = torch.empty_like(z)
+    n = z.shape[1]
+    hip.neuron_fwd(z, out, Tq, 1, n, 0, n, 0, n, sn)
+    return out.view(Tq, B_, N1, Cc)
+
+
 class _Block:
     def __init__(self, blk, device, nsplit, name=""):
         self.name = name
         a = blk.attn
+        self.attn_sn = _np(a.attn_sn, device)
         self.nH, self.window_size, self.shift_size = a.num_heads, blk.window_size, blk.shift_size
         self.q = _Lin(a.linear_q, a.bn_q.norm_layer, device, nsplit)
         self.k = _Lin(a.linear_k, a.bn_k.norm_layer, device, nsplit)
@@ -166,7 +183,7 @@ class MSFlowEngine:
         if torch.device(device).type != "cuda":
             raise hip.SdfError("module forwards run on the MI355X HIP engine only (no CPU fallback): move the module and its input to 'cuda'")
         hip.lib()
-        e.device, e.nsplit, e._maps, e._deconv, e.tape, e._masks = torch.device(device), nsplit, {}, {}, None, {}
+        e.device, e.nsplit, e._maps, e._deconv, e.tape, e._masks, e.scores = torch.device(device), nsplit, {}, {}, None, {}, None
         return e
 
     def __init__(self, model):
@@ -195,6 +212,7 @@ class MSFlowEngine:
         self.proj_bn, self.proj_sn = bn_affine(pe.proj.norm_layer, dev), _np(pe.proj.sn, dev)
         self._maps, self._deconv = {}, {}
         self.tape = None            # parity tests set a list: every neuron layer's spikes are recorded (see _rec)
+        self.scores = None          # `log=True`: a list that receives the attention score of the last block of every stage
         self._init_stages(model, unet, sw, dev, ns, U)
 
     def _init_stages(self, model, unet, sw, dev, ns, U):
@@ -359,8 +377,9 @@ class MSFlowEngine:
             res = res.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
         return self._conv3x3(s1, self.proj_w, self.proj_w.shape[1], stride=2, bn=self.proj_bn, resid=res)
 
-    def attention(self, x, blk: _Block):
-        """x (B,D,H,W,C) += SSA(x), in place (reference Spiking_swin_transformer3D.py:781-821, 661-717, :840)."""
+    def attention(self, x, blk: _Block, score_out=None):
+        """x (B,D,H,W,C) += SSA(x), in place (reference Spiking_swin_transformer3D.py:781-821, 661-717, :840).  `score_out` (a list)
+        also receives the block's attention score (T', B_, Wh, Ww, C) - `return_attention=True` (:807-808) without abandoning x."""
         self._check_cl(x)
         B, D, H, W, Cc = x.shape
         ws, ss = get_window_size((D, H, W), blk.window_size, blk.shift_size)
@@ -373,7 +392,7 @@ class MSFlowEngine:
         Tq, N1 = ws[0], ws[1] * ws[2]
         # one C-ABI call: neuron over the gathered slices -> q|k spike GEMM (+BN, +PE, neurons fused) -> token gate ->
         # projection spike GEMM through the head scramble with bias + BN + scatter + residual (csrc/qk_attn.hip)
-        keep = None
+        keep = [] if score_out is not None else None
         if self.tape is not None:
             # the slice spikes are overwritten by the gate inside the call: the tape runs the same kernel on the same input first
             rows, keep = B_ * N1, []
@@ -385,7 +404,11 @@ class MSFlowEngine:
         else:
             hip.qk_attn(x, rowmap, B_, Tq, N1, blk.nH, blk.p, blk.sn_proj, blk.sn_q, blk.sn_k, blk.sn2_q,
                         q_lin=blk.q, k_lin=blk.k, pe=blk.pe, keep_ws=keep)
-        if keep:
+        if score_out is not None:
+            # the gate's output replaced the slice spikes at the head of the workspace (csrc/qk_attn.hip)
+            e = keep[0][:Tq * B_ * N1 * Cc].view(Tq, B_ * N1, Cc)
+            score_out.append(attention_score(e, blk.attn_sn, blk.nH, Tq, B_, N1).view(Tq, B_, ws[1], ws[2], Cc))
+        if keep and self.tape is not None:
             M = Tq * B_ * N1
             qk = keep[0][(M * Cc + 255) // 256 * 256:][:M * 2 * Cc]
             q, k = (qk.view(M, 2 * Cc)[:, :Cc], qk.view(M, 2 * Cc)[:, Cc:]) if blk.qk is not None else (qk[:M * Cc], qk[M * Cc:])
@@ -407,7 +430,8 @@ class MSFlowEngine:
 
     def swin_block(self, x, s, i):
         blk = self.stages[s][i]
-        return self.mlp(self.attention(x, blk), blk)
+        last = self.scores is not None and i == len(self.stages[s]) - 1          # log=True: the last block of every stage (:1090-1105)
+        return self.mlp(self.attention(x, blk, self.scores if last else None), blk)
 
     def patch_merge(self, x, s, packed=None):
         """(B,D,H,W,C) -> (B,D,H/2,W/2,2C) (reference :952-974)."""
@@ -613,12 +637,19 @@ class MSFlowEngine:
             y = z
         return [None if p is None else p[..., :self.preds[0][3]] for p in preds]
 
-    def forward(self, x):
-        """(B,bins,2,H,W) fp32 on the GPU -> list of E flow maps (B,2,H,W) (reference :278-305)."""
+    def forward(self, x, scores=None):
+        """(B,bins,2,H,W) fp32 on the GPU -> list of E flow maps (B,2,H,W) (reference :278-305).  `scores` (a list) receives the
+        `log=True` output (:283-284): the attention score (T', B_, Wh, Ww, C) of the last block of every stage - what the reference's
+        `get_layer_attention_scores` is written to return (its own call chain raises: oracle/sdformer_oracle.py `swin_encoder`)."""
         if not x.is_cuda:
             raise hip.SdfError("input must be a GPU tensor (no CPU fallback)")
         x = x.float().contiguous()
         H, W = x.shape[-2:]
-        preds = self.unet_tail(self.encoder(x), out_size=(H, W))
+        self.scores = scores
+        try:
+            feats = self.encoder(x)
+        finally:
+            self.scores = None
+        preds = self.unet_tail(feats, out_size=(H, W))
         # sum over time + nearest upsampling to the input size: done by the prediction head's launch, else one small kernel per scale
         return [f if f is not None else hip.flow_out(p, H, W, H / p.shape[2], W / p.shape[3]) for p, f in zip(preds, self._flows)]

@@ -44,11 +44,13 @@ def ms_block_forward(mod, x, mask_matrix=None, return_attention=False):
     takes no mask (:661), `mask_matrix` is accepted and unused like in the reference."""
     from .engine import MSFlowEngine, _Block
     _eval_only(mod)
-    if return_attention:
-        raise NotImplementedError("attention-score logging (attn_sn) is dead on the reference's forward path and not built")
     eng, blk = packed(mod, lambda dev: (MSFlowEngine.bare(dev), _Block(mod, dev, 2)))
     with torch.no_grad():
         y = _cl(x).clone()                                             # the engine updates the stream in place
+        if return_attention:                                           # :836-837: the score (T',B_,Wh,Ww,C) instead of the block's output
+            score = []
+            eng.attention(y, blk, score)
+            return score[0]
         return eng.mlp(eng.attention(y, blk), blk)
 
 
@@ -73,7 +75,7 @@ def ms_mlp_forward(mod, x):
 
 def qk_attention_forward(mod, x, mask=None):
     """`Spiking_QK_WindowAttention3D.forward` (reference :661-717): x (T',B_,Wh,Ww,C) window slices -> (out (B_, T'*Wh*Ww, C),
-    None).  The second return value of the reference is `attn_sn(Z)`, which nothing consumes; it is not computed."""
+    attn (T',B_,Wh,Ww,C)), attn = `attn_sn(Z)` (:711) - the attention score that `log=True` collects."""
     from .engine import _Block
     _eval_only(mod)
 
@@ -86,6 +88,7 @@ def qk_attention_forward(mod, x, mask=None):
         b.p = _Lin(a.proj, a.proj_bn.norm_layer, dev, 2)
         b.pe = a.positional_encoding.detach().float().to(dev).contiguous()
         b.sn_proj, b.sn_q, b.sn_k, b.sn2_q = (_np(m, dev) for m in (a.proj_sn, a.sn_q, a.sn_k, a.sn2_q))
+        b.attn_sn = _np(a.attn_sn, dev)
         return b
     blk = packed(mod, build)
     with torch.no_grad():
@@ -105,7 +108,9 @@ def qk_attention_forward(mod, x, mask=None):
         out = torch.empty((M, Cc), dtype=torch.float32, device=x.device)
         hip.spike_gemm(e, blk.p.Wp, out, M, Cc, Cc, bias=blk.p.bias, alpha=blk.p.alpha, beta=blk.p.beta,
                        zg=(blk.nH, Tq, B_, N1))                                                      # head scramble + proj + BN (:709-714)
-        return out.view(B_, Tq * N1, Cc), None                                                      # the raw reshape of :715
+        from .engine import attention_score
+        score = attention_score(e.view(Tq, rows, Cc), blk.attn_sn, blk.nH, Tq, B_, N1).view(Tq, B_, Wh, Ww, Cc)
+        return out.view(B_, Tq * N1, Cc), score                                                     # the raw reshape of :715
 
 
 def ms_patch_merging_forward(mod, x):

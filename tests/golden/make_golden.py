@@ -87,6 +87,38 @@ def gold_neurons():
     save("neurons", **out)
 
 
+def gold_neurons_extra():
+    """The three neuron types no shipped configuration uses (reference Spiking_modules.py:49-56, 75-92), through the reference's own
+    `Spiking_neuron` switch in multi-step mode: plif with a non-trivial w, SLTTlif, glif with random gates."""
+    from models.STSwinNet_SNN.Spiking_modules import Spiking_neuron as RefSN
+    out = {}
+    for T in (4, 10):
+        x = rnd((T, 3, 8, 6, 10), 300 + T, -0.3, 0.6)
+        out[f"x_T{T}"] = x
+        for tag, v_reset in (("soft", None), ("hard", 0.0), ("hard05", 0.05)):
+            for kind in ("plif", "SLTTlif"):
+                if kind == "SLTTlif" and tag == "hard05":
+                    continue
+                m = RefSN(num_steps=T, neuron_type=kind, v_th=0.1, v_reset=v_reset, surrogate_fun="surrogate.ATan()", tau=2.0,
+                          detach_reset=True)
+                if kind == "plif":
+                    m.spiking_neuron.w.fill_(0.3 * T - 2.0)
+                    out[f"plif_T{T}_w"] = m.spiking_neuron.w.data.clone()
+                functional.set_step_mode(m, "m")
+                functional.reset_net(m)
+                m.eval()
+                out[f"{kind}_{tag}_T{T}_s"] = m(x).to(torch.uint8)
+        g = RefSN(num_steps=T, neuron_type="glif", surrogate_fun="surrogate.ATan()")
+        sd = {k: rnd(tuple(v.shape), 700 + 16 * T + i, -1.0, 2.0) for i, (k, v) in enumerate(g.state_dict().items())}
+        g.load_state_dict(sd)
+        functional.reset_net(g)
+        g.eval()
+        for k, v in sd.items():
+            out[f"glif_T{T}/{k}"] = v
+        out[f"glif_T{T}_s"] = g(3.0 * x).to(torch.uint8)                           # gates ~ sigmoid(U(-1, 1)), threshold ~ 0.5
+    save("neurons_extra", **out)
+
+
 # ------------------------------------------------------------------ 2. window index maps
 def gold_index_maps():
     out = {}
@@ -131,6 +163,22 @@ def gold_qk_attention():
         out[f"{tag}_y"] = y
         out[f"{tag}_cfg"] = np.array([B_, C, nH, 7 + C])
     save("qk_attention", **out)
+
+
+def gold_qk_attention_scores():
+    """Second return value of `Spiking_QK_WindowAttention3D.forward` (`attn = self.attn_sn(x)`, :709-711) on the inputs of
+    `gold_qk_attention` - what `log=True` is written to collect per stage (kept in its own file: qk_attention.npz is unchanged)."""
+    out = {}
+    for tag, (B_, C, nH), kind in (("c96_lif", (4, 96, 3), "lif"), ("c96_psn", (4, 96, 3), "psn"),
+                                   ("c192_lif", (2, 192, 6), "lif"), ("c384_psn", (1, 384, 12), "psn")):
+        m = ref_swin.Spiking_QK_WindowAttention3D(C, (2, 9, 9), (0, 0, 0), nH, norm="BN", **spk_kwargs(kind, 10))
+        load_synth(m)
+        x = rnd((2, B_, 9, 9, C), 7 + C, -0.5, 1.0)
+        _, attn = m(x)                                                # (2, B_, 9, 9, C) spikes
+        out[f"{tag}_attn"] = np.packbits(attn.to(torch.uint8).numpy())
+        out[f"{tag}_shape"] = np.array(attn.shape)
+        out[f"{tag}_rate"] = np.array(float(attn.mean()))
+    save("qk_attention_scores", **out)
 
 
 # ------------------------------------------------------------------ 4. a9 SEW attention with mask
@@ -606,8 +654,8 @@ def gold_formats():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["neurons", "index_maps", "qk_attention", "sew_attention", "ann_attention",
-                             "ms_block", "end_to_end", "sew_end_to_end", "ann_end_to_end", "ann_odd_size", "formats", "neuron_grads", "train_block", "train_step", "train_step_forced", "ms_block_config5"]
+    which = sys.argv[1:] or ["neurons", "neurons_extra", "index_maps", "qk_attention", "sew_attention", "ann_attention",
+                             "qk_attention_scores", "ms_block", "end_to_end", "sew_end_to_end", "ann_end_to_end", "ann_odd_size", "formats", "neuron_grads", "train_block", "train_step", "train_step_forced", "ms_block_config5"]
     for w in which:
         globals()["gold_" + w]()
 

@@ -1,5 +1,7 @@
 """GPU parity tests: each HIP kernel, through the C ABI, against the CPU oracle on identical inputs.
 Spikes are compared bit-for-bit; fp32 GEMM outputs to 1e-5 relative (tolerance stated per test)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -829,3 +831,37 @@ def test_pointwise_conv_f32_exact_matrix_pipe(imgs, H, W, N, stride):
     got0 = hip.pointwise_conv_f32(x.to(DEV), w.to(DEV), stride).cpu()
     assert (got0.double() - (ref - b.double())).abs().max() <= 2e-6 * ref.abs().max()
     assert not hip.pointwise_conv_supported(64, 96)
+
+
+@pytest.mark.parametrize("T", [4, 10])
+def test_plif_slttlif_glif_neurons_against_the_reference_fixture(T):
+    """neuron types outside the shipped configurations (reference Spiking_modules.py:49-56, 75-92): plif runs on the LIF kernels through
+    the multiplicative `tau` (0 < tau < 1, csrc/common.h sdf_inv_tau), SLTTlif IS the LIF forward - both bit-equal to the reference
+    switch's output (tests/golden/neurons_extra.npz); glif is torch ops on the GPU tensor (its sigmoid gates may round differently on
+    the device: decisions at the threshold may flip, nothing else)."""
+    import numpy as np
+    from sdformerflow_amd.STSwinNet_SNN.Spiking_modules import Spiking_neuron
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "neurons_extra.npz"))
+    x = torch.from_numpy(g[f"x_T{T}"]).to(DEV)
+    for tag, vr in (("soft", None), ("hard", 0.0), ("hard05", 0.05)):
+        for kind in ("plif", "SLTTlif"):
+            if f"{kind}_{tag}_T{T}_s" not in g:
+                continue
+            m = Spiking_neuron(num_steps=T, neuron_type=kind, v_th=0.1, v_reset=vr, tau=2.0).to(DEV).eval()
+            if kind == "plif":
+                m.load_state_dict({"spiking_neuron.w": torch.from_numpy(g[f"plif_T{T}_w"])})
+                assert 0.0 < m.spiking_neuron.tau < 1.0
+            want = torch.from_numpy(g[f"{kind}_{tag}_T{T}_s"]).to(DEV)
+            assert torch.equal(m(x).to(torch.uint8), want), (kind, tag)
+            # the strided descriptor form (what the engine's fused launches configure) takes the same parameters
+            p = hip.NeuronParams("lif", m.spiking_neuron.tau, 0.1, vr)
+            out = torch.empty(x.shape, dtype=torch.uint8, device=DEV)
+            n = x[0].numel()
+            hip.neuron_fwd(x, out, T, 1, n, 0, n, 0, n, p)
+            assert torch.equal(out, want), (kind, tag)
+    m = Spiking_neuron(num_steps=T, neuron_type="glif").to(DEV).eval()
+    m.load_state_dict({kk[len(f"glif_T{T}/"):]: torch.from_numpy(v) for kk, v in g.items() if kk.startswith(f"glif_T{T}/")})
+    got, want = m(3.0 * x).to(torch.uint8), torch.from_numpy(g[f"glif_T{T}_s"]).to(DEV)
+    assert (got != want).float().mean().item() <= 1e-3
+    with pytest.raises(hip.SdfError):
+        hip.lif_fwd(x, tau=1.0)                                                  # tau = 1 is neither form

@@ -48,8 +48,20 @@ def test_qk_window_attention_module_matches_the_reference_module(tag, kind):
     B_, C, nH, seed = (int(v) for v in g[f"{tag}_cfg"])
     m, _ = load_synth(SW.Spiking_QK_WindowAttention3D(C, (2, 9, 9), (0, 0, 0), nH, norm="BN", **kw(kind, 10)))
     y, attn = m(rnd((2, B_, 9, 9, C), seed, -0.5, 1.0).to(DEV))
-    assert attn is None
     print(tag, "flip-touched", close(y, g[f"{tag}_y"], 2e-3))
+    # second return value: `attn_sn` on the gated tensor (reference :709-711; what log=True collects) against the reference module's.
+    # Binary in, binary out: it differs only where an upstream q / k / token spike flipped at its threshold (the same rate as above)
+    gs = np.load(os.path.join(G, "qk_attention_scores.npz"))
+    want = np.unpackbits(gs[f"{tag}_attn"])[:attn.numel()].reshape(tuple(attn.shape))
+    assert attn.dtype == torch.float32 and tuple(attn.shape) == (2, B_, 9, 9, C)
+    miss = float((attn.cpu().numpy() != want).mean())
+    print(tag, "attention-score mismatches", miss)
+    assert miss <= 2e-3 and abs(float(attn.mean()) - float(gs[f"{tag}_rate"])) <= 2e-3
+    if kind == "lif":                                                          # return_attention=True of the block (:836-837)
+        blk, _ = load_synth(SW.MS_Spiking_SwinTransformerBlock3D(C, (18, 18), nH, window_size=(2, 9, 9), shift_size=(0, 0, 0),
+                                                                 norm_layer="BN", **kw(kind, 4)))
+        sc = blk(rnd((1, 4, 18, 18, C), 19, -0.5, 1.0).to(DEV), None, return_attention=True)
+        assert tuple(sc.shape) == (2, 8, 9, 9, C) and 0.01 < float(sc.mean()) < 0.99
 
 
 @pytest.mark.parametrize("tag,kind", [("lif_sw", "lif"), ("lif_w", "lif"), ("psn_sw", "psn")])

@@ -38,8 +38,17 @@ def _case(B, D, H, W, Cc, kind, ns, seed=0):
     a2, b2 = rnd((Cc,), 905 + seed, 0.5, 1.5), rnd((Cc,), 906 + seed, -0.2, 0.2)
     Wn = rnd((D, D), 907 + seed, -0.5, 0.5) + 0.5 * torch.eye(D)
     bn = torch.full((D,), -0.1)
-    p = hip.NeuronParams(kind, 2.0, 0.1, None, Wn.to(DEV), bn.to(DEV))
+    p = hip.NeuronParams(_kind(kind), _tau(kind), 0.1, None, Wn.to(DEV), bn.to(DEV))
     return x0, W1, W2, a1, b1, a2, b2, Wn, bn, p, _L(W1, a1, b1, ns), _L(W2, a2, b2, ns)
+
+
+def _kind(kind):
+    return "lif" if kind == "plif" else kind
+
+
+def _tau(kind):
+    """'plif' = the multiplicative charge of ParametricLIFNode: the C ABI carries k = sigmoid(w) in the `tau` field (0 < tau < 1)."""
+    return 0.3775406777858734 if kind == "plif" else 2.0
 
 
 def _weff(Wp):
@@ -56,11 +65,11 @@ def _spikes_of(ws, ntok, Cc, Ch):
 
 
 @pytest.mark.parametrize("ns", [2, 3, 1])
-@pytest.mark.parametrize("kind", ["lif", "psn"])
+@pytest.mark.parametrize("kind", ["lif", "psn", "plif"])
 @pytest.mark.parametrize("B,D,H,W,Cc", [(2, 10, 9, 12, 96), (1, 10, 7, 5, 192), (1, 20, 5, 9, 96), (3, 5, 6, 7, 96),
                                         (1, 20, 3, 7, 192)])
 def test_ms_mlp_one_launch_steps_against_the_oracle(B, D, H, W, Cc, kind, ns):
-    if ns != 2 and (kind == "psn" or D != 10):
+    if ns != 2 and (kind != "lif" or D != 10):
         pytest.skip("plane formats 1 / 3 are covered on the shipped T = 10 LIF shapes")
     x0, W1, W2, a1, b1, a2, b2, Wn, bn, p, fc1, fc2 = _case(B, D, H, W, Cc, kind, ns)
     Ch, ntok = 4 * Cc, B * D * H * W
@@ -70,7 +79,7 @@ def test_ms_mlp_one_launch_steps_against_the_oracle(B, D, H, W, Cc, kind, ns):
     s1g, s2g = (t.cpu() for t in _spikes_of(keep[0], ntok, Cc, Ch))
     # (a) SN1 over D: bit-exact
     xt = x0.permute(1, 0, 2, 3, 4).contiguous()                                               # (D,B,H,W,C)
-    s1r = R.neuron_ref(xt, kind, 2.0, 0.1, None, psn_w=Wn, psn_b=bn).permute(1, 0, 2, 3, 4).reshape(ntok, Cc)
+    s1r = R.neuron_ref(xt, _kind(kind), _tau(kind), 0.1, None, psn_w=Wn, psn_b=bn).permute(1, 0, 2, 3, 4).reshape(ntok, Cc)
     assert torch.equal(s1g.float(), s1r), "SN1 spikes differ from the oracle"
     assert 0.03 < s1r.mean() < 0.97
     # (b) SN2 on the kernel's own s1: every decision explained by the reference's margin
@@ -79,7 +88,7 @@ def test_ms_mlp_one_launch_steps_against_the_oracle(B, D, H, W, Cc, kind, ns):
     h = (s1g.double() @ W1e.t()) * a1.double() + b1.double()                                   # (ntok, Ch) rows (b,t,hw)
     ht = h.view(B, D, H * W, Ch).permute(1, 0, 2, 3).float().contiguous()
     got = s2g.view(B, D, H * W, Ch).permute(1, 0, 2, 3).float().contiguous()
-    ncfg = O.NeuronCfg(kind, 0.1, None, 2.0, D)
+    ncfg = O.NeuronCfg(_kind(kind), 0.1, None, _tau(kind), D)
     delta = 16 * 2.0 ** -23 * max(float(ht.pow(2).mean().sqrt()), 0.1)                         # 16 ulp, as tests/replay.py
     rep = O.delta_consistent(ht, got, ncfg, {"w.weight": Wn, "w.bias": bn.view(-1, 1)}, "w.", delta)
     assert rep["unexplained"] == 0, rep

@@ -51,6 +51,33 @@ def test_lif_matches_reference_stub(T):
         assert np.array_equal(v.numpy(), g[f"lif_{tag}_T{T}_v"])                        # bit-exact membrane
 
 
+@pytest.mark.parametrize("T", [4, 10])
+def test_plif_slttlif_glif_match_the_reference_switch(T):
+    """The neuron types no shipped configuration uses (reference Spiking_modules.py:49-56, 75-92; fixture = the reference's own
+    `Spiking_neuron` in multi-step mode): python oracle and C oracle for plif / SLTTlif, the package's torch module for glif."""
+    from oracle import neuron_ref as R
+    from sdformerflow_amd.STSwinNet_SNN.Spiking_modules import Spiking_neuron
+    g = gold("neurons_extra")
+    x = torch.from_numpy(g[f"x_T{T}"])
+    k = float(torch.sigmoid(torch.from_numpy(g[f"plif_T{T}_w"])))
+    assert 0.0 < k < 1.0 and k != 0.5
+    for tag, vr in (("soft", None), ("hard", 0.0), ("hard05", 0.05)):
+        for kind, tau in (("plif", k), ("SLTTlif", 2.0)):
+            if f"{kind}_{tag}_T{T}_s" not in g:
+                continue
+            want = g[f"{kind}_{tag}_T{T}_s"]
+            assert np.array_equal(O.lif_multistep(x, tau, 0.1, vr).numpy().astype(np.uint8), want), (kind, tag)
+            assert np.array_equal(R.neuron_ref(x, "lif", tau, 0.1, vr).numpy().astype(np.uint8), want), (kind, tag)
+            sd = {"n.w": torch.from_numpy(g[f"plif_T{T}_w"])}
+            assert np.array_equal(O.neuron(x, O.NeuronCfg(kind, 0.1, vr, 2.0, T), sd, "n.").numpy().astype(np.uint8), want)
+    m = Spiking_neuron(num_steps=T, neuron_type="glif").eval()
+    m.load_state_dict({kk[len(f"glif_T{T}/"):]: torch.from_numpy(v) for kk, v in g.items() if kk.startswith(f"glif_T{T}/")})
+    got = m(3.0 * x)
+    assert np.array_equal(got.numpy().astype(np.uint8), g[f"glif_T{T}_s"]) and 0.05 < got.mean() < 0.95
+    with pytest.raises(NotImplementedError):
+        m.train()(x)                                                             # inference only, loudly
+
+
 @pytest.mark.parametrize("T", [2, 10, 20])
 def test_psn_matches_reference(T):
     g = gold("neurons")
@@ -100,6 +127,12 @@ def test_qk_attention_matches_reference(tag, kind):
     # explicit gather table == the reshape/permute formulation
     tab = torch.from_numpy(O.z_gather_table(B_, nH, 2, 81, C // nH))
     assert torch.equal(e.reshape(-1)[tab.reshape(-1)].view_as(z), z)
+    # the module's second return value (`attn_sn` on the gated tensor: what log=True collects), bit for bit
+    gs = gold("qk_attention_scores")
+    want = np.unpackbits(gs[f"{tag}_attn"])[:2 * B_ * 81 * C].reshape(2, B_, 81, C)
+    score = O.attention_score(z, sd, "", ncfg(kind, 2))
+    assert tuple(gs[f"{tag}_shape"]) == (2, B_, 9, 9, C) and np.array_equal(score.numpy().astype(np.uint8), want)
+    assert 0.03 < score.mean() < 0.97
 
 
 # ---------------------------------------------------------------- a9

@@ -94,6 +94,39 @@ def test_batch_of_two_three_encoders():
     check("psn", 2, (144, 192), 78, en4=False)
 
 
+def test_plif_and_slttlif_models_three_encoders():
+    """The neuron types no shipped configuration uses (reference Spiking_modules.py:49-56, 75-82) through the whole fused engine:
+    plif's multiplicative charge (k = sigmoid(w), w = -0.1 from the synthetic state) reaches every fused kernel through `tau`."""
+    check("plif", 1, (144, 192), 79, en4=False)
+    check("SLTTlif", 1, (144, 192), 80, en4=False)
+    with pytest.raises(Exception, match="no fused kernel"):
+        build("glif", (144, 192), en4=False)[0].engine()
+
+
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+def test_log_true_attention_scores_equal_the_replayed_oracle(kind):
+    """`model(x, log=True)["attn"]` (reference Spiking_STSwinNet.py:283-284): the attention score `attn_sn(gated k)` of the last block
+    of every stage, (T', B_, Wh, Ww, C).  In the spike-forced replay the oracle's gated tensor IS the GPU's, and `attn_sn` reads 0 / 1
+    inputs (no rounding anywhere): the scores must be bit-equal.  (The reference's own `get_layer_attention_scores` raises for every
+    model - oracle/sdformer_oracle.py `swin_encoder`; the score itself is pinned on the reference module's second return value in
+    tests/test_oracle_golden.py.)"""
+    size = (144, 192)
+    model, sd, ocfg = build(kind, size, en4=False)
+    chunk = harness.prepare_chunk(synth_voxel(1, 10, size[0], size[1], seed=4242))
+    want = []
+    flows, ref, report = replay.run(model.engine(), chunk.to(DEV), chunk, sd, lambda c: O.forward_flownet(c, sd, ocfg, want))
+    assert replay.summarise(report)["unexplained"] == 0
+    out = model(chunk.to(DEV), log=True)
+    assert all(torch.equal(a, b) for a, b in zip(out["flow"], flows))                     # logging does not disturb the forward
+    assert len(out["attn"]) == len(want) == 3
+    for s, (got, w) in enumerate(zip(out["attn"], want)):
+        C = 96 << s
+        assert got.shape[0] == 2 and tuple(got.shape[2:]) == (9, 9, C) and got.dtype == torch.float32
+        assert torch.equal(got.cpu().reshape(w.shape), w), f"stage {s}"
+        assert 0.005 < float(w.mean()) < 0.995, float(w.mean())
+    assert model(chunk.to(DEV))["attn"] is None
+
+
 def test_config5_shape_T20_odd_sizes():
     """20 bins / T = 20, a width whose stage maps need padding and cropping (88 -> 90, 44 -> 45, 22 -> 27, 11 -> 18; reduced from
     480 x 640 so that the oracle finishes in seconds; the smallest stage must still hold one 9 x 9 window, as in the reference)."""
