@@ -41,6 +41,9 @@ int sdf_version(void);
  * Replaces: neuron.LIFNode multi-step forward (reference Spiking_modules.py:40-47,98-99; the
  * CuPy backend of eval_DSEC_flow_SNN.py:118-119).  Arithmetic (each op separately rounded):
  *   h = v + (x_t - v)/tau ; s = (h - v_th >= 0) ; v = h - s*v_th (soft) | (1-s)*h + s*v_reset
+ *   tau > 1: spikingjelly LIFNode.  0 < tau < 1 (every forward entry point and descriptor that carries a neuron): the
+ *   multiplicative charge h = v + (x_t - v)*tau of ParametricLIFNode, tau = sigmoid(w) (reference Spiking_modules.py:75-82).
+ *   tau <= 0 or tau == 1: SDF_E_SHAPE.  The backward entry points take tau > 1 only.
  * v starts at 0 (soft) or v_reset (hard).  `v_last` (fp32, N) receives the final membrane or is NULL.
  */
 int sdf_lif_fwd(const float* x, void* spike, float* v_last, int T, int64_t N, float tau, float v_th,
