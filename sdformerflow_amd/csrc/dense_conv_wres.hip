@@ -37,6 +37,7 @@
 // consecutive halo rows; four consecutive pixels cover the four 64-byte quarters of a 256-byte bank row, and the four rows put
 // the slot they all ask for at four different places of its quarter.  Weight rows are 2K + 16 bytes (4 x odd dwords).
 #include "spike_mm.h"
+#include <stdlib.h>
 
 #ifdef SDF_STAMP
 // diagnostic build only (tools/stamp_dense.sh): cycle accounting of wave 0 of each group of workgroup 0
@@ -51,18 +52,27 @@ __device__ unsigned long long g_dense_stamp[32];
 namespace sdfmm {
 namespace {
 
-constexpr int TH = 4, TW = 8;                   // output pixels of a wave's tile: 32 MFMA rows = 4 rows x 8 pixels
-constexpr int HH = TH + 2, HWID = TW + 2;       // its halo image
+constexpr int TW = 8;                           // a pixel block = 32 MFMA columns = 4 rows x 8 pixels
+constexpr int HWID = TW + 2;                    // halo width
 constexpr int NB = 32;                          // output columns of a workgroup pass
 constexpr int REC = 64;                         // bytes of a pixel record in memory (16 channels, hi + lo)
-constexpr int NW = 12;                          // wavefronts of a workgroup: three per SIMD
 constexpr int PS = 64;                          // pixel stride in the halo image: 4 slots of 16 B = hi 0-7, hi 8-15, lo 0-7, lo 8-15,
                                                 // stored at slot ^ (halo row & 3) - see the bank note above
 constexpr int RPB = HWID * PS;                  // halo row pitch (640 bytes)
-constexpr int HALO = HH * RPB;                  // 3840 bytes per wave
-constexpr int PIECES = HH * HWID * 4;           // 16-byte pieces of a halo image (240)
-constexpr int CPL = (PIECES + 63) / 64;         // pieces per lane
 constexpr uint32_t INV = 0x80000000u;
+// A wave's tile is TPW pixel blocks stacked vertically (4 TPW rows x 8 pixels) over ONE halo image.  TPW = 1: twelve waves (three per
+// SIMD), 3.75 KB images.  TPW = 2: eight waves (two per SIMD), 6.25 KB images; a weight fragment read from LDS feeds two MFMAs (one
+// per block), the halo rows the two blocks share are loaded once, and every per-step instruction is amortised over 54 MFMAs instead
+// of 27: 1.0 instead of 1.33 ds_read_b128 per MFMA (the LDS array was the busiest unit of the TPW = 1 kernel: 4 reads + 8 halo
+// stores per 3 MFMAs x 12 waves is ~90 % of its cycles at full matrix rate, profiles/r2p_pmc_dense.txt).
+template <int TPW>
+struct Geo {
+  static constexpr int TH = 4 * TPW, HH = TH + 2;
+  static constexpr int NW = TPW == 1 ? 12 : 8;
+  static constexpr int HALO = HH * RPB;
+  static constexpr int PIECES = HH * HWID * 4;  // 16-byte pieces of a halo image (240 / 400)
+  static constexpr int CPL = (PIECES + 63) / 64;
+};
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) _Float16 h2;
@@ -99,8 +109,10 @@ __device__ __forceinline__ float4 piece_to(u32x4 v) {
   return make_float4((float)ha.x + (float)la.x, (float)ha.y + (float)la.y, (float)hb.x + (float)lb.x, (float)hb.y + (float)lb.y);
 }
 
-template <int CCH>
-__global__ __launch_bounds__(64 * NW) void dense_conv_wres_kernel(DenseParams P) {
+template <int CCH, int TPW>
+__global__ __launch_bounds__(64 * Geo<TPW>::NW) void dense_conv_wres_kernel(DenseParams P) {
+  constexpr int TH = Geo<TPW>::TH, NW = Geo<TPW>::NW, HALO = Geo<TPW>::HALO, PIECES = Geo<TPW>::PIECES,
+                CPL = Geo<TPW>::CPL;
   constexpr int K = 9 * 16 * CCH;
   constexpr int WP = 2 * K + 16;                                      // weight row pitch (bytes): 4 x odd dwords
   constexpr int W_BYTES = 2 * NB * WP;
@@ -270,9 +282,11 @@ __global__ __launch_bounds__(64 * NW) void dense_conv_wres_kernel(DenseParams P)
     halo_store(hreg[0]);
     request(hreg[1]);
   }
-  f32x16 acc;
-  uint32_t pixoff = INV, pixres = INV;                                // byte offset of this lane's pixel in out / resid (first piece), or INV
-  u32x4 rs[4];
+  f32x16 acc[TPW];
+  uint32_t pixoff[TPW], pixres[TPW];                                  // byte offset of this lane's pixel in out / resid (first piece), or INV
+  u32x4 rs[TPW][4];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) pixoff[t] = pixres[t] = INV;
   int ch = 0;
   // one step: request step s + 2 into `hnew`, multiply step s, then write step s + 1 (requested a step ago, in `hold`)
   auto step = [&](int s, u32x4 (&hnew)[CPL], const u32x4 (&hold)[CPL]) __attribute__((always_inline)) {
@@ -280,35 +294,44 @@ __global__ __launch_bounds__(64 * NW) void dense_conv_wres_kernel(DenseParams P)
     request(hnew);
     if (ch == 0) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
     }
     if (ch == CCH - 1) {
       // the epilogue's addresses and its residual, requested before the last MFMAs: piece q of the lane = channels
       // n0 + 8q + 4*lh .. + 3 = record 2cb + (q >> 1), piece 2(q & 1) + lh of that record
       const int img = pc.img;
-      const int y = pc.ty * TH + (l31 >> 3), x = pc.tx * TW + (l31 & 7);
-      const bool ok = y < H && x < W;
-      const uint32_t pix = (uint32_t)((img * H + y) * W + x);
-      pixres = ok ? (uint32_t)(img * nch + 2 * cb) * (uint32_t)(H * W) * REC + (uint32_t)(y * W + x) * REC + (uint32_t)lh * 16u : INV;
-      pixoff = !ok ? INV : out_f32 ? pix * (uint32_t)N * 4u + (uint32_t)(n0 + 4 * lh) * 4u : pixres;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        rs[q] = u32x4{0u, 0u, 0u, 0u};
-        if (has_res) rs[q] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, ok ? pixres + (uint32_t)((q >> 1) * H * W * REC + (q & 1) * 32) : INV, 0, 0);
+      for (int t = 0; t < TPW; ++t) {
+        const int y = pc.ty * TH + 4 * t + (l31 >> 3), x = pc.tx * TW + (l31 & 7);
+        const bool ok = y < H && x < W;
+        const uint32_t pix = (uint32_t)((img * H + y) * W + x);
+        pixres[t] = ok ? (uint32_t)(img * nch + 2 * cb) * (uint32_t)(H * W) * REC + (uint32_t)(y * W + x) * REC + (uint32_t)lh * 16u : INV;
+        pixoff[t] = !ok ? INV : out_f32 ? pix * (uint32_t)N * 4u + (uint32_t)(n0 + 4 * lh) * 4u : pixres[t];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          rs[t][q] = u32x4{0u, 0u, 0u, 0u};
+          if (has_res)
+            rs[t][q] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, ok ? pixres[t] + (uint32_t)((q >> 1) * H * W * REC + (q & 1) * 32) : INV, 0, 0);
+        }
       }
     }
     STAMP(s1);
 
     // ------------------------------ MFMA phase: 9 taps x 3 products ------------------------------
     constexpr int PF = 2;                                             // taps of fragments in flight
-    bf16x8 fa[PF + 1][2], fb[PF + 1][2];
+    bf16x8 fa[PF + 1][TPW][2], fb[PF + 1][2];
     const uint32_t w_step = w_lane + (uint32_t)ch * (9 * 32);
     auto frag = [&](int tap, int set) __attribute__((always_inline)) {
       const int ky = tap / 3, kx = tap - 3 * ky;
-      fa[set][0] = *reinterpret_cast<const bf16x8*>(H_s + a_row[ky] + kx * PS);
-      fa[set][1] = *reinterpret_cast<const bf16x8*>(H_s + (a_row[ky] ^ 32u) + kx * PS);
       fb[set][0] = *reinterpret_cast<const bf16x8*>(W_s + w_step + tap * 32);
       fb[set][1] = *reinterpret_cast<const bf16x8*>(W_s + w_step + (NB * WP + tap * 32));
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {                                  // block t sits 4 halo rows lower: same swizzle (4 = 0 mod 4)
+        fa[set][t][0] = *reinterpret_cast<const bf16x8*>(H_s + a_row[ky] + (kx * PS + t * 4 * RPB));
+        fa[set][t][1] = *reinterpret_cast<const bf16x8*>(H_s + (a_row[ky] ^ 32u) + (kx * PS + t * 4 * RPB));
+      }
     };
 #pragma unroll
     for (int i = 0; i < PF; ++i) frag(i, i);
@@ -317,9 +340,12 @@ __global__ __launch_bounds__(64 * NW) void dense_conv_wres_kernel(DenseParams P)
       if (tap + PF < 9) frag(tap + PF, (tap + PF) % (PF + 1));
       __builtin_amdgcn_sched_barrier(0);
       const int f = tap % (PF + 1);
-      acc = mma<2>(fb[f][0], fa[f][1], acc);                          // w_hi * a_lo: small terms first
-      acc = mma<2>(fb[f][1], fa[f][0], acc);                          // w_lo * a_hi
-      acc = mma<2>(fb[f][0], fa[f][0], acc);                          // w_hi * a_hi
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) acc[t] = mma<2>(fb[f][0], fa[f][t][1], acc[t]);   // w_hi * a_lo: small terms first
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) acc[t] = mma<2>(fb[f][1], fa[f][t][0], acc[t]);   // w_lo * a_hi
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) acc[t] = mma<2>(fb[f][0], fa[f][t][0], acc[t]);   // w_hi * a_hi
       __builtin_amdgcn_sched_barrier(0);
     }
     STAMP(s2);
@@ -330,14 +356,16 @@ __global__ __launch_bounds__(64 * NW) void dense_conv_wres_kernel(DenseParams P)
     // ------------------------------ epilogue after the last channel step ------------------------------
     if (ch == CCH - 1) {
 #pragma unroll
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 al4 = *reinterpret_cast<const float4*>(par_s + 8 * q + 4 * lh);
         const float4 be4 = *reinterpret_cast<const float4*>(par_s + NB + 8 * q + 4 * lh);
         float4 o;
-        o.x = __builtin_fmaf(acc[q * 4 + 0], al4.x, be4.x); o.y = __builtin_fmaf(acc[q * 4 + 1], al4.y, be4.y);
-        o.z = __builtin_fmaf(acc[q * 4 + 2], al4.z, be4.z); o.w = __builtin_fmaf(acc[q * 4 + 3], al4.w, be4.w);
+        o.x = __builtin_fmaf(acc[t][q * 4 + 0], al4.x, be4.x); o.y = __builtin_fmaf(acc[t][q * 4 + 1], al4.y, be4.y);
+        o.z = __builtin_fmaf(acc[t][q * 4 + 2], al4.z, be4.z); o.w = __builtin_fmaf(acc[t][q * 4 + 3], al4.w, be4.w);
         if (has_res) {
-          const float4 r = piece_to(rs[q]);
+          const float4 r = piece_to(rs[t][q]);
           o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         if (relu) {
@@ -348,12 +376,12 @@ __global__ __launch_bounds__(64 * NW) void dense_conv_wres_kernel(DenseParams P)
         uint32_t off;
         if (out_f32) {
           st.x = __float_as_uint(o.x); st.y = __float_as_uint(o.y); st.z = __float_as_uint(o.z); st.w = __float_as_uint(o.w);
-          off = pixoff + (uint32_t)(q * 32);
+          off = pixoff[t] + (uint32_t)(q * 32);
         } else {
           st = piece_from(o);
-          off = pixoff + (uint32_t)((q >> 1) * H * W * REC + (q & 1) * 32);
+          off = pixoff[t] + (uint32_t)((q >> 1) * H * W * REC + (q & 1) * 32);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(st, out_rs, pixoff != INV ? off : INV, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(st, out_rs, pixoff[t] != INV ? off : INV, 0, 0);
       }
     }
     if (++ch == CCH) { ch = 0; advance(pc); }
@@ -496,15 +524,22 @@ extern "C" int sdf_dense_conv3x3_fwd(const SdfDenseConvDesc* d, void* stream) {
   if (px * (d->x_records > 0 ? d->x_records : d->cin_records) * REC >= lim || px * d->N * 4 >= lim) return SDF_E_SHAPE;   // 31-bit buffer offsets
   DenseParams P;
   P.d = *d;
-  P.wtiles = (int)((int64_t)d->imgs * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW));
   const int ncb = d->N / NB;
   if (ncb > 32) return SDF_E_SHAPE;
+  // two pixel blocks per wave where the map is tall enough for 8-row tiles to waste little (a 36-row map would multiply 40 rows)
+  static const int tpw_env = [] { const char* e = getenv("SDF_DENSE_TPW"); return e ? atoi(e) : 0; }();
+  const int waste8 = ((d->H + 7) / 8) * 8 - d->H, waste4 = ((d->H + 3) / 4) * 4 - d->H;
+  int tpw = (d->cin_records == 6 && (waste8 == waste4 || d->H >= 128)) ? 2 : 1;
+  if (d->cin_records == 6 && (tpw_env == 1 || tpw_env == 2)) tpw = tpw_env;
+  const int TH = 4 * tpw, NW = tpw == 1 ? Geo<1>::NW : Geo<2>::NW;
+  P.wtiles = (int)((int64_t)d->imgs * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW));
   const int want = (P.wtiles + NW - 1) / NW;                           // a workgroup wants at least one tile per wave
   P.ranges = want < 256 / ncb ? want : 256 / ncb;
   const int G = P.ranges == 256 / ncb ? 256 : P.ranges * ncb;
   hipStream_t s = sdf_stream(stream);
-  if (d->cin_records == 1) hipLaunchKernelGGL((dense_conv_wres_kernel<1>), dim3(G), dim3(64 * NW), 0, s, P);
-  else hipLaunchKernelGGL((dense_conv_wres_kernel<6>), dim3(G), dim3(64 * NW), 0, s, P);
+  if (d->cin_records == 1) hipLaunchKernelGGL((dense_conv_wres_kernel<1, 1>), dim3(G), dim3(64 * NW), 0, s, P);
+  else if (tpw == 1) hipLaunchKernelGGL((dense_conv_wres_kernel<6, 1>), dim3(G), dim3(64 * NW), 0, s, P);
+  else hipLaunchKernelGGL((dense_conv_wres_kernel<6, 2>), dim3(G), dim3(64 * NW), 0, s, P);
   SDF_LAUNCH_CHECK();
   return 0;
 }
