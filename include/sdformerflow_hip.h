@@ -385,9 +385,10 @@ int sdf_qk_gate_strided_fwd(const uint8_t* q, const uint8_t* k, uint8_t* e, int 
  * one kernel, spikes out.  Replaces MS_PED_Spiking_PatchEmbed_Conv_sfn.head (reference Spiking_modules.py:1782).
  *   x   (B*T, H, W, Cin) fp32, NHWC, image index = b*T + t          w (Cout, Cin, 3, 3) fp32 (the module's layout)
  *   out (B*T, H, W, Cout) u8 spikes                                  alpha / beta (Cout) or NULL
- * Accumulation: one fmaf chain per output in (ky, kx, cin) order starting from 0.  Built for (Cin, Cout) in
- * {(2,32), (2,48), (2,64), (4,48)}, T in {5, 10, 20}, W % 16 == 0; anything else returns SDF_E_SHAPE and the caller keeps
- * its library convolution + sdf_neuron_fwd pair.
+ * Accumulation: fp32 products and sums in (ky, kx, cin) order - on the exact fp32 matrix pipe (v_mfma_f32_32x32x2_f32) for LIF / IF
+ * neurons when W % 32 == 0, else (and for the PSN, which needs all T pre-activations at once) one fmaf chain per output on the
+ * vector pipe.  Built for (Cin, Cout) in {(2,32), (2,48), (2,64), (4,48)}, T in {5, 10, 20}, W % 16 == 0; anything else returns
+ * SDF_E_SHAPE and the caller keeps its library convolution + sdf_neuron_fwd pair.
  */
 typedef struct SdfHeadConvDesc {
   const float* x;

@@ -12,6 +12,7 @@
 //      resolution (reference Spiking_STSwinNet.py:289-303: flow.sum(0) then F.interpolate(scale_factor=H/h, W/w)).
 // Compiled with -ffp-contract=off (the neuron arithmetic is the separately-rounded op sequence of neuron.hip).
 #include "spike_mm.h"
+#include <stdlib.h>
 
 namespace {
 using sdfmm::lif_steps;
@@ -110,6 +111,151 @@ __global__ __launch_bounds__(256) void head_conv_sn_kernel(HeadParams P) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same head on the exact fp32 matrix pipe (LIF / IF neurons; the PSN keeps the kernel above: it needs all T pre-activations of a
+// channel at once).  A wave owns 32 consecutive pixels of one image row for all T steps:
+//   * v_mfma_f32_32x32x2_f32, the WEIGHTS as the row operand (9 * Cin / 2 registers per 32-channel block, loaded once per wave), the
+//     pixels as the column operand: k-step s multiplies (tap, channel) pairs k = 2s + (lane / 32), i.e. with Cin = 2 one tap per
+//     step, lane half = polarity.  fp32 products and sums - the numerics of an fmaf chain, no 16-bit split;
+//   * the operand values come straight from the voxel by buffer loads (lanes = consecutive x: coalesced; the 9 taps are L1 hits;
+//     the time step is the instruction's scalar offset; outside the image the lane's offset is out of range -> 0), requested one
+//     step ahead of the MFMAs that consume them;
+//   * a lane's accumulator quads are 4 consecutive channels of its pixel: BatchNorm and the neuron step run on them in registers
+//     (the membrane of 16 channels per block lives in the lane across the T steps), four spikes pack to one dword;
+//   * spikes leave through a wave-private LDS tile (T' steps x 32 pixels x Cout bytes) as whole 16-byte pieces of the NHWC image.
+// The first version (above) spent 108 us on config 2's 288 x 384 head - 4.5 x its own FMA issue time, on per-lane weight loads,
+// index arithmetic and byte traffic through LDS; this one takes 50 us (profiles/r3p_forward_sequence.txt): 2.5 GFLOP incl. the
+// padding of 48 channels to 64 rows is 16 us of the fp32 matrix pipe, the BatchNorm + LIF + packing of 24 outputs per lane and
+// step is about as many vector cycles, and two waves per SIMD (186 registers) overlap the two only partly.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4h;
+
+template <int T, int CIN, int NOUT, bool FAST>
+__global__ __launch_bounds__(256) void head_conv_mfma_kernel(HeadParams P, int tiles) {
+  constexpr int KS = 9 * CIN / 2, NBLK = (NOUT + 31) / 32, TF = 5, ROW = 32 * NOUT;        // ROW: spike bytes of a tile per time step
+  static_assert(T % TF == 0, "flush period");
+  const SdfHeadConvDesc& d = P.d;
+  __shared__ __attribute__((aligned(16))) uint8_t sp_s[4][TF][ROW];
+  __shared__ __attribute__((aligned(16))) float par_s[2][32 * NBLK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  if (tid < 32 * NBLK) {
+    par_s[0][tid] = (tid < NOUT && d.alpha) ? d.alpha[tid] : 1.f;
+    par_s[1][tid] = (tid < NOUT && d.alpha) ? d.beta[tid] : 0.f;
+  }
+  // this lane's weights: row = channel 32 blk + l31, k = 2s + lh -> (tap, ci); module layout w[cout][cin][ky][kx]
+  float wa[NBLK][KS];
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk)
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_) {
+      const int k = 2 * s_ + lh, tap = k / CIN, ci = k - tap * CIN, n = 32 * blk + l31;
+      wa[blk][s_] = n < NOUT ? d.w[(n * CIN + ci) * 9 + tap] : 0.f;
+    }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, 0x7FFFFFFF, 0x00020000);
+  const int xt = d.W >> 5;
+  const bool soft = d.soft_reset != 0, is_if = d.sn_kind == SDF_IF;
+  constexpr bool fast = FAST;                                          // LIF, soft reset, multiplicative charge (the shipped setting)
+  const bool reset0 = soft || d.v_reset == 0.f;
+  const float v_th = d.v_th, v_reset = d.v_reset, tau = d.tau, inv_tau = P.inv_tau;
+  uint8_t* my_s = &sp_s[wave][0][0];
+
+#pragma unroll 1
+  for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
+    const int x0 = (tile % xt) << 5, y = (tile / xt) % d.H, b = tile / (xt * d.H);
+    // byte offsets of this lane's KS operand values at t = 0 (0x80000000 = outside the image: the load returns 0)
+    uint32_t off[KS];
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_) {
+      const int k = 2 * s_ + lh, tap = k / CIN, ci = k - tap * CIN;
+      const int yy = y + tap / 3 - 1, xx = x0 + l31 + tap % 3 - 1;
+      const bool ok = (unsigned)yy < (unsigned)d.H && (unsigned)xx < (unsigned)d.W;
+      off[s_] = ok ? (uint32_t)(((int64_t)b * d.x_sb + (int64_t)yy * d.x_sy + (int64_t)xx * d.x_sx + d.x_sc[ci]) * 4) : 0x80000000u;
+    }
+    const uint32_t st4 = (uint32_t)(d.x_st * 4);
+    float xin[2][KS];
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_) xin[0][s_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rs, off[s_], 0, 0));
+    float v[NBLK][16];
+#pragma unroll
+    for (int blk = 0; blk < NBLK; ++blk)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[blk][e] = soft ? 0.f : v_reset;
+
+    auto one_step = [&](int t, const float (&xc)[KS], float (&xn)[KS]) __attribute__((always_inline)) {
+      if (t + 1 < T) {
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_)
+          xn[s_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rs, off[s_], (uint32_t)(t + 1) * st4, 0));
+      }
+      f32x16 acc[NBLK];
+#pragma unroll
+      for (int blk = 0; blk < NBLK; ++blk)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[blk][e] = 0.f;
+#pragma unroll
+      for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+        for (int blk = 0; blk < NBLK; ++blk) acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[blk][s_], xc[s_], acc[blk], 0, 0, 0);
+      uint8_t* row = my_s + (t % TF) * ROW + l31 * NOUT + 4 * lh;
+      int pofs = 4 * lh;                                                // the BatchNorm pairs are re-read every step (not kept in 48 registers)
+      asm volatile("" : "+v"(pofs));
+#pragma unroll
+      for (int blk = 0; blk < NBLK; ++blk)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (32 * blk + 8 * q >= NOUT) continue;                       // padding rows of the last block
+          const float4 al = *reinterpret_cast<const float4*>(&par_s[0][32 * blk + 8 * q + pofs]);
+          const float4 be = *reinterpret_cast<const float4*>(&par_s[1][32 * blk + 8 * q + pofs]);
+          const float a4[4] = {al.x, al.y, al.z, al.w}, b4[4] = {be.x, be.y, be.z, be.w};
+          uint32_t word = 0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float xv = __builtin_fmaf(acc[blk][4 * q + i], a4[i], b4[i]);
+            float& vm = v[blk][4 * q + i];
+            bool fire;
+            if constexpr (fast) {
+              const float h = vm + (xv - vm) * inv_tau;
+              fire = h - v_th >= 0.f;
+              vm = fire ? h - v_th : h;
+            } else {
+              float h;
+              if (is_if) h = vm + xv;
+              else {
+                const float dl = reset0 ? (xv - vm) : (xv - (vm - v_reset));
+                h = vm + ((inv_tau != 0.f) ? dl * inv_tau : dl / tau);
+              }
+              fire = h - v_th >= 0.f;
+              const float sp = fire ? 1.f : 0.f;
+              vm = soft ? (h - sp * v_th) : ((1.f - sp) * h + sp * v_reset);
+            }
+            word |= fire ? (1u << (8 * i)) : 0u;
+          }
+          *reinterpret_cast<uint32_t*>(row + 32 * blk + 8 * q) = word;
+        }
+      if (t % TF == TF - 1) {                                           // whole 16-byte pieces of TF rows of the NHWC spike image
+        constexpr int PT = ROW / 16, PIECES = TF * PT;
+        const int t0 = t - (TF - 1);
+        const uint32_t obase = (uint32_t)(((((int64_t)b * T + t0) * d.H + y) * d.W + x0) * NOUT), ostep = (uint32_t)(d.H * d.W * NOUT);
+#pragma unroll
+        for (int j = 0; j < (PIECES + 63) / 64; ++j) {
+          const int pc = lane + 64 * j;
+          const int tt = pc / PT, o = (pc - tt * PT) * 16;
+          const u32x4h val = *reinterpret_cast<const u32x4h*>(my_s + (pc < PIECES ? tt * ROW + o : 0));
+          __builtin_amdgcn_raw_buffer_store_b128(val, o_rs, pc < PIECES ? obase + (uint32_t)tt * ostep + (uint32_t)o : 0x80000000u, 0, 0);
+        }
+      }
+    };
+#pragma unroll 1
+    for (int t = 0; t < T; t += 2) {                                    // T is odd only for T = 5: the guard is uniform
+      one_step(t, xin[0], xin[1]);
+      if (t + 1 < T) one_step(t + 1, xin[1], xin[0]);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void flow_out_kernel(const float* __restrict__ pred, float* __restrict__ out, int B, int D,
                                                        int h, int w, int64_t ldp, int C, int H, int W, float sy, float sx) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -157,6 +303,23 @@ __global__ __launch_bounds__(256) void deconv_col2im_kernel(const float* __restr
 }
 
 template <int T>
+int launch_head_mfma(const HeadParams& P, hipStream_t s) {
+  const int tiles = P.d.B * P.d.H * (P.d.W / 32);
+  const int want = (tiles + 3) / 4;
+  dim3 grid((unsigned)(want < 768 ? want : 768));                  // three workgroups per CU are resident; the rest of the tiles loop
+  const bool fast = P.d.sn_kind == SDF_LIF && P.d.soft_reset != 0 && P.inv_tau != 0.f;
+#define SDF_HEAD_CASE(CI, CO)                                                                                              \
+  if (P.d.Cin == CI && P.d.Cout == CO) {                                                                                   \
+    if (fast) hipLaunchKernelGGL((head_conv_mfma_kernel<T, CI, CO, true>), grid, dim3(256), 0, s, P, tiles);               \
+    else hipLaunchKernelGGL((head_conv_mfma_kernel<T, CI, CO, false>), grid, dim3(256), 0, s, P, tiles);                   \
+    return 0;                                                                                                              \
+  }
+  SDF_HEAD_CASE(2, 48) SDF_HEAD_CASE(2, 32) SDF_HEAD_CASE(2, 64) SDF_HEAD_CASE(4, 48)
+#undef SDF_HEAD_CASE
+  return SDF_E_SHAPE;
+}
+
+template <int T>
 int launch_head(const HeadParams& P, dim3 grid, hipStream_t s) {
   if (P.d.Cin == 2 && P.d.Cout == 48) { hipLaunchKernelGGL((head_conv_sn_kernel<T, 3, 2>), grid, dim3(256), 0, s, P); return 0; }
   if (P.d.Cin == 2 && P.d.Cout == 32) { hipLaunchKernelGGL((head_conv_sn_kernel<T, 2, 2>), grid, dim3(256), 0, s, P); return 0; }
@@ -181,7 +344,32 @@ extern "C" int sdf_head_conv_sn_fwd(const SdfHeadConvDesc* d, void* stream) {
   if (tiles >= (1LL << 31)) return SDF_E_SHAPE;
   dim3 grid((unsigned)tiles);
   hipStream_t s = sdf_stream(stream);
+  if (d->x_sy == 0) {                                                  // the packed NHWC layout as strides
+    P.d.x_sb = (int64_t)d->T * d->H * d->W * d->Cin; P.d.x_st = (int64_t)d->H * d->W * d->Cin;
+    P.d.x_sy = (int64_t)d->W * d->Cin; P.d.x_sx = d->Cin;
+    for (int ci = 0; ci < 4; ++ci) P.d.x_sc[ci] = ci;
+  }
+  // fp32 matrix-pipe kernel: LIF / IF, 32-pixel tiles, 31-bit byte offsets into the voxel
+  static const bool no_mfma = [] { const char* e = getenv("SDF_HEAD_MFMA"); return e && e[0] == '0'; }();
+  int64_t span = (int64_t)(d->B - 1) * P.d.x_sb + (int64_t)(d->T - 1) * P.d.x_st + (int64_t)(d->H - 1) * P.d.x_sy + (int64_t)(d->W - 1) * P.d.x_sx;
+  int64_t scmax = 0;
+  for (int ci = 0; ci < d->Cin && ci < 4; ++ci) scmax = P.d.x_sc[ci] > scmax ? P.d.x_sc[ci] : scmax;
+  const bool mfma_ok = !no_mfma && d->sn_kind != SDF_PSN && d->W % 32 == 0 && (span + scmax + 1) * 4 < (1LL << 31) && d->Cin <= 4 &&
+                       (int64_t)d->B * d->T * d->H * d->W * d->Cout < (1LL << 31) &&
+                       P.d.x_sb >= 0 && P.d.x_st >= 0 && P.d.x_sy >= 0 && P.d.x_sx >= 0;
   int rc;
+  if (mfma_ok) {
+    switch (d->T) {
+      case 5: rc = launch_head_mfma<5>(P, s); break;
+      case 10: rc = launch_head_mfma<10>(P, s); break;
+      case 20: rc = launch_head_mfma<20>(P, s); break;
+      default: rc = SDF_E_SHAPE;
+    }
+    if (rc) return rc;
+    SDF_LAUNCH_CHECK();
+    return 0;
+  }
+  P.d = *d;
   switch (d->T) {
     case 5: rc = launch_head<5>(P, grid, s); break;
     case 10: rc = launch_head<10>(P, grid, s); break;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch sequence of ONE steady-state eager forward from a rocprofv3 --kernel-trace CSV of tools/forward_one.py: the launches
-between the last two `head_conv_sn_kernel` markers (start offset, gap, duration, workgroups, LDS, kernel) + a per-kernel summary.
+between the last two `head_conv_*` launches (start offset, gap, duration, workgroups, LDS, kernel) + a per-kernel summary.
 usage: prof_seq2.py <dir> [marker]"""
 import csv
 import glob
@@ -8,7 +8,7 @@ import sys
 from collections import OrderedDict
 
 d = sys.argv[1]
-marker = sys.argv[2] if len(sys.argv) > 2 else "head_conv_sn_kernel"
+marker = sys.argv[2] if len(sys.argv) > 2 else "head_conv_"
 f = glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
