@@ -77,17 +77,9 @@ __device__ __forceinline__ void signal(uint32_t* p, int lane) {
   if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// 8 spike bytes {0,1} -> 8 x 16-bit {0, 1.0}; the 24-bit multiply is a full-rate VALU op (the operands are 17 / 14 bits)
+// 8 activation bytes -> 8 x 16-bit values (spike_mm.h `expand_spikes`: fp16 planes take any byte value exactly)
 template <int NSPLIT>
-__device__ __forceinline__ bf16x8 expand_spikes24(uint2 v) {
-  constexpr uint32_t ONE = NSPLIT == 2 ? 0x3C00u : 0x3F80u;
-  union { bf16x8 h; uint32_t u[4]; } r;
-  r.u[0] = __umul24(__builtin_amdgcn_perm(0u, v.x, 0x0c010c00u), ONE);
-  r.u[1] = __umul24(__builtin_amdgcn_perm(0u, v.x, 0x0c030c02u), ONE);
-  r.u[2] = __umul24(__builtin_amdgcn_perm(0u, v.y, 0x0c010c00u), ONE);
-  r.u[3] = __umul24(__builtin_amdgcn_perm(0u, v.y, 0x0c030c02u), ONE);
-  return r.h;
-}
+__device__ __forceinline__ bf16x8 expand_spikes24(uint2 v) { return expand_spikes<NSPLIT>(v); }
 
 template <int CIN16>
 struct Geo {

@@ -38,15 +38,29 @@ __device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// 8 spike bytes {0,1} -> 8 x 16-bit {0, 1.0}: (b0 | b1 << 16) * ONE with ONE = 0x3F80 (bf16) or 0x3C00 (fp16)
+// 8 activation bytes -> 8 x 16-bit values.  fp16 planes (NSPLIT == 2): ANY byte n in 0..255 becomes fp16(n) exactly - the byte
+// pair {n, 0x64} is fp16(1024 + n), one packed add takes the 1024 off - so the A operand may be a spike (0 / 1) or a SUM of spikes
+// (the SEW stream between blocks, reference Spiking_swin_transformer3D.py:840-845: small non-negative integers); same instruction
+// count as the spike-only form.  bf16 planes: spikes only, (b0 | b1 << 16) * 0x3F80.
 template <int NSPLIT>
 __device__ __forceinline__ bf16x8 expand_spikes(uint2 v) {
-  constexpr uint32_t ONE = NSPLIT == 2 ? 0x3C00u : 0x3F80u;
   union { bf16x8 h; uint32_t u[4]; } r;
-  r.u[0] = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u) * ONE;
-  r.u[1] = __builtin_amdgcn_perm(0u, v.x, 0x0c030c02u) * ONE;
-  r.u[2] = __builtin_amdgcn_perm(0u, v.y, 0x0c010c00u) * ONE;
-  r.u[3] = __builtin_amdgcn_perm(0u, v.y, 0x0c030c02u) * ONE;
+  if constexpr (NSPLIT == 2) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2v;
+    const h2v off = {(_Float16)-1024.0f, (_Float16)-1024.0f};
+    const uint32_t sel[2] = {0x04010400u, 0x04030402u};                 // result bytes {b_lo, 0x64, b_hi, 0x64}
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t w = __builtin_amdgcn_perm(0x64646464u, i < 2 ? v.x : v.y, sel[i & 1]);
+      r.u[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2v, w) + off);
+    }
+  } else {
+    constexpr uint32_t ONE = 0x3F80u;
+    r.u[0] = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u) * ONE;
+    r.u[1] = __builtin_amdgcn_perm(0u, v.x, 0x0c030c02u) * ONE;
+    r.u[2] = __builtin_amdgcn_perm(0u, v.y, 0x0c010c00u) * ONE;
+    r.u[3] = __builtin_amdgcn_perm(0u, v.y, 0x0c030c02u) * ONE;
+  }
   return r.h;
 }
 

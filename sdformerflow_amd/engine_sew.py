@@ -2,12 +2,18 @@
 (reference models/STSwinNet_SNN/Spiking_STSwinNet.py:254-311, Spiking_swin_transformer3D.py:115-162, 184-370, 720-950,
 Spiking_modules.py:397-456, 571-603, 827-878).
 
-Same patch embedding as the MS models (inherited).  Behind it the stream between blocks is a SUM of spike tensors, so the
-layers that read it see small non-negative numbers, not spikes: those products (q/k/v and fc1 projections, patch-merging
-reduction, the first convolution of a res-block, the transposed convolutions) are dense fp32 library calls (rocBLAS /
-MIOpen through torch - plain library GEMMs / convolutions), everything that reads spikes (fc2, the second res-block
-convolution, the flow predictions) runs on the spike kernels, every BatchNorm is folded into the neuron kernel that
-follows it, the score / bias / mask / .V core is the fused window-attention kernel (csrc/win_attn.hip, SEW mode); the window
+Same patch embedding as the MS models (inherited): its output is a real-valued membrane, and the stream between blocks is that
+membrane plus a SUM of spike tensors - real numbers in stage 0, small non-negative integers behind the first patch merging (whose
+output is spikes).  The Linear layers that read the stream (q / k / v, fc1, the patch-merging reduction) and the projection behind the
+real-valued attention output run on `sdf_dense_linear_fwd` (both operands as fp16 hi + lo planes on the 16-bit matrix pipe - exact to
+22 bits for integers and reals alike); the first convolution of a res-block reads the integer stream of the last stage as BYTES through
+the spike convolution kernels (whose fp16 A-operand expansion takes any byte value exactly, csrc/spike_mm.h `expand_spikes`);
+everything that reads spikes (fc2, the second res-block convolution, the flow predictions) runs on the spike kernels, every BatchNorm
+is folded into the neuron kernel that follows it.  The transposed convolutions of the decoders read a concatenation of a real-valued
+prediction, spikes and a skip tensor (real-valued at the last level): they run as the dense 3x3 convolution (csrc/dense_conv_wres.hip,
+chained over 96-channel record groups) of the zero-upsampled input with the flipped kernel - ConvTranspose2d(k 3, s 2, p 1, op 1) written
+as a correlation.  No rocBLAS / MIOpen kernel is left in a SEW forward (profiles/r3q_sew_kernel_stats.txt; MIOpen served the transposed
+convolutions with its naive fallback kernel: 27.6 of the forward's 35 ms), the score / bias / mask / .V core is the fused window-attention kernel (csrc/win_attn.hip, SEW mode); the window
 partition is the row map the q / k / v neuron kernel gathers through (the projections run on un-partitioned rows), the window
 reverse a row scatter through the same map (no materialised pad / roll / permute / crop).
 No CPU fallback: everything here raises off-GPU."""
@@ -26,16 +32,16 @@ class _SewBlock:
     def __init__(self, blk, device, nsplit, name):
         a, m = blk.attn, blk.mlp
         self.name, self.nH, self.window_size, self.shift_size = name, a.num_heads, blk.window_size, blk.shift_size
-        self.wq, self.wk, self.wv = (getattr(a, f"linear_{n}").weight.detach().float().t().contiguous().to(device) for n in "qkv")
+        self.wq, self.wk, self.wv = (hip.pack_dense_linear_weight(getattr(a, f"linear_{n}").weight.detach().float().to(device)) for n in "qkv")
         self.bn = {n: bn_affine(getattr(a, f"bn_{n}").norm_layer, device) for n in "qkv"}
         self.sn = {n: _np(getattr(a, f"sn_{n}"), device) for n in "qkv"}
         self.scale = torch.full((a.num_heads,), float(a.scale), device=device)
         self.table = a.relative_position_bias_table.detach().float().to(device)
         self.index = a.relative_position_index.to(device)
-        self.wp_t = a.proj.weight.detach().float().t().contiguous().to(device)
+        self.wp = hip.pack_dense_linear_weight(a.proj.weight.detach().float().to(device))
         self.bp = a.proj.bias.detach().float().contiguous().to(device)
         self.proj_bn, self.proj_sn = bn_affine(a.proj_bn.norm_layer, device), _np(a.proj_sn, device)
-        self.w1_t = m.fc1.weight.detach().float().t().contiguous().to(device)
+        self.w1 = hip.pack_dense_linear_weight(m.fc1.weight.detach().float().to(device))
         self.bn1, self.sn1 = bn_affine(m.bn1.norm_layer, device), _np(m.sn1, device)
         self.fc2 = _Lin(m.fc2, m.bn2.norm_layer, device, nsplit)                 # fc2 reads spikes: the spike GEMM
         self.sn2 = _np(m.sn2, device)
@@ -56,15 +62,14 @@ class SEWFlowEngine(MSFlowEngine):
                                 for bi, b in enumerate(layer.swin_blocks)])
             if layer.downsample is not None:
                 d = layer.downsample
-                self.merges.append((d.reduction.weight.detach().float().t().contiguous().to(dev), bn_affine(d.norm.norm_layer, dev),
+                self.merges.append((hip.pack_dense_linear_weight(d.reduction.weight.detach().float().to(dev)), bn_affine(d.norm.norm_layer, dev),
                                     _np(d.sn, dev)))
         self.unet_res = []
         for i, rb in enumerate(unet.resblocks):
-            r = _ResBlock(rb, dev, ns, U + f"resblocks.{i}.")                    # conv2 reads spikes: planes; conv1 reads the stream
-            r.w1_dense = rb.conv1[0].weight.detach().float().contiguous(memory_format=torch.channels_last).to(dev)
-            self.unet_res.append(r)
+            self.unet_res.append(_ResBlock(rb, dev, ns, U + f"resblocks.{i}."))  # conv2 reads spikes, conv1 the integer stream as bytes
         self.decoders = [(d.deconv[0].weight.detach().float().to(dev), bn_affine(d.norm_layer.norm_layer, dev), _np(d.sn, dev))
                          for d in unet.decoders]
+        self._deconv_dense = {}
         self.preds = []
         for p in unet.preds:
             w2 = p.conv[0].weight.detach().float().reshape(p.conv[0].weight.shape[0], -1)
@@ -112,21 +117,21 @@ class SEWFlowEngine(MSFlowEngine):
         x2 = x.view(-1, Cc)
         spk = {}
         for n, w in (("q", blk.wq), ("k", blk.wk), ("v", blk.wv)):
-            y = torch.mm(x2, w)
+            y = hip.dense_linear(x2, w)
             spk[n] = torch.empty((M, Cc), dtype=torch.uint8, device=x.device)
             hip.neuron_fwd(y, spk[n], Tq, 1, M // Tq * Cc, 0, 0, 0, M // Tq * Cc, blk.sn[n], rowmap=rowmap, rowlen=Cc,
                            alpha=blk.bn[n][0], beta=blk.bn[n][1], Cch=Cc, inner=1)
             self._rec(blk.name + f"attn.sn_{n}.spiking_neuron.", spk[n], "flat")
         mask = self._mask(D, H, W, ws, ss) if any(s > 0 for s in ss) else None
         z = hip.win_attn_sew(spk["q"], spk["k"], spk["v"], blk.scale, blk.bias(Tq * N1), mask, blk.nH, Tq, B_, N1)
-        y = torch.addmm(blk.bp, z.view(M, Cc), blk.wp_t)
+        y = hip.dense_linear(z.view(M, Cc), blk.wp, blk.bp)
         s = self._sn_rows(y, Tq, blk.proj_sn, blk.proj_bn, blk.name + "attn.proj_sn.spiking_neuron.")
         return hip.rows_scatter(s, rowmap, B * D * H * W).view(B, D, H, W, Cc)     # window reverse (+ roll back, crop)
 
     def mlp(self, x, blk: _SewBlock):
         """MLP(x) over the true time axis D (reference :147-162): spikes, (B,D,H,W,C) fp32."""
         B, D, H, W, Cc = x.shape
-        h = torch.mm(x.view(-1, Cc), blk.w1_t).view(B, D, H, W, -1)
+        h = hip.dense_linear(x.view(-1, Cc), blk.w1).view(B, D, H, W, -1)
         s1 = self._neuron_bd(h, blk.sn1, bn=blk.bn1)
         self._rec(blk.name + "mlp.sn1.spiking_neuron.", s1, "BDHWC->TBHWC")
         y = torch.empty((B, D, H, W, Cc), dtype=torch.float32, device=x.device)
@@ -142,26 +147,70 @@ class SEWFlowEngine(MSFlowEngine):
 
     def patch_merge(self, x, s, packed=None):
         """2x2 gather -> Linear -> BN -> SN (reference :914-934): spikes (B,D,H/2,W/2,2C) fp32."""
-        w_t, bn, sn = self.merges[s] if packed is None else packed
+        wpk, bn, sn = self.merges[s] if packed is None else packed
         self._check_cl(x)
         B, D, H, W, Cc = x.shape
         rowmap, H2, W2, _ = self._merge_map(B, D, H, W)
         rows = B * H2 * W2
         xg = hip.rows_gather(x.view(-1, Cc), rowmap).view(D * rows, 4 * Cc)       # (t, b, h2, w2) rows of the 4C concat
-        out = self._sn_rows(torch.mm(xg, w_t), D, sn, bn, f"sttmultires_unet.encoders.swin3d.layers.{s}.downsample.sn.spiking_neuron.")
+        out = self._sn_rows(hip.dense_linear(xg, wpk), D, sn, bn, f"sttmultires_unet.encoders.swin3d.layers.{s}.downsample.sn.spiking_neuron.")
         out = out.view(D, B, H2, W2, -1)
         return out.permute(1, 0, 2, 3, 4).contiguous() if B > 1 else out.view(B, D, H2, W2, -1)
+
+    @staticmethod
+    def _stream_bytes(x):
+        """The integer-valued SEW stream as the byte operand of the spike kernels (checked: an integer below 256 everywhere)."""
+        xu = x.to(torch.uint8)
+        if not torch.equal(xu.float(), x):
+            raise hip.SdfError("the SEW stream in front of a res-block is not a sum of spike tensors (a model with a single swin "
+                               "stage feeds the real-valued patch embedding here)")
+        return xu
 
     def _sew_resblock(self, x, rb):
         """conv-BN-SN-conv-BN-SN + identity (reference Spiking_modules.py:852-878)."""
         B, D, h, w, Cc = x.shape
-        y = F.conv2d(x.view(B * D, h, w, Cc).permute(0, 3, 1, 2), rb.w1_dense, None, 1, 1)
-        y = y.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).view(B, D, h, w, -1)
+        # the stream behind a patch merging is a sum of spike tensors: exact bytes (at most one spike per block half and level)
+        y = self._conv3x3(self._stream_bytes(x), rb.w1, rb.C)
         s1 = self._neuron_bd(y, rb.sn1, bn=rb.bn1)
         self._rec(rb.name + "sn1.spiking_neuron.", s1, "BDHWC->TBCHW")
         s2 = self._neuron_bd(self._conv3x3(s1, rb.w2, rb.C, bn=rb.bn2), rb.sn2, out_dtype=torch.float32)
         self._rec(rb.name + "sn2.spiking_neuron.", s2.to(torch.uint8), "BDHWC->TBCHW")
         return s2 + x
+
+    def _deconv_dense_fwd(self, i, parts, wdec):
+        """ConvTranspose2d(k 3, s 2, p 1, output_padding 1) of cat(parts, channels) (reference Spiking_modules.py:449-456) on the dense
+        convolution kernel: out[o] = sum_k u[o + 1 - k] w[k] with u the zero-upsampled input (u[2 i] = x[i]) is the 3x3 / pad 1
+        correlation of u with the flipped kernel.  `parts`: channel-last (B,D,h,w,c) tensors in the reference's channel order, all of
+        one size; physically each starts on a 16-channel record and the record count is brought to 6 k or 6 k + 1 (what
+        `hip.dense_conv_slices` chains), the padding channels are zero in the input and in the weights."""
+        B, D, h, w, _ = parts[0].shape
+        imgs, cout = B * D, wdec.shape[1]
+        cs = [p.shape[-1] for p in parts]
+        recs = [-(-c // 16) for c in cs]
+        total = sum(recs)
+        while total % 6 > 1:
+            total += 1
+        if cout % 32 or hip.dense_conv_slices(total) is None or imgs * 4 * h * w * max(total * 64, cout * 4) >= 1 << 31:
+            cat = torch.cat(parts, dim=-1)                                         # shapes outside the kernel's build: the library
+            z = F.conv_transpose2d(cat.view(imgs, h, w, -1).permute(0, 3, 1, 2), wdec, None, stride=2, padding=1, output_padding=1)
+            return z.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).view(B, D, 2 * h, 2 * w, -1)
+        key = (i, tuple(cs))
+        if key not in self._deconv_dense:
+            wphys = torch.zeros((total * 16, cout, 3, 3), dtype=torch.float32, device=wdec.device)
+            c_ref = r0 = 0
+            for c, r in zip(cs, recs):
+                wphys[16 * r0:16 * r0 + c] = wdec[c_ref:c_ref + c]
+                c_ref, r0 = c_ref + c, r0 + r
+            wconv = wphys.flip(2, 3).permute(1, 0, 2, 3).contiguous()              # (Cout, Cin, 3, 3) of the equivalent correlation
+            self._deconv_dense[key] = [((a, n), hip.pack_dense_conv_weight(wconv[:, 16 * a:16 * (a + n)]))
+                                       for a, n in hip.dense_conv_slices(total)]
+        up = torch.zeros((imgs, total * 16, 2 * h, 2 * w), dtype=torch.float32, device=wdec.device)
+        r0 = 0
+        for p_, c, r in zip(parts, cs, recs):
+            up[:, 16 * r0:16 * r0 + c, ::2, ::2] = p_.reshape(imgs, h, w, c).permute(0, 3, 1, 2)
+            r0 += r
+        z = hip.dense_conv3x3_wide(hip.pack_planes(up), self._deconv_dense[key], out_f32=True)
+        return z.view(B, D, 2 * h, 2 * w, cout)
 
     def unet_tail(self, feats, out_size=None):
         """SEW res-blocks + decoders (ConvT -> BN -> SN) + plain 1x1 predictions (reference Spiking_STSwinNet.py:161-182)."""
@@ -176,10 +225,8 @@ class SEWFlowEngine(MSFlowEngine):
             parts = ([preds[-1][..., :self.preds[i - 1][2]]] if i > 0 else []) + [y, skip]      # [prediction | y | skip] (:168-172)
             parts = [F.pad(p, (0, 0, (w - p.shape[3]) // 2, w - p.shape[3] - (w - p.shape[3]) // 2,
                                (h - p.shape[2]) // 2, h - p.shape[2] - (h - p.shape[2]) // 2)) for p in parts]
-            cat = torch.cat(parts, dim=-1)
             wdec, bn, sn = self.decoders[i]
-            z = F.conv_transpose2d(cat.view(B * D, h, w, -1).permute(0, 3, 1, 2), wdec, None, stride=2, padding=1, output_padding=1)
-            z = z.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).view(B, D, 2 * h, 2 * w, -1)
+            z = self._deconv_dense_fwd(i, parts, wdec)
             sp = self._neuron_bd(z, sn, bn=bn)                                    # u8 spikes
             self._rec(f"sttmultires_unet.decoders.{i}.sn.spiking_neuron.", sp, "BDHWC->TBCHW")
             pw, pb, nout = self.preds[i]

@@ -152,7 +152,7 @@ def sew_mlp_forward(mod, x):
             pass
         b = P()
         b.name = ""
-        b.w1_t = mod.fc1.weight.detach().float().t().contiguous().to(dev)
+        b.w1 = hip.pack_dense_linear_weight(mod.fc1.weight.detach().float().to(dev))
         b.bn1, b.sn1 = bn_affine(mod.bn1.norm_layer, dev), _np(mod.sn1, dev)
         b.fc2, b.sn2 = _Lin(mod.fc2, mod.bn2.norm_layer, dev, 2), _np(mod.sn2, dev)
         return SEWFlowEngine.bare(dev), b
@@ -167,7 +167,7 @@ def sew_patch_merging_forward(mod, x):
     from .engine import _np, bn_affine
     from .engine_sew import SEWFlowEngine
     _eval_only(mod)
-    eng, pk = packed(mod, lambda dev: (SEWFlowEngine.bare(dev), (mod.reduction.weight.detach().float().t().contiguous().to(dev),
+    eng, pk = packed(mod, lambda dev: (SEWFlowEngine.bare(dev), (hip.pack_dense_linear_weight(mod.reduction.weight.detach().float().to(dev)),
                                                                  bn_affine(mod.norm.norm_layer, dev), _np(mod.sn, dev))))
     with torch.no_grad():
         return eng.patch_merge(_cl(x), 0, packed=pk)

@@ -865,3 +865,25 @@ def test_plif_slttlif_glif_neurons_against_the_reference_fixture(T):
     assert (got != want).float().mean().item() <= 1e-3
     with pytest.raises(hip.SdfError):
         hip.lif_fwd(x, tau=1.0)                                                  # tau = 1 is neither form
+
+
+@pytest.mark.parametrize("M,N,K", [(700, 96, 384), (4320, 1536, 384), (130, 192, 768)])
+def test_spike_gemm_and_conv_take_sums_of_spikes_as_bytes(M, N, K):
+    """The fp16-plane kernels expand ANY activation byte exactly (csrc/spike_mm.h expand_spikes: {n, 0x64} = fp16(1024 + n), minus
+    1024): the SEW stream behind a patch merging - sums of spike tensors (reference Spiking_swin_transformer3D.py:840-845) - is their
+    A operand as it stands.  Bytes 0..255 against fp64, GEMM and 3x3 convolution (the SEW res-block's first convolution)."""
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randint(0, 256, (M, K), generator=g, dtype=torch.uint8)
+    a[::3] = torch.randint(0, 4, a[::3].shape, generator=g, dtype=torch.uint8)          # the realistic range as well
+    w = rnd((N, K), 777, -0.1, 0.1)
+    ref = a.double() @ w.double().t()
+    out = torch.empty((M, N), device=DEV)
+    hip.spike_gemm(a.to(DEV), hip.split_weight(w.to(DEV), 2), out, M, N, K)
+    assert (out.cpu().double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    imgs, H, W, Cc = 3, 10, 12, 384
+    x = torch.randint(0, 12, (imgs, H, W, Cc), generator=g, dtype=torch.uint8)
+    wc = rnd((Cc, Cc, 3, 3), 778, -0.05, 0.05)
+    cref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), wc.double(), None, 1, 1).permute(0, 2, 3, 1).reshape(-1, Cc)
+    cout = torch.empty((imgs * H * W, Cc), device=DEV)
+    hip.spike_conv2d(x.to(DEV), hip.pack_conv_weight(wc.to(DEV), 2), imgs, H, W, Cc, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=cout)
+    assert (cout.cpu().double() - cref).abs().max().item() <= 2e-6 * cref.abs().max().item()
