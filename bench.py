@@ -34,17 +34,18 @@ PEAK_BF16_DENSE_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: ~2
 PEAK_HBM_GBPS = 8000.0              # same guide: 8.0 TB/s spec (6.3 TB/s achievable)
 # HBM bytes per launch of the roofline shape from the PMC counters.  They cannot be read inside this process (rocprofv3 owns the
 # counters), so the figure is the one measured by tools/pmc_traffic.sh on the build named in CONV_TRAFFIC_SOURCE
-# (round 3: profiles/r3g_pmc_kernels.txt, the shipped three-group kernel; both epilogue forms, since `roofline` averages over them)
-CONV_TRAFFIC_KIB = {"membrane_and_spikes": (95362.0, 131136.0), "spikes_only": (42605.0, 27456.0)}     # (FETCH_SIZE, WRITE_SIZE) KiB / launch
+# (round 3: profiles/r3r_pmc_conv_mapping.txt, the shipped three-group kernel; both epilogue forms, since `roofline` averages over them)
+CONV_TRAFFIC_KIB = {"membrane_and_spikes": (68120.9, 130273.0), "spikes_only": (15407.2, 25879.0)}    # (FETCH_SIZE, WRITE_SIZE) KiB / launch
 CONV_TRAFFIC_BYTES = sum(2 * f + w for f, w in CONV_TRAFFIC_KIB.values()) / 2 * 1024                 # FETCH_SIZE x 2: gfx950 correction
 CONV_ALGORITHMIC_BYTES = {"membrane_and_spikes": 10 * 144 * 192 * 96 * (1 + 4 + 4 + 1) + 3 * 96 * 864,
                           "spikes_only": 10 * 144 * 192 * 96 * (1 + 1) + 3 * 96 * 864}
-CONV_TRAFFIC_SOURCE = ("NOT measured in this run (rocprofv3 owns the counters): profiles/r3g_pmc_kernels.txt (round-3 tree, tools/pmc_kernels.sh: "
+CONV_TRAFFIC_SOURCE = ("NOT measured in this run (rocprofv3 owns the counters): profiles/r3r_pmc_conv_mapping.txt (tools/pmc_conv_ab.sh: "
                        "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes on this exact launch, gfx950 x2 read "
-                       "correction, KiB = 1024 B): membrane + spikes form 195.3 MB read + 134.3 MB written against 265.7 MB algorithmic "
-                       "(1.24x: the 26.5 MB spike image is read once per 32-column block, 3x, plus halo rows; the write side is exact); "
-                       "spikes-only form 87.3 + 28.1 MB against 53.4 MB (2.2x, the same 3x image reads); `traffic` is their mean, as "
-                       "`achieved` is the mean over the forward's two launches of each form")
+                       "correction, KiB = 1024 B): membrane + spikes form 139.5 MB read + 133.4 MB written against 265.7 MB algorithmic "
+                       "(1.03x), spikes-only form 31.6 + 26.5 MB against 53.4 MB (1.09x).  The three workgroups that serve the column blocks "
+                       "of a tile range now sit on one XCD and walk it side by side (the spike image leaves HBM once; round 2's column-block-"
+                       "major ranges read it 3x: 196.9 / 88.7 MB, same file); `traffic` is the mean of the two forms, as `achieved` is the "
+                       "mean over the forward's two launches of each form")
 
 
 def build_model(kind, device):

@@ -471,10 +471,21 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
   const int Gd = gridDim.x;
   int wg = blockIdx.x;
   if ((Gd & 7) == 0) wg = (wg & 7) * (Gd >> 3) + (wg >> 3);
-  const int nitems = P.ntiles;
-  const int base = nitems / Gd, rem = nitems % Gd;
-  const int t_begin = wg * base + (wg < rem ? wg : rem);
-  const int n_my = base + (wg < rem ? 1 : 0);
+  int t_begin, n_my;
+  if (P.cb_inner) {
+    // the tiles_n workgroups that serve the column blocks of ONE tile range are neighbours on one XCD and walk the range side by
+    // side: the spike image leaves HBM once and comes out of that L2 for the other column blocks (column-block-major ranges put
+    // the three readers of a tile on three XCDs: 3 x the image from HBM, profiles/r3g_pmc_kernels.txt)
+    const int nr = Gd / P.tiles_n, r = wg / P.tiles_n, cbw = wg - r * P.tiles_n;
+    const int base = P.tiles_m / nr, rem = P.tiles_m % nr;
+    t_begin = cbw * P.tiles_m + r * base + (r < rem ? r : rem);
+    n_my = base + (r < rem ? 1 : 0);
+  } else {
+    const int nitems = P.ntiles;
+    const int base = nitems / Gd, rem = nitems % Gd;
+    t_begin = wg * base + (wg < rem ? wg : rem);
+    n_my = base + (wg < rem ? 1 : 0);
+  }
 
   // halo image: pass i of the group's 256 lanes moves halo rows 2i and 2i+1, lane (half, j) the j-th 16-byte piece of its row
   const int hhalf = gl >> 7, hj = gl & 127;
@@ -826,6 +837,14 @@ int launch_spike_conv_wres(const GemmParams& Pin, hipStream_t s) {
       const int ng = (d.sn_T > 0 && th == 8 && (eg0 ? eg0[0] == '3' : true)) ? 3 : 2;
       const int rounds = (P.ntiles + 256 * ng - 1) / (256 * ng), per = ng * rounds;
       if (P.ntiles >= 64) G = (P.ntiles + per - 1) / per;
+      // column blocks of a tile range side by side on one XCD (see the kernel): the grid becomes a multiple of 8 * tiles_n, or of
+      // tiles_n with every workgroup's share still `per` items
+      static const bool cbi = [] { const char* e = getenv("SDF_CONV_WRES_CB_INNER"); return !e || e[0] != '0'; }();
+      if (cbi && P.ntiles >= 64) {
+        const int nr = (P.tiles_m + per - 1) / per;                     // tile ranges of at most `per` items
+        const int g2 = nr * P.tiles_n;
+        if (g2 <= 256 && g2 % 8 == 0) { G = g2; P.cb_inner = 1; }
+      }
     }
     // fused-neuron items are T steps long and their epilogue (neuron + two stores) outweighs their MFMAs: with few of them
     // (batch 1: 648 on this shape) THREE groups of waves per workgroup - 768 slots, one item each, the matrix pipe shared

@@ -24,6 +24,7 @@ struct GemmParams {
   int ksplit, spc;            // split-K (warp-specialised kernel): K chunks per tile, stages per chunk
   float* partial;             // [ksplit][M][N] fp32 partial sums in the caller's workspace
   float acc_scale;            // multiplies the accumulator before the epilogue (1 / weight scale of the fp16 planes; else 1)
+  int cb_inner = 0;           // digit convolution: workgroup -> (tile range, column block) with the column block fastest (one XCD per range)
 };
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
