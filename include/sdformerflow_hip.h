@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SDF_VERSION 101
+#define SDF_VERSION 102
 
 enum { SDF_F32 = 0, SDF_U8 = 1 };
 enum { SDF_LIF = 0, SDF_PSN = 1, SDF_IF = 2 };
@@ -264,7 +264,9 @@ int sdf_rows_scatter_fwd(const float* y, const int32_t* map, float* out, int64_t
 /* ---------------------------------------------------------------------------------------------
  * Spiking QK window attention, whole (rows a5 + a6):  x += SSA(x) in place.
  * Replaces: Spiking_SwinTransformerBlock3D.SSA + Spiking_QK_WindowAttention3D.forward + the shortcut add
- * (reference Spiking_swin_transformer3D.py:781-821, :661-717, :840).  Four launches on `stream`:
+ * (reference Spiking_swin_transformer3D.py:781-821, :661-717, :840).  TWO launches on `stream` where the first half has its
+ * one-launch kernel (csrc/qk_front.hip: T' = 2, N1 <= 96, C % 96 == 0, fp16 planes, the four neurons of one class - the first
+ * three steps below on a (slice pair, head) per workgroup, xs and q | k never in memory), else four:
  *   xs = SN_proj(x gathered through slice_map)                                  (T', B_*N1, C) u8
  *   q | k = SN_q/k( BN( xs [Wq;Wk]^T ) [+ positional_encoding on the k half] )  fused into the GEMM epilogue
  *   E = k AND SN2_q( sum over each head's 32 channels of q )                    (token gate)
@@ -296,7 +298,13 @@ typedef struct SdfQkAttnDesc {
   SdfNeuronCfg sn_proj, sn_q, sn_k, sn2_q;
   void* workspace;      int64_t workspace_bytes;
   void* gemm_workspace; int64_t gemm_workspace_bytes;
+  int32_t flags;        /* SDF_QK_* bits */
 } SdfQkAttnDesc;
+
+enum {
+  SDF_QK_KEEP_SPIKES = 1,    /* leave the q | k spikes in `workspace` behind E (what the four-launch form always does; the parity tape) */
+  SDF_QK_FOUR_LAUNCHES = 2   /* never take the one-launch first half (A/B reference; same as SDF_QK_FRONT=0 in the environment) */
+};
 
 int64_t sdf_qk_attn_workspace_bytes(int64_t B_, int Tq, int N1, int C);
 int sdf_qk_attn_fwd(const SdfQkAttnDesc* d, void* stream);

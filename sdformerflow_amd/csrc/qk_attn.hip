@@ -76,13 +76,25 @@ extern "C" int sdf_qk_attn_fwd(const SdfQkAttnDesc* d, void* stream) {
   uint8_t* xs = reinterpret_cast<uint8_t*>(d->workspace);
   uint8_t* qk = xs + (M * C + 255) / 256 * 256;
 
+  // steps 1 - 3 as one launch where the kernel has an instantiation (SDF_QK_FRONT=0 / SDF_QK_FOUR_LAUNCHES: the A/B reference below)
+  bool front = false;
+  {
+    static const bool off = [] { const char* e = getenv("SDF_QK_FRONT"); return e && e[0] == '0'; }();
+    if (!off && !(d->flags & SDF_QK_FOUR_LAUNCHES) && sdfmm::qk_front_supports(d)) {
+      const int rc0 = sdfmm::launch_qk_front(d, xs, qk, (d->flags & SDF_QK_KEEP_SPIKES) != 0, sdf_stream(stream));
+      if (rc0) return rc0;
+      front = true;
+    }
+  }
+  int rc = 0;
+  if (!front) {
   // 1. proj_sn over the T' frames of every window slice, gathered through the slice map (pad / roll / partition folded in)
   SdfNeuronDesc n = {};
   n.x = d->x; n.out = xs; n.T = Tq; n.out_dtype = SDF_U8;
   n.nb = 1; n.ni = rows * C; n.x_sb = 0; n.x_st = 0; n.o_sb = 0; n.o_st = rows * C;
   n.rowmap = d->slice_map; n.rowlen = C;
   fill_neuron(n, d->sn_proj);
-  int rc = sdf_neuron_fwd(&n, stream);
+  rc = sdf_neuron_fwd(&n, stream);
   if (rc) return rc;
 
   // 2. q = SN(BN(xs Wq^T)), k = SN(BN(xs Wk^T) + PE): the neuron runs in the GEMM epilogue, q / k never exist in fp32
@@ -113,6 +125,7 @@ extern "C" int sdf_qk_attn_fwd(const SdfQkAttnDesc* d, void* stream) {
   rc = sdf_qk_gate_strided_fwd(qp, kp, xs, Tq, rows, C, ldq, ldk, d->sn2_q.kind, d->sn2_q.tau, d->sn2_q.v_th, d->sn2_q.v_reset,
                                d->sn2_q.soft_reset, d->sn2_q.psn_w, d->sn2_q.psn_b, stream);
   if (rc) return rc;
+  }
 
   // 4. x[slice_map] += BN(Z Wp^T + b), Z = E read through the reference's raw head reshape
   SdfSpikeGemmDesc g = {};

@@ -131,6 +131,9 @@ __device__ __forceinline__ void neuron_T(const float (&xs)[T], float (&sp)[T], c
   }
 }
 
+bool qk_front_supports(const SdfQkAttnDesc* d);
+int launch_qk_front(const SdfQkAttnDesc* d, uint8_t* e, uint8_t* qk, bool keep, hipStream_t s);
+
 // host side: 1 / tau where that is exact (tau a power of two; 0 = divide), and the compile-time class of a neuron setting
 static inline float inv_tau_of(const SdfNeuronCfg& n) {
   return sdf_inv_tau(n.kind, n.tau);

@@ -416,7 +416,10 @@ class QkAttnDesc(C.Structure):
                 ("p_acc_scale", C.c_float),
                 ("sn_proj", NeuronCfg), ("sn_q", NeuronCfg), ("sn_k", NeuronCfg), ("sn2_q", NeuronCfg),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-                ("gemm_workspace", C.c_void_p), ("gemm_workspace_bytes", C.c_int64)]
+                ("gemm_workspace", C.c_void_p), ("gemm_workspace_bytes", C.c_int64), ("flags", C.c_int32)]
+
+
+SDF_QK_KEEP_SPIKES, SDF_QK_FOUR_LAUNCHES = 1, 2
 
 
 def _ncfg(c, p: NeuronParams):
@@ -439,7 +442,8 @@ def window_slice_map(B, D, H, W, ws, ss, device):
     return m, B_
 
 
-def qk_attn(x, slice_map, B_, Tq, N1, nH, p_lin, sn_proj, sn_q, sn_k, sn2_q, qk=None, q_lin=None, k_lin=None, pe=None, keep_ws=None):
+def qk_attn(x, slice_map, B_, Tq, N1, nH, p_lin, sn_proj, sn_q, sn_k, sn2_q, qk=None, q_lin=None, k_lin=None, pe=None, keep_ws=None,
+            four_launches=False):
     """sdf_qk_attn_fwd: x (B,D,H,W,C) fp32 channel-last += SSA(x), in place.  `qk` = {"Wp", "alpha", "beta", "add"} for the
     stacked projection, or q_lin / k_lin (objects with Wp / alpha / beta) + pe for separate ones; p_lin has Wp / bias / alpha / beta."""
     Cc = x.shape[-1]
@@ -463,6 +467,7 @@ def qk_attn(x, slice_map, B_, Tq, N1, nH, p_lin, sn_proj, sn_q, sn_k, sn2_q, qk=
     d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
     gws = workspace(x.device)
     d.gemm_workspace, d.gemm_workspace_bytes = gws.data_ptr(), gws.numel()
+    d.flags = (SDF_QK_KEEP_SPIKES if keep_ws is not None else 0) | (SDF_QK_FOUR_LAUNCHES if four_launches else 0)
     _check(lib().sdf_qk_attn_fwd(C.byref(d), _stream()), "sdf_qk_attn_fwd")
     if keep_ws is not None:
         keep_ws.append(ws)                  # the call's intermediates (u8 spikes, layout: sdf_qk_attn_workspace_bytes) for the parity tape
