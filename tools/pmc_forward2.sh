@@ -29,7 +29,7 @@ for d in sorted(glob.glob(out + "/p*")):
     for r in rows:
         byd[int(r["Dispatch_Id"])][r["Counter_Name"]] = (float(r["Counter_Value"]), r["Kernel_Name"])
     ids = sorted(byd)
-    heads = [i for i in ids if "head_conv_sn_kernel" in next(iter(byd[i].values()))[1]]
+    heads = [i for i in ids if "head_conv_" in next(iter(byd[i].values()))[1]]
     lo, hi = heads[-2], heads[-1]                       # the launches from the 4th forward's head convolution to the 5th's
     for i in ids:
         if lo <= i < hi:
@@ -39,7 +39,7 @@ for d in sorted(glob.glob(out + "/p*")):
                 cnt[short(next(iter(byd[i].values()))[1])] += 1
 dur = collections.defaultdict(float)
 rows = sorted((r for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True) for r in csv.DictReader(open(f))), key=lambda r: int(r["Start_Timestamp"]))
-heads = [i for i, r in enumerate(rows) if "head_conv_sn_kernel" in r["Kernel_Name"]]
+heads = [i for i, r in enumerate(rows) if "head_conv_" in r["Kernel_Name"]]
 for r in rows[heads[-2]:heads[-1]]:
     dur[short(r["Kernel_Name"])] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 tot = collections.defaultdict(float)

@@ -5,14 +5,14 @@ TAG=${1:-r2}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_$TAG
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o $TAG -- python3 $R/bench.py --no-cpu > $R/gpurun_out/prof_$TAG.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o $TAG -- python3 $R/bench.py --no-cpu --no-sides > $R/gpurun_out/prof_$TAG.log 2>&1
 cd $R
 tail -c 600 gpurun_out/prof_$TAG.log
-python3 - <<PY
+python3 - <<PY | tee gpurun_out/prof_${TAG}_kernel_stats.txt
 import csv, glob
 f = glob.glob("gpurun_out/prof_$TAG/**/*_kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
-print("rocprofv3 --kernel-trace --stats of: python3 bench.py --no-cpu   (default 300 steps, 3 forwards in flight, HIP-graph replay)")
+print("rocprofv3 --kernel-trace --stats of: python3 bench.py --no-cpu --no-sides   (default 300 steps, 3 forwards in flight, HIP-graph replay)")
 for r in rows[:28]:
     print(f"{r['Name'][:110]:110s} calls {int(r['Calls']):6d}  total {float(r['TotalDurationNs'])/1e6:9.2f} ms  avg {float(r['AverageNs'])/1e3:8.1f} us  {float(r['Percentage']):5.1f} %")
 PY
