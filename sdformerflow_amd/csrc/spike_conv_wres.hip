@@ -438,7 +438,7 @@ template <int TT, int CIN16, int RB, int NGRP>
 __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmParams P, const float* __restrict__ col_scale) {
   using G = GeoI8<CIN16, RB>;
   constexpr bool SPIKE = TT > 0;
-  constexpr int T = SPIKE ? TT : 1;
+  const int T = SPIKE ? P.d.sn_T : 1;             // the time loop is rolled: TT > 0 selects the fused form, its length comes with the call (5 / 10 / 20)
   constexpr int CIN = G::CIN, K = G::K, PS = G::PS, RPB = G::RPB, WP = G::WP, TH8 = G::TH8, TW8 = G::TW8;
   constexpr int W_BYTES = 3 * NB * WP;
   constexpr int PAR = 2 * NB * 4;
@@ -790,7 +790,7 @@ bool spike_conv_wres_supports(const GemmParams& P, bool any_size) {
   if (c.dy[0] != -1 || c.dy[1] != 0 || c.dy[2] != 1 || c.dx[0] != -1 || c.dx[1] != 0 || c.dx[2] != 1) return false;
   if (d.N % NB || (d.nsplit != 1 && d.nsplit != 2 && d.nsplit != SDF_PLANES_I8X3) || d.out_rowmap || d.add || d.zg_nH > 0) return false;
   if (d.nsplit == SDF_PLANES_I8X3 && (!d.col_scale || d.bias)) return false;
-  if (d.sn_T != 0 && d.sn_T != 10) return false;
+  if (d.sn_T != 0 && d.sn_T != 10 && !(d.nsplit == SDF_PLANES_I8X3 && (d.sn_T == 5 || d.sn_T == 20))) return false;
   const int64_t imgs = d.M / ((int64_t)c.OH * c.OW);
   if (d.sn_T > 0) {
     if (d.sn_kind == SDF_PSN || d.bias) return false;

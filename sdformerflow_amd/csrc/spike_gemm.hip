@@ -563,7 +563,8 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
   P.inv_tau = 0.f;
   P.acc_scale = i8x3 ? 1.f : sdf_acc_scale(d);
   if (spike) {
-    if (d->sn_T != 10 || d->pos_count < 1 || d->pos_inner < 1 || d->pos_count * d->sn_T != d->M) return SDF_E_SHAPE;
+    if ((d->sn_T != 10 && !(i8x3 && (d->sn_T == 5 || d->sn_T == 20))) || d->pos_count < 1 || d->pos_inner < 1 ||
+        d->pos_count * d->sn_T != d->M) return SDF_E_SHAPE;          // streaming kernels: T = 10; the digit kernel rolls its time loop
     if (d->sn_kind != SDF_LIF && d->sn_kind != SDF_PSN && d->sn_kind != SDF_IF) return SDF_E_DTYPE;
     if (d->sn_kind == SDF_PSN && (!d->psn_w || !d->psn_b)) return SDF_E_NULL;
     if (!sdf_tau_ok(d->sn_kind, d->tau)) return SDF_E_SHAPE;

@@ -281,7 +281,7 @@ class MSFlowEngine:
         hip.neuron_fwd(x, out, D, B, n, D * n, n, D * n, n, p, alpha=a, beta=b, Cch=Cc, inner=1)
         return out
 
-    def _conv3x3(self, s, Wp, Cout, stride=1, bn=None, resid=None, sn=None, membrane=False):
+    def _conv3x3(self, s, Wp, Cout, stride=1, bn=None, resid=None, sn=None, membrane=False, _dst=None):
         """3x3 / pad 1 spike convolution on (B,D,h,w,Cin) u8 -> (B,D,oh,ow,Cout): fp32 (BN, + resid) or, with `sn`,
         spikes of the fused BN + neuron over D; with `membrane` as well, (fp32 BN + resid, spikes of SN(that)) from one launch."""
         B, D, h, w, Cin = s.shape
@@ -289,31 +289,65 @@ class MSFlowEngine:
         a, b = bn if bn is not None else (None, None)
         # large 3x3 / stride-1 launches on 96 channels: int8 digit planes, weights resident in LDS (csrc/spike_conv_wres.hip)
         digits = getattr(Wp, "digits", None)
-        if digits is not None and sn is not None and (sn.kind == "psn" or D != 10) and \
+        if digits is not None and B > 1 and not hip.conv_wres_applicable(B * D, h, w, Cin, Cout, stride, 1):
+            # too large for the digit kernel's 31-bit operand offsets as one launch (configs[4]: 80 images of 240 x 320 x 96 fp32):
+            # batch elements are independent - the largest batch chunk that fits runs per launch, writing into its slice of the outputs
+            bc = self._digit_chunk(B, D, h, w, Cin, Cout, stride)
+            if bc:
+                kinds = [torch.float32] if sn is None else ([torch.float32, torch.uint8] if membrane else [torch.uint8])
+                outs = tuple(torch.empty((B, D, oh, ow, Cout), dtype=k, device=s.device) for k in kinds)
+                for b0 in range(0, B, bc):
+                    dst = tuple(o[b0:b0 + bc] for o in outs)
+                    r = self._conv3x3(s[b0:b0 + bc], Wp, Cout, stride, bn, None if resid is None else resid[b0:b0 + bc], sn, membrane, dst)
+                    r = r if isinstance(r, tuple) else (r,)
+                    for o, t in zip(dst, r):
+                        if t.data_ptr() != o.data_ptr():                  # (the two-launch PSN form allocates its own)
+                            o.copy_(t)
+                return outs if len(outs) > 1 else outs[0]
+        if digits is not None and sn is not None and (sn.kind == "psn" or D not in (5, 10, 20)) and \
                 hip.conv_wres_applicable(B * D, h, w, Cin, Cout, stride, 1):
-            # the digit kernel's fused form is LIF / IF over T = 10; other neurons (the shipped PSN) take its fp32 form and
+            # the digit kernel's fused form is LIF / IF over T = 5 / 10 / 20; other neurons (the shipped PSN) take its fp32 form and
             # the neuron kernel behind it - still ahead of the streaming kernel's fused epilogue (profiles/r2j_psn.txt)
             m = self._conv3x3(s, Wp, Cout, stride, bn=bn, resid=resid if membrane else None)
             sp = self._neuron_bd(m, sn)
             return (m, sp) if membrane else sp
-        if digits is not None and (sn is None or (sn.kind != "psn" and D == 10)) and \
+        if digits is not None and (sn is None or (sn.kind != "psn" and D in (5, 10, 20))) and \
                 hip.conv_wres_applicable(B * D, h, w, Cin, Cout, stride, D if sn is not None else 1):
-            Wp = digits                                               # (the kernel's fused form: LIF / IF over T = 10)
+            Wp = digits                                               # (the kernel's fused form: LIF / IF over T = 5 / 10 / 20)
         if sn is None:
-            out = torch.empty((B, D, oh, ow, Cout), dtype=torch.float32, device=s.device)
+            out = _dst[0] if _dst is not None and len(_dst) == 1 and _dst[0].dtype == torch.float32 else \
+                torch.empty((B, D, oh, ow, Cout), dtype=torch.float32, device=s.device)
             hip.spike_conv2d(s, Wp, B * D, h, w, Cin, oh, ow, 3, 3, stride, (-1, 0, 1), (-1, 0, 1), out=out, alpha=a, beta=b,
                              resid=resid)
             return out
-        out = torch.empty((B, D, oh, ow, Cout), dtype=torch.uint8, device=s.device)
-        m = torch.empty((B, D, oh, ow, Cout), dtype=torch.float32, device=s.device) if membrane else None
+        if _dst is not None and len(_dst) == (2 if membrane else 1) and _dst[-1].dtype == torch.uint8:
+            out, m = _dst[-1], (_dst[0] if membrane else None)
+        else:
+            out = torch.empty((B, D, oh, ow, Cout), dtype=torch.uint8, device=s.device)
+            m = torch.empty((B, D, oh, ow, Cout), dtype=torch.float32, device=s.device) if membrane else None
         hip.spike_conv2d(s, Wp, B * D, h, w, Cin, oh, ow, 3, 3, stride, (-1, 0, 1), (-1, 0, 1), out=m, out_spike=out, alpha=a, beta=b,
                          resid=resid if membrane else None, sn=sn, sn_T=D, pos=(B * oh * ow, oh * ow, D * oh * ow, oh * ow))
         return (m, out) if membrane else out
 
     @staticmethod
-    def _fusable(B, D, h, w, C):
-        """The fused-neuron convolution epilogue is built for T = 10 and pays off once the tiles fill the chip."""
-        return D == 10 and (B * D * h * w + 255) // 256 * (C // 96) >= 128
+    def _digit_chunk(B, D, h, w, Cin, Cout, stride):
+        """Largest number of batch elements per launch the digit kernel addresses (0: none)."""
+        for bc in range(B - 1, 0, -1):
+            if hip.conv_wres_applicable(bc * D, h, w, Cin, Cout, stride, 1):
+                return bc
+        return 0
+
+    @staticmethod
+    def _fusable(B, D, h, w, C, Wp=None):
+        """The fused-neuron convolution epilogue pays off once the tiles fill the chip.  The streaming kernels have it for T = 10; the
+        weight-resident digit kernel (96 -> 96 channels, `Wp.digits`) rolls its time loop and takes T = 5 / 20 as well (configs[4])."""
+        big = (B * D * h * w + 255) // 256 * (C // 96) >= 128
+        if D == 10:
+            return big
+        if not (big and D in (5, 20) and C == 96 and getattr(Wp, "digits", None) is not None and Wp.shape[-1] == 9 * 96):
+            return False
+        bc = B if hip.conv_wres_applicable(B * D, h, w, 96, C, 1, 1) else MSFlowEngine._digit_chunk(B, D, h, w, 96, C, 1)
+        return bc > 0 and hip.conv_wres_applicable(bc * D, h, w, 96, C, 1, D)
 
     def _resblock(self, m, rb, s1=None, next_sn=None):
         """MS_ResBlock on a (B,D,h,w,C) membrane: SN -> conv+BN+SN (one kernel) -> conv+BN+identity (one kernel)
@@ -323,7 +357,7 @@ class MSFlowEngine:
         if s1 is None:
             s1 = self._neuron_bd(m, rb.sn1)
         self._rec(rb.name + "sn1.spiking_neuron.", s1, "BDHWC->TBCHW")
-        fus = self._fusable(B, D, h, w, rb.C)
+        fus = self._fusable(B, D, h, w, rb.C, rb.w1)
         if fus:
             s2 = self._conv3x3(s1, rb.w1, rb.C, bn=rb.bn1, sn=rb.sn2)
         else:       # few rows (U-Net bottleneck): the fp32 epilogue can split K over the chip; neuron as its own launch

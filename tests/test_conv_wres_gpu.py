@@ -136,6 +136,41 @@ def test_fused_neuron_with_membrane_output(with_resid, ns):
     assert torch.equal(sp.float(), R.neuron_ref(m.view(T, -1), "lif", 2.0, 0.1, None).view(T * n, Cc))
 
 
+@pytest.mark.parametrize("T,B,H,W", [(20, 2, 24, 32), (5, 2, 24, 48), (20, 4, 32, 32)])
+def test_digit_kernel_fused_neuron_at_T5_and_T20(T, B, H, W):
+    """The digit kernel's fused form rolls its time loop: T = 5 / 20 (BASELINE configs[4]: 20 bins) run the same kernel as T = 10.
+    (b, t) image order as the engine uses it; fp32 membrane within 1e-5 of fp64, spikes = C-oracle neuron of the kernel's OWN
+    membrane bit for bit; the spikes-only form gives the same spikes."""
+    Cc = 96
+    x = spikes((B * T, H, W, Cc), 230 + T)
+    w = rnd((Cc, Cc, 3, 3), 231, -0.1, 0.1)
+    alpha, beta = rnd((Cc,), 232, 0.5, 1.5), rnd((Cc,), 233, -0.2, 0.2)
+    n = H * W
+    resid = rnd((B * T * n, Cc), 234)
+    Wp = pack(w, "i8x3")
+    pos = (B * n, n, T * n, n)
+    sn = hip.NeuronParams("lif", 2.0, 0.1, None)
+    m = torch.full((B * T * n, Cc), float("nan"), device=DEV)
+    sp = torch.zeros((B * T * n, Cc), dtype=torch.uint8, device=DEV)
+    hip.spike_conv2d(x.to(DEV), Wp, B * T, H, W, Cc, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=m, out_spike=sp, alpha=alpha.to(DEV),
+                     beta=beta.to(DEV), resid=resid.to(DEV), sn=sn, sn_T=T, pos=pos)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 1, 1).permute(0, 2, 3, 1).reshape(-1, Cc)
+    ref = ref * alpha.double() + beta.double() + resid.double()
+    m = m.cpu()
+    assert (m.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    mt = m.view(B, T, n * Cc).permute(1, 0, 2).contiguous()                                     # (T, B, ...)
+    want = R.neuron_ref(mt.view(T, -1), "lif", 2.0, 0.1, None).view(T, B, n * Cc).permute(1, 0, 2).reshape(B * T * n, Cc)
+    assert torch.equal(sp.cpu().float(), want) and 0.03 < want.mean() < 0.97
+    sp2 = torch.zeros_like(sp)
+    hip.spike_conv2d(x.to(DEV), Wp, B * T, H, W, Cc, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out_spike=sp2, alpha=alpha.to(DEV),
+                     beta=beta.to(DEV), sn=sn, sn_T=T, pos=pos)
+    h0 = (torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 1, 1).permute(0, 2, 3, 1).reshape(-1, Cc)
+          * alpha.double() + beta.double()).float()
+    w0 = R.neuron_ref(h0.view(B, T, n * Cc).permute(1, 0, 2).contiguous().view(T, -1), "lif", 2.0, 0.1, None)
+    w0 = w0.view(T, B, n * Cc).permute(1, 0, 2).reshape(B * T * n, Cc)
+    assert (sp2.cpu().float() != w0).float().mean().item() <= 2e-4
+
+
 def test_i8x3_digit_planes_reconstruct_the_weight():
     """sdf_split_weight_i8x3: (d2*65536 + d1*256 + d0) * scale is the weight to 2^-23 of the row maximum, digits in range."""
     w = rnd((96, 864), 230, -0.2, 0.2)
