@@ -512,7 +512,7 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
   {
     const char* e = getenv("SDF_GEMM_WS");
     const bool legal = d->N % 96 == 0 && spike_mm_pp_supports(P, false);
-    bool use_pp = legal && ((spike && d->sn_T == 10) ||
+    bool use_pp = legal && ((spike && (d->sn_T == 10 || d->sn_T == 20)) ||
                            (!spike && ((d->K >= 384 && d->M >= 32768) || d->K >= 2048 || (d->K >= 384 && d->N >= 864))));
     if (e && e[0] == '0') use_pp = false;
     if (e && e[0] == '2') use_pp = legal;

@@ -627,6 +627,9 @@ int launch_t(const GemmParams& P, dim3 grid, hipStream_t s) {
       if constexpr (!CONV) { hipLaunchKernelGGL((spike_mm_pp_kernel<NSPLIT, 2, CONV>), grid, dim3(768), 0, s, P); return 0; }
       return SDF_E_SHAPE;
     case 10: hipLaunchKernelGGL((spike_mm_pp_kernel<NSPLIT, 10, CONV>), grid, dim3(768), 0, s, P); return 0;
+    case 20:                                                       // one position per lane half (20 of its 32 accumulator slots)
+      if constexpr (!CONV && NSPLIT == 2) { hipLaunchKernelGGL((spike_mm_pp_kernel<NSPLIT, 20, CONV>), grid, dim3(768), 0, s, P); return 0; }
+      return SDF_E_SHAPE;
     default: return SDF_E_SHAPE;
   }
 }
@@ -637,7 +640,7 @@ int launch_t(const GemmParams& P, dim3 grid, hipStream_t s) {
 bool spike_mm_pp_supports(const GemmParams& P, bool conv) {
   const SdfSpikeGemmDesc& d = P.d;
   if (d.N % BN) return false;
-  if (d.sn_T != 0 && d.sn_T != 10 && !(d.sn_T == 2 && !conv)) return false;
+  if (d.sn_T != 0 && d.sn_T != 10 && !(d.sn_T == 2 && !conv) && !(d.sn_T == 20 && !conv && d.nsplit == 2)) return false;
   // every operand is addressed with a 31-bit byte offset against a raw buffer descriptor
   const int64_t lim = (int64_t)1 << 31;
   int64_t rows = d.M;                                           // highest row index + 1 touched in A / out_spike
