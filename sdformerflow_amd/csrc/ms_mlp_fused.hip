@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64 * RG * CG * TEAMS, (MlpGeo<NSPLIT, T, C16, CG, N
   constexpr int PPG = G::PPG, PPW = G::PPW, PPI = G::PPI;
   constexpr int A1P = G::A1P, A2P = G::A2P, W1P = G::W1P, W2P = G::W2P, WIT = G::WIT, WPIECES = G::WPIECES;
   __shared__ __attribute__((aligned(16))) uint8_t smem[G::LDS];
+  __shared__ __attribute__((aligned(16))) float psn_s[NK == 1 ? 2 * PSN_TABLE(T) : 4];   // PSN: both neurons' coefficients (spike_mm.h psn_T_lds)
   const int wtid = threadIdx.x;
   const int wwave = __builtin_amdgcn_readfirstlane(wtid >> 6);
   const int team = wwave / NW;
@@ -141,6 +142,10 @@ __global__ __launch_bounds__(64 * RG * CG * TEAMS, (MlpGeo<NSPLIT, T, C16, CG, N
   uint8_t* Wb = A2 + G::A2B;
   uint32_t* bar = reinterpret_cast<uint32_t*>(smem + TEAMS * G::TEAM_LDS) + team;
   if (wtid < 16) reinterpret_cast<uint32_t*>(smem + TEAMS * G::TEAM_LDS)[wtid] = 0;
+  if constexpr (NK == 1) {
+    psn_stage<T>(psn_s, P.sn1, wtid, 64 * RG * CG * TEAMS);
+    psn_stage<T>(psn_s + PSN_TABLE(T), P.sn2, wtid, 64 * RG * CG * TEAMS);
+  }
   __syncthreads();                                                      // the only workgroup-wide barrier: counters are zero
   uint32_t epoch = 0;
 #define TEAM_BARRIER()                                         \
@@ -228,7 +233,8 @@ __global__ __launch_bounds__(64 * RG * CG * TEAMS, (MlpGeo<NSPLIT, T, C16, CG, N
         float xs[T], sp[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) xs[t] = e == 0 ? v[t].x : (e == 1 ? v[t].y : (e == 2 ? v[t].z : v[t].w));
-        neuron_T<NK, T>(xs, sp, P.sn1, P.inv_tau1);
+        if constexpr (NK == 1) psn_T_lds<T>(xs, sp, psn_s);
+        else neuron_T<NK, T>(xs, sp, P.sn1, P.inv_tau1);
 #pragma unroll
         for (int t = 0; t < T; ++t) pk[t] |= ((__float_as_uint(sp[t]) >> 29) & 1u) << (8 * e);      // 1.0f has bit 29 set
       }
@@ -332,7 +338,8 @@ __global__ __launch_bounds__(64 * RG * CG * TEAMS, (MlpGeo<NSPLIT, T, C16, CG, N
           const int slot = pp * T + t;
           xs[t] = __builtin_fmaf(acc1[slot >> 2][nb][slot & 3], al, be);      // al carries the accumulator scale (a power of two: exact)
         }
-        neuron_T<NK, T>(xs, sp, P.sn2, P.inv_tau2);
+        if constexpr (NK == 1) psn_T_lds<T>(xs, sp, psn_s + PSN_TABLE(T));
+        else neuron_T<NK, T>(xs, sp, P.sn2, P.inv_tau2);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
           const int slot = pp * T + t;

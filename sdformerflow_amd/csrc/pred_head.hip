@@ -28,6 +28,12 @@ template <int T, int LPP, int NK>
 __global__ __launch_bounds__(256) void pred_head_kernel(PredParams P) {
   constexpr int Cin = 12 * LPP, PPW = 64 / LPP;
   const SdfPredHeadDesc& d = P.d;
+  __shared__ __attribute__((aligned(16))) float psn_s[NK == 1 ? 2 * sdfmm::PSN_TABLE(T) : 4];   // PSN: coefficients of SN_pred and SN_next
+  if constexpr (NK == 1) {
+    sdfmm::psn_stage<T>(psn_s, d.sn_pred, threadIdx.x, 256);
+    if (d.next_spikes) sdfmm::psn_stage<T>(psn_s + sdfmm::PSN_TABLE(T), d.sn_next, threadIdx.x, 256);
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane % LPP, pw = lane / LPP;
   const int64_t pos = ((int64_t)blockIdx.x * 4 + wave) * PPW + pw;
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(256) void pred_head_kernel(PredParams P) {
       float xs[T], sp[T];
 #pragma unroll
       for (int t = 0; t < T; ++t) xs[t] = e == 0 ? v[t].x : (e == 1 ? v[t].y : (e == 2 ? v[t].z : v[t].w));
-      neuron_T<NK, T>(xs, sp, d.sn_pred, P.inv_tau_p);
+      if constexpr (NK == 1) sdfmm::psn_T_lds<T>(xs, sp, psn_s); else neuron_T<NK, T>(xs, sp, d.sn_pred, P.inv_tau_p);
       const float we0 = e == 0 ? w0.x : (e == 1 ? w0.y : (e == 2 ? w0.z : w0.w));
       const float we1 = e == 0 ? w1.x : (e == 1 ? w1.y : (e == 2 ? w1.z : w1.w));
 #pragma unroll
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(256) void pred_head_kernel(PredParams P) {
         pk[t] |= ((__float_as_uint(sp[t]) >> 29) & 1u) << (8 * e);          // 1.0f has bit 29 set
       }
       if (to_next && !P.same_next) {
-        neuron_T<NK, T>(xs, sp, d.sn_next, P.inv_tau_n);
+        if constexpr (NK == 1) sdfmm::psn_T_lds<T>(xs, sp, psn_s + sdfmm::PSN_TABLE(T)); else neuron_T<NK, T>(xs, sp, d.sn_next, P.inv_tau_n);
 #pragma unroll
         for (int t = 0; t < T; ++t) pk2[t] |= ((__float_as_uint(sp[t]) >> 29) & 1u) << (8 * e);
       }
@@ -117,10 +123,10 @@ __global__ __launch_bounds__(256) void pred_head_kernel(PredParams P) {
       float sp0[T], sp1[T], xs[T];
 #pragma unroll
       for (int t = 0; t < T; ++t) xs[t] = acc[t][0];
-      neuron_T<NK, T>(xs, sp0, d.sn_next, P.inv_tau_n);
+      if constexpr (NK == 1) sdfmm::psn_T_lds<T>(xs, sp0, psn_s + sdfmm::PSN_TABLE(T)); else neuron_T<NK, T>(xs, sp0, d.sn_next, P.inv_tau_n);
 #pragma unroll
       for (int t = 0; t < T; ++t) xs[t] = acc[t][1];
-      neuron_T<NK, T>(xs, sp1, d.sn_next, P.inv_tau_n);
+      if constexpr (NK == 1) sdfmm::psn_T_lds<T>(xs, sp1, psn_s + sdfmm::PSN_TABLE(T)); else neuron_T<NK, T>(xs, sp1, d.sn_next, P.inv_tau_n);
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const uint32_t w = ((__float_as_uint(sp0[t]) >> 29) & 1u) | (((__float_as_uint(sp1[t]) >> 29) & 1u) << 8);

@@ -101,7 +101,18 @@ __device__ __forceinline__ void lif_steps(const float (&xs)[T], float (&sp)[T], 
 // tau a power of two: straight-line body), 1 = PSN (the k-ordered fmaf chain of neuron.hip), 2 = any other LIF / IF setting
 template <int NK, int T>
 __device__ __forceinline__ void neuron_T(const float (&xs)[T], float (&sp)[T], const SdfNeuronCfg& n, float inv_tau) {
-  if constexpr (NK == 1) {
+  if constexpr (NK == 1 && T <= 4) {
+    // a 2 x 2 (T' of the window attention) up to 4 x 4 matrix: straight-line, the coefficients are loop-invariant scalar loads the
+    // compiler keeps in registers across calls (the rolled form below re-reads a row per iteration: one scalar-load latency each,
+    // 70 calls per workgroup in qk_front.hip)
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      float hh = n.psn_b[t];
+#pragma unroll
+      for (int k = 0; k < T; ++k) hh = __builtin_fmaf(n.psn_w[t * T + k], xs[k], hh);
+      sp[t] = hh >= 0.f ? 1.f : 0.f;
+    }
+  } else if constexpr (NK == 1) {
     // the row loop is kept rolled (one row of T coefficients in scalar registers at a time); decisions travel as a bit mask
     uint32_t m = 0;
 #pragma unroll 1
@@ -129,6 +140,41 @@ __device__ __forceinline__ void neuron_T(const float (&xs)[T], float (&sp)[T], c
   } else {
     lif_steps<T>(xs, sp, n.kind, n.soft_reset != 0, n.v_reset, n.v_th, n.tau, inv_tau);
   }
+}
+
+// PSN with its coefficients staged in LDS: table = T rows of PSN_TP(T) floats (row t = W[t][0..T-1], zero padded) followed by the T biases.
+// The rolled scalar-load form of neuron_T<1, T> pays one scalar-memory latency per row and call (T = 10: the one-launch MLP ran 96 us
+// with the PSN against 47 us with the LIF, the prediction heads 35-43 against 15-24); here a row is three wave-uniform 16-byte LDS
+// reads (broadcasts) and the next row's reads overlap this row's chain.  Same k-ordered fmaf chain: bit-equal.
+__host__ __device__ constexpr int PSN_TP(int T) { return (T + 3) & ~3; }
+__host__ __device__ constexpr int PSN_TABLE(int T) { return T * PSN_TP(T) + PSN_TP(T); }          // floats
+template <int T>
+__device__ __forceinline__ void psn_stage(float* tbl, const SdfNeuronCfg& n, int tid, int nthreads) {
+  constexpr int TP = PSN_TP(T);
+  for (int i = tid; i < PSN_TABLE(T); i += nthreads) {
+    const int r = i / TP, k = i - r * TP;
+    tbl[i] = r < T ? (k < T ? n.psn_w[r * T + k] : 0.f) : (k < T ? n.psn_b[k] : 0.f);
+  }
+}
+template <int T>
+__device__ __forceinline__ void psn_T_lds(const float (&xs)[T], float (&sp)[T], const float* tbl) {
+  constexpr int TP = PSN_TP(T);
+  uint32_t m = 0;
+#pragma unroll 2
+  for (int t = 0; t < T; ++t) {
+    float w[TP];
+#pragma unroll
+    for (int k4 = 0; k4 < TP / 4; ++k4) {
+      const float4 q = *reinterpret_cast<const float4*>(tbl + t * TP + 4 * k4);
+      w[4 * k4] = q.x; w[4 * k4 + 1] = q.y; w[4 * k4 + 2] = q.z; w[4 * k4 + 3] = q.w;
+    }
+    float hh = tbl[T * TP + t];
+#pragma unroll
+    for (int k = 0; k < T; ++k) hh = __builtin_fmaf(w[k], xs[k], hh);
+    m |= (hh >= 0.f ? 1u : 0u) << t;
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) sp[t] = ((m >> t) & 1u) ? 1.f : 0.f;
 }
 
 bool qk_front_supports(const SdfQkAttnDesc* d);
