@@ -256,6 +256,125 @@ __global__ __launch_bounds__(256) void head_conv_mfma_kernel(HeadParams P, int t
   }
 }
 
+// The PSN form of the same kernel (T <= 10).  A PSN decision needs all T pre-activations of its channel: H[t'] = b[t'] + sum_t W[t'][t] x_t
+// is accumulated on the fly - step t adds W[.][t] x_t to the T accumulators of every channel, the k-ordered fmaf chain of neuron.hip -
+// one 32-channel block at a time (16 channels x T accumulators = 160 registers per lane at T = 10): per block the T steps' MFMAs, then
+// the decisions.  The matrix work is the same as the LIF form's (each block's products are issued once); the voxel is read once per
+// block (L1 / L2 hits the second time).  W is staged transposed in LDS (column t contiguous), read as broadcasts.
+template <int T, int CIN, int NOUT>
+__global__ __launch_bounds__(256) void head_conv_mfma_psn_kernel(HeadParams P, int tiles) {
+  constexpr int KS = 9 * CIN / 2, NBLK = (NOUT + 31) / 32, ROW = 32 * NOUT, TP = sdfmm::PSN_TP(T);
+  const SdfHeadConvDesc& d = P.d;
+  __shared__ __attribute__((aligned(16))) uint8_t sp_s[4][T][ROW];
+  __shared__ __attribute__((aligned(16))) float par_s[2][32 * NBLK];
+  __shared__ __attribute__((aligned(16))) float wt_s[T * TP + TP];                     // wt_s[t * TP + t'] = W[t'][t]; then the biases
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  if (tid < 32 * NBLK) {
+    par_s[0][tid] = (tid < NOUT && d.alpha) ? d.alpha[tid] : 1.f;
+    par_s[1][tid] = (tid < NOUT && d.alpha) ? d.beta[tid] : 0.f;
+  }
+  for (int i = tid; i < T * TP + TP; i += 256) {
+    const int r = i / TP, k = i - r * TP;
+    wt_s[i] = r < T ? (k < T ? d.psn_w[k * T + r] : 0.f) : (k < T ? d.psn_b[k] : 0.f);
+  }
+  float wa[NBLK][KS];
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk)
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_) {
+      const int k = 2 * s_ + lh, tap = k / CIN, ci = k - tap * CIN, n = 32 * blk + l31;
+      wa[blk][s_] = n < NOUT ? d.w[(n * CIN + ci) * 9 + tap] : 0.f;
+    }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, 0x7FFFFFFF, 0x00020000);
+  const int xt = d.W >> 5;
+  uint8_t* my_s = &sp_s[wave][0][0];
+
+#pragma unroll 1
+  for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
+    const int x0 = (tile % xt) << 5, y = (tile / xt) % d.H, b = tile / (xt * d.H);
+    uint32_t off[KS];
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_) {
+      const int k = 2 * s_ + lh, tap = k / CIN, ci = k - tap * CIN;
+      const int yy = y + tap / 3 - 1, xx = x0 + l31 + tap % 3 - 1;
+      const bool ok = (unsigned)yy < (unsigned)d.H && (unsigned)xx < (unsigned)d.W;
+      off[s_] = ok ? (uint32_t)(((int64_t)b * d.x_sb + (int64_t)yy * d.x_sy + (int64_t)xx * d.x_sx + d.x_sc[ci]) * 4) : 0x80000000u;
+    }
+    const uint32_t st4 = (uint32_t)(d.x_st * 4);
+#pragma unroll
+    for (int blk = 0; blk < NBLK; ++blk) {
+      float hacc[T][16];
+#pragma unroll
+      for (int t2 = 0; t2 < T; ++t2) {
+        const float bt = wt_s[T * TP + t2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) hacc[t2][e] = bt;
+      }
+      float xin[2][KS];
+#pragma unroll
+      for (int s_ = 0; s_ < KS; ++s_) xin[0][s_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rs, off[s_], 0, 0));
+      auto one_step = [&](int t, const float (&xc)[KS], float (&xn)[KS]) __attribute__((always_inline)) {
+        if (t + 1 < T) {
+#pragma unroll
+          for (int s_ = 0; s_ < KS; ++s_)
+            xn[s_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rs, off[s_], (uint32_t)(t + 1) * st4, 0));
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[blk][s_], xc[s_], acc, 0, 0, 0);
+        float xv[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 al = *reinterpret_cast<const float4*>(&par_s[0][32 * blk + 8 * q + 4 * lh]);
+          const float4 be = *reinterpret_cast<const float4*>(&par_s[1][32 * blk + 8 * q + 4 * lh]);
+          xv[4 * q + 0] = __builtin_fmaf(acc[4 * q + 0], al.x, be.x); xv[4 * q + 1] = __builtin_fmaf(acc[4 * q + 1], al.y, be.y);
+          xv[4 * q + 2] = __builtin_fmaf(acc[4 * q + 2], al.z, be.z); xv[4 * q + 3] = __builtin_fmaf(acc[4 * q + 3], al.w, be.w);
+        }
+        float wc[TP];                                                   // column t of W: W[t'][t], t' = 0..T-1
+#pragma unroll
+        for (int k4 = 0; k4 < TP / 4; ++k4) {
+          const float4 q = *reinterpret_cast<const float4*>(&wt_s[t * TP + 4 * k4]);
+          wc[4 * k4] = q.x; wc[4 * k4 + 1] = q.y; wc[4 * k4 + 2] = q.z; wc[4 * k4 + 3] = q.w;
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < T; ++t2)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) hacc[t2][e] = __builtin_fmaf(wc[t2], xv[e], hacc[t2][e]);
+      };
+#pragma unroll 1
+      for (int t = 0; t < T; t += 2) {
+        one_step(t, xin[0], xin[1]);
+        if (t + 1 < T) one_step(t + 1, xin[1], xin[0]);
+      }
+      // decisions of this block: channel 32 blk + 8 q + 4 lh + i of pixel l31, all T steps
+#pragma unroll
+      for (int t2 = 0; t2 < T; ++t2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (32 * blk + 8 * q >= NOUT) continue;
+          uint32_t word = 0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) word |= (hacc[t2][4 * q + i] >= 0.f ? 1u : 0u) << (8 * i);
+          *reinterpret_cast<uint32_t*>(my_s + t2 * ROW + l31 * NOUT + 4 * lh + 32 * blk + 8 * q) = word;
+        }
+    }
+    constexpr int PT = ROW / 16, PIECES = T * PT;
+    const uint32_t obase = (uint32_t)(((((int64_t)b * T) * d.H + y) * d.W + x0) * NOUT), ostep = (uint32_t)(d.H * d.W * NOUT);
+#pragma unroll
+    for (int j = 0; j < (PIECES + 63) / 64; ++j) {
+      const int pc = lane + 64 * j;
+      const int tt = pc / PT, o = (pc - tt * PT) * 16;
+      const u32x4h val = *reinterpret_cast<const u32x4h*>(my_s + (pc < PIECES ? tt * ROW + o : 0));
+      __builtin_amdgcn_raw_buffer_store_b128(val, o_rs, pc < PIECES ? obase + (uint32_t)tt * ostep + (uint32_t)o : 0x80000000u, 0, 0);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void flow_out_kernel(const float* __restrict__ pred, float* __restrict__ out, int B, int D,
                                                        int h, int w, int64_t ldp, int C, int H, int W, float sy, float sx) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -307,6 +426,13 @@ int launch_head_mfma(const HeadParams& P, hipStream_t s) {
   const int tiles = P.d.B * P.d.H * (P.d.W / 32);
   const int want = (tiles + 3) / 4;
   dim3 grid((unsigned)(want < 768 ? want : 768));                  // three workgroups per CU are resident; the rest of the tiles loop
+  if (P.d.sn_kind == SDF_PSN) {
+    if constexpr (T <= 10) {
+      if (P.d.Cin == 2 && P.d.Cout == 48) { hipLaunchKernelGGL((head_conv_mfma_psn_kernel<T, 2, 48>), grid, dim3(256), 0, s, P, tiles); return 0; }
+      if (P.d.Cin == 2 && P.d.Cout == 32) { hipLaunchKernelGGL((head_conv_mfma_psn_kernel<T, 2, 32>), grid, dim3(256), 0, s, P, tiles); return 0; }
+    }
+    return SDF_E_SHAPE;
+  }
   const bool fast = P.d.sn_kind == SDF_LIF && P.d.soft_reset != 0 && P.inv_tau != 0.f;
 #define SDF_HEAD_CASE(CI, CO)                                                                                              \
   if (P.d.Cin == CI && P.d.Cout == CO) {                                                                                   \
@@ -354,7 +480,8 @@ extern "C" int sdf_head_conv_sn_fwd(const SdfHeadConvDesc* d, void* stream) {
   int64_t span = (int64_t)(d->B - 1) * P.d.x_sb + (int64_t)(d->T - 1) * P.d.x_st + (int64_t)(d->H - 1) * P.d.x_sy + (int64_t)(d->W - 1) * P.d.x_sx;
   int64_t scmax = 0;
   for (int ci = 0; ci < d->Cin && ci < 4; ++ci) scmax = P.d.x_sc[ci] > scmax ? P.d.x_sc[ci] : scmax;
-  const bool mfma_ok = !no_mfma && d->sn_kind != SDF_PSN && d->W % 32 == 0 && (span + scmax + 1) * 4 < (1LL << 31) && d->Cin <= 4 &&
+  const bool psn_mfma = d->sn_kind == SDF_PSN && d->T <= 10 && d->Cin == 2 && (d->Cout == 48 || d->Cout == 32);
+  const bool mfma_ok = !no_mfma && (d->sn_kind != SDF_PSN || psn_mfma) && d->W % 32 == 0 && (span + scmax + 1) * 4 < (1LL << 31) && d->Cin <= 4 &&
                        (int64_t)d->B * d->T * d->H * d->W * d->Cout < (1LL << 31) &&
                        P.d.x_sb >= 0 && P.d.x_st >= 0 && P.d.x_sy >= 0 && P.d.x_sx >= 0;
   int rc;
