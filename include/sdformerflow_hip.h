@@ -348,9 +348,10 @@ int sdf_ms_mlp_fwd(const SdfMsMlpDesc* d, void* stream);
  *   row m = (img, oy, ox) reads input pixel (oy*sy + dy[ky], ox*sx + dx[kx]); zero outside the image
  *     (a 3x3 / pad 1 convolution: dy = dx = {-1, 0, 1}; the parity classes of a stride-2 transposed convolution
  *     are 1- or 2-tap grids with their own offsets and an out_rowmap that places the class's outputs)
- *   epilogue: the fp32 one (alpha/beta/resid/out_rowmap, out is (rows, Cout) fp32 NHWC) or, with sn_T == 10,
+ *   epilogue: the fp32 one (alpha/beta/resid/out_rowmap, out is (rows, Cout) fp32 NHWC) or, with sn_T == 10 (int8 digit
+ *     planes on the weight-resident kernel: also 5 and 20, its time loop is rolled),
  *     the fused neuron (out_spike u8 NHWC); pos_* describe how the imgs dimension factors into (time, position).
- *     With sn_T == 10 and g.out != NULL the pre-activation  fmaf(acc, alpha, beta) (+ g.resid)  is ALSO stored to g.out
+ *     With sn_T > 0 and g.out != NULL the pre-activation  fmaf(acc, alpha, beta) (+ g.resid)  is ALSO stored to g.out
  *     (fp32, row stride g.ldo) and the neuron runs on that sum: MS_ResBlock's conv2 -> BN -> + identity and the next
  *     block's sn1 in one launch (reference Spiking_modules.py:922-933).
  */
@@ -393,9 +394,9 @@ int sdf_qk_gate_strided_fwd(const uint8_t* q, const uint8_t* k, uint8_t* e, int 
  * one kernel, spikes out.  Replaces MS_PED_Spiking_PatchEmbed_Conv_sfn.head (reference Spiking_modules.py:1782).
  *   x   (B*T, H, W, Cin) fp32, NHWC, image index = b*T + t          w (Cout, Cin, 3, 3) fp32 (the module's layout)
  *   out (B*T, H, W, Cout) u8 spikes                                  alpha / beta (Cout) or NULL
- * Accumulation: fp32 products and sums in (ky, kx, cin) order - on the exact fp32 matrix pipe (v_mfma_f32_32x32x2_f32) for LIF / IF
- * neurons when W % 32 == 0, else (and for the PSN, which needs all T pre-activations at once) one fmaf chain per output on the
- * vector pipe.  Built for (Cin, Cout) in {(2,32), (2,48), (2,64), (4,48)}, T in {5, 10, 20}, W % 16 == 0; anything else returns
+ * Accumulation: fp32 products and sums in (ky, kx, cin) order - on the exact fp32 matrix pipe (v_mfma_f32_32x32x2_f32) when
+ * W % 32 == 0 (LIF / IF; the PSN for T <= 10 and Cin = 2: its H is accumulated on the fly per 32-channel block), else one fmaf
+ * chain per output on the vector pipe.  Built for (Cin, Cout) in {(2,32), (2,48), (2,64), (4,48)}, T in {5, 10, 20}, W % 16 == 0; anything else returns
  * SDF_E_SHAPE and the caller keeps its library convolution + sdf_neuron_fwd pair.
  */
 typedef struct SdfHeadConvDesc {
