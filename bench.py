@@ -144,13 +144,14 @@ def time_dominant_kernels(model, iters=40):
             "traffic": CONV_TRAFFIC_BYTES if digits else None, "traffic_unit": "bytes per launch (HBM read + write), mean of the two forms",
             "traffic_over_algorithmic": CONV_TRAFFIC_BYTES / (sum(CONV_ALGORITHMIC_BYTES.values()) / 2) if digits else None,
             "traffic_source": CONV_TRAFFIC_SOURCE,
-            "pmc": "profiles/r3g_pmc_kernels.txt: 683 MFMA and 5 600 VALU instructions per wave (8.2 VALU per MFMA), "
-                   "SQ_VALU_MFMA_BUSY_CYCLES = 34-38 % of the kernel's cycles per SIMD at an effective 2.2 GHz, LDS bank conflicts 6 % of "
-                   "LDS cycles: the kernel is bound by its epilogue's vector instructions, not by the matrix pipe",
+            "pmc": "profiles/r3s_pmc_forward.txt (the four launches inside one forward) and r3i_pmc_kernels_after_operand_swap.txt: 683 MFMA "
+                   "and ~4 000 VALU instructions per wave (6 VALU per MFMA; 8.2 before the weights became the MFMA's row operand, "
+                   "r3g_pmc_kernels.txt), SQ_VALU_MFMA_BUSY_CYCLES = 39 % of the kernel's cycles per SIMD at an effective 2.2 GHz, LDS bank "
+                   "conflicts 6 % of LDS cycles: the kernel is bound by its epilogue's vector instructions, not by the matrix pipe",
             "note": "algorithmic flops (2 per multiply-add of the convolution) against the dense bf16/f16 MFMA peak.  The kernel issues "
                     + ("3 int8 digit MFMAs (v_mfma_i32_32x32x32_i8, K = 32 in the cycles the 16-bit form needs for K = 16) per product: 1.5x "
                        "the algorithmic work on the 16-bit pipe's scale" if digits else f"{ns} 16-bit MFMAs per product") +
-                    "; the matrix pipe is busy 34-38 % of the kernel's cycles (PMC, profiles/r3g_pmc_kernels.txt)"}
+                    "; the matrix pipe is busy 39 % of the kernel's cycles (PMC, profiles/r3s_pmc_forward.txt)"}
     gemm["frac"] = gemm["achieved"] / gemm["peak"]
     gemm["frac_of_issued_mfma"] = issued * gemm["frac"]
     # neuron: T=10 over the stage-0 MLP hidden tensor shape (10 x 72*96*384 fp32 in, u8 out)
