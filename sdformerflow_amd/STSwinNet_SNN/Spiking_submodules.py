@@ -137,6 +137,9 @@ class GatedLIFNode(nn.Module):
             raise NotImplementedError("GatedLIFNode: inference only (the surrogate gradient is not built)")
         if x_seq.shape[0] != self.T:
             raise hip.SdfError(f"GatedLIFNode(T={self.T}) got {x_seq.shape[0]} steps")
+        if not x_seq.is_cuda:
+            raise hip.SdfError("GatedLIFNode runs on the GPU tensor's device only (no CPU path in the product; the CPU restatement "
+                               "is oracle.sdformer_oracle.glif_multistep)")
         with torch.no_grad():
             al, be, ga = self.alpha.sigmoid(), self.beta.sigmoid(), self.gamma.sigmoid()
             leak = 1 - al * (1 - self.tau.sigmoid())

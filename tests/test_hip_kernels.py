@@ -860,9 +860,11 @@ def test_plif_slttlif_glif_neurons_against_the_reference_fixture(T):
             hip.neuron_fwd(x, out, T, 1, n, 0, n, 0, n, p)
             assert torch.equal(out, want), (kind, tag)
     m = Spiking_neuron(num_steps=T, neuron_type="glif").to(DEV).eval()
-    m.load_state_dict({kk[len(f"glif_T{T}/"):]: torch.from_numpy(v) for kk, v in g.items() if kk.startswith(f"glif_T{T}/")})
+    gsd = {kk[len(f"glif_T{T}/"):]: torch.from_numpy(v) for kk, v in g.items() if kk.startswith(f"glif_T{T}/")}
+    m.load_state_dict(gsd)
     got, want = m(3.0 * x).to(torch.uint8), torch.from_numpy(g[f"glif_T{T}_s"]).to(DEV)
     assert (got != want).float().mean().item() <= 1e-3
+    assert torch.equal(want.cpu(), O.glif_multistep(3.0 * x.cpu(), gsd, "spiking_neuron.").to(torch.uint8))      # the oracle is exact
     with pytest.raises(hip.SdfError):
         hip.lif_fwd(x, tau=1.0)                                                  # tau = 1 is neither form
 
