@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SDF_VERSION 102
+#define SDF_VERSION 103
 
 enum { SDF_F32 = 0, SDF_U8 = 1 };
 enum { SDF_LIF = 0, SDF_PSN = 1, SDF_IF = 2 };
@@ -299,15 +299,36 @@ typedef struct SdfQkAttnDesc {
   void* workspace;      int64_t workspace_bytes;
   void* gemm_workspace; int64_t gemm_workspace_bytes;
   int32_t flags;        /* SDF_QK_* bits */
+  /* Wide stages (C >= 256, T' = 2, LIF / IF neurons, two fp16 planes; csrc/ms_wide.hip): with x_src set the call is THREE launches -
+   * slice neuron, one kernel for q | k + BN + neurons + token gate, and the projection as a "position-major" product whose waves own
+   * all xD time steps of a few positions of the (xB, xD, xHW, C) buffer x (xB * xD * xHW == x_rows):
+   *   x_src   : int32 per row of x, made by sdf_window_zsrc_map from slice_map (where that row's gated spikes start in E); NULL = the
+   *             general kernels above
+   *   emit_s1 : optional u8 [x_rows][C]: receives SN_emit( x after the update ) over the xD steps of every position - the first
+   *             neuron of the MLP that follows (reference Spiking_swin_transformer3D.py:168; hand it to SdfMsMlpDesc.s1_in), so the
+   *             updated x is not read again; emit_sn = that neuron (LIF / IF). */
+  const int32_t* x_src;
+  int32_t xB, xD;
+  int64_t xHW;
+  uint8_t* emit_s1;
+  SdfNeuronCfg emit_sn;
 } SdfQkAttnDesc;
 
 enum {
   SDF_QK_KEEP_SPIKES = 1,    /* leave the q | k spikes in `workspace` behind E (what the four-launch form always does; the parity tape) */
-  SDF_QK_FOUR_LAUNCHES = 2   /* never take the one-launch first half (A/B reference; same as SDF_QK_FRONT=0 in the environment) */
+  SDF_QK_FOUR_LAUNCHES = 2,  /* never take the one-launch first half (A/B reference; same as SDF_QK_FRONT=0 in the environment) */
+  SDF_QK_NARROW = 4          /* never take the wide-stage kernels (A/B reference; same as SDF_WIDE=0 in the environment) */
 };
+
+/* Inverse of the slice map for the projection's head scramble (reference Spiking_swin_transformer3D.py:709-710): x_src[r] = byte offset
+ * in the gated-spike tensor E (T', B_, N1, C) of Z[t, b, n, 0] for the slice-map entry (t, b, n) that names row r of x; rows no entry
+ * names keep their old value (there are none for a map made by sdf_window_slice_map over the same x).  x_src: int32 [x_rows]. */
+int sdf_window_zsrc_map(const int32_t* slice_map, int64_t B_, int Tq, int N1, int nH, int32_t* x_src, void* stream);
 
 int64_t sdf_qk_attn_workspace_bytes(int64_t B_, int Tq, int N1, int C);
 int sdf_qk_attn_fwd(const SdfQkAttnDesc* d, void* stream);
+/* 1 when sdf_qk_attn_fwd will run this descriptor on the wide-stage kernels (and therefore honours emit_s1), else 0; host-only. */
+int sdf_qk_attn_is_wide(const SdfQkAttnDesc* d);
 
 /* ---------------------------------------------------------------------------------------------
  * MS MLP, whole (row a7):  x += BN2( SN2( BN1( SN1(x) W1^T ) ) W2^T )  in place on a (B, D, HW, C) fp32 buffer, neurons over
@@ -327,16 +348,23 @@ typedef struct SdfMsMlpDesc {
   void* workspace;      int64_t workspace_bytes;
   void* gemm_workspace; int64_t gemm_workspace_bytes;
   int32_t flags;        /* SDF_MLP_* bits */
+  /* Wide stages (C >= 256, LIF / IF, two fp16 planes, D in {10, 20}; csrc/ms_wide.hip): fc1 + BN1 + SN2 and fc2 + BN2 + shortcut as two
+   * position-major launches.  s1_in != NULL: the SN1 spikes are already at the head of `workspace` (written there by
+   * SdfQkAttnDesc.emit_s1 == workspace): no neuron launch, x is only read by the last launch's shortcut. */
+  const uint8_t* s1_in;
 } SdfMsMlpDesc;
 
 enum {
   SDF_MLP_KEEP_SPIKES = 1,   /* leave SN1's and SN2's spikes in `workspace` (u8 [tokens][C], then [tokens][Ch] at the next 256-byte
                                 boundary): what the three-launch form always does; the one-launch form only on request */
-  SDF_MLP_THREE_LAUNCHES = 2 /* never take the one-launch kernel (A/B reference; same as SDF_MLP_FUSED=0 in the environment) */
+  SDF_MLP_THREE_LAUNCHES = 2,/* never take the one-launch kernel (A/B reference; same as SDF_MLP_FUSED=0 in the environment) */
+  SDF_MLP_NARROW = 4         /* never take the wide-stage kernels (A/B reference; same as SDF_WIDE=0 in the environment) */
 };
 
 int64_t sdf_ms_mlp_workspace_bytes(int64_t tokens, int C, int Ch);
 int sdf_ms_mlp_fwd(const SdfMsMlpDesc* d, void* stream);
+/* 1 when sdf_ms_mlp_fwd will run this descriptor on the wide-stage kernels (and therefore accepts s1_in), else 0; host-only. */
+int sdf_ms_mlp_is_wide(const SdfMsMlpDesc* d);
 
 /* ---------------------------------------------------------------------------------------------
  * Spike convolution (implicit GEMM):  out = epilogue( im2col(X) x W^T ) with X an NHWC u8 spike image batch.

@@ -60,7 +60,20 @@ extern "C" int sdf_window_slice_map(int32_t* map, int B, int D, int H, int W, in
 extern "C" int64_t sdf_qk_attn_workspace_bytes(int64_t B_, int Tq, int N1, int C) {
   if (B_ < 1 || Tq < 1 || N1 < 1 || C < 1) return 0;
   const int64_t M = B_ * Tq * N1;
-  return ((M * C + 255) / 256 * 256) + M * 2 * C;              // spikes of the slices (later E), then q | k
+  // spikes of the slices (later E), then q | k; the wide-stage form (ms_wide.hip) keeps the slice spikes in a third region
+  return ((M * C + 255) / 256 * 256) + ((M * 2 * C + 255) / 256 * 256) + M * C;
+}
+
+extern "C" int sdf_qk_attn_is_wide(const SdfQkAttnDesc* d) {
+  if (!d || !d->x || !d->slice_map || !d->p_planes) return 0;
+  if (d->B_ < 1 || d->Tq < 1 || d->N1 < 1 || d->C < 32 || d->C % 32 || d->nH < 1 || d->C != d->nH * 32) return 0;
+  return sdfmm::ms_wide_attn_supports(d) ? 1 : 0;
+}
+
+extern "C" int sdf_ms_mlp_is_wide(const SdfMsMlpDesc* d) {
+  if (!d || !d->x || !d->fc1_planes || !d->fc2_planes) return 0;
+  if (d->B < 1 || d->D < 1 || d->HW < 1 || d->C < 32 || d->C % 32 || d->Ch < 32 || d->Ch % 32) return 0;
+  return sdfmm::ms_wide_mlp_supports(d) ? 1 : 0;
 }
 
 extern "C" int sdf_qk_attn_fwd(const SdfQkAttnDesc* d, void* stream) {
@@ -75,6 +88,23 @@ extern "C" int sdf_qk_attn_fwd(const SdfQkAttnDesc* d, void* stream) {
   const int64_t rows = d->B_ * d->N1, M = rows * Tq;
   uint8_t* xs = reinterpret_cast<uint8_t*>(d->workspace);
   uint8_t* qk = xs + (M * C + 255) / 256 * 256;
+
+  // wide stages: slice neuron -> [q | k + BN + PE + neurons + gate] -> position-major projection (+ the MLP's first neuron)
+  if (sdfmm::ms_wide_attn_supports(d)) {
+    uint8_t* e = xs;
+    uint8_t* xsw = qk + (M * 2 * C + 255) / 256 * 256;
+    SdfNeuronDesc n = {};
+    n.x = d->x; n.out = xsw; n.T = Tq; n.out_dtype = SDF_U8;
+    n.nb = 1; n.ni = rows * C; n.x_sb = 0; n.x_st = 0; n.o_sb = 0; n.o_st = rows * C;
+    n.rowmap = d->slice_map; n.rowlen = C;
+    fill_neuron(n, d->sn_proj);
+    int rcw = sdf_neuron_fwd(&n, stream);
+    if (rcw) return rcw;
+    rcw = sdfmm::launch_ms_wide_front(d, xsw, e, qk, (d->flags & SDF_QK_KEEP_SPIKES) != 0, sdf_stream(stream));
+    if (rcw) return rcw;
+    return sdfmm::launch_ms_wide_proj(d, e, sdf_stream(stream));
+  }
+  if (d->emit_s1) return SDF_E_SHAPE;                           // only the wide-stage form emits the next neuron's spikes
 
   // steps 1 - 3 as one launch where the kernel has an instantiation (SDF_QK_FRONT=0 / SDF_QK_FOUR_LAUNCHES: the A/B reference below)
   bool front = false;
@@ -155,6 +185,20 @@ extern "C" int sdf_ms_mlp_fwd(const SdfMsMlpDesc* d, void* stream) {
   const int64_t hw = d->HW;
   uint8_t* s1 = reinterpret_cast<uint8_t*>(d->workspace);
   uint8_t* s2 = s1 + (tokens * C + 255) / 256 * 256;
+  // wide stages: [SN1 unless the attention's projection already emitted it] -> fc1 + BN1 + SN2 -> fc2 + BN2 + shortcut
+  if (sdfmm::ms_wide_mlp_supports(d)) {
+    if (d->s1_in && d->s1_in != s1) return SDF_E_SHAPE;
+    if (!d->s1_in) {
+      SdfNeuronDesc n = {};
+      n.x = d->x; n.out = s1; n.T = D; n.out_dtype = SDF_U8;
+      n.nb = d->B; n.ni = hw * C; n.x_sb = (int64_t)D * hw * C; n.x_st = hw * C; n.o_sb = (int64_t)D * hw * C; n.o_st = hw * C;
+      fill_neuron(n, d->sn1);
+      const int rcw = sdf_neuron_fwd(&n, stream);
+      if (rcw) return rcw;
+    }
+    return sdfmm::launch_ms_wide_mlp(d, s1, s2, sdf_stream(stream));
+  }
+  if (d->s1_in) return SDF_E_SHAPE;
   // one launch where the kernel has an instantiation (SDF_MLP_FUSED=0 / SDF_MLP_THREE_LAUNCHES: the A/B reference below)
   {
     const char* e = getenv("SDF_MLP_FUSED");

@@ -411,9 +411,17 @@ class MSFlowEngine:
             res = res.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
         return self._conv3x3(s1, self.proj_w, self.proj_w.shape[1], stride=2, bn=self.proj_bn, resid=res)
 
-    def attention(self, x, blk: _Block, score_out=None):
+    def _zsrc_map(self, rowmap, B_, Tq, N1, nH, x_rows, key):
+        key = ("zsrc", nH) + key
+        if key not in self._maps:
+            self._maps[key] = hip.window_zsrc_map(rowmap, B_, Tq, N1, nH, x_rows)     # built on the device, cached per shape
+        return self._maps[key]
+
+    def attention(self, x, blk: _Block, score_out=None, emit=None):
         """x (B,D,H,W,C) += SSA(x), in place (reference Spiking_swin_transformer3D.py:781-821, 661-717, :840).  `score_out` (a list)
-        also receives the block's attention score (T', B_, Wh, Ww, C) - `return_attention=True` (:807-808) without abandoning x."""
+        also receives the block's attention score (T', B_, Wh, Ww, C) - `return_attention=True` (:807-808) without abandoning x.
+        `emit` = (u8 buffer, neuron): on the wide stages the projection's launch also leaves SN(x) over D there (the MLP's first
+        neuron, csrc/ms_wide.hip); `self._emitted` says whether it did."""
         self._check_cl(x)
         B, D, H, W, Cc = x.shape
         ws, ss = get_window_size((D, H, W), blk.window_size, blk.shift_size)
@@ -433,11 +441,11 @@ class MSFlowEngine:
             xs = torch.empty((Tq, rows, Cc), dtype=torch.uint8, device=x.device)
             hip.neuron_fwd(x, xs, Tq, 1, rows * Cc, 0, 0, 0, rows * Cc, blk.sn_proj, rowmap=rowmap, rowlen=Cc)
             self._rec(blk.name + "attn.proj_sn.spiking_neuron.", xs, "flat")
-        if blk.qk is not None:
-            hip.qk_attn(x, rowmap, B_, Tq, N1, blk.nH, blk.p, blk.sn_proj, blk.sn_q, blk.sn_k, blk.sn2_q, qk=blk.qk, keep_ws=keep)
-        else:
-            hip.qk_attn(x, rowmap, B_, Tq, N1, blk.nH, blk.p, blk.sn_proj, blk.sn_q, blk.sn_k, blk.sn2_q,
-                        q_lin=blk.q, k_lin=blk.k, pe=blk.pe, keep_ws=keep)
+        info = {}
+        zsrc = self._zsrc_map(rowmap, B_, Tq, N1, blk.nH, B * D * H * W, (B, D, H, W, tuple(ws), tuple(ss))) if Cc >= 256 and Tq == 2 else None
+        kw = dict(qk=blk.qk) if blk.qk is not None else dict(q_lin=blk.q, k_lin=blk.k, pe=blk.pe)
+        hip.qk_attn(x, rowmap, B_, Tq, N1, blk.nH, blk.p, blk.sn_proj, blk.sn_q, blk.sn_k, blk.sn2_q, keep_ws=keep, x_src=zsrc, emit=emit,
+                    info=info, **kw)
         if score_out is not None:
             # the gate's output replaced the slice spikes at the head of the workspace (csrc/qk_attn.hip)
             e = keep[0][:Tq * B_ * N1 * Cc].view(Tq, B_ * N1, Cc)
@@ -448,13 +456,15 @@ class MSFlowEngine:
             q, k = (qk.view(M, 2 * Cc)[:, :Cc], qk.view(M, 2 * Cc)[:, Cc:]) if blk.qk is not None else (qk[:M * Cc], qk[M * Cc:])
             self._rec(blk.name + "attn.sn_q.spiking_neuron.", q.reshape(Tq, B_ * N1, Cc), "flat")
             self._rec(blk.name + "attn.sn_k.spiking_neuron.", k.reshape(Tq, B_ * N1, Cc), "flat")
+        self._emitted = bool(info.get("emitted"))
         return x
 
-    def mlp(self, x, blk: _Block):
-        """x (B,D,H,W,C) += MLP(x) over the true time axis D, in place (reference :164-181, :845)."""
+    def mlp(self, x, blk: _Block, ws=None, s1_ready=False):
+        """x (B,D,H,W,C) += MLP(x) over the true time axis D, in place (reference :164-181, :845).  `ws` / `s1_ready`: the caller's
+        workspace with SN1's spikes already at its head (wide stages: left there by the attention's projection)."""
         self._check_cl(x)
         keep = [] if self.tape is not None else None
-        hip.ms_mlp(x, blk.fc1, blk.fc2, blk.sn1, blk.sn2, keep_ws=keep)      # one C-ABI call (csrc/qk_attn.hip: sdf_ms_mlp_fwd)
+        hip.ms_mlp(x, blk.fc1, blk.fc2, blk.sn1, blk.sn2, keep_ws=keep, ws=ws, s1_ready=s1_ready)      # one C-ABI call (csrc/qk_attn.hip: sdf_ms_mlp_fwd)
         if keep:
             B, D, H, W, Cc = x.shape
             tok = B * D * H * W
@@ -465,7 +475,9 @@ class MSFlowEngine:
     def swin_block(self, x, s, i):
         blk = self.stages[s][i]
         last = self.scores is not None and i == len(self.stages[s]) - 1          # log=True: the last block of every stage (:1090-1105)
-        return self.mlp(self.attention(x, blk, self.scores if last else None), blk)
+        ws = hip.ms_mlp_workspace(x, blk.fc1.N) if x.shape[-1] >= 256 else None      # wide stages: the projection emits the MLP's first spikes
+        self.attention(x, blk, self.scores if last else None, emit=(ws, blk.sn1) if ws is not None else None)
+        return self.mlp(x, blk, ws=ws, s1_ready=self._emitted)
 
     def patch_merge(self, x, s, packed=None):
         """(B,D,H,W,C) -> (B,D,H/2,W/2,2C) (reference :952-974)."""

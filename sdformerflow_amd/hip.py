@@ -23,7 +23,7 @@ KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
 EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
            "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd", "sdf_head_conv_sn_fwd",
            "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes",
-           "sdf_window_slice_map", "sdf_qk_attn_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
+           "sdf_window_slice_map", "sdf_window_zsrc_map", "sdf_qk_attn_fwd", "sdf_qk_attn_is_wide", "sdf_ms_mlp_is_wide", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
            "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_pred_head_fwd", "sdf_pointwise_conv_f32_fwd", "sdf_neuron_multi_fwd", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
            "sdf_rows_gather_fwd", "sdf_rows_scatter_fwd",
            "sdf_split_weight_i8x3", "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd",
@@ -416,10 +416,12 @@ class QkAttnDesc(C.Structure):
                 ("p_acc_scale", C.c_float),
                 ("sn_proj", NeuronCfg), ("sn_q", NeuronCfg), ("sn_k", NeuronCfg), ("sn2_q", NeuronCfg),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-                ("gemm_workspace", C.c_void_p), ("gemm_workspace_bytes", C.c_int64), ("flags", C.c_int32)]
+                ("gemm_workspace", C.c_void_p), ("gemm_workspace_bytes", C.c_int64), ("flags", C.c_int32),
+                ("x_src", C.c_void_p), ("xB", C.c_int32), ("xD", C.c_int32), ("xHW", C.c_int64), ("emit_s1", C.c_void_p),
+                ("emit_sn", NeuronCfg)]
 
 
-SDF_QK_KEEP_SPIKES, SDF_QK_FOUR_LAUNCHES = 1, 2
+SDF_QK_KEEP_SPIKES, SDF_QK_FOUR_LAUNCHES, SDF_QK_NARROW = 1, 2, 4
 
 
 def _ncfg(c, p: NeuronParams):
@@ -442,10 +444,22 @@ def window_slice_map(B, D, H, W, ws, ss, device):
     return m, B_
 
 
+def window_zsrc_map(slice_map, B_, Tq, N1, nH, x_rows):
+    """sdf_window_zsrc_map: per row of x the byte offset of its gated spikes in E behind the reference's head scramble - what the
+    wide-stage projection (csrc/ms_wide.hip) gathers its operand through.  int32 (x_rows,)."""
+    z = torch.zeros((x_rows,), dtype=torch.int32, device=slice_map.device)
+    _check(lib().sdf_window_zsrc_map(C.c_void_p(slice_map.data_ptr()), C.c_int64(B_), C.c_int(Tq), C.c_int(N1), C.c_int(nH),
+                                     C.c_void_p(z.data_ptr()), _stream()), "sdf_window_zsrc_map")
+    return z
+
+
 def qk_attn(x, slice_map, B_, Tq, N1, nH, p_lin, sn_proj, sn_q, sn_k, sn2_q, qk=None, q_lin=None, k_lin=None, pe=None, keep_ws=None,
-            four_launches=False):
+            four_launches=False, x_src=None, emit=None, narrow=False, info=None):
     """sdf_qk_attn_fwd: x (B,D,H,W,C) fp32 channel-last += SSA(x), in place.  `qk` = {"Wp", "alpha", "beta", "add"} for the
-    stacked projection, or q_lin / k_lin (objects with Wp / alpha / beta) + pe for separate ones; p_lin has Wp / bias / alpha / beta."""
+    stacked projection, or q_lin / k_lin (objects with Wp / alpha / beta) + pe for separate ones; p_lin has Wp / bias / alpha / beta.
+    `x_src` (window_zsrc_map) lets the library take its wide-stage kernels; `emit` = (u8 buffer, NeuronParams): the projection
+    also writes SN(x after the update) over D there (the MLP's first neuron) when the call runs on the wide-stage kernels - `info`
+    (a dict) then receives "emitted": True; `narrow` forces the general kernels (A/B)."""
     Cc = x.shape[-1]
     d = QkAttnDesc()
     d.x, d.slice_map = _ptr(x, torch.float32), _ptr(slice_map, torch.int32)
@@ -467,7 +481,15 @@ def qk_attn(x, slice_map, B_, Tq, N1, nH, p_lin, sn_proj, sn_q, sn_k, sn2_q, qk=
     d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
     gws = workspace(x.device)
     d.gemm_workspace, d.gemm_workspace_bytes = gws.data_ptr(), gws.numel()
-    d.flags = (SDF_QK_KEEP_SPIKES if keep_ws is not None else 0) | (SDF_QK_FOUR_LAUNCHES if four_launches else 0)
+    d.flags = (SDF_QK_KEEP_SPIKES if keep_ws is not None else 0) | (SDF_QK_FOUR_LAUNCHES if four_launches else 0) | \
+        (SDF_QK_NARROW if narrow else 0)
+    if x_src is not None:
+        d.x_src, d.xB, d.xD, d.xHW = _ptr(x_src, torch.int32), x.shape[0], x.shape[1], x.shape[2] * x.shape[3]
+    if emit is not None and lib().sdf_qk_attn_is_wide(C.byref(d)) == 1 and emit[1].kind in ("lif", "if"):
+        d.emit_s1 = _ptr(emit[0], torch.uint8)                # (only the wide-stage projection emits the next neuron's spikes)
+        _ncfg(d.emit_sn, emit[1])
+        if info is not None:
+            info["emitted"] = True
     _check(lib().sdf_qk_attn_fwd(C.byref(d), _stream()), "sdf_qk_attn_fwd")
     if keep_ws is not None:
         keep_ws.append(ws)                  # the call's intermediates (u8 spikes, layout: sdf_qk_attn_workspace_bytes) for the parity tape
@@ -481,15 +503,23 @@ class MsMlpDesc(C.Structure):
                 ("fc2_planes", C.c_void_p), ("fc2_alpha", C.c_void_p), ("fc2_beta", C.c_void_p), ("fc2_acc_scale", C.c_float),
                 ("sn1", NeuronCfg), ("sn2", NeuronCfg),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-                ("gemm_workspace", C.c_void_p), ("gemm_workspace_bytes", C.c_int64), ("flags", C.c_int32)]
+                ("gemm_workspace", C.c_void_p), ("gemm_workspace_bytes", C.c_int64), ("flags", C.c_int32), ("s1_in", C.c_void_p)]
 
 
-MLP_KEEP_SPIKES, MLP_THREE_LAUNCHES = 1, 2
+MLP_KEEP_SPIKES, MLP_THREE_LAUNCHES, MLP_NARROW = 1, 2, 4
 
 
-def ms_mlp(x, fc1, fc2, sn1, sn2, keep_ws=None, three_launches=False):
+def ms_mlp_workspace(x, Ch):
+    """The caller-owned workspace of ms_mlp for x (B,D,H,W,C): u8, SN1's spikes [tokens][C] at its head (what qk_attn's `emit` fills)."""
+    B, D, H, W, Cc = x.shape
+    nbytes = lib().sdf_ms_mlp_workspace_bytes(C.c_int64(B * D * H * W), C.c_int(Cc), C.c_int(Ch))
+    return torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+
+
+def ms_mlp(x, fc1, fc2, sn1, sn2, keep_ws=None, three_launches=False, ws=None, s1_ready=False, narrow=False):
     """sdf_ms_mlp_fwd: x (B,D,H,W,C) fp32 channel-last += MLP(x) over the time axis D, in place.  `keep_ws` (a list) receives
-    the workspace with the SN1 / SN2 spikes (parity tape); `three_launches` selects the unfused A/B reference."""
+    the workspace with the SN1 / SN2 spikes (parity tape); `three_launches` selects the unfused A/B reference.  `ws` =
+    ms_mlp_workspace(...) of the caller; with `s1_ready` its head already holds SN1(x) (wide stages: written by qk_attn's `emit`)."""
     B, D, H, W, Cc = x.shape
     d = MsMlpDesc()
     d.x, d.B, d.D, d.HW, d.C, d.Ch, d.nsplit = _ptr(x, torch.float32), B, D, H * W, Cc, fc1.N, fc1.Wp.shape[0]
@@ -497,12 +527,18 @@ def ms_mlp(x, fc1, fc2, sn1, sn2, keep_ws=None, three_launches=False):
     d.fc2_planes, d.fc2_alpha, d.fc2_beta, d.fc2_acc_scale = _ptr(fc2.Wp, torch.int16), _ptr(fc2.alpha), _ptr(fc2.beta), _acc_scale(fc2.Wp)
     _ncfg(d.sn1, sn1)
     _ncfg(d.sn2, sn2)
-    nbytes = lib().sdf_ms_mlp_workspace_bytes(C.c_int64(B * D * H * W), C.c_int(Cc), C.c_int(fc1.N))
-    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
-    d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+    if ws is None:
+        if s1_ready:
+            raise SdfError("s1_ready needs the caller's workspace (ms_mlp_workspace) with SN1's spikes at its head")
+        ws = ms_mlp_workspace(x, fc1.N)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     gws = workspace(x.device)
     d.gemm_workspace, d.gemm_workspace_bytes = gws.data_ptr(), gws.numel()
-    d.flags = (MLP_KEEP_SPIKES if keep_ws is not None else 0) | (MLP_THREE_LAUNCHES if three_launches else 0)
+    d.flags = (MLP_KEEP_SPIKES if keep_ws is not None else 0) | (MLP_THREE_LAUNCHES if three_launches else 0) | (MLP_NARROW if narrow else 0)
+    if s1_ready:
+        d.s1_in = ws.data_ptr()
+        if lib().sdf_ms_mlp_is_wide(C.byref(d)) != 1:
+            raise SdfError("s1_ready: this MLP does not run on the wide-stage kernels (the spikes at the head of `ws` would be ignored)")
     _check(lib().sdf_ms_mlp_fwd(C.byref(d), _stream()), "sdf_ms_mlp_fwd")
     if keep_ws is not None:
         keep_ws.append(ws)

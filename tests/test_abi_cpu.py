@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), name
     lib.sdf_version.restype = ctypes.c_int
-    assert lib.sdf_version() == 102            # host-only call, no GPU needed
+    assert lib.sdf_version() == 103            # host-only call, no GPU needed
 
 
 def test_product_refuses_cpu_tensors():
@@ -93,7 +93,29 @@ def test_argument_errors_are_reported_before_any_launch():
     q.C, q.workspace_bytes = 96, 16
     assert lib.sdf_qk_attn_fwd(C.byref(q), None) == E_SHAPE     # workspace smaller than sdf_qk_attn_workspace_bytes
     lib.sdf_qk_attn_workspace_bytes.restype = C.c_int64
-    assert lib.sdf_qk_attn_workspace_bytes(C.c_int64(4), C.c_int(2), C.c_int(81), C.c_int(96)) == 62208 + 2 * 62208
+    # E (padded to 256 bytes), q | k (padded), and the slice spikes of the wide-stage form (round 4)
+    assert lib.sdf_qk_attn_workspace_bytes(C.c_int64(4), C.c_int(2), C.c_int(81), C.c_int(96)) == 62208 + 2 * 62208 + 62208
+    # wide-stage additions (round 4): the inverse slice map, and the host-only "will this run wide" queries
+    assert lib.sdf_window_zsrc_map(None, C.c_int64(4), 2, 81, 12, p, None) == E_NULL
+    assert lib.sdf_window_zsrc_map(p, C.c_int64(0), 2, 81, 12, p, None) == E_SHAPE
+    assert lib.sdf_qk_attn_is_wide(None) == 0 and lib.sdf_ms_mlp_is_wide(None) == 0
+    assert lib.sdf_qk_attn_is_wide(C.byref(q)) == 0              # C = 96: the general kernels
+    q.emit_s1 = 0x10000
+    q.workspace_bytes = 1 << 30
+    assert lib.sdf_qk_attn_fwd(C.byref(q), None) == E_SHAPE     # only the wide-stage projection emits the next neuron's spikes
+    q.emit_s1 = None
+    m = hip.MsMlpDesc()
+    m.x, m.fc1_planes, m.fc2_planes, m.workspace, m.fc1_alpha, m.fc1_beta, m.fc2_alpha, m.fc2_beta = (0x10000,) * 8
+    m.B, m.D, m.HW, m.C, m.Ch, m.nsplit, m.workspace_bytes = 1, 10, 432, 384, 1536, 2, 1 << 30
+    m.sn1.kind = m.sn2.kind = hip.SDF_LIF
+    m.sn1.tau = m.sn2.tau = 2.0
+    assert lib.sdf_ms_mlp_is_wide(C.byref(m)) == 1
+    m.flags = hip.MLP_NARROW
+    assert lib.sdf_ms_mlp_is_wide(C.byref(m)) == 0
+    m.flags, m.nsplit = 0, 3
+    assert lib.sdf_ms_mlp_is_wide(C.byref(m)) == 0              # the exact three-plane mode keeps the general kernels
+    m.nsplit, m.C, m.Ch, m.s1_in = 2, 96, 384, 0x10000
+    assert lib.sdf_ms_mlp_fwd(C.byref(m), None) == E_SHAPE      # s1_in is a wide-stage input
     assert lib.sdf_window_slice_map(None, 1, 2, 9, 9, 2, 9, 9, 0, 0, 0, None, None) == E_NULL
     assert lib.sdf_window_slice_map(p, 1, 2, 9, 9, 0, 9, 9, 0, 0, 0, None, None) == E_SHAPE
     # dense kernels of the ANN path (round 2)
