@@ -299,19 +299,28 @@ typedef struct SdfQkAttnDesc {
   void* workspace;      int64_t workspace_bytes;
   void* gemm_workspace; int64_t gemm_workspace_bytes;
   int32_t flags;        /* SDF_QK_* bits */
-  /* Wide stages (C >= 256, T' = 2, LIF / IF neurons, two fp16 planes; csrc/ms_wide.hip): with x_src set the call is THREE launches -
+  /* Wide stages (C >= 256, T' = 2, LIF / IF neurons, digit planes given - see below; csrc/ms_wide.hip): with x_src set the call is THREE launches -
    * slice neuron, one kernel for q | k + BN + neurons + token gate, and the projection as a "position-major" product whose waves own
    * all xD time steps of a few positions of the (xB, xD, xHW, C) buffer x (xB * xD * xHW == x_rows):
    *   x_src   : int32 per row of x, made by sdf_window_zsrc_map from slice_map (where that row's gated spikes start in E); NULL = the
    *             general kernels above
    *   emit_s1 : optional u8 [x_rows][C]: receives SN_emit( x after the update ) over the xD steps of every position - the first
    *             neuron of the MLP that follows (reference Spiking_swin_transformer3D.py:168; hand it to SdfMsMlpDesc.s1_in), so the
-   *             updated x is not read again; emit_sn = that neuron (LIF / IF). */
+   *             updated x is not read again; emit_sn = that neuron (LIF / IF).  Layout: the wide kernels' TILED hand-over form
+   *             ([80-row unit][C / 16][row][16 B], (x_rows + 80) * C bytes) - opaque to the caller - unless SDF_QK_KEEP_SPIKES is
+   *             set: then plain row-major [x_rows][C] (the parity tape). */
   const int32_t* x_src;
   int32_t xB, xD;
   int64_t xHW;
   uint8_t* emit_s1;
   SdfNeuronCfg emit_sn;
+  /* The wide-stage kernels multiply on the int8 matrix pipe (spike bytes are int8 values): the same weights again as digit planes
+   * int8_t[3][rows][C] + one power-of-two scale per output channel, made by sdf_split_weight_i8x3 (stacked [Wq; Wk] as 2C rows for
+   * the qk_* form, else q_* and k_*; p_* = the output projection).  All NULL = the general kernels on the 16-bit planes above. */
+  const int8_t* qk_digits; const float* qk_cscale;
+  const int8_t* q_digits;  const float* q_cscale;
+  const int8_t* k_digits;  const float* k_cscale;
+  const int8_t* p_digits;  const float* p_cscale;
 } SdfQkAttnDesc;
 
 enum {
@@ -348,10 +357,15 @@ typedef struct SdfMsMlpDesc {
   void* workspace;      int64_t workspace_bytes;
   void* gemm_workspace; int64_t gemm_workspace_bytes;
   int32_t flags;        /* SDF_MLP_* bits */
-  /* Wide stages (C >= 256, LIF / IF, two fp16 planes, D in {10, 20}; csrc/ms_wide.hip): fc1 + BN1 + SN2 and fc2 + BN2 + shortcut as two
+  /* Wide stages (C >= 256, LIF / IF, digit planes given - see below, D in {10, 20}; csrc/ms_wide.hip): fc1 + BN1 + SN2 and fc2 + BN2 + shortcut as two
    * position-major launches.  s1_in != NULL: the SN1 spikes are already at the head of `workspace` (written there by
-   * SdfQkAttnDesc.emit_s1 == workspace): no neuron launch, x is only read by the last launch's shortcut. */
+   * SdfQkAttnDesc.emit_s1 == workspace; tiled, or row-major when both calls carry their KEEP_SPIKES flag): no neuron launch, x is
+   * only read by the last launch's shortcut.  Without SDF_MLP_KEEP_SPIKES the hidden spikes travel in the tiled form too. */
   const uint8_t* s1_in;
+  /* the weights again as int8 digit planes int8_t[3][N][K] + a power-of-two scale per output channel (sdf_split_weight_i8x3): what
+   * the wide-stage kernels multiply by; NULL = the general kernels on the 16-bit planes above. */
+  const int8_t* fc1_digits; const float* fc1_cscale;
+  const int8_t* fc2_digits; const float* fc2_cscale;
 } SdfMsMlpDesc;
 
 enum {

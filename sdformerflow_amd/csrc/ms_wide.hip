@@ -13,14 +13,19 @@
 //                         fc1  : s2 = SN2( BN1( s1 W1^T ) )                                             (:170-174)
 //                         fc2  : x += BN2( s2 W2^T )                                                   (:175-178, :845)
 //
-// Main loop (both kernels): v_mfma_f32_16x16x32 (f16 / bf16 planes), spikes are the ROW operand.  The wave's A operand never
-// touches LDS: a lane loads 16 bytes (the k-pieces 2j, 2j + 1 of a 64-deep K pair, j = lane / 16) of its row straight into
-// registers one pair ahead (raw buffer loads, invalid rows read zeros), and expands 8 bytes to 8 halves per MFMA step.  The
-// workgroup's NW waves share BN = 16 CB weight columns: 64-deep K chunks of both planes go global -> registers -> LDS one chunk
-// ahead into a two-buffer ring, ONE barrier per chunk.  LDS weight layout [plane][k-piece][column ^ (k-piece & 7)] x 16 B: the
-// eight 16-byte pieces of a 128-byte weight row are written by eight neighbouring lanes to eight different bank quads, and every
-// fragment read (lane = column + 16 k-group) is conflict-free (tools/probes: /tmp bank model in DESIGN.md section 5).
-// Workgroups that share a column group are neighbours on one XCD (its L2 serves the weight re-reads).
+// Main loop (both kernels): v_mfma_i32_16x16x64_i8.  Spike bytes {0, 1} ARE int8 values and the weights arrive as three int8 digit
+// planes + a power-of-two scale per output channel (sdf_split_weight_i8x3: w = (d2 65536 + d1 256 + d0) s_n, 22 bits + sign
+// against the channel's largest weight), so a spike x weight dot product is three exact int32 sums - no expansion of the spikes to
+// 16-bit floats (that cost one vector instruction per byte and MFMA: 2 per MFMA at two column blocks), three MFMAs per 64 k
+// where the fp16 hi / lo planes need four, order-independent and bit-reproducible; the sums meet in fp32 as
+// fma(acc2, 65536, acc1 256 + acc0) s_n.  Spikes are the ROW operand and never touch LDS: a lane loads the 16 bytes (k-piece
+// j = lane / 16 of a 64-deep step) of its row straight into the registers the MFMA reads, one 128-deep chunk ahead (raw buffer
+// loads, invalid rows read zeros).  The workgroup's 4 waves share BN = 16 CB weight columns: 128-deep chunks of the three planes go
+// global -> registers -> LDS one chunk ahead into a two-buffer ring, ONE barrier per chunk.  LDS weight layout
+// [plane][k-piece][column ^ (k-piece & 7)] x 16 B: the eight 16-byte pieces of a 128-byte weight row are written by eight
+// neighbouring lanes to eight different bank quads, and every fragment read (lane = column + 16 k-group) is conflict-free.
+// Workgroups are ordered row group major: an XCD owns a contiguous range of rows, whose spikes it fetches once (its L2 serves
+// the column groups' re-reads) beside one copy of the weights.
 //
 // Epilogues: BN (+ bias, + positional term) on the accumulators; LIF / IF over T per lane (neuron_T of spike_mm.h - the separately
 // rounded op sequence of neuron.hip; compiled with -ffp-contract=off); spike bits -> bytes by one 24-bit multiply per 4 rows, a
@@ -29,6 +34,33 @@
 // layout (64-byte runs per row and column block; the buffers are L2-resident at these sizes).
 #include "spike_mm.h"
 #include <stdlib.h>
+
+#ifdef SDF_STAMP
+// diagnostic build only (tools/stamp_wide.sh): cycle accounting of wave 0 of the middle workgroup, per kernel kind
+// (0 = front, 1 = fc1, 2 = fc2, 3 = projection), and every workgroup's life in 100 MHz real time
+__device__ unsigned long long g_wide_stamp[4 * 8];
+__device__ unsigned long long g_wide_census[4 * 2 * 1024];
+#define WSTAMP(var) var = __builtin_readcyclecounter()
+#define WSTAMP_DECL unsigned long long ws0 = 0, ws1 = 0, ws2 = 0, ws3 = 0, ws4 = 0; const unsigned long long wr0 = __builtin_amdgcn_s_memrealtime()
+#define WSTAMP_OUT(kind)                                                                                          \
+  do {                                                                                                            \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
+    WSTAMP(ws4);                                                                                                  \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                                  \
+      g_wide_census[(kind) * 2048 + 2 * blockIdx.x] = wr0;                                                        \
+      g_wide_census[(kind) * 2048 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();                       \
+    }                                                                                                             \
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) {                                                        \
+      unsigned long long* o = g_wide_stamp + 8 * (kind);                                                          \
+      o[0] = ws1 - ws0; o[1] = ws2 - ws1; o[2] = ws3 - ws2; o[3] = ws4 - ws3; o[4] = ws4 - ws0;                   \
+      o[5] = __builtin_amdgcn_s_memrealtime() - wr0; o[6] = gridDim.x;                                            \
+    }                                                                                                             \
+  } while (0)
+#else
+#define WSTAMP(var)
+#define WSTAMP_DECL
+#define WSTAMP_OUT(kind)
+#endif
 
 namespace sdfmm {
 namespace {
@@ -39,27 +71,6 @@ constexpr uint32_t INV = 0x80000000u;               // buffer offset of "no such
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)INV, 0x00020000);
-}
-
-// 8 spike bytes {0, 1} -> 8 x 16-bit {0, 1.0} (fp16 for two planes, bf16 otherwise); the 24-bit multiply is a full-rate op
-template <int NSPLIT>
-__device__ __forceinline__ bf16x8 expand01(uint32_t lo, uint32_t hi) {
-  constexpr uint32_t ONE = NSPLIT == 2 ? 0x3C00u : 0x3F80u;
-  union { bf16x8 h; uint32_t u[4]; } r;
-  r.u[0] = __umul24(__builtin_amdgcn_perm(0u, lo, 0x0c010c00u), ONE);
-  r.u[1] = __umul24(__builtin_amdgcn_perm(0u, lo, 0x0c030c02u), ONE);
-  r.u[2] = __umul24(__builtin_amdgcn_perm(0u, hi, 0x0c010c00u), ONE);
-  r.u[3] = __umul24(__builtin_amdgcn_perm(0u, hi, 0x0c030c02u), ONE);
-  return r.h;
-}
-
-template <int NSPLIT>
-__device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
-  if constexpr (NSPLIT == 2)
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a),
-                                                   __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, b), c, 0, 0, 0);
 }
 
 // 4 bits -> 4 bytes {0, 1}: bit i lands in byte i (i + 7 i = 8 i; the cross terms i + 7 k, k != i, miss every byte's bit 0)
@@ -87,195 +98,180 @@ __device__ __forceinline__ uint32_t row_sum16(uint32_t v) {
   return v;
 }
 
-constexpr int KCH = 64;                              // K chunk = one "pair" of MFMA steps
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+constexpr int KCH = 128;                             // K chunk = two 64-deep MFMA steps
 constexpr int RBW = 5;                               // row blocks of a wave in the position-major kernel: 80 rows = 20 slots per lane
 
 __host__ __device__ constexpr int s_pitch(int bytes) { return ((bytes + 16) / 4) % 8 == 4 ? bytes + 16 : bytes + 32; }
+__host__ __device__ constexpr int w_pieces(int CB) { return 3 * 16 * CB * 8; }                   // 16-byte pieces of a weight chunk
+__host__ __device__ constexpr int w_steps(int CB) { return (w_pieces(CB) + 255) / 256; }         // per thread (256 threads)
+__host__ __device__ constexpr int w_buf(int CB) { return w_pieces(CB) * 16 + 16; }               // ring buffer bytes (+ a dump slot)
+
+// the three exact integer sums of an output -> one fp32 number (the two low digits meet as integers: < 2^27 at K = 3072)
+__device__ __forceinline__ float digits_f32(int a0, int a1, int a2) { return __builtin_fmaf((float)a2, 65536.f, (float)(a1 * 256 + a0)); }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// The shared main loop.  acc[RB][CB] += A[rows of this wave][K] x W[BN columns][K]^T over K = 64 npairs, npairs EVEN.
-//   a_base[rb] : byte offset of this lane's first 16-byte piece of row block rb's row (lane % 16) in the A buffer, or INV
-//   a_step     : bytes between two K pairs of a row (64 for plain rows; 2 G through the head scramble)
+// The shared main loop.  acc[digit][rb][cb] += A[rows of this wave][K] x D_digit[BN columns][K]^T over K = 128 nchunks.
+//   a_base[rb] : byte offset of this lane's 16-byte piece (row lane % 16 of row block rb, k-piece lane / 16 of 64-deep step 0), or INV
+//   a_step     : bytes between two 64-deep steps of that piece (64 in a row-major tensor; 4 pieces x 80 rows x 16 B in a tiled one;
+//                2 G through the head scramble)
 //   w_goff[i]  : byte offset of this thread's i-th weight piece of chunk 0 in its buffer (or INV); chunk c adds 128 c
-//   w_lds[i]   : where that piece goes inside a ring buffer
-// One barrier per chunk; chunk c + 1 is committed to the other LDS buffer at the top of chunk c's MFMAs and chunk c + 2 requested.
-// The loop body is straight-line (requests beyond the last chunk read zeros through INV offsets, no branches): the compiler's
-// vmcnt bookkeeping stays exact, so a wait for the pair about to be multiplied leaves the next pair's loads in flight.
-template <int WIT>
-struct WPieces {
-  uint32_t goff[WIT], lds[WIT];
-  int which[WIT];                                     // buffer resource of piece i (0 / 1), compile-time after unrolling
-};
-
-template <int NSPLIT, int RB, int CB, int WIT>
-__device__ __forceinline__ void wide_mainloop(f32x4 (&acc)[RB][CB], const __amdgpu_buffer_rsrc_t A_rs, const uint32_t (&a_base)[RB],
-                                              uint32_t a_step, int npairs, bool active, uint8_t* Wlds, const __amdgpu_buffer_rsrc_t W0_rs,
+//   w_lds[i]   : where that piece goes inside a ring buffer (the dump slot for a thread without an i-th piece)
+// The spike operand goes global -> registers in the MFMA's own layout, one chunk ahead (measured, profiles/r4c_*: staging it through
+// LDS costs more in ds_write issue - 13 cycles per 16-byte store and wave - than the lane-per-row loads lose in the L1; with the
+// producer writing the TILED layout [unit][k-piece][row][16 B] the 16 lanes of a k-group read 256 contiguous bytes).
+// Weights: one barrier per chunk; chunk c + 1 is committed to the other ring buffer at the top of chunk c's MFMAs and chunk c + 2
+// requested.  The loop body is straight-line (requests beyond the last chunk read zeros through INV offsets, no branches): the
+// compiler's vmcnt bookkeeping stays exact, so the wait for what is committed next leaves the following chunk's loads in flight.
+template <int RB, int CB, int WIT, class Extra>
+__device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __amdgpu_buffer_rsrc_t A_rs, const uint32_t (&a_base)[RB],
+                                              uint32_t a_step, int nchunks, uint8_t* Wlds, const __amdgpu_buffer_rsrc_t W0_rs,
                                               const __amdgpu_buffer_rsrc_t W1_rs, const uint32_t (&w_goff)[WIT], const uint32_t (&w_lds)[WIT],
-                                              int lane) {
-  constexpr int BN = 16 * CB, WBUF = NSPLIT * BN * 8 * 16;
+                                              int lane, Extra extra_requests) {
+  constexpr int BN = 16 * CB, WBUF = w_buf(CB);
   u32x4 wreg[WIT];
+  i32x4 aCur[2][RB], aNxt[2][RB];
   auto wreq = [&](int ch) __attribute__((always_inline)) {
-    const bool in = ch < npairs;
+    const bool in = ch < nchunks;
 #pragma unroll
     for (int i = 0; i < WIT; ++i)
-      wreg[i] = __builtin_amdgcn_raw_buffer_load_b128((i & 1) ? W1_rs : W0_rs, in ? w_goff[i] : INV, (uint32_t)ch * (KCH * 2), 0);
+      wreg[i] = __builtin_amdgcn_raw_buffer_load_b128((i & 1) ? W1_rs : W0_rs, in ? w_goff[i] : INV, (uint32_t)ch * KCH, 0);
   };
   auto w_commit = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < WIT; ++i) *reinterpret_cast<u32x4*>(Wlds + buf * WBUF + w_lds[i]) = wreg[i];
   };
+  auto areq = [&](i32x4 (&a)[2][RB], int ch) __attribute__((always_inline)) {
+    const bool in = ch < nchunks;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+        a[h][rb] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(A_rs, in ? a_base[rb] : INV, (uint32_t)(2 * ch + h) * a_step, 0));
+  };
   const int l16 = lane & 15, lj = lane >> 4;
-  // this lane's fragment of (column block cb, plane p, step h): piece kp = 2 lj + h of the chunk
-  auto compute_pair = [&](const u32x4 (&a)[RB], int buf) __attribute__((always_inline)) {
+  // One chunk of this wave: 2 steps x CB column blocks x 3 digit planes = units of RB MFMAs on one weight fragment.  The fragments
+  // of units g + 1 and g + 2 are in flight while unit g multiplies (an LDS read takes longer than five MFMAs); the fences keep the
+  // scheduler from pulling every read back in front of its use.
+  auto compute = [&](const i32x4 (&a)[2][RB], int buf) __attribute__((always_inline)) {
     const uint8_t* wb = Wlds + buf * WBUF;
+    constexpr int UPS = CB * 3, NU = 2 * UPS;
+    i32x4 b[3];
+    auto load_b = [&](int g) __attribute__((always_inline)) {
+      const int h = g / UPS, r = g - h * UPS, cb = r / 3, dg = r - 3 * cb, kp = 4 * h + lj;
+      b[g % 3] = *reinterpret_cast<const i32x4*>(wb + ((dg * 8 + kp) * BN + ((cb * 16 + l16) ^ kp)) * 16);
+    };
+    load_b(0);
+    load_b(1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      bf16x8 ax[RB];
+    for (int g = 0; g < NU; ++g) {
+      if (g + 2 < NU) load_b(g + 2);
+      const int h = g / UPS, r = g - h * UPS, cb = r / 3, dg = r - 3 * cb;
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) ax[rb] = h == 0 ? expand01<NSPLIT>(a[rb][0], a[rb][1]) : expand01<NSPLIT>(a[rb][2], a[rb][3]);
-      const int kp = 2 * lj + h;
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) {
-#pragma unroll
-        for (int p = 0; p < NSPLIT; ++p) {
-          const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + ((p * 8 + kp) * BN + ((cb * 16 + l16) ^ kp)) * 16);
-#pragma unroll
-          for (int rb = 0; rb < RB; ++rb) acc[rb][cb] = mma16<NSPLIT>(ax[rb], b, acc[rb][cb]);
-        }
-      }
+      for (int rb = 0; rb < RB; ++rb) acc[dg][rb][cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[h][rb], b[g % 3], acc[dg][rb][cb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
-  auto a_load = [&](u32x4 (&a)[RB], int s) __attribute__((always_inline)) {
-    const bool in = s < npairs;
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) a[rb] = __builtin_amdgcn_raw_buffer_load_b128(A_rs, in ? a_base[rb] : INV, (uint32_t)s * a_step, 0);
-  };
-  u32x4 aA[RB], aB[RB];
   wreq(0);
-  a_load(aA, 0);
+  areq(aCur, 0);
   w_commit(0);
   wreq(1);
+  areq(aNxt, 1);
+  extra_requests();                                                   // (the caller's own loads: behind the first two chunks in the queue)
   __syncthreads();
 #pragma unroll 1
-  for (int s = 0; s < npairs; s += 2) {
-    w_commit(1);
-    wreq(s + 2);
-    a_load(aB, s + 1);
-    if (active) compute_pair(aA, 0);
-    __syncthreads();
-    w_commit(0);
-    wreq(s + 3);
-    a_load(aA, s + 2);
-    if (active) compute_pair(aB, 1);
+  for (int c = 0; c < nchunks; ++c) {
+    const int cur = c & 1;
+    w_commit(cur ^ 1);                                                // chunk c + 1 (zeros behind the last one) into the other buffer
+    wreq(c + 2);
+    compute(aCur, cur);                                               // (a wave without rows multiplies zeros: no branch around the
+#pragma unroll                                                        //  accumulators, which would cost a register copy of each per chunk)
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) aCur[h][rb] = aNxt[h][rb];
+    areq(aNxt, c + 2);
     __syncthreads();
   }
 }
 
-// this thread's weight pieces of a 64-deep chunk: piece = (plane p, column col of the group, k-piece kp); 256 threads take 32 columns
-// x 8 k-pieces per step.  row_of(p, col) -> element offset of (plane p, column col, k = 0) in the weight buffer
-template <int NSPLIT, int CB, class RowOf>
-__device__ __forceinline__ void wide_pieces(uint32_t (&goff)[NSPLIT * CB / 2], uint32_t (&lds)[NSPLIT * CB / 2], int tid, RowOf row_of) {
-  constexpr int BN = 16 * CB, WIT = NSPLIT * CB / 2;
+// this thread's weight pieces of a 128-deep chunk: piece = (digit plane p, column col of the group, k-piece kp); 256 threads take
+// 32 columns x 8 k-pieces per step.  row_of(p, col, i) -> byte offset of (plane p, column col, k = 0) in the weight buffer, or INV
+template <int CB, class RowOf>
+__device__ __forceinline__ void wide_pieces(uint32_t (&goff)[w_steps(CB)], uint32_t (&lds)[w_steps(CB)], int tid, RowOf row_of) {
+  constexpr int BN = 16 * CB, WIT = w_steps(CB);
   const int kp = tid & 7, r = tid >> 3;
 #pragma unroll
   for (int i = 0; i < WIT; ++i) {
-    constexpr int dummy = 0;
-    (void)dummy;
     const int p0 = (32 * i) / BN, rem0 = (32 * i) % BN;
-    const bool wrap = rem0 + r >= BN;
-    const int p = p0 + (wrap ? 1 : 0), col = rem0 + r - (wrap ? BN : 0);
-    goff[i] = row_of(p, col, i) + 16u * kp;
-    lds[i] = (uint32_t)(((p * 8 + kp) * BN + (col ^ kp)) * 16);
+    int p = p0, col = rem0 + r;
+    if (col >= BN) { col -= BN; ++p; }
+    if (col >= BN) { col -= BN; ++p; }                               // (BN = 16: a 32-column step spans two planes)
+    const bool ok = p < 3;
+    const uint32_t g = ok ? row_of(p, col, i) : INV;
+    goff[i] = g == INV ? INV : g + 16u * kp;
+    lds[i] = ok ? (uint32_t)(((p * 8 + kp) * BN + (col ^ kp)) * 16) : (uint32_t)(w_buf(CB) - 16);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Position-major GEMM.
+//
+// TILED spike tensors (the hand-over format between two position-major launches): [unit][channel piece K / 16][row 0..79][16 B],
+// unit = the 80 tile rows (20 / T x 4 positions x T steps) one wave owns, row = its MFMA tile row.  The producer's epilogue writes
+// 1 280 contiguous bytes per channel piece; the consumer's 16 lanes of a k-group read 256 contiguous bytes.  The parity tape and
+// a caller that made the spikes with the neuron kernel use the row-major form [rows][K] instead (bit-equal results: the integer
+// sums do not depend on the order).
 struct WidePmParams {
-  const uint8_t* A;          // plain: u8 [rows][K];  head scramble: the gated spikes E, flat
+  const uint8_t* A;          // row-major u8 [rows][K], or tiled, or (zsrc) the gated spikes E, flat
+  int a_tiled;
   const int32_t* zsrc;       // head scramble: per activation row the byte offset of (k-group 0, byte 0) in E; null = plain rows
   uint32_t zg_G;             // head scramble: bytes between two k-groups (T' * N1 * 32)
-  const uint16_t* W;         // [NSPLIT][N][K]
+  const int8_t* W;           // digit planes [3][N][K]
+  const float* cscale;       // (N) power-of-two scale of every output channel
   int N, K, HW;
   int64_t P;                 // positions = B * HW; rows = P * T in (B, T, HW) order
-  float asc;
   const float *bias, *alpha, *beta;
   float* x;                  // fp32 epilogue: out = resid, row stride ldo
   int ldo;
-  uint8_t* out_spike;        // neuron epilogue: u8 [rows][ldsp]
-  int ldsp;
+  uint8_t* out_spike;        // neuron epilogue: u8 [rows][ldsp] or tiled (K = ldsp)
+  int ldsp, out_tiled;
   SdfNeuronCfg sn;
   float inv_tau;
-  int ncg, nrg, nunits;
+  int ncg, nrg, nunits, passes;   // a workgroup walks `passes` row groups (grid = ncg x ceil(nrg / passes))
 };
 
 // EPI: 1 = neuron (spikes out), 2 = fp32 (+ shortcut), 3 = fp32 and the neuron on the updated shortcut stream
-template <int NSPLIT, int T, int CB, int NW, int EPI, int NK>
-__global__ __launch_bounds__(64 * NW, (CB >= 6 ? 1 : 2)) void wide_pm_kernel(WidePmParams P) {
-  constexpr int RB = RBW, ROWS = 16 * RB, SLOTS = 4 * RB, PPG = SLOTS / T, PPW = 4 * PPG;
-  constexpr int BN = 16 * CB, NT = 64 * NW, PIECES = NSPLIT * BN * 8, WBUF = PIECES * 16;
+template <int T, int CB, int EPI, int NK>
+__global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
+  constexpr int NW = 4, RB = RBW, ROWS = 16 * RB, SLOTS = 4 * RB, PPG = SLOTS / T, PPW = 4 * PPG;
+  constexpr int BN = 16 * CB, WBUF = w_buf(CB), WIT = w_steps(CB);
   constexpr int SP = s_pitch(BN), STILE = ROWS * SP;
   constexpr int LDSB = 2 * WBUF > NW * STILE ? 2 * WBUF : NW * STILE;
   static_assert(SLOTS % T == 0, "T must divide the 20 accumulator slots of a lane");
-  static_assert(!(EPI & 2) || CB <= 3, "the fp32 epilogue keeps every shortcut load in flight: three column blocks at most");
+  static_assert(!(EPI & 2) || CB <= 2, "the fp32 epilogue keeps every shortcut load in flight beside the accumulators: two column blocks");
   __shared__ __attribute__((aligned(16))) uint8_t smem[LDSB];
   __shared__ int32_t rowtab[NW * ROWS];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, lq = lane >> 4;
-  // (column group, row group): workgroups of one column group are neighbours on one XCD
+  WSTAMP_DECL;
+  WSTAMP(ws0);
+  // (row-group range, column group), column group fastest: the workgroups of an XCD (ids equal mod 8) cover a contiguous range of rows
   int item = blockIdx.x;
   const int G = gridDim.x;
   if ((G & 7) == 0) item = (item & 7) * (G >> 3) + (item >> 3);
-  if (item >= P.ncg * P.nrg) return;
-  const int cg = item / P.nrg, rg = item - cg * P.nrg;
+  const int nrgp = (P.nrg + P.passes - 1) / P.passes;
+  if (item >= P.ncg * nrgp) return;
+  const int rgp = item / P.ncg, cg = item - rgp * P.ncg;
   const int n0 = cg * BN;
-  const int unit = rg * NW + wave;
-  const bool active = unit < P.nunits;
   const int K = P.K, N = P.N, HW = P.HW;
-
-  // activation row (or -1) of every tile row of this wave
-  for (int r = lane; r < ROWS; r += 64) {
-    const int rb = r >> 4, i = r & 15, q = i >> 2, slot = 4 * rb + (i & 3);
-    const int pp = slot / T, t = slot - pp * T;
-    const int64_t pos = (int64_t)unit * PPW + q * PPG + pp;
-    int32_t g = -1;
-    if (active && pos < P.P) {
-      const int64_t b = pos / HW, hw = pos - b * HW;
-      g = (int32_t)((b * T + t) * HW + hw);
-    }
-    rowtab[wave * ROWS + r] = g;
-  }
-  asm volatile("" ::: "memory");                          // (same-wave LDS operations execute in order: no wait between the table's writes and reads)
-  const __amdgpu_buffer_rsrc_t A_rs = make_rsrc(P.A), W_rs = make_rsrc(P.W);
-  uint32_t a_base[RB];
-  uint32_t a_step = KCH;
-#pragma unroll
-  for (int rb = 0; rb < RB; ++rb) {
-    const int32_t g = rowtab[wave * ROWS + 16 * rb + l16];
-    a_base[rb] = INV;
-    if (g >= 0) a_base[rb] = P.zsrc ? (uint32_t)P.zsrc[g] + (uint32_t)(lq >> 1) * P.zg_G + 16u * (lq & 1) : (uint32_t)g * (uint32_t)K + 16u * lq;
-  }
-  if (P.zsrc) a_step = 2 * P.zg_G;
-
-  f32x4 acc[RB][CB];
-#pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int WIT = PIECES / NT;
-  static_assert(PIECES % NT == 0 && NT == 256, "weight pieces: 256 threads x whole steps");
+  const __amdgpu_buffer_rsrc_t A_rs = make_rsrc(P.A), W_rs = make_rsrc(P.W), x_rs = make_rsrc(P.x), o_rs = make_rsrc(P.out_spike);
   uint32_t w_goff[WIT], w_lds[WIT];
-  wide_pieces<NSPLIT, CB>(w_goff, w_lds, tid, [&](int p, int col, int) -> uint32_t {
-    return n0 + col < N ? (uint32_t)((p * N + n0 + col) * K) * 2u : INV;
+  wide_pieces<CB>(w_goff, w_lds, tid, [&](int p, int col, int) -> uint32_t {
+    return n0 + col < N ? (uint32_t)((p * N + n0 + col) * K) : INV;
   });
-  wide_mainloop<NSPLIT, RB, CB, WIT>(acc, A_rs, a_base, a_step, K / KCH, active, smem, W_rs, W_rs, w_goff, w_lds, lane);
-  if (!active) return;                                    // (every barrier is behind this wave)
-
-  // ---------------- epilogue ----------------
-  int lnl = lane;
-  asm volatile("" : "+v"(lnl));                           // row offsets are computed here, not hoisted above the main loop
-  const int c = lnl & 15, q = lnl >> 4;
-  float al[CB], be[CB], bs[CB];
+  const int c = lane & 15, q = lane >> 4;
+  float al[CB], be[CB], bs[CB], cs[CB];
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
     const int n = n0 + 16 * cb + c;
@@ -283,72 +279,139 @@ __global__ __launch_bounds__(64 * NW, (CB >= 6 ? 1 : 2)) void wide_pm_kernel(Wid
     al[cb] = P.alpha ? P.alpha[nc] : 1.f;
     be[cb] = P.alpha ? P.beta[nc] : 0.f;
     bs[cb] = P.bias ? P.bias[nc] : 0.f;
+    cs[cb] = P.cscale[nc];
   }
-  if constexpr ((EPI & 2) != 0) {
-    const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(P.x);
-    uint32_t xo[SLOTS];
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-      const int32_t g = rowtab[wave * ROWS + 16 * (s >> 2) + 4 * q + (s & 3)];
-      xo[s] = (g >= 0 && n0 + c < N) ? ((uint32_t)g * (uint32_t)P.ldo + (uint32_t)(n0 + c)) * 4u : INV;
+
+#pragma unroll 1
+  for (int pass = 0; pass < P.passes; ++pass) {
+    const int rg = rgp * P.passes + pass;
+    if (rg >= P.nrg) break;                                // (uniform over the workgroup)
+    const int unit = rg * NW + wave;
+    const bool active = unit < P.nunits;
+    // activation row (or -1) of every tile row of this wave
+    for (int r = lane; r < ROWS; r += 64) {
+      const int rb = r >> 4, i = r & 15, qq = i >> 2, slot = 4 * rb + (i & 3);
+      const int pp = slot / T, t = slot - pp * T;
+      const int64_t pos = (int64_t)unit * PPW + qq * PPG + pp;
+      int32_t g = -1;
+      if (active && pos < P.P) {
+        const int64_t b = pos / HW, hw = pos - b * HW;
+        g = (int32_t)((b * T + t) * HW + hw);
+      }
+      rowtab[wave * ROWS + r] = g;
     }
-    float res[CB][SLOTS];
+    asm volatile("" ::: "memory");                         // (same-wave LDS operations execute in order: no wait between the table's writes and reads)
+    uint32_t a_base[RB];
+    uint32_t a_step = 64;
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-      for (int s = 0; s < SLOTS; ++s)
-        res[cb][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rs, (n0 + 16 * cb + c < N) ? xo[s] : INV, 64u * cb, 0));
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
+    for (int rb = 0; rb < RB; ++rb) {
+      const int32_t g = rowtab[wave * ROWS + 16 * rb + l16];
+      a_base[rb] = INV;
+      if (P.a_tiled) {
+        if (active) a_base[rb] = (((uint32_t)unit * (uint32_t)(K >> 4) + (uint32_t)lq) * ROWS + 16 * rb + l16) * 16u;
+      } else if (g >= 0) {
+        a_base[rb] = P.zsrc ? (uint32_t)P.zsrc[g] + (uint32_t)(lq >> 1) * P.zg_G + 16u * (lq & 1) : (uint32_t)g * (uint32_t)K + 16u * lq;
+      }
+    }
+    if (P.a_tiled) a_step = 4 * ROWS * 16;
+    else if (P.zsrc) a_step = 2 * P.zg_G;
+
+    // the shortcut values of this lane's outputs are requested behind the first operand chunks and arrive under the main loop
+    uint32_t xo[(EPI & 2) ? SLOTS : 1];
+    float res[(EPI & 2) ? CB : 1][(EPI & 2) ? SLOTS : 1];
+    if constexpr ((EPI & 2) != 0) {
 #pragma unroll
       for (int s = 0; s < SLOTS; ++s) {
-        float v = acc[s >> 2][cb][s & 3] * P.asc;
-        v = v + bs[cb];
-        v = __builtin_fmaf(v, al[cb], be[cb]);
-        v = v + res[cb][s];
-        acc[s >> 2][cb][s & 3] = v;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), x_rs, (n0 + 16 * cb + c < N) ? xo[s] : INV, 64u * cb, 0);
+        const int32_t g = rowtab[wave * ROWS + 16 * (s >> 2) + 4 * q + (s & 3)];
+        xo[s] = (g >= 0 && n0 + c < N) ? ((uint32_t)g * (uint32_t)P.ldo + (uint32_t)(n0 + c)) * 4u : INV;
       }
-  }
-  if constexpr ((EPI & 1) != 0) {
-    uint8_t* S = smem + wave * STILE;                    // per-wave byte tile [80][SP]; aliases the weight ring (the main loop ends with a barrier)
-    uint32_t sel1, sel2;
-    quad_sel(lnl, sel1, sel2);
-    const int m4 = (c >> 2), ci = c & 3;
+    }
+    auto resid_requests = [&]() __attribute__((always_inline)) {
+      if constexpr ((EPI & 2) != 0) {
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      uint32_t bits = 0;
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-      for (int pp = 0; pp < PPG; ++pp) {
-        float xs[T], sp[T];
+          for (int s = 0; s < SLOTS; ++s)
+            res[cb][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rs, (n0 + 16 * cb + c < N) ? xo[s] : INV, 64u * cb, 0));
+      }
+    };
+
+    i32x4 acc[3][RB][CB];
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const int s = pp * T + t;
-          if constexpr (EPI == 1) xs[t] = __builtin_fmaf(acc[s >> 2][cb][s & 3] * P.asc + bs[cb], al[cb], be[cb]);
-          else xs[t] = acc[s >> 2][cb][s & 3];
+    for (int dg = 0; dg < 3; ++dg)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) acc[dg][rb][cb] = i32x4{0, 0, 0, 0};
+    WSTAMP(ws1);
+    wide_mainloop<RB, CB, WIT>(acc, A_rs, a_base, a_step, K / KCH, smem, W_rs, W_rs, w_goff, w_lds, lane, resid_requests);
+    WSTAMP(ws2);
+
+    // ---------------- epilogue (an inactive wave has no valid row: its stores are dropped) ----------------
+    float val[(EPI & 2) ? CB : 1][(EPI & 2) ? SLOTS : 1];   // fp32 forms: the updated shortcut stream, kept for the neuron
+    if constexpr ((EPI & 2) != 0) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+          float v = digits_f32(acc[0][s >> 2][cb][s & 3], acc[1][s >> 2][cb][s & 3], acc[2][s >> 2][cb][s & 3]) * cs[cb];
+          v = v + bs[cb];
+          v = __builtin_fmaf(v, al[cb], be[cb]);
+          v = v + res[cb][s];
+          val[cb][s] = v;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), x_rs, (n0 + 16 * cb + c < N) ? xo[s] : INV, 64u * cb, 0);
         }
-        neuron_T<NK, T>(xs, sp, P.sn, P.inv_tau);
+    }
+    WSTAMP(ws3);
+    if constexpr ((EPI & 1) != 0) {
+      uint8_t* S = smem + wave * STILE;                    // per-wave byte tile [80][SP]; aliases the weight ring (the main loop ends with a barrier)
+      uint32_t sel1, sel2;
+      quad_sel(lane, sel1, sel2);
+      const int m4 = (c >> 2), ci = c & 3;
 #pragma unroll
-        for (int t = 0; t < T; ++t) bits |= ((__float_as_uint(sp[t]) >> 29) & 1u) << (pp * T + t);      // 1.0f has bit 29 set
+      for (int cb = 0; cb < CB; ++cb) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int pp = 0; pp < PPG; ++pp) {
+          float xs[T], sp[T];
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const int s = pp * T + t;
+            if constexpr (EPI == 1)
+              xs[t] = __builtin_fmaf(digits_f32(acc[0][s >> 2][cb][s & 3], acc[1][s >> 2][cb][s & 3], acc[2][s >> 2][cb][s & 3]) * cs[cb] + bs[cb], al[cb], be[cb]);
+            else
+              xs[t] = val[cb][s];
+          }
+          neuron_T<NK, T>(xs, sp, P.sn, P.inv_tau);
+#pragma unroll
+          for (int t = 0; t < T; ++t) bits |= ((__float_as_uint(sp[t]) >> 29) & 1u) << (pp * T + t);      // 1.0f has bit 29 set
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          const uint32_t w = quad_tr_bytes(spread4(bits >> (4 * rb)), sel1, sel2);
+          *reinterpret_cast<uint32_t*>(S + (16 * rb + 4 * q + ci) * SP + 16 * cb + 4 * m4) = w;
+        }
       }
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
-        const uint32_t w = quad_tr_bytes(spread4(bits >> (4 * rb)), sel1, sel2);
-        *reinterpret_cast<uint32_t*>(S + (16 * rb + 4 * q + ci) * SP + 16 * cb + 4 * m4) = w;
+      for (int it = 0; it < (ROWS * CB + 63) / 64; ++it) {
+        const int pc = lane + 64 * it;
+        if (pc < ROWS * CB) {
+          // tiled: piece-major (80 consecutive rows of a channel piece are 1 280 contiguous bytes); row-major: row-major pieces
+          const int r = P.out_tiled ? pc % ROWS : pc / CB, k16 = P.out_tiled ? pc / ROWS : pc % CB;
+          const int32_t g = rowtab[wave * ROWS + r];
+          const u32x4 v = *reinterpret_cast<const u32x4*>(S + r * SP + 16 * k16);
+          uint32_t off = INV;
+          if (n0 + 16 * k16 < N) {
+            if (P.out_tiled) { if (active) off = (((uint32_t)unit * (uint32_t)(P.ldsp >> 4) + (uint32_t)((n0 >> 4) + k16)) * ROWS + r) * 16u; }
+            else if (g >= 0) off = (uint32_t)g * (uint32_t)P.ldsp + (uint32_t)(n0 + 16 * k16);
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, off, 0, 0);
+        }
       }
     }
-    const __amdgpu_buffer_rsrc_t o_rs = make_rsrc(P.out_spike);
-#pragma unroll
-    for (int it = 0; it < (ROWS * CB + 63) / 64; ++it) {
-      const int pc = lnl + 64 * it;
-      if (pc < ROWS * CB) {
-        const int r = pc / CB, k16 = pc - r * CB;
-        const int32_t g = rowtab[wave * ROWS + r];
-        const u32x4 v = *reinterpret_cast<const u32x4*>(S + r * SP + 16 * k16);
-        __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, (g >= 0 && n0 + 16 * k16 < N) ? (uint32_t)g * (uint32_t)P.ldsp + (uint32_t)(n0 + 16 * k16) : INV, 0, 0);
-      }
-    }
+    if (pass + 1 < P.passes) __syncthreads();              // the byte tiles alias the weight ring of the next pass
   }
+  WSTAMP_OUT(EPI);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -357,11 +420,11 @@ struct WideFrontParams {
   const uint8_t* xs;         // (2, rows, C) u8: SN_proj of the gathered slices
   int64_t rows;              // B_ * N1
   int N1, C, nH;
-  const uint16_t* wq; const uint16_t* wk;  // planes, row pitch C; plane strides (elements)
+  const int8_t* wq; const int8_t* wk;      // digit planes, row pitch C; plane strides (bytes)
   int64_t wq_plane, wk_plane;
+  const float *q_cs, *k_cs;                // (C) power-of-two channel scales
   const float *q_al, *q_be, *k_al, *k_be;
   const float* pe; int64_t pe_ld;          // k's additive term pe[(t * N1 + n) * pe_ld + c] or null
-  float q_asc, k_asc;
   SdfNeuronCfg sn_q, sn_k, sn2_q;
   float it_q, it_k, it_2;
   uint8_t* e;                // (2, rows, C)
@@ -370,56 +433,62 @@ struct WideFrontParams {
   int nrg, ntiles;           // row groups (NW tiles each), token tiles
 };
 
-template <int NSPLIT, int RB, int NK, bool KEEP>
-__global__ __launch_bounds__(256, 2) void wide_front_kernel(WideFrontParams P) {
-  constexpr int NW = 4, CB = 4, BN = 64, NT = 256, PIECES = NSPLIT * BN * 8, WBUF = PIECES * 16, WIT = PIECES / NT;
-  static_assert(NSPLIT == 2, "piece step i = 2 p + (q | k) needs 64 columns = two steps per plane");
+template <int RB, int NK, bool KEEP>
+__global__ __launch_bounds__(256, 1) void wide_front_kernel(WideFrontParams P) {
+  constexpr int NW = 4, CB = 4, WBUF = w_buf(CB), WIT = w_steps(CB);           // 64 columns: 6 piece steps = 3 planes x (q | k)
   constexpr int ROWS = 16 * RB, SB = KEEP ? 96 : 32, SP = s_pitch(SB), STILE = ROWS * SP;
   constexpr int LDSB = 2 * WBUF > NW * STILE ? 2 * WBUF : NW * STILE;
-  static_assert(PIECES % NT == 0, "weight pieces must divide over the threads");
+  static_assert(WIT == 6, "piece step i = 2 p + (q | k)");
   __shared__ __attribute__((aligned(16))) uint8_t smem[LDSB];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, lq = lane >> 4;
+  WSTAMP_DECL;
+  WSTAMP(ws0);
   int item = blockIdx.x;
   const int G = gridDim.x;
   if ((G & 7) == 0) item = (item & 7) * (G >> 3) + (item >> 3);
   if (item >= P.nH * P.nrg) return;
-  const int hd = item / P.nrg, rg = item - hd * P.nrg;
+  const int rg = item / P.nH, hd = item - rg * P.nH;                 // head fastest: an XCD owns a contiguous range of token tiles
   const int tile = rg * NW + wave;
   const bool active = tile < P.ntiles;
   const int C = P.C;
   const int64_t tok0 = (int64_t)tile * (8 * RB);
 
   const __amdgpu_buffer_rsrc_t A_rs = make_rsrc(P.xs), Wq_rs = make_rsrc(P.wq), Wk_rs = make_rsrc(P.wk);
-  uint32_t a_base[RB];
+  uint32_t a_base[RB];                                               // tile row r = 2 (token of the tile) + step
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const int64_t tk = tok0 + 8 * rb + (l16 >> 1);
     a_base[rb] = (active && tk < P.rows) ? (uint32_t)(((int64_t)(l16 & 1) * P.rows + tk) * C) + 16u * lq : INV;
   }
-  f32x4 acc[RB][CB];
+  i32x4 acc[3][RB][CB];
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
+  for (int dg = 0; dg < 3; ++dg)
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[dg][rb][cb] = i32x4{0, 0, 0, 0};
   // weight pieces: step i = 2 p + (0: the head's 32 q rows, 1: its 32 k rows) - the buffer of a piece is a compile-time choice
   uint32_t w_goff[WIT], w_lds[WIT];
-  wide_pieces<NSPLIT, CB>(w_goff, w_lds, tid, [&](int p, int col, int i) -> uint32_t {
-    return (uint32_t)((p * ((i & 1) ? P.wk_plane : P.wq_plane) + (int64_t)(hd * 32 + (col & 31)) * C) * 2);
+  wide_pieces<CB>(w_goff, w_lds, tid, [&](int p, int col, int i) -> uint32_t {
+    return (uint32_t)(p * ((i & 1) ? P.wk_plane : P.wq_plane) + (int64_t)(hd * 32 + (col & 31)) * C);
   });
-  wide_mainloop<NSPLIT, RB, CB, WIT>(acc, A_rs, a_base, (uint32_t)KCH, C / KCH, active, smem, Wq_rs, Wk_rs, w_goff, w_lds, lane);
+  WSTAMP(ws1);
+  wide_mainloop<RB, CB, WIT>(acc, A_rs, a_base, 64u, C / KCH, smem, Wq_rs, Wk_rs, w_goff, w_lds, lane, [] {});
+  WSTAMP(ws2);
   if (!active) return;                                    // (the main loop ends with a barrier: the per-wave byte tiles may alias the weight ring)
 
   // ---------------- epilogue ----------------
   int lnl = lane;
   asm volatile("" : "+v"(lnl));
   const int c = lnl & 15, q = lnl >> 4;
-  float qa[2], qb[2], ka[2], kb[2];
+  float qa[2], qb[2], ka[2], kb[2], qc[2], kc[2];
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int ch = hd * 32 + 16 * cb + c;
     qa[cb] = P.q_al ? P.q_al[ch] : 1.f; qb[cb] = P.q_al ? P.q_be[ch] : 0.f;
     ka[cb] = P.k_al ? P.k_al[ch] : 1.f; kb[cb] = P.k_al ? P.k_be[ch] : 0.f;
+    qc[cb] = P.q_cs[ch]; kc[cb] = P.k_cs[ch];
   }
   // positional term of k: pe[(t * N1 + n) * pe_ld + channel], n = token % N1
   const int nbase = (int)(tok0 % P.N1);
@@ -451,8 +520,9 @@ __global__ __launch_bounds__(256, 2) void wide_front_kernel(WideFrontParams P) {
         float xq[2], xk[2], sq[2], sk[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          xq[t] = __builtin_fmaf(acc[rb][cb][2 * m + t] * P.q_asc, qa[cb], qb[cb]);
-          xk[t] = __builtin_fmaf(acc[rb][2 + cb][2 * m + t] * P.k_asc, ka[cb], kb[cb]);
+          const int e = 2 * m + t;
+          xq[t] = __builtin_fmaf(digits_f32(acc[0][rb][cb][e], acc[1][rb][cb][e], acc[2][rb][cb][e]) * qc[cb], qa[cb], qb[cb]);
+          xk[t] = __builtin_fmaf(digits_f32(acc[0][rb][2 + cb][e], acc[1][rb][2 + cb][e], acc[2][rb][2 + cb][e]) * kc[cb], ka[cb], kb[cb]);
           if (P.pe) xk[t] = xk[t] + pev[rb][m][t][cb];
         }
         neuron_T<NK, 2>(xq, sq, P.sn_q, P.it_q);
@@ -485,6 +555,7 @@ __global__ __launch_bounds__(256, 2) void wide_front_kernel(WideFrontParams P) {
       }
     }
   }
+  WSTAMP(ws3);
   // byte tile -> E (and the q / k tape): tile row r = 16 rb + 2 tokl + t
   constexpr int PPR = SB / 16;
 #pragma unroll
@@ -502,6 +573,7 @@ __global__ __launch_bounds__(256, 2) void wide_front_kernel(WideFrontParams P) {
       }
     }
   }
+  WSTAMP_OUT(0);
 }
 
 __global__ __launch_bounds__(256) void zsrc_kernel(const int32_t* __restrict__ map, int32_t* __restrict__ zsrc, int64_t B_, int Tq, int N1,
@@ -530,13 +602,13 @@ int pick_cb(int64_t units, int N, const int* cbs, int ncb) {
   return 0;
 }
 
-template <int NSPLIT, int T, int CB, int EPI>
+template <int T, int CB, int EPI>
 int launch_pm_nk(const WidePmParams& P, int nk, dim3 grid, hipStream_t s) {
   if constexpr (EPI == 2) {
-    hipLaunchKernelGGL((wide_pm_kernel<NSPLIT, T, CB, 4, EPI, 0>), grid, dim3(256), 0, s, P);
+    hipLaunchKernelGGL((wide_pm_kernel<T, CB, EPI, 0>), grid, dim3(256), 0, s, P);
   } else {
-    if (nk == 0) hipLaunchKernelGGL((wide_pm_kernel<NSPLIT, T, CB, 4, EPI, 0>), grid, dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((wide_pm_kernel<NSPLIT, T, CB, 4, EPI, 2>), grid, dim3(256), 0, s, P);
+    if (nk == 0) hipLaunchKernelGGL((wide_pm_kernel<T, CB, EPI, 0>), grid, dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((wide_pm_kernel<T, CB, EPI, 2>), grid, dim3(256), 0, s, P);
   }
   return 0;
 }
@@ -545,19 +617,30 @@ template <int T>
 int launch_pm_t(WidePmParams& P, int epi, hipStream_t s) {
   constexpr int PPW = 4 * (20 / T);
   const int64_t units = (P.P + PPW - 1) / PPW;
-  static const int cbs_n[2] = {3, 6}, cbs_f[2] = {2, 3};
-  const int cb = pick_cb(units, P.N, epi == 1 ? cbs_n : cbs_f, 2);
+  // the fp32 epilogues hold the shortcut values and the updated stream beside the accumulators: two column blocks; the neuron-only
+  // epilogue (fc1) takes three where that still fills the chip
+  static const int cbs[2] = {2, 3};
+  int cb = pick_cb(units, P.N, cbs, epi == 1 ? 2 : 1);
+  if (const char* e = getenv("SDF_WIDE_CB")) {                     // tuning override (fc1): 2 / 3
+    const int v = e[0] - '0';
+    if (epi == 1 && (v == 2 || v == 3) && P.N % (16 * v) == 0) cb = v;
+  }
   if (!cb || units >= (1LL << 28)) return SDF_E_SHAPE;
   P.nunits = (int)units;
   P.nrg = (int)((units + 3) / 4);
   P.ncg = P.N / (16 * cb);
-  const int64_t items = (int64_t)P.ncg * P.nrg;
+  // one workgroup per compute unit (the kernels take most of its registers): a launch of up to four rounds runs as ONE round of
+  // workgroups that walk several row groups (the prologue is paid once, no second dispatch wave)
+  const int64_t all = (int64_t)P.ncg * P.nrg;
+  P.passes = all > 256 && all <= 1024 ? (int)((all + 255) / 256) : 1;
+  if (const char* e = getenv("SDF_WIDE_PASSES")) { const int v = atoi(e); if (v >= 1 && v <= 8) P.passes = v; }     // tuning override
+  const int64_t items = (int64_t)P.ncg * ((P.nrg + P.passes - 1) / P.passes);
   if (items >= (1LL << 31) - 8) return SDF_E_SHAPE;
   const dim3 grid((unsigned)((items + 7) / 8 * 8));
   const int nk = neuron_class(P.sn);
-  if (epi == 1) return cb == 6 ? launch_pm_nk<2, T, 6, 1>(P, nk, grid, s) : launch_pm_nk<2, T, 3, 1>(P, nk, grid, s);
-  if (epi == 2) return cb == 3 ? launch_pm_nk<2, T, 3, 2>(P, 0, grid, s) : launch_pm_nk<2, T, 2, 2>(P, 0, grid, s);
-  return cb == 3 ? launch_pm_nk<2, T, 3, 3>(P, nk, grid, s) : launch_pm_nk<2, T, 2, 3>(P, nk, grid, s);
+  if (epi == 1) return cb == 3 ? launch_pm_nk<T, 3, 1>(P, nk, grid, s) : launch_pm_nk<T, 2, 1>(P, nk, grid, s);
+  if (epi == 2) return launch_pm_nk<T, 2, 2>(P, 0, grid, s);
+  return launch_pm_nk<T, 2, 3>(P, nk, grid, s);
 }
 
 int launch_pm(WidePmParams& P, int T, int epi, hipStream_t s) {
@@ -580,30 +663,33 @@ bool wide_env_off() {
 }  // namespace
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
-// Shapes the wide forms are built for: two fp16 planes, LIF / IF neurons (the PSN keeps the general kernels), C a multiple of 128
-// from 256 on, T in {10, 20}, operands within the kernels' 31-bit buffer offsets.
+// Shapes the wide forms are built for: int8 digit planes beside the 16-bit ones (the caller packs both; the default two-plane
+// mode only - the exact three-plane and the one-plane bf16 modes keep the general kernels), LIF / IF neurons (the PSN keeps the
+// general kernels), C a multiple of 128 from 256 on, T in {10, 20}, operands within the kernels' 31-bit buffer offsets.
 bool ms_wide_mlp_supports(const SdfMsMlpDesc* d) {
   if (wide_env_off() || (d->flags & SDF_MLP_NARROW)) return false;
+  if (!d->fc1_digits || !d->fc1_cscale || !d->fc2_digits || !d->fc2_cscale) return false;
   if (d->nsplit != 2 || d->C < 256 || d->C % 128 || d->Ch % 128 || d->Ch % 96) return false;
   if (d->D != 10 && d->D != 20) return false;
   if (!neuron_ok(d->sn1) || !neuron_ok(d->sn2)) return false;
   const int64_t tokens = (int64_t)d->B * d->D * d->HW;
   if (tokens * d->Ch >= (1LL << 31) || tokens * d->C * 4 >= (1LL << 31)) return false;
   if (!d->fc1_alpha || !d->fc1_beta || !d->fc2_alpha || !d->fc2_beta) return false;
-  return sdf_aligned(d->x, 16) && sdf_aligned(d->fc1_planes, 16) && sdf_aligned(d->fc2_planes, 16);
+  return sdf_aligned(d->x, 16) && sdf_aligned(d->fc1_digits, 16) && sdf_aligned(d->fc2_digits, 16);
 }
 
-// s1 = SN1(x) must already be in `s1` (u8 [tokens][C]); s2 receives the hidden spikes; x is updated in place
-int launch_ms_wide_mlp(const SdfMsMlpDesc* d, const uint8_t* s1, uint8_t* s2, hipStream_t s) {
+// s1 = SN1(x) must already be in `s1` (row-major u8 [tokens][C], or tiled); s2 receives the hidden spikes (row-major for the
+// parity tape, else tiled); x is updated in place
+int launch_ms_wide_mlp(const SdfMsMlpDesc* d, const uint8_t* s1, bool s1_tiled, uint8_t* s2, bool s2_tiled, hipStream_t s) {
   WidePmParams P = {};
-  P.A = s1; P.W = d->fc1_planes; P.N = d->Ch; P.K = d->C; P.HW = (int)d->HW; P.P = (int64_t)d->B * d->HW;
-  P.asc = d->fc1_acc_scale; P.alpha = d->fc1_alpha; P.beta = d->fc1_beta;
+  P.A = s1; P.a_tiled = s1_tiled; P.out_tiled = s2_tiled; P.W = d->fc1_digits; P.cscale = d->fc1_cscale; P.N = d->Ch; P.K = d->C; P.HW = (int)d->HW; P.P = (int64_t)d->B * d->HW;
+  P.alpha = d->fc1_alpha; P.beta = d->fc1_beta;
   P.out_spike = s2; P.ldsp = d->Ch; P.sn = d->sn2; P.inv_tau = inv_tau_of(d->sn2);
   int rc = launch_pm(P, d->D, 1, s);
   if (rc) return rc;
   WidePmParams Q = {};
-  Q.A = s2; Q.W = d->fc2_planes; Q.N = d->C; Q.K = d->Ch; Q.HW = (int)d->HW; Q.P = P.P;
-  Q.asc = d->fc2_acc_scale; Q.alpha = d->fc2_alpha; Q.beta = d->fc2_beta; Q.x = d->x; Q.ldo = d->C;
+  Q.A = s2; Q.a_tiled = s2_tiled; Q.W = d->fc2_digits; Q.cscale = d->fc2_cscale; Q.N = d->C; Q.K = d->Ch; Q.HW = (int)d->HW; Q.P = P.P;
+  Q.alpha = d->fc2_alpha; Q.beta = d->fc2_beta; Q.x = d->x; Q.ldo = d->C;
   Q.sn = d->sn2;
   return launch_pm(Q, d->D, 2, s);
 }
@@ -621,13 +707,14 @@ bool ms_wide_attn_supports(const SdfQkAttnDesc* d) {
   const int64_t M = d->B_ * d->N1 * d->Tq;
   if (M * d->C >= (1LL << 31) || d->x_rows * d->C * 4 >= (1LL << 31) || M >= (1LL << 31)) return false;
   const bool fused = d->qk_planes != nullptr;
-  if (!fused && (!d->q_planes || !d->k_planes)) return false;
+  if (fused ? (!d->qk_digits || !d->qk_cscale) : (!d->q_digits || !d->q_cscale || !d->k_digits || !d->k_cscale)) return false;
+  if (!d->p_digits || !d->p_cscale) return false;
   const float* al[4] = {fused ? d->qk_alpha : d->q_alpha, fused ? d->qk_beta : d->q_beta, fused ? d->qk_alpha : d->k_alpha,
                         fused ? d->qk_beta : d->k_beta};
   if ((al[0] == nullptr) != (al[1] == nullptr) || (al[2] == nullptr) != (al[3] == nullptr)) return false;
   if (d->p_alpha && !d->p_beta) return false;
-  return sdf_aligned(d->x, 16) && sdf_aligned(d->p_planes, 16) && sdf_aligned(fused ? (const void*)d->qk_planes : (const void*)d->q_planes, 16) &&
-         (fused || sdf_aligned(d->k_planes, 16));
+  return sdf_aligned(d->x, 16) && sdf_aligned(d->p_digits, 16) && sdf_aligned(fused ? (const void*)d->qk_digits : (const void*)d->q_digits, 16) &&
+         (fused || sdf_aligned(d->k_digits, 16));
 }
 
 // xs (2, rows, C) = SN_proj of the gathered slices -> E (2, rows, C) [+ q | k tape] ; then x += proj(E) (+ emit)
@@ -637,21 +724,19 @@ int launch_ms_wide_front(const SdfQkAttnDesc* d, const uint8_t* xs, uint8_t* e, 
   const int64_t rows = d->B_ * d->N1, M = rows * d->Tq;
   P.xs = xs; P.rows = rows; P.N1 = d->N1; P.C = C; P.nH = d->nH;
   if (d->qk_planes) {
-    P.wq = d->qk_planes; P.wk = d->qk_planes + (int64_t)C * C; P.wq_plane = P.wk_plane = 2LL * C * C;
+    P.wq = d->qk_digits; P.wk = d->qk_digits + (int64_t)C * C; P.wq_plane = P.wk_plane = 2LL * C * C;
+    P.q_cs = d->qk_cscale; P.k_cs = d->qk_cscale + C;
     P.q_al = d->qk_alpha; P.q_be = d->qk_beta;
     P.k_al = d->qk_alpha ? d->qk_alpha + C : nullptr; P.k_be = d->qk_beta ? d->qk_beta + C : nullptr;
     P.pe = d->qk_add ? d->qk_add + C : nullptr; P.pe_ld = 2LL * C;
-    P.q_asc = P.k_asc = d->qk_acc_scale;
     P.qs = qk; P.ks = qk + C; P.ldq = P.ldk = 2LL * C;
   } else {
-    P.wq = d->q_planes; P.wk = d->k_planes; P.wq_plane = P.wk_plane = (int64_t)C * C;
+    P.wq = d->q_digits; P.wk = d->k_digits; P.wq_plane = P.wk_plane = (int64_t)C * C;
+    P.q_cs = d->q_cscale; P.k_cs = d->k_cscale;
     P.q_al = d->q_alpha; P.q_be = d->q_beta; P.k_al = d->k_alpha; P.k_be = d->k_beta;
     P.pe = d->k_add; P.pe_ld = C;
-    P.q_asc = d->q_acc_scale; P.k_asc = d->k_acc_scale;
     P.qs = qk; P.ks = qk + M * C; P.ldq = P.ldk = C;
   }
-  if (P.q_asc == 0.f) P.q_asc = 1.f;
-  if (P.k_asc == 0.f) P.k_asc = 1.f;
   P.sn_q = d->sn_q; P.sn_k = d->sn_k; P.sn2_q = d->sn2_q;
   P.it_q = inv_tau_of(d->sn_q); P.it_k = inv_tau_of(d->sn_k); P.it_2 = inv_tau_of(d->sn2_q);
   P.e = e;
@@ -667,8 +752,8 @@ int launch_ms_wide_front(const SdfQkAttnDesc* d, const uint8_t* xs, uint8_t* e, 
   const int nk = neuron_class(d->sn_q);
 #define SDF_WF(RB_, NK_)                                                                                  \
   do {                                                                                                    \
-    if (keep) hipLaunchKernelGGL((wide_front_kernel<2, RB_, NK_, true>), grid, dim3(256), 0, s, P);       \
-    else hipLaunchKernelGGL((wide_front_kernel<2, RB_, NK_, false>), grid, dim3(256), 0, s, P);           \
+    if (keep) hipLaunchKernelGGL((wide_front_kernel<RB_, NK_, true>), grid, dim3(256), 0, s, P);          \
+    else hipLaunchKernelGGL((wide_front_kernel<RB_, NK_, false>), grid, dim3(256), 0, s, P);              \
   } while (0)
   if (big) { if (nk == 0) SDF_WF(5, 0); else SDF_WF(5, 2); }
   else { if (nk == 0) SDF_WF(2, 0); else SDF_WF(2, 2); }
@@ -680,15 +765,22 @@ int launch_ms_wide_front(const SdfQkAttnDesc* d, const uint8_t* xs, uint8_t* e, 
 int launch_ms_wide_proj(const SdfQkAttnDesc* d, const uint8_t* e, hipStream_t s) {
   WidePmParams P = {};
   P.A = e; P.zsrc = d->x_src; P.zg_G = (uint32_t)d->Tq * (uint32_t)d->N1 * 32u;
-  P.W = d->p_planes; P.N = d->C; P.K = d->C; P.HW = (int)d->xHW; P.P = (int64_t)d->xB * d->xHW;
-  P.asc = d->p_acc_scale; P.bias = d->p_bias; P.alpha = d->p_alpha; P.beta = d->p_beta;
+  P.W = d->p_digits; P.cscale = d->p_cscale; P.N = d->C; P.K = d->C; P.HW = (int)d->xHW; P.P = (int64_t)d->xB * d->xHW;
+  P.bias = d->p_bias; P.alpha = d->p_alpha; P.beta = d->p_beta;
   P.x = d->x; P.ldo = d->C;
-  P.out_spike = d->emit_s1; P.ldsp = d->C;
+  P.out_spike = d->emit_s1; P.ldsp = d->C; P.out_tiled = (d->flags & SDF_QK_KEEP_SPIKES) ? 0 : 1;
   P.sn = d->emit_s1 ? d->emit_sn : d->sn_proj; P.inv_tau = inv_tau_of(P.sn);
   return launch_pm(P, d->xD, d->emit_s1 ? 3 : 2, s);
 }
 
 }  // namespace sdfmm
+
+#ifdef SDF_STAMP
+extern "C" int sdf_debug_read_stamps_wide(unsigned long long* host32, unsigned long long* census) {
+  (void)hipMemcpyFromSymbol(census, HIP_SYMBOL(g_wide_census), sizeof(g_wide_census));
+  return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(g_wide_stamp), sizeof(g_wide_stamp));
+}
+#endif
 
 extern "C" int sdf_window_zsrc_map(const int32_t* slice_map, int64_t B_, int Tq, int N1, int nH, int32_t* x_src, void* stream) {
   if (!slice_map || !x_src) return SDF_E_NULL;

@@ -171,7 +171,8 @@ extern "C" int sdf_qk_attn_fwd(const SdfQkAttnDesc* d, void* stream) {
 // MS MLP, whole (row a7): x += BN2(W2 SN2(BN1(W1 SN1(x))))  over the true time axis D of a (B, D, HW, C) buffer.
 extern "C" int64_t sdf_ms_mlp_workspace_bytes(int64_t tokens, int C, int Ch) {
   if (tokens < 1 || C < 1 || Ch < 1) return 0;
-  return ((tokens * C + 255) / 256 * 256) + tokens * Ch;
+  // (+ 80 rows each: the tiled hand-over layout of the wide-stage kernels rounds the rows up to whole 80-row units)
+  return (((tokens + 80) * C + 255) / 256 * 256) + (tokens + 80) * Ch;
 }
 
 extern "C" int sdf_ms_mlp_fwd(const SdfMsMlpDesc* d, void* stream) {
@@ -185,9 +186,12 @@ extern "C" int sdf_ms_mlp_fwd(const SdfMsMlpDesc* d, void* stream) {
   const int64_t hw = d->HW;
   uint8_t* s1 = reinterpret_cast<uint8_t*>(d->workspace);
   uint8_t* s2 = s1 + (tokens * C + 255) / 256 * 256;
-  // wide stages: [SN1 unless the attention's projection already emitted it] -> fc1 + BN1 + SN2 -> fc2 + BN2 + shortcut
+  // wide stages: [SN1 unless the attention's projection already emitted it] -> fc1 + BN1 + SN2 -> fc2 + BN2 + shortcut.  With the
+  // tape both spike tensors are row-major at the documented offsets; without it they travel in the tiled hand-over layout
   if (sdfmm::ms_wide_mlp_supports(d)) {
     if (d->s1_in && d->s1_in != s1) return SDF_E_SHAPE;
+    const bool tape = (d->flags & SDF_MLP_KEEP_SPIKES) != 0;
+    uint8_t* s2w = tape ? s2 : s1 + ((tokens + 80) * C + 255) / 256 * 256;
     if (!d->s1_in) {
       SdfNeuronDesc n = {};
       n.x = d->x; n.out = s1; n.T = D; n.out_dtype = SDF_U8;
@@ -196,7 +200,7 @@ extern "C" int sdf_ms_mlp_fwd(const SdfMsMlpDesc* d, void* stream) {
       const int rcw = sdf_neuron_fwd(&n, stream);
       if (rcw) return rcw;
     }
-    return sdfmm::launch_ms_wide_mlp(d, s1, s2, sdf_stream(stream));
+    return sdfmm::launch_ms_wide_mlp(d, s1, d->s1_in != nullptr && !tape, s2w, !tape, sdf_stream(stream));
   }
   if (d->s1_in) return SDF_E_SHAPE;
   // one launch where the kernel has an instantiation (SDF_MLP_FUSED=0 / SDF_MLP_THREE_LAUNCHES: the A/B reference below)

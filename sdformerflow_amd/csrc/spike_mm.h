@@ -223,7 +223,7 @@ bool ms_mlp_fused_supports(const SdfMsMlpDesc* d);
 int launch_ms_mlp_fused(const SdfMsMlpDesc* d, uint8_t* keep_s1, uint8_t* keep_s2, hipStream_t s);
 // wide stages (ms_wide.hip): the block's matrix products as position-major kernels with the neurons in their epilogues
 bool ms_wide_mlp_supports(const SdfMsMlpDesc* d);
-int launch_ms_wide_mlp(const SdfMsMlpDesc* d, const uint8_t* s1, uint8_t* s2, hipStream_t s);
+int launch_ms_wide_mlp(const SdfMsMlpDesc* d, const uint8_t* s1, bool s1_tiled, uint8_t* s2, bool s2_tiled, hipStream_t s);
 bool ms_wide_attn_supports(const SdfQkAttnDesc* d);
 int launch_ms_wide_front(const SdfQkAttnDesc* d, const uint8_t* xs, uint8_t* e, uint8_t* qk, bool keep, hipStream_t s);
 int launch_ms_wide_proj(const SdfQkAttnDesc* d, const uint8_t* e, hipStream_t s);

@@ -44,6 +44,8 @@ class _Lin:
         w = linear.weight.detach().float().to(device).contiguous()
         self.N, self.K = w.shape
         self.Wp = hip.split_weight(w, nsplit)
+        # wide layers (swin stages 2 - 3) also carry int8 digit planes: what csrc/ms_wide.hip multiplies by (default plane mode only)
+        self.digits = hip.split_weight_i8x3(w) if nsplit == 2 and self.K >= 256 and self.K % 128 == 0 and self.N % 32 == 0 else None
         self.bias = None if linear.bias is None else linear.bias.detach().float().to(device).contiguous()
         self.alpha, self.beta = bn_affine(bn, device) if bn is not None else (None, None)
 
@@ -90,7 +92,8 @@ class _Block:
         sq, sk = self.sn_q, self.sn_k
         if sq.kind != "psn" and (sq.kind, sq.tau, sq.v_th, sq.v_reset) == (sk.kind, sk.tau, sk.v_th, sk.v_reset):
             w = torch.cat([a.linear_q.weight.detach().float(), a.linear_k.weight.detach().float()], 0).to(device).contiguous()
-            self.qk = {"Wp": hip.split_weight(w, nsplit), "alpha": torch.cat([self.q.alpha, self.k.alpha]).contiguous(),
+            self.qk = {"Wp": hip.split_weight(w, nsplit), "digits": hip.split_weight_i8x3(w) if self.q.digits is not None else None,
+                       "alpha": torch.cat([self.q.alpha, self.k.alpha]).contiguous(),
                        "beta": torch.cat([self.q.beta, self.k.beta]).contiguous(),
                        # the positional table is consumed as flat (Tq, N1, C) memory (the reference's raw reshape, :678-679)
                        "add": torch.cat([torch.zeros((self.pe.numel() // self.q.N, self.q.N), device=device),
@@ -475,7 +478,9 @@ class MSFlowEngine:
     def swin_block(self, x, s, i):
         blk = self.stages[s][i]
         last = self.scores is not None and i == len(self.stages[s]) - 1          # log=True: the last block of every stage (:1090-1105)
-        ws = hip.ms_mlp_workspace(x, blk.fc1.N) if x.shape[-1] >= 256 else None      # wide stages: the projection emits the MLP's first spikes
+        # wide stages: the projection emits the MLP's first spikes (tiled hand-over layout; the tape / score paths keep row-major spikes
+        # and let the MLP run its own first neuron)
+        ws = hip.ms_mlp_workspace(x, blk.fc1.N) if x.shape[-1] >= 256 and self.tape is None and not last else None
         self.attention(x, blk, self.scores if last else None, emit=(ws, blk.sn1) if ws is not None else None)
         return self.mlp(x, blk, ws=ws, s1_ready=self._emitted)
 

@@ -307,7 +307,8 @@ PLANES_I8X3 = 4
 
 def split_weight_i8x3(W):
     """fp32 weight (N, K) -> int8 digit planes (3, N, K) + per-row power-of-two scales (attribute `sdf_col_scale`):
-    w = (d2*65536 + d1*256 + d0) * scale (sdf_split_weight_i8x3).  Only the weight-resident 3x3 convolution reads this format."""
+    w = (d2*65536 + d1*256 + d0) * scale (sdf_split_weight_i8x3).  Read by the weight-resident 3x3 convolution and the wide-stage
+    kernels of the swin blocks (csrc/ms_wide.hip)."""
     W = W.contiguous()
     N, K = W.shape
     planes = torch.empty((3, N, K), dtype=torch.int8, device=W.device)
@@ -418,7 +419,9 @@ class QkAttnDesc(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
                 ("gemm_workspace", C.c_void_p), ("gemm_workspace_bytes", C.c_int64), ("flags", C.c_int32),
                 ("x_src", C.c_void_p), ("xB", C.c_int32), ("xD", C.c_int32), ("xHW", C.c_int64), ("emit_s1", C.c_void_p),
-                ("emit_sn", NeuronCfg)]
+                ("emit_sn", NeuronCfg),
+                ("qk_digits", C.c_void_p), ("qk_cscale", C.c_void_p), ("q_digits", C.c_void_p), ("q_cscale", C.c_void_p),
+                ("k_digits", C.c_void_p), ("k_cscale", C.c_void_p), ("p_digits", C.c_void_p), ("p_cscale", C.c_void_p)]
 
 
 SDF_QK_KEEP_SPIKES, SDF_QK_FOUR_LAUNCHES, SDF_QK_NARROW = 1, 2, 4
@@ -442,6 +445,13 @@ def window_slice_map(B, D, H, W, ws, ss, device):
                                       _stream()), "sdf_window_slice_map")
     assert nw.value == B_
     return m, B_
+
+
+def _digits(dg):
+    """(planes pointer, channel-scale pointer) of int8 digit planes made by split_weight_i8x3, or (None, None)."""
+    if dg is None:
+        return None, None
+    return _ptr(dg, torch.int8), _ptr(dg.sdf_col_scale, torch.float32)
 
 
 def window_zsrc_map(slice_map, B_, Tq, N1, nH, x_rows):
@@ -485,6 +495,13 @@ def qk_attn(x, slice_map, B_, Tq, N1, nH, p_lin, sn_proj, sn_q, sn_k, sn2_q, qk=
         (SDF_QK_NARROW if narrow else 0)
     if x_src is not None:
         d.x_src, d.xB, d.xD, d.xHW = _ptr(x_src, torch.int32), x.shape[0], x.shape[1], x.shape[2] * x.shape[3]
+        # the wide-stage kernels multiply int8 digit planes (`digits` of the layer objects / of the qk dict, made by split_weight_i8x3)
+        d.p_digits, d.p_cscale = _digits(getattr(p_lin, "digits", None))
+        if qk is not None:
+            d.qk_digits, d.qk_cscale = _digits(qk.get("digits"))
+        else:
+            d.q_digits, d.q_cscale = _digits(getattr(q_lin, "digits", None))
+            d.k_digits, d.k_cscale = _digits(getattr(k_lin, "digits", None))
     if emit is not None and lib().sdf_qk_attn_is_wide(C.byref(d)) == 1 and emit[1].kind in ("lif", "if"):
         d.emit_s1 = _ptr(emit[0], torch.uint8)                # (only the wide-stage projection emits the next neuron's spikes)
         _ncfg(d.emit_sn, emit[1])
@@ -503,7 +520,8 @@ class MsMlpDesc(C.Structure):
                 ("fc2_planes", C.c_void_p), ("fc2_alpha", C.c_void_p), ("fc2_beta", C.c_void_p), ("fc2_acc_scale", C.c_float),
                 ("sn1", NeuronCfg), ("sn2", NeuronCfg),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-                ("gemm_workspace", C.c_void_p), ("gemm_workspace_bytes", C.c_int64), ("flags", C.c_int32), ("s1_in", C.c_void_p)]
+                ("gemm_workspace", C.c_void_p), ("gemm_workspace_bytes", C.c_int64), ("flags", C.c_int32), ("s1_in", C.c_void_p),
+                ("fc1_digits", C.c_void_p), ("fc1_cscale", C.c_void_p), ("fc2_digits", C.c_void_p), ("fc2_cscale", C.c_void_p)]
 
 
 MLP_KEEP_SPIKES, MLP_THREE_LAUNCHES, MLP_NARROW = 1, 2, 4
@@ -535,6 +553,8 @@ def ms_mlp(x, fc1, fc2, sn1, sn2, keep_ws=None, three_launches=False, ws=None, s
     gws = workspace(x.device)
     d.gemm_workspace, d.gemm_workspace_bytes = gws.data_ptr(), gws.numel()
     d.flags = (MLP_KEEP_SPIKES if keep_ws is not None else 0) | (MLP_THREE_LAUNCHES if three_launches else 0) | (MLP_NARROW if narrow else 0)
+    d.fc1_digits, d.fc1_cscale = _digits(getattr(fc1, "digits", None))
+    d.fc2_digits, d.fc2_cscale = _digits(getattr(fc2, "digits", None))
     if s1_ready:
         d.s1_in = ws.data_ptr()
         if lib().sdf_ms_mlp_is_wide(C.byref(d)) != 1:

@@ -109,6 +109,8 @@ def test_argument_errors_are_reported_before_any_launch():
     m.B, m.D, m.HW, m.C, m.Ch, m.nsplit, m.workspace_bytes = 1, 10, 432, 384, 1536, 2, 1 << 30
     m.sn1.kind = m.sn2.kind = hip.SDF_LIF
     m.sn1.tau = m.sn2.tau = 2.0
+    assert lib.sdf_ms_mlp_is_wide(C.byref(m)) == 0              # no int8 digit planes given: the general kernels
+    m.fc1_digits, m.fc1_cscale, m.fc2_digits, m.fc2_cscale = (0x10000,) * 4
     assert lib.sdf_ms_mlp_is_wide(C.byref(m)) == 1
     m.flags = hip.MLP_NARROW
     assert lib.sdf_ms_mlp_is_wide(C.byref(m)) == 0

@@ -30,13 +30,15 @@ class _L:
     def __init__(self, W, alpha, beta, bias=None, ns=2):
         self.N, self.K = W.shape
         self.Wp = hip.split_weight(W.to(DEV).contiguous(), ns)
+        self.digits = hip.split_weight_i8x3(W.to(DEV).contiguous())
         self.alpha, self.beta = alpha.to(DEV).contiguous(), beta.to(DEV).contiguous()
         self.bias = None if bias is None else bias.to(DEV).contiguous()
 
 
-def _weff(Wp):
-    """The fp64 value of the weight the planes carry (what the kernel multiplies by, exactly)."""
-    return Wp.cpu().view(torch.float16).double().sum(0) * Wp.sdf_acc_scale
+def _weff(dg):
+    """The fp64 value of the weight the int8 digit planes carry (what the wide-stage kernels multiply by, exactly)."""
+    d = dg.cpu().double()
+    return (d[2] * 65536 + d[1] * 256 + d[0]) * dg.sdf_col_scale.cpu().double().view(-1, 1)
 
 
 NEURONS = {                        # name -> (kind, tau, v_reset): class 0 (soft reset, power-of-two tau / plif) and the general class 2
@@ -91,7 +93,8 @@ def test_wide_mlp_steps_against_the_oracle(B, D, H, W, Cc, name):
     assert torch.equal(s1g.float(), s1r), "SN1 spikes differ from the oracle"
     assert 0.03 < s1r.mean() < 0.97
     # (b) SN2 on the kernel's own s1
-    W1e, W2e = _weff(fc1.Wp), _weff(fc2.Wp)
+    W1e, W2e = _weff(fc1.digits), _weff(fc2.digits)
+    assert (W1e - W1.double()).abs().max() <= 2.0 ** -22 * W1.abs().max()
     h = (s1g.double() @ W1e.t()) * a1.double() + b1.double()
     ht = h.view(B, D, H * W, Ch).permute(1, 0, 2, 3).float().contiguous()
     got = s2g.view(B, D, H * W, Ch).permute(1, 0, 2, 3).float().contiguous()
@@ -145,14 +148,14 @@ def test_wide_attention_steps_against_the_oracle(B, D, H, W, Cc, window, shift, 
     plin = _L(Wp, ap, bp, biasp)
     qlin, klin = _L(Wq, aq, bq), _L(Wk, ak, bk)
     if stacked:
-        Wqk = hip.split_weight(torch.cat([Wq, Wk], 0).to(DEV).contiguous(), 2)
-        qk = {"Wp": Wqk, "alpha": torch.cat([aq, ak]).to(DEV), "beta": torch.cat([bq, bk]).to(DEV),
-              "add": torch.cat([torch.zeros_like(pe), pe], -1).to(DEV).contiguous()}
+        wcat = torch.cat([Wq, Wk], 0).to(DEV).contiguous()
+        qk = {"Wp": hip.split_weight(wcat, 2), "digits": hip.split_weight_i8x3(wcat), "alpha": torch.cat([aq, ak]).to(DEV),
+              "beta": torch.cat([bq, bk]).to(DEV), "add": torch.cat([torch.zeros_like(pe), pe], -1).to(DEV).contiguous()}
         kw = dict(qk=qk)
-        Wqe, Wke = _weff(Wqk)[:Cc], _weff(Wqk)[Cc:]
+        Wqe, Wke = _weff(qk["digits"])[:Cc], _weff(qk["digits"])[Cc:]
     else:
         kw = dict(q_lin=qlin, k_lin=klin, pe=pe.to(DEV).contiguous())
-        Wqe, Wke = _weff(qlin.Wp), _weff(klin.Wp)
+        Wqe, Wke = _weff(qlin.digits), _weff(klin.digits)
     rowmap, B_ = hip.window_slice_map(B, D, H, W, window, shift, DEV)
     x_rows, rows = B * D * H * W, B_ * N1
     M = Tq * rows
@@ -197,7 +200,7 @@ def test_wide_attention_steps_against_the_oracle(B, D, H, W, Cc, window, shift, 
     assert 0.01 < e_ref.mean() < 0.9
     # (d) projection through the head scramble + BN + scatter + shortcut, on the kernel's own E
     Z = e.reshape(B_, nH, Tq, N1, 32).permute(2, 0, 3, 1, 4).reshape(M, Cc).double()
-    Y = ((Z @ _weff(plin.Wp).t()) + biasp.double()) * ap.double() + bp.double()
+    Y = ((Z @ _weff(plin.digits).t()) + biasp.double()) * ap.double() + bp.double()
     ref = x0.reshape(x_rows, Cc).double().clone()
     ref[rm[ok]] += Y[ok]
     err = (xg.cpu().reshape(x_rows, Cc).double() - ref).abs().max().item()
@@ -225,9 +228,9 @@ def test_wide_block_through_the_engine_matches_the_general_kernels():
     Ch = 4 * Cc
     p = _np("lif")
     plin = _L(Wp, ap, bp, biasp)
-    Wqk = hip.split_weight(torch.cat([Wq, Wk], 0).to(DEV).contiguous(), 2)
-    qk = {"Wp": Wqk, "alpha": torch.cat([aq, ak]).to(DEV), "beta": torch.cat([bq, bk]).to(DEV),
-          "add": torch.cat([torch.zeros_like(pe), pe], -1).to(DEV).contiguous()}
+    wcat = torch.cat([Wq, Wk], 0).to(DEV).contiguous()
+    qk = {"Wp": hip.split_weight(wcat, 2), "digits": hip.split_weight_i8x3(wcat), "alpha": torch.cat([aq, ak]).to(DEV),
+          "beta": torch.cat([bq, bk]).to(DEV), "add": torch.cat([torch.zeros_like(pe), pe], -1).to(DEV).contiguous()}
     fc1 = _L(rnd((Ch, Cc), 861, -0.15, 0.15), rnd((Ch,), 863, 0.5, 1.5), rnd((Ch,), 864, -0.2, 0.2))
     fc2 = _L(rnd((Cc, Ch), 862, -0.05, 0.05), rnd((Cc,), 865, 0.5, 1.5), rnd((Cc,), 866, -0.2, 0.2))
     rowmap, B_ = hip.window_slice_map(B, D, H, W, window, shift, DEV)

@@ -1,0 +1,35 @@
+#!/usr/bin/env bash
+# diagnostic build of the wide-stage kernels (csrc/ms_wide.hip) with in-kernel cycle stamps: where does a workgroup's time go
+# (prologue / main loop / fp32 epilogue / neuron epilogue + stores), and how do the workgroups of a launch spread in time?
+# The diagnostic library lives beside, not over, the product one.   usage (GPU box): tools/stamp_wide.sh [B D H W C]
+set -e
+cd "$(dirname "$0")/.."
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-slp-vectorize -Wno-pass-failed -DSDF_STAMP ${SDF_EXTRA_FLAGS:-} -c sdformerflow_amd/csrc/ms_wide.hip -o /tmp/wide_stamp.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libsdf_stamp_wide.so /tmp/wide_stamp.o $(ls sdformerflow_amd/csrc/obj/*.o | grep -v ms_wide)
+SDF_HIP_LIB=/tmp/libsdf_stamp_wide.so python3 - "$@" <<'PY'
+import ctypes, sys, os, torch
+import numpy as np
+sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+from sdformerflow_amd import hip
+import wide_one
+a = [int(v) for v in sys.argv[1:6]] if len(sys.argv) >= 6 else [1, 10, 18, 24, 384]
+run = wide_one.block(*a)
+for _ in range(20):
+    run()
+torch.cuda.synchronize()
+b = (ctypes.c_ulonglong * 32)()
+c = (ctypes.c_ulonglong * (4 * 2048))()
+hip.lib().sdf_debug_read_stamps_wide(b, c)
+print("shape", a)
+for kind, name in ((0, "front"), (3, "proj+SN1"), (1, "fc1"), (2, "fc2")):
+    o = b[8 * kind:8 * kind + 8]
+    clk = o[4] / max(o[5], 1) * 100e6 / 1e9
+    g = int(o[6]) & 0xFFFFFFFF
+    lp = (int(o[6]) >> 32, int(o[7]) & 0xFFFFFFFF, int(o[7]) >> 32)
+    arr = np.array(c[kind * 2048:kind * 2048 + 2 * min(g, 1024)], dtype=np.int64).reshape(-1, 2)
+    arr = arr[arr[:, 1] > 0]
+    base = arr[:, 0].min()
+    print(f"{name:9s} grid {g:4d}: prologue {o[0]:6d}  main loop {o[1]:6d}  fp32 epilogue {o[2]:6d}  neuron + stores {o[3]:6d}  total {o[4]:6d} cycles = {o[5] / 100:.2f} us at {clk:.2f} GHz [loop: commit + requests {lp[0]}  MFMAs {lp[1]}  barrier {lp[2]}]"
+          f" | launch: first start -> last end {(arr[:, 1].max() - base) / 100:.2f} us, starts spread {(arr[:, 0].max() - base) / 100:.2f} us, mean life {(arr[:, 1] - arr[:, 0]).mean() / 100:.2f} us, max life {(arr[:, 1] - arr[:, 0]).max() / 100:.2f} us")
+PY
