@@ -233,7 +233,8 @@ typedef struct SdfSpikeGemmDesc {
 /* Weight-format helper for the 3x3 `layer.Conv2d` weights of MS_ResBlock / SEWResBlock (reference Spiking_modules.py:845-846,
  * 898-899; the reference has no counterpart - it multiplies fp32 weights with fp32 spike tensors in MIOpen / cuDNN).
  * fp32 weights (N, K) -> three int8 digit planes [3][N][K] + per-row power-of-two scales: q = rint(w / s) with
- * s = 2^(ceil(log2 max_k |w[n][k]|) - 22) (22 bits + sign against the row's largest weight), balanced base-256 digits.
+ * s = 2^(e - 23) with 2^e the power of two above max_k |w[n][k]| (23 bits + sign; 22 where the row maximum exceeds 0.996 * 2^e and the
+ * top digit would leave int8), balanced base-256 digits.
  * Spikes are int8 values already: the spike x weight dot product becomes three exact int32 MFMA sums. */
 int sdf_split_weight_i8x3(const float* W, int8_t* planes, float* col_scale, int N, int K, void* stream);
 

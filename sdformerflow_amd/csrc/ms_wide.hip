@@ -14,7 +14,7 @@
 //                         fc2  : x += BN2( s2 W2^T )                                                   (:175-178, :845)
 //
 // Main loop (both kernels): v_mfma_i32_16x16x64_i8.  Spike bytes {0, 1} ARE int8 values and the weights arrive as three int8 digit
-// planes + a power-of-two scale per output channel (sdf_split_weight_i8x3: w = (d2 65536 + d1 256 + d0) s_n, 22 bits + sign
+// planes + a power-of-two scale per output channel (sdf_split_weight_i8x3: w = (d2 65536 + d1 256 + d0) s_n, 22 - 23 bits + sign
 // against the channel's largest weight), so a spike x weight dot product is three exact int32 sums - no expansion of the spikes to
 // 16-bit floats (that cost one vector instruction per byte and MFMA: 2 per MFMA at two column blocks), three MFMAs per 64 k
 // where the fp16 hi / lo planes need four, order-independent and bit-reproducible; the sums meet in fp32 as
@@ -40,6 +40,7 @@
 // (0 = front, 1 = fc1, 2 = fc2, 3 = projection), and every workgroup's life in 100 MHz real time
 __device__ unsigned long long g_wide_stamp[4 * 8];
 __device__ unsigned long long g_wide_census[4 * 2 * 1024];
+__device__ unsigned long long g_wide_loop[8];          // main-loop phases of the LAST launch (middle workgroup, thread 0)
 #define WSTAMP(var) var = __builtin_readcyclecounter()
 #define WSTAMP_DECL unsigned long long ws0 = 0, ws1 = 0, ws2 = 0, ws3 = 0, ws4 = 0; const unsigned long long wr0 = __builtin_amdgcn_s_memrealtime()
 #define WSTAMP_OUT(kind)                                                                                          \
@@ -107,6 +108,14 @@ __host__ __device__ constexpr int w_pieces(int CB) { return 3 * 16 * CB * 8; }  
 __host__ __device__ constexpr int w_steps(int CB) { return (w_pieces(CB) + 255) / 256; }         // per thread (256 threads)
 __host__ __device__ constexpr int w_buf(int CB) { return w_pieces(CB) * 16 + 16; }               // ring buffer bytes (+ a dump slot)
 
+// acc += A x B on the int8 matrix pipe, accumulating IN PLACE in the accumulator registers.  Written as inline assembly with the
+// accumulator tied to an AGPR quad: left to the register allocator (the builtin), the 120 - 240 accumulators of a wave were split
+// between VGPRs and AGPRs and shuttled through a scratch quad around every MFMA (4 copies + wait states each: the matrix pipe ran
+// at half rate, /tmp ISA of round 4).  The same accumulator is not touched again for >= 30 MFMAs (no software wait states needed).
+__device__ __forceinline__ void mfma_i8(i32x4& acc, const i32x4& a, const i32x4& b) {
+  asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
 // the three exact integer sums of an output -> one fp32 number (the two low digits meet as integers: < 2^27 at K = 3072)
 __device__ __forceinline__ float digits_f32(int a0, int a1, int a2) { return __builtin_fmaf((float)a2, 65536.f, (float)(a1 * 256 + a0)); }
 
@@ -169,30 +178,52 @@ __device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __a
       if (g + 2 < NU) load_b(g + 2);
       const int h = g / UPS, r = g - h * UPS, cb = r / 3, dg = r - 3 * cb;
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) acc[dg][rb][cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[h][rb], b[g % 3], acc[dg][rb][cb], 0, 0, 0);
+      for (int rb = 0; rb < RB; ++rb) mfma_i8(acc[dg][rb][cb], a[h][rb], b[g % 3]);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+#ifdef SDF_STAMP
+  unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, t_commit = 0, t_mfma = 0, t_copy = 0, t_bar = 0, p0, p1, p2, p3, first = 0;
+  WSTAMP(p0);
+#endif
   wreq(0);
   areq(aCur, 0);
+  WSTAMP(p1);
   w_commit(0);
+  WSTAMP(p2);
   wreq(1);
   areq(aNxt, 1);
   extra_requests();                                                   // (the caller's own loads: behind the first two chunks in the queue)
   __syncthreads();
+  WSTAMP(p3);
 #pragma unroll 1
   for (int c = 0; c < nchunks; ++c) {
     const int cur = c & 1;
+    WSTAMP(m0);
     w_commit(cur ^ 1);                                                // chunk c + 1 (zeros behind the last one) into the other buffer
     wreq(c + 2);
+    WSTAMP(m1);
     compute(aCur, cur);                                               // (a wave without rows multiplies zeros: no branch around the
+    WSTAMP(m2);
 #pragma unroll                                                        //  accumulators, which would cost a register copy of each per chunk)
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) aCur[h][rb] = aNxt[h][rb];
     areq(aNxt, c + 2);
+    WSTAMP(m3);
     __syncthreads();
+    WSTAMP(m4);
+#ifdef SDF_STAMP
+    if (c == 0) first = m4 - m0;
+    else { t_commit += m1 - m0; t_mfma += m2 - m1; t_copy += m3 - m2; t_bar += m4 - m3; }
+#endif
   }
+#ifdef SDF_STAMP
+  if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) {
+    g_wide_loop[0] = t_commit; g_wide_loop[1] = t_mfma; g_wide_loop[2] = t_copy; g_wide_loop[3] = t_bar; g_wide_loop[4] = nchunks;
+    g_wide_loop[5] = ((p1 - p0) << 32) | (p2 - p1); g_wide_loop[6] = p3 - p2; g_wide_loop[7] = first;
+  }
+#endif
 }
 
 // this thread's weight pieces of a 128-deep chunk: piece = (digit plane p, column col of the group, k-piece kp); 256 threads take
@@ -778,7 +809,8 @@ int launch_ms_wide_proj(const SdfQkAttnDesc* d, const uint8_t* e, hipStream_t s)
 #ifdef SDF_STAMP
 extern "C" int sdf_debug_read_stamps_wide(unsigned long long* host32, unsigned long long* census) {
   (void)hipMemcpyFromSymbol(census, HIP_SYMBOL(g_wide_census), sizeof(g_wide_census));
-  return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(g_wide_stamp), sizeof(g_wide_stamp));
+  (void)hipMemcpyFromSymbol(host32, HIP_SYMBOL(g_wide_stamp), sizeof(g_wide_stamp));
+  return (int)hipMemcpyFromSymbol(host32 + 32, HIP_SYMBOL(g_wide_loop), sizeof(g_wide_loop));
 }
 #endif
 

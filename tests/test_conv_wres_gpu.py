@@ -179,7 +179,7 @@ def test_i8x3_digit_planes_reconstruct_the_weight():
     planes = hip.split_weight_i8x3(w.to(DEV))
     d = planes.cpu().to(torch.float64)
     sc = planes.sdf_col_scale.cpu().to(torch.float64)
-    assert planes.dtype == torch.int8 and d[2].abs().max() <= 64
+    assert planes.dtype == torch.int8 and d[2].abs().max() <= 127       # (23 bits against 2^ceil(log2 max) where the digits hold them)
     rec = (d[2] * 65536 + d[1] * 256 + d[0]) * sc[:, None]
     err = (rec - w.double()).abs().max(1).values
     assert (err <= w.double().abs().max(1).values * 2.0 ** -22 + 1e-300).all()

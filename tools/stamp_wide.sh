@@ -18,18 +18,22 @@ run = wide_one.block(*a)
 for _ in range(20):
     run()
 torch.cuda.synchronize()
-b = (ctypes.c_ulonglong * 32)()
+b = (ctypes.c_ulonglong * 40)()
 c = (ctypes.c_ulonglong * (4 * 2048))()
 hip.lib().sdf_debug_read_stamps_wide(b, c)
 print("shape", a)
+lp = b[32:40]
 for kind, name in ((0, "front"), (3, "proj+SN1"), (1, "fc1"), (2, "fc2")):
     o = b[8 * kind:8 * kind + 8]
     clk = o[4] / max(o[5], 1) * 100e6 / 1e9
-    g = int(o[6]) & 0xFFFFFFFF
-    lp = (int(o[6]) >> 32, int(o[7]) & 0xFFFFFFFF, int(o[7]) >> 32)
+    g = int(o[6])
     arr = np.array(c[kind * 2048:kind * 2048 + 2 * min(g, 1024)], dtype=np.int64).reshape(-1, 2)
     arr = arr[arr[:, 1] > 0]
     base = arr[:, 0].min()
-    print(f"{name:9s} grid {g:4d}: prologue {o[0]:6d}  main loop {o[1]:6d}  fp32 epilogue {o[2]:6d}  neuron + stores {o[3]:6d}  total {o[4]:6d} cycles = {o[5] / 100:.2f} us at {clk:.2f} GHz [loop: commit + requests {lp[0]}  MFMAs {lp[1]}  barrier {lp[2]}]"
+    print(f"{name:9s} grid {g:4d}: prologue {o[0]:6d}  main loop {o[1]:6d}  fp32 epilogue {o[2]:6d}  neuron + stores {o[3]:6d}  total {o[4]:6d} cycles = {o[5] / 100:.2f} us at {clk:.2f} GHz"
           f" | launch: first start -> last end {(arr[:, 1].max() - base) / 100:.2f} us, starts spread {(arr[:, 0].max() - base) / 100:.2f} us, mean life {(arr[:, 1] - arr[:, 0]).mean() / 100:.2f} us, max life {(arr[:, 1] - arr[:, 0]).max() / 100:.2f} us")
+print(f"main loop of the last launch (fc2), thread 0 of the middle workgroup, {lp[4]} chunks: weight commit + request {lp[0]}  MFMA chunk {lp[1]}  "
+      f"operand copy + request {lp[2]}  barrier {lp[3]} cycles over chunks 1..; fill: issue {lp[5] >> 32}  first weights landed + committed {lp[5] & 0xFFFFFFFF}  "
+      f"second requests + barrier {lp[6]}  chunk 0 whole {lp[7]}")
 PY
+
