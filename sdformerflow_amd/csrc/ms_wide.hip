@@ -132,14 +132,14 @@ __device__ __forceinline__ float digits_f32(int a0, int a1, int a2) { return __b
 // Weights: one barrier per chunk; chunk c + 1 is committed to the other ring buffer at the top of chunk c's MFMAs and chunk c + 2
 // requested.  The loop body is straight-line (requests beyond the last chunk read zeros through INV offsets, no branches): the
 // compiler's vmcnt bookkeeping stays exact, so the wait for what is committed next leaves the following chunk's loads in flight.
-template <int RB, int CB, int WIT, class Extra>
-__device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __amdgpu_buffer_rsrc_t A_rs, const uint32_t (&a_base)[RB],
-                                              uint32_t a_step, int nchunks, uint8_t* Wlds, const __amdgpu_buffer_rsrc_t W0_rs,
+template <int RB, int CB, int WIT, class PrepA, class Extra>
+__device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __amdgpu_buffer_rsrc_t A_rs, uint32_t (&a_base)[RB],
+                                              const uint32_t a_step, int nchunks, uint8_t* Wlds, const __amdgpu_buffer_rsrc_t W0_rs,
                                               const __amdgpu_buffer_rsrc_t W1_rs, const uint32_t (&w_goff)[WIT], const uint32_t (&w_lds)[WIT],
-                                              int lane, Extra extra_requests) {
+                                              int lane, PrepA prepare_a, Extra extra_requests) {
   constexpr int BN = 16 * CB, WBUF = w_buf(CB);
   u32x4 wreg[WIT];
-  i32x4 aCur[2][RB], aNxt[2][RB];
+  i32x4 aX[2][RB], aY[2][RB];
   auto wreq = [&](int ch) __attribute__((always_inline)) {
     const bool in = ch < nchunks;
 #pragma unroll
@@ -182,48 +182,46 @@ __device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __a
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-#ifdef SDF_STAMP
-  unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, t_commit = 0, t_mfma = 0, t_copy = 0, t_bar = 0, p0, p1, p2, p3, first = 0;
-  WSTAMP(p0);
-#endif
-  wreq(0);
-  areq(aCur, 0);
-  WSTAMP(p1);
-  w_commit(0);
-  WSTAMP(p2);
-  wreq(1);
-  areq(aNxt, 1);
+  // One chunk per trip (a two-chunk body with the spike registers alternating by name made the register allocator copy every
+  // accumulator once per chunk at the join; the 40 register moves of the rolled form are cheaper).  Chunk 0 is peeled so that the
+  // first TWO weight chunks are requested back to back at the top (second register set): a launch starts with cold caches and
+  // address translations, and one cold latency is paid instead of two.
+  u32x4 wreg2[WIT];
+  wreq(0);                                                            // (first in the queue: the first wait below covers nothing else)
+#pragma unroll
+  for (int i = 0; i < WIT; ++i)
+    wreg2[i] = __builtin_amdgcn_raw_buffer_load_b128((i & 1) ? W1_rs : W0_rs, 1 < nchunks ? w_goff[i] : INV, (uint32_t)KCH, 0);
+  prepare_a();                                                        // the caller's row addressing: may load (projection: the inverse map)
+  areq(aX, 0);
+  areq(aY, 1);
   extra_requests();                                                   // (the caller's own loads: behind the first two chunks in the queue)
+  w_commit(0);
   __syncthreads();
-  WSTAMP(p3);
-#pragma unroll 1
-  for (int c = 0; c < nchunks; ++c) {
-    const int cur = c & 1;
-    WSTAMP(m0);
-    w_commit(cur ^ 1);                                                // chunk c + 1 (zeros behind the last one) into the other buffer
-    wreq(c + 2);
-    WSTAMP(m1);
-    compute(aCur, cur);                                               // (a wave without rows multiplies zeros: no branch around the
-    WSTAMP(m2);
-#pragma unroll                                                        //  accumulators, which would cost a register copy of each per chunk)
+  {                                                                   // chunk 0
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) *reinterpret_cast<u32x4*>(Wlds + WBUF + w_lds[i]) = wreg2[i];
+    wreq(2);
+    compute(aX, 0);
+#pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) aCur[h][rb] = aNxt[h][rb];
-    areq(aNxt, c + 2);
-    WSTAMP(m3);
+      for (int rb = 0; rb < RB; ++rb) aX[h][rb] = aY[h][rb];
+    areq(aY, 2);
     __syncthreads();
-    WSTAMP(m4);
-#ifdef SDF_STAMP
-    if (c == 0) first = m4 - m0;
-    else { t_commit += m1 - m0; t_mfma += m2 - m1; t_copy += m3 - m2; t_bar += m4 - m3; }
-#endif
   }
-#ifdef SDF_STAMP
-  if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) {
-    g_wide_loop[0] = t_commit; g_wide_loop[1] = t_mfma; g_wide_loop[2] = t_copy; g_wide_loop[3] = t_bar; g_wide_loop[4] = nchunks;
-    g_wide_loop[5] = ((p1 - p0) << 32) | (p2 - p1); g_wide_loop[6] = p3 - p2; g_wide_loop[7] = first;
+#pragma unroll 1
+  for (int c = 1; c < nchunks; ++c) {
+    const int cur = c & 1;
+    w_commit(cur ^ 1);                                                // chunk c + 1 (zeros behind the last one) into the other buffer
+    wreq(c + 2);
+    compute(aX, cur);                                                 // (a wave without rows multiplies zeros: no branch around the accumulators)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) aX[h][rb] = aY[h][rb];
+    areq(aY, c + 2);
+    __syncthreads();
   }
-#endif
 }
 
 // this thread's weight pieces of a 128-deep chunk: piece = (digit plane p, column col of the group, k-piece kp); 256 threads take
@@ -302,16 +300,9 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
     return n0 + col < N ? (uint32_t)((p * N + n0 + col) * K) : INV;
   });
   const int c = lane & 15, q = lane >> 4;
-  float al[CB], be[CB], bs[CB], cs[CB];
+  float al[CB], be[CB], bs[CB], cs[CB];                   // BN / bias / digit scale of this lane's columns: requested in pass 0, behind the operands
 #pragma unroll
-  for (int cb = 0; cb < CB; ++cb) {
-    const int n = n0 + 16 * cb + c;
-    const int nc = n < N ? n : 0;
-    al[cb] = P.alpha ? P.alpha[nc] : 1.f;
-    be[cb] = P.alpha ? P.beta[nc] : 0.f;
-    bs[cb] = P.bias ? P.bias[nc] : 0.f;
-    cs[cb] = P.cscale[nc];
-  }
+  for (int cb = 0; cb < CB; ++cb) al[cb] = be[cb] = bs[cb] = cs[cb] = 0.f;
 
 #pragma unroll 1
   for (int pass = 0; pass < P.passes; ++pass) {
@@ -319,51 +310,61 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
     if (rg >= P.nrg) break;                                // (uniform over the workgroup)
     const int unit = rg * NW + wave;
     const bool active = unit < P.nunits;
-    // activation row (or -1) of every tile row of this wave
-    for (int r = lane; r < ROWS; r += 64) {
-      const int rb = r >> 4, i = r & 15, qq = i >> 2, slot = 4 * rb + (i & 3);
-      const int pp = slot / T, t = slot - pp * T;
-      const int64_t pos = (int64_t)unit * PPW + qq * PPG + pp;
-      int32_t g = -1;
-      if (active && pos < P.P) {
-        const int64_t b = pos / HW, hw = pos - b * HW;
-        g = (int32_t)((b * T + t) * HW + hw);
-      }
-      rowtab[wave * ROWS + r] = g;
-    }
-    asm volatile("" ::: "memory");                         // (same-wave LDS operations execute in order: no wait between the table's writes and reads)
     uint32_t a_base[RB];
-    uint32_t a_step = 64;
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-      const int32_t g = rowtab[wave * ROWS + 16 * rb + l16];
-      a_base[rb] = INV;
-      if (P.a_tiled) {
-        if (active) a_base[rb] = (((uint32_t)unit * (uint32_t)(K >> 4) + (uint32_t)lq) * ROWS + 16 * rb + l16) * 16u;
-      } else if (g >= 0) {
-        a_base[rb] = P.zsrc ? (uint32_t)P.zsrc[g] + (uint32_t)(lq >> 1) * P.zg_G + 16u * (lq & 1) : (uint32_t)g * (uint32_t)K + 16u * lq;
-      }
-    }
-    if (P.a_tiled) a_step = 4 * ROWS * 16;
-    else if (P.zsrc) a_step = 2 * P.zg_G;
-
-    // the shortcut values of this lane's outputs are requested behind the first operand chunks and arrive under the main loop
+    const uint32_t a_step = __builtin_amdgcn_readfirstlane(P.a_tiled ? 4u * ROWS * 16u : (P.zsrc ? 2u * P.zg_G : 64u));
     uint32_t xo[(EPI & 2) ? SLOTS : 1];
     float res[(EPI & 2) ? CB : 1][(EPI & 2) ? SLOTS : 1];
-    if constexpr ((EPI & 2) != 0) {
-#pragma unroll
-      for (int s = 0; s < SLOTS; ++s) {
-        const int32_t g = rowtab[wave * ROWS + 16 * (s >> 2) + 4 * q + (s & 3)];
-        xo[s] = (g >= 0 && n0 + c < N) ? ((uint32_t)g * (uint32_t)P.ldo + (uint32_t)(n0 + c)) * 4u : INV;
+    // row addressing of this wave's tile (runs behind the first weight request of the main loop)
+    auto prepare_a = [&]() __attribute__((always_inline)) {
+      // activation row (or -1) of every tile row of this wave
+      for (int r = lane; r < ROWS; r += 64) {
+        const int rb = r >> 4, i = r & 15, qq = i >> 2, slot = 4 * rb + (i & 3);
+        const int pp = slot / T, t = slot - pp * T;
+        const uint32_t pos = (uint32_t)unit * PPW + qq * PPG + pp;     // (positions and rows fit 31 bits: the host checks)
+        int32_t g = -1;
+        if (active && pos < (uint32_t)P.P) {
+          const uint32_t b = pos / (uint32_t)HW, hw = pos - b * (uint32_t)HW;
+          g = (int32_t)((b * T + t) * (uint32_t)HW + hw);
+        }
+        rowtab[wave * ROWS + r] = g;
       }
-    }
-    auto resid_requests = [&]() __attribute__((always_inline)) {
+      asm volatile("" ::: "memory");                       // (same-wave LDS operations execute in order: no wait between the table's writes and reads)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const int32_t g = rowtab[wave * ROWS + 16 * rb + l16];
+        a_base[rb] = INV;
+        if (P.a_tiled) {
+          if (active) a_base[rb] = (((uint32_t)unit * (uint32_t)(K >> 4) + (uint32_t)lq) * ROWS + 16 * rb + l16) * 16u;
+        } else if (g >= 0) {
+          a_base[rb] = P.zsrc ? (uint32_t)P.zsrc[g] + (uint32_t)(lq >> 1) * P.zg_G + 16u * (lq & 1) : (uint32_t)g * (uint32_t)K + 16u * lq;
+        }
+      }
+    };
+    // the shortcut values of this lane's outputs (and, once, its column parameters) are requested behind the first operand chunks
+    // and arrive under the main loop
+    auto late_requests = [&]() __attribute__((always_inline)) {
       if constexpr ((EPI & 2) != 0) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+          const int32_t g = rowtab[wave * ROWS + 16 * (s >> 2) + 4 * q + (s & 3)];
+          xo[s] = (g >= 0 && n0 + c < N) ? ((uint32_t)g * (uint32_t)P.ldo + (uint32_t)(n0 + c)) * 4u : INV;
+        }
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
           for (int s = 0; s < SLOTS; ++s)
             res[cb][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rs, (n0 + 16 * cb + c < N) ? xo[s] : INV, 64u * cb, 0));
+      }
+      if (pass == 0) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+          const int n = n0 + 16 * cb + c;
+          const int nc = n < N ? n : 0;
+          al[cb] = P.alpha ? P.alpha[nc] : 1.f;
+          be[cb] = P.alpha ? P.beta[nc] : 0.f;
+          bs[cb] = P.bias ? P.bias[nc] : 0.f;
+          cs[cb] = P.cscale[nc];
+        }
       }
     };
 
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) acc[dg][rb][cb] = i32x4{0, 0, 0, 0};
     WSTAMP(ws1);
-    wide_mainloop<RB, CB, WIT>(acc, A_rs, a_base, a_step, K / KCH, smem, W_rs, W_rs, w_goff, w_lds, lane, resid_requests);
+    wide_mainloop<RB, CB, WIT>(acc, A_rs, a_base, a_step, K / KCH, smem, W_rs, W_rs, w_goff, w_lds, lane, prepare_a, late_requests);
     WSTAMP(ws2);
 
     // ---------------- epilogue (an inactive wave has no valid row: its stores are dropped) ----------------
@@ -504,39 +505,41 @@ __global__ __launch_bounds__(256, 1) void wide_front_kernel(WideFrontParams P) {
   wide_pieces<CB>(w_goff, w_lds, tid, [&](int p, int col, int i) -> uint32_t {
     return (uint32_t)(p * ((i & 1) ? P.wk_plane : P.wq_plane) + (int64_t)(hd * 32 + (col & 31)) * C);
   });
+  // BN / digit scales of this lane's columns and the positional term of k (pe[(t * N1 + n) * pe_ld + channel], n = token % N1):
+  // requested behind the first operand chunks, they arrive under the main loop
+  const int c = lane & 15, q = lane >> 4;
+  float qa[2], qb[2], ka[2], kb[2], qc[2], kc[2];
+  float pev[RB][2][2][2];                                 // [rb][m][t][cb]
+  auto late_requests = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int ch = hd * 32 + 16 * cb + c;
+      qa[cb] = P.q_al ? P.q_al[ch] : 1.f; qb[cb] = P.q_al ? P.q_be[ch] : 0.f;
+      ka[cb] = P.k_al ? P.k_al[ch] : 1.f; kb[cb] = P.k_al ? P.k_be[ch] : 0.f;
+      qc[cb] = P.q_cs[ch]; kc[cb] = P.k_cs[ch];
+    }
+    const int nbase = (int)(tok0 % P.N1);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        int n = nbase + 8 * rb + 2 * q + m;
+        n = n >= P.N1 ? n - P.N1 : n;
+        n = n >= P.N1 ? n - P.N1 : n;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+            pev[rb][m][t][cb] = P.pe ? P.pe[((int64_t)t * P.N1 + n) * P.pe_ld + hd * 32 + 16 * cb + c] : 0.f;
+      }
+  };
   WSTAMP(ws1);
-  wide_mainloop<RB, CB, WIT>(acc, A_rs, a_base, 64u, C / KCH, smem, Wq_rs, Wk_rs, w_goff, w_lds, lane, [] {});
+  wide_mainloop<RB, CB, WIT>(acc, A_rs, a_base, 64u, C / KCH, smem, Wq_rs, Wk_rs, w_goff, w_lds, lane, [] {}, late_requests);
   WSTAMP(ws2);
   if (!active) return;                                    // (the main loop ends with a barrier: the per-wave byte tiles may alias the weight ring)
 
   // ---------------- epilogue ----------------
-  int lnl = lane;
-  asm volatile("" : "+v"(lnl));
-  const int c = lnl & 15, q = lnl >> 4;
-  float qa[2], qb[2], ka[2], kb[2], qc[2], kc[2];
-#pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
-    const int ch = hd * 32 + 16 * cb + c;
-    qa[cb] = P.q_al ? P.q_al[ch] : 1.f; qb[cb] = P.q_al ? P.q_be[ch] : 0.f;
-    ka[cb] = P.k_al ? P.k_al[ch] : 1.f; kb[cb] = P.k_al ? P.k_be[ch] : 0.f;
-    qc[cb] = P.q_cs[ch]; kc[cb] = P.k_cs[ch];
-  }
-  // positional term of k: pe[(t * N1 + n) * pe_ld + channel], n = token % N1
-  const int nbase = (int)(tok0 % P.N1);
-  float pev[RB][2][2][2];                                 // [rb][m][t][cb]
-#pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      int n = nbase + 8 * rb + 2 * q + m;
-      n = n >= P.N1 ? n - P.N1 : n;
-      n = n >= P.N1 ? n - P.N1 : n;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-          pev[rb][m][t][cb] = P.pe ? P.pe[((int64_t)t * P.N1 + n) * P.pe_ld + hd * 32 + 16 * cb + c] : 0.f;
-    }
+  const int lnl = lane;
   uint8_t* S = smem + wave * STILE;
   uint32_t sel1, sel2;
   quad_sel(lnl, sel1, sel2);
@@ -686,6 +689,14 @@ int launch_pm(WidePmParams& P, int T, int epi, hipStream_t s) {
   return e != hipSuccess ? (int)e : 0;
 }
 
+// These kernels are built for problems that are small in rows (one workgroup per compute unit, a prologue per 320 rows): up to 256
+// 80-row units.  Larger problems (configs[4]: 96 000 rows at stage 2) keep the streaming kernels, which they fill; SDF_WIDE=2 lifts
+// the limit (tests, A/B).
+constexpr int64_t WIDE_MAX_ROWS = 256 * 80;
+bool wide_env_any() {
+  const char* e = getenv("SDF_WIDE");
+  return e && e[0] == '2';
+}
 bool wide_env_off() {
   const char* e = getenv("SDF_WIDE");
   return e && e[0] == '0';
@@ -705,6 +716,7 @@ bool ms_wide_mlp_supports(const SdfMsMlpDesc* d) {
   if (!neuron_ok(d->sn1) || !neuron_ok(d->sn2)) return false;
   const int64_t tokens = (int64_t)d->B * d->D * d->HW;
   if (tokens * d->Ch >= (1LL << 31) || tokens * d->C * 4 >= (1LL << 31)) return false;
+  if (tokens > WIDE_MAX_ROWS && !wide_env_any()) return false;
   if (!d->fc1_alpha || !d->fc1_beta || !d->fc2_alpha || !d->fc2_beta) return false;
   return sdf_aligned(d->x, 16) && sdf_aligned(d->fc1_digits, 16) && sdf_aligned(d->fc2_digits, 16);
 }
@@ -737,6 +749,7 @@ bool ms_wide_attn_supports(const SdfQkAttnDesc* d) {
   if (d->emit_s1 && !neuron_ok(d->emit_sn)) return false;
   const int64_t M = d->B_ * d->N1 * d->Tq;
   if (M * d->C >= (1LL << 31) || d->x_rows * d->C * 4 >= (1LL << 31) || M >= (1LL << 31)) return false;
+  if (d->x_rows > WIDE_MAX_ROWS && !wide_env_any()) return false;
   const bool fused = d->qk_planes != nullptr;
   if (fused ? (!d->qk_digits || !d->qk_cscale) : (!d->q_digits || !d->q_cscale || !d->k_digits || !d->k_cscale)) return false;
   if (!d->p_digits || !d->p_cscale) return false;
@@ -771,9 +784,10 @@ int launch_ms_wide_front(const SdfQkAttnDesc* d, const uint8_t* xs, uint8_t* e, 
   P.sn_q = d->sn_q; P.sn_k = d->sn_k; P.sn2_q = d->sn2_q;
   P.it_q = inv_tau_of(d->sn_q); P.it_k = inv_tau_of(d->sn_k); P.it_2 = inv_tau_of(d->sn2_q);
   P.e = e;
-  // token tiles of 8 RB tokens: 40 (RB = 5) while that leaves >= 600 waves, else 16 (RB = 2)
-  const int64_t t5 = (rows + 39) / 40, t2 = (rows + 15) / 16;
-  const bool big = t5 * d->nH >= 600;
+  // token tiles of 8 RB tokens: 32 (RB = 4: the accumulators leave room for the early positional-term loads) while that leaves
+  // >= 600 waves, else 16 (RB = 2)
+  const int64_t t5 = (rows + 31) / 32, t2 = (rows + 15) / 16;
+  const bool big = t5 * d->nH >= 800;
   const int64_t ntiles = big ? t5 : t2;
   P.ntiles = (int)ntiles;
   P.nrg = (int)((ntiles + 3) / 4);
@@ -786,7 +800,7 @@ int launch_ms_wide_front(const SdfQkAttnDesc* d, const uint8_t* xs, uint8_t* e, 
     if (keep) hipLaunchKernelGGL((wide_front_kernel<RB_, NK_, true>), grid, dim3(256), 0, s, P);          \
     else hipLaunchKernelGGL((wide_front_kernel<RB_, NK_, false>), grid, dim3(256), 0, s, P);              \
   } while (0)
-  if (big) { if (nk == 0) SDF_WF(5, 0); else SDF_WF(5, 2); }
+  if (big) { if (nk == 0) SDF_WF(4, 0); else SDF_WF(4, 2); }
   else { if (nk == 0) SDF_WF(2, 0); else SDF_WF(2, 2); }
 #undef SDF_WF
   hipError_t err = hipGetLastError();
