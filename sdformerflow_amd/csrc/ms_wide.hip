@@ -132,11 +132,14 @@ __device__ __forceinline__ float digits_f32(int a0, int a1, int a2) { return __b
 // Weights: one barrier per chunk; chunk c + 1 is committed to the other ring buffer at the top of chunk c's MFMAs and chunk c + 2
 // requested.  The loop body is straight-line (requests beyond the last chunk read zeros through INV offsets, no branches): the
 // compiler's vmcnt bookkeeping stays exact, so the wait for what is committed next leaves the following chunk's loads in flight.
-template <int RB, int CB, int WIT, class PrepA, class Extra>
-__device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __amdgpu_buffer_rsrc_t A_rs, uint32_t (&a_base)[RB],
-                                              const uint32_t a_step, int nchunks, uint8_t* Wlds, const __amdgpu_buffer_rsrc_t W0_rs,
-                                              const __amdgpu_buffer_rsrc_t W1_rs, const uint32_t (&w_goff)[WIT], const uint32_t (&w_lds)[WIT],
-                                              int lane, PrepA prepare_a, Extra extra_requests) {
+//   a_addr(ch, h, rb, voff, soff) : the caller's address of this lane's piece of chunk ch, step h, row block rb (plain rows:
+//                voff = a_base[rb], soff = (2 ch + h) a_step; the 3x3 convolution folds its tap into both)
+//   c0         : first chunk of this workgroup's K range (split-K), added to the weight addressing only
+template <int RB, int CB, int WIT, class AAddr, class PrepA, class Extra>
+__device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __amdgpu_buffer_rsrc_t A_rs, AAddr a_addr, int nchunks, int c0,
+                                              uint8_t* Wlds, const __amdgpu_buffer_rsrc_t W0_rs, const __amdgpu_buffer_rsrc_t W1_rs,
+                                              const uint32_t (&w_goff)[WIT], const uint32_t (&w_lds)[WIT], int lane, PrepA prepare_a,
+                                              Extra extra_requests) {
   constexpr int BN = 16 * CB, WBUF = w_buf(CB);
   u32x4 wreg[WIT];
   i32x4 aX[2][RB], aY[2][RB];
@@ -144,7 +147,7 @@ __device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __a
     const bool in = ch < nchunks;
 #pragma unroll
     for (int i = 0; i < WIT; ++i)
-      wreg[i] = __builtin_amdgcn_raw_buffer_load_b128((i & 1) ? W1_rs : W0_rs, in ? w_goff[i] : INV, (uint32_t)ch * KCH, 0);
+      wreg[i] = __builtin_amdgcn_raw_buffer_load_b128((i & 1) ? W1_rs : W0_rs, in ? w_goff[i] : INV, (uint32_t)(c0 + ch) * KCH, 0);
   };
   auto w_commit = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -155,8 +158,11 @@ __device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __a
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb)
-        a[h][rb] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(A_rs, in ? a_base[rb] : INV, (uint32_t)(2 * ch + h) * a_step, 0));
+      for (int rb = 0; rb < RB; ++rb) {
+        uint32_t voff, soff;
+        a_addr(ch, h, rb, voff, soff);
+        a[h][rb] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(A_rs, in ? voff : INV, soff, 0));
+      }
   };
   const int l16 = lane & 15, lj = lane >> 4;
   // One chunk of this wave: 2 steps x CB column blocks x 3 digit planes = units of RB MFMAs on one weight fragment.  The fragments
@@ -190,7 +196,7 @@ __device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __a
   wreq(0);                                                            // (first in the queue: the first wait below covers nothing else)
 #pragma unroll
   for (int i = 0; i < WIT; ++i)
-    wreg2[i] = __builtin_amdgcn_raw_buffer_load_b128((i & 1) ? W1_rs : W0_rs, 1 < nchunks ? w_goff[i] : INV, (uint32_t)KCH, 0);
+    wreg2[i] = __builtin_amdgcn_raw_buffer_load_b128((i & 1) ? W1_rs : W0_rs, 1 < nchunks ? w_goff[i] : INV, (uint32_t)(c0 + 1) * KCH, 0);
   prepare_a();                                                        // the caller's row addressing: may load (projection: the inverse map)
   areq(aX, 0);
   areq(aY, 1);
@@ -268,6 +274,13 @@ struct WidePmParams {
   SdfNeuronCfg sn;
   float inv_tau;
   int ncg, nrg, nunits, passes;   // a workgroup walks `passes` row groups (grid = ncg x ceil(nrg / passes))
+  // 3x3 / stride 1 / pad 1 convolution on an NHWC u8 image batch (imgs = B * T, position = pixel): A = the image, K = 9 Cin in
+  // (tap, channel) order; cv_cpt = 128-deep chunks per tap (0 = not a convolution)
+  int cv_H, cv_W, cv_Cin, cv_cpt;
+  // split-K: the workgroup grid has a third factor, K range ks covers chunks [ks * cps, (ks + 1) * cps); EPI 4 stores the raw fp32
+  // sums (digit scale applied) to partial[ks][row][N] for wide_reduce_kernel
+  int ksplit, cps;
+  float* partial;
 };
 
 // EPI: 1 = neuron (spikes out), 2 = fp32 (+ shortcut), 3 = fp32 and the neuron on the updated shortcut stream
@@ -279,6 +292,7 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
   constexpr int LDSB = 2 * WBUF > NW * STILE ? 2 * WBUF : NW * STILE;
   static_assert(SLOTS % T == 0, "T must divide the 20 accumulator slots of a lane");
   static_assert(!(EPI & 2) || CB <= 2, "the fp32 epilogue keeps every shortcut load in flight beside the accumulators: two column blocks");
+  static_assert(EPI >= 1 && EPI <= 4, "epilogue: 1 neuron, 2 fp32, 3 both, 4 split-K partial");
   __shared__ __attribute__((aligned(16))) uint8_t smem[LDSB];
   __shared__ int32_t rowtab[NW * ROWS];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -290,9 +304,13 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
   const int G = gridDim.x;
   if ((G & 7) == 0) item = (item & 7) * (G >> 3) + (item >> 3);
   const int nrgp = (P.nrg + P.passes - 1) / P.passes;
-  if (item >= P.ncg * nrgp) return;
+  const int nks = P.ksplit > 1 ? P.ksplit : 1;
+  if (item >= P.ncg * nrgp * nks) return;
+  const int ks = item / (P.ncg * nrgp);                   // K range slowest: the workgroups of one range share its weight slices in L2
+  item -= ks * P.ncg * nrgp;
   const int rgp = item / P.ncg, cg = item - rgp * P.ncg;
   const int n0 = cg * BN;
+  const int nch = P.ksplit > 1 ? P.cps : P.K / KCH, c0 = P.ksplit > 1 ? ks * P.cps : 0;
   const int K = P.K, N = P.N, HW = P.HW;
   const __amdgpu_buffer_rsrc_t A_rs = make_rsrc(P.A), W_rs = make_rsrc(P.W), x_rs = make_rsrc(P.x), o_rs = make_rsrc(P.out_spike);
   uint32_t w_goff[WIT], w_lds[WIT];
@@ -310,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
     if (rg >= P.nrg) break;                                // (uniform over the workgroup)
     const int unit = rg * NW + wave;
     const bool active = unit < P.nunits;
-    uint32_t a_base[RB];
+    uint32_t a_base[RB], a_mask[RB];                      // (a_mask: convolution - which of the 9 taps of the row's pixel lie inside the image)
     const uint32_t a_step = __builtin_amdgcn_readfirstlane(P.a_tiled ? 4u * ROWS * 16u : (P.zsrc ? 2u * P.zg_G : 64u));
     uint32_t xo[(EPI & 2) ? SLOTS : 1];
     float res[(EPI & 2) ? CB : 1][(EPI & 2) ? SLOTS : 1];
@@ -333,7 +351,20 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
       for (int rb = 0; rb < RB; ++rb) {
         const int32_t g = rowtab[wave * ROWS + 16 * rb + l16];
         a_base[rb] = INV;
-        if (P.a_tiled) {
+        a_mask[rb] = 0;
+        if (P.cv_cpt) {
+          if (g >= 0) {
+            const uint32_t pix = (uint32_t)g % (uint32_t)HW, y = pix / (uint32_t)P.cv_W, xx = pix - y * (uint32_t)P.cv_W;
+            a_base[rb] = (uint32_t)g * (uint32_t)P.cv_Cin + 16u * lq;
+            uint32_t m = 0;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+              const int yy = (int)y + tap / 3 - 1, xw = (int)xx + tap % 3 - 1;
+              if (yy >= 0 && yy < P.cv_H && xw >= 0 && xw < P.cv_W) m |= 1u << tap;
+            }
+            a_mask[rb] = m;
+          }
+        } else if (P.a_tiled) {
           if (active) a_base[rb] = (((uint32_t)unit * (uint32_t)(K >> 4) + (uint32_t)lq) * ROWS + 16 * rb + l16) * 16u;
         } else if (g >= 0) {
           a_base[rb] = P.zsrc ? (uint32_t)P.zsrc[g] + (uint32_t)(lq >> 1) * P.zg_G + 16u * (lq & 1) : (uint32_t)g * (uint32_t)K + 16u * lq;
@@ -376,7 +407,18 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) acc[dg][rb][cb] = i32x4{0, 0, 0, 0};
     WSTAMP(ws1);
-    wide_mainloop<RB, CB, WIT>(acc, A_rs, a_base, a_step, K / KCH, smem, W_rs, W_rs, w_goff, w_lds, lane, prepare_a, late_requests);
+    auto a_addr = [&](int ch, int h, int rb, uint32_t& voff, uint32_t& soff) __attribute__((always_inline)) {
+      if (P.cv_cpt) {                                      // (uniform) chunk -> (tap, channel offset); the tap moves the pixel
+        const int cg_ = c0 + ch, tap = cg_ / P.cv_cpt, cin0 = (cg_ - tap * P.cv_cpt) * KCH + 64 * h;
+        const int toff = ((tap / 3 - 1) * P.cv_W + (tap % 3 - 1)) * P.cv_Cin;
+        voff = ((a_mask[rb] >> tap) & 1u) ? a_base[rb] + (uint32_t)toff : INV;
+        soff = (uint32_t)cin0;
+      } else {
+        voff = a_base[rb];
+        soff = (uint32_t)(2 * ch + h) * a_step;
+      }
+    };
+    wide_mainloop<RB, CB, WIT>(acc, A_rs, a_addr, nch, c0, smem, W_rs, W_rs, w_goff, w_lds, lane, prepare_a, late_requests);
     WSTAMP(ws2);
 
     // ---------------- epilogue (an inactive wave has no valid row: its stores are dropped) ----------------
@@ -393,6 +435,21 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
           val[cb][s] = v;
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), x_rs, (n0 + 16 * cb + c < N) ? xo[s] : INV, 64u * cb, 0);
         }
+    }
+    if constexpr (EPI == 4) {
+      // split-K partial: the raw sums (digit scale applied) of this K range, fp32 [ks][row][N]; BN / shortcut / neuron happen in
+      // wide_reduce_kernel on the k-ordered total
+      const __amdgpu_buffer_rsrc_t p_rs = make_rsrc(P.partial + (int64_t)ks * P.P * T * N);
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        const int32_t g = rowtab[wave * ROWS + 16 * (s >> 2) + 4 * q + (s & 3)];
+        const uint32_t po = (g >= 0 && n0 + c < N) ? ((uint32_t)g * (uint32_t)N + (uint32_t)(n0 + c)) * 4u : INV;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+          const float v = digits_f32(acc[0][s >> 2][cb][s & 3], acc[1][s >> 2][cb][s & 3], acc[2][s >> 2][cb][s & 3]) * cs[cb];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), p_rs, (n0 + 16 * cb + c < N) ? po : INV, 64u * cb, 0);
+        }
+      }
     }
     WSTAMP(ws3);
     if constexpr ((EPI & 1) != 0) {
@@ -534,7 +591,11 @@ __global__ __launch_bounds__(256, 1) void wide_front_kernel(WideFrontParams P) {
       }
   };
   WSTAMP(ws1);
-  wide_mainloop<RB, CB, WIT>(acc, A_rs, a_base, 64u, C / KCH, smem, Wq_rs, Wk_rs, w_goff, w_lds, lane, [] {}, late_requests);
+  auto a_addr = [&](int ch, int h, int rb, uint32_t& voff, uint32_t& soff) __attribute__((always_inline)) {
+    voff = a_base[rb];
+    soff = (uint32_t)(2 * ch + h) * 64u;
+  };
+  wide_mainloop<RB, CB, WIT>(acc, A_rs, a_addr, C / KCH, 0, smem, Wq_rs, Wk_rs, w_goff, w_lds, lane, [] {}, late_requests);
   WSTAMP(ws2);
   if (!active) return;                                    // (the main loop ends with a barrier: the per-wave byte tiles may alias the weight ring)
 
@@ -608,6 +669,70 @@ __global__ __launch_bounds__(256, 1) void wide_front_kernel(WideFrontParams P) {
     }
   }
   WSTAMP_OUT(0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Second pass of the split-K convolution: out = fmaf(sum over the K ranges (in range order: deterministic), alpha, beta) (+ resid),
+// stored as fp32 and / or turned into the spikes of the neuron over T.  A thread owns (position, 4 channels) with all T steps: all
+// its loads are issued before the first use.  rows are (b, t, pixel) as everywhere in this file.
+struct WideReduceParams {
+  const float* partial;      // [ksplit][rows][N]
+  int ksplit, N, HW;
+  int64_t P;                 // positions = B * HW
+  const float *alpha, *beta, *resid;
+  float* out;                // fp32 [rows][N] or null
+  uint8_t* out_spike;        // u8 [rows][N] or null
+  SdfNeuronCfg sn;
+  float inv_tau;
+};
+
+template <int T, int NK>
+__global__ __launch_bounds__(256) void wide_reduce_kernel(WideReduceParams P) {
+  const int n4 = P.N >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P.P * n4) return;
+  const int64_t pos = i / n4;
+  const int c4 = (int)(i - pos * n4);
+  const int64_t b = pos / P.HW, hw = pos - b * P.HW;
+  const int64_t row0 = (b * T) * P.HW + hw, tstride = (int64_t)P.HW * P.N, kstride = P.P * T * P.N;
+  const float* src = P.partial + row0 * P.N + 4 * c4;
+  float4 v[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) v[t] = *reinterpret_cast<const float4*>(src + t * tstride);
+  for (int k = 1; k < P.ksplit; ++k) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const float4 w = *reinterpret_cast<const float4*>(src + k * kstride + t * tstride);
+      v[t].x += w.x; v[t].y += w.y; v[t].z += w.z; v[t].w += w.w;
+    }
+  }
+  float4 al = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (P.alpha) { al = *reinterpret_cast<const float4*>(P.alpha + 4 * c4); be = *reinterpret_cast<const float4*>(P.beta + 4 * c4); }
+  uint32_t pk[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    v[t].x = __builtin_fmaf(v[t].x, al.x, be.x); v[t].y = __builtin_fmaf(v[t].y, al.y, be.y);
+    v[t].z = __builtin_fmaf(v[t].z, al.z, be.z); v[t].w = __builtin_fmaf(v[t].w, al.w, be.w);
+    if (P.resid) {
+      const float4 r = *reinterpret_cast<const float4*>(P.resid + row0 * P.N + 4 * c4 + t * tstride);
+      v[t].x += r.x; v[t].y += r.y; v[t].z += r.z; v[t].w += r.w;
+    }
+    if (P.out) *reinterpret_cast<float4*>(P.out + row0 * P.N + 4 * c4 + t * tstride) = v[t];
+    pk[t] = 0;
+  }
+  if (P.out_spike) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float xs[T], sp[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) xs[t] = e == 0 ? v[t].x : (e == 1 ? v[t].y : (e == 2 ? v[t].z : v[t].w));
+      neuron_T<NK, T>(xs, sp, P.sn, P.inv_tau);
+#pragma unroll
+      for (int t = 0; t < T; ++t) pk[t] |= ((__float_as_uint(sp[t]) >> 29) & 1u) << (8 * e);
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) *reinterpret_cast<uint32_t*>(P.out_spike + row0 * P.N + 4 * c4 + t * tstride) = pk[t];
+  }
 }
 
 __global__ __launch_bounds__(256) void zsrc_kernel(const int32_t* __restrict__ map, int32_t* __restrict__ zsrc, int64_t B_, int Tq, int N1,
@@ -816,6 +941,75 @@ int launch_ms_wide_proj(const SdfQkAttnDesc* d, const uint8_t* e, hipStream_t s)
   P.out_spike = d->emit_s1; P.ldsp = d->C; P.out_tiled = (d->flags & SDF_QK_KEEP_SPIKES) ? 0 : 1;
   P.sn = d->emit_s1 ? d->emit_sn : d->sn_proj; P.inv_tau = inv_tau_of(P.sn);
   return launch_pm(P, d->xD, d->emit_s1 ? 3 : 2, s);
+}
+
+// ---- 3x3 convolution of few rows against many weights (the U-Net bottleneck's res-blocks: 1 080 rows x 768 x 6 912) -----------------
+// K is split over workgroups so that the weight digits (16 MB) leave HBM once, spread over the whole chip; the partial sums meet in
+// wide_reduce_kernel together with BN, the shortcut and the neuron.
+bool wide_conv_supports(const GemmParams& P) {
+  const SdfSpikeGemmDesc& d = P.d;
+  const ConvGeom& cv = P.cv;
+  if (wide_env_off()) return false;
+  if (d.nsplit != SDF_PLANES_I8X3 || !d.col_scale) return false;
+  if (cv.KWc != 3 || d.K != 9 * cv.Cin || cv.Cin % KCH || cv.sy != 1 || cv.sx != 1 || cv.OH != cv.H || cv.OW != cv.W) return false;
+  if (cv.dy[0] != -1 || cv.dy[1] != 0 || cv.dy[2] != 1 || cv.dx[0] != -1 || cv.dx[1] != 0 || cv.dx[2] != 1) return false;
+  if (d.N % 32 || d.out_rowmap || d.bias || d.add || d.zg_nH) return false;
+  const int64_t hw = (int64_t)cv.H * cv.W, imgs = d.M / hw;
+  int T = d.sn_T;
+  if (T == 0) T = imgs % 10 == 0 ? 10 : (imgs % 20 == 0 ? 20 : 0);
+  if (T != 10 && T != 20) return false;
+  if (imgs % T || d.M > WIDE_MAX_ROWS) return false;
+  if (d.sn_T > 0) {
+    if (!neuron_ok({d.sn_kind, d.tau, d.v_th, d.v_reset, d.soft_reset, nullptr, nullptr})) return false;
+    if (d.pos_inner != hw || d.t_stride != hw || d.pos_ostride != (int64_t)T * hw || d.pos_count * T != d.M) return false;   // rows (b, t, pixel)
+  }
+  if (d.M * (int64_t)cv.Cin >= (1LL << 31) || d.M * (int64_t)d.N * 4 >= (1LL << 31) || (int64_t)d.N * d.K * 3 >= (1LL << 31)) return false;
+  // split-K plan: >= 200 workgroups of whole chunks
+  const int nchunks = d.K / KCH, ncg = d.N / 32;
+  int ks = 1;
+  while (ks < nchunks && (ncg * ks < 200 || nchunks % ks)) ++ks;
+  if (nchunks % ks) return false;
+  if (!d.workspace || d.workspace_bytes < (int64_t)ks * d.M * d.N * 4) return false;
+  return sdf_aligned(d.A, 16) && sdf_aligned(d.Wp, 16) && sdf_aligned(d.workspace, 16) && (!d.out || sdf_aligned(d.out, 16)) &&
+         (!d.resid || sdf_aligned(d.resid, 16)) && (!d.alpha || (sdf_aligned(d.alpha, 16) && sdf_aligned(d.beta, 16))) &&
+         (!d.out_spike || sdf_aligned(d.out_spike, 4)) && d.ldo == d.N;
+}
+
+int launch_wide_conv(const GemmParams& G, hipStream_t s) {
+  const SdfSpikeGemmDesc& d = G.d;
+  const ConvGeom& cv = G.cv;
+  const int64_t hw = (int64_t)cv.H * cv.W, imgs = d.M / hw;
+  int T = d.sn_T;
+  if (T == 0) T = imgs % 10 == 0 ? 10 : 20;
+  const int nchunks = d.K / KCH, ncg = d.N / 32;
+  int ks = 1;
+  while (ks < nchunks && (ncg * ks < 200 || nchunks % ks)) ++ks;
+  WidePmParams P = {};
+  P.A = d.A; P.W = reinterpret_cast<const int8_t*>(d.Wp); P.cscale = d.col_scale; P.N = d.N; P.K = d.K; P.HW = (int)hw; P.P = (imgs / T) * hw;
+  P.cv_H = cv.H; P.cv_W = cv.W; P.cv_Cin = cv.Cin; P.cv_cpt = cv.Cin / KCH;
+  P.ksplit = ks;                                            // (one range: the same path, slot 0 of the partial buffer)
+  P.cps = nchunks / ks;
+  P.partial = reinterpret_cast<float*>(d.workspace);
+  const int PPW = 4 * (20 / T);
+  const int64_t units = (P.P + PPW - 1) / PPW;
+  P.nunits = (int)units; P.nrg = (int)((units + 3) / 4); P.ncg = ncg;
+  P.passes = P.nrg;                                         // one workgroup per (column group, K range) walks every row group
+  const int64_t items = (int64_t)ncg * ks;
+  const dim3 grid((unsigned)((items + 7) / 8 * 8));
+  if (T == 10) hipLaunchKernelGGL((wide_pm_kernel<10, 2, 4, 0>), grid, dim3(256), 0, s, P);
+  else hipLaunchKernelGGL((wide_pm_kernel<20, 2, 4, 0>), grid, dim3(256), 0, s, P);
+  WideReduceParams R = {};
+  R.partial = P.partial; R.ksplit = ks; R.N = d.N; R.HW = (int)hw; R.P = P.P;
+  R.alpha = d.alpha; R.beta = d.beta; R.resid = d.resid; R.out = d.out; R.out_spike = d.sn_T > 0 ? d.out_spike : nullptr;
+  R.sn = {d.sn_kind, d.tau, d.v_th, d.v_reset, d.soft_reset, nullptr, nullptr};
+  R.inv_tau = d.sn_T > 0 ? inv_tau_of(R.sn) : 0.f;
+  const int64_t nthr = R.P * (d.N / 4);
+  const dim3 rgrid((unsigned)((nthr + 255) / 256));
+  const int nk = d.sn_T > 0 ? neuron_class(R.sn) : 0;
+  if (T == 10) { if (nk == 0) hipLaunchKernelGGL((wide_reduce_kernel<10, 0>), rgrid, dim3(256), 0, s, R); else hipLaunchKernelGGL((wide_reduce_kernel<10, 2>), rgrid, dim3(256), 0, s, R); }
+  else { if (nk == 0) hipLaunchKernelGGL((wide_reduce_kernel<20, 0>), rgrid, dim3(256), 0, s, R); else hipLaunchKernelGGL((wide_reduce_kernel<20, 2>), rgrid, dim3(256), 0, s, R); }
+  hipError_t e = hipGetLastError();
+  return e != hipSuccess ? (int)e : 0;
 }
 
 }  // namespace sdfmm

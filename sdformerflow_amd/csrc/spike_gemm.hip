@@ -580,6 +580,9 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
   cv.KWc = c->KW;
   cv.kw_mul = c->KW == 1 ? 32 : (c->KW == 2 ? 16 : 11);
   for (int i = 0; i < 3; ++i) { cv.dy[i] = c->dy[i]; cv.dx[i] = c->dx[i]; }
+  // few rows against many weights (the U-Net bottleneck's res-blocks) with digit planes: split-K over the chip on the wide-stage
+  // main loop + one reduce / BN / shortcut / neuron pass (csrc/ms_wide.hip)
+  if (i8x3 && wide_conv_supports(P)) return launch_wide_conv(P, sdf_stream(stream));
   // 3x3 / stride 1 on 96 channels with enough tiles to fill the chip: weights resident in LDS, halo tiles instead of im2col
   const char* ewr = getenv("SDF_CONV_WRES");                  // A/B override: 0 = always the streaming kernels below, 2 = at any size
   if (!(ewr && ewr[0] == '0') && spike_conv_wres_supports(P, i8x3 || (ewr && ewr[0] == '2'))) return launch_spike_conv_wres(P, sdf_stream(stream));

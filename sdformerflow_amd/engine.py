@@ -111,8 +111,8 @@ def _conv_planes(w, nsplit, cin_pad=None):
 def _conv_digits(w, nsplit):
     """int8 digit planes of a 3x3 convolution on 96 input channels (what the weight-resident kernel reads for large launches,
     csrc/spike_conv_wres.hip); None where that kernel has no instantiation or the exact 3-plane / 1-plane modes were asked for."""
-    if nsplit != 2 or w.shape[1] != 96 or tuple(w.shape[2:]) != (3, 3) or w.shape[0] % 32:
-        return None
+    if nsplit != 2 or tuple(w.shape[2:]) != (3, 3) or w.shape[0] % 32 or not (w.shape[1] == 96 or w.shape[1] % 128 == 0):
+        return None                                        # (96 channels: the weight-resident kernel; multiples of 128: the small-M split-K form)
     return hip.pack_conv_weight_i8x3(w.detach().float())
 
 
@@ -292,6 +292,14 @@ class MSFlowEngine:
         a, b = bn if bn is not None else (None, None)
         # large 3x3 / stride-1 launches on 96 channels: int8 digit planes, weights resident in LDS (csrc/spike_conv_wres.hip)
         digits = getattr(Wp, "digits", None)
+        if digits is not None and (sn is None or sn.kind in ("lif", "if")) and hip.wide_conv_applicable(B * D, h, w, Cin, Cout, stride, D):
+            # few rows against many weights (the U-Net bottleneck: 1 080 rows x 768 x 6 912): split-K over the whole chip + one pass
+            # for the sum, BN, shortcut and neuron (csrc/ms_wide.hip)
+            out = None if sn is not None and not membrane else torch.empty((B, D, oh, ow, Cout), dtype=torch.float32, device=s.device)
+            sp = torch.empty((B, D, oh, ow, Cout), dtype=torch.uint8, device=s.device) if sn is not None else None
+            hip.spike_conv2d(s, digits, B * D, h, w, Cin, oh, ow, 3, 3, stride, (-1, 0, 1), (-1, 0, 1), out=out, out_spike=sp, alpha=a, beta=b,
+                             resid=resid if (membrane or sn is None) else None, sn=sn, sn_T=D if sn is not None else 0, pos=(B * oh * ow, oh * ow, D * oh * ow, oh * ow))
+            return sp if sn is not None and not membrane else ((out, sp) if sn is not None else out)
         if digits is not None and B > 1 and not hip.conv_wres_applicable(B * D, h, w, Cin, Cout, stride, 1):
             # too large for the digit kernel's 31-bit operand offsets as one launch (configs[4]: 80 images of 240 x 320 x 96 fp32):
             # batch elements are independent - the largest batch chunk that fits runs per launch, writing into its slice of the outputs
@@ -360,7 +368,8 @@ class MSFlowEngine:
         if s1 is None:
             s1 = self._neuron_bd(m, rb.sn1)
         self._rec(rb.name + "sn1.spiking_neuron.", s1, "BDHWC->TBCHW")
-        fus = self._fusable(B, D, h, w, rb.C, rb.w1)
+        fus = self._fusable(B, D, h, w, rb.C, rb.w1) or \
+            (getattr(rb.w1, "digits", None) is not None and rb.sn2.kind in ("lif", "if") and hip.wide_conv_applicable(B * D, h, w, rb.C, rb.C, 1, D))
         if fus:
             s2 = self._conv3x3(s1, rb.w1, rb.C, bn=rb.bn1, sn=rb.sn2)
         else:       # few rows (U-Net bottleneck): the fp32 epilogue can split K over the chip; neuron as its own launch
@@ -579,9 +588,11 @@ class MSFlowEngine:
         (reference Spiking_STSwinNet.py:161-182).  Returns the per-scale predictions (B,D,h',w',2) fp32; with `out_size` = (H, W)
         the flow maps (time sum + nearest upsampling, reference :289-303) of the levels whose prediction head ran as one launch
         are left in `self._flows` (None where the three-launch form ran: forward() calls sdf_flow_out_fwd for those)."""
-        y = feats[-1]
-        for rb in self.unet_res:
-            y = self._resblock(y, rb)
+        y, s1 = feats[-1], None
+        for i, rb in enumerate(self.unet_res):                # a block's second convolution also emits the next block's first spikes
+            nxt = self.unet_res[i + 1].sn1 if i + 1 < len(self.unet_res) else None
+            r = self._resblock(y, rb, s1=s1, next_sn=nxt)
+            y, s1 = r if nxt is not None else (r, None)
         preds, E = [], len(feats)
         self._flows = [None] * E
         carried = None          # this level's spike image with the [y | prediction] slices already written by the previous level's head

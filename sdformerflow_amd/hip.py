@@ -333,6 +333,14 @@ def conv_wres_applicable(imgs, H, W, Cin, Cout, stride, T=1):
     return tiles * (Cout // 32) >= 512
 
 
+def wide_conv_applicable(imgs, H, W, Cin, Cout, stride, T):
+    """Mirror of the library's dispatch rule for the small-M digit convolution (csrc/ms_wide.hip: wide_conv_supports): 3x3 / stride 1
+    on Cin % 128 == 0 channels, at most 20 480 output rows in (B, T, H, W) order with T in {10, 20}."""
+    if os.environ.get("SDF_WIDE", "") == "0" or stride != 1 or Cin % 128 or Cout % 32:
+        return False
+    return T in (10, 20) and imgs % T == 0 and imgs * H * W <= 256 * 80
+
+
 def pack_conv_weight_i8x3(w):
     """Conv2d weight (Cout, Cin, KH, KW) fp32 -> int8 digit planes (3, Cout, KH*KW*Cin), K in (ky, kx, cin) order."""
     Cout, Cin, KH, KW = w.shape
@@ -935,6 +943,8 @@ def spike_conv2d(x, Wp, imgs, H, W, Cin, OH, OW, KH, KW, stride, dy, dx, out=Non
     g.resid, g.out_rowmap = _ptr(resid, torch.float32), _ptr(out_rowmap, torch.int32)
     if out_rowmap is not None and out is not None:
         g.out_rows = out.numel() // g.ldo
+    if sn is not None or Wp.dtype == torch.int8:
+        _set_ws(g, x)                                             # (split-K scratch: the small-M digit convolution always splits)
     if sn is not None:
         g.out_spike = _ptr(out_spike, torch.uint8)
         g.out = _ptr(out, torch.float32)                          # optional membrane output (pre-activation + resid)
