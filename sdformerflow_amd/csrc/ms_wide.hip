@@ -34,12 +34,13 @@
 // layout (64-byte runs per row and column block; the buffers are L2-resident at these sizes).
 #include "spike_mm.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #ifdef SDF_STAMP
 // diagnostic build only (tools/stamp_wide.sh): cycle accounting of wave 0 of the middle workgroup, per kernel kind
 // (0 = front, 1 = fc1, 2 = fc2, 3 = projection), and every workgroup's life in 100 MHz real time
-__device__ unsigned long long g_wide_stamp[4 * 8];
-__device__ unsigned long long g_wide_census[4 * 2 * 1024];
+__device__ unsigned long long g_wide_stamp[5 * 8];
+__device__ unsigned long long g_wide_census[5 * 2 * 1024];
 __device__ unsigned long long g_wide_loop[8];          // main-loop phases of the LAST launch (middle workgroup, thread 0)
 #define WSTAMP(var) var = __builtin_readcyclecounter()
 #define WSTAMP_DECL unsigned long long ws0 = 0, ws1 = 0, ws2 = 0, ws3 = 0, ws4 = 0; const unsigned long long wr0 = __builtin_amdgcn_s_memrealtime()
@@ -144,7 +145,11 @@ __device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __a
   u32x4 wreg[WIT];
   i32x4 aX[2][RB], aY[2][RB];
   auto wreq = [&](int ch) __attribute__((always_inline)) {
+#ifdef WIDE_X_NOWLOAD
+    const bool in = false;
+#else
     const bool in = ch < nchunks;
+#endif
 #pragma unroll
     for (int i = 0; i < WIT; ++i)
       wreg[i] = __builtin_amdgcn_raw_buffer_load_b128((i & 1) ? W1_rs : W0_rs, in ? w_goff[i] : INV, (uint32_t)(c0 + ch) * KCH, 0);
@@ -154,24 +159,48 @@ __device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __a
     for (int i = 0; i < WIT; ++i) *reinterpret_cast<u32x4*>(Wlds + buf * WBUF + w_lds[i]) = wreg[i];
   };
   auto areq = [&](i32x4 (&a)[2][RB], int ch) __attribute__((always_inline)) {
+#ifdef WIDE_X_NOALOAD
+    const bool in = false;
+#else
     const bool in = ch < nchunks;
+#endif
+    a_addr.chunk(ch);
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
         uint32_t voff, soff;
-        a_addr(ch, h, rb, voff, soff);
+        a_addr.get(h, rb, voff, soff);
         a[h][rb] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(A_rs, in ? voff : INV, soff, 0));
       }
   };
   const int l16 = lane & 15, lj = lane >> 4;
+  auto a_load1 = [&](i32x4& dst, int ch, int h, int rb) __attribute__((always_inline)) {
+#ifdef WIDE_X_NOALOAD
+    const bool in = false;
+#else
+    const bool in = ch < nchunks;
+#endif
+    uint32_t voff, soff;
+    a_addr.get(h, rb, voff, soff);
+    dst = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(A_rs, in ? voff : INV, soff, 0));
+  };
   // One chunk of this wave: 2 steps x CB column blocks x 3 digit planes = units of RB MFMAs on one weight fragment.  The fragments
-  // of units g + 1 and g + 2 are in flight while unit g multiplies (an LDS read takes longer than five MFMAs); the fences keep the
-  // scheduler from pulling every read back in front of its use.
-  auto compute = [&](const i32x4 (&a)[2][RB], int buf) __attribute__((always_inline)) {
-    const uint8_t* wb = Wlds + buf * WBUF;
+  // of units g + 1 and g + 2 are in flight while unit g multiplies (an LDS read takes longer than five MFMAs).  Everything else a
+  // chunk needs rides in the shadow of those MFMAs, a few instructions behind each unit (one wave per SIMD: nothing else would
+  // overlap them - measured in round 4: done before / after the MFMAs, commit + copies + requests cost as much as the MFMAs):
+  //   units 0 .. WIT-1      : one piece of weight chunk c + 1 each goes registers -> the other ring buffer
+  //   unit  WIT             : weight chunk c + 2 is requested
+  //   units UPS .. UPS+RB-1 : step 0's spike registers are dead: each takes over the next chunk's and is re-requested (chunk c + 2)
+  //   behind the last unit  : the same for step 1
+  // The fences pin that order (the scheduler would pull every read in front of its use and push the rest behind the MFMAs).
+  auto chunk = [&](int c, int cur) __attribute__((always_inline)) {
+    const uint8_t* wb = Wlds + cur * WBUF;
+    uint8_t* wn = Wlds + (cur ^ 1) * WBUF;
     constexpr int UPS = CB * 3, NU = 2 * UPS;
+    static_assert(WIT + 1 <= UPS && UPS + RB <= NU, "the chunk's side work must fit its units");
     i32x4 b[3];
+    a_addr.chunk(c + 2);                                              // (every spike request of this chunk is for chunk c + 2)
     auto load_b = [&](int g) __attribute__((always_inline)) {
       const int h = g / UPS, r = g - h * UPS, cb = r / 3, dg = r - 3 * cb, kp = 4 * h + lj;
       b[g % 3] = *reinterpret_cast<const i32x4*>(wb + ((dg * 8 + kp) * BN + ((cb * 16 + l16) ^ kp)) * 16);
@@ -184,48 +213,45 @@ __device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __a
       if (g + 2 < NU) load_b(g + 2);
       const int h = g / UPS, r = g - h * UPS, cb = r / 3, dg = r - 3 * cb;
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) mfma_i8(acc[dg][rb][cb], a[h][rb], b[g % 3]);
+      for (int rb = 0; rb < RB; ++rb) {
+#ifndef WIDE_X_NOMFMA
+        mfma_i8(acc[dg][rb][cb], aX[h][rb], b[g % 3]);
+#else
+        asm volatile("" :: "v"(aX[h][rb]), "v"(b[g % 3]));
+#endif
+      }
+      if (g < WIT) *reinterpret_cast<u32x4*>(wn + w_lds[g]) = wreg[g];
+      if (g == WIT) wreq(c + 2);
+      if (g >= UPS && g < UPS + RB) {
+        aX[0][g - UPS] = aY[0][g - UPS];
+        a_load1(aY[0][g - UPS], c + 2, 0, g - UPS);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      aX[1][rb] = aY[1][rb];
+      a_load1(aY[1][rb], c + 2, 1, rb);
+    }
   };
-  // One chunk per trip (a two-chunk body with the spike registers alternating by name made the register allocator copy every
-  // accumulator once per chunk at the join; the 40 register moves of the rolled form are cheaper).  Chunk 0 is peeled so that the
-  // first TWO weight chunks are requested back to back at the top (second register set): a launch starts with cold caches and
-  // address translations, and one cold latency is paid instead of two.
+  // A launch starts with cold caches and address translations: the first TWO weight chunks and spike chunks are requested back
+  // to back at the top (one cold latency instead of two), the caller's own loads behind them.
   u32x4 wreg2[WIT];
   wreq(0);                                                            // (first in the queue: the first wait below covers nothing else)
 #pragma unroll
   for (int i = 0; i < WIT; ++i)
     wreg2[i] = __builtin_amdgcn_raw_buffer_load_b128((i & 1) ? W1_rs : W0_rs, 1 < nchunks ? w_goff[i] : INV, (uint32_t)(c0 + 1) * KCH, 0);
   prepare_a();                                                        // the caller's row addressing: may load (projection: the inverse map)
-  areq(aX, 0);
-  areq(aY, 1);
-  extra_requests();                                                   // (the caller's own loads: behind the first two chunks in the queue)
-  w_commit(0);
+  extra_requests();                                                   // the caller's own loads (shortcut values, column parameters): AHEAD of the
+  areq(aX, 0);                                                        // spike chunks in the in-order return queue - all of these are cold lines
+  areq(aY, 1);                                                        // another launch wrote, one latency covers them together; behind the
+  w_commit(0);                                                        // second chunk they stalled the third chunk's operands (round 4 stamps)
+#pragma unroll
+  for (int i = 0; i < WIT; ++i) wreg[i] = wreg2[i];
   __syncthreads();
-  {                                                                   // chunk 0
-#pragma unroll
-    for (int i = 0; i < WIT; ++i) *reinterpret_cast<u32x4*>(Wlds + WBUF + w_lds[i]) = wreg2[i];
-    wreq(2);
-    compute(aX, 0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) aX[h][rb] = aY[h][rb];
-    areq(aY, 2);
-    __syncthreads();
-  }
 #pragma unroll 1
-  for (int c = 1; c < nchunks; ++c) {
-    const int cur = c & 1;
-    w_commit(cur ^ 1);                                                // chunk c + 1 (zeros behind the last one) into the other buffer
-    wreq(c + 2);
-    compute(aX, cur);                                                 // (a wave without rows multiplies zeros: no branch around the accumulators)
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) aX[h][rb] = aY[h][rb];
-    areq(aY, c + 2);
+  for (int c = 0; c < nchunks; ++c) {
+    chunk(c, c & 1);                                                  // (a wave without rows multiplies zeros: no branch around the accumulators)
     __syncthreads();
   }
 }
@@ -352,7 +378,7 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
         const int32_t g = rowtab[wave * ROWS + 16 * rb + l16];
         a_base[rb] = INV;
         a_mask[rb] = 0;
-        if (P.cv_cpt) {
+        if (EPI == 4) {
           if (g >= 0) {
             const uint32_t pix = (uint32_t)g % (uint32_t)HW, y = pix / (uint32_t)P.cv_W, xx = pix - y * (uint32_t)P.cv_W;
             a_base[rb] = (uint32_t)g * (uint32_t)P.cv_Cin + 16u * lq;
@@ -407,17 +433,29 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) acc[dg][rb][cb] = i32x4{0, 0, 0, 0};
     WSTAMP(ws1);
-    auto a_addr = [&](int ch, int h, int rb, uint32_t& voff, uint32_t& soff) __attribute__((always_inline)) {
-      if (P.cv_cpt) {                                      // (uniform) chunk -> (tap, channel offset); the tap moves the pixel
-        const int cg_ = c0 + ch, tap = cg_ / P.cv_cpt, cin0 = (cg_ - tap * P.cv_cpt) * KCH + 64 * h;
-        const int toff = ((tap / 3 - 1) * P.cv_W + (tap % 3 - 1)) * P.cv_Cin;
-        voff = ((a_mask[rb] >> tap) & 1u) ? a_base[rb] + (uint32_t)toff : INV;
-        soff = (uint32_t)cin0;
-      } else {
-        voff = a_base[rb];
-        soff = (uint32_t)(2 * ch + h) * a_step;
+    // this lane's piece address of (chunk, step, row block).  The convolution form (EPI 4 only) decodes the chunk once - chunk ->
+    // (tap, channel offset), the tap moves the pixel - in scalar registers; the plain forms carry no trace of it.
+    struct AddrPlain {
+      const uint32_t* base; uint32_t step, ch2;
+      __device__ __forceinline__ void chunk(int ch) { ch2 = 2u * (uint32_t)ch; }
+      __device__ __forceinline__ void get(int h, int rb, uint32_t& voff, uint32_t& soff) const { voff = base[rb]; soff = (ch2 + (uint32_t)h) * step; }
+    };
+    struct AddrConv {
+      const uint32_t* base; const uint32_t* mask; int cpt, W, Cin, c0, tap; uint32_t toff, cin0;
+      __device__ __forceinline__ void chunk(int ch) {
+        const int cg_ = __builtin_amdgcn_readfirstlane(c0 + ch);
+        tap = cg_ / cpt;
+        cin0 = (uint32_t)((cg_ - tap * cpt) * KCH);
+        toff = (uint32_t)(((tap / 3 - 1) * W + (tap % 3 - 1)) * Cin);
+      }
+      __device__ __forceinline__ void get(int h, int rb, uint32_t& voff, uint32_t& soff) const {
+        voff = ((mask[rb] >> tap) & 1u) ? base[rb] + toff : INV;
+        soff = cin0 + 64u * (uint32_t)h;
       }
     };
+    typename std::conditional<EPI == 4, AddrConv, AddrPlain>::type a_addr;
+    if constexpr (EPI == 4) a_addr = AddrConv{a_base, a_mask, P.cv_cpt, P.cv_W, P.cv_Cin, c0, 0, 0u, 0u};
+    else a_addr = AddrPlain{a_base, a_step, 0u};
     wide_mainloop<RB, CB, WIT>(acc, A_rs, a_addr, nch, c0, smem, W_rs, W_rs, w_goff, w_lds, lane, prepare_a, late_requests);
     WSTAMP(ws2);
 
@@ -591,10 +629,11 @@ __global__ __launch_bounds__(256, 1) void wide_front_kernel(WideFrontParams P) {
       }
   };
   WSTAMP(ws1);
-  auto a_addr = [&](int ch, int h, int rb, uint32_t& voff, uint32_t& soff) __attribute__((always_inline)) {
-    voff = a_base[rb];
-    soff = (uint32_t)(2 * ch + h) * 64u;
-  };
+  struct AddrPlain {
+    const uint32_t* base; uint32_t ch2;
+    __device__ __forceinline__ void chunk(int ch) { ch2 = 2u * (uint32_t)ch; }
+    __device__ __forceinline__ void get(int h, int rb, uint32_t& voff, uint32_t& soff) const { voff = base[rb]; soff = (ch2 + (uint32_t)h) * 64u; }
+  } a_addr{a_base, 0u};
   wide_mainloop<RB, CB, WIT>(acc, A_rs, a_addr, C / KCH, 0, smem, Wq_rs, Wk_rs, w_goff, w_lds, lane, [] {}, late_requests);
   WSTAMP(ws2);
   if (!active) return;                                    // (the main loop ends with a barrier: the per-wave byte tiles may alias the weight ring)
@@ -950,6 +989,14 @@ bool wide_conv_supports(const GemmParams& P) {
   const SdfSpikeGemmDesc& d = P.d;
   const ConvGeom& cv = P.cv;
   if (wide_env_off()) return false;
+  // Measured on MI355X (round 4, tools/stamp_wide.sh conv): 50 us + 20 us for the reduce pass on the bottleneck's 1 080 x 768 x 6 912
+  // problem, against 50 + 5 us of the streaming ping-pong kernel with its split-K - no gain (four row passes per workgroup each pay
+  // the pipeline fill; the reduce pass is latency-bound on 81 workgroups), so the engine does not take it: SDF_WIDE_CONV=1 opts in
+  // (tests, A/B).
+  {
+    const char* e = getenv("SDF_WIDE_CONV");
+    if (!(e && e[0] == '1')) return false;
+  }
   if (d.nsplit != SDF_PLANES_I8X3 || !d.col_scale) return false;
   if (cv.KWc != 3 || d.K != 9 * cv.Cin || cv.Cin % KCH || cv.sy != 1 || cv.sx != 1 || cv.OH != cv.H || cv.OW != cv.W) return false;
   if (cv.dy[0] != -1 || cv.dy[1] != 0 || cv.dy[2] != 1 || cv.dx[0] != -1 || cv.dx[1] != 0 || cv.dx[2] != 1) return false;
@@ -1018,7 +1065,7 @@ int launch_wide_conv(const GemmParams& G, hipStream_t s) {
 extern "C" int sdf_debug_read_stamps_wide(unsigned long long* host32, unsigned long long* census) {
   (void)hipMemcpyFromSymbol(census, HIP_SYMBOL(g_wide_census), sizeof(g_wide_census));
   (void)hipMemcpyFromSymbol(host32, HIP_SYMBOL(g_wide_stamp), sizeof(g_wide_stamp));
-  return (int)hipMemcpyFromSymbol(host32 + 32, HIP_SYMBOL(g_wide_loop), sizeof(g_wide_loop));
+  return (int)hipMemcpyFromSymbol(host32 + 40, HIP_SYMBOL(g_wide_loop), sizeof(g_wide_loop));
 }
 #endif
 

@@ -111,8 +111,10 @@ def _conv_planes(w, nsplit, cin_pad=None):
 def _conv_digits(w, nsplit):
     """int8 digit planes of a 3x3 convolution on 96 input channels (what the weight-resident kernel reads for large launches,
     csrc/spike_conv_wres.hip); None where that kernel has no instantiation or the exact 3-plane / 1-plane modes were asked for."""
-    if nsplit != 2 or tuple(w.shape[2:]) != (3, 3) or w.shape[0] % 32 or not (w.shape[1] == 96 or w.shape[1] % 128 == 0):
-        return None                                        # (96 channels: the weight-resident kernel; multiples of 128: the small-M split-K form)
+    import os
+    wide = os.environ.get("SDF_WIDE_CONV", "") == "1" and w.shape[1] % 128 == 0       # (opt-in small-M split-K form, csrc/ms_wide.hip)
+    if nsplit != 2 or tuple(w.shape[2:]) != (3, 3) or w.shape[0] % 32 or not (w.shape[1] == 96 or wide):
+        return None
     return hip.pack_conv_weight_i8x3(w.detach().float())
 
 

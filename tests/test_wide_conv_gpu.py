@@ -17,6 +17,7 @@ from sdformerflow_amd.synthetic import synth_uniform as rnd
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+os.environ["SDF_WIDE_CONV"] = "1"               # the form is opt-in (measured no faster than the streaming kernel + split-K on the shipped shape)
 
 
 def spikes(shape, seed, rate=0.3):

@@ -4,7 +4,7 @@
 # The diagnostic library lives beside, not over, the product one.   usage (GPU box): tools/stamp_wide.sh [B D H W C]
 set -e
 cd "$(dirname "$0")/.."
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-slp-vectorize -Wno-pass-failed -DSDF_STAMP ${SDF_EXTRA_FLAGS:-} -c sdformerflow_amd/csrc/ms_wide.hip -o /tmp/wide_stamp.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-slp-vectorize -Wno-pass-failed -DSDF_STAMP ${SDF_EXTRA_FLAGS:-} -c ${SDF_WIDE_SRC:-sdformerflow_amd/csrc/ms_wide.hip} -o /tmp/wide_stamp.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libsdf_stamp_wide.so /tmp/wide_stamp.o $(ls sdformerflow_amd/csrc/obj/*.o | grep -v ms_wide)
 SDF_HIP_LIB=/tmp/libsdf_stamp_wide.so python3 - "$@" <<'PY'
 import ctypes, sys, os, torch
@@ -13,17 +13,22 @@ sys.path.insert(0, os.getcwd())
 sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
 from sdformerflow_amd import hip
 import wide_one
-a = [int(v) for v in sys.argv[1:6]] if len(sys.argv) >= 6 else [1, 10, 18, 24, 384]
-run = wide_one.block(*a)
+conv = len(sys.argv) > 1 and sys.argv[1] == "conv"
+if conv:                                     # the U-Net bottleneck's 3x3 convolution: stamp_wide.sh conv [B T H W Cin Cout]
+    a = [int(v) for v in sys.argv[2:8]] if len(sys.argv) >= 8 else [1, 10, 9, 12, 768, 768]
+    run = wide_one.conv(*a)
+else:
+    a = [int(v) for v in sys.argv[1:6]] if len(sys.argv) >= 6 else [1, 10, 18, 24, 384]
+    run = wide_one.block(*a)
 for _ in range(20):
     run()
 torch.cuda.synchronize()
-b = (ctypes.c_ulonglong * 40)()
-c = (ctypes.c_ulonglong * (4 * 2048))()
+b = (ctypes.c_ulonglong * 48)()
+c = (ctypes.c_ulonglong * (5 * 2048))()
 hip.lib().sdf_debug_read_stamps_wide(b, c)
 print("shape", a)
-lp = b[32:40]
-for kind, name in ((0, "front"), (3, "proj+SN1"), (1, "fc1"), (2, "fc2")):
+lp = b[40:48]
+for kind, name in (((4, "conv K-split"),) if conv else ((0, "front"), (3, "proj+SN1"), (1, "fc1"), (2, "fc2"))):
     o = b[8 * kind:8 * kind + 8]
     clk = o[4] / max(o[5], 1) * 100e6 / 1e9
     g = int(o[6])

@@ -40,6 +40,22 @@ def block(B, D, H, W, Cc, window=(2, 9, 9), shift=(1, 4, 4)):
     return run
 
 
+def conv(B, T, H, W, Cin, Cout):
+    """The U-Net bottleneck's 3x3 spike convolution with the fused BN + LIF epilogue (small M, digit planes)."""
+    dev = "cuda:0"
+    imgs, hw = B * T, H * W
+    x = (rnd((imgs, H, W, Cin), 21) < -0.4).to(torch.uint8).to(dev)
+    dg = hip.pack_conv_weight_i8x3(rnd((Cout, Cin, 3, 3), 22, -0.05, 0.05).to(dev))
+    al, be = rnd((Cout,), 23, 0.5, 1.5).to(dev), rnd((Cout,), 24, -0.1, 0.3).to(dev)
+    sp = torch.empty((imgs * hw, Cout), dtype=torch.uint8, device=dev)
+    p = hip.NeuronParams("lif", 2.0, 0.1, None)
+
+    def run():
+        hip.spike_conv2d(x, dg, imgs, H, W, Cin, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out_spike=sp, alpha=al, beta=be, sn=p, sn_T=T,
+                         pos=(B * hw, hw, T * hw, hw))
+    return run
+
+
 if __name__ == "__main__":
     a = [int(v) for v in sys.argv[1:6]] if len(sys.argv) >= 6 else [1, 10, 18, 24, 384]
     run = block(*a)
