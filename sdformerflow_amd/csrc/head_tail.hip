@@ -476,7 +476,8 @@ extern "C" int sdf_head_conv_sn_fwd(const SdfHeadConvDesc* d, void* stream) {
     for (int ci = 0; ci < 4; ++ci) P.d.x_sc[ci] = ci;
   }
   // fp32 matrix-pipe kernel: LIF / IF, 32-pixel tiles, 31-bit byte offsets into the voxel
-  static const bool no_mfma = [] { const char* e = getenv("SDF_HEAD_MFMA"); return e && e[0] == '0'; }();
+  const char* e_hm = getenv("SDF_HEAD_MFMA");                        // (read per call)
+  const bool no_mfma = e_hm && e_hm[0] == '0';
   int64_t span = (int64_t)(d->B - 1) * P.d.x_sb + (int64_t)(d->T - 1) * P.d.x_st + (int64_t)(d->H - 1) * P.d.x_sy + (int64_t)(d->W - 1) * P.d.x_sx;
   int64_t scmax = 0;
   for (int ci = 0; ci < d->Cin && ci < 4; ++ci) scmax = P.d.x_sc[ci] > scmax ? P.d.x_sc[ci] : scmax;

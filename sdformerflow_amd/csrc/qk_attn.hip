@@ -109,7 +109,8 @@ extern "C" int sdf_qk_attn_fwd(const SdfQkAttnDesc* d, void* stream) {
   // steps 1 - 3 as one launch where the kernel has an instantiation (SDF_QK_FRONT=0 / SDF_QK_FOUR_LAUNCHES: the A/B reference below)
   bool front = false;
   {
-    static const bool off = [] { const char* e = getenv("SDF_QK_FRONT"); return e && e[0] == '0'; }();
+    const char* e_front = getenv("SDF_QK_FRONT");                    // (read per call, like SDF_MLP_FUSED)
+    const bool off = e_front && e_front[0] == '0';
     if (!off && !(d->flags & SDF_QK_FOUR_LAUNCHES) && sdfmm::qk_front_supports(d)) {
       const int rc0 = sdfmm::launch_qk_front(d, xs, qk, (d->flags & SDF_QK_KEEP_SPIKES) != 0, sdf_stream(stream));
       if (rc0) return rc0;

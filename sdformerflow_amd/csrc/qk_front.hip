@@ -273,7 +273,8 @@ bool qk_front_supports(const SdfQkAttnDesc* d) {
   // chunks on (C >= 288: few pairs, every head's workgroup repeats the pair's SN_proj, a chain of chunk latencies per workgroup)
   // the three pipelined launches are as fast or faster (stage 2: 32 vs 32 us, stage 3: 33 vs 55 us) and stay.  SDF_QK_FRONT_ANY=1
   // lifts the limit (tests).
-  static const bool any = [] { const char* e = getenv("SDF_QK_FRONT_ANY"); return e && e[0] == '1'; }();
+  const char* e_any = getenv("SDF_QK_FRONT_ANY");                     // (read per call: a test may scope it)
+  const bool any = e_any && e_any[0] == '1';
   if (!any && d->C / QF_KC > 2) return false;
   const SdfNeuronCfg* ns[4] = {&d->sn_proj, &d->sn_q, &d->sn_k, &d->sn2_q};
   const int nk = neuron_class(*ns[0]);

@@ -344,9 +344,11 @@ class MSFlowEngine:
 
     @staticmethod
     def _digit_chunk(B, D, h, w, Cin, Cout, stride):
-        """Largest number of batch elements per launch the digit kernel addresses (0: none)."""
+        """Largest number of batch elements per launch the digit kernel addresses, chosen among the DIVISORS of B so that every chunk is
+        the same launch (a ragged last chunk could miss the kernel's "enough tiles" rule and fall to a streaming kernel that has no T = 5 / 20
+        form); 0: none."""
         for bc in range(B - 1, 0, -1):
-            if hip.conv_wres_applicable(bc * D, h, w, Cin, Cout, stride, 1):
+            if B % bc == 0 and hip.conv_wres_applicable(bc * D, h, w, Cin, Cout, stride, 1):
                 return bc
         return 0
 

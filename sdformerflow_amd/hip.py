@@ -98,11 +98,65 @@ class DenseLinearDesc(C.Structure):
 
 
 _lib = None
+_PROF = None            # bench.py's per-call profile: a list of (entry point, note, start event, end event) while profile_calls() is active
+_NOTE = {}
+
+
+class _TimedLib:
+    """The library with every `*_fwd` entry point bracketed by two HIP events on the stream it launches on (profile_calls())."""
+
+    def __init__(self, cdll):
+        self._c = cdll
+
+    def __getattr__(self, name):
+        f = getattr(self._c, name)
+        if not name.endswith("_fwd"):
+            return f
+
+        def timed(*a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            note = dict(_NOTE)
+            _NOTE.clear()
+            e0.record()
+            rc = f(*a)
+            e1.record()
+            _PROF.append((name, note, e0, e1))
+            return rc
+        return timed
+
+
+def _note(**kw):
+    """What the next C-ABI call computes (algorithmic flop / bytes, shape) - kept only while a profile is being taken."""
+    if _PROF is not None:
+        _NOTE.update(kw)
+
+
+class profile_calls:
+    """`with hip.profile_calls() as rec:` - every C-ABI `*_fwd` call inside is timed with HIP events on its own stream; afterwards
+    `rec.rows()` = [(entry point, note dict, microseconds)] in call order (bench.py: `roofline.by_time`)."""
+
+    def __enter__(self):
+        global _PROF
+        lib()
+        _PROF = []
+        return self
+
+    def __exit__(self, *exc):
+        global _PROF
+        torch.cuda.synchronize()
+        self._rows = [(n, note, e0.elapsed_time(e1) * 1e3) for n, note, e0, e1 in _PROF]
+        _PROF = None
+        _NOTE.clear()
+
+    def rows(self):
+        return self._rows
 
 
 def lib():
     """Load the shared library once; fail loudly when it is absent."""
     global _lib
+    if _lib is not None and _PROF is not None:
+        return _TimedLib(_lib)
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise SdfError(f"{LIB_PATH} not built - run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -188,6 +242,7 @@ def neuron_fwd(x, out, T, nb, ni, x_sb, x_st, o_sb, o_st, p: NeuronParams, rowma
                alpha=None, beta=None, Cch=0, inner=1, add=None, add_st=0, add_period=0, v_last=None):
     """sdf_neuron_fwd: see include/sdformerflow_hip.h for the addressing contract."""
     d = _neuron_desc(x, out, T, nb, ni, x_sb, x_st, o_sb, o_st, p, rowmap, rowlen, alpha, beta, Cch, inner, add, add_st, add_period, v_last)
+    _note(bytes=T * nb * ni * (4 + out.element_size()), shape=(T, nb * ni))
     _check(lib().sdf_neuron_fwd(C.byref(d), _stream()), "sdf_neuron_fwd")
     return out
 
@@ -372,6 +427,7 @@ def spike_gemm(A, Wp, out, M, N, K, lda=None, ldo=None, bias=None, alpha=None, b
     if zg is not None:
         d.zg_nH, d.zg_T, d.zg_B, d.zg_N1 = zg
     _set_ws(d, A)
+    _note(flop=2 * int(d.M) * int(d.N) * int(d.K), shape=(int(d.M), int(d.N), int(d.K)))
     _check(lib().sdf_spike_gemm_fwd(C.byref(d), _stream()), "sdf_spike_gemm_fwd")
     return out
 
@@ -389,6 +445,7 @@ def spike_gemm_sn(A, Wp, out_spike, N, K, T, pos_count, pos_inner, pos_ostride, 
     d.psn_w, d.psn_b = _ptr(p.psn_w, torch.float32), _ptr(p.psn_b, torch.float32)
     d.pos_count, d.pos_inner, d.pos_ostride, d.t_stride = pos_count, pos_inner, pos_ostride, t_stride
     d.add, d.add_prows = _ptr(add, torch.float32), add_prows
+    _note(flop=2 * int(d.M) * int(d.N) * int(d.K), shape=(int(d.M), int(d.N), int(d.K)))
     _check(lib().sdf_spike_gemm_fwd(C.byref(d), _stream()), "sdf_spike_gemm_fwd")
     return out_spike
 
@@ -515,6 +572,7 @@ def qk_attn(x, slice_map, B_, Tq, N1, nH, p_lin, sn_proj, sn_q, sn_k, sn2_q, qk=
         _ncfg(d.emit_sn, emit[1])
         if info is not None:
             info["emitted"] = True
+    _note(flop=2 * Tq * B_ * N1 * Cc * 3 * Cc, shape=(Tq * B_ * N1, Cc))
     _check(lib().sdf_qk_attn_fwd(C.byref(d), _stream()), "sdf_qk_attn_fwd")
     if keep_ws is not None:
         keep_ws.append(ws)                  # the call's intermediates (u8 spikes, layout: sdf_qk_attn_workspace_bytes) for the parity tape
@@ -567,6 +625,7 @@ def ms_mlp(x, fc1, fc2, sn1, sn2, keep_ws=None, three_launches=False, ws=None, s
         d.s1_in = ws.data_ptr()
         if lib().sdf_ms_mlp_is_wide(C.byref(d)) != 1:
             raise SdfError("s1_ready: this MLP does not run on the wide-stage kernels (the spikes at the head of `ws` would be ignored)")
+    _note(flop=4 * B * D * H * W * Cc * fc1.N, shape=(B * D * H * W, Cc, fc1.N))
     _check(lib().sdf_ms_mlp_fwd(C.byref(d), _stream()), "sdf_ms_mlp_fwd")
     if keep_ws is not None:
         keep_ws.append(ws)
@@ -835,12 +894,21 @@ def dense_conv3x3(xp, wplanes, alpha=None, beta=None, resid=None, relu=False, ou
     d.alpha, d.beta = _ptr(alpha, torch.float32), _ptr(beta, torch.float32)
     d.resid, d.out = _ptr(resid, torch.float16), out.data_ptr()
     d.imgs, d.H, d.W, d.cin_records, d.N, d.relu, d.out_f32 = imgs, H, W, rec, N, int(relu), int(out_f32)
-    d.acc_scale = getattr(wplanes, "sdf_acc_scale", 1.0)
+    d.acc_scale = _dense_scale(wplanes)
     _check(lib().sdf_dense_conv3x3_fwd(C.byref(d), _stream()), "sdf_dense_conv3x3_fwd")
     return out
 
 
 # ---- Linear layer on real-valued activations (ANN swin blocks; csrc/dense_linear.hip) ----
+def _dense_scale(wplanes):
+    """1 / weight scale of dense fp16 planes made by pack_dense_linear_weight / pack_dense_conv_weight.  The scale travels as an attribute of
+    the planes tensor: a copy (.to(), .clone(), a slice, a state_dict round trip) drops it, and the kernels would then return results
+    wrong by a power of two - so a tensor without it is refused."""
+    if not hasattr(wplanes, "sdf_acc_scale"):
+        raise SdfError("dense fp16 weight planes without their scale: use the tensor returned by pack_dense_*_weight as is")
+    return wplanes.sdf_acc_scale
+
+
 def _f16_planes(w):
     """fp32 (N, K) -> fp16 planes (2, N, K) of s * w: hi = fp16(s w), lo = fp16(s w - hi), s the power of two that puts max|w| in
     [2^14, 2^15) - every weight within 2^-13 of the largest keeps 22 significant bits (unscaled, a weight of 0.02 has an fp16-subnormal
@@ -880,7 +948,7 @@ def dense_linear(a, wplanes, bias=None, gelu=False, resid=None, out=None):
     d = DenseLinearDesc()
     d.a, d.w, d.bias, d.resid, d.out = _ptr(a, torch.float32), _ptr(wplanes, torch.float16), _ptr(bias, torch.float32), _ptr(resid, torch.float32), _ptr(out, torch.float32)
     d.M, d.N, d.K, d.gelu = M, N, K, int(gelu)
-    d.acc_scale = getattr(wplanes, "sdf_acc_scale", 1.0)
+    d.acc_scale = _dense_scale(wplanes)
     _check(lib().sdf_dense_linear_fwd(C.byref(d), _stream()), "sdf_dense_linear_fwd")
     return out
 
@@ -911,7 +979,7 @@ def dense_conv3x3_strided(x_cl, wplanes, bias, stride, out_T=0):
     d.a, d.w, d.bias, d.resid, d.out = _ptr(x_cl, torch.float32), _ptr(wplanes, torch.float16), _ptr(bias, torch.float32), None, _ptr(out)
     d.M, d.N, d.K, d.gelu = imgs * OH * OW, N, 9 * Cc, 0
     d.cv_H, d.cv_W, d.cv_C, d.cv_stride, d.cv_OH, d.cv_OW, d.out_T = H, W, Cc, stride, OH, OW, out_T
-    d.acc_scale = getattr(wplanes, "sdf_acc_scale", 1.0)
+    d.acc_scale = _dense_scale(wplanes)
     _check(lib().sdf_dense_linear_fwd(C.byref(d), _stream()), "sdf_dense_linear_fwd")
     return out
 
@@ -959,6 +1027,7 @@ def spike_conv2d(x, Wp, imgs, H, W, Cin, OH, OW, KH, KW, stride, dy, dx, out=Non
     for i in range(3):
         d.dy[i] = dy[i] if i < len(dy) else 0
         d.dx[i] = dx[i] if i < len(dx) else 0
+    _note(flop=2 * g.M * g.N * g.K, shape=(int(g.M), int(g.N), int(g.K)), fused_neuron=sn is not None)
     _check(lib().sdf_spike_conv2d_fwd(C.byref(d), _stream()), "sdf_spike_conv2d_fwd")
     return out if sn is None else out_spike
 

@@ -354,12 +354,14 @@ class GradientBuckets:
 
 
 def train_step(model, optimizer, chunk, label, mask, buckets=None, dist=None, world=1, clip_grad=100.0, flow_scaling=1.0,
-               lambda_mod=1.0, amp=False):
+               lambda_mod=1.0, amp=False, forward_fn=None):
     """One step of train_flow_parallel_supervised_SNN.py's loop body (:233-336) on this rank's shard of the batch; returns the
     loss tensor (this rank's samples' mean of err / n_global; the mean over ranks is the gathered-batch loss).
     `amp`: the reference trains under `torch.cuda.amp.autocast` with fp16 + GradScaler (`optimizer.use_amp: true`,
     :248, :314-331); here the same regions run under bf16 autocast (no scaler needed) - spikes are exact in bf16, the
-    membranes / neuron kernels, BatchNorm statistics, the loss and the optimiser stay fp32."""
+    membranes / neuron kernels, BatchNorm statistics, the loss and the optimiser stay fp32.
+    `forward_fn(model, chunk) -> flows` replaces the HIP train-mode forward (the CPU dry run of the N > 1 plumbing, bench.py --train
+    --plumbing: everything else in this function is the code the GPU ranks run)."""
     from .spikingjelly_compat import functional
     model.train()
     functional.reset_net(model)
@@ -368,7 +370,7 @@ def train_step(model, optimizer, chunk, label, mask, buckets=None, dist=None, wo
     else:
         optimizer.zero_grad(set_to_none=True)
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-        flows = forward_train(model, chunk)
+        flows = forward_train(model, chunk) if forward_fn is None else forward_fn(model, chunk)
     n_valid = global_valid_count(mask, dist, world)
     # local mean over B_local of err_i / n_global, times 1 / world from the gradient average = the gathered-batch mean
     loss = flow_loss_supervised([f.float() for f in flows], label, mask, flow_scaling, lambda_mod, n_valid=n_valid)

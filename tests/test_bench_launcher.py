@@ -80,3 +80,20 @@ def test_launcher_counts_gpus_from_the_kfd_topology_without_hip(tmp_path, monkey
     src = open(BENCH).read()
     body = src[src.index("def launch_ranks"):src.index("def init_ranks")]
     assert "torch.cuda" not in body                                               # the launcher makes no torch.cuda call at all
+
+
+def test_train_gpus_2_runs_the_real_step_under_gloo():
+    """`bench.py --train --gpus 2` end to end on the CPU: launcher, rendezvous, then the REAL
+    sdformerflow_amd.train.train_step on a torch stand-in model - GradientBuckets with several buckets whose all-reduces leave from the
+    grad-ready hooks, the global valid-pixel count (each rank has its own label / mask), clip, AdamW - and the rank records.  The two
+    ranks see different data, so a loss that falls on both and equal parameters at the end mean the gradients were averaged."""
+    out = _run(["--train", "--gpus", "2", "--steps", "6", "--warmup", "1", "--local-batch", "2", "--plumbing"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = _line(out)
+    assert r["n_gpus"] == 2 and r["world_size"] == 2 and sorted(x["rank"] for x in r["ranks"]) == [0, 1]
+    assert len({x["host_pid"] for x in r["ranks"]}) == 2
+    assert r["buckets"] >= 2                                                  # the hook-launched path with more than one bucket
+    assert "dry run" in r["metric"] and r["config"]["local_batch"] == 2
+    first, last = r["loss_first_last"]
+    assert last < first and last == last
+    assert abs(r["value"] - 2 * 2 * 6 / (r["ms_per_step"] * 6e-3)) < 1e-6 * r["value"]

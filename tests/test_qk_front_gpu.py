@@ -18,7 +18,14 @@ import os
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-os.environ["SDF_QK_FRONT_ANY"] = "1"            # wide stages too (the dispatcher keeps three launches from C = 288 on: slower there)
+
+
+@pytest.fixture(autouse=True)
+def _front_on_every_width(monkeypatch):
+    """Wide stages too (the dispatcher keeps three launches from C = 288 on); scoped to this file's tests - the library reads the
+    variable per call, so the rest of the suite runs the SHIPPED dispatch."""
+    monkeypatch.setenv("SDF_QK_FRONT_ANY", "1")
+    monkeypatch.setenv("SDF_WIDE", "0")             # (the wide-stage kernels would take C >= 256 away from the kernel under test)
 
 
 def _block(kind, Cc, nH, H, W, window, shift):
