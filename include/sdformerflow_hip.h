@@ -367,6 +367,11 @@ typedef struct SdfMsMlpDesc {
    * the wide-stage kernels multiply by; NULL = the general kernels on the 16-bit planes above. */
   const int8_t* fc1_digits; const float* fc1_cscale;
   const int8_t* fc2_digits; const float* fc2_cscale;
+  /* wide-stage form only: emit_next != NULL (u8 [tokens][C], row-major) also receives SN_emit( x after the update ) over the D steps of
+   * every position - the first neuron of whatever reads x next (the patch merging's `sn`, reference Spiking_swin_transformer3D.py:970,
+   * or MS_ResBlock.sn1 of the U-Net bottleneck, Spiking_modules.py:922) - from the last launch's epilogue, so x is not read again. */
+  uint8_t* emit_next;
+  SdfNeuronCfg emit_sn;
 } SdfMsMlpDesc;
 
 enum {
@@ -380,6 +385,23 @@ int64_t sdf_ms_mlp_workspace_bytes(int64_t tokens, int C, int Ch);
 int sdf_ms_mlp_fwd(const SdfMsMlpDesc* d, void* stream);
 /* 1 when sdf_ms_mlp_fwd will run this descriptor on the wide-stage kernels (and therefore accepts s1_in), else 0; host-only. */
 int sdf_ms_mlp_is_wide(const SdfMsMlpDesc* d);
+
+/* ---------------------------------------------------------------------------------------------
+ * MS patch merging on spikes (row a8):  out = BN( cat_2x2( S ) W^T ),  S = SN(x) as u8 (B, D, H, W, C), W (N, 4C) given as int8 digit
+ * planes, out (B, D, ceil(H/2), ceil(W/2), N) fp32 (odd sizes read zero spikes, the reference's F.pad in front of the neuron).  Replaces MS_SpikingPatchMerging.forward behind its neuron (reference
+ * Spiking_swin_transformer3D.py:965-972: the four strided slices, the concatenation along channels in quadrant order
+ * (dh, dw) = (q % 2, q / 2), sj_layer.Linear, the BatchNorm) - the concatenation is index arithmetic in the operand loads of the
+ * wide-stage main loop (csrc/ms_wide.hip), nothing is materialised.  C % 128 == 0, N % 32 == 0, D in {10, 20}, at most
+ * 20 480 output rows; SDF_E_SHAPE otherwise (the caller keeps its gather map + sdf_spike_gemm_fwd). */
+typedef struct SdfMsMergeDesc {
+  const uint8_t* spikes;
+  const int8_t* digits; const float* cscale;   /* sdf_split_weight_i8x3 of the (N, 4C) reduction weight */
+  const float* alpha; const float* beta;       /* BatchNorm as (alpha, beta) per output channel, or NULL */
+  float* out;
+  int32_t B, D, H, W, C, N;
+} SdfMsMergeDesc;
+
+int sdf_ms_patch_merge_fwd(const SdfMsMergeDesc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Spike convolution (implicit GEMM):  out = epilogue( im2col(X) x W^T ) with X an NHWC u8 spike image batch.

@@ -307,10 +307,14 @@ struct WidePmParams {
   // sums (digit scale applied) to partial[ks][row][N] for wide_reduce_kernel
   int ksplit, cps;
   float* partial;
+  int no_resid;              // fp32 epilogue without a shortcut: out = BN(...) (patch merging writes a new tensor)
 };
 
 // EPI: 1 = neuron (spikes out), 2 = fp32 (+ shortcut), 3 = fp32 and the neuron on the updated shortcut stream
-template <int T, int CB, int EPI, int NK>
+// AM (address mode of the spike operand): 0 = rows of a tensor (row-major / tiled / head scramble), 1 = 3x3 convolution taps (EPI 4),
+// 2 = the 2x2 concatenation of patch merging (K = 4 C in quadrant order (dh, dw) = (q % 2, q / 2), reference
+// Spiking_swin_transformer3D.py:965-970; cv_W / cv_Cin = the SOURCE map's width and channels, HW = the merged map's positions)
+template <int T, int CB, int EPI, int NK, int AM = (EPI == 4 ? 1 : 0)>
 __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
   constexpr int NW = 4, RB = RBW, ROWS = 16 * RB, SLOTS = 4 * RB, PPG = SLOTS / T, PPW = 4 * PPG;
   constexpr int BN = 16 * CB, WBUF = w_buf(CB), WIT = w_steps(CB);
@@ -378,7 +382,15 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
         const int32_t g = rowtab[wave * ROWS + 16 * rb + l16];
         a_base[rb] = INV;
         a_mask[rb] = 0;
-        if (EPI == 4) {
+        if (AM == 2) {
+          if (g >= 0) {                                      // merged position (b, t, h2, w2) -> source pixel (2 h2, 2 w2) of the same (b, t)
+            const uint32_t W2 = ((uint32_t)P.cv_W + 1u) >> 1, img = (uint32_t)g / (uint32_t)HW, pix = (uint32_t)g - img * (uint32_t)HW;
+            const uint32_t h2 = pix / W2, w2 = pix - h2 * W2;
+            a_base[rb] = ((img * (uint32_t)P.cv_H + 2 * h2) * (uint32_t)P.cv_W + 2 * w2) * (uint32_t)P.cv_Cin + 16u * lq;
+            const uint32_t hin = 2 * h2 + 1 < (uint32_t)P.cv_H ? 0xFu : 0x5u, win = 2 * w2 + 1 < (uint32_t)P.cv_W ? 0xFu : 0x3u;
+            a_mask[rb] = hin & win;                          // odd sizes: the reference pads zeros in front of the neuron, SN(0) = 0
+          }
+        } else if (AM == 1) {
           if (g >= 0) {
             const uint32_t pix = (uint32_t)g % (uint32_t)HW, y = pix / (uint32_t)P.cv_W, xx = pix - y * (uint32_t)P.cv_W;
             a_base[rb] = (uint32_t)g * (uint32_t)P.cv_Cin + 16u * lq;
@@ -410,7 +422,7 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
           for (int s = 0; s < SLOTS; ++s)
-            res[cb][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rs, (n0 + 16 * cb + c < N) ? xo[s] : INV, 64u * cb, 0));
+            res[cb][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rs, (n0 + 16 * cb + c < N && !P.no_resid) ? xo[s] : INV, 64u * cb, 0));
       }
       if (pass == 0) {
 #pragma unroll
@@ -446,15 +458,16 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
         const int cg_ = __builtin_amdgcn_readfirstlane(c0 + ch);
         tap = cg_ / cpt;
         cin0 = (uint32_t)((cg_ - tap * cpt) * KCH);
-        toff = (uint32_t)(((tap / 3 - 1) * W + (tap % 3 - 1)) * Cin);
+        if constexpr (AM == 2) toff = (uint32_t)(((tap & 1) * W + (tap >> 1)) * Cin);       // quadrant (dh, dw) = (q % 2, q / 2)
+        else toff = (uint32_t)(((tap / 3 - 1) * W + (tap % 3 - 1)) * Cin);
       }
       __device__ __forceinline__ void get(int h, int rb, uint32_t& voff, uint32_t& soff) const {
         voff = ((mask[rb] >> tap) & 1u) ? base[rb] + toff : INV;
         soff = cin0 + 64u * (uint32_t)h;
       }
     };
-    typename std::conditional<EPI == 4, AddrConv, AddrPlain>::type a_addr;
-    if constexpr (EPI == 4) a_addr = AddrConv{a_base, a_mask, P.cv_cpt, P.cv_W, P.cv_Cin, c0, 0, 0u, 0u};
+    typename std::conditional<AM != 0, AddrConv, AddrPlain>::type a_addr;
+    if constexpr (AM != 0) a_addr = AddrConv{a_base, a_mask, P.cv_cpt, P.cv_W, P.cv_Cin, c0, 0, 0u, 0u};
     else a_addr = AddrPlain{a_base, a_step, 0u};
     wide_mainloop<RB, CB, WIT>(acc, A_rs, a_addr, nch, c0, smem, W_rs, W_rs, w_goff, w_lds, lane, prepare_a, late_requests);
     WSTAMP(ws2);
@@ -877,7 +890,7 @@ bool ms_wide_mlp_supports(const SdfMsMlpDesc* d) {
   if (!d->fc1_digits || !d->fc1_cscale || !d->fc2_digits || !d->fc2_cscale) return false;
   if (d->nsplit != 2 || d->C < 256 || d->C % 128 || d->Ch % 128 || d->Ch % 96) return false;
   if (d->D != 10 && d->D != 20) return false;
-  if (!neuron_ok(d->sn1) || !neuron_ok(d->sn2)) return false;
+  if (!neuron_ok(d->sn1) || !neuron_ok(d->sn2) || (d->emit_next && !neuron_ok(d->emit_sn))) return false;
   const int64_t tokens = (int64_t)d->B * d->D * d->HW;
   if (tokens * d->Ch >= (1LL << 31) || tokens * d->C * 4 >= (1LL << 31)) return false;
   if (tokens > WIDE_MAX_ROWS && !wide_env_any()) return false;
@@ -895,10 +908,43 @@ int launch_ms_wide_mlp(const SdfMsMlpDesc* d, const uint8_t* s1, bool s1_tiled, 
   int rc = launch_pm(P, d->D, 1, s);
   if (rc) return rc;
   WidePmParams Q = {};
-  Q.A = s2; Q.a_tiled = s2_tiled; Q.W = d->fc2_digits; Q.cscale = d->fc2_cscale; Q.N = d->C; Q.K = d->Ch; Q.HW = (int)d->HW; Q.P = P.P;
+  Q.A = s2; Q.a_tiled = s2_tiled;
+  Q.W = d->fc2_digits; Q.cscale = d->fc2_cscale; Q.N = d->C; Q.K = d->Ch; Q.HW = (int)d->HW; Q.P = P.P;
   Q.alpha = d->fc2_alpha; Q.beta = d->fc2_beta; Q.x = d->x; Q.ldo = d->C;
-  Q.sn = d->sn2;
-  return launch_pm(Q, d->D, 2, s);
+  Q.sn = d->emit_next ? d->emit_sn : d->sn2; Q.inv_tau = inv_tau_of(Q.sn);
+  Q.out_spike = d->emit_next; Q.ldsp = d->C; Q.out_tiled = 0;     // the next layer's first neuron on the updated stream, row-major
+  return launch_pm(Q, d->D, d->emit_next ? 3 : 2, s);
+}
+
+// ---- patch merging on the wide main loop: out = BN( [2x2 concat of the spikes] W^T ) -------------------------------------------------
+bool wide_merge_supports(const SdfMsMergeDesc* d) {
+  if (wide_env_off()) return false;
+  if (d->B < 1 || d->H < 1 || d->W < 1 || (d->D != 10 && d->D != 20)) return false;
+  if (d->C % KCH || d->C < 64 || d->N % 32) return false;
+  const int64_t rows = (int64_t)d->B * d->D * ((d->H + 1) / 2) * ((d->W + 1) / 2);
+  if (rows > WIDE_MAX_ROWS && !wide_env_any()) return false;
+  if (rows * 4 * d->C >= (1LL << 31) || rows * (int64_t)d->N * 4 >= (1LL << 31) || (int64_t)d->N * 4 * d->C * 3 >= (1LL << 31)) return false;
+  return sdf_aligned(d->spikes, 16) && sdf_aligned(d->digits, 16) && sdf_aligned(d->out, 16);
+}
+
+int launch_wide_merge(const SdfMsMergeDesc* d, hipStream_t s) {
+  WidePmParams P = {};
+  P.A = d->spikes; P.W = d->digits; P.cscale = d->cscale; P.N = d->N; P.K = 4 * d->C;
+  P.HW = ((d->H + 1) / 2) * ((d->W + 1) / 2); P.P = (int64_t)d->B * P.HW;
+  P.alpha = d->alpha; P.beta = d->beta; P.x = d->out; P.ldo = d->N; P.no_resid = 1;
+  P.cv_H = d->H; P.cv_W = d->W; P.cv_Cin = d->C; P.cv_cpt = d->C / KCH;
+  const int T = d->D, PPW = 4 * (20 / T);
+  const int64_t units = (P.P + PPW - 1) / PPW;
+  if (units >= (1LL << 28)) return SDF_E_SHAPE;
+  P.nunits = (int)units; P.nrg = (int)((units + 3) / 4); P.ncg = d->N / 32;
+  const int64_t all = (int64_t)P.ncg * P.nrg;
+  P.passes = all > 256 && all <= 1024 ? (int)((all + 255) / 256) : 1;
+  const int64_t items = (int64_t)P.ncg * ((P.nrg + P.passes - 1) / P.passes);
+  const dim3 grid((unsigned)((items + 7) / 8 * 8));
+  if (T == 10) hipLaunchKernelGGL((wide_pm_kernel<10, 2, 2, 0, 2>), grid, dim3(256), 0, s, P);
+  else hipLaunchKernelGGL((wide_pm_kernel<20, 2, 2, 0, 2>), grid, dim3(256), 0, s, P);
+  hipError_t e = hipGetLastError();
+  return e != hipSuccess ? (int)e : 0;
 }
 
 bool ms_wide_attn_supports(const SdfQkAttnDesc* d) {
@@ -1068,6 +1114,14 @@ extern "C" int sdf_debug_read_stamps_wide(unsigned long long* host32, unsigned l
   return (int)hipMemcpyFromSymbol(host32 + 40, HIP_SYMBOL(g_wide_loop), sizeof(g_wide_loop));
 }
 #endif
+
+extern "C" int sdf_ms_patch_merge_fwd(const SdfMsMergeDesc* d, void* stream) {
+  if (!d) return SDF_E_NULL;
+  if (!d->spikes || !d->digits || !d->cscale || !d->out) return SDF_E_NULL;
+  if (d->alpha && !d->beta) return SDF_E_NULL;
+  if (!sdfmm::wide_merge_supports(d)) return SDF_E_SHAPE;
+  return sdfmm::launch_wide_merge(d, sdf_stream(stream));
+}
 
 extern "C" int sdf_window_zsrc_map(const int32_t* slice_map, int64_t B_, int Tq, int N1, int nH, int32_t* x_src, void* stream) {
   if (!slice_map || !x_src) return SDF_E_NULL;

@@ -203,7 +203,7 @@ extern "C" int sdf_ms_mlp_fwd(const SdfMsMlpDesc* d, void* stream) {
     }
     return sdfmm::launch_ms_wide_mlp(d, s1, d->s1_in != nullptr && !tape, s2w, !tape, sdf_stream(stream));
   }
-  if (d->s1_in) return SDF_E_SHAPE;
+  if (d->s1_in || d->emit_next) return SDF_E_SHAPE;            // wide-stage inputs / outputs
   // one launch where the kernel has an instantiation (SDF_MLP_FUSED=0 / SDF_MLP_THREE_LAUNCHES: the A/B reference below)
   {
     const char* e = getenv("SDF_MLP_FUSED");

@@ -475,12 +475,13 @@ class MSFlowEngine:
         self._emitted = bool(info.get("emitted"))
         return x
 
-    def mlp(self, x, blk: _Block, ws=None, s1_ready=False):
+    def mlp(self, x, blk: _Block, ws=None, s1_ready=False, emit_next=None):
         """x (B,D,H,W,C) += MLP(x) over the true time axis D, in place (reference :164-181, :845).  `ws` / `s1_ready`: the caller's
-        workspace with SN1's spikes already at its head (wide stages: left there by the attention's projection)."""
+        workspace with SN1's spikes already at its head (wide stages: left there by the attention's projection); `emit_next`: see
+        _next_spikes."""
         self._check_cl(x)
         keep = [] if self.tape is not None else None
-        hip.ms_mlp(x, blk.fc1, blk.fc2, blk.sn1, blk.sn2, keep_ws=keep, ws=ws, s1_ready=s1_ready)      # one C-ABI call (csrc/qk_attn.hip: sdf_ms_mlp_fwd)
+        hip.ms_mlp(x, blk.fc1, blk.fc2, blk.sn1, blk.sn2, keep_ws=keep, ws=ws, s1_ready=s1_ready, emit_next=emit_next)      # one C-ABI call (csrc/qk_attn.hip: sdf_ms_mlp_fwd)
         if keep:
             B, D, H, W, Cc = x.shape
             tok = B * D * H * W
@@ -488,41 +489,69 @@ class MSFlowEngine:
             self._rec(blk.name + "mlp.sn2.spiking_neuron.", keep[0][(tok * Cc + 255) // 256 * 256:][:tok * blk.fc1.N].view(B, D, H, W, -1), "BDHWC->TBHWC")
         return x
 
-    def swin_block(self, x, s, i):
+    def swin_block(self, x, s, i, emit_next=None):
         blk = self.stages[s][i]
         last = self.scores is not None and i == len(self.stages[s]) - 1          # log=True: the last block of every stage (:1090-1105)
         # wide stages: the projection emits the MLP's first spikes (tiled hand-over layout; the tape / score paths keep row-major spikes
         # and let the MLP run its own first neuron)
         ws = hip.ms_mlp_workspace(x, blk.fc1.N) if x.shape[-1] >= 256 and self.tape is None and not last else None
         self.attention(x, blk, self.scores if last else None, emit=(ws, blk.sn1) if ws is not None else None)
-        return self.mlp(x, blk, ws=ws, s1_ready=self._emitted)
+        return self.mlp(x, blk, ws=ws, s1_ready=self._emitted, emit_next=emit_next)
 
-    def patch_merge(self, x, s, packed=None):
-        """(B,D,H,W,C) -> (B,D,H/2,W/2,2C) (reference :952-974)."""
+    def _tail_kwargs(self):
+        """encoder() arguments of forward(): the neuron that reads the last stage's output first (MS_ResBlock.sn1 of the bottleneck)."""
+        return {"tail_sn": self.unet_res[0].sn1} if self.unet_res else {}
+
+    def _next_spikes(self, x, blk, sn):
+        """(u8 buffer, neuron) for the MLP of `blk` to fill with SN(x after its update) - the first neuron of the layer behind the
+        stage - or None where that MLP does not run on the wide-stage kernels (the layer then runs its own neuron)."""
+        if x.shape[-1] < 256 or not hip.ms_mlp_is_wide(x, blk.fc1, blk.fc2, blk.sn1, blk.sn2, emit_sn=sn):
+            return None
+        return torch.empty(x.shape, dtype=torch.uint8, device=x.device), sn
+
+    def patch_merge(self, x, s, packed=None, spikes=None):
+        """(B,D,H,W,C) -> (B,D,H/2,W/2,2C) (reference :952-974).  `spikes` = SN(x) (B,D,H,W,C) u8 when the stage's last MLP emitted
+        them: the 2x2 concatenation is then index arithmetic inside the reduction GEMM (hip.ms_patch_merge)."""
         lin, sn = self.merges[s] if packed is None else packed
         self._check_cl(x)
         B, D, H, W, Cc = x.shape
+        name = f"sttmultires_unet.encoders.swin3d.layers.{s}.downsample.sn.spiking_neuron."
+        if spikes is not None:
+            out = hip.ms_patch_merge(spikes, lin)
+            if out is not None:
+                if self.tape is not None:                   # the tape holds the reference's (T, B, H/2, W/2, 4C) concatenation
+                    src, H2, W2 = merge_row_map(B, D, H, W)
+                    idx = torch.from_numpy(src.reshape(-1).astype("int64")).to(x.device)
+                    flat = torch.cat([spikes.view(-1, Cc), spikes.new_zeros(1, Cc)], 0)
+                    self._rec(name, flat[idx].view(D, B, H2, W2, 4 * Cc), "flat")
+                return out
         rowmap, H2, W2, out_map = self._merge_map(B, D, H, W)
         rows = B * H2 * W2
         sp = torch.empty((D * rows, 4 * Cc), dtype=torch.uint8, device=x.device)
         hip.neuron_fwd(x, sp, D, 1, rows * 4 * Cc, 0, 0, 0, rows * 4 * Cc, sn, rowmap=rowmap, rowlen=Cc)
-        self._rec(f"sttmultires_unet.encoders.swin3d.layers.{s}.downsample.sn.spiking_neuron.", sp.view(D, B, H2, W2, 4 * Cc), "flat")
+        self._rec(name, sp.view(D, B, H2, W2, 4 * Cc), "flat")
         out = torch.empty((B, D, H2, W2, lin.N), dtype=torch.float32, device=x.device)
         hip.spike_gemm(sp, lin.Wp, out, D * rows, lin.N, 4 * Cc, alpha=lin.alpha, beta=lin.beta, out_rowmap=out_map)
         return out
 
-    def encoder(self, x):
-        """-> per-stage features, channel-last (B,D,h,w,C) (reference :1223-1246 + Spiking_STSwinNet.py:77-85)."""
+    def encoder(self, x, tail_sn=None):
+        """-> per-stage features, channel-last (B,D,h,w,C) (reference :1223-1246 + Spiking_STSwinNet.py:77-85).  `tail_sn` = the first
+        neuron of whatever reads the last stage's output: where the last MLP can emit its spikes they are left in `self.tail_spikes`."""
         y = self.patch_embed(x)
         feats = []
+        self.tail_spikes = None
         for s, blocks in enumerate(self.stages):
+            nxt_sn = self.merges[s][1] if s < len(self.merges) else tail_sn
+            emit = None
             for i in range(len(blocks)):
-                y = self.swin_block(y, s, i)
+                if i == len(blocks) - 1 and nxt_sn is not None:
+                    emit = self._next_spikes(y, blocks[i], nxt_sn)
+                y = self.swin_block(y, s, i, **({"emit_next": emit} if emit is not None else {}))
+            feats.append(y)                                 # the merge writes a new tensor; nothing touches y after this
             if s < len(self.merges):
-                feats.append(y)                             # the merge writes a new tensor; nothing touches y after this
-                y = self.patch_merge(y, s)
-            else:
-                feats.append(y)
+                y = self.patch_merge(y, s, **({"spikes": emit[0]} if emit is not None else {}))
+            elif emit is not None:
+                self.tail_spikes = emit[0]
         return feats
 
     def _deconv_classes(self, i, B, D, h, w, cin_pad, wkey="ref", wuse=None):
@@ -587,12 +616,13 @@ class MSFlowEngine:
         hip.neuron_multi_fwd(calls)
         return imgs
 
-    def unet_tail(self, feats, out_size=None):
+    def unet_tail(self, feats, out_size=None, s1=None):
         """res-blocks + decoders + per-scale predictions on channel-last (B,D,h,w,C) features
-        (reference Spiking_STSwinNet.py:161-182).  Returns the per-scale predictions (B,D,h',w',2) fp32; with `out_size` = (H, W)
+        (reference Spiking_STSwinNet.py:161-182).  `s1` = the first res-block's SN1(feats[-1]) where the encoder's last MLP emitted it
+        (encoder(..., tail_sn=)).  Returns the per-scale predictions (B,D,h',w',2) fp32; with `out_size` = (H, W)
         the flow maps (time sum + nearest upsampling, reference :289-303) of the levels whose prediction head ran as one launch
         are left in `self._flows` (None where the three-launch form ran: forward() calls sdf_flow_out_fwd for those)."""
-        y, s1 = feats[-1], None
+        y = feats[-1]
         for i, rb in enumerate(self.unet_res):                # a block's second convolution also emits the next block's first spikes
             nxt = self.unet_res[i + 1].sn1 if i + 1 < len(self.unet_res) else None
             r = self._resblock(y, rb, s1=s1, next_sn=nxt)
@@ -713,9 +743,10 @@ class MSFlowEngine:
         H, W = x.shape[-2:]
         self.scores = scores
         try:
-            feats = self.encoder(x)
+            feats = self.encoder(x, **self._tail_kwargs())
         finally:
             self.scores = None
-        preds = self.unet_tail(feats, out_size=(H, W))
+        preds = self.unet_tail(feats, out_size=(H, W), **({"s1": self.tail_spikes} if getattr(self, "tail_spikes", None) is not None else {}))
+        self.tail_spikes = None
         # sum over time + nearest upsampling to the input size: done by the prediction head's launch, else one small kernel per scale
         return [f if f is not None else hip.flow_out(p, H, W, H / p.shape[2], W / p.shape[3]) for p, f in zip(preds, self._flows)]

@@ -147,6 +147,12 @@ class SEWFlowEngine(MSFlowEngine):
         x = self.attention(x, blk) + x                                            # SEW ADD (:840)
         return self.mlp(x, blk) + x                                               # (:845)
 
+    def _tail_kwargs(self):
+        return {}
+
+    def _next_spikes(self, x, blk, sn):
+        return None                                         # the SEW stream is not a membrane: every layer runs its own neuron
+
     def patch_merge(self, x, s, packed=None):
         """2x2 gather -> Linear -> BN -> SN (reference :914-934): spikes (B,D,H/2,W/2,2C) fp32."""
         wpk, bn, sn = self.merges[s] if packed is None else packed

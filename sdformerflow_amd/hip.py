@@ -23,7 +23,7 @@ KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
 EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
            "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd", "sdf_head_conv_sn_fwd",
            "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes",
-           "sdf_window_slice_map", "sdf_window_zsrc_map", "sdf_qk_attn_fwd", "sdf_qk_attn_is_wide", "sdf_ms_mlp_is_wide", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
+           "sdf_window_slice_map", "sdf_window_zsrc_map", "sdf_qk_attn_fwd", "sdf_qk_attn_is_wide", "sdf_ms_mlp_is_wide", "sdf_ms_patch_merge_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
            "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_pred_head_fwd", "sdf_pointwise_conv_f32_fwd", "sdf_neuron_multi_fwd", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
            "sdf_rows_gather_fwd", "sdf_rows_scatter_fwd",
            "sdf_split_weight_i8x3", "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd",
@@ -171,6 +171,9 @@ def lib():
         _lib.sdf_bn_train_workspace_bytes.restype = C.c_int64
         _lib.sdf_qk_gate_bwd_workspace_bytes.restype = C.c_int64
     return _lib
+
+
+E_NULL, E_SHAPE = -1, -2          # include/sdformerflow_hip.h: SDF_E_NULL, SDF_E_SHAPE
 
 
 def _check(rc, what):
@@ -587,7 +590,14 @@ class MsMlpDesc(C.Structure):
                 ("sn1", NeuronCfg), ("sn2", NeuronCfg),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
                 ("gemm_workspace", C.c_void_p), ("gemm_workspace_bytes", C.c_int64), ("flags", C.c_int32), ("s1_in", C.c_void_p),
-                ("fc1_digits", C.c_void_p), ("fc1_cscale", C.c_void_p), ("fc2_digits", C.c_void_p), ("fc2_cscale", C.c_void_p)]
+                ("fc1_digits", C.c_void_p), ("fc1_cscale", C.c_void_p), ("fc2_digits", C.c_void_p), ("fc2_cscale", C.c_void_p),
+                ("emit_next", C.c_void_p), ("emit_sn", NeuronCfg)]
+
+
+class MsMergeDesc(C.Structure):
+    _fields_ = [("spikes", C.c_void_p), ("digits", C.c_void_p), ("cscale", C.c_void_p), ("alpha", C.c_void_p), ("beta", C.c_void_p),
+                ("out", C.c_void_p), ("B", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("N", C.c_int32)]
 
 
 MLP_KEEP_SPIKES, MLP_THREE_LAUNCHES, MLP_NARROW = 1, 2, 4
@@ -600,10 +610,12 @@ def ms_mlp_workspace(x, Ch):
     return torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
 
 
-def ms_mlp(x, fc1, fc2, sn1, sn2, keep_ws=None, three_launches=False, ws=None, s1_ready=False, narrow=False):
+def ms_mlp(x, fc1, fc2, sn1, sn2, keep_ws=None, three_launches=False, ws=None, s1_ready=False, narrow=False, emit_next=None):
     """sdf_ms_mlp_fwd: x (B,D,H,W,C) fp32 channel-last += MLP(x) over the time axis D, in place.  `keep_ws` (a list) receives
     the workspace with the SN1 / SN2 spikes (parity tape); `three_launches` selects the unfused A/B reference.  `ws` =
-    ms_mlp_workspace(...) of the caller; with `s1_ready` its head already holds SN1(x) (wide stages: written by qk_attn's `emit`)."""
+    ms_mlp_workspace(...) of the caller; with `s1_ready` its head already holds SN1(x) (wide stages: written by qk_attn's `emit`).
+    `emit_next` = (u8 (B,D,H,W,C) buffer, neuron): wide stages only - the last launch also writes that neuron's spikes of the
+    updated x (the patch merging's / the bottleneck's first neuron)."""
     B, D, H, W, Cc = x.shape
     d = MsMlpDesc()
     d.x, d.B, d.D, d.HW, d.C, d.Ch, d.nsplit = _ptr(x, torch.float32), B, D, H * W, Cc, fc1.N, fc1.Wp.shape[0]
@@ -623,13 +635,63 @@ def ms_mlp(x, fc1, fc2, sn1, sn2, keep_ws=None, three_launches=False, ws=None, s
     d.fc2_digits, d.fc2_cscale = _digits(getattr(fc2, "digits", None))
     if s1_ready:
         d.s1_in = ws.data_ptr()
-        if lib().sdf_ms_mlp_is_wide(C.byref(d)) != 1:
-            raise SdfError("s1_ready: this MLP does not run on the wide-stage kernels (the spikes at the head of `ws` would be ignored)")
+    if emit_next is not None:
+        buf, nsn = emit_next
+        if buf.numel() != x.numel() or buf.dtype != torch.uint8:
+            raise SdfError("emit_next: need a u8 buffer of x's shape")
+        d.emit_next = _ptr(buf, torch.uint8)
+        _ncfg(d.emit_sn, nsn)
+    if (s1_ready or emit_next is not None) and lib().sdf_ms_mlp_is_wide(C.byref(d)) != 1:
+        raise SdfError("s1_ready / emit_next: this MLP does not run on the wide-stage kernels (they would be ignored)")
     _note(flop=4 * B * D * H * W * Cc * fc1.N, shape=(B * D * H * W, Cc, fc1.N))
     _check(lib().sdf_ms_mlp_fwd(C.byref(d), _stream()), "sdf_ms_mlp_fwd")
     if keep_ws is not None:
         keep_ws.append(ws)
     return x
+
+
+def ms_mlp_is_wide(x, fc1, fc2, sn1, sn2, emit_sn=None):
+    """Whether ms_mlp of this layer on x runs on the wide-stage kernels (host-only query; then `s1_ready` / `emit_next` - with the
+    neuron `emit_sn` - are accepted)."""
+    if getattr(fc1, "digits", None) is None or getattr(fc2, "digits", None) is None:
+        return False
+    B, D, H, W, Cc = x.shape
+    d = MsMlpDesc()
+    d.x, d.B, d.D, d.HW, d.C, d.Ch, d.nsplit = _ptr(x, torch.float32), B, D, H * W, Cc, fc1.N, fc1.Wp.shape[0]
+    d.fc1_planes, d.fc2_planes = _ptr(fc1.Wp, torch.int16), _ptr(fc2.Wp, torch.int16)
+    d.fc1_alpha, d.fc1_beta, d.fc2_alpha, d.fc2_beta = _ptr(fc1.alpha), _ptr(fc1.beta), _ptr(fc2.alpha), _ptr(fc2.beta)
+    _ncfg(d.sn1, sn1)
+    _ncfg(d.sn2, sn2)
+    d.workspace, d.workspace_bytes = 256, 1 << 40               # not dereferenced by the query
+    if emit_sn is not None:
+        d.emit_next = 256
+        _ncfg(d.emit_sn, emit_sn)
+    d.fc1_digits, d.fc1_cscale = _digits(fc1.digits)
+    d.fc2_digits, d.fc2_cscale = _digits(fc2.digits)
+    return lib().sdf_ms_mlp_is_wide(C.byref(d)) == 1
+
+
+def ms_patch_merge(spikes, lin, out=None):
+    """sdf_ms_patch_merge_fwd: spikes u8 (B,D,H,W,C) = SN(x) -> BN(cat_2x2(spikes) W^T) fp32 (B,D,ceil(H/2),ceil(W/2),N); `lin` carries
+    the reduction weight as digit planes (`digits`) and the BatchNorm as (alpha, beta).  Returns None when the shape is not covered
+    (the caller keeps its gather map + spike_gemm)."""
+    B, D, H, W, Cc = spikes.shape
+    if getattr(lin, "digits", None) is None:
+        return None
+    d = MsMergeDesc()
+    d.spikes = _ptr(spikes, torch.uint8)
+    d.digits, d.cscale = _digits(lin.digits)
+    d.alpha, d.beta = _ptr(lin.alpha), _ptr(lin.beta)
+    d.B, d.D, d.H, d.W, d.C, d.N = B, D, H, W, Cc, lin.N
+    if out is None:
+        out = torch.empty((B, D, (H + 1) // 2, (W + 1) // 2, lin.N), dtype=torch.float32, device=spikes.device)
+    d.out = _ptr(out, torch.float32)
+    _note(flop=2 * out.numel() * 4 * Cc, shape=(out.numel() // lin.N, lin.N, 4 * Cc))
+    rc = lib().sdf_ms_patch_merge_fwd(C.byref(d), _stream())
+    if rc == E_SHAPE:
+        return None
+    _check(rc, "sdf_ms_patch_merge_fwd")
+    return out
 
 
 def bn_train_fwd(x2, weight, bias, running_mean, running_var, momentum, eps):

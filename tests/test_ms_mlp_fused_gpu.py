@@ -20,7 +20,13 @@ from sdformerflow_amd.synthetic import synth_uniform as rnd
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-os.environ["SDF_MLP_FUSED_ANY"] = "1"          # small C = 192 cases take the one-launch kernel too (the dispatcher would not)
+
+
+@pytest.fixture(autouse=True)
+def _any_size(monkeypatch):
+    """Small C = 192 cases take the one-launch kernel too (the dispatcher would not); read per call by the library, set for these
+    tests only."""
+    monkeypatch.setenv("SDF_MLP_FUSED_ANY", "1")
 
 
 class _L:

@@ -253,3 +253,71 @@ def test_wide_block_through_the_engine_matches_the_general_kernels():
     d = (xa - xc).abs().view(-1, Cc)
     close = (d.max(dim=1).values <= 2e-5 * xc.abs().max()).float().mean().item()
     assert close > 0.85, close                                              # rows untouched by a flipped spike agree to rounding
+
+
+# ------------------------------------------------------------------------- fc2's emission of the next neuron + patch merging
+@pytest.mark.parametrize("name", ["lif", "plif", "lif_hard", "if"])
+@pytest.mark.parametrize("B,D,H,W,Cc", [(1, 10, 15, 20, 384), (1, 10, 8, 10, 768), (2, 10, 5, 7, 384), (1, 20, 6, 5, 384)])
+def test_wide_mlp_emits_the_next_layers_first_spikes(B, D, H, W, Cc, name):
+    """SdfMsMlpDesc.emit_next: SN_next(x after the update), bit-equal to the oracle neuron on the kernel's OWN updated x (what the patch
+    merging - reference Spiking_swin_transformer3D.py:970 - or the bottleneck's MS_ResBlock.sn1 - Spiking_modules.py:922 - computes
+    first), and x itself unchanged by asking for it."""
+    if name != "lif" and (D != 10 or B != 1):
+        pytest.skip("the other neuron classes are covered on the shipped T = 10 shapes")
+    Ch = 4 * Cc
+    x0 = rnd((B, D, H, W, Cc), 900, -0.5, 1.0)
+    fc1 = _L(rnd((Ch, Cc), 901, -0.15, 0.15), rnd((Ch,), 903, 0.5, 1.5), rnd((Ch,), 904, -0.2, 0.2))
+    fc2 = _L(rnd((Cc, Ch), 902, -0.05, 0.05), rnd((Cc,), 905, 0.5, 1.5), rnd((Cc,), 906, -0.2, 0.2))
+    p, pn = _np("lif"), _np(name, v_th=0.25)
+    buf = torch.full((B, D, H, W, Cc), 7, dtype=torch.uint8, device=DEV)
+    xg = hip.ms_mlp(x0.to(DEV).clone(), fc1, fc2, p, p, emit_next=(buf, pn))
+    xb = hip.ms_mlp(x0.to(DEV).clone(), fc1, fc2, p, p)
+    torch.cuda.synchronize()
+    assert torch.equal(xg, xb)
+    ref = _ref_neuron(xg.cpu().permute(1, 0, 2, 3, 4).contiguous(), name, v_th=0.25).permute(1, 0, 2, 3, 4)
+    assert torch.equal(buf.cpu().float(), ref), "emitted spikes differ from the oracle neuron on the updated x"
+    assert 0.02 < ref.mean() < 0.98
+
+
+def _merge_ref(sp, We, alpha, beta):
+    """fp64 BN(cat_2x2(S) W^T) in the reference's order (Spiking_swin_transformer3D.py:960-972): zero padding to even sizes, the four
+    strided slices x0..x3 = (0,0), (1,0), (0,1), (1,1), concatenation along channels."""
+    B, D, H, W, Cc = sp.shape
+    s = torch.nn.functional.pad(sp.double(), (0, 0, 0, W % 2, 0, H % 2))
+    cat = torch.cat([s[:, :, 0::2, 0::2], s[:, :, 1::2, 0::2], s[:, :, 0::2, 1::2], s[:, :, 1::2, 1::2]], -1)
+    return (cat @ We.t()) * alpha.double() + beta.double()
+
+
+@pytest.mark.parametrize("B,D,H,W,Cc", [(1, 10, 15, 20, 384), (1, 10, 30, 40, 256), (2, 10, 7, 9, 384), (1, 20, 6, 5, 128),
+                                        (1, 10, 1, 3, 128), (3, 20, 4, 4, 256)])
+def test_wide_patch_merge_against_the_oracle(B, D, H, W, Cc):
+    """sdf_ms_patch_merge_fwd on given spikes: exact integer sums -> fp64 reference to 1e-6 of the range, odd sizes included (15 x 20 is
+    the shipped stage-2 map), and against the gather-map + spike GEMM path it replaces."""
+    N = 2 * Cc
+    sp = (rnd((B, D, H, W, Cc), 910, 0.0, 1.0) < 0.3).to(torch.uint8)
+    Wr = rnd((N, 4 * Cc), 911, -0.08, 0.08)
+    lin = _L(Wr, rnd((N,), 912, 0.5, 1.5), rnd((N,), 913, -0.2, 0.2))
+    out = hip.ms_patch_merge(sp.to(DEV), lin)
+    assert out is not None, "the wide merge refused a shape it is built for"
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (B, D, (H + 1) // 2, (W + 1) // 2, N)
+    ref = _merge_ref(sp, _weff(lin.digits), lin.alpha.cpu(), lin.beta.cpu())
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= 1e-6 * ref.abs().max().item(), err
+    # the general path: neuron output gathered through merge_row_map, then the spike GEMM
+    from sdformerflow_amd.STSwinNet_SNN.Spiking_swin_transformer3D import merge_row_map
+    src, H2, W2 = merge_row_map(B, D, H, W)
+    idx = torch.from_numpy(src.reshape(-1).astype("int64"))
+    flat = torch.cat([sp.view(-1, Cc), sp.new_zeros(1, Cc)], 0)[idx].view(D * B * H2 * W2, 4 * Cc).to(DEV)        # (T, B, H2, W2, 4C)
+    o2 = torch.empty((D * B * H2 * W2, N), dtype=torch.float32, device=DEV)
+    hip.spike_gemm(flat, lin.Wp, o2, o2.shape[0], N, 4 * Cc, alpha=lin.alpha, beta=lin.beta)
+    o2 = o2.view(D, B, H2, W2, N).permute(1, 0, 2, 3, 4)
+    assert (out - o2).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+def test_wide_patch_merge_refuses_what_it_is_not_built_for():
+    lin = _L(rnd((192, 384), 920, -0.1, 0.1), rnd((192,), 921, 0.5, 1.5), rnd((192,), 922, -0.2, 0.2))
+    sp = torch.zeros((1, 10, 8, 8, 96), dtype=torch.uint8, device=DEV)                  # C % 128 != 0
+    assert hip.ms_patch_merge(sp, lin) is None
+    lin2 = _L(rnd((256, 512), 923, -0.1, 0.1), rnd((256,), 924, 0.5, 1.5), rnd((256,), 925, -0.2, 0.2))
+    assert hip.ms_patch_merge(torch.zeros((1, 4, 8, 8, 128), dtype=torch.uint8, device=DEV), lin2) is None    # D not in {10, 20}

@@ -5,8 +5,6 @@ wide_reduce_kernel) through the C ABI `sdf_spike_conv2d_fwd` with int8 digit pla
   * fused neuron: the spikes are delta-consistent with the oracle neuron on that fp64 pre-activation (0 unexplained decisions), and
     bit-equal to the C oracle neuron applied to the kernel's OWN fp32 pre-activation when it also stores it (membrane form);
   * against the streaming kernel on the fp16 planes of the same weights (the A/B reference)."""
-import os
-
 import pytest
 import torch
 
@@ -17,7 +15,13 @@ from sdformerflow_amd.synthetic import synth_uniform as rnd
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-os.environ["SDF_WIDE_CONV"] = "1"               # the form is opt-in (measured no faster than the streaming kernel + split-K on the shipped shape)
+
+
+@pytest.fixture(autouse=True)
+def _opt_in(monkeypatch):
+    """The form is opt-in (measured no faster than the streaming kernel + split-K on the shipped shape); the library reads the switch
+    per call, so it is set for these tests only."""
+    monkeypatch.setenv("SDF_WIDE_CONV", "1")
 
 
 def spikes(shape, seed, rate=0.3):
@@ -37,7 +41,7 @@ def _ref(x, w_eff, Cin, Cout, alpha, beta, resid):
 
 @pytest.mark.parametrize("B,T,H,W,Cin,Cout,with_res", [(1, 10, 9, 12, 768, 768, True), (1, 10, 9, 12, 768, 768, False), (2, 10, 5, 7, 384, 96, True),
                                                      (1, 20, 6, 5, 128, 64, True), (1, 10, 1, 1, 256, 32, False)])
-def test_fp32_epilogue_against_fp64(B, T, H, W, Cin, Cout, with_res):
+def test_fp32_epilogue_against_fp64(B, T, H, W, Cin, Cout, with_res, monkeypatch):
     imgs = B * T
     assert hip.wide_conv_applicable(imgs, H, W, Cin, Cout, 1, T)
     x = spikes((imgs, H, W, Cin), 300 + H)
@@ -52,13 +56,10 @@ def test_fp32_epilogue_against_fp64(B, T, H, W, Cin, Cout, with_res):
     assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
     # the streaming kernel on the fp16 planes of the same weights
     if Cout % 96 == 0:
-        os.environ["SDF_WIDE"] = "0"
-        try:
-            old = torch.empty_like(out)
-            hip.spike_conv2d(x.to(DEV), hip.pack_conv_weight(w.to(DEV), 2), imgs, H, W, Cin, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=old,
-                             alpha=alpha.to(DEV), beta=beta.to(DEV), resid=None if resid is None else resid.to(DEV))
-        finally:
-            os.environ.pop("SDF_WIDE", None)
+        monkeypatch.setenv("SDF_WIDE", "0")
+        old = torch.empty_like(out)
+        hip.spike_conv2d(x.to(DEV), hip.pack_conv_weight(w.to(DEV), 2), imgs, H, W, Cin, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=old,
+                         alpha=alpha.to(DEV), beta=beta.to(DEV), resid=None if resid is None else resid.to(DEV))
         assert (out - old).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
