@@ -229,6 +229,8 @@ typedef struct SdfSpikeGemmDesc {
 } SdfSpikeGemmDesc;
 
 #define SDF_PLANES_I8X3 4
+/* the same digits in MFMA fragment order (sdf_tile_weight_i8x3 below): what the small-M convolution kernel streams at full rate */
+#define SDF_PLANES_I8X3_TILED 5
 
 /* Weight-format helper for the 3x3 `layer.Conv2d` weights of MS_ResBlock / SEWResBlock (reference Spiking_modules.py:845-846,
  * 898-899; the reference has no counterpart - it multiplies fp32 weights with fp32 spike tensors in MIOpen / cuDNN).
@@ -237,6 +239,13 @@ typedef struct SdfSpikeGemmDesc {
  * top digit would leave int8), balanced base-256 digits.
  * Spikes are int8 values already: the spike x weight dot product becomes three exact int32 MFMA sums. */
 int sdf_split_weight_i8x3(const float* W, int8_t* planes, float* col_scale, int N, int K, void* stream);
+
+/* Digit planes [3][N][K] (sdf_split_weight_i8x3) -> fragment order [N / 16][K / 64][3][64][16 B]: the 1 KB a wave reads for one
+ * 16-column x 64-deep x one-plane MFMA operand is contiguous and in lane order (lane l: column 16 j + l % 16, k = 64 s + 16 (l / 16) ..).
+ * Same size as the planes; passed to sdf_spike_conv2d_fwd with nsplit = SDF_PLANES_I8X3_TILED and the same col_scale.  Only the
+ * small-M convolution (3x3 / stride 1, Cin % 64 == 0, at most 5 120 rows in (B, T, H, W) order: the U-Net bottleneck of reference
+ * Spiking_modules.py:906-933) reads it; other shapes return SDF_E_SHAPE.  N % 16 == 0, K % 64 == 0. */
+int sdf_tile_weight_i8x3(const int8_t* planes, int8_t* tiled, int N, int K, void* stream);
 
 int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream);
 

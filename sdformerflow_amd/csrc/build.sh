@@ -7,8 +7,8 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function -Wno-pass-failed ${SDF_EXTRA_FLAGS:-}"
 mkdir -p obj
 pids=()
-for f in ms_wide neuron neuron_bwd bn_train qk_attn qk_front ms_mlp_fused pred_head pointwise_conv qk_gate_train spike_gemm spike_mm_ws spike_mm_pp spike_conv_wres dense_conv_wres dense_linear qk_gate elementwise win_attn head_tail; do
-  if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ common.h -nt obj/$f.o ] || [ spike_mm.h -nt obj/$f.o ] || [ ../../include/sdformerflow_hip.h -nt obj/$f.o ]; then
+for f in ms_wide ms_smallm neuron neuron_bwd bn_train qk_attn qk_front ms_mlp_fused pred_head pointwise_conv qk_gate_train spike_gemm spike_mm_ws spike_mm_pp spike_conv_wres dense_conv_wres dense_linear qk_gate elementwise win_attn head_tail; do
+  if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ common.h -nt obj/$f.o ] || [ spike_mm.h -nt obj/$f.o ] || [ wide_common.h -nt obj/$f.o ] || [ ../../include/sdformerflow_hip.h -nt obj/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o obj/$f.o &
     pids+=($!)
   fi

@@ -1,0 +1,529 @@
+// Spike products that are SMALL IN ROWS against MANY weights, for gfx950: the 3x3 convolutions of the U-Net bottleneck's MS_ResBlocks
+// (reference Spiking_modules.py:906-933: 1 080 rows x 768 columns x K = 6 912 at batch 1 - 0.8 MB of spikes against 16 MB of weight
+// digits) and every other layer of that kind.  Row b of SURVEY.md section 8's table for rows a9 / a10.
+//
+// What the streaming kernels did with it (profiles/r3s_*, r4h_*): spike_mm_pp_kernel split K over 120 workgroups, wrote fp32 partials
+// and a second launch (splitk_reduce) added them, a third ran the neuron: 9.7 + 48.4 + 5.6 us per convolution, the weights streamed
+// at 0.4 TB/s.  The wide-stage main loop (ms_wide.hip) in a split-K form measured no better (50 + 20 us): with few rows per column
+// group its workgroups are all pipeline fill, and the partial sums are 3 x the output.
+//
+// Here the K split happens INSIDE a workgroup: a workgroup owns one output tile - 80 rows (= (20 / T) x 4 positions x all T steps, the
+// position-major unit of ms_wide.hip) x 32 columns - and its four waves take every fourth 64-deep K step of it.  No operand is shared
+// between waves, so the main loop has NO barrier.  Per step a wave loads 5 spike pieces and 6 weight-digit pieces of 1 KB, one step
+// ahead, and issues 30 v_mfma_i32_16x16x64_i8.  How the pieces are addressed decides the kernel (measured, round 4: 75 us with
+// fragment-shaped loads - lane = row + 16 k-group, i.e. 16 B from each of 16 different cache lines per lane quad - against the
+// texture path's one line per quad and clock):
+//   spikes  : a lane QUAD reads the 64 contiguous bytes of one row (lane = 4 row + piece), the wave writes the 1 KB piece to its own
+//             LDS strip as it arrived (ds_write_b128, lane-linear) and reads it back in MFMA order (ds_read_b128, lane = row + 16
+//             k-group); the pieces of a row sit XOR-swizzled by 2 (row / 8) so that read is conflict-free (the 16-lane groups of
+//             ds_read_b128, MI355X_MICROARCH.md section LDS).  Same-wave LDS operations execute in order: no barrier, no second strip;
+//   weights : pre-tiled at pack time (sdf_tile_weight_i8x3: [N / 16][K / 64][plane][lane][16 B] - every fragment is 1 KB contiguous in
+//             lane order), loaded straight into the registers the MFMA reads.  Row-major digit planes are read too (fragment-shaped
+//             loads: the slow form, kept for callers that only hold those).  The four partial accumulators are exact integers: they meet in LDS (the two
+// low digits first folded into one int32: 40 KB instead of 90), two barriers, then wave 0 holds the complete sums and runs the same
+// epilogue as the wide stages - BN, shortcut, LIF / IF over T in registers, spike bytes through the quad transpose - so one launch
+// replaces neuron + GEMM + reduce, and nothing but the output leaves the chip.  The grid is (column group) x (unit) with the column
+// group slowest: the workgroups of an XCD (ids equal mod 8) share a contiguous range of column groups, whose weight digits its L2
+// holds once (3 groups x 0.66 MB at the bottleneck) while every workgroup re-reads them; the 0.8 MB of spikes are L2-resident anyway.
+// What bounds it: 22 KB of operands per 60 MFMAs and wave, i.e. the L2 -> L1 path (64 B / clk / CU), not the matrix pipe.
+//
+// Results are bit-equal to any other order of the same integer sums (wide_pm_kernel, the row-major reference in the tests).
+#include "wide_common.h"
+#include <stdlib.h>
+
+#ifdef SDF_STAMP
+// diagnostic build only (tools/smallm_ablate.sh stamp): cycle accounting of every wave of the middle workgroup and every workgroup's
+// life in 100 MHz real time
+__device__ unsigned long long g_smallm_stamp[4 * 8];
+__device__ unsigned long long g_smallm_census[2 * 1024];
+#define MSTAMP(i) do { st[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MSTAMP(i)
+#endif
+
+namespace sdfmm {
+namespace {
+
+struct SmallMParams {
+  const uint8_t* A;          // AM 0: u8 [rows][K]; AM 1: NHWC u8 images, image = (b, t), K = 9 Cin in (tap, channel) order
+  const int8_t* W;           // digit planes [3][N][K], or tiled [N / 16][K / 64][3][64][16 B]
+  const float* cscale;       // (N) power-of-two scale of every output channel
+  int N, K, HW;
+  int64_t P;                 // positions = B * HW; rows = P * T in (B, T, HW) order
+  const float *bias, *alpha, *beta;
+  const float* resid;        // fp32 [rows][ldo] or null
+  float* out;                // fp32 [rows][ldo] (EPI & 2)
+  int ldo;
+  uint8_t* out_spike;        // u8 [rows][ldsp] (EPI & 1)
+  int ldsp;
+  SdfNeuronCfg sn;
+  float inv_tau;
+  int ncg, nunits;
+  int cv_H, cv_W, cv_Cin, cv_spt;      // convolution: 64-deep steps per tap
+};
+
+// EPI: 1 = neuron on BN(...) [+ shortcut] -> spikes, 2 = the fp32 value is stored, 3 = both.  AM: 0 = rows of a tensor, 1 = 3x3 taps.
+// BT: the weight digits are tiled.  CB = column blocks of a tile (2: 32 columns, two workgroups per compute unit, one operand step in
+// flight per wave; 3: 48 columns, one workgroup per compute unit, two steps in flight - fewer, larger tiles re-read less).
+template <int T, int EPI, int NK, int AM, bool BT, int CB>
+__global__ __launch_bounds__(256, CB == 2 ? 2 : 1) void smallm_kernel(SmallMParams P) {
+  constexpr int RB = RBW, NS = CB == 2 ? 1 : 2, NBUF = NS + 1, ROWS = 16 * RB, SLOTS = 4 * RB, PPG = SLOTS / T, PPW = 4 * PPG, BN = 16 * CB;
+  constexpr int SP = s_pitch(BN), STILE = ROWS * SP, NACC = RB * CB;
+  constexpr int REDB = 2 * 2 * NACC * 64 * 16;            // two waves x (lo, hi) x 10 accumulator quads x 64 lanes
+  static_assert(SLOTS % T == 0, "T must divide the 20 accumulator slots of a lane");
+  static_assert(STILE <= REDB, "the byte tile aliases the reduction buffer");
+  __shared__ __attribute__((aligned(16))) uint8_t smem[REDB];
+  __shared__ __attribute__((aligned(16))) uint8_t strip[4][RB * 1024];     // per wave: one step's spike pieces on their way to MFMA order
+  __shared__ int32_t rowtab[ROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, lq = lane >> 4;
+  int item = blockIdx.x;
+  const int G = gridDim.x;
+  if ((G & 7) == 0) item = (item & 7) * (G >> 3) + (item >> 3);
+  if (item >= P.ncg * P.nunits) return;
+#ifdef SDF_STAMP
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+  auto stamp_out = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MSTAMP(5);
+    if (lane == 0 && wave == 0 && blockIdx.x < 1024) {
+      g_smallm_census[2 * blockIdx.x] = rt0;
+      g_smallm_census[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (lane == 0 && blockIdx.x == gridDim.x / 2) {
+      unsigned long long* o = g_smallm_stamp + 8 * wave;
+      for (int i = 0; i < 5; ++i) o[i] = st[i + 1] > st[i] ? st[i + 1] - st[i] : 0;
+      o[5] = st[5] - st[0]; o[6] = __builtin_amdgcn_s_memrealtime() - rt0; o[7] = gridDim.x;
+    }
+  };
+#endif
+  MSTAMP(0);
+  const int cg = item / P.nunits, unit = item - cg * P.nunits;
+  const int n0 = cg * BN, K = P.K, N = P.N, HW = P.HW;
+  const __amdgpu_buffer_rsrc_t A_rs = make_rsrc(P.A), W_rs = make_rsrc(P.W);
+  const int nst = K >> 6;
+
+  // L2 warm-up.  The workgroups of an XCD stream the SAME few column groups' weights (and all of the spikes) at the same pace: left to
+  // the main loop, every new line is one HBM / Infinity-Cache miss that all of them wait for - the stream ran at one miss latency per
+  // step (measured: 32 us at 27 steps).  Instead every wave of the XCD touches its share of those bytes once, up front, one lane per
+  // 128-byte line: the whole working set (2 - 3 MB per XCD) arrives in about one latency, the main loop hits L2.  The values are not
+  // used; they are "consumed" behind the first operand requests (in-order return: that wait does not cover the operands).
+  uint32_t pf[6] = {0, 0, 0, 0, 0, 0};
+  if constexpr (BT) {
+    const int per = G >> 3, first = (blockIdx.x & 7) * per;
+    const uint32_t nw = 4u * (uint32_t)per, wi = 4u * (uint32_t)((blockIdx.x >> 3)) + (uint32_t)wave;
+    const int cg_lo = first / P.nunits, cg_hi = min(P.ncg - 1, (first + per - 1) / P.nunits);
+    const uint32_t cgb = (uint32_t)(CB * nst) * 3072u, wbase = (uint32_t)cg_lo * cgb, wlines = ((uint32_t)(cg_hi - cg_lo + 1) * cgb) >> 7;
+    const uint32_t Lw = (wlines + nw - 1) / nw;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t ln = 64u * j + lane, line = wi * Lw + ln;
+      pf[j] = __builtin_amdgcn_raw_buffer_load_b32(W_rs, (ln < Lw && line < wlines) ? wbase + line * 128u : INV, 0, 0);
+    }
+    const uint32_t alines = (uint32_t)(((int64_t)P.P * T * (AM == 1 ? P.cv_Cin : K)) >> 7), La = (alines + nw - 1) / nw;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t ln = 64u * j + lane, line = wi * La + ln;
+      pf[4 + j] = __builtin_amdgcn_raw_buffer_load_b32(A_rs, (ln < La && line < alines) ? line * 128u : INV, 0, 0);
+    }
+  }
+
+  // activation row (or -1) of every tile row
+  if (tid < ROWS) {
+    const int rb = tid >> 4, i = tid & 15, qq = i >> 2, slot = 4 * rb + (i & 3);
+    const int pp = slot / T, t = slot - pp * T;
+    const uint32_t pos = (uint32_t)unit * PPW + qq * PPG + pp;
+    int32_t g = -1;
+    if (pos < (uint32_t)P.P) {
+      const uint32_t b = pos / (uint32_t)HW, hw = pos - b * (uint32_t)HW;
+      g = (int32_t)((b * T + t) * (uint32_t)HW + hw);
+    }
+    rowtab[tid] = g;
+  }
+  __syncthreads();
+  // spike pieces: this lane loads piece (lane & 3) ^ swz of tile row 16 rb + lane / 4, swz = 2 (row / 8): LDS slot = lane
+  uint32_t a_base[RB], a_mask[RB], b_off[CB];
+  const int lr = lane >> 2, lp = (lane & 3) ^ ((lr >> 2) & 2);
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int32_t g = rowtab[16 * rb + lr];
+    a_base[rb] = INV;
+    a_mask[rb] = 0;
+    if (g >= 0) {
+      if constexpr (AM == 1) {
+        const uint32_t pix = (uint32_t)g % (uint32_t)HW, y = pix / (uint32_t)P.cv_W, xx = pix - y * (uint32_t)P.cv_W;
+        a_base[rb] = (uint32_t)g * (uint32_t)P.cv_Cin + 16u * lp;
+        uint32_t m = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int yy = (int)y + tap / 3 - 1, xw = (int)xx + tap % 3 - 1;
+          if (yy >= 0 && yy < P.cv_H && xw >= 0 && xw < P.cv_W) m |= 1u << tap;
+        }
+        a_mask[rb] = m;
+      } else {
+        a_base[rb] = (uint32_t)g * (uint32_t)K + 16u * lp;
+      }
+    }
+  }
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    if constexpr (BT) b_off[cb] = n0 + 16 * cb < N ? (uint32_t)(((n0 >> 4) + cb) * nst) * 3072u + 16u * lane : INV;
+    else b_off[cb] = n0 + 16 * cb + l16 < N ? (uint32_t)(n0 + 16 * cb + l16) * (uint32_t)K + 16u * lq : INV;
+  }
+  // MFMA-order read of the strip: lane = row + 16 k-group -> slot 4 row + (k-group ^ swz)
+  uint8_t* mystrip = strip[wave];
+  const uint32_t rd_off = (uint32_t)((4 * l16 + (lq ^ ((l16 >> 2) & 2))) * 16), wr_off = 16u * lane;
+
+  i32x4 acc[3][RB][CB];
+#pragma unroll
+  for (int dg = 0; dg < 3; ++dg)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[dg][rb][cb] = i32x4{0, 0, 0, 0};
+
+  // ---------------- main loop: this wave's steps s = wave, wave + 4, ... ----------------
+  constexpr bool DBL = CB == 3;                            // registers for two sets of MFMA-order spike fragments (one workgroup per CU)
+  i32x4 araw[NS][RB], a2[DBL ? 2 : 1][RB], b[NBUF][3][CB];
+  int sa_next = wave, sb_next = wave;                      // next step whose spikes / weights are requested (scalar)
+  int tap = 0, cstep = 0;                                  // convolution: sa_next = tap * spt + cstep
+  if constexpr (AM == 1) { tap = wave / P.cv_spt; cstep = wave - tap * P.cv_spt; }
+  const uint32_t plane = (uint32_t)N * (uint32_t)K;
+#ifdef SMX_NOA
+  constexpr bool XA = false;                               // (diagnostic builds, tools/smallm_ablate.sh: one operand's loads read nothing)
+#else
+  constexpr bool XA = true;
+#endif
+#ifdef SMX_NOB
+  constexpr bool XB = false;
+#else
+  constexpr bool XB = true;
+#endif
+  auto issue_a = [&](int ra) __attribute__((always_inline)) {
+    const bool in = XA && sa_next < nst;
+    if constexpr (AM == 1) {
+      const uint32_t toff = (uint32_t)(((tap / 3 - 1) * P.cv_W + (tap % 3 - 1)) * P.cv_Cin), cin0 = (uint32_t)cstep * 64u;
+      // (a step beyond the last has tap >= 9: no mask bit - the select is arithmetic, a branch here would cost a vmcnt(0))
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const uint32_t ok = (0u - ((a_mask[rb] >> tap) & 1u)) & (0u - (uint32_t)XA);
+        araw[ra][rb] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(A_rs, ((a_base[rb] + toff) & ok) | (INV & ~ok), cin0, 0));
+      }
+      cstep += 4;                                          // (four steps further; a tap has cv_spt >= 1 steps)
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (cstep >= P.cv_spt) { cstep -= P.cv_spt; ++tap; }
+    } else {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+        araw[ra][rb] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(A_rs, in ? a_base[rb] : INV, (uint32_t)sa_next * 64u, 0));
+    }
+    sa_next += 4;
+  };
+  auto issue_b = [&](int rbuf) __attribute__((always_inline)) {
+    const bool in = XB && sb_next < nst;
+#pragma unroll
+    for (int dg = 0; dg < 3; ++dg)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const uint32_t so = BT ? (uint32_t)(sb_next * 3 + dg) * 1024u : (uint32_t)dg * plane + (uint32_t)sb_next * 64u;
+        b[rbuf][dg][cb] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(W_rs, in ? b_off[cb] : INV, so, 0));
+      }
+    sb_next += 4;
+  };
+  auto strip_write = [&](int ra) __attribute__((always_inline)) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) *reinterpret_cast<i32x4*>(mystrip + rb * 1024 + wr_off) = araw[ra][rb];
+  };
+  auto strip_read = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) a2[set][rb] = *reinterpret_cast<const i32x4*>(mystrip + rb * 1024 + rd_off);
+  };
+  // Step i: 3 CB groups of RB MFMAs on (spike fragments of step i, weight fragments requested NS + 1 steps ago).  Everything the NEXT
+  // step needs rides behind those groups: its spike pieces (requested NS steps ago) go raw registers -> strip behind group 0, the raw
+  // registers are re-requested (step i + 1 + NS) behind group 1, the strip is read back in MFMA order behind group 2 (into the second
+  // fragment set; with one set - the 32-column tile, 128 registers - behind the last group), and the weight registers this step used
+  // are re-requested (step i + NBUF) at its end.  Same-wave LDS operations execute in order: one strip, no barrier.
+  auto step = [&](int i) __attribute__((always_inline)) {
+    const int cur = DBL ? (i & 1) : 0, nxt = DBL ? (cur ^ 1) : 0;
+#pragma unroll
+    for (int g = 0; g < 3 * CB; ++g) {
+      const int dg = g / CB, cb = g - dg * CB;
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+#ifndef SMX_NOMFMA
+        mfma_i8(acc[dg][rb][cb], a2[cur][rb], b[i % NBUF][dg][cb]);
+#else
+        asm volatile("" :: "v"(a2[cur][rb]), "v"(b[i % NBUF][dg][cb]));
+#endif
+      }
+      if (g == 0) strip_write((i + 1) % NS);
+      if (g == 1) issue_a((i + 1) % NS);
+      if (g == 2 && DBL) strip_read(nxt);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!DBL) strip_read(nxt);
+    issue_b(i % NBUF);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  MSTAMP(1);
+#pragma unroll
+  for (int j = 0; j < NS; ++j) issue_a(j);
+#pragma unroll
+  for (int j = 0; j < NBUF; ++j) issue_b(j);
+  asm volatile("" :: "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]));      // (the warm-up loads end here)
+  strip_write(0);
+  issue_a(0);
+  strip_read(0);
+  __builtin_amdgcn_sched_barrier(0);
+  constexpr int U = DBL ? 6 : 2;                           // steps per round: every register ring is back where it started
+  static_assert(U % NS == 0 && U % NBUF == 0, "ring sizes divide the round");
+  const int nrounds = ((nst + 3) / 4 + U - 1) / U;         // (uniform over the workgroup: steps beyond the wave's last multiply zeros)
+#pragma unroll 1
+  for (int r = 0; r < nrounds; ++r) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) step(j);
+  }
+
+  MSTAMP(2);
+  // ---------------- the four partial sums meet: (lo, hi) = (d1 256 + d0, d2) as exact int32, tree over two barriers ----------------
+  i32x4 lo[RB][CB], hi[RB][CB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      lo[rb][cb] = acc[1][rb][cb] * 256 + acc[0][rb][cb];
+      hi[rb][cb] = acc[2][rb][cb];
+    }
+  const int c = lane & 15, q = lane >> 4;
+  uint32_t xo[SLOTS];
+  float res[CB][SLOTS];
+  float al[CB], be[CB], bs[CB], cs[CB];
+  if (wave == 0) {                                         // the shortcut values and column parameters travel under the reduction
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const int32_t g = rowtab[16 * (s >> 2) + 4 * q + (s & 3)];
+      xo[s] = (g >= 0 && n0 + c < N) ? ((uint32_t)g * (uint32_t)P.ldo + (uint32_t)(n0 + c)) * 4u : INV;
+    }
+    const __amdgpu_buffer_rsrc_t r_rs = make_rsrc(P.resid);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s)
+        res[cb][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, (n0 + 16 * cb + c < N && P.resid) ? xo[s] : INV, 64u * cb, 0));
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      const int n = n0 + 16 * cb + c;
+      const int nc = n < N ? n : 0;
+      al[cb] = P.alpha ? P.alpha[nc] : 1.f;
+      be[cb] = P.alpha ? P.beta[nc] : 0.f;
+      bs[cb] = P.bias ? P.bias[nc] : 0.f;
+      cs[cb] = P.cscale[nc];
+    }
+  }
+  i32x4* red = reinterpret_cast<i32x4*>(smem);
+  auto red_write = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        red[((slot * 2 + 0) * NACC + rb * CB + cb) * 64 + lane] = lo[rb][cb];
+        red[((slot * 2 + 1) * NACC + rb * CB + cb) * 64 + lane] = hi[rb][cb];
+      }
+  };
+  auto red_add = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        lo[rb][cb] += red[((slot * 2 + 0) * NACC + rb * CB + cb) * 64 + lane];
+        hi[rb][cb] += red[((slot * 2 + 1) * NACC + rb * CB + cb) * 64 + lane];
+      }
+  };
+  if (wave >= 2) red_write(wave - 2);
+  __syncthreads();
+  if (wave < 2) red_add(wave);
+  __syncthreads();
+  if (wave == 1) red_write(0);
+  __syncthreads();
+  MSTAMP(3);
+#ifdef SDF_STAMP
+  if (wave != 0) { st[4] = st[3]; stamp_out(); return; }
+#else
+  if (wave != 0) return;
+#endif
+  red_add(0);
+
+  // ---------------- epilogue (wave 0): BN (+ bias), shortcut, [store], [neuron over T -> spike bytes] ----------------
+  const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(P.out), o_rs = make_rsrc(P.out_spike);
+  float val[CB][SLOTS];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      float v = __builtin_fmaf((float)hi[s >> 2][cb][s & 3], 65536.f, (float)lo[s >> 2][cb][s & 3]) * cs[cb];
+      v = v + bs[cb];
+      v = __builtin_fmaf(v, al[cb], be[cb]);
+      v = v + res[cb][s];
+      val[cb][s] = v;
+      if constexpr ((EPI & 2) != 0)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), x_rs, (n0 + 16 * cb + c < N) ? xo[s] : INV, 64u * cb, 0);
+    }
+  if constexpr ((EPI & 1) != 0) {
+    uint8_t* S = smem;                                     // byte tile [80][SP] over the reduction buffer (this wave's reads of it are done)
+    uint32_t sel1, sel2;
+    quad_sel(lane, sel1, sel2);
+    const int m4 = (c >> 2), ci = c & 3;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      uint32_t bits = 0;
+#pragma unroll
+      for (int pp = 0; pp < PPG; ++pp) {
+        float xs[T], sp[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) xs[t] = val[cb][pp * T + t];
+        neuron_T<NK, T>(xs, sp, P.sn, P.inv_tau);
+#pragma unroll
+        for (int t = 0; t < T; ++t) bits |= ((__float_as_uint(sp[t]) >> 29) & 1u) << (pp * T + t);      // 1.0f has bit 29 set
+      }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const uint32_t w = quad_tr_bytes(spread4(bits >> (4 * rb)), sel1, sel2);
+        *reinterpret_cast<uint32_t*>(S + (16 * rb + 4 * q + ci) * SP + 16 * cb + 4 * m4) = w;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < (ROWS * CB + 63) / 64; ++it) {
+      const int pc = lane + 64 * it;
+      if (pc < ROWS * CB) {
+        const int r = pc / CB, k16 = pc % CB;
+        const int32_t g = rowtab[r];
+        const u32x4 v = *reinterpret_cast<const u32x4*>(S + r * SP + 16 * k16);
+        const uint32_t off = (g >= 0 && n0 + 16 * k16 < N) ? (uint32_t)g * (uint32_t)P.ldsp + (uint32_t)(n0 + 16 * k16) : INV;
+        __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, off, 0, 0);
+      }
+    }
+  }
+#ifdef SDF_STAMP
+  MSTAMP(4);
+  stamp_out();
+#endif
+}
+
+template <int T, int AM, bool BT, int CB>
+void launch_t(const SmallMParams& P, int epi, int nk, dim3 grid, hipStream_t s) {
+  if (epi == 2) hipLaunchKernelGGL((smallm_kernel<T, 2, 0, AM, BT, CB>), grid, dim3(256), 0, s, P);
+  else if (epi == 1) {
+    if (nk == 0) hipLaunchKernelGGL((smallm_kernel<T, 1, 0, AM, BT, CB>), grid, dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((smallm_kernel<T, 1, 2, AM, BT, CB>), grid, dim3(256), 0, s, P);
+  } else {
+    if (nk == 0) hipLaunchKernelGGL((smallm_kernel<T, 3, 0, AM, BT, CB>), grid, dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((smallm_kernel<T, 3, 2, AM, BT, CB>), grid, dim3(256), 0, s, P);
+  }
+}
+
+template <int T, int AM>
+void launch_bt(const SmallMParams& P, int epi, int nk, bool bt, int cb, dim3 grid, hipStream_t s) {
+  if (bt) { if (cb == 3) launch_t<T, AM, true, 3>(P, epi, nk, grid, s); else launch_t<T, AM, true, 2>(P, epi, nk, grid, s); }
+  else launch_t<T, AM, false, 2>(P, epi, nk, grid, s);
+}
+
+// fp32 digit planes [3][N][K] -> fragment order [N / 16][K / 64][3][64 lanes][16 B]: lane l of fragment (column block, step, plane) holds
+// W[plane][16 block + l % 16][64 step + 16 (l / 16) ...]
+__global__ __launch_bounds__(256) void tile_weight_i8x3_kernel(const int8_t* __restrict__ planes, int8_t* __restrict__ tiled, int N, int K) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, total = (int64_t)3 * N * (K >> 4);
+  if (i >= total) return;
+  const int lane = (int)(i & 63);
+  int64_t f = i >> 6;
+  const int p = (int)(f % 3);
+  f /= 3;
+  const int nst = K >> 6, st = (int)(f % nst), cbk = (int)(f / nst);
+  const int8_t* src = planes + ((int64_t)p * N + 16 * cbk + (lane & 15)) * K + 64 * st + 16 * (lane >> 4);
+  *reinterpret_cast<u32x4*>(tiled + i * 16) = *reinterpret_cast<const u32x4*>(src);
+}
+
+}  // namespace
+
+static bool smallm_neuron_ok(const SdfNeuronCfg& n) {
+  if (n.kind != SDF_LIF && n.kind != SDF_IF) return false;
+  return sdf_tau_ok(n.kind, n.tau);
+}
+
+// 3x3 / stride 1 / pad 1 spike convolution in (B, T, H, W) row order with int8 digit planes, up to SMALLM_MAX_ROWS rows: beyond that the
+// weight re-reads of the (unit x column group) grid outgrow what the streaming kernels pay (they keep those shapes)
+constexpr int64_t SMALLM_MAX_ROWS = 64 * 80;
+
+bool smallm_conv_supports(const GemmParams& P) {
+  const SdfSpikeGemmDesc& d = P.d;
+  const ConvGeom& cv = P.cv;
+  if (const char* e = getenv("SDF_SMALLM")) { if (e[0] == '0') return false; }
+  if ((d.nsplit != SDF_PLANES_I8X3 && d.nsplit != SDF_PLANES_I8X3_TILED) || !d.col_scale) return false;
+  if (cv.KWc != 3 || d.K != 9 * cv.Cin || cv.Cin % 64 || cv.sy != 1 || cv.sx != 1 || cv.OH != cv.H || cv.OW != cv.W) return false;
+  if (cv.dy[0] != -1 || cv.dy[1] != 0 || cv.dy[2] != 1 || cv.dx[0] != -1 || cv.dx[1] != 0 || cv.dx[2] != 1) return false;
+  if (d.N % 32 || d.out_rowmap || d.bias || d.add || d.zg_nH) return false;
+  const int64_t hw = (int64_t)cv.H * cv.W, imgs = d.M / hw;
+  int T = d.sn_T;
+  if (T == 0) T = imgs % 10 == 0 ? 10 : (imgs % 20 == 0 ? 20 : 0);
+  if (T != 10 && T != 20) return false;
+  if (imgs % T || d.M > SMALLM_MAX_ROWS) return false;
+  if (d.sn_T > 0) {
+    if (!smallm_neuron_ok({d.sn_kind, d.tau, d.v_th, d.v_reset, d.soft_reset, nullptr, nullptr})) return false;
+    if (d.pos_inner != hw || d.t_stride != hw || d.pos_ostride != (int64_t)T * hw || d.pos_count * T != d.M) return false;   // rows (b, t, pixel)
+    if (!d.out_spike) return false;
+  } else if (!d.out) {
+    return false;
+  }
+  if (d.M * (int64_t)cv.Cin >= (1LL << 31) || d.M * (int64_t)d.N * 4 >= (1LL << 31) || (int64_t)d.N * d.K * 3 >= (1LL << 31)) return false;
+  return sdf_aligned(d.A, 16) && sdf_aligned(d.Wp, 16) && (!d.out || sdf_aligned(d.out, 16)) && (!d.resid || sdf_aligned(d.resid, 16)) &&
+         (!d.out_spike || sdf_aligned(d.out_spike, 16)) && (!d.out || d.ldo == d.N);
+}
+
+int launch_smallm_conv(const GemmParams& G, hipStream_t s) {
+  const SdfSpikeGemmDesc& d = G.d;
+  const ConvGeom& cv = G.cv;
+  const int64_t hw = (int64_t)cv.H * cv.W, imgs = d.M / hw;
+  int T = d.sn_T;
+  if (T == 0) T = imgs % 10 == 0 ? 10 : 20;
+  SmallMParams P = {};
+  P.A = d.A; P.W = reinterpret_cast<const int8_t*>(d.Wp); P.cscale = d.col_scale; P.N = d.N; P.K = d.K; P.HW = (int)hw; P.P = (imgs / T) * hw;
+  P.alpha = d.alpha; P.beta = d.beta; P.resid = d.resid; P.out = d.out; P.ldo = d.N;
+  P.out_spike = d.sn_T > 0 ? d.out_spike : nullptr; P.ldsp = d.N;
+  P.sn = {d.sn_kind, d.tau, d.v_th, d.v_reset, d.soft_reset, nullptr, nullptr};
+  P.inv_tau = d.sn_T > 0 ? inv_tau_of(P.sn) : 0.f;
+  P.cv_H = cv.H; P.cv_W = cv.W; P.cv_Cin = cv.Cin; P.cv_spt = cv.Cin / 64;
+  const int PPW = 4 * (20 / T);
+  P.nunits = (int)((P.P + PPW - 1) / PPW);
+  const bool bt = d.nsplit == SDF_PLANES_I8X3_TILED;
+  // tile width: 48 columns where that is one workgroup per compute unit at most (fewer re-reads of the spikes, deeper prefetch) and the
+  // 32-column grid would not fit the chip in one round either; else 32 columns (two workgroups per compute unit)
+  int cb = 2;
+  if (bt && d.N % 48 == 0 && (int64_t)(d.N / 32) * P.nunits > 256 && (int64_t)(d.N / 48) * P.nunits <= 256) cb = 3;
+  if (const char* e = getenv("SDF_SMALLM_CB")) { if (bt && e[0] == '3' && d.N % 48 == 0) cb = 3; else if (e[0] == '2') cb = 2; }   // tuning override
+  P.ncg = d.N / (16 * cb);
+  const int64_t items = (int64_t)P.ncg * P.nunits;
+  const dim3 grid((unsigned)((items + 7) / 8 * 8));
+  const int epi = d.sn_T > 0 ? (d.out ? 3 : 1) : 2, nk = d.sn_T > 0 ? neuron_class(P.sn) : 0;
+  if (T == 10) launch_bt<10, 1>(P, epi, nk, bt, cb, grid, s); else launch_bt<20, 1>(P, epi, nk, bt, cb, grid, s);
+  hipError_t e = hipGetLastError();
+  return e != hipSuccess ? (int)e : 0;
+}
+
+}  // namespace sdfmm
+
+#ifdef SDF_STAMP
+extern "C" int sdf_debug_read_stamps_smallm(unsigned long long* host32, unsigned long long* census) {
+  (void)hipMemcpyFromSymbol(census, HIP_SYMBOL(g_smallm_census), sizeof(g_smallm_census));
+  return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(g_smallm_stamp), sizeof(g_smallm_stamp));
+}
+#endif
+
+extern "C" int sdf_tile_weight_i8x3(const int8_t* planes, int8_t* tiled, int N, int K, void* stream) {
+  if (!planes || !tiled) return SDF_E_NULL;
+  if (N < 16 || N % 16 || K < 64 || K % 64 || (int64_t)3 * N * K >= (1LL << 31)) return SDF_E_SHAPE;
+  if (!sdf_aligned(planes, 16) || !sdf_aligned(tiled, 16)) return SDF_E_ALIGN;
+  const int64_t total = (int64_t)3 * N * (K >> 4);
+  hipLaunchKernelGGL(sdfmm::tile_weight_i8x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sdf_stream(stream), planes, tiled, N, K);
+  SDF_LAUNCH_CHECK();
+  return 0;
+}

@@ -32,7 +32,7 @@
 // 4 x 4 byte transpose inside each lane quad (two DPP moves + two v_perm) so that a lane holds four consecutive CHANNELS of a row,
 // one ds_write_b32 into a per-wave LDS tile and 16-byte global stores.  The fp32 shortcut is read and written in the accumulator
 // layout (64-byte runs per row and column block; the buffers are L2-resident at these sizes).
-#include "spike_mm.h"
+#include "wide_common.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -66,59 +66,6 @@ __device__ unsigned long long g_wide_loop[8];          // main-loop phases of th
 
 namespace sdfmm {
 namespace {
-
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-constexpr uint32_t INV = 0x80000000u;               // buffer offset of "no such row": loads return zeros, stores are dropped
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)INV, 0x00020000);
-}
-
-// 4 bits -> 4 bytes {0, 1}: bit i lands in byte i (i + 7 i = 8 i; the cross terms i + 7 k, k != i, miss every byte's bit 0)
-__device__ __forceinline__ uint32_t spread4(uint32_t nib) { return __umul24(nib & 0xFu, 0x204081u) & 0x01010101u; }
-
-// 4 x 4 byte transpose inside every quad of lanes: in: lane i of the quad holds bytes (rows 0..3) of column i; out: lane i holds
-// bytes (columns 0..3) of row i.  sel1 / sel2 are the lane's v_perm selectors (quad_sel).
-__device__ __forceinline__ void quad_sel(int lane, uint32_t& sel1, uint32_t& sel2) {
-  sel1 = (lane & 1) ? 0x03070105u : 0x06020400u;
-  sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
-}
-__device__ __forceinline__ uint32_t quad_tr_bytes(uint32_t w, uint32_t sel1, uint32_t sel2) {
-  const uint32_t t1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xF, 0xF, false);     // lane ^ 1
-  const uint32_t a = __builtin_amdgcn_perm(t1, w, sel1);
-  const uint32_t t2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x4E, 0xF, 0xF, false);     // lane ^ 2
-  return __builtin_amdgcn_perm(t2, a, sel2);
-}
-
-// sum over the 16 lanes of a DPP row (all lanes end with the total)
-__device__ __forceinline__ uint32_t row_sum16(uint32_t v) {
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);                    // quad_perm [1,0,3,2]
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);                    // quad_perm [2,3,0,1]
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);                   // row_half_mirror
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);                   // row_mirror
-  return v;
-}
-
-typedef __attribute__((ext_vector_type(4))) int i32x4;
-constexpr int KCH = 128;                             // K chunk = two 64-deep MFMA steps
-constexpr int RBW = 5;                               // row blocks of a wave in the position-major kernel: 80 rows = 20 slots per lane
-
-__host__ __device__ constexpr int s_pitch(int bytes) { return ((bytes + 16) / 4) % 8 == 4 ? bytes + 16 : bytes + 32; }
-__host__ __device__ constexpr int w_pieces(int CB) { return 3 * 16 * CB * 8; }                   // 16-byte pieces of a weight chunk
-__host__ __device__ constexpr int w_steps(int CB) { return (w_pieces(CB) + 255) / 256; }         // per thread (256 threads)
-__host__ __device__ constexpr int w_buf(int CB) { return w_pieces(CB) * 16 + 16; }               // ring buffer bytes (+ a dump slot)
-
-// acc += A x B on the int8 matrix pipe, accumulating IN PLACE in the accumulator registers.  Written as inline assembly with the
-// accumulator tied to an AGPR quad: left to the register allocator (the builtin), the 120 - 240 accumulators of a wave were split
-// between VGPRs and AGPRs and shuttled through a scratch quad around every MFMA (4 copies + wait states each: the matrix pipe ran
-// at half rate, /tmp ISA of round 4).  The same accumulator is not touched again for >= 30 MFMAs (no software wait states needed).
-__device__ __forceinline__ void mfma_i8(i32x4& acc, const i32x4& a, const i32x4& b) {
-  asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-}
-
-// the three exact integer sums of an output -> one fp32 number (the two low digits meet as integers: < 2^27 at K = 3072)
-__device__ __forceinline__ float digits_f32(int a0, int a1, int a2) { return __builtin_fmaf((float)a2, 65536.f, (float)(a1 * 256 + a0)); }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // The shared main loop.  acc[digit][rb][cb] += A[rows of this wave][K] x D_digit[BN columns][K]^T over K = 128 nchunks.

@@ -551,7 +551,8 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
   if (c->Cin < 48 || c->Cin % 16 || c->KH < 1 || c->KH > 3 || c->KW < 1 || c->KW > 3 || c->sy < 1 || c->sx < 1) return SDF_E_SHAPE;
   if (d->K != c->KH * c->KW * c->Cin || d->N % 32 || d->M % ((int64_t)c->OH * c->OW) || d->M >= (1LL << 31)) return SDF_E_SHAPE;
   if ((d->M / ((int64_t)c->OH * c->OW)) * c->H * c->W >= (1LL << 31)) return SDF_E_SHAPE;
-  const bool i8x3 = d->nsplit == SDF_PLANES_I8X3;                 // int8 digit planes: only the weight-resident kernel reads them
+  const bool tiled = d->nsplit == SDF_PLANES_I8X3_TILED;          // digit planes in fragment order: only the small-M kernel reads them
+  const bool i8x3 = d->nsplit == SDF_PLANES_I8X3 || tiled;       // int8 digit planes: the weight-resident / wide / small-M kernels
   if (!i8x3 && (d->nsplit < 1 || d->nsplit > 3)) return SDF_E_DTYPE;
   if (!i8x3 && !sdf_scale_ok(d)) return SDF_E_DTYPE;
   if (i8x3 && !d->col_scale) return SDF_E_NULL;
@@ -580,9 +581,11 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
   cv.KWc = c->KW;
   cv.kw_mul = c->KW == 1 ? 32 : (c->KW == 2 ? 16 : 11);
   for (int i = 0; i < 3; ++i) { cv.dy[i] = c->dy[i]; cv.dx[i] = c->dx[i]; }
-  // few rows against many weights (the U-Net bottleneck's res-blocks) with digit planes: split-K over the chip on the wide-stage
-  // main loop + one reduce / BN / shortcut / neuron pass (csrc/ms_wide.hip)
+  // few rows against many weights (the U-Net bottleneck's res-blocks) with digit planes: one launch, K split over the waves of a
+  // workgroup (csrc/ms_smallm.hip); SDF_WIDE_CONV=1 selects the split-K-over-workgroups form it replaced (csrc/ms_wide.hip, A/B)
   if (i8x3 && wide_conv_supports(P)) return launch_wide_conv(P, sdf_stream(stream));
+  if (i8x3 && smallm_conv_supports(P)) return launch_smallm_conv(P, sdf_stream(stream));
+  if (tiled) return SDF_E_SHAPE;
   // 3x3 / stride 1 on 96 channels with enough tiles to fill the chip: weights resident in LDS, halo tiles instead of im2col
   const char* ewr = getenv("SDF_CONV_WRES");                  // A/B override: 0 = always the streaming kernels below, 2 = at any size
   if (!(ewr && ewr[0] == '0') && spike_conv_wres_supports(P, i8x3 || (ewr && ewr[0] == '2'))) return launch_spike_conv_wres(P, sdf_stream(stream));

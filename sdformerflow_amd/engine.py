@@ -109,13 +109,12 @@ def _conv_planes(w, nsplit, cin_pad=None):
 
 
 def _conv_digits(w, nsplit):
-    """int8 digit planes of a 3x3 convolution on 96 input channels (what the weight-resident kernel reads for large launches,
-    csrc/spike_conv_wres.hip); None where that kernel has no instantiation or the exact 3-plane / 1-plane modes were asked for."""
-    import os
-    wide = os.environ.get("SDF_WIDE_CONV", "") == "1" and w.shape[1] % 128 == 0       # (opt-in small-M split-K form, csrc/ms_wide.hip)
-    if nsplit != 2 or tuple(w.shape[2:]) != (3, 3) or w.shape[0] % 32 or not (w.shape[1] == 96 or wide):
+    """int8 digit planes of a 3x3 convolution: on 96 input channels what the weight-resident kernel reads for large launches
+    (csrc/spike_conv_wres.hip), on multiples of 64 what the small-M kernel reads (csrc/ms_smallm.hip: the U-Net bottleneck); None where
+    neither has an instantiation or the exact 3-plane / 1-plane modes were asked for."""
+    if nsplit != 2 or tuple(w.shape[2:]) != (3, 3) or w.shape[0] % 32 or not (w.shape[1] == 96 or w.shape[1] % 64 == 0):
         return None
-    return hip.pack_conv_weight_i8x3(w.detach().float())
+    return hip.pack_conv_weight_i8x3(w.detach().float(), tiled=w.shape[1] != 96)       # (fragment order: only the small-M kernel reads those)
 
 
 class _ResBlock:
@@ -294,9 +293,9 @@ class MSFlowEngine:
         a, b = bn if bn is not None else (None, None)
         # large 3x3 / stride-1 launches on 96 channels: int8 digit planes, weights resident in LDS (csrc/spike_conv_wres.hip)
         digits = getattr(Wp, "digits", None)
-        if digits is not None and (sn is None or sn.kind in ("lif", "if")) and hip.wide_conv_applicable(B * D, h, w, Cin, Cout, stride, D):
-            # few rows against many weights (the U-Net bottleneck: 1 080 rows x 768 x 6 912): split-K over the whole chip + one pass
-            # for the sum, BN, shortcut and neuron (csrc/ms_wide.hip)
+        if digits is not None and (sn is None or sn.kind in ("lif", "if")) and hip.smallm_conv_applicable(B * D, h, w, Cin, Cout, stride, D):
+            # few rows against many weights (the U-Net bottleneck: 1 080 rows x 768 x 6 912): one launch, K split over the waves of a
+            # workgroup, sum + BN + shortcut + neuron in its epilogue (csrc/ms_smallm.hip)
             out = None if sn is not None and not membrane else torch.empty((B, D, oh, ow, Cout), dtype=torch.float32, device=s.device)
             sp = torch.empty((B, D, oh, ow, Cout), dtype=torch.uint8, device=s.device) if sn is not None else None
             hip.spike_conv2d(s, digits, B * D, h, w, Cin, oh, ow, 3, 3, stride, (-1, 0, 1), (-1, 0, 1), out=out, out_spike=sp, alpha=a, beta=b,
@@ -373,7 +372,7 @@ class MSFlowEngine:
             s1 = self._neuron_bd(m, rb.sn1)
         self._rec(rb.name + "sn1.spiking_neuron.", s1, "BDHWC->TBCHW")
         fus = self._fusable(B, D, h, w, rb.C, rb.w1) or \
-            (getattr(rb.w1, "digits", None) is not None and rb.sn2.kind in ("lif", "if") and hip.wide_conv_applicable(B * D, h, w, rb.C, rb.C, 1, D))
+            (getattr(rb.w1, "digits", None) is not None and rb.sn2.kind in ("lif", "if") and hip.smallm_conv_applicable(B * D, h, w, rb.C, rb.C, 1, D))
         if fus:
             s2 = self._conv3x3(s1, rb.w1, rb.C, bn=rb.bn1, sn=rb.sn2)
         else:       # few rows (U-Net bottleneck): the fp32 epilogue can split K over the chip; neuron as its own launch

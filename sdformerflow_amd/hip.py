@@ -23,7 +23,7 @@ KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
 EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
            "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd", "sdf_head_conv_sn_fwd",
            "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes",
-           "sdf_window_slice_map", "sdf_window_zsrc_map", "sdf_qk_attn_fwd", "sdf_qk_attn_is_wide", "sdf_ms_mlp_is_wide", "sdf_ms_patch_merge_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
+           "sdf_window_slice_map", "sdf_window_zsrc_map", "sdf_qk_attn_fwd", "sdf_qk_attn_is_wide", "sdf_ms_mlp_is_wide", "sdf_ms_patch_merge_fwd", "sdf_tile_weight_i8x3", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
            "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_pred_head_fwd", "sdf_pointwise_conv_f32_fwd", "sdf_neuron_multi_fwd", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
            "sdf_rows_gather_fwd", "sdf_rows_scatter_fwd",
            "sdf_split_weight_i8x3", "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd",
@@ -361,6 +361,7 @@ def split_weight(W, nsplit=3):
 
 
 PLANES_I8X3 = 4
+PLANES_I8X3_TILED = 5
 
 
 def split_weight_i8x3(W):
@@ -399,10 +400,32 @@ def wide_conv_applicable(imgs, H, W, Cin, Cout, stride, T):
     return T in (10, 20) and imgs % T == 0 and imgs * H * W <= 256 * 80
 
 
-def pack_conv_weight_i8x3(w):
-    """Conv2d weight (Cout, Cin, KH, KW) fp32 -> int8 digit planes (3, Cout, KH*KW*Cin), K in (ky, kx, cin) order."""
+def smallm_conv_applicable(imgs, H, W, Cin, Cout, stride, T):
+    """Mirror of the library's dispatch rule for the small-M digit convolution (csrc/ms_smallm.hip: smallm_conv_supports): 3x3 / stride 1
+    on Cin % 64 == 0 channels, at most 5 120 output rows in (B, T, H, W) order with T in {10, 20}."""
+    if os.environ.get("SDF_SMALLM", "") == "0" or stride != 1 or Cin % 64 or Cout % 32:
+        return False
+    return T in (10, 20) and imgs % T == 0 and imgs * H * W <= 64 * 80
+
+
+def tile_weight_i8x3(planes):
+    """sdf_tile_weight_i8x3: digit planes (3, N, K) -> the same digits in MFMA fragment order [N / 16][K / 64][3][64][16 B] (kept under
+    the shape (3, N, K); attribute `sdf_tiled`): what the small-M convolution streams at full rate (csrc/ms_smallm.hip)."""
+    _, N, K = planes.shape
+    tiled = torch.empty_like(planes)
+    _check(lib().sdf_tile_weight_i8x3(C.c_void_p(_ptr(planes, torch.int8)), C.c_void_p(tiled.data_ptr()), C.c_int(N), C.c_int(K), _stream()),
+           "sdf_tile_weight_i8x3")
+    tiled.sdf_col_scale = planes.sdf_col_scale
+    tiled.sdf_tiled = True
+    return tiled
+
+
+def pack_conv_weight_i8x3(w, tiled=False):
+    """Conv2d weight (Cout, Cin, KH, KW) fp32 -> int8 digit planes (3, Cout, KH*KW*Cin), K in (ky, kx, cin) order; `tiled`: in the
+    fragment order of tile_weight_i8x3."""
     Cout, Cin, KH, KW = w.shape
-    return split_weight_i8x3(w.detach().float().permute(0, 2, 3, 1).reshape(Cout, KH * KW * Cin))
+    planes = split_weight_i8x3(w.detach().float().permute(0, 2, 3, 1).reshape(Cout, KH * KW * Cin))
+    return tile_weight_i8x3(planes) if tiled else planes
 
 
 def _acc_scale(Wp):
@@ -1066,7 +1089,7 @@ def spike_conv2d(x, Wp, imgs, H, W, Cin, OH, OW, KH, KW, stride, dy, dx, out=Non
     g.M, g.N, g.K = imgs * OH * OW, Wp.shape[1], KH * KW * Cin
     g.lda, g.ldo, g.nsplit, g.acc_scale = 0, Wp.shape[1], Wp.shape[0], _acc_scale(Wp)
     if Wp.dtype == torch.int8:                                    # digit planes (split_weight_i8x3)
-        g.nsplit, g.col_scale = PLANES_I8X3, _ptr(Wp.sdf_col_scale, torch.float32)
+        g.nsplit, g.col_scale = (PLANES_I8X3_TILED if getattr(Wp, "sdf_tiled", False) else PLANES_I8X3), _ptr(Wp.sdf_col_scale, torch.float32)
     elif Wp.dtype != torch.int16:
         raise SdfError(f"weight planes must be int16 (16-bit float planes) or int8 (digit planes), got {Wp.dtype}")
     g.alpha, g.beta = _ptr(alpha, torch.float32), _ptr(beta, torch.float32)

@@ -1,0 +1,103 @@
+"""The small-M 3x3 spike convolution of the U-Net bottleneck (csrc/ms_smallm.hip: one launch, K split over the waves of a workgroup,
+exact integer reduction in LDS, BN + shortcut + neuron in the epilogue) through the C ABI `sdf_spike_conv2d_fwd` with int8 digit planes -
+reference `MS_ResBlock.forward` (Spiking_modules.py:906-933: sn -> conv3x3 -> BN -> sn -> conv3x3 -> BN -> + identity):
+  * fp32 epilogue (BN + shortcut): against an fp64 convolution with the weights the digit planes carry, to 1e-5 of the range;
+  * fused neuron: the spikes are delta-consistent with the oracle neuron on that fp64 pre-activation (0 unexplained decisions), and
+    bit-equal to the C oracle neuron applied to the kernel's OWN fp32 pre-activation when it also stores it (membrane form);
+  * row-major digit planes and the same digits in fragment order (sdf_tile_weight_i8x3) give bit-equal results;
+  * against the streaming kernel on the fp16 planes of the same weights (the A/B reference)."""
+import pytest
+import torch
+
+from oracle import neuron_ref as R
+from oracle import sdformer_oracle as O
+from sdformerflow_amd import hip
+from sdformerflow_amd.synthetic import synth_uniform as rnd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def spikes(shape, seed, rate=0.3):
+    return (rnd(shape, seed) < rate).to(torch.uint8)
+
+
+def _weff(dg):
+    d = dg.cpu().double()
+    return (d[2] * 65536 + d[1] * 256 + d[0]) * dg.sdf_col_scale.cpu().double().view(-1, 1)
+
+
+def _ref(x, w_eff, Cin, Cout, alpha, beta, resid):
+    w = w_eff.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)                  # planes are packed (ky, kx, cin)
+    y = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w, None, 1, 1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    return y * alpha.double() + beta.double() + (resid.double() if resid is not None else 0)
+
+
+@pytest.mark.parametrize("B,T,H,W,Cin,Cout,with_res", [(1, 10, 9, 12, 768, 768, True), (1, 10, 9, 12, 768, 768, False), (2, 10, 5, 7, 384, 96, True),
+                                                     (1, 20, 6, 5, 128, 64, True), (1, 10, 1, 1, 256, 32, False), (1, 10, 8, 10, 192, 96, True), (4, 10, 3, 3, 64, 32, True)])
+def test_fp32_epilogue_against_fp64(B, T, H, W, Cin, Cout, with_res, monkeypatch):
+    imgs = B * T
+    assert hip.smallm_conv_applicable(imgs, H, W, Cin, Cout, 1, T)
+    x = spikes((imgs, H, W, Cin), 300 + H)
+    w = rnd((Cout, Cin, 3, 3), 301, -0.05, 0.05)
+    alpha, beta = rnd((Cout,), 302, 0.5, 1.5), rnd((Cout,), 303, -0.2, 0.2)
+    resid = rnd((imgs * H * W, Cout), 304) if with_res else None
+    dg = hip.pack_conv_weight_i8x3(w.to(DEV))
+    out = torch.full((imgs * H * W, Cout), float("nan"), device=DEV)
+    hip.spike_conv2d(x.to(DEV), dg, imgs, H, W, Cin, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=out, alpha=alpha.to(DEV), beta=beta.to(DEV),
+                     resid=None if resid is None else resid.to(DEV))
+    ref = _ref(x, _weff(dg), Cin, Cout, alpha, beta, resid)
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    alt = torch.full_like(out, float("nan"))                               # the digits in fragment order (what the engine packs): bit-equal
+    hip.spike_conv2d(x.to(DEV), hip.tile_weight_i8x3(dg), imgs, H, W, Cin, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=alt, alpha=alpha.to(DEV),
+                     beta=beta.to(DEV), resid=None if resid is None else resid.to(DEV))
+    assert torch.equal(alt, out)
+    if Cout % 48 == 0:                                                     # the 48-column tile (two operand steps in flight): bit-equal
+        monkeypatch.setenv("SDF_SMALLM_CB", "3")
+        alt3 = torch.full_like(out, float("nan"))
+        hip.spike_conv2d(x.to(DEV), hip.tile_weight_i8x3(dg), imgs, H, W, Cin, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=alt3, alpha=alpha.to(DEV),
+                         beta=beta.to(DEV), resid=None if resid is None else resid.to(DEV))
+        monkeypatch.delenv("SDF_SMALLM_CB")
+        assert torch.equal(alt3, out)
+    # the streaming kernel on the fp16 planes of the same weights
+    if Cout % 96 == 0:
+        monkeypatch.setenv("SDF_SMALLM", "0")
+        old = torch.empty_like(out)
+        hip.spike_conv2d(x.to(DEV), hip.pack_conv_weight(w.to(DEV), 2), imgs, H, W, Cin, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=old,
+                         alpha=alpha.to(DEV), beta=beta.to(DEV), resid=None if resid is None else resid.to(DEV))
+        assert (out - old).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("kind,v_reset", [("lif", None), ("lif", 0.0), ("if", None)])
+@pytest.mark.parametrize("B,T,H,W,Cin,Cout", [(1, 10, 9, 12, 768, 768), (2, 10, 4, 5, 384, 96), (1, 20, 6, 5, 128, 64)])
+@pytest.mark.parametrize("membrane", [False, True])
+@pytest.mark.parametrize("tile", ["2", "3"])
+def test_fused_neuron_forms(B, T, H, W, Cin, Cout, membrane, kind, v_reset, tile, monkeypatch):
+    if tile == "3" and (Cout % 48 or not membrane):
+        pytest.skip("the 48-column tile reads digits in fragment order, 48 | Cout")
+    monkeypatch.setenv("SDF_SMALLM_CB", tile)
+    if kind != "lif" or v_reset is not None:
+        if (H, W) != (9, 12):
+            pytest.skip("the other neuron classes are covered on the shipped shape")
+    imgs, hw = B * T, H * W
+    x = spikes((imgs, H, W, Cin), 310 + H)
+    w = rnd((Cout, Cin, 3, 3), 311, -0.05, 0.05)
+    alpha, beta = rnd((Cout,), 312, 0.5, 1.5), rnd((Cout,), 313, -0.1, 0.3)
+    resid = rnd((imgs * hw, Cout), 314, -0.3, 0.3) if membrane else None
+    p = hip.NeuronParams(kind, 2.0, 0.1, v_reset)
+    dg = hip.pack_conv_weight_i8x3(w.to(DEV), tiled=membrane)            # (both weight layouts take part)
+    sp = torch.full((imgs * hw, Cout), 7, dtype=torch.uint8, device=DEV)
+    m = torch.full((imgs * hw, Cout), float("nan"), device=DEV) if membrane else None
+    hip.spike_conv2d(x.to(DEV), dg, imgs, H, W, Cin, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=m, out_spike=sp, alpha=alpha.to(DEV),
+                     beta=beta.to(DEV), resid=None if resid is None else resid.to(DEV), sn=p, sn_T=T, pos=(B * hw, hw, T * hw, hw))
+    ref = _ref(x, _weff(hip.pack_conv_weight_i8x3(w.to(DEV))), Cin, Cout, alpha, beta, resid)
+    got = sp.cpu().view(B, T, hw, Cout).permute(1, 0, 2, 3).float().contiguous()
+    ht = ref.view(B, T, hw, Cout).permute(1, 0, 2, 3).float().contiguous()
+    delta = 16 * 2.0 ** -23 * max(float(ht.pow(2).mean().sqrt()), 0.1)
+    rep = O.delta_consistent(ht, got, O.NeuronCfg(kind, 0.1, v_reset, 2.0, T), {}, "w.", delta)
+    assert rep["unexplained"] == 0, rep
+    assert 0.02 < got.mean() < 0.98
+    if membrane:
+        assert (m.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+        own = R.neuron_ref(m.cpu().view(B, T, hw, Cout).permute(1, 0, 2, 3).contiguous(), kind, 2.0, 0.1, v_reset)
+        assert torch.equal(own, got), "spikes are not the neuron of the stored membrane"

@@ -2,11 +2,18 @@
 # diagnostic build of the wide-stage kernels (csrc/ms_wide.hip) with in-kernel cycle stamps: where does a workgroup's time go
 # (prologue / main loop / fp32 epilogue / neuron epilogue + stores), and how do the workgroups of a launch spread in time?
 # The diagnostic library lives beside, not over, the product one.   usage (GPU box): tools/stamp_wide.sh [B D H W C]
+# SDF_STAMP_LIB=path: use a diagnostic library built beforehand (tools/stamp_wide.sh build NAME [flags] -> build/stamp/libNAME.so; the
+# hipcc cross-compile runs off the GPU box and the .so travels with the snapshot) instead of compiling on the box.
 set -e
 cd "$(dirname "$0")/.."
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-slp-vectorize -Wno-pass-failed -DSDF_STAMP ${SDF_EXTRA_FLAGS:-} -c ${SDF_WIDE_SRC:-sdformerflow_amd/csrc/ms_wide.hip} -o /tmp/wide_stamp.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libsdf_stamp_wide.so /tmp/wide_stamp.o $(ls sdformerflow_amd/csrc/obj/*.o | grep -v ms_wide)
-SDF_HIP_LIB=/tmp/libsdf_stamp_wide.so python3 - "$@" <<'PY'
+build() {   # $1 = output .so, rest = extra flags
+  local out=$1; shift
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-slp-vectorize -Wno-pass-failed -DSDF_STAMP ${SDF_EXTRA_FLAGS:-} "$@" -c ${SDF_WIDE_SRC:-sdformerflow_amd/csrc/ms_wide.hip} -o ${out%.so}.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out ${out%.so}.o $(ls sdformerflow_amd/csrc/obj/*.o | grep -v ms_wide)
+}
+if [ "$1" = build ]; then mkdir -p build/stamp; name=$2; shift 2; build build/stamp/lib$name.so "$@"; echo build/stamp/lib$name.so; exit 0; fi
+if [ -z "$SDF_STAMP_LIB" ]; then build /tmp/libsdf_stamp_wide.so; SDF_STAMP_LIB=/tmp/libsdf_stamp_wide.so; fi
+SDF_HIP_LIB=$SDF_STAMP_LIB python3 - "$@" <<'PY'
 import ctypes, sys, os, torch
 import numpy as np
 sys.path.insert(0, os.getcwd())

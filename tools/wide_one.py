@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One MS swin block at a wide-stage shape through the C ABI (attention with the projection's hand-over + MLP), a few times - for
-rocprofv3 passes and tools/stamp_wide.sh.  usage: wide_one.py [B D H W C] [narrow]"""
+rocprofv3 passes and tools/stamp_wide.sh.  usage: wide_one.py [B D H W C] [narrow] | wide_one.py conv [B T H W Cin Cout]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sdformerflow_amd import hip
@@ -45,7 +45,7 @@ def conv(B, T, H, W, Cin, Cout):
     dev = "cuda:0"
     imgs, hw = B * T, H * W
     x = (rnd((imgs, H, W, Cin), 21) < -0.4).to(torch.uint8).to(dev)
-    dg = hip.pack_conv_weight_i8x3(rnd((Cout, Cin, 3, 3), 22, -0.05, 0.05).to(dev))
+    dg = hip.pack_conv_weight_i8x3(rnd((Cout, Cin, 3, 3), 22, -0.05, 0.05).to(dev), tiled=os.environ.get("SDF_WIDE_CONV", "") != "1" and os.environ.get("ROWMAJOR", "") != "1")
     al, be = rnd((Cout,), 23, 0.5, 1.5).to(dev), rnd((Cout,), 24, -0.1, 0.3).to(dev)
     sp = torch.empty((imgs * hw, Cout), dtype=torch.uint8, device=dev)
     p = hip.NeuronParams("lif", 2.0, 0.1, None)
@@ -57,6 +57,13 @@ def conv(B, T, H, W, Cin, Cout):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "conv":          # wide_one.py conv [B T H W Cin Cout]: the small-M convolution alone
+        a = [int(v) for v in sys.argv[2:8]] if len(sys.argv) >= 8 else [1, 10, 9, 12, 768, 768]
+        run = conv(*a)
+        for _ in range(20):
+            run()
+        torch.cuda.synchronize()
+        sys.exit(0)
     a = [int(v) for v in sys.argv[1:6]] if len(sys.argv) >= 6 else [1, 10, 18, 24, 384]
     run = block(*a)
     for _ in range(10):
