@@ -400,7 +400,7 @@ int sdf_ms_mlp_is_wide(const SdfMsMlpDesc* d);
  * planes, out (B, D, ceil(H/2), ceil(W/2), N) fp32 (odd sizes read zero spikes, the reference's F.pad in front of the neuron).  Replaces MS_SpikingPatchMerging.forward behind its neuron (reference
  * Spiking_swin_transformer3D.py:965-972: the four strided slices, the concatenation along channels in quadrant order
  * (dh, dw) = (q % 2, q / 2), sj_layer.Linear, the BatchNorm) - the concatenation is index arithmetic in the operand loads of the
- * wide-stage main loop (csrc/ms_wide.hip), nothing is materialised.  C % 128 == 0, N % 32 == 0, D in {10, 20}, at most
+ * wide-stage main loop (csrc/ms_wide.hip), nothing is materialised.  C % 64 == 0, N % 32 == 0, D in {10, 20}, at most
  * 20 480 output rows; SDF_E_SHAPE otherwise (the caller keeps its gather map + sdf_spike_gemm_fwd). */
 typedef struct SdfMsMergeDesc {
   const uint8_t* spikes;

@@ -60,6 +60,7 @@ struct SmallMParams {
   float inv_tau;
   int ncg, nunits;
   int cv_H, cv_W, cv_Cin, cv_spt;      // convolution: 64-deep steps per tap
+  int cv_inv;                          // ceil(2^16 / cv_spt): step / cv_spt == (step * cv_inv) >> 16 for every step the kernel forms
 };
 
 // EPI: 1 = neuron on BN(...) [+ shortcut] -> spikes, 2 = the fp32 value is stored, 3 = both.  AM: 0 = rows of a tensor, 1 = 3x3 taps.
@@ -68,13 +69,13 @@ struct SmallMParams {
 template <int T, int EPI, int NK, int AM, bool BT, int CB>
 __global__ __launch_bounds__(256, CB == 2 ? 2 : 1) void smallm_kernel(SmallMParams P) {
   constexpr int RB = RBW, NS = CB == 2 ? 1 : 2, NBUF = NS + 1, ROWS = 16 * RB, SLOTS = 4 * RB, PPG = SLOTS / T, PPW = 4 * PPG, BN = 16 * CB;
-  constexpr int SP = s_pitch(BN), STILE = ROWS * SP, NACC = RB * CB;
-  constexpr int REDB = 2 * 2 * NACC * 64 * 16;            // two waves x (lo, hi) x 10 accumulator quads x 64 lanes
+  constexpr int SP1 = s_pitch(16), REDC = 3 * 2 * RB * 64 * 16;          // per column block: three contributors x (lo, hi) x RB quads x 64 lanes
+  constexpr int STRIPB = 4 * RB * 1024, REDB = CB * REDC;
   static_assert(SLOTS % T == 0, "T must divide the 20 accumulator slots of a lane");
-  static_assert(STILE <= REDB, "the byte tile aliases the reduction buffer");
-  __shared__ __attribute__((aligned(16))) uint8_t smem[REDB];
-  __shared__ __attribute__((aligned(16))) uint8_t strip[4][RB * 1024];     // per wave: one step's spike pieces on their way to MFMA order
+  static_assert(ROWS * SP1 <= REDC && STRIPB <= REDB, "the byte tiles and the strips lie inside the reduction buffer");
+  __shared__ __attribute__((aligned(16))) uint8_t smem[REDB];              // main loop: the waves' strips; then the reduction buffer
   __shared__ int32_t rowtab[ROWS];
+  __shared__ uint32_t masktab[AM == 1 ? ROWS : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, lq = lane >> 4;
   int item = blockIdx.x;
@@ -140,6 +141,18 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : 1) void smallm_kernel(SmallMPara
       g = (int32_t)((b * T + t) * (uint32_t)HW + hw);
     }
     rowtab[tid] = g;
+    if constexpr (AM == 1) {                               // which of the 9 taps of the row's pixel lie inside the image (once per row)
+      uint32_t m = 0;
+      if (g >= 0) {
+        const uint32_t pix = (uint32_t)g % (uint32_t)HW, y = pix / (uint32_t)P.cv_W, xx = pix - y * (uint32_t)P.cv_W;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+          const int yy = (int)y + tp / 3 - 1, xw = (int)xx + tp % 3 - 1;
+          if (yy >= 0 && yy < P.cv_H && xw >= 0 && xw < P.cv_W) m |= 1u << tp;
+        }
+      }
+      masktab[tid] = m;
+    }
   }
   __syncthreads();
   // spike pieces: this lane loads piece (lane & 3) ^ swz of tile row 16 rb + lane / 4, swz = 2 (row / 8): LDS slot = lane
@@ -152,15 +165,8 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : 1) void smallm_kernel(SmallMPara
     a_mask[rb] = 0;
     if (g >= 0) {
       if constexpr (AM == 1) {
-        const uint32_t pix = (uint32_t)g % (uint32_t)HW, y = pix / (uint32_t)P.cv_W, xx = pix - y * (uint32_t)P.cv_W;
         a_base[rb] = (uint32_t)g * (uint32_t)P.cv_Cin + 16u * lp;
-        uint32_t m = 0;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int yy = (int)y + tap / 3 - 1, xw = (int)xx + tap % 3 - 1;
-          if (yy >= 0 && yy < P.cv_H && xw >= 0 && xw < P.cv_W) m |= 1u << tap;
-        }
-        a_mask[rb] = m;
+        a_mask[rb] = masktab[16 * rb + lr];
       } else {
         a_base[rb] = (uint32_t)g * (uint32_t)K + 16u * lp;
       }
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : 1) void smallm_kernel(SmallMPara
     else b_off[cb] = n0 + 16 * cb + l16 < N ? (uint32_t)(n0 + 16 * cb + l16) * (uint32_t)K + 16u * lq : INV;
   }
   // MFMA-order read of the strip: lane = row + 16 k-group -> slot 4 row + (k-group ^ swz)
-  uint8_t* mystrip = strip[wave];
+  uint8_t* mystrip = smem + wave * (RB * 1024);            // (one step's spike pieces on their way to MFMA order)
   const uint32_t rd_off = (uint32_t)((4 * l16 + (lq ^ ((l16 >> 2) & 2))) * 16), wr_off = 16u * lane;
 
   i32x4 acc[3][RB][CB];
@@ -187,8 +193,6 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : 1) void smallm_kernel(SmallMPara
   constexpr bool DBL = CB == 3;                            // registers for two sets of MFMA-order spike fragments (one workgroup per CU)
   i32x4 araw[NS][RB], a2[DBL ? 2 : 1][RB], b[NBUF][3][CB];
   int sa_next = wave, sb_next = wave;                      // next step whose spikes / weights are requested (scalar)
-  int tap = 0, cstep = 0;                                  // convolution: sa_next = tap * spt + cstep
-  if constexpr (AM == 1) { tap = wave / P.cv_spt; cstep = wave - tap * P.cv_spt; }
   const uint32_t plane = (uint32_t)N * (uint32_t)K;
 #ifdef SMX_NOA
   constexpr bool XA = false;                               // (diagnostic builds, tools/smallm_ablate.sh: one operand's loads read nothing)
@@ -200,51 +204,43 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : 1) void smallm_kernel(SmallMPara
 #else
   constexpr bool XB = true;
 #endif
-  auto issue_a = [&](int ra) __attribute__((always_inline)) {
-    const bool in = XA && sa_next < nst;
+  // spike piece rb of step sa_next -> raw registers.  Convolution: step -> (tap, channel offset) by a multiply (cv_inv = ceil(2^16 / steps
+  // per tap), exact for the step counts the host admits); a step beyond the last has tap >= 9, i.e. no mask bit - the select is
+  // arithmetic, a branch here would cost a vmcnt(0)
+  auto issue_a1 = [&](int ra, int rb) __attribute__((always_inline)) {
     if constexpr (AM == 1) {
+      const int tap = (int)(((uint32_t)sa_next * (uint32_t)P.cv_inv) >> 16), cstep = sa_next - tap * P.cv_spt;
       const uint32_t toff = (uint32_t)(((tap / 3 - 1) * P.cv_W + (tap % 3 - 1)) * P.cv_Cin), cin0 = (uint32_t)cstep * 64u;
-      // (a step beyond the last has tap >= 9: no mask bit - the select is arithmetic, a branch here would cost a vmcnt(0))
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
-        const uint32_t ok = (0u - ((a_mask[rb] >> tap) & 1u)) & (0u - (uint32_t)XA);
-        araw[ra][rb] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(A_rs, ((a_base[rb] + toff) & ok) | (INV & ~ok), cin0, 0));
-      }
-      cstep += 4;                                          // (four steps further; a tap has cv_spt >= 1 steps)
-#pragma unroll
-      for (int w = 0; w < 4; ++w)
-        if (cstep >= P.cv_spt) { cstep -= P.cv_spt; ++tap; }
+      const uint32_t ok = (0u - ((a_mask[rb] >> tap) & 1u)) & (0u - (uint32_t)XA);
+      araw[ra][rb] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(A_rs, ((a_base[rb] + toff) & ok) | (INV & ~ok), cin0, 0));
     } else {
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb)
-        araw[ra][rb] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(A_rs, in ? a_base[rb] : INV, (uint32_t)sa_next * 64u, 0));
+      const bool in = XA && sa_next < nst;
+      araw[ra][rb] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(A_rs, in ? a_base[rb] : INV, (uint32_t)sa_next * 64u, 0));
     }
-    sa_next += 4;
   };
-  auto issue_b = [&](int rbuf) __attribute__((always_inline)) {
+  // weight fragment f = (digit, column block) of step sb_next -> its ring registers
+  auto issue_b1 = [&](int rbuf, int f) __attribute__((always_inline)) {
     const bool in = XB && sb_next < nst;
-#pragma unroll
-    for (int dg = 0; dg < 3; ++dg)
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) {
-        const uint32_t so = BT ? (uint32_t)(sb_next * 3 + dg) * 1024u : (uint32_t)dg * plane + (uint32_t)sb_next * 64u;
-        b[rbuf][dg][cb] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(W_rs, in ? b_off[cb] : INV, so, 0));
-      }
-    sb_next += 4;
+    const int dg = f / CB, cb = f - dg * CB;
+    const uint32_t so = BT ? (uint32_t)(sb_next * 3 + dg) * 1024u : (uint32_t)dg * plane + (uint32_t)sb_next * 64u;
+    b[rbuf][dg][cb] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(W_rs, in ? b_off[cb] : INV, so, 0));
   };
-  auto strip_write = [&](int ra) __attribute__((always_inline)) {
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) *reinterpret_cast<i32x4*>(mystrip + rb * 1024 + wr_off) = araw[ra][rb];
+  auto strip_write1 = [&](int ra, int rb) __attribute__((always_inline)) {
+    *reinterpret_cast<i32x4*>(mystrip + rb * 1024 + wr_off) = araw[ra][rb];
   };
-  auto strip_read = [&](int set) __attribute__((always_inline)) {
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) a2[set][rb] = *reinterpret_cast<const i32x4*>(mystrip + rb * 1024 + rd_off);
+  auto strip_read1 = [&](int set, int rb) __attribute__((always_inline)) {
+    a2[set][rb] = *reinterpret_cast<const i32x4*>(mystrip + rb * 1024 + rd_off);
   };
-  // Step i: 3 CB groups of RB MFMAs on (spike fragments of step i, weight fragments requested NS + 1 steps ago).  Everything the NEXT
-  // step needs rides behind those groups: its spike pieces (requested NS steps ago) go raw registers -> strip behind group 0, the raw
-  // registers are re-requested (step i + 1 + NS) behind group 1, the strip is read back in MFMA order behind group 2 (into the second
-  // fragment set; with one set - the 32-column tile, 128 registers - behind the last group), and the weight registers this step used
-  // are re-requested (step i + NBUF) at its end.  Same-wave LDS operations execute in order: one strip, no barrier.
+  // Step i: 3 CB groups of RB MFMAs on (spike fragments of step i, weight fragments requested NBUF steps ago).  One wave per SIMD (or
+  // two): whatever else the wave issues between two MFMAs of 16 cycles must be SHORT or the matrix pipe drains (measured: with the
+  // side work in blocks between groups a step took 1 100 cycles for 720 of MFMA, loads reading nothing).  So everything the next steps
+  // need is cut into one small piece behind each MFMA, pinned there by a fence:
+  //   group 0      : spike piece rb of step i + 1 (requested NS steps ago) goes raw registers -> strip
+  //   group 1      : that raw register is re-requested (step i + 1 + NS)
+  //   group 2      : the strip is read back in MFMA order, piece rb (second fragment set; with one set - the 32-column tile, 128
+  //                  registers - behind the last MFMA instead)
+  //   group g >= 1 : the weight fragment group g - 1 used is re-requested (step i + NBUF); the last one behind the last MFMA
+  // Same-wave LDS operations execute in order: one strip, no barrier.
   auto step = [&](int i) __attribute__((always_inline)) {
     const int cur = DBL ? (i & 1) : 0, nxt = DBL ? (cur ^ 1) : 0;
 #pragma unroll
@@ -257,25 +253,43 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : 1) void smallm_kernel(SmallMPara
 #else
         asm volatile("" :: "v"(a2[cur][rb]), "v"(b[i % NBUF][dg][cb]));
 #endif
+        if (g == 0) strip_write1((i + 1) % NS, rb);
+        if (g == 1) issue_a1((i + 1) % NS, rb);
+        if (g == 2 && DBL) strip_read1(nxt, rb);
+        if (g >= 1 && rb == (g == 1 ? RB - 1 : 0)) issue_b1(i % NBUF, g - 1);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (g == 0) strip_write((i + 1) % NS);
-      if (g == 1) issue_a((i + 1) % NS);
-      if (g == 2 && DBL) strip_read(nxt);
-      __builtin_amdgcn_sched_barrier(0);
     }
-    if (!DBL) strip_read(nxt);
-    issue_b(i % NBUF);
+    sa_next += 4;
+    issue_b1(i % NBUF, 3 * CB - 1);
+    sb_next += 4;
+    if (!DBL) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) strip_read1(nxt, rb);
+    }
     __builtin_amdgcn_sched_barrier(0);
   };
   MSTAMP(1);
 #pragma unroll
-  for (int j = 0; j < NS; ++j) issue_a(j);
+  for (int j = 0; j < NS; ++j) {
 #pragma unroll
-  for (int j = 0; j < NBUF; ++j) issue_b(j);
+    for (int rb = 0; rb < RB; ++rb) issue_a1(j, rb);
+    sa_next += 4;
+  }
+#pragma unroll
+  for (int j = 0; j < NBUF; ++j) {
+#pragma unroll
+    for (int f = 0; f < 3 * CB; ++f) issue_b1(j, f);
+    sb_next += 4;
+  }
   asm volatile("" :: "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]));      // (the warm-up loads end here)
-  strip_write(0);
-  issue_a(0);
-  strip_read(0);
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) strip_write1(0, rb);
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) issue_a1(0, rb);
+  sa_next += 4;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) strip_read1(0, rb);
   __builtin_amdgcn_sched_barrier(0);
   constexpr int U = DBL ? 6 : 2;                           // steps per round: every register ring is back where it started
   static_assert(U % NS == 0 && U % NBUF == 0, "ring sizes divide the round");
@@ -287,120 +301,105 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : 1) void smallm_kernel(SmallMPara
   }
 
   MSTAMP(2);
-  // ---------------- the four partial sums meet: (lo, hi) = (d1 256 + d0, d2) as exact int32, tree over two barriers ----------------
-  i32x4 lo[RB][CB], hi[RB][CB];
-#pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      lo[rb][cb] = acc[1][rb][cb] * 256 + acc[0][rb][cb];
-      hi[rb][cb] = acc[2][rb][cb];
-    }
+  // ---------------- the four partial sums meet ----------------
+  // (lo, hi) = (d1 256 + d0, d2) as exact int32.  Wave c < CB finishes column block c: every other wave hands it its sums of that
+  // block through LDS (one barrier; a second one in front because the buffer lies over the strips), so the epilogue runs on CB waves
+  // side by side instead of one (round 4 stamps: tree reduction + one-wave epilogue were 12.7 k of a workgroup's 64 k cycles).
   const int c = lane & 15, q = lane >> 4;
+  const bool owner = wave < CB;
+  const int mycb = owner ? wave : 0;
   uint32_t xo[SLOTS];
-  float res[CB][SLOTS];
-  float al[CB], be[CB], bs[CB], cs[CB];
-  if (wave == 0) {                                         // the shortcut values and column parameters travel under the reduction
+  float res[SLOTS];
+  float al = 1.f, be = 0.f, bs = 0.f, cs = 0.f;
+  const int ncol = n0 + 16 * mycb + c;
+  if (owner) {                                             // the shortcut values and column parameters travel under the reduction
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
       const int32_t g = rowtab[16 * (s >> 2) + 4 * q + (s & 3)];
-      xo[s] = (g >= 0 && n0 + c < N) ? ((uint32_t)g * (uint32_t)P.ldo + (uint32_t)(n0 + c)) * 4u : INV;
+      xo[s] = (g >= 0 && ncol < N) ? ((uint32_t)g * (uint32_t)P.ldo + (uint32_t)ncol) * 4u : INV;
     }
     const __amdgpu_buffer_rsrc_t r_rs = make_rsrc(P.resid);
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-      for (int s = 0; s < SLOTS; ++s)
-        res[cb][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, (n0 + 16 * cb + c < N && P.resid) ? xo[s] : INV, 64u * cb, 0));
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      const int n = n0 + 16 * cb + c;
-      const int nc = n < N ? n : 0;
-      al[cb] = P.alpha ? P.alpha[nc] : 1.f;
-      be[cb] = P.alpha ? P.beta[nc] : 0.f;
-      bs[cb] = P.bias ? P.bias[nc] : 0.f;
-      cs[cb] = P.cscale[nc];
-    }
+    for (int s = 0; s < SLOTS; ++s) res[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, P.resid ? xo[s] : INV, 0, 0));
+    const int nc = ncol < N ? ncol : 0;
+    al = P.alpha ? P.alpha[nc] : 1.f;
+    be = P.alpha ? P.beta[nc] : 0.f;
+    bs = P.bias ? P.bias[nc] : 0.f;
+    cs = P.cscale[nc];
   }
-  i32x4* red = reinterpret_cast<i32x4*>(smem);
-  auto red_write = [&](int slot) __attribute__((always_inline)) {
+  i32x4* red = reinterpret_cast<i32x4*>(smem);             // [column block][contributor 0..2][lo | hi][row block][lane]
+  __syncthreads();                                         // (every wave is out of its strip)
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+  for (int cb = 0; cb < CB; ++cb)
+    if (wave != cb) {
+      const int j = wave < cb ? wave : wave - 1;
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) {
-        red[((slot * 2 + 0) * NACC + rb * CB + cb) * 64 + lane] = lo[rb][cb];
-        red[((slot * 2 + 1) * NACC + rb * CB + cb) * 64 + lane] = hi[rb][cb];
+      for (int rb = 0; rb < RB; ++rb) {
+        red[(((cb * 3 + j) * 2 + 0) * RB + rb) * 64 + lane] = acc[1][rb][cb] * 256 + acc[0][rb][cb];
+        red[(((cb * 3 + j) * 2 + 1) * RB + rb) * 64 + lane] = acc[2][rb][cb];
       }
-  };
-  auto red_add = [&](int slot) __attribute__((always_inline)) {
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) {
-        lo[rb][cb] += red[((slot * 2 + 0) * NACC + rb * CB + cb) * 64 + lane];
-        hi[rb][cb] += red[((slot * 2 + 1) * NACC + rb * CB + cb) * 64 + lane];
-      }
-  };
-  if (wave >= 2) red_write(wave - 2);
-  __syncthreads();
-  if (wave < 2) red_add(wave);
-  __syncthreads();
-  if (wave == 1) red_write(0);
+    }
   __syncthreads();
   MSTAMP(3);
 #ifdef SDF_STAMP
-  if (wave != 0) { st[4] = st[3]; stamp_out(); return; }
+  if (!owner) { st[4] = st[3]; stamp_out(); return; }
 #else
-  if (wave != 0) return;
+  if (!owner) return;
 #endif
-  red_add(0);
-
-  // ---------------- epilogue (wave 0): BN (+ bias), shortcut, [store], [neuron over T -> spike bytes] ----------------
-  const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(P.out), o_rs = make_rsrc(P.out_spike);
-  float val[CB][SLOTS];
+  i32x4 lo[RB], hi[RB];
 #pragma unroll
-  for (int cb = 0; cb < CB; ++cb)
+  for (int cb = 0; cb < CB; ++cb)                          // (this wave's own sums of its block: a compile-time index per branch)
+    if (wave == cb) {
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-      float v = __builtin_fmaf((float)hi[s >> 2][cb][s & 3], 65536.f, (float)lo[s >> 2][cb][s & 3]) * cs[cb];
-      v = v + bs[cb];
-      v = __builtin_fmaf(v, al[cb], be[cb]);
-      v = v + res[cb][s];
-      val[cb][s] = v;
-      if constexpr ((EPI & 2) != 0)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), x_rs, (n0 + 16 * cb + c < N) ? xo[s] : INV, 64u * cb, 0);
+      for (int rb = 0; rb < RB; ++rb) { lo[rb] = acc[1][rb][cb] * 256 + acc[0][rb][cb]; hi[rb] = acc[2][rb][cb]; }
     }
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      lo[rb] += red[(((mycb * 3 + j) * 2 + 0) * RB + rb) * 64 + lane];
+      hi[rb] += red[(((mycb * 3 + j) * 2 + 1) * RB + rb) * 64 + lane];
+    }
+
+  // ---------------- epilogue (wave c on column block c): BN (+ bias), shortcut, [store], [neuron over T -> spike bytes] ----------------
+  const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(P.out), o_rs = make_rsrc(P.out_spike);
+  float val[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    float v = __builtin_fmaf((float)hi[s >> 2][s & 3], 65536.f, (float)lo[s >> 2][s & 3]) * cs;
+    v = v + bs;
+    v = __builtin_fmaf(v, al, be);
+    v = v + res[s];
+    val[s] = v;
+    if constexpr ((EPI & 2) != 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), x_rs, xo[s], 0, 0);
+  }
   if constexpr ((EPI & 1) != 0) {
-    uint8_t* S = smem;                                     // byte tile [80][SP] over the reduction buffer (this wave's reads of it are done)
+    uint8_t* S = smem + mycb * REDC;                       // byte tile [80][16 + pad] over this wave's part of the buffer (its reads are done)
     uint32_t sel1, sel2;
     quad_sel(lane, sel1, sel2);
     const int m4 = (c >> 2), ci = c & 3;
+    uint32_t bits = 0;
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      uint32_t bits = 0;
+    for (int pp = 0; pp < PPG; ++pp) {
+      float xs[T], sp[T];
 #pragma unroll
-      for (int pp = 0; pp < PPG; ++pp) {
-        float xs[T], sp[T];
+      for (int t = 0; t < T; ++t) xs[t] = val[pp * T + t];
+      neuron_T<NK, T>(xs, sp, P.sn, P.inv_tau);
 #pragma unroll
-        for (int t = 0; t < T; ++t) xs[t] = val[cb][pp * T + t];
-        neuron_T<NK, T>(xs, sp, P.sn, P.inv_tau);
-#pragma unroll
-        for (int t = 0; t < T; ++t) bits |= ((__float_as_uint(sp[t]) >> 29) & 1u) << (pp * T + t);      // 1.0f has bit 29 set
-      }
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
-        const uint32_t w = quad_tr_bytes(spread4(bits >> (4 * rb)), sel1, sel2);
-        *reinterpret_cast<uint32_t*>(S + (16 * rb + 4 * q + ci) * SP + 16 * cb + 4 * m4) = w;
-      }
+      for (int t = 0; t < T; ++t) bits |= ((__float_as_uint(sp[t]) >> 29) & 1u) << (pp * T + t);      // 1.0f has bit 29 set
     }
 #pragma unroll
-    for (int it = 0; it < (ROWS * CB + 63) / 64; ++it) {
-      const int pc = lane + 64 * it;
-      if (pc < ROWS * CB) {
-        const int r = pc / CB, k16 = pc % CB;
+    for (int rb = 0; rb < RB; ++rb) {
+      const uint32_t w = quad_tr_bytes(spread4(bits >> (4 * rb)), sel1, sel2);
+      *reinterpret_cast<uint32_t*>(S + (16 * rb + 4 * q + ci) * SP1 + 4 * m4) = w;
+    }
+#pragma unroll
+    for (int it = 0; it < (ROWS + 63) / 64; ++it) {
+      const int r = lane + 64 * it;
+      if (r < ROWS) {
         const int32_t g = rowtab[r];
-        const u32x4 v = *reinterpret_cast<const u32x4*>(S + r * SP + 16 * k16);
-        const uint32_t off = (g >= 0 && n0 + 16 * k16 < N) ? (uint32_t)g * (uint32_t)P.ldsp + (uint32_t)(n0 + 16 * k16) : INV;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(S + r * SP1);
+        const uint32_t off = (g >= 0 && n0 + 16 * mycb < N) ? (uint32_t)g * (uint32_t)P.ldsp + (uint32_t)(n0 + 16 * mycb) : INV;
         __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, off, 0, 0);
       }
     }
@@ -492,6 +491,9 @@ int launch_smallm_conv(const GemmParams& G, hipStream_t s) {
   P.sn = {d.sn_kind, d.tau, d.v_th, d.v_reset, d.soft_reset, nullptr, nullptr};
   P.inv_tau = d.sn_T > 0 ? inv_tau_of(P.sn) : 0.f;
   P.cv_H = cv.H; P.cv_W = cv.W; P.cv_Cin = cv.Cin; P.cv_spt = cv.Cin / 64;
+  P.cv_inv = (65536 + P.cv_spt - 1) / P.cv_spt;
+  for (int st = 0; st < 9 * P.cv_spt + 64; ++st)            // (steps up to a few rounds beyond the last are formed and must decode to tap >= 9)
+    if ((int)(((uint32_t)st * (uint32_t)P.cv_inv) >> 16) != st / P.cv_spt) return SDF_E_SHAPE;
   const int PPW = 4 * (20 / T);
   P.nunits = (int)((P.P + PPW - 1) / PPW);
   const bool bt = d.nsplit == SDF_PLANES_I8X3_TILED;

@@ -83,23 +83,27 @@ namespace {
 //   a_addr(ch, h, rb, voff, soff) : the caller's address of this lane's piece of chunk ch, step h, row block rb (plain rows:
 //                voff = a_base[rb], soff = (2 ch + h) a_step; the 3x3 convolution folds its tap into both)
 //   c0         : first chunk of this workgroup's K range (split-K), added to the weight addressing only
+//   ksteps     : 64-deep steps of the K range (2 nchunks, or 2 nchunks - 1: K = 192 at swin stage 1 - the second step of the last chunk
+//                then reads zeros on both sides, through INV offsets like everything beyond the range)
 template <int RB, int CB, int WIT, class AAddr, class PrepA, class Extra>
-__device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __amdgpu_buffer_rsrc_t A_rs, AAddr a_addr, int nchunks, int c0,
+__device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __amdgpu_buffer_rsrc_t A_rs, AAddr a_addr, int nchunks, int ksteps, int c0,
                                               uint8_t* Wlds, const __amdgpu_buffer_rsrc_t W0_rs, const __amdgpu_buffer_rsrc_t W1_rs,
                                               const uint32_t (&w_goff)[WIT], const uint32_t (&w_lds)[WIT], int lane, PrepA prepare_a,
                                               Extra extra_requests) {
   constexpr int BN = 16 * CB, WBUF = w_buf(CB);
   u32x4 wreg[WIT];
   i32x4 aX[2][RB], aY[2][RB];
+  const uint32_t w_kp16 = 16u * (threadIdx.x & 7);                     // this thread's pieces start at byte w_kp16 of a chunk (wide_pieces)
   auto wreq = [&](int ch) __attribute__((always_inline)) {
 #ifdef WIDE_X_NOWLOAD
     const bool in = false;
 #else
     const bool in = ch < nchunks;
 #endif
+    const uint32_t left = in ? (uint32_t)(ksteps - 2 * ch) * 64u : 0u;          // bytes of the range from this chunk on (>= 128: all pieces)
 #pragma unroll
     for (int i = 0; i < WIT; ++i)
-      wreg[i] = __builtin_amdgcn_raw_buffer_load_b128((i & 1) ? W1_rs : W0_rs, in ? w_goff[i] : INV, (uint32_t)(c0 + ch) * KCH, 0);
+      wreg[i] = __builtin_amdgcn_raw_buffer_load_b128((i & 1) ? W1_rs : W0_rs, w_kp16 < left ? w_goff[i] : INV, (uint32_t)(c0 + ch) * KCH, 0);
   };
   auto w_commit = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -109,7 +113,7 @@ __device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __a
 #ifdef WIDE_X_NOALOAD
     const bool in = false;
 #else
-    const bool in = ch < nchunks;
+    const bool in = true;
 #endif
     a_addr.chunk(ch);
 #pragma unroll
@@ -118,7 +122,7 @@ __device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __a
       for (int rb = 0; rb < RB; ++rb) {
         uint32_t voff, soff;
         a_addr.get(h, rb, voff, soff);
-        a[h][rb] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(A_rs, in ? voff : INV, soff, 0));
+        a[h][rb] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(A_rs, (in && 2 * ch + h < ksteps) ? voff : INV, soff, 0));
       }
   };
   const int l16 = lane & 15, lj = lane >> 4;
@@ -126,7 +130,7 @@ __device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __a
 #ifdef WIDE_X_NOALOAD
     const bool in = false;
 #else
-    const bool in = ch < nchunks;
+    const bool in = 2 * ch + h < ksteps;
 #endif
     uint32_t voff, soff;
     a_addr.get(h, rb, voff, soff);
@@ -187,7 +191,8 @@ __device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __a
   wreq(0);                                                            // (first in the queue: the first wait below covers nothing else)
 #pragma unroll
   for (int i = 0; i < WIT; ++i)
-    wreg2[i] = __builtin_amdgcn_raw_buffer_load_b128((i & 1) ? W1_rs : W0_rs, 1 < nchunks ? w_goff[i] : INV, (uint32_t)(c0 + 1) * KCH, 0);
+    wreg2[i] = __builtin_amdgcn_raw_buffer_load_b128((i & 1) ? W1_rs : W0_rs, w_kp16 < (1 < nchunks ? (uint32_t)(ksteps - 2) * 64u : 0u) ? w_goff[i] : INV,
+                                                     (uint32_t)(c0 + 1) * KCH, 0);
   prepare_a();                                                        // the caller's row addressing: may load (projection: the inverse map)
   extra_requests();                                                   // the caller's own loads (shortcut values, column parameters): AHEAD of the
   areq(aX, 0);                                                        // spike chunks in the in-order return queue - all of these are cold lines
@@ -287,7 +292,8 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
   item -= ks * P.ncg * nrgp;
   const int rgp = item / P.ncg, cg = item - rgp * P.ncg;
   const int n0 = cg * BN;
-  const int nch = P.ksplit > 1 ? P.cps : P.K / KCH, c0 = P.ksplit > 1 ? ks * P.cps : 0;
+  const int nch = P.ksplit > 1 ? P.cps : (P.K + KCH - 1) / KCH, c0 = P.ksplit > 1 ? ks * P.cps : 0;
+  const int kst = P.ksplit > 1 ? 2 * P.cps : P.K / 64;
   const int K = P.K, N = P.N, HW = P.HW;
   const __amdgpu_buffer_rsrc_t A_rs = make_rsrc(P.A), W_rs = make_rsrc(P.W), x_rs = make_rsrc(P.x), o_rs = make_rsrc(P.out_spike);
   uint32_t w_goff[WIT], w_lds[WIT];
@@ -400,23 +406,35 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
       __device__ __forceinline__ void get(int h, int rb, uint32_t& voff, uint32_t& soff) const { voff = base[rb]; soff = (ch2 + (uint32_t)h) * step; }
     };
     struct AddrConv {
-      const uint32_t* base; const uint32_t* mask; int cpt, W, Cin, c0, tap; uint32_t toff, cin0;
+      const uint32_t* base; const uint32_t* mask; int cpt, W, Cin, c0; int tap[2]; uint32_t toff[2], cin0[2];
       __device__ __forceinline__ void chunk(int ch) {
-        const int cg_ = __builtin_amdgcn_readfirstlane(c0 + ch);
-        tap = cg_ / cpt;
-        cin0 = (uint32_t)((cg_ - tap * cpt) * KCH);
-        if constexpr (AM == 2) toff = (uint32_t)(((tap & 1) * W + (tap >> 1)) * Cin);       // quadrant (dh, dw) = (q % 2, q / 2)
-        else toff = (uint32_t)(((tap / 3 - 1) * W + (tap % 3 - 1)) * Cin);
+        if constexpr (AM == 2) {
+          // patch merging: `cpt` counts 64-deep STEPS per quadrant (C = 192: a 128-deep chunk straddles two quadrants) - each step
+          // decodes its own quadrant (dh, dw) = (q % 2, q / 2)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int st = __builtin_amdgcn_readfirstlane(2 * (c0 + ch) + h);
+            tap[h] = st / cpt;
+            cin0[h] = (uint32_t)((st - tap[h] * cpt) * 64);
+            toff[h] = (uint32_t)(((tap[h] & 1) * W + (tap[h] >> 1)) * Cin);
+          }
+        } else {
+          const int cg_ = __builtin_amdgcn_readfirstlane(c0 + ch);
+          tap[0] = tap[1] = cg_ / cpt;
+          cin0[0] = (uint32_t)((cg_ - tap[0] * cpt) * KCH);
+          cin0[1] = cin0[0] + 64u;
+          toff[0] = toff[1] = (uint32_t)(((tap[0] / 3 - 1) * W + (tap[0] % 3 - 1)) * Cin);
+        }
       }
       __device__ __forceinline__ void get(int h, int rb, uint32_t& voff, uint32_t& soff) const {
-        voff = ((mask[rb] >> tap) & 1u) ? base[rb] + toff : INV;
-        soff = cin0 + 64u * (uint32_t)h;
+        voff = ((mask[rb] >> tap[h]) & 1u) ? base[rb] + toff[h] : INV;
+        soff = cin0[h];
       }
     };
     typename std::conditional<AM != 0, AddrConv, AddrPlain>::type a_addr;
-    if constexpr (AM != 0) a_addr = AddrConv{a_base, a_mask, P.cv_cpt, P.cv_W, P.cv_Cin, c0, 0, 0u, 0u};
+    if constexpr (AM != 0) a_addr = AddrConv{a_base, a_mask, P.cv_cpt, P.cv_W, P.cv_Cin, c0, {0, 0}, {0u, 0u}, {0u, 0u}};
     else a_addr = AddrPlain{a_base, a_step, 0u};
-    wide_mainloop<RB, CB, WIT>(acc, A_rs, a_addr, nch, c0, smem, W_rs, W_rs, w_goff, w_lds, lane, prepare_a, late_requests);
+    wide_mainloop<RB, CB, WIT>(acc, A_rs, a_addr, nch, kst, c0, smem, W_rs, W_rs, w_goff, w_lds, lane, prepare_a, late_requests);
     WSTAMP(ws2);
 
     // ---------------- epilogue (an inactive wave has no valid row: its stores are dropped) ----------------
@@ -594,7 +612,7 @@ __global__ __launch_bounds__(256, 1) void wide_front_kernel(WideFrontParams P) {
     __device__ __forceinline__ void chunk(int ch) { ch2 = 2u * (uint32_t)ch; }
     __device__ __forceinline__ void get(int h, int rb, uint32_t& voff, uint32_t& soff) const { voff = base[rb]; soff = (ch2 + (uint32_t)h) * 64u; }
   } a_addr{a_base, 0u};
-  wide_mainloop<RB, CB, WIT>(acc, A_rs, a_addr, C / KCH, 0, smem, Wq_rs, Wk_rs, w_goff, w_lds, lane, [] {}, late_requests);
+  wide_mainloop<RB, CB, WIT>(acc, A_rs, a_addr, (C + KCH - 1) / KCH, C / 64, 0, smem, Wq_rs, Wk_rs, w_goff, w_lds, lane, [] {}, late_requests);
   WSTAMP(ws2);
   if (!active) return;                                    // (the main loop ends with a barrier: the per-wave byte tiles may alias the weight ring)
 
@@ -835,7 +853,7 @@ bool wide_env_off() {
 bool ms_wide_mlp_supports(const SdfMsMlpDesc* d) {
   if (wide_env_off() || (d->flags & SDF_MLP_NARROW)) return false;
   if (!d->fc1_digits || !d->fc1_cscale || !d->fc2_digits || !d->fc2_cscale) return false;
-  if (d->nsplit != 2 || d->C < 256 || d->C % 128 || d->Ch % 128 || d->Ch % 96) return false;
+  if (d->nsplit != 2 || d->C < 192 || d->C % 64 || d->Ch % 64 || d->Ch % 96) return false;
   if (d->D != 10 && d->D != 20) return false;
   if (!neuron_ok(d->sn1) || !neuron_ok(d->sn2) || (d->emit_next && !neuron_ok(d->emit_sn))) return false;
   const int64_t tokens = (int64_t)d->B * d->D * d->HW;
@@ -867,7 +885,7 @@ int launch_ms_wide_mlp(const SdfMsMlpDesc* d, const uint8_t* s1, bool s1_tiled, 
 bool wide_merge_supports(const SdfMsMergeDesc* d) {
   if (wide_env_off()) return false;
   if (d->B < 1 || d->H < 1 || d->W < 1 || (d->D != 10 && d->D != 20)) return false;
-  if (d->C % KCH || d->C < 64 || d->N % 32) return false;
+  if (d->C % 64 || d->C < 64 || d->N % 32) return false;
   const int64_t rows = (int64_t)d->B * d->D * ((d->H + 1) / 2) * ((d->W + 1) / 2);
   if (rows > WIDE_MAX_ROWS && !wide_env_any()) return false;
   if (rows * 4 * d->C >= (1LL << 31) || rows * (int64_t)d->N * 4 >= (1LL << 31) || (int64_t)d->N * 4 * d->C * 3 >= (1LL << 31)) return false;
@@ -879,7 +897,7 @@ int launch_wide_merge(const SdfMsMergeDesc* d, hipStream_t s) {
   P.A = d->spikes; P.W = d->digits; P.cscale = d->cscale; P.N = d->N; P.K = 4 * d->C;
   P.HW = ((d->H + 1) / 2) * ((d->W + 1) / 2); P.P = (int64_t)d->B * P.HW;
   P.alpha = d->alpha; P.beta = d->beta; P.x = d->out; P.ldo = d->N; P.no_resid = 1;
-  P.cv_H = d->H; P.cv_W = d->W; P.cv_Cin = d->C; P.cv_cpt = d->C / KCH;
+  P.cv_H = d->H; P.cv_W = d->W; P.cv_Cin = d->C; P.cv_cpt = d->C / 64;          // (64-deep steps per quadrant)
   const int T = d->D, PPW = 4 * (20 / T);
   const int64_t units = (P.P + PPW - 1) / PPW;
   if (units >= (1LL << 28)) return SDF_E_SHAPE;
@@ -896,7 +914,7 @@ int launch_wide_merge(const SdfMsMergeDesc* d, hipStream_t s) {
 
 bool ms_wide_attn_supports(const SdfQkAttnDesc* d) {
   if (wide_env_off() || (d->flags & SDF_QK_NARROW)) return false;
-  if (d->nsplit != 2 || d->Tq != 2 || d->C < 256 || d->C % 128 || d->C != d->nH * 32 || d->N1 < 24) return false;
+  if (d->nsplit != 2 || d->Tq != 2 || d->C < 192 || d->C % 64 || d->C != d->nH * 32 || d->N1 < 24) return false;
   if (!d->x_src || d->xB < 1 || d->xHW < 1 || (d->xD != 10 && d->xD != 20)) return false;
   if ((int64_t)d->xB * d->xD * d->xHW != d->x_rows) return false;
   const SdfNeuronCfg* ns[4] = {&d->sn_proj, &d->sn_q, &d->sn_k, &d->sn2_q};

@@ -44,8 +44,10 @@ class _Lin:
         w = linear.weight.detach().float().to(device).contiguous()
         self.N, self.K = w.shape
         self.Wp = hip.split_weight(w, nsplit)
-        # wide layers (swin stages 2 - 3) also carry int8 digit planes: what csrc/ms_wide.hip multiplies by (default plane mode only)
-        self.digits = hip.split_weight_i8x3(w) if nsplit == 2 and self.K >= 256 and self.K % 128 == 0 and self.N % 32 == 0 else None
+        # wide layers (swin stages 2 - 3) also carry int8 digit planes: what csrc/ms_wide.hip multiplies by (default plane mode only).
+        # The kernels take K = 192 (stage 1) as well; measured there (round 4, 17 280 rows) a block costs 110.7 us on them against
+        # 112.7 us on the streaming kernels - two-chunk K is all prologue - so stage 1 keeps the path it has been tested on for 3 rounds
+        self.digits = hip.split_weight_i8x3(w) if nsplit == 2 and self.K >= 256 and self.K % 64 == 0 and self.N % 32 == 0 else None
         self.bias = None if linear.bias is None else linear.bias.detach().float().to(device).contiguous()
         self.alpha, self.beta = bn_affine(bn, device) if bn is not None else (None, None)
 

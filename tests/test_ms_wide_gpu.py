@@ -71,7 +71,7 @@ def _delta(h, v_th=0.1):
 # ------------------------------------------------------------------------------------------------------------------ MLP
 @pytest.mark.parametrize("name", ["lif", "plif", "lif_hard", "if"])
 @pytest.mark.parametrize("B,D,H,W,Cc", [(1, 10, 18, 24, 384), (1, 10, 9, 12, 768), (2, 10, 5, 7, 384), (1, 20, 6, 5, 384),
-                                        (1, 20, 3, 3, 768), (3, 10, 1, 3, 256)])
+                                        (1, 20, 3, 3, 768), (3, 10, 1, 3, 256), (1, 10, 36, 48, 192), (2, 20, 5, 3, 192), (1, 10, 4, 6, 320)])
 def test_wide_mlp_steps_against_the_oracle(B, D, H, W, Cc, name):
     if name != "lif" and (D != 10 or B != 1):
         pytest.skip("the other neuron classes are covered on the shipped T = 10 shapes")
@@ -134,6 +134,7 @@ def _attn_case(B, D, H, W, Cc, window, shift, seed=0):
 @pytest.mark.parametrize("name", ["lif", "plif", "lif_hard", "if"])
 @pytest.mark.parametrize("stacked", [True, False])
 @pytest.mark.parametrize("B,D,H,W,Cc,window,shift", [
+    (1, 10, 36, 48, 192, (2, 9, 9), (1, 4, 4)),          # stage 1: K = 192 = one and a half 128-deep chunks
     (1, 10, 18, 24, 384, (2, 9, 9), (1, 4, 4)),          # stage 2 of the shipped model: padded width, shifted
     (1, 10, 18, 24, 384, (2, 9, 9), (0, 0, 0)),
     (1, 10, 9, 12, 768, (2, 9, 9), (1, 4, 4)),           # stage 3
@@ -289,7 +290,7 @@ def _merge_ref(sp, We, alpha, beta):
 
 
 @pytest.mark.parametrize("B,D,H,W,Cc", [(1, 10, 15, 20, 384), (1, 10, 30, 40, 256), (2, 10, 7, 9, 384), (1, 20, 6, 5, 128),
-                                        (1, 10, 1, 3, 128), (3, 20, 4, 4, 256)])
+                                        (1, 10, 1, 3, 128), (3, 20, 4, 4, 256), (1, 10, 36, 48, 192), (2, 10, 5, 7, 64), (1, 20, 3, 4, 320)])
 def test_wide_patch_merge_against_the_oracle(B, D, H, W, Cc):
     """sdf_ms_patch_merge_fwd on given spikes: exact integer sums -> fp64 reference to 1e-6 of the range, odd sizes included (15 x 20 is
     the shipped stage-2 map), and against the gather-map + spike GEMM path it replaces."""
@@ -317,7 +318,7 @@ def test_wide_patch_merge_against_the_oracle(B, D, H, W, Cc):
 
 def test_wide_patch_merge_refuses_what_it_is_not_built_for():
     lin = _L(rnd((192, 384), 920, -0.1, 0.1), rnd((192,), 921, 0.5, 1.5), rnd((192,), 922, -0.2, 0.2))
-    sp = torch.zeros((1, 10, 8, 8, 96), dtype=torch.uint8, device=DEV)                  # C % 128 != 0
+    sp = torch.zeros((1, 10, 8, 8, 96), dtype=torch.uint8, device=DEV)                  # C % 64 != 0
     assert hip.ms_patch_merge(sp, lin) is None
     lin2 = _L(rnd((256, 512), 923, -0.1, 0.1), rnd((256,), 924, 0.5, 1.5), rnd((256,), 925, -0.2, 0.2))
     assert hip.ms_patch_merge(torch.zeros((1, 4, 8, 8, 128), dtype=torch.uint8, device=DEV), lin2) is None    # D not in {10, 20}
