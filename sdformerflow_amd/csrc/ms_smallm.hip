@@ -511,6 +511,36 @@ int launch_smallm_conv(const GemmParams& G, hipStream_t s) {
   return e != hipSuccess ? (int)e : 0;
 }
 
+// out (M, N) fp32 = [BN]( A (M, K) u8 x W^T + bias ) + resid with the digits in fragment order: the stacked-tap product of the first
+// decoder (reference Spiking_modules.py:461-474 as one GEMM, 1 080 rows x 3 456 columns x K = 1 536) and anything else of that shape
+bool smallm_gemm_supports(const GemmParams& P) {
+  const SdfSpikeGemmDesc& d = P.d;
+  if (const char* e = getenv("SDF_SMALLM")) { if (e[0] == '0') return false; }
+  if (d.nsplit != SDF_PLANES_I8X3_TILED || !d.col_scale || d.sn_T > 0 || !d.out) return false;
+  if (d.K % 64 || d.K < 64 || d.N % 32 || d.lda != d.K || d.out_rowmap || d.add || d.zg_nH) return false;
+  if (d.M % 10 || d.M > SMALLM_MAX_ROWS) return false;            // (rows are walked as 10 "steps" x M / 10 "positions": any order serves the fp32 form)
+  if (d.M * (int64_t)d.K >= (1LL << 31) || d.M * (int64_t)d.ldo * 4 >= (1LL << 31) || (int64_t)d.N * d.K * 3 >= (1LL << 31)) return false;
+  return sdf_aligned(d.A, 16) && sdf_aligned(d.Wp, 16) && sdf_aligned(d.out, 16) && (!d.resid || sdf_aligned(d.resid, 16)) && d.ldo >= d.N;
+}
+
+int launch_smallm_gemm(const GemmParams& G, hipStream_t s) {
+  const SdfSpikeGemmDesc& d = G.d;
+  SmallMParams P = {};
+  P.A = d.A; P.W = reinterpret_cast<const int8_t*>(d.Wp); P.cscale = d.col_scale; P.N = d.N; P.K = d.K; P.HW = (int)(d.M / 10); P.P = d.M / 10;
+  P.alpha = d.alpha; P.beta = d.beta; P.bias = d.bias; P.resid = d.resid; P.out = d.out; P.ldo = (int)d.ldo;
+  P.nunits = (int)((P.P + 7) / 8);
+  int cb = d.N % 48 == 0 ? 3 : 2;
+  if (const char* e = getenv("SDF_SMALLM_CB")) { if (e[0] == '3' && d.N % 48 == 0) cb = 3; else if (e[0] == '2') cb = 2; }   // tuning override
+  P.ncg = d.N / (16 * cb);
+  const int64_t items = (int64_t)P.ncg * P.nunits;
+  if (items >= (1LL << 31) - 8) return SDF_E_SHAPE;
+  const dim3 grid((unsigned)((items + 7) / 8 * 8));
+  if (cb == 3) hipLaunchKernelGGL((smallm_kernel<10, 2, 0, 0, true, 3>), grid, dim3(256), 0, s, P);
+  else hipLaunchKernelGGL((smallm_kernel<10, 2, 0, 0, true, 2>), grid, dim3(256), 0, s, P);
+  hipError_t e = hipGetLastError();
+  return e != hipSuccess ? (int)e : 0;
+}
+
 }  // namespace sdfmm
 
 #ifdef SDF_STAMP

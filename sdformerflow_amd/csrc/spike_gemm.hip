@@ -453,6 +453,13 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
   const bool spike = d->sn_T > 0;
   if (spike ? !d->out_spike : !d->out) return SDF_E_NULL;
   if (d->M < 1 || d->M >= (1LL << 31) || d->N < 32 || d->K < 32 || d->K % 32 || d->N % 32) return SDF_E_SHAPE;
+  if (d->nsplit == SDF_PLANES_I8X3_TILED) {                      // digit planes in fragment order: few rows against many weights, fp32 out
+    if (!d->col_scale) return SDF_E_NULL;
+    if (d->alpha && !d->beta) return SDF_E_NULL;
+    GemmParams Q;
+    Q.d = *d;
+    return smallm_gemm_supports(Q) ? launch_smallm_gemm(Q, sdf_stream(stream)) : SDF_E_SHAPE;
+  }
   if (d->nsplit < 1 || d->nsplit > 3) return SDF_E_DTYPE;         // 1 = bf16, 2 = fp16 hi/lo (scaled), 3 = bf16 hi/mid/lo
   if (!sdf_scale_ok(d)) return SDF_E_DTYPE;
   if (d->alpha && !d->beta) return SDF_E_NULL;

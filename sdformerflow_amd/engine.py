@@ -177,7 +177,10 @@ def deconv_tap_weights(w, cin_pad, nsplit):
     Cin, Cout = w.shape[:2]
     wk = torch.zeros((9 * Cout, cin_pad), dtype=torch.float32, device=w.device)
     wk[:, :Cin] = w.detach().float().permute(2, 3, 1, 0).reshape(9 * Cout, Cin)
-    return hip.split_weight(wk, nsplit)
+    planes = hip.split_weight(wk, nsplit)
+    if nsplit == 2 and cin_pad % 64 == 0:                    # (the small-M kernel's operand: the same matrix as int8 digits in fragment order)
+        planes.digits = hip.tile_weight_i8x3(hip.split_weight_i8x3(wk))
+    return planes
 
 
 class MSFlowEngine:
@@ -689,7 +692,10 @@ class MSFlowEngine:
                 if key not in self._deconv:
                     self._deconv[key] = deconv_tap_weights(wuse, cp, self.nsplit)
                 Y = torch.empty((B * D * h * w, 9 * cout), dtype=torch.float32, device=y.device)
-                hip.spike_gemm(s, self._deconv[key], Y, B * D * h * w, 9 * cout, cp)
+                taps = self._deconv[key]
+                if getattr(taps, "digits", None) is not None and hip.smallm_gemm_applicable(B * D * h * w, 9 * cout, cp):
+                    taps = taps.digits                        # few rows against many weights (level 0: 1 080 x 3 456 x 1 536): csrc/ms_smallm.hip
+                hip.spike_gemm(s, taps, Y, B * D * h * w, 9 * cout, cp)
                 hip.deconv_col2im(Y, B * D, h, w, cout, alpha=bn[0], beta=bn[1], out=z)
             # the conv kernel addresses its operands with 31-bit byte offsets: a larger z (config 5: 80 images of
             # 240 x 320 x 96 fp32) goes image chunk by image chunk - the row map of the first n images serves every chunk

@@ -420,6 +420,15 @@ def tile_weight_i8x3(planes):
     return tiled
 
 
+def smallm_gemm_applicable(M, N, K):
+    """Mirror of the library's rule for the plain small-M product (csrc/ms_smallm.hip: smallm_gemm_supports) plus the engine's
+    own bound: it pays where K is long enough to amortise a workgroup's prologue and reduction (measured: the first decoder's
+    1 080 x 3 456 x 1 536 product; not the second's 4 320 x 1 728 x 832)."""
+    if os.environ.get("SDF_SMALLM", "") == "0" or M % 10 or N % 32 or K % 64:
+        return False
+    return M <= 64 * 80 and K >= (int(os.environ["SDF_SMALLM_MINK"]) if "SDF_SMALLM_MINK" in os.environ else 1024)
+
+
 def pack_conv_weight_i8x3(w, tiled=False):
     """Conv2d weight (Cout, Cin, KH, KW) fp32 -> int8 digit planes (3, Cout, KH*KW*Cin), K in (ky, kx, cin) order; `tiled`: in the
     fragment order of tile_weight_i8x3."""
@@ -441,11 +450,17 @@ def spike_gemm(A, Wp, out, M, N, K, lda=None, ldo=None, bias=None, alpha=None, b
     """sdf_spike_gemm_fwd.  A: u8 spikes, Wp: int16 (nsplit,N,K) bf16 planes, out: fp32.
     zg = (nH, Tq, B_, N1) selects the head-scramble A addressing."""
     d = SpikeGemmDesc()
-    d.A, d.Wp, d.out = _ptr(A, torch.uint8), _ptr(Wp, torch.int16), _ptr(out, torch.float32)
+    d.A, d.Wp, d.out = _ptr(A, torch.uint8), _ptr(Wp), _ptr(out, torch.float32)
     d.M, d.N, d.K = M, N, K
     d.lda = K if lda is None else lda
     d.ldo = N if ldo is None else ldo
     d.nsplit, d.acc_scale = Wp.shape[0], _acc_scale(Wp)
+    if Wp.dtype == torch.int8:                                   # digit planes in fragment order (tile_weight_i8x3): the small-M kernel
+        if not getattr(Wp, "sdf_tiled", False):
+            raise SdfError("sdf_spike_gemm_fwd reads int8 digit planes in fragment order only (tile_weight_i8x3)")
+        d.nsplit, d.col_scale = PLANES_I8X3_TILED, _ptr(Wp.sdf_col_scale, torch.float32)
+    elif Wp.dtype != torch.int16:
+        raise SdfError(f"weight planes must be int16 (16-bit float planes) or int8 (tiled digit planes), got {Wp.dtype}")
     d.bias, d.alpha, d.beta = _ptr(bias, torch.float32), _ptr(alpha, torch.float32), _ptr(beta, torch.float32)
     d.resid, d.out_rowmap = _ptr(resid, torch.float32), _ptr(out_rowmap, torch.int32)
     if out_rowmap is not None:

@@ -101,3 +101,37 @@ def test_fused_neuron_forms(B, T, H, W, Cin, Cout, membrane, kind, v_reset, tile
         assert (m.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
         own = R.neuron_ref(m.cpu().view(B, T, hw, Cout).permute(1, 0, 2, 3).contiguous(), kind, 2.0, 0.1, v_reset)
         assert torch.equal(own, got), "spikes are not the neuron of the stored membrane"
+
+
+@pytest.mark.parametrize("M,N,K,extras", [(1080, 3456, 1536, False), (1080, 96, 1536, True), (200, 64, 128, True), (10, 32, 64, False), (4320, 192, 832, True)])
+def test_plain_product_with_fp32_epilogue(M, N, K, extras):
+    """`sdf_spike_gemm_fwd` with digits in fragment order (nsplit = SDF_PLANES_I8X3_TILED): the first decoder's stacked-tap GEMM
+    (reference Spiking_modules.py:461-474 written as one product + col2im) - exact integer sums against fp64 to 1e-6 of the range, and
+    against the streaming kernel on the fp16 planes of the same weights."""
+    assert hip.smallm_gemm_applicable(M, N, K) or K < 1024
+    A = spikes((M, K), 400 + N, 0.25)
+    Wt = rnd((N, K), 401, -0.07, 0.07)
+    dg = hip.tile_weight_i8x3(hip.split_weight_i8x3(Wt.to(DEV)))
+    kw, ref = {}, None
+    We = _weff(hip.split_weight_i8x3(Wt.to(DEV)))
+    ref = A.double() @ We.t()
+    if extras:
+        alpha, beta, bias, resid = rnd((N,), 402, 0.5, 1.5), rnd((N,), 403, -0.2, 0.2), rnd((N,), 404, -0.1, 0.1), rnd((M, N), 405)
+        kw = dict(alpha=alpha.to(DEV), beta=beta.to(DEV), bias=bias.to(DEV), resid=resid.to(DEV))
+        ref = (ref + bias.double()) * alpha.double() + beta.double() + resid.double()
+    out = torch.full((M, N), float("nan"), device=DEV)
+    hip.spike_gemm(A.to(DEV), dg, out, M, N, K, **kw)
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
+    old = torch.empty_like(out)
+    hip.spike_gemm(A.to(DEV), hip.split_weight(Wt.to(DEV), 2), old, M, N, K, **kw)
+    assert (out - old).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+def test_plain_product_refuses_what_it_is_not_built_for():
+    Wt = rnd((64, 128), 410, -0.1, 0.1)
+    dg = hip.tile_weight_i8x3(hip.split_weight_i8x3(Wt.to(DEV)))
+    out = torch.empty((12, 64), device=DEV)
+    with pytest.raises(hip.SdfError):
+        hip.spike_gemm(spikes((12, 128), 411).to(DEV), dg, out, 12, 64, 128)                 # M % 10 != 0
+    with pytest.raises(hip.SdfError):
+        hip.spike_gemm(spikes((10, 128), 412).to(DEV), hip.split_weight_i8x3(Wt.to(DEV)), torch.empty((10, 64), device=DEV), 10, 64, 128)   # row-major digits

@@ -37,7 +37,7 @@ for f in glob.glob(d + "/trace/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for kn in sorted(acc):
-    if "wide_" not in kn and "neuron_kernel" not in kn:
+    if "wide_" not in kn and "neuron_kernel" not in kn and "smallm_" not in kn:
         continue
     m = {k: sum(v[len(v) // 2:]) / max(len(v[len(v) // 2:]), 1) for k, v in acc[kn].items()}      # later launches: warm
     dd = dur.get(kn, [])
