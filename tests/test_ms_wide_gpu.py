@@ -166,6 +166,11 @@ def test_wide_attention_steps_against_the_oracle(B, D, H, W, Cc, window, shift, 
     hip.qk_attn(xg, rowmap, B_, Tq, N1, nH, plin, p, p, p, p, keep_ws=keep, x_src=zsrc, emit=(ws_mlp, p), info=info, **kw)
     torch.cuda.synchronize()
     assert info.get("emitted") is True, "the wide-stage kernels were not taken"
+    # the production form (no tape, nothing emitted) must give the same x bit for bit
+    xh = x0.to(DEV).clone()
+    hip.qk_attn(xh, rowmap, B_, Tq, N1, nH, plin, p, p, p, p, x_src=zsrc, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(xh, xg), "the tape changes the result"
     ws = keep[0].cpu()
     pad = lambda n: (n + 255) // 256 * 256
     e = ws[:M * Cc].view(Tq, rows, Cc)
