@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SDF_VERSION 103
+#define SDF_VERSION 104
 
 enum { SDF_F32 = 0, SDF_U8 = 1 };
 enum { SDF_LIF = 0, SDF_PSN = 1, SDF_IF = 2 };
