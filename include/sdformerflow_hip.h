@@ -383,6 +383,11 @@ typedef struct SdfMsMlpDesc {
    * or MS_ResBlock.sn1 of the U-Net bottleneck, Spiking_modules.py:922) - from the last launch's epilogue, so x is not read again. */
   uint8_t* emit_next;
   SdfNeuronCfg emit_sn;
+  /* wide-stage form, optional: fc2's digits again in MFMA fragment order (sdf_tile_weight_i8x3 of fc2_digits; fc2_cscale serves both).
+   * With it fc2 runs on the small-M kernel (csrc/ms_smallm.hip: K split over the waves of a workgroup, two workgroups per compute
+   * unit) instead of the wide main loop where its (80-row unit x 32-column) tiles fit the chip in one round (<= 512 tiles: swin stage 3 at
+   * batch 1, 30.9 -> 19.9 us) - bit-equal results; NULL = the wide main loop. */
+  const int8_t* fc2_tiled;
 } SdfMsMlpDesc;
 
 enum {

@@ -511,6 +511,43 @@ int launch_smallm_conv(const GemmParams& G, hipStream_t s) {
   return e != hipSuccess ? (int)e : 0;
 }
 
+// fc2 of the wide-stage MLP (reference Spiking_swin_transformer3D.py:175-178, :845): x += BN2( s2 W2^T ) in place on the (B, D, HW, C)
+// stream, s2 = the hidden spikes row-major [tokens][Ch]; with emit_next also SN_emit over D of the updated x.  Measured against the wide
+// main loop (round 4): 30.9 -> 19.9 us at stage 3 (1 080 tokens x 768 x 3 072: 336 tiles, all resident at two per compute unit), but
+// 20.1 -> 24.0 us at stage 2 (4 320 x 384 x 1 536: 648 tiles of 6 steps per wave - two rounds of mostly prologue and reduction), so the
+// form is taken while the tiles fit the chip in one round (<= 512).
+bool smallm_fc2_supports(const SdfMsMlpDesc* d) {
+  if (const char* e = getenv("SDF_SMALLM")) { if (e[0] == '0') return false; }
+  if (const char* e = getenv("SDF_SMALLM_FC2")) { if (e[0] == '0') return false; }
+  if (!d->fc2_tiled || !d->fc2_cscale || (d->D != 10 && d->D != 20) || d->Ch % 64 || d->C % 32) return false;
+  const int64_t tokens = (int64_t)d->B * d->D * d->HW;
+  if (tokens > SMALLM_MAX_ROWS || tokens * d->Ch >= (1LL << 31) || tokens * d->C * 4 >= (1LL << 31) || (int64_t)d->C * d->Ch * 3 >= (1LL << 31)) return false;
+  if (d->emit_next && !smallm_neuron_ok(d->emit_sn)) return false;
+  {
+    const int64_t ppw = 4 * (20 / d->D), units = ((int64_t)d->B * d->HW + ppw - 1) / ppw;
+    const char* e = getenv("SDF_SMALLM_FC2");
+    if (units * (d->C / 32) > 512 && !(e && e[0] == '2')) return false;       // (SDF_SMALLM_FC2=2: at any size, tests / A/B)
+  }
+  return sdf_aligned(d->fc2_tiled, 16) && sdf_aligned(d->x, 16) && (!d->emit_next || sdf_aligned(d->emit_next, 16));
+}
+
+int launch_smallm_fc2(const SdfMsMlpDesc* d, const uint8_t* s2, hipStream_t s) {
+  SmallMParams P = {};
+  P.A = s2; P.W = d->fc2_tiled; P.cscale = d->fc2_cscale; P.N = d->C; P.K = d->Ch; P.HW = (int)d->HW; P.P = (int64_t)d->B * d->HW;
+  P.alpha = d->fc2_alpha; P.beta = d->fc2_beta; P.resid = d->x; P.out = d->x; P.ldo = d->C;        // (a lane reads its shortcut values before it writes them)
+  P.out_spike = d->emit_next; P.ldsp = d->C; P.sn = d->emit_sn; P.inv_tau = d->emit_next ? inv_tau_of(d->emit_sn) : 0.f;
+  const int T = d->D, PPW = 4 * (20 / T);
+  P.nunits = (int)((P.P + PPW - 1) / PPW);
+  P.ncg = d->C / 32;                                              // 32-column tiles: two workgroups per compute unit
+  const int64_t items = (int64_t)P.ncg * P.nunits;
+  if (items >= (1LL << 31) - 8) return SDF_E_SHAPE;
+  const dim3 grid((unsigned)((items + 7) / 8 * 8));
+  const int epi = d->emit_next ? 3 : 2, nk = d->emit_next ? neuron_class(d->emit_sn) : 0;
+  if (T == 10) launch_t<10, 0, true, 2>(P, epi, nk, grid, s); else launch_t<20, 0, true, 2>(P, epi, nk, grid, s);
+  hipError_t e = hipGetLastError();
+  return e != hipSuccess ? (int)e : 0;
+}
+
 // out (M, N) fp32 = [BN]( A (M, K) u8 x W^T + bias ) + resid with the digits in fragment order: the stacked-tap product of the first
 // decoder (reference Spiking_modules.py:461-474 as one GEMM, 1 080 rows x 3 456 columns x K = 1 536) and anything else of that shape
 bool smallm_gemm_supports(const GemmParams& P) {

@@ -866,12 +866,15 @@ bool ms_wide_mlp_supports(const SdfMsMlpDesc* d) {
 // s1 = SN1(x) must already be in `s1` (row-major u8 [tokens][C], or tiled); s2 receives the hidden spikes (row-major for the
 // parity tape, else tiled); x is updated in place
 int launch_ms_wide_mlp(const SdfMsMlpDesc* d, const uint8_t* s1, bool s1_tiled, uint8_t* s2, bool s2_tiled, hipStream_t s) {
+  const bool fc2_small = smallm_fc2_supports(d);            // few tokens against a long K: fc2 on the small-M kernel (reads s2 row-major)
+  if (fc2_small) s2_tiled = false;
   WidePmParams P = {};
   P.A = s1; P.a_tiled = s1_tiled; P.out_tiled = s2_tiled; P.W = d->fc1_digits; P.cscale = d->fc1_cscale; P.N = d->Ch; P.K = d->C; P.HW = (int)d->HW; P.P = (int64_t)d->B * d->HW;
   P.alpha = d->fc1_alpha; P.beta = d->fc1_beta;
   P.out_spike = s2; P.ldsp = d->Ch; P.sn = d->sn2; P.inv_tau = inv_tau_of(d->sn2);
   int rc = launch_pm(P, d->D, 1, s);
   if (rc) return rc;
+  if (fc2_small) return launch_smallm_fc2(d, s2, s);
   WidePmParams Q = {};
   Q.A = s2; Q.a_tiled = s2_tiled;
   Q.W = d->fc2_digits; Q.cscale = d->fc2_cscale; Q.N = d->C; Q.K = d->Ch; Q.HW = (int)d->HW; Q.P = P.P;

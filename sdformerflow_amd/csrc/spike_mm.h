@@ -229,6 +229,8 @@ int launch_ms_wide_front(const SdfQkAttnDesc* d, const uint8_t* xs, uint8_t* e, 
 int launch_ms_wide_proj(const SdfQkAttnDesc* d, const uint8_t* e, hipStream_t s);
 bool smallm_conv_supports(const GemmParams& P);          // ms_smallm.hip: few rows against many weights, K split inside the workgroup
 int launch_smallm_conv(const GemmParams& P, hipStream_t s);
+bool smallm_fc2_supports(const SdfMsMlpDesc* d);          // the wide-stage MLP's second product on the small-M kernel
+int launch_smallm_fc2(const SdfMsMlpDesc* d, const uint8_t* s2, hipStream_t s);
 bool smallm_gemm_supports(const GemmParams& P);          // plain rows, fp32 epilogue (the decoders' stacked-tap product)
 int launch_smallm_gemm(const GemmParams& P, hipStream_t s);
 bool wide_merge_supports(const SdfMsMergeDesc* d);

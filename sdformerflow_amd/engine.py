@@ -103,6 +103,8 @@ class _Block:
         m = blk.mlp
         self.fc1 = _Lin(m.fc1, m.bn1.norm_layer, device, nsplit)
         self.fc2 = _Lin(m.fc2, m.bn2.norm_layer, device, nsplit)
+        if self.fc2.digits is not None:                      # wide stages: fc2 (K = 4 C against few tokens) runs on the small-M kernel
+            self.fc2.digits_tiled = hip.tile_weight_i8x3(self.fc2.digits)
         self.sn1, self.sn2 = _np(m.sn1, device), _np(m.sn2, device)
 
 

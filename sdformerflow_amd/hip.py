@@ -629,7 +629,7 @@ class MsMlpDesc(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
                 ("gemm_workspace", C.c_void_p), ("gemm_workspace_bytes", C.c_int64), ("flags", C.c_int32), ("s1_in", C.c_void_p),
                 ("fc1_digits", C.c_void_p), ("fc1_cscale", C.c_void_p), ("fc2_digits", C.c_void_p), ("fc2_cscale", C.c_void_p),
-                ("emit_next", C.c_void_p), ("emit_sn", NeuronCfg)]
+                ("emit_next", C.c_void_p), ("emit_sn", NeuronCfg), ("fc2_tiled", C.c_void_p)]
 
 
 class MsMergeDesc(C.Structure):
@@ -671,6 +671,7 @@ def ms_mlp(x, fc1, fc2, sn1, sn2, keep_ws=None, three_launches=False, ws=None, s
     d.flags = (MLP_KEEP_SPIKES if keep_ws is not None else 0) | (MLP_THREE_LAUNCHES if three_launches else 0) | (MLP_NARROW if narrow else 0)
     d.fc1_digits, d.fc1_cscale = _digits(getattr(fc1, "digits", None))
     d.fc2_digits, d.fc2_cscale = _digits(getattr(fc2, "digits", None))
+    d.fc2_tiled = _ptr(getattr(fc2, "digits_tiled", None), torch.int8)      # (fragment order: fc2 on the small-M kernel, csrc/ms_smallm.hip)
     if s1_ready:
         d.s1_in = ws.data_ptr()
     if emit_next is not None:

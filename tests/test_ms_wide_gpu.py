@@ -31,6 +31,7 @@ class _L:
         self.N, self.K = W.shape
         self.Wp = hip.split_weight(W.to(DEV).contiguous(), ns)
         self.digits = hip.split_weight_i8x3(W.to(DEV).contiguous())
+        self.digits_tiled = hip.tile_weight_i8x3(self.digits)            # (fc2 of <= 5 120 tokens takes the small-M kernel through these)
         self.alpha, self.beta = alpha.to(DEV).contiguous(), beta.to(DEV).contiguous()
         self.bias = None if bias is None else bias.to(DEV).contiguous()
 
@@ -327,3 +328,27 @@ def test_wide_patch_merge_refuses_what_it_is_not_built_for():
     assert hip.ms_patch_merge(sp, lin) is None
     lin2 = _L(rnd((256, 512), 923, -0.1, 0.1), rnd((256,), 924, 0.5, 1.5), rnd((256,), 925, -0.2, 0.2))
     assert hip.ms_patch_merge(torch.zeros((1, 4, 8, 8, 128), dtype=torch.uint8, device=DEV), lin2) is None    # D not in {10, 20}
+
+
+@pytest.mark.parametrize("B,D,H,W,Cc", [(1, 10, 18, 24, 384), (1, 10, 9, 12, 768), (2, 20, 5, 3, 384), (3, 10, 4, 6, 192)])
+def test_fc2_on_the_small_m_kernel_equals_the_wide_main_loop(B, D, H, W, Cc, monkeypatch):
+    """`SdfMsMlpDesc.fc2_tiled`: fc2 on csrc/ms_smallm.hip (K split over the waves of a workgroup) against the wide main loop - the same
+    integer sums and the same fp32 epilogue: x and the emitted next-layer spikes bit-equal."""
+    Ch = 4 * Cc
+    x0 = rnd((B, D, H, W, Cc), 930, -0.5, 1.0)
+    fc1 = _L(rnd((Ch, Cc), 931, -0.15, 0.15), rnd((Ch,), 933, 0.5, 1.5), rnd((Ch,), 934, -0.2, 0.2))
+    fc2 = _L(rnd((Cc, Ch), 932, -0.05, 0.05), rnd((Cc,), 935, 0.5, 1.5), rnd((Cc,), 936, -0.2, 0.2))
+    p, pn = _np("lif"), _np("lif", v_th=0.25)
+
+    def run():
+        buf = torch.full((B, D, H, W, Cc), 7, dtype=torch.uint8, device=DEV)
+        x = hip.ms_mlp(x0.to(DEV).clone(), fc1, fc2, p, p, emit_next=(buf, pn))
+        y = hip.ms_mlp(x0.to(DEV).clone(), fc1, fc2, p, p)
+        torch.cuda.synchronize()
+        return x, buf, y
+    monkeypatch.setenv("SDF_SMALLM_FC2", "2")                          # (at any size: the dispatcher takes it up to 512 tiles)
+    xs, bs, ys = run()
+    monkeypatch.setenv("SDF_SMALLM_FC2", "0")
+    xw, bw, yw = run()
+    assert torch.equal(xs, xw) and torch.equal(bs, bw) and torch.equal(ys, yw) and torch.equal(xs, ys)
+    assert not torch.equal(xs, x0.to(DEV))
