@@ -497,10 +497,11 @@ int launch_smallm_conv(const GemmParams& G, hipStream_t s) {
   const int PPW = 4 * (20 / T);
   P.nunits = (int)((P.P + PPW - 1) / PPW);
   const bool bt = d.nsplit == SDF_PLANES_I8X3_TILED;
-  // tile width: 48 columns where that is one workgroup per compute unit at most (fewer re-reads of the spikes, deeper prefetch) and the
-  // 32-column grid would not fit the chip in one round either; else 32 columns (two workgroups per compute unit)
+  // tile width: 32 columns, two workgroups per compute unit.  The 48-column tile (one workgroup per compute unit, two operand steps in
+  // flight) is 2 us faster on its own at the bottleneck shape (25.2 vs 27.5 us) but holds 224 whole compute units where this one packs
+  // 336 workgroups onto 168: with three forwards in flight the headline measured +0.9 % with the narrow tile (three alternating pairs
+  // of runs on one box: 687.8 / 683.5 / 685.7 against 680.7 / 677.2 / 679.6 samples/s).  SDF_SMALLM_CB=3 selects the wide tile.
   int cb = 2;
-  if (bt && d.N % 48 == 0 && (int64_t)(d.N / 32) * P.nunits > 256 && (int64_t)(d.N / 48) * P.nunits <= 256) cb = 3;
   if (const char* e = getenv("SDF_SMALLM_CB")) { if (bt && e[0] == '3' && d.N % 48 == 0) cb = 3; else if (e[0] == '2') cb = 2; }   // tuning override
   P.ncg = d.N / (16 * cb);
   const int64_t items = (int64_t)P.ncg * P.nunits;
@@ -566,7 +567,7 @@ int launch_smallm_gemm(const GemmParams& G, hipStream_t s) {
   P.A = d.A; P.W = reinterpret_cast<const int8_t*>(d.Wp); P.cscale = d.col_scale; P.N = d.N; P.K = d.K; P.HW = (int)(d.M / 10); P.P = d.M / 10;
   P.alpha = d.alpha; P.beta = d.beta; P.bias = d.bias; P.resid = d.resid; P.out = d.out; P.ldo = (int)d.ldo;
   P.nunits = (int)((P.P + 7) / 8);
-  int cb = d.N % 48 == 0 ? 3 : 2;
+  int cb = 2;                                                     // (as the convolution: the narrow tile packs two workgroups per compute unit)
   if (const char* e = getenv("SDF_SMALLM_CB")) { if (e[0] == '3' && d.N % 48 == 0) cb = 3; else if (e[0] == '2') cb = 2; }   // tuning override
   P.ncg = d.N / (16 * cb);
   const int64_t items = (int64_t)P.ncg * P.nunits;
