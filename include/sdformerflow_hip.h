@@ -444,6 +444,11 @@ typedef struct SdfSpikeConvDesc {
 } SdfSpikeConvDesc;
 
 int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream);
+/* n (1 .. 4 fused) convolutions with the fp32 epilogue on the SAME images and output buffer that differ only in taps (KH, KW, dy, dx),
+ * weights and g.out_rowmap - the four output-parity classes of ConvTranspose2d(k 3, s 2, p 1, op 1) in MS_SpikingTransposeDecoderLayer
+ * (reference Spiking_modules.py:461-474), whose row maps write disjoint rows: ONE launch where the library's streaming kernel serves
+ * every one of them (each class alone fills about half of the chip), otherwise exactly n calls of sdf_spike_conv2d_fwd in order. */
+int sdf_spike_conv2d_multi_fwd(const SdfSpikeConvDesc* cs, int n, void* stream);
 
 /* W (fp32, n elements) -> nsplit bf16 planes (round-to-nearest-even residual split). */
 int sdf_split_weight_bf16(const float* W, uint16_t* planes, int64_t n, int nsplit, void* stream);

@@ -548,7 +548,8 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
 
 // ---------------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution on spike images (NHWC u8): the same persistent MFMA kernel with an im2col loader.
-extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
+// argument checks of sdf_spike_conv2d_fwd + the kernel-side parameter block (no launch)
+static int conv2d_build(const SdfSpikeConvDesc* c, GemmParams& P, bool& i8x3, bool& tiled) {
   if (!c) return SDF_E_NULL;
   const SdfSpikeGemmDesc* d = &c->g;
   if (!d->A || !d->Wp) return SDF_E_NULL;
@@ -558,14 +559,13 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
   if (c->Cin < 48 || c->Cin % 16 || c->KH < 1 || c->KH > 3 || c->KW < 1 || c->KW > 3 || c->sy < 1 || c->sx < 1) return SDF_E_SHAPE;
   if (d->K != c->KH * c->KW * c->Cin || d->N % 32 || d->M % ((int64_t)c->OH * c->OW) || d->M >= (1LL << 31)) return SDF_E_SHAPE;
   if ((d->M / ((int64_t)c->OH * c->OW)) * c->H * c->W >= (1LL << 31)) return SDF_E_SHAPE;
-  const bool tiled = d->nsplit == SDF_PLANES_I8X3_TILED;          // digit planes in fragment order: only the small-M kernel reads them
-  const bool i8x3 = d->nsplit == SDF_PLANES_I8X3 || tiled;       // int8 digit planes: the weight-resident / wide / small-M kernels
+  tiled = d->nsplit == SDF_PLANES_I8X3_TILED;          // digit planes in fragment order: only the small-M kernel reads them
+  i8x3 = d->nsplit == SDF_PLANES_I8X3 || tiled;       // int8 digit planes: the weight-resident / wide / small-M kernels
   if (!i8x3 && (d->nsplit < 1 || d->nsplit > 3)) return SDF_E_DTYPE;
   if (!i8x3 && !sdf_scale_ok(d)) return SDF_E_DTYPE;
   if (i8x3 && !d->col_scale) return SDF_E_NULL;
   if (d->alpha && !d->beta) return SDF_E_NULL;
   if (d->zg_nH > 0) return SDF_E_SHAPE;
-  GemmParams P;
   P.d = *d;
   P.d.lda = 0;
   P.inv_tau = 0.f;
@@ -588,6 +588,18 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
   cv.KWc = c->KW;
   cv.kw_mul = c->KW == 1 ? 32 : (c->KW == 2 ? 16 : 11);
   for (int i = 0; i < 3; ++i) { cv.dy[i] = c->dy[i]; cv.dx[i] = c->dx[i]; }
+  return 0;
+}
+
+extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
+  GemmParams P;
+  bool i8x3 = false, tiled = false;
+  {
+    const int rc = conv2d_build(c, P, i8x3, tiled);
+    if (rc) return rc;
+  }
+  const SdfSpikeGemmDesc* d = &c->g;
+  const bool spike = d->sn_T > 0;
   // few rows against many weights (the U-Net bottleneck's res-blocks) with digit planes: one launch, K split over the waves of a
   // workgroup (csrc/ms_smallm.hip); SDF_WIDE_CONV=1 selects the split-K-over-workgroups form it replaced (csrc/ms_wide.hip, A/B)
   if (i8x3 && wide_conv_supports(P)) return launch_wide_conv(P, sdf_stream(stream));
@@ -629,6 +641,36 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
   if (d->N % 96) return SDF_E_SHAPE;                              // the streaming kernels work on 96-column blocks
   if (d->nsplit == 2 || (spike && d->out)) return SDF_E_DTYPE;   // only the ping-pong kernel has these
   return launch_spike_mm_ws(P, true, sdf_stream(stream));
+}
+
+// n convolutions on the same images that differ only in taps / weights / output row map (the four output-parity classes of a
+// stride-2 transposed convolution): ONE launch of the ping-pong kernel where every one of them would take it, else one call each.
+extern "C" int sdf_spike_conv2d_multi_fwd(const SdfSpikeConvDesc* cs, int n, void* stream) {
+  if (!cs) return SDF_E_NULL;
+  if (n < 1) return SDF_E_SHAPE;
+  const char* epp = getenv("SDF_CONV_PP");
+  const char* emu = getenv("SDF_CONV_MULTI");                 // A/B override: 0 = one launch per convolution
+  if (n >= 2 && n <= 4 && !(epp && epp[0] == '0') && !(emu && emu[0] == '0')) {
+    GemmParams Ps[4];
+    bool one = true;
+    for (int i = 0; i < n; ++i) {
+      bool i8x3 = false, tiled = false;
+      const int rc = conv2d_build(cs + i, Ps[i], i8x3, tiled);
+      if (rc) return rc;
+      const char* ewr = getenv("SDF_CONV_WRES");
+      const bool wres = !(ewr && ewr[0] == '0') && spike_conv_wres_supports(Ps[i], i8x3 || (ewr && ewr[0] == '2'));
+      one = one && !i8x3 && cs[i].g.sn_T == 0 && !wres && spike_mm_pp_supports(Ps[i], true);
+    }
+    if (one) {
+      const int rc = launch_spike_mm_pp_multi(Ps, n, sdf_stream(stream));
+      if (rc != SDF_E_SHAPE) return rc;                        // (SDF_E_SHAPE: not one family after all - e.g. a split-K plan)
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    const int rc = sdf_spike_conv2d_fwd(cs + i, stream);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 extern "C" int sdf_split_weight_f16x2(const float* W, uint16_t* planes, int64_t n, float scale, void* stream) {

@@ -91,8 +91,10 @@ __device__ __forceinline__ void signal(uint32_t* p, int lane) {
   if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// The kernel's body: `blk` / `G` = this workgroup's index and the number of workgroups that share P's work items (the plain kernel's
+// blockIdx.x / gridDim.x; the multi-problem kernel below deals a range of its grid to every problem).
 template <int NSPLIT, int TT, bool CONV>
-__global__ __launch_bounds__(768) void spike_mm_pp_kernel(GemmParams P) {
+__device__ __forceinline__ void spike_mm_pp_body(const GemmParams& P, const int blk, const int G) {
   constexpr bool SPIKE = TT > 0;
   constexpr int T = SPIKE ? TT : 1;
   constexpr int NPOS = 32 / T;                                   // positions per lane-half (2 row blocks = 32 slots)
@@ -139,8 +141,7 @@ __global__ __launch_bounds__(768) void spike_mm_pp_kernel(GemmParams P) {
   // contiguous range of work items of this workgroup; item = tile * ksplit + kchunk, tiles column-block-major
   // (t = cb * tiles_m + rt).  Workgroups are dealt round-robin to the 8 XCDs, so consecutive ranges go to the
   // workgroups of ONE XCD: neighbouring row tiles (which share their im2col halo rows) meet in the same L2.
-  const int G = gridDim.x;
-  int wg = blockIdx.x;
+  int wg = blk;
   if ((G & 7) == 0) wg = (wg & 7) * (G >> 3) + (wg >> 3);
   const int nitems = P.ntiles * ksplit;
   const int base = nitems / G, rem = nitems % G;
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(768) void spike_mm_pp_kernel(GemmParams P) {
       step(R1, q + 1);
     }
 #ifdef SDF_STAMP
-    if (blockIdx.x == 0 && tid == 512) { g_sdf_stamp[0] = s_wait; g_sdf_stamp[1] = s_store; g_sdf_stamp[2] = s_dec; g_sdf_stamp[3] = s_load; g_sdf_stamp[4] = Q; }
+    if (blk == 0 && tid == 512) { g_sdf_stamp[0] = s_wait; g_sdf_stamp[1] = s_store; g_sdf_stamp[2] = s_dec; g_sdf_stamp[3] = s_load; g_sdf_stamp[4] = Q; }
 #endif
     return;
   }
@@ -611,12 +612,58 @@ __global__ __launch_bounds__(768) void spike_mm_pp_kernel(GemmParams P) {
     STAMP_ADD(s_epi, c2, c3);
   }
 #ifdef SDF_STAMP
-  if (blockIdx.x == 0 && (tid == 0 || tid == 256)) {
+  if (blk == 0 && (tid == 0 || tid == 256)) {
     const int o = tid == 0 ? 5 : 10;
     g_sdf_stamp[o] = s_cwait; g_sdf_stamp[o + 1] = s_mma; g_sdf_stamp[o + 2] = s_epi; g_sdf_stamp[o + 3] = __builtin_readcyclecounter() - kstart;
     g_sdf_stamp[o + 4] = (n_my + 1 - grp) / 2;
   }
 #endif
+}
+
+template <int NSPLIT, int TT, bool CONV>
+__global__ __launch_bounds__(768) void spike_mm_pp_kernel(GemmParams P) {
+  spike_mm_pp_body<NSPLIT, TT, CONV>(P, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Up to four convolutions that differ only in their taps, weights and output row map - the output-parity classes of a stride-2
+// transposed convolution (reference Spiking_modules.py:461-474; engine.py: deconv_classes) - as ONE launch: every class gets a range of
+// the grid and walks its own work items.  Alone, each class fills about half of the chip (135 two-item workgroups at the last decoder
+// level); together they fill it, and three launch boundaries go.  The per-class fields are scalar selects on the class index.
+constexpr int PP_MULTI_MAX = 4;
+struct GemmMulti {
+  GemmParams base;
+  const uint16_t* Wp[PP_MULTI_MAX];
+  const int32_t* rowmap[PP_MULTI_MAX];
+  int K[PP_MULTI_MAX], spc[PP_MULTI_MAX], KWc[PP_MULTI_MAX], kw_mul[PP_MULTI_MAX];
+  int dy[PP_MULTI_MAX][3], dx[PP_MULTI_MAX][3];
+  float acc_scale[PP_MULTI_MAX];
+  int first[PP_MULTI_MAX + 1];        // first workgroup of class i; first[n] = grid size
+  int n;
+};
+
+template <int NSPLIT>
+__global__ __launch_bounds__(768) void spike_mm_pp_multi_kernel(GemmMulti M) {
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < PP_MULTI_MAX; ++k)
+    if (k < M.n && (int)blockIdx.x >= M.first[k]) i = k;
+  i = __builtin_amdgcn_readfirstlane(i);
+#define SDF_PICK(f) (i == 0 ? M.f[0] : (i == 1 ? M.f[1] : (i == 2 ? M.f[2] : M.f[3])))
+#define SDF_PICK2(f, j) (i == 0 ? M.f[0][j] : (i == 1 ? M.f[1][j] : (i == 2 ? M.f[2][j] : M.f[3][j])))
+  GemmParams P = M.base;
+  P.d.Wp = SDF_PICK(Wp);
+  P.d.out_rowmap = SDF_PICK(rowmap);
+  P.d.K = SDF_PICK(K);
+  P.spc = SDF_PICK(spc);
+  P.cv.KWc = SDF_PICK(KWc);
+  P.cv.kw_mul = SDF_PICK(kw_mul);
+  P.acc_scale = SDF_PICK(acc_scale);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { P.cv.dy[j] = SDF_PICK2(dy, j); P.cv.dx[j] = SDF_PICK2(dx, j); }
+  const int f0 = SDF_PICK(first), f1 = i == 0 ? M.first[1] : (i == 1 ? M.first[2] : (i == 2 ? M.first[3] : M.first[4]));
+#undef SDF_PICK
+#undef SDF_PICK2
+  spike_mm_pp_body<NSPLIT, 0, true>(P, (int)blockIdx.x - f0, f1 - f0);
 }
 
 template <int NSPLIT, bool CONV>
@@ -656,8 +703,8 @@ bool spike_mm_pp_supports(const GemmParams& P, bool conv) {
   return true;
 }
 
-int launch_spike_mm_pp(const GemmParams& Pin, bool conv, hipStream_t s) {
-  GemmParams P = Pin;
+// tiles, split-K plan and the number of workgroups of one problem (P is completed in place); < 0 = an SDF_E_* code
+static int pp_plan(GemmParams& P) {
   const SdfSpikeGemmDesc& d = P.d;
   if (d.N % BN) return SDF_E_SHAPE;
   const bool spike = d.sn_T > 0;
@@ -684,6 +731,14 @@ int launch_spike_mm_pp(const GemmParams& Pin, bool conv, hipStream_t s) {
     const int rounds = (nitems + 255) / 256;
     G = (nitems + rounds - 1) / rounds;
   }
+  return G;
+}
+
+int launch_spike_mm_pp(const GemmParams& Pin, bool conv, hipStream_t s) {
+  GemmParams P = Pin;
+  const SdfSpikeGemmDesc& d = P.d;
+  const int G = pp_plan(P);
+  if (G < 0) return G;
   dim3 grid((unsigned)G);
   int rc;
   if (conv)
@@ -694,6 +749,53 @@ int launch_spike_mm_pp(const GemmParams& Pin, bool conv, hipStream_t s) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return launch_splitk_reduce(P, s);
+}
+
+int launch_spike_mm_pp_multi(const GemmParams* Ps, int n, hipStream_t s) {
+  if (n < 2 || n > PP_MULTI_MAX) return SDF_E_SHAPE;
+  GemmMulti M = {};
+  M.n = n;
+  int wgs = 0;
+  // longest K first: workgroups start in grid order, and the tail of the launch should be the short classes
+  int order[PP_MULTI_MAX] = {0, 1, 2, 3};
+  for (int a = 0; a < n; ++a)
+    for (int b = a + 1; b < n; ++b)
+      if (Ps[order[b]].d.K > Ps[order[a]].d.K) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
+  for (int i = 0; i < n; ++i) {
+    GemmParams P = Ps[order[i]];
+    if (P.d.sn_T != 0) return SDF_E_SHAPE;
+    const int G = pp_plan(P);
+    if (G < 0) return G;
+    if (P.ksplit != 1) return SDF_E_SHAPE;                       // (a split-K member needs its own reduce pass: the caller launches one by one)
+    if (i == 0) {
+      M.base = P;
+    } else {                                                     // one family: everything but taps / weights / row map / K is shared
+      const SdfSpikeGemmDesc &a = M.base.d, &b = P.d;
+      const ConvGeom &u = M.base.cv, &v = P.cv;
+      if (a.A != b.A || a.out != b.out || a.M != b.M || a.N != b.N || a.ldo != b.ldo || a.nsplit != b.nsplit || a.bias != b.bias ||
+          a.alpha != b.alpha || a.beta != b.beta || a.resid != b.resid || a.out_rows != b.out_rows || a.zg_nH != b.zg_nH ||
+          u.H != v.H || u.W != v.W || u.Cin != v.Cin || u.OH != v.OH || u.OW != v.OW || u.sy != v.sy || u.sx != v.sx ||
+          M.base.tiles_m != P.tiles_m || M.base.tiles_n != P.tiles_n)
+        return SDF_E_SHAPE;
+    }
+    M.Wp[i] = P.d.Wp; M.rowmap[i] = P.d.out_rowmap; M.K[i] = P.d.K; M.spc[i] = P.spc; M.KWc[i] = P.cv.KWc; M.kw_mul[i] = P.cv.kw_mul;
+    M.acc_scale[i] = P.acc_scale;
+    for (int j = 0; j < 3; ++j) { M.dy[i][j] = P.cv.dy[j]; M.dx[i][j] = P.cv.dx[j]; }
+    M.first[i] = wgs;
+    wgs += G;
+  }
+  for (int i = n; i <= PP_MULTI_MAX; ++i) M.first[i] = wgs;
+  for (int i = n; i < PP_MULTI_MAX; ++i) { M.Wp[i] = M.Wp[0]; M.rowmap[i] = M.rowmap[0]; M.K[i] = M.K[0]; M.spc[i] = M.spc[0]; M.KWc[i] = M.KWc[0];
+                                            M.kw_mul[i] = M.kw_mul[0]; M.acc_scale[i] = M.acc_scale[0]; }
+  const dim3 grid((unsigned)wgs);
+  switch (M.base.d.nsplit) {
+    case 1: hipLaunchKernelGGL((spike_mm_pp_multi_kernel<1>), grid, dim3(768), 0, s, M); break;
+    case 2: hipLaunchKernelGGL((spike_mm_pp_multi_kernel<2>), grid, dim3(768), 0, s, M); break;
+    case 3: hipLaunchKernelGGL((spike_mm_pp_multi_kernel<3>), grid, dim3(768), 0, s, M); break;
+    default: return SDF_E_SHAPE;
+  }
+  hipError_t e = hipGetLastError();
+  return e != hipSuccess ? (int)e : 0;
 }
 
 }  // namespace sdfmm

@@ -704,7 +704,12 @@ class MSFlowEngine:
             imgs = per = B * D
             while per * 4 * h * w * cout * 4 >= 1 << 31:
                 per = (per + 1) // 2
-            for cls in ([] if as_gemm else self._deconv_classes(i, B, D, h, w, cp, wkey, wuse)):
+            classes = [] if as_gemm else self._deconv_classes(i, B, D, h, w, cp, wkey, wuse)
+            if classes and per == imgs:
+                # the four parity classes write disjoint rows of z and each fills about half of the chip: one launch for all of them
+                hip.spike_conv2d_multi(s.view(imgs, h, w, cp), classes, imgs, h, w, cp, h, w, z.view(imgs, 4 * h * w, cout), alpha=bn[0], beta=bn[1])
+                classes = []
+            for cls in classes:
                 for i0 in range(0, imgs, per):
                     n = min(per, imgs - i0)
                     hip.spike_conv2d(s.view(imgs, h, w, cp)[i0:i0 + n], cls["Wp"], n, h, w, cp, h, w, cls["KH"], cls["KW"], 1,

@@ -23,7 +23,7 @@ KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
 EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
            "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_spike_conv2d_fwd", "sdf_head_conv_sn_fwd",
            "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes",
-           "sdf_window_slice_map", "sdf_window_zsrc_map", "sdf_qk_attn_fwd", "sdf_qk_attn_is_wide", "sdf_ms_mlp_is_wide", "sdf_ms_patch_merge_fwd", "sdf_tile_weight_i8x3", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
+           "sdf_window_slice_map", "sdf_window_zsrc_map", "sdf_qk_attn_fwd", "sdf_qk_attn_is_wide", "sdf_ms_mlp_is_wide", "sdf_ms_patch_merge_fwd", "sdf_tile_weight_i8x3", "sdf_spike_conv2d_multi_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
            "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_pred_head_fwd", "sdf_pointwise_conv_f32_fwd", "sdf_neuron_multi_fwd", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
            "sdf_rows_gather_fwd", "sdf_rows_scatter_fwd",
            "sdf_split_weight_i8x3", "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd",
@@ -1099,6 +1099,30 @@ def spike_conv2d(x, Wp, imgs, H, W, Cin, OH, OW, KH, KW, stride, dy, dx, out=Non
                  resid=None, out_rowmap=None, sn=None, sn_T=0, pos=None):
     """sdf_spike_conv2d_fwd.  x: u8 spikes NHWC (imgs,H,W,Cin); Wp: planes (nsplit, Cout, KH*KW*Cin).
     fp32 epilogue -> `out` (rows, Cout); fused neuron (sn, sn_T=10, pos=(count, inner, ostride, t_stride)) -> `out_spike`."""
+    d = _conv_desc(x, Wp, imgs, H, W, Cin, OH, OW, KH, KW, stride, dy, dx, out, out_spike, alpha, beta, resid, out_rowmap, sn, sn_T, pos)
+    g = d.g
+    _note(flop=2 * g.M * g.N * g.K, shape=(int(g.M), int(g.N), int(g.K)), fused_neuron=sn is not None)
+    _check(lib().sdf_spike_conv2d_fwd(C.byref(d), _stream()), "sdf_spike_conv2d_fwd")
+    return out if sn is None else out_spike
+
+
+def spike_conv2d_multi(x, classes, imgs, H, W, Cin, OH, OW, out, alpha=None, beta=None):
+    """sdf_spike_conv2d_multi_fwd: up to four stride-1 convolutions of the same spike images into the same fp32 buffer that differ only in
+    taps, weights and output row map - `classes` = [{"Wp", "KH", "KW", "dy", "dx", "rowmap"}, ...], the output-parity classes of a
+    transposed convolution - as one launch where the library can (else one call each)."""
+    arr = (SpikeConvDesc * len(classes))()
+    flop = 0
+    for i, c in enumerate(classes):
+        d = _conv_desc(x, c["Wp"], imgs, H, W, Cin, OH, OW, c["KH"], c["KW"], 1, c["dy"], c["dx"], out, None, alpha, beta, None, c["rowmap"],
+                       None, 0, None)
+        C.memmove(C.byref(arr, i * C.sizeof(SpikeConvDesc)), C.byref(d), C.sizeof(SpikeConvDesc))
+        flop += 2 * d.g.M * d.g.N * d.g.K
+    _note(flop=flop, shape=(int(arr[0].g.M), int(arr[0].g.N), len(classes)))
+    _check(lib().sdf_spike_conv2d_multi_fwd(arr, C.c_int(len(classes)), _stream()), "sdf_spike_conv2d_multi_fwd")
+    return out
+
+
+def _conv_desc(x, Wp, imgs, H, W, Cin, OH, OW, KH, KW, stride, dy, dx, out, out_spike, alpha, beta, resid, out_rowmap, sn, sn_T, pos):
     d = SpikeConvDesc()
     g = d.g
     g.A, g.Wp = _ptr(x, torch.uint8), _ptr(Wp)
@@ -1128,9 +1152,7 @@ def spike_conv2d(x, Wp, imgs, H, W, Cin, OH, OW, KH, KW, stride, dy, dx, out=Non
     for i in range(3):
         d.dy[i] = dy[i] if i < len(dy) else 0
         d.dx[i] = dx[i] if i < len(dx) else 0
-    _note(flop=2 * g.M * g.N * g.K, shape=(int(g.M), int(g.N), int(g.K)), fused_neuron=sn is not None)
-    _check(lib().sdf_spike_conv2d_fwd(C.byref(d), _stream()), "sdf_spike_conv2d_fwd")
-    return out if sn is None else out_spike
+    return d
 
 
 def head_conv_sn_supported(T, H, W, Cin, Cout):
