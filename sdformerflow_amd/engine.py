@@ -619,6 +619,11 @@ class MSFlowEngine:
             calls.append((skip[0], img[0].view(-1)[c1:], D, hw, C2, C2, hw * C2, cp, hw * cp, sn))
             imgs.append(img)
             c1 = cout
+        # level 0's own input y rides in the same launch (its neuron is the level's `sn` too; six descriptors at most)
+        self._ready_has_y = len(calls) < 6
+        if self._ready_has_y:
+            cy, hw0, cp0 = y0.shape[-1], h0 * w0, imgs[0].shape[-1]
+            calls.append((y0[0], imgs[0][0].view(-1), D, hw0, cy, cy, hw0 * cy, cp0, hw0 * cp0, self.decoders[0][2]))
         hip.neuron_multi_fwd(calls)
         return imgs
 
@@ -656,7 +661,7 @@ class MSFlowEngine:
                 as_gemm, cp = self._decoder_geometry(i, B, D, h, w, cin)
                 if ready is not None:
                     s, c0 = ready[i], 0                                   # skip slice (and padding) already in place; level 0 takes y now
-                    srcs = [(y, C1, C1)] if i == 0 else []
+                    srcs = [(y, C1, C1)] if i == 0 and not self._ready_has_y else []
                 elif carried is not None:
                     s, srcs, c0 = carried, [(skip, C2, C2)], C1          # [y | . | prediction | zeros] came from the level above
                 else:
