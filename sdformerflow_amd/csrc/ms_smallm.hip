@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : 1) void smallm_kernel(SmallMPara
 #pragma unroll
     for (int j = 0; j < U; ++j) step(j);
   }
+  mfma_drain(acc);                                         // (the accumulators are read by vector instructions from here on)
 
   MSTAMP(2);
   // ---------------- the four partial sums meet ----------------

@@ -211,9 +211,9 @@ __device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __a
 #pragma unroll
   for (int i = 0; i < WIT; ++i) wreg[i] = wreg2[i];
   __syncthreads();
-  // even chunk count: two chunks per round - the register sets aX / aY alternate as "current" and each is refilled (chunk c + 2) as it
-  // dies: no copies between the sets (the single-chunk body moves the next chunk's 40 registers into the current one's every chunk;
-  // measured at stage 2: fc2 20.1 -> 17.0 us)
+  // two chunks per round - the register sets aX / aY alternate as "current" and each is refilled (chunk c + 2) as it dies: no copies
+  // between the sets (the single-chunk body moves the next chunk's 40 registers into the current one's every chunk; measured at stage 2:
+  // fc2 20.1 -> 17.0 us); an odd count ends with one lone chunk on aX
   if constexpr (CB == 3) {
     // three column blocks (180 accumulators): the single-chunk body (measured: the two-chunk round costs fc1 at K = 384 - three chunks
     // padded to four - 20.8 -> 22.0 us)
@@ -223,17 +223,21 @@ __device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __a
       __syncthreads();
     }
   } else {
-    // an odd chunk count runs one more chunk, of zeros (requests beyond the range read zeros).  (A two-chunk round followed by one lone
-    // chunk was built too: wrong sums in the projection's instantiations, not understood; a second, single-chunk body beside this one
-    // costs more in registers than the zero chunk does in MFMAs.)
+    int c = 0;
 #pragma unroll 1
-    for (int c = 0; c < nchunks; c += 2) {
+    for (; c + 1 < nchunks; c += 2) {
       chunk(c, 0, aX, std::false_type{});
       __syncthreads();
       chunk(c + 1, 1, aY, std::false_type{});
+      mfma_drain(acc);                                                // (the exit edge of the round may shuffle accumulators: wide_common.h)
+      __syncthreads();
+    }
+    if (c < nchunks) {                                                // odd count: the last chunk alone
+      chunk(c, 0, aX, std::false_type{});
       __syncthreads();
     }
   }
+  mfma_drain(acc);                                                    // (the accumulators are read by vector instructions from here on)
 }
 
 // this thread's weight pieces of a 128-deep chunk: piece = (digit plane p, column col of the group, k-piece kp); 256 threads take

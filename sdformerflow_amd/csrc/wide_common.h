@@ -56,6 +56,24 @@ __device__ __forceinline__ void mfma_i8(i32x4& acc, const i32x4& a, const i32x4&
   asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 
+// The MFMAs above are inline assembly: hipcc's hazard recogniser does not see that they write the accumulators, so nothing pads the
+// wait states an MFMA result needs before any OTHER kind of instruction may read or move it (cdna_hip_programming.md section 5.7 item 2:
+// "an MFMA's D -> any reader ... including compiler code after the asm", 12 states for an 8-pass MFMA).  mfma_drain() is that pad: the
+// nops, then every accumulator quad named as "+a" in an (empty) volatile statement behind them - volatile statements keep their order, so
+// no compiler-made read or copy of a quad can land between its last MFMA and the nops.  Call it behind the last MFMA of a main loop (and
+// of every loop ROUND where the compiler may shuffle accumulators on the loop's exit edge).  Found in round 4: a lone chunk behind a
+// two-chunk loop round gave wrong sums in some instantiations - accumulator copies on the exit edge, a few cycles behind the last MFMA.
+template <int A, int B, int C_>
+__device__ __forceinline__ void mfma_drain(i32x4 (&acc)[A][B][C_]) {
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+#pragma unroll
+  for (int a = 0; a < A; ++a)
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int c = 0; c < C_; ++c) asm volatile("" : "+a"(acc[a][b][c]));
+}
+
 // the three exact integer sums of an output -> one fp32 number (the two low digits meet as integers: < 2^27 at K = 3072)
 __device__ __forceinline__ float digits_f32(int a0, int a1, int a2) { return __builtin_fmaf((float)a2, 65536.f, (float)(a1 * 256 + a0)); }
 
