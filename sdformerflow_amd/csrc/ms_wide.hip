@@ -142,12 +142,10 @@ __device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __a
   // overlap them - measured in round 4: done before / after the MFMAs, commit + copies + requests cost as much as the MFMAs):
   //   units 0 .. WIT-1      : one piece of weight chunk c + 1 each goes registers -> the other ring buffer
   //   unit  WIT             : weight chunk c + 2 is requested
-  //   units UPS .. UPS+RB-1 : step 0's spike registers are dead: each takes over the next chunk's and is re-requested (chunk c + 2)
+  //   units UPS .. UPS+RB-1 : step 0's spike registers are dead: each is re-requested (chunk c + 2: the two register sets alternate)
   //   behind the last unit  : the same for step 1
   // The fences pin that order (the scheduler would pull every read in front of its use and push the rest behind the MFMAs).
-  // `rolled`: the single-chunk body of an odd chunk count - the current set is always aX, the next chunk's registers (aY) are copied
-  // into it as they die and aY is re-requested; else the two-chunk round below, where the sets alternate and nothing is copied
-  auto chunk = [&](int c, int cur, i32x4 (&aC)[2][RB], auto rolled) __attribute__((always_inline)) {
+  auto chunk = [&](int c, int cur, i32x4 (&aC)[2][RB]) __attribute__((always_inline)) {
     const uint8_t* wb = Wlds + cur * WBUF;
     uint8_t* wn = Wlds + (cur ^ 1) * WBUF;
     constexpr int UPS = CB * 3, NU = 2 * UPS;
@@ -175,25 +173,11 @@ __device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __a
       }
       if (g < WIT) *reinterpret_cast<u32x4*>(wn + w_lds[g]) = wreg[g];
       if (g == WIT) wreq(c + 2);
-      if (g >= UPS && g < UPS + RB) {                                  // (step 0's registers are dead: chunk c + 2 moves in)
-        if constexpr (decltype(rolled)::value) {
-          aX[0][g - UPS] = aY[0][g - UPS];
-          a_load1(aY[0][g - UPS], c + 2, 0, g - UPS);
-        } else {
-          a_load1(aC[0][g - UPS], c + 2, 0, g - UPS);
-        }
-      }
+      if (g >= UPS && g < UPS + RB) a_load1(aC[0][g - UPS], c + 2, 0, g - UPS);      // (step 0's registers are dead: chunk c + 2 moves in)
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-      if constexpr (decltype(rolled)::value) {
-        aX[1][rb] = aY[1][rb];
-        a_load1(aY[1][rb], c + 2, 1, rb);
-      } else {
-        a_load1(aC[1][rb], c + 2, 1, rb);
-      }
-    }
+    for (int rb = 0; rb < RB; ++rb) a_load1(aC[1][rb], c + 2, 1, rb);
   };
   // A launch starts with cold caches and address translations: the first TWO weight chunks and spike chunks are requested back
   // to back at the top (one cold latency instead of two), the caller's own loads behind them.
@@ -214,28 +198,18 @@ __device__ __forceinline__ void wide_mainloop(i32x4 (&acc)[3][RB][CB], const __a
   // two chunks per round - the register sets aX / aY alternate as "current" and each is refilled (chunk c + 2) as it dies: no copies
   // between the sets (the single-chunk body moves the next chunk's 40 registers into the current one's every chunk; measured at stage 2:
   // fc2 20.1 -> 17.0 us); an odd count ends with one lone chunk on aX
-  if constexpr (CB == 3) {
-    // three column blocks (180 accumulators): the single-chunk body (measured: the two-chunk round costs fc1 at K = 384 - three chunks
-    // padded to four - 20.8 -> 22.0 us)
+  int c = 0;
 #pragma unroll 1
-    for (int c = 0; c < nchunks; ++c) {
-      chunk(c, c & 1, aX, std::true_type{});                          // (a wave without rows multiplies zeros: no branch around the accumulators)
-      __syncthreads();
-    }
-  } else {
-    int c = 0;
-#pragma unroll 1
-    for (; c + 1 < nchunks; c += 2) {
-      chunk(c, 0, aX, std::false_type{});
-      __syncthreads();
-      chunk(c + 1, 1, aY, std::false_type{});
-      mfma_drain(acc);                                                // (the exit edge of the round may shuffle accumulators: wide_common.h)
-      __syncthreads();
-    }
-    if (c < nchunks) {                                                // odd count: the last chunk alone
-      chunk(c, 0, aX, std::false_type{});
-      __syncthreads();
-    }
+  for (; c + 1 < nchunks; c += 2) {
+    chunk(c, 0, aX);                                                  // (a wave without rows multiplies zeros: no branch around the accumulators)
+    __syncthreads();
+    chunk(c + 1, 1, aY);
+    mfma_drain(acc);                                                  // (the exit edge of the round may shuffle accumulators: wide_common.h)
+    __syncthreads();
+  }
+  if (c < nchunks) {                                                  // odd count: the last chunk alone
+    chunk(c, 0, aX);
+    __syncthreads();
   }
   mfma_drain(acc);                                                    // (the accumulators are read by vector instructions from here on)
 }
