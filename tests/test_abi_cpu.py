@@ -118,6 +118,24 @@ def test_argument_errors_are_reported_before_any_launch():
     assert lib.sdf_ms_mlp_is_wide(C.byref(m)) == 0              # the exact three-plane mode keeps the general kernels
     m.nsplit, m.C, m.Ch, m.s1_in = 2, 96, 384, 0x10000
     assert lib.sdf_ms_mlp_fwd(C.byref(m), None) == E_SHAPE      # s1_in is a wide-stage input
+    # round 4, late: the small-M kernel's weight format, patch merging on emitted spikes, several convolutions in one launch
+    q16 = C.c_void_p(0x10000)
+    assert lib.sdf_tile_weight_i8x3(None, q16, 64, 128, None) == E_NULL
+    assert lib.sdf_tile_weight_i8x3(q16, q16, 60, 128, None) == E_SHAPE       # N in blocks of 16
+    assert lib.sdf_tile_weight_i8x3(q16, q16, 64, 100, None) == E_SHAPE       # K in steps of 64
+    assert lib.sdf_ms_patch_merge_fwd(None, None) == E_NULL
+    mg = hip.MsMergeDesc()
+    mg.spikes = mg.digits = mg.cscale = mg.out = 0x10000
+    mg.B, mg.D, mg.H, mg.W, mg.C, mg.N = 1, 4, 8, 8, 128, 256
+    assert lib.sdf_ms_patch_merge_fwd(C.byref(mg), None) == E_SHAPE          # D in {10, 20}
+    mg.D, mg.C = 10, 96
+    assert lib.sdf_ms_patch_merge_fwd(C.byref(mg), None) == E_SHAPE          # C in steps of 64
+    assert lib.sdf_spike_conv2d_multi_fwd(None, 4, None) == E_NULL
+    assert lib.sdf_spike_conv2d_multi_fwd(q16, 0, None) == E_SHAPE
+    g5 = hip.SpikeGemmDesc()
+    g5.A, g5.Wp, g5.out, g5.col_scale = 0x10000, 0x10000, 0x10000, 0x10000
+    g5.M, g5.N, g5.K, g5.lda, g5.ldo, g5.nsplit = 12, 64, 128, 128, 64, hip.PLANES_I8X3_TILED
+    assert lib.sdf_spike_gemm_fwd(C.byref(g5), None) == E_SHAPE              # tiled digits: M in multiples of 10 (no other kernel reads them)
     assert lib.sdf_window_slice_map(None, 1, 2, 9, 9, 2, 9, 9, 0, 0, 0, None, None) == E_NULL
     assert lib.sdf_window_slice_map(p, 1, 2, 9, 9, 0, 9, 9, 0, 0, 0, None, None) == E_SHAPE
     # dense kernels of the ANN path (round 2)
