@@ -25,6 +25,10 @@ from . import hip
 from .STSwinNet_SNN.Spiking_swin_transformer3D import get_window_size, merge_row_map, window_slice_map
 
 BN_EPS = 1e-5
+# Narrowest stage the wide-stage kernels (csrc/ms_wide.hip) take: C = 192 = swin stage 1 of the shipped model.  Measured at the end of
+# round 4 (two alternating pairs of runs): 704.6 / 694.9 against 698.9 / 694.2 samples/s with 256, single-stream latency 2.14 - 2.16
+# against 2.18 - 2.20 ms, swin stages 1.035 against 1.052 ms - and two launches fewer per stage-1 block (its SN1 rides in the projection).
+_WIDE_MINC = 192
 
 
 def bn_affine(bn, device):
@@ -44,10 +48,8 @@ class _Lin:
         w = linear.weight.detach().float().to(device).contiguous()
         self.N, self.K = w.shape
         self.Wp = hip.split_weight(w, nsplit)
-        # wide layers (swin stages 2 - 3) also carry int8 digit planes: what csrc/ms_wide.hip multiplies by (default plane mode only).
-        # The kernels take K = 192 (stage 1) as well; measured there (round 4, 17 280 rows) a block costs 110.7 us on them against
-        # 112.7 us on the streaming kernels - two-chunk K is all prologue - so stage 1 keeps the path it has been tested on for 3 rounds
-        self.digits = hip.split_weight_i8x3(w) if nsplit == 2 and self.K >= 256 and self.K % 64 == 0 and self.N % 32 == 0 else None
+        # wide layers (swin stages 1 - 3) also carry int8 digit planes: what csrc/ms_wide.hip multiplies by (default plane mode only)
+        self.digits = hip.split_weight_i8x3(w) if nsplit == 2 and self.K >= _WIDE_MINC and self.K % 64 == 0 and self.N % 32 == 0 else None
         self.bias = None if linear.bias is None else linear.bias.detach().float().to(device).contiguous()
         self.alpha, self.beta = bn_affine(bn, device) if bn is not None else (None, None)
 
@@ -464,7 +466,7 @@ class MSFlowEngine:
             hip.neuron_fwd(x, xs, Tq, 1, rows * Cc, 0, 0, 0, rows * Cc, blk.sn_proj, rowmap=rowmap, rowlen=Cc)
             self._rec(blk.name + "attn.proj_sn.spiking_neuron.", xs, "flat")
         info = {}
-        zsrc = self._zsrc_map(rowmap, B_, Tq, N1, blk.nH, B * D * H * W, (B, D, H, W, tuple(ws), tuple(ss))) if Cc >= 256 and Tq == 2 else None
+        zsrc = self._zsrc_map(rowmap, B_, Tq, N1, blk.nH, B * D * H * W, (B, D, H, W, tuple(ws), tuple(ss))) if Cc >= _WIDE_MINC and Tq == 2 else None
         kw = dict(qk=blk.qk) if blk.qk is not None else dict(q_lin=blk.q, k_lin=blk.k, pe=blk.pe)
         hip.qk_attn(x, rowmap, B_, Tq, N1, blk.nH, blk.p, blk.sn_proj, blk.sn_q, blk.sn_k, blk.sn2_q, keep_ws=keep, x_src=zsrc, emit=emit,
                     info=info, **kw)
@@ -500,7 +502,7 @@ class MSFlowEngine:
         last = self.scores is not None and i == len(self.stages[s]) - 1          # log=True: the last block of every stage (:1090-1105)
         # wide stages: the projection emits the MLP's first spikes (tiled hand-over layout; the tape / score paths keep row-major spikes
         # and let the MLP run its own first neuron)
-        ws = hip.ms_mlp_workspace(x, blk.fc1.N) if x.shape[-1] >= 256 and self.tape is None and not last else None
+        ws = hip.ms_mlp_workspace(x, blk.fc1.N) if x.shape[-1] >= _WIDE_MINC and self.tape is None and not last else None
         self.attention(x, blk, self.scores if last else None, emit=(ws, blk.sn1) if ws is not None else None)
         return self.mlp(x, blk, ws=ws, s1_ready=self._emitted, emit_next=emit_next)
 
@@ -511,7 +513,7 @@ class MSFlowEngine:
     def _next_spikes(self, x, blk, sn):
         """(u8 buffer, neuron) for the MLP of `blk` to fill with SN(x after its update) - the first neuron of the layer behind the
         stage - or None where that MLP does not run on the wide-stage kernels (the layer then runs its own neuron)."""
-        if x.shape[-1] < 256 or not hip.ms_mlp_is_wide(x, blk.fc1, blk.fc2, blk.sn1, blk.sn2, emit_sn=sn):
+        if x.shape[-1] < _WIDE_MINC or not hip.ms_mlp_is_wide(x, blk.fc1, blk.fc2, blk.sn1, blk.sn2, emit_sn=sn):
             return None
         return torch.empty(x.shape, dtype=torch.uint8, device=x.device), sn
 
