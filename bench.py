@@ -144,14 +144,14 @@ def time_dominant_kernels(model, iters=40):
             "traffic": CONV_TRAFFIC_BYTES if digits else None, "traffic_unit": "bytes per launch (HBM read + write), mean of the two forms",
             "traffic_over_algorithmic": CONV_TRAFFIC_BYTES / (sum(CONV_ALGORITHMIC_BYTES.values()) / 2) if digits else None,
             "traffic_source": CONV_TRAFFIC_SOURCE,
-            "pmc": "profiles/r4d_pmc_forward.txt (the four launches inside one forward of the round-4 tree: 6.1 VALU per MFMA, pipe busy 39.5 %, LDS conflicts 5.9 %), r3s_pmc_forward.txt and r3i_pmc_kernels_after_operand_swap.txt: 683 MFMA "
+            "pmc": "profiles/r4e_pmc_forward.txt (the four launches inside one forward of the round-4 tree: 6.1 VALU per MFMA, pipe busy 39.5 %, LDS conflicts 5.9 %), r3s_pmc_forward.txt and r3i_pmc_kernels_after_operand_swap.txt: 683 MFMA "
                    "and ~4 000 VALU instructions per wave (6 VALU per MFMA; 8.2 before the weights became the MFMA's row operand, "
                    "r3g_pmc_kernels.txt), SQ_VALU_MFMA_BUSY_CYCLES = 39 % of the kernel's cycles per SIMD at an effective 2.2 GHz, LDS bank "
                    "conflicts 6 % of LDS cycles: the kernel is bound by its epilogue's vector instructions, not by the matrix pipe",
             "note": "algorithmic flops (2 per multiply-add of the convolution) against the dense bf16/f16 MFMA peak.  The kernel issues "
                     + ("3 int8 digit MFMAs (v_mfma_i32_32x32x32_i8, K = 32 in the cycles the 16-bit form needs for K = 16) per product: 1.5x "
                        "the algorithmic work on the 16-bit pipe's scale" if digits else f"{ns} 16-bit MFMAs per product") +
-                    "; the matrix pipe is busy 39 % of the kernel's cycles (PMC, profiles/r4d_pmc_forward.txt)"}
+                    "; the matrix pipe is busy 39 % of the kernel's cycles (PMC, profiles/r4e_pmc_forward.txt)"}
     gemm["frac"] = gemm["achieved"] / gemm["peak"]
     gemm["frac_of_issued_mfma"] = issued * gemm["frac"]
     # neuron: T=10 over the stage-0 MLP hidden tensor shape (10 x 72*96*384 fp32 in, u8 out)
@@ -221,7 +221,7 @@ def time_config3(iters=10):
                          "algorithmic_flop_per_launch": flop, "operand_sets_in_rotation": 2, "traffic": 1.714e9 + 0.680e9,
                          "traffic_over_algorithmic": (1.714e9 + 0.680e9) / 2.04e9,
                          "traffic_note": "HBM bytes per launch of the shipped dense_conv_wres_kernel<6, 2>, NOT measured in this run (rocprofv3 owns the "
-                                         "counters): profiles/r4d_pmc_dense_conv.txt (tools/pmc_dense_conv.sh, round 4: FETCH_SIZE 837 023 KiB x 2 on gfx950 "
+                                         "counters): profiles/r4e_pmc_dense_conv.txt (tools/pmc_dense_conv.sh, round 4: FETCH_SIZE 837 023 KiB x 2 on gfx950 "
                                          "+ WRITE_SIZE 663 560 KiB, separate --pmc passes, program directly behind `--`); algorithmic 2.04e9 (round 2's "
                                          "kernel: 2.61e9, profiles/r2p_pmc_dense.txt)"}}
 
