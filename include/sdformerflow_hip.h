@@ -311,7 +311,7 @@ typedef struct SdfQkAttnDesc {
   void* workspace;      int64_t workspace_bytes;
   void* gemm_workspace; int64_t gemm_workspace_bytes;
   int32_t flags;        /* SDF_QK_* bits */
-  /* Wide stages (C >= 256, T' = 2, LIF / IF neurons, digit planes given - see below; csrc/ms_wide.hip): with x_src set the call is THREE launches -
+  /* Wide stages (C >= 192 in steps of 64, T' = 2, LIF / IF neurons, digit planes given - see below; csrc/ms_wide.hip): with x_src set the call is THREE launches -
    * slice neuron, one kernel for q | k + BN + neurons + token gate, and the projection as a "position-major" product whose waves own
    * all xD time steps of a few positions of the (xB, xD, xHW, C) buffer x (xB * xD * xHW == x_rows):
    *   x_src   : int32 per row of x, made by sdf_window_zsrc_map from slice_map (where that row's gated spikes start in E); NULL = the
@@ -369,7 +369,7 @@ typedef struct SdfMsMlpDesc {
   void* workspace;      int64_t workspace_bytes;
   void* gemm_workspace; int64_t gemm_workspace_bytes;
   int32_t flags;        /* SDF_MLP_* bits */
-  /* Wide stages (C >= 256, LIF / IF, digit planes given - see below, D in {10, 20}; csrc/ms_wide.hip): fc1 + BN1 + SN2 and fc2 + BN2 + shortcut as two
+  /* Wide stages (C >= 192 in steps of 64, LIF / IF, digit planes given - see below, D in {10, 20}; csrc/ms_wide.hip): fc1 + BN1 + SN2 and fc2 + BN2 + shortcut as two
    * position-major launches.  s1_in != NULL: the SN1 spikes are already at the head of `workspace` (written there by
    * SdfQkAttnDesc.emit_s1 == workspace; tiled, or row-major when both calls carry their KEEP_SPIKES flag): no neuron launch, x is
    * only read by the last launch's shortcut.  Without SDF_MLP_KEEP_SPIKES the hidden spikes travel in the tiled form too. */

@@ -1,4 +1,4 @@
-// Wide stages (C >= 288: swin stages 2 and 3 of the shipped model) of the MS swin block for gfx950 - rows a5 / a6 / a7 of
+// Wide stages (C >= 192: swin stages 1 - 3 of the shipped model) of the MS swin block for gfx950 - rows a5 / a6 / a7 of
 // SURVEY.md section 8 at the shapes where the problem is SMALL IN ROWS (batch 1: 4 320 / 1 080 token rows against 0.6 - 9.4 MB of
 // weight planes per layer).  The general spike GEMM (spike_gemm.hip: 128 x 32 tiles, two barriers per 96-deep stage, 64-bit index
 // arithmetic per element) ran these layers at 4 - 7 % of the matrix peak with 24 - 31 vector instructions per MFMA
