@@ -840,7 +840,11 @@ int launch_pm(WidePmParams& P, int T, int epi, hipStream_t s) {
 // These kernels are built for problems that are small in rows (one workgroup per compute unit, a prologue per 320 rows): up to 256
 // 80-row units.  Larger problems (configs[4]: 96 000 rows at stage 2) keep the streaming kernels, which they fill; SDF_WIDE=2 lifts
 // the limit (tests, A/B).
-constexpr int64_t WIDE_MAX_ROWS = 256 * 80;
+static int64_t wide_max_rows() {                      // (SDF_WIDE_MAXROWS: tuning override)
+  if (const char* e = getenv("SDF_WIDE_MAXROWS")) { const long v = atol(e); if (v >= 80) return v; }
+  return 256 * 80;
+}
+#define WIDE_MAX_ROWS wide_max_rows()
 bool wide_env_any() {
   const char* e = getenv("SDF_WIDE");
   return e && e[0] == '2';
