@@ -112,6 +112,11 @@ class MS_ResBlock(nn.Module):
         self.sn1 = Spiking_neuron(**_neuron_kwargs(spiking_kwargs))
         self.sn2 = Spiking_neuron(**_neuron_kwargs(spiking_kwargs))
 
+    def forward(self, x):
+        """(T,B,C,H,W) membrane -> same shape, on the HIP engine (module_forward.ms_resblock_forward)."""
+        from ..module_forward import ms_resblock_forward
+        return ms_resblock_forward(self, x)
+
 
 class MS_spiking_residual_feature_generator(nn.Module):
     """reference :935-973."""
@@ -205,6 +210,9 @@ class MS_SpikingPredLayer(nn.Module):
 class SEWResBlock(MS_ResBlock):
     """conv-BN-SN-conv-BN-SN + identity (spike-element-wise ADD; reference :827-878).  Same parameters as `MS_ResBlock`; the
     order of neuron and convolution differs, which the SEW engine schedules."""
+
+    def forward(self, x):
+        raise NotImplementedError("SEWResBlock runs inside SEWFlowEngine (the whole-model forward); it has no module-level forward")
 
 
 class SpikingTransposeDecoderLayer(MS_SpikingTransposeDecoderLayer):

@@ -123,6 +123,19 @@ def ms_patch_merging_forward(mod, x):
 
 
 # ------------------------------------------------------------------------------------------------ SEW family
+def ms_resblock_forward(mod, x):
+    """`MS_ResBlock.forward` (reference Spiking_modules.py:906-933): x (T,B,C,H,W) membrane -> SN - conv - BN - SN - conv - BN + identity,
+    same shape.  The shipped form only: BatchNorm behind both convolutions, the ADD shortcut, stride 1."""
+    from .engine import MSFlowEngine, _ResBlock
+    _eval_only(mod)
+    if mod.norm is None or mod.connect_function != "ADD" or mod.conv1[0].stride != (1, 1):
+        raise NotImplementedError("MS_ResBlock.forward at module level: spike_norm='BN', connect_function='ADD', stride 1 (the shipped form)")
+    eng, rb = packed(mod, lambda dev: (MSFlowEngine.bare(dev), _ResBlock(mod, dev, 2)))
+    with torch.no_grad():
+        m = _cl(x).permute(1, 0, 3, 4, 2).contiguous()                 # (B, T, H, W, C): the engine's channel-last membrane
+        return eng._resblock(m, rb).permute(1, 0, 4, 2, 3).contiguous()
+
+
 def _sew(mod_block):
     from .engine_sew import SEWFlowEngine, _SewBlock
     return packed(mod_block, lambda dev: (SEWFlowEngine.bare(dev), _SewBlock(mod_block, dev, 2, "")))

@@ -110,6 +110,21 @@ def test_sew_block_mlp_and_merging_modules_against_the_oracle(kind):
     close(pm(xp.to(DEV)), ref, 5e-3)
 
 
+@pytest.mark.parametrize("kind,C,H,W", [("lif", 96, 18, 24), ("psn", 96, 9, 12), ("lif", 768, 9, 12)])
+def test_ms_resblock_module_against_the_oracle(kind, C, H, W):
+    """`MS_ResBlock.forward` (reference Spiking_modules.py:906-933) at module level; C = 768 at 9 x 12 is the U-Net bottleneck: the
+    small-M kernel with both fused epilogues."""
+    from sdformerflow_amd.STSwinNet_SNN import Spiking_modules as SM
+    rb, sd = load_synth(SM.MS_ResBlock(C, C, 1, "ADD", **kw(kind, 10)))
+    x = rnd((10, 1, C, H, W), 41, -0.5, 1.0)
+    with torch.no_grad():
+        ref = O.ms_resblock(x, sd, "", O.NeuronCfg(kind, 0.1, None, 2.0, 10))
+    xd = x.to(DEV)
+    y = rb(xd)
+    assert torch.equal(xd.cpu(), x) and tuple(y.shape) == tuple(x.shape)
+    close(y, ref, 5e-3)
+
+
 def test_module_forward_refuses_cpu_tensors():
     from sdformerflow_amd.hip import SdfError
     m = SW.MS_SpikingPatchMerging((9, 21), 96, norm_layer="BN", **kw("lif", 4)).eval()
