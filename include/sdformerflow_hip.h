@@ -408,7 +408,7 @@ int sdf_ms_mlp_is_wide(const SdfMsMlpDesc* d);
  * Spiking_swin_transformer3D.py:965-972: the four strided slices, the concatenation along channels in quadrant order
  * (dh, dw) = (q % 2, q / 2), sj_layer.Linear, the BatchNorm) - the concatenation is index arithmetic in the operand loads of the
  * wide-stage main loop (csrc/ms_wide.hip), nothing is materialised.  C % 64 == 0, N % 32 == 0, D in {10, 20}, at most
- * 20 480 output rows; SDF_E_SHAPE otherwise (the caller keeps its gather map + sdf_spike_gemm_fwd). */
+ * 32 000 output rows; SDF_E_SHAPE otherwise (the caller keeps its gather map + sdf_spike_gemm_fwd). */
 typedef struct SdfMsMergeDesc {
   const uint8_t* spikes;
   const int8_t* digits; const float* cscale;   /* sdf_split_weight_i8x3 of the (N, 4C) reduction weight */

@@ -837,12 +837,13 @@ int launch_pm(WidePmParams& P, int T, int epi, hipStream_t s) {
   return e != hipSuccess ? (int)e : 0;
 }
 
-// These kernels are built for problems that are small in rows (one workgroup per compute unit, a prologue per 320 rows): up to 256
-// 80-row units.  Larger problems (configs[4]: 96 000 rows at stage 2) keep the streaming kernels, which they fill; SDF_WIDE=2 lifts
-// the limit (tests, A/B).
+// These kernels are built for problems that are small in rows (one workgroup per compute unit, a prologue per 320 rows): up to 400
+// 80-row units (configs[4]'s stage 3 - 24 000 rows - measured +1 % on them: 119.5 against 118.1 samples/s).  Larger problems
+// (configs[4]: 96 000 rows at stage 2) keep the streaming kernels, which they fill: measured 119 -> 109 samples/s with the limit lifted
+// (SDF_WIDE=2: tests, A/B).
 static int64_t wide_max_rows() {                      // (SDF_WIDE_MAXROWS: tuning override)
   if (const char* e = getenv("SDF_WIDE_MAXROWS")) { const long v = atol(e); if (v >= 80) return v; }
-  return 256 * 80;
+  return 400 * 80;
 }
 #define WIDE_MAX_ROWS wide_max_rows()
 bool wide_env_any() {
