@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : 1) void smallm_kernel(SmallMPara
   __shared__ __attribute__((aligned(16))) uint8_t smem[REDB];              // main loop: the waves' strips; then the reduction buffer
   __shared__ int32_t rowtab[ROWS];
   __shared__ uint32_t masktab[AM == 1 ? ROWS : 1];
+  __shared__ __attribute__((aligned(16))) float psn_tbl[NK == 1 ? PSN_TABLE(T) : 4];   // PSN: W (T x T) and b (spike_mm.h: psn_T_lds)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, lq = lane >> 4;
   int item = blockIdx.x;
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : 1) void smallm_kernel(SmallMPara
       masktab[tid] = m;
     }
   }
+  if constexpr (NK == 1) psn_stage<T>(psn_tbl, P.sn, tid, 256);
   __syncthreads();
   // spike pieces: this lane loads piece (lane & 3) ^ swz of tile row 16 rb + lane / 4, swz = 2 (row / 8): LDS slot = lane
   uint32_t a_base[RB], a_mask[RB], b_off[CB];
@@ -329,15 +331,18 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : 1) void smallm_kernel(SmallMPara
     cs = P.cscale[nc];
   }
   i32x4* red = reinterpret_cast<i32x4*>(smem);             // [column block][contributor 0..2][lo | hi][row block][lane]
+  __builtin_amdgcn_sched_barrier(0);                       // (the folding of the low digits below must not be scheduled up here: 80 registers)
   __syncthreads();                                         // (every wave is out of its strip)
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb)
     if (wave != cb) {
       const int j = wave < cb ? wave : wave - 1;
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
-        red[(((cb * 3 + j) * 2 + 0) * RB + rb) * 64 + lane] = acc[1][rb][cb] * 256 + acc[0][rb][cb];
-        red[(((cb * 3 + j) * 2 + 1) * RB + rb) * 64 + lane] = acc[2][rb][cb];
+        red[(((cb * 3 + j) * 2 + 0) * RB + rb) * 64 + lane] = acc_read(acc[1][rb][cb]) * 256 + acc_read(acc[0][rb][cb]);
+        red[(((cb * 3 + j) * 2 + 1) * RB + rb) * 64 + lane] = acc_read(acc[2][rb][cb]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   __syncthreads();
@@ -347,32 +352,33 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : 1) void smallm_kernel(SmallMPara
 #else
   if (!owner) return;
 #endif
-  i32x4 lo[RB], hi[RB];
-#pragma unroll
-  for (int cb = 0; cb < CB; ++cb)                          // (this wave's own sums of its block: a compile-time index per branch)
-    if (wave == cb) {
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) { lo[rb] = acc[1][rb][cb] * 256 + acc[0][rb][cb]; hi[rb] = acc[2][rb][cb]; }
-    }
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-      lo[rb] += red[(((mycb * 3 + j) * 2 + 0) * RB + rb) * 64 + lane];
-      hi[rb] += red[(((mycb * 3 + j) * 2 + 1) * RB + rb) * 64 + lane];
-    }
-
-  // ---------------- epilogue (wave c on column block c): BN (+ bias), shortcut, [store], [neuron over T -> spike bytes] ----------------
+  // ---------------- the sums of this wave's column block, one row block at a time, straight into the epilogue: BN (+ bias), shortcut,
+  // [store], [neuron over T -> spike bytes].  (Formed for all five row blocks at once, the 40 sum registers + 120 of reads in flight
+  // + the shortcut values did not fit the two-workgroups-per-CU budget of 128 + 128 registers: 9 - 12 spilled)
   const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(P.out), o_rs = make_rsrc(P.out_spike);
   float val[SLOTS];
 #pragma unroll
-  for (int s = 0; s < SLOTS; ++s) {
-    float v = __builtin_fmaf((float)hi[s >> 2][s & 3], 65536.f, (float)lo[s >> 2][s & 3]) * cs;
-    v = v + bs;
-    v = __builtin_fmaf(v, al, be);
-    v = v + res[s];
-    val[s] = v;
-    if constexpr ((EPI & 2) != 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), x_rs, xo[s], 0, 0);
+  for (int rb = 0; rb < RB; ++rb) {
+    i32x4 lo = i32x4{0, 0, 0, 0}, hi = i32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)                        // (this wave's own sums of its block: a compile-time index per branch)
+      if (wave == cb) { lo = acc_read(acc[1][rb][cb]) * 256 + acc_read(acc[0][rb][cb]); hi = acc_read(acc[2][rb][cb]); }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      lo += red[(((mycb * 3 + j) * 2 + 0) * RB + rb) * 64 + lane];
+      hi += red[(((mycb * 3 + j) * 2 + 1) * RB + rb) * 64 + lane];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int s = 4 * rb + e;
+      float v = __builtin_fmaf((float)hi[e], 65536.f, (float)lo[e]) * cs;
+      v = v + bs;
+      v = __builtin_fmaf(v, al, be);
+      v = v + res[s];
+      val[s] = v;
+      if constexpr ((EPI & 2) != 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), x_rs, xo[s], 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
   if constexpr ((EPI & 1) != 0) {
     uint8_t* S = smem + mycb * REDC;                       // byte tile [80][16 + pad] over this wave's part of the buffer (its reads are done)
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : 1) void smallm_kernel(SmallMPara
       float xs[T], sp[T];
 #pragma unroll
       for (int t = 0; t < T; ++t) xs[t] = val[pp * T + t];
-      neuron_T<NK, T>(xs, sp, P.sn, P.inv_tau);
+      neuron_any<NK, T>(xs, sp, P.sn, P.inv_tau, psn_tbl);
 #pragma unroll
       for (int t = 0; t < T; ++t) bits |= ((__float_as_uint(sp[t]) >> 29) & 1u) << (pp * T + t);      // 1.0f has bit 29 set
     }
@@ -416,9 +422,11 @@ void launch_t(const SmallMParams& P, int epi, int nk, dim3 grid, hipStream_t s) 
   if (epi == 2) hipLaunchKernelGGL((smallm_kernel<T, 2, 0, AM, BT, CB>), grid, dim3(256), 0, s, P);
   else if (epi == 1) {
     if (nk == 0) hipLaunchKernelGGL((smallm_kernel<T, 1, 0, AM, BT, CB>), grid, dim3(256), 0, s, P);
+    else if (nk == 1) hipLaunchKernelGGL((smallm_kernel<T, 1, 1, AM, BT, CB>), grid, dim3(256), 0, s, P);
     else hipLaunchKernelGGL((smallm_kernel<T, 1, 2, AM, BT, CB>), grid, dim3(256), 0, s, P);
   } else {
     if (nk == 0) hipLaunchKernelGGL((smallm_kernel<T, 3, 0, AM, BT, CB>), grid, dim3(256), 0, s, P);
+    else if (nk == 1) hipLaunchKernelGGL((smallm_kernel<T, 3, 1, AM, BT, CB>), grid, dim3(256), 0, s, P);
     else hipLaunchKernelGGL((smallm_kernel<T, 3, 2, AM, BT, CB>), grid, dim3(256), 0, s, P);
   }
 }
@@ -446,6 +454,7 @@ __global__ __launch_bounds__(256) void tile_weight_i8x3_kernel(const int8_t* __r
 }  // namespace
 
 static bool smallm_neuron_ok(const SdfNeuronCfg& n) {
+  if (n.kind == SDF_PSN) return n.psn_w != nullptr && n.psn_b != nullptr;      // (T x T, T = the kernel's time axis: staged in LDS)
   if (n.kind != SDF_LIF && n.kind != SDF_IF) return false;
   return sdf_tau_ok(n.kind, n.tau);
 }
@@ -468,7 +477,7 @@ bool smallm_conv_supports(const GemmParams& P) {
   if (T != 10 && T != 20) return false;
   if (imgs % T || d.M > SMALLM_MAX_ROWS) return false;
   if (d.sn_T > 0) {
-    if (!smallm_neuron_ok({d.sn_kind, d.tau, d.v_th, d.v_reset, d.soft_reset, nullptr, nullptr})) return false;
+    if (!smallm_neuron_ok({d.sn_kind, d.tau, d.v_th, d.v_reset, d.soft_reset, d.psn_w, d.psn_b})) return false;
     if (d.pos_inner != hw || d.t_stride != hw || d.pos_ostride != (int64_t)T * hw || d.pos_count * T != d.M) return false;   // rows (b, t, pixel)
     if (!d.out_spike) return false;
   } else if (!d.out) {
@@ -489,7 +498,7 @@ int launch_smallm_conv(const GemmParams& G, hipStream_t s) {
   P.A = d.A; P.W = reinterpret_cast<const int8_t*>(d.Wp); P.cscale = d.col_scale; P.N = d.N; P.K = d.K; P.HW = (int)hw; P.P = (imgs / T) * hw;
   P.alpha = d.alpha; P.beta = d.beta; P.resid = d.resid; P.out = d.out; P.ldo = d.N;
   P.out_spike = d.sn_T > 0 ? d.out_spike : nullptr; P.ldsp = d.N;
-  P.sn = {d.sn_kind, d.tau, d.v_th, d.v_reset, d.soft_reset, nullptr, nullptr};
+  P.sn = {d.sn_kind, d.tau, d.v_th, d.v_reset, d.soft_reset, d.psn_w, d.psn_b};
   P.inv_tau = d.sn_T > 0 ? inv_tau_of(P.sn) : 0.f;
   P.cv_H = cv.H; P.cv_W = cv.W; P.cv_Cin = cv.Cin; P.cv_spt = cv.Cin / 64;
   P.cv_inv = (65536 + P.cv_spt - 1) / P.cv_spt;

@@ -283,10 +283,12 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
   static_assert(EPI >= 1 && EPI <= 4, "epilogue: 1 neuron, 2 fp32, 3 both, 4 split-K partial");
   __shared__ __attribute__((aligned(16))) uint8_t smem[LDSB];
   __shared__ int32_t rowtab[NW * ROWS];
+  __shared__ __attribute__((aligned(16))) float psn_tbl[NK == 1 ? PSN_TABLE(T) : 4];   // PSN: W (T x T) and b staged once (spike_mm.h: psn_T_lds)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, lq = lane >> 4;
   WSTAMP_DECL;
   WSTAMP(ws0);
+  if constexpr (NK == 1) psn_stage<T>(psn_tbl, P.sn, tid, 256);      // (visible behind the main loop's first barrier)
   // (row-group range, column group), column group fastest: the workgroups of an XCD (ids equal mod 8) cover a contiguous range of rows
   int item = blockIdx.x;
   const int G = gridDim.x;
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
             else
               xs[t] = val[cb][s];
           }
-          neuron_T<NK, T>(xs, sp, P.sn, P.inv_tau);
+          neuron_any<NK, T>(xs, sp, P.sn, P.inv_tau, psn_tbl);
 #pragma unroll
           for (int t = 0; t < T; ++t) bits |= ((__float_as_uint(sp[t]) >> 29) & 1u) << (pp * T + t);      // 1.0f has bit 29 set
         }
@@ -770,7 +772,10 @@ __global__ __launch_bounds__(256) void zsrc_kernel(const int32_t* __restrict__ m
   zsrc[r] = (int32_t)((((b * nH) * Tq + t) * N1 + n) * 32);
 }
 
+// neurons the epilogues run: LIF / IF (classes 0 and 2 of spike_mm.h) and the PSN (class 1: its T x T matrix and bias, T = the
+// kernel's time axis, staged in LDS or - T' = 2 - read as scalars)
 bool neuron_ok(const SdfNeuronCfg& n) {
+  if (n.kind == SDF_PSN) return n.psn_w != nullptr && n.psn_b != nullptr;
   if (n.kind != SDF_LIF && n.kind != SDF_IF) return false;
   return sdf_tau_ok(n.kind, n.tau);
 }
@@ -790,6 +795,7 @@ int launch_pm_nk(const WidePmParams& P, int nk, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL((wide_pm_kernel<T, CB, EPI, 0>), grid, dim3(256), 0, s, P);
   } else {
     if (nk == 0) hipLaunchKernelGGL((wide_pm_kernel<T, CB, EPI, 0>), grid, dim3(256), 0, s, P);
+    else if (nk == 1) hipLaunchKernelGGL((wide_pm_kernel<T, CB, EPI, 1>), grid, dim3(256), 0, s, P);
     else hipLaunchKernelGGL((wide_pm_kernel<T, CB, EPI, 2>), grid, dim3(256), 0, s, P);
   }
   return 0;
@@ -859,8 +865,9 @@ bool wide_env_off() {
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
 // Shapes the wide forms are built for: int8 digit planes beside the 16-bit ones (the caller packs both; the default two-plane
-// mode only - the exact three-plane and the one-plane bf16 modes keep the general kernels), LIF / IF neurons (the PSN keeps the
-// general kernels), C a multiple of 128 from 256 on, T in {10, 20}, operands within the kernels' 31-bit buffer offsets.
+// mode only - the exact three-plane and the one-plane bf16 modes keep the general kernels), LIF / IF / PSN neurons (round 5: the PSN's
+// T x T matrix is staged in LDS, its rows read as broadcasts), C >= 192 in steps of 64 with Ch % 96 == 0, T in {10, 20}, at most
+// WIDE_MAX_ROWS (32 000, SDF_WIDE_MAXROWS) rows, operands within the kernels' 31-bit buffer offsets.
 bool ms_wide_mlp_supports(const SdfMsMlpDesc* d) {
   if (wide_env_off() || (d->flags & SDF_MLP_NARROW)) return false;
   if (!d->fc1_digits || !d->fc1_cscale || !d->fc2_digits || !d->fc2_cscale) return false;
@@ -989,8 +996,8 @@ int launch_ms_wide_front(const SdfQkAttnDesc* d, const uint8_t* xs, uint8_t* e, 
     if (keep) hipLaunchKernelGGL((wide_front_kernel<RB_, NK_, true>), grid, dim3(256), 0, s, P);          \
     else hipLaunchKernelGGL((wide_front_kernel<RB_, NK_, false>), grid, dim3(256), 0, s, P);              \
   } while (0)
-  if (big) { if (nk == 0) SDF_WF(4, 0); else SDF_WF(4, 2); }
-  else { if (nk == 0) SDF_WF(2, 0); else SDF_WF(2, 2); }
+  if (big) { if (nk == 0) SDF_WF(4, 0); else if (nk == 1) SDF_WF(4, 1); else SDF_WF(4, 2); }
+  else { if (nk == 0) SDF_WF(2, 0); else if (nk == 1) SDF_WF(2, 1); else SDF_WF(2, 2); }
 #undef SDF_WF
   hipError_t err = hipGetLastError();
   return err != hipSuccess ? (int)err : 0;

@@ -177,6 +177,13 @@ __device__ __forceinline__ void psn_T_lds(const float (&xs)[T], float (&sp)[T], 
   for (int t = 0; t < T; ++t) sp[t] = ((m >> t) & 1u) ? 1.f : 0.f;
 }
 
+// neuron of class NK over the T values a lane holds, PSN coefficients from the LDS table `tbl` (psn_stage) where T > 4
+template <int NK, int T>
+__device__ __forceinline__ void neuron_any(const float (&xs)[T], float (&sp)[T], const SdfNeuronCfg& n, float inv_tau, const float* tbl) {
+  if constexpr (NK == 1 && (T > 4)) psn_T_lds<T>(xs, sp, tbl);
+  else neuron_T<NK, T>(xs, sp, n, inv_tau);
+}
+
 bool qk_front_supports(const SdfQkAttnDesc* d);
 int launch_qk_front(const SdfQkAttnDesc* d, uint8_t* e, uint8_t* qk, bool keep, hipStream_t s);
 

@@ -74,6 +74,17 @@ __device__ __forceinline__ void mfma_drain(i32x4 (&acc)[A][B][C_]) {
       for (int c = 0; c < C_; ++c) asm volatile("" : "+a"(acc[a][b][c]));
 }
 
+// One accumulator quad AGPR -> VGPR, HERE (volatile, ordered against memory operations): left to the register allocator, the copies of
+// ALL of a wave's accumulators were placed right behind the main loop - 120 registers live across the reduction's barriers, which
+// pushed the small-M kernel's two-workgroups-per-CU builds (128 + 128 registers) into scratch.
+__device__ __forceinline__ i32x4 acc_read(const i32x4& a) {
+  const int x0 = a[0], x1 = a[1], x2 = a[2], x3 = a[3];
+  int r0, r1, r2, r3;
+  asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7"
+               : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "a"(x0), "a"(x1), "a"(x2), "a"(x3) : "memory");
+  return i32x4{r0, r1, r2, r3};
+}
+
 // the three exact integer sums of an output -> one fp32 number (the two low digits meet as integers: < 2^27 at K = 3072)
 __device__ __forceinline__ float digits_f32(int a0, int a1, int a2) { return __builtin_fmaf((float)a2, 65536.f, (float)(a1 * 256 + a0)); }
 

@@ -302,7 +302,7 @@ class MSFlowEngine:
         a, b = bn if bn is not None else (None, None)
         # large 3x3 / stride-1 launches on 96 channels: int8 digit planes, weights resident in LDS (csrc/spike_conv_wres.hip)
         digits = getattr(Wp, "digits", None)
-        if digits is not None and (sn is None or sn.kind in ("lif", "if")) and hip.smallm_conv_applicable(B * D, h, w, Cin, Cout, stride, D):
+        if digits is not None and (sn is None or sn.kind in ("lif", "if", "psn")) and hip.smallm_conv_applicable(B * D, h, w, Cin, Cout, stride, D):
             # few rows against many weights (the U-Net bottleneck: 1 080 rows x 768 x 6 912): one launch, K split over the waves of a
             # workgroup, sum + BN + shortcut + neuron in its epilogue (csrc/ms_smallm.hip)
             out = None if sn is not None and not membrane else torch.empty((B, D, oh, ow, Cout), dtype=torch.float32, device=s.device)
@@ -381,7 +381,7 @@ class MSFlowEngine:
             s1 = self._neuron_bd(m, rb.sn1)
         self._rec(rb.name + "sn1.spiking_neuron.", s1, "BDHWC->TBCHW")
         fus = self._fusable(B, D, h, w, rb.C, rb.w1) or \
-            (getattr(rb.w1, "digits", None) is not None and rb.sn2.kind in ("lif", "if") and hip.smallm_conv_applicable(B * D, h, w, rb.C, rb.C, 1, D))
+            (getattr(rb.w1, "digits", None) is not None and rb.sn2.kind in ("lif", "if", "psn") and hip.smallm_conv_applicable(B * D, h, w, rb.C, rb.C, 1, D))
         if fus:
             s2 = self._conv3x3(s1, rb.w1, rb.C, bn=rb.bn1, sn=rb.sn2)
         else:       # few rows (U-Net bottleneck): the fp32 epilogue can split K over the chip; neuron as its own launch

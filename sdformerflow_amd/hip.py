@@ -608,11 +608,17 @@ def qk_attn(x, slice_map, B_, Tq, N1, nH, p_lin, sn_proj, sn_q, sn_k, sn2_q, qk=
         else:
             d.q_digits, d.q_cscale = _digits(getattr(q_lin, "digits", None))
             d.k_digits, d.k_cscale = _digits(getattr(k_lin, "digits", None))
-    if emit is not None and lib().sdf_qk_attn_is_wide(C.byref(d)) == 1 and emit[1].kind in ("lif", "if"):
+    if emit is not None:
+        # the query sees the descriptor as the call will (emit neuron included: the library refuses neurons it has no epilogue for);
+        # refused -> the call runs without the emission and the caller's MLP runs its own first neuron
         d.emit_s1 = _ptr(emit[0], torch.uint8)                # (only the wide-stage projection emits the next neuron's spikes)
         _ncfg(d.emit_sn, emit[1])
-        if info is not None:
-            info["emitted"] = True
+        if lib().sdf_qk_attn_is_wide(C.byref(d)) == 1:
+            if info is not None:
+                info["emitted"] = True
+        else:
+            d.emit_s1 = None
+            _ncfg(d.emit_sn, NeuronParams())
     _note(flop=2 * Tq * B_ * N1 * Cc * 3 * Cc, shape=(Tq * B_ * N1, Cc))
     _check(lib().sdf_qk_attn_fwd(C.byref(d), _stream()), "sdf_qk_attn_fwd")
     if keep_ws is not None:

@@ -42,27 +42,43 @@ def _weff(dg):
     return (d[2] * 65536 + d[1] * 256 + d[0]) * dg.sdf_col_scale.cpu().double().view(-1, 1)
 
 
-NEURONS = {                        # name -> (kind, tau, v_reset): class 0 (soft reset, power-of-two tau / plif) and the general class 2
-    "lif": ("lif", 2.0, None),
+NEURONS = {                        # name -> (kind, tau, v_reset): class 0 (soft reset, power-of-two tau / plif), the general class 2,
+    "lif": ("lif", 2.0, None),     # and class 1 = the PSN the reference ships (configs/train_DSEC_supervised_SDformerFlow_en4.yml:49)
     "plif": ("lif", 0.3775406777858734, None),
     "lif_hard": ("lif", 2.0, 0.0),
     "if": ("if", 2.0, None),
+    "psn": ("psn", 2.0, None),
 }
+ALL = ["lif", "plif", "lif_hard", "if", "psn"]
 
 
-def _np(name, v_th=0.1):
-    kind, tau, vr = NEURONS[name]
-    return hip.NeuronParams(kind, tau, v_th, vr)
+class _N:
+    """One neuron instance for both sides: NeuronParams for the kernels, the C oracle neuron, the NeuronCfg / state dict of
+    O.delta_consistent.  PSN (reference Spiking_submodules.py:183-211): its own T x T matrix and bias per instance - `gain` scales
+    the matrix to the size of the pre-activation (the token gate sees head sums 0..32), `bias` sets the firing rate."""
 
+    def __init__(self, name, T, v_th=0.1, seed=0, gain=1.0, bias=-0.1):
+        self.name, self.T, self.v_th = name, T, v_th
+        self.kind, self.tau, self.vr = NEURONS[name]
+        self.w = self.b = None
+        if self.kind == "psn":
+            self.w = ((torch.eye(T) * 0.8 + rnd((T, T), 7700 + seed, -0.15, 0.15)) * gain).contiguous()
+            self.b = (torch.full((T,), float(bias)) + rnd((T,), 7800 + seed, -0.03, 0.03)).contiguous()
+            self.p = hip.NeuronParams("psn", psn_w=self.w.to(DEV), psn_b=self.b.to(DEV))
+        else:
+            self.p = hip.NeuronParams(self.kind, self.tau, v_th, self.vr)
 
-def _ref_neuron(xt, name, v_th=0.1):
-    kind, tau, vr = NEURONS[name]
-    return R.neuron_ref(xt, kind, tau, v_th, vr)
+    def ref(self, xt):
+        """spikes of the oracle neuron on xt (T, ...) fp32 (C restatement: true fmaf chain / separately rounded LIF ops)"""
+        if self.kind == "psn":
+            return R.neuron_ref(xt, "psn", psn_w=self.w, psn_b=self.b)
+        return R.neuron_ref(xt, self.kind, self.tau, self.v_th, self.vr)
 
-
-def _ncfg(name, T, v_th=0.1):
-    kind, tau, vr = NEURONS[name]
-    return O.NeuronCfg(kind, v_th, vr, tau, T)
+    def check(self, h, got):
+        """O.delta_consistent of `got` against the pre-activation h (T, ...)"""
+        sd = {"w.weight": self.w, "w.bias": self.b.view(-1, 1)} if self.kind == "psn" else {}
+        cfg = O.NeuronCfg(self.kind, self.v_th, self.vr, self.tau, self.T)
+        return O.delta_consistent(h, got, cfg, sd, "w.", _delta(h, self.v_th))
 
 
 def _delta(h, v_th=0.1):
@@ -70,27 +86,27 @@ def _delta(h, v_th=0.1):
 
 
 # ------------------------------------------------------------------------------------------------------------------ MLP
-@pytest.mark.parametrize("name", ["lif", "plif", "lif_hard", "if"])
+@pytest.mark.parametrize("name", ALL)
 @pytest.mark.parametrize("B,D,H,W,Cc", [(1, 10, 18, 24, 384), (1, 10, 9, 12, 768), (2, 10, 5, 7, 384), (1, 20, 6, 5, 384),
                                         (1, 20, 3, 3, 768), (3, 10, 1, 3, 256), (1, 10, 36, 48, 192), (2, 20, 5, 3, 192), (1, 10, 4, 6, 320)])
 def test_wide_mlp_steps_against_the_oracle(B, D, H, W, Cc, name):
-    if name != "lif" and (D != 10 or B != 1):
+    if name not in ("lif", "psn") and (D != 10 or B != 1):
         pytest.skip("the other neuron classes are covered on the shipped T = 10 shapes")
     Ch, ntok = 4 * Cc, B * D * H * W
     x0 = rnd((B, D, H, W, Cc), 700, -0.5, 1.0)
     W1, W2 = rnd((Ch, Cc), 701, -0.15, 0.15), rnd((Cc, Ch), 702, -0.05, 0.05)
     a1, b1 = rnd((Ch,), 703, 0.5, 1.5), rnd((Ch,), 704, -0.2, 0.2)
     a2, b2 = rnd((Cc,), 705, 0.5, 1.5), rnd((Cc,), 706, -0.2, 0.2)
-    fc1, fc2, p = _L(W1, a1, b1), _L(W2, a2, b2), _np(name)
+    fc1, fc2, n1, n2 = _L(W1, a1, b1), _L(W2, a2, b2), _N(name, D, seed=1), _N(name, D, seed=2)
     keep = []
-    xg = hip.ms_mlp(x0.to(DEV).clone(), fc1, fc2, p, p, keep_ws=keep)
+    xg = hip.ms_mlp(x0.to(DEV).clone(), fc1, fc2, n1.p, n2.p, keep_ws=keep)
     torch.cuda.synchronize()
     ws = keep[0].cpu()
     s1g = ws[:ntok * Cc].view(ntok, Cc)
     s2g = ws[(ntok * Cc + 255) // 256 * 256:][:ntok * Ch].view(ntok, Ch)
     # (a) SN1 over D: bit-exact
     xt = x0.permute(1, 0, 2, 3, 4).contiguous()
-    s1r = _ref_neuron(xt, name).permute(1, 0, 2, 3, 4).reshape(ntok, Cc)
+    s1r = n1.ref(xt).permute(1, 0, 2, 3, 4).reshape(ntok, Cc)
     assert torch.equal(s1g.float(), s1r), "SN1 spikes differ from the oracle"
     assert 0.03 < s1r.mean() < 0.97
     # (b) SN2 on the kernel's own s1
@@ -99,7 +115,7 @@ def test_wide_mlp_steps_against_the_oracle(B, D, H, W, Cc, name):
     h = (s1g.double() @ W1e.t()) * a1.double() + b1.double()
     ht = h.view(B, D, H * W, Ch).permute(1, 0, 2, 3).float().contiguous()
     got = s2g.view(B, D, H * W, Ch).permute(1, 0, 2, 3).float().contiguous()
-    rep = O.delta_consistent(ht, got, _ncfg(name, D), {}, "w.", _delta(ht))
+    rep = n2.check(ht, got)
     assert rep["unexplained"] == 0, rep
     assert rep["flips"] <= 2e-4 * got.numel(), rep
     assert 0.03 < got.mean() < 0.97
@@ -109,7 +125,7 @@ def test_wide_mlp_steps_against_the_oracle(B, D, H, W, Cc, name):
     assert err <= 1e-5 * ref.abs().max().item(), err
     # (d) the general kernels of the same entry point: SN1 bit-equal, SN2 equal up to near-threshold decisions
     kb = []
-    xb = hip.ms_mlp(x0.to(DEV).clone(), fc1, fc2, p, p, keep_ws=kb, narrow=True)
+    xb = hip.ms_mlp(x0.to(DEV).clone(), fc1, fc2, n1.p, n2.p, keep_ws=kb, narrow=True)
     torch.cuda.synchronize()
     wb = kb[0].cpu()
     assert torch.equal(wb[:ntok * Cc], ws[:ntok * Cc])
@@ -132,7 +148,7 @@ def _attn_case(B, D, H, W, Cc, window, shift, seed=0):
     return nH, Tq, N1, x0, Wq, Wk, Wp, aq, bq, ak, bk, ap, bp, biasp, pe
 
 
-@pytest.mark.parametrize("name", ["lif", "plif", "lif_hard", "if"])
+@pytest.mark.parametrize("name", ALL)
 @pytest.mark.parametrize("stacked", [True, False])
 @pytest.mark.parametrize("B,D,H,W,Cc,window,shift", [
     (1, 10, 36, 48, 192, (2, 9, 9), (1, 4, 4)),          # stage 1: K = 192 = one and a half 128-deep chunks
@@ -145,10 +161,16 @@ def _attn_case(B, D, H, W, Cc, window, shift, seed=0):
     (1, 20, 7, 9, 256, (2, 5, 5), (1, 2, 2)),            # T = 20, 25-token windows
 ])
 def test_wide_attention_steps_against_the_oracle(B, D, H, W, Cc, window, shift, stacked, name):
-    if (name != "lif" or not stacked) and (Cc != 384 or D != 10 or B != 1 or shift[0] != 1):
+    if name == "psn" and stacked:
+        pytest.skip("every PSN has its own matrix: q and k are separate projections (engine.py:_Block)")
+    if name == "psn":
+        if B != 1 and D != 20:
+            pytest.skip("PSN: the shipped shapes, every K chunk count and T = 20")
+    elif (name != "lif" or not stacked) and (Cc != 384 or D != 10 or B != 1 or shift[0] != 1):
         pytest.skip("neuron classes / separate projections are covered on the shipped stage-2 shape")
     nH, Tq, N1, x0, Wq, Wk, Wp, aq, bq, ak, bk, ap, bp, biasp, pe = _attn_case(B, D, H, W, Cc, window, shift)
-    p = _np(name)
+    npj, nq, nk_, ng, ne = _N(name, Tq, seed=11), _N(name, Tq, seed=12), _N(name, Tq, seed=13), \
+        _N(name, Tq, seed=14, gain=0.12, bias=-1.2), _N(name, D, seed=15)
     plin = _L(Wp, ap, bp, biasp)
     qlin, klin = _L(Wq, aq, bq), _L(Wk, ak, bk)
     if stacked:
@@ -166,7 +188,7 @@ def test_wide_attention_steps_against_the_oracle(B, D, H, W, Cc, window, shift, 
     zsrc = hip.window_zsrc_map(rowmap, B_, Tq, N1, nH, x_rows)
     ws_mlp = torch.zeros((x_rows * Cc,), dtype=torch.uint8, device=DEV)
     xg, keep, info = x0.to(DEV).clone(), [], {}
-    hip.qk_attn(xg, rowmap, B_, Tq, N1, nH, plin, p, p, p, p, keep_ws=keep, x_src=zsrc, emit=(ws_mlp, p), info=info, **kw)
+    hip.qk_attn(xg, rowmap, B_, Tq, N1, nH, plin, npj.p, nq.p, nk_.p, ng.p, keep_ws=keep, x_src=zsrc, emit=(ws_mlp, ne.p), info=info, **kw)
     torch.cuda.synchronize()
     assert info.get("emitted") is True, "the wide-stage kernels were not taken"
     ws = keep[0].cpu()
@@ -183,7 +205,7 @@ def test_wide_attention_steps_against_the_oracle(B, D, H, W, Cc, window, shift, 
     xg0 = torch.zeros((M, Cc))
     ok = rm >= 0
     xg0[ok] = x0.reshape(x_rows, Cc)[rm[ok]]
-    xs_ref = _ref_neuron(xg0.view(Tq, rows, Cc), name)
+    xs_ref = npj.ref(xg0.view(Tq, rows, Cc))
     assert torch.equal(xs.float(), xs_ref), "slice spikes differ from the oracle"
     assert 0.03 < xs_ref.mean() < 0.97
     # (b) q | k on the kernel's own slice spikes
@@ -191,14 +213,15 @@ def test_wide_attention_steps_against_the_oracle(B, D, H, W, Cc, window, shift, 
     hq = ((xsd @ Wqe.t()) * aq.double() + bq.double()).view(Tq, rows, Cc)
     hk = ((xsd @ Wke.t()) * ak.double() + bk.double()).view(Tq, rows, Cc)
     hk = (hk.view(Tq, B_, N1, Cc) + pe.double().view(Tq, 1, N1, Cc)).view(Tq, rows, Cc)
-    for h, got, what in ((hq, qs, "q"), (hk, ks, "k")):
-        rep = O.delta_consistent(h.float().contiguous(), got.float().contiguous(), _ncfg(name, Tq), {}, "w.", _delta(h.float()))
+    for h, got, what, nn in ((hq, qs, "q", nq), (hk, ks, "k", nk_)):
+        rep = nn.check(h.float().contiguous(), got.float().contiguous())
         assert rep["unexplained"] == 0, (what, rep)
         assert rep["flips"] <= 2e-4 * got.numel(), (what, rep)
         assert 0.03 < got.float().mean() < 0.97, what
     # (c) token gate: exact on the kernel's own q and k
     a = qs.float().view(Tq, rows, nH, 32).sum(-1)
-    gate = _ref_neuron(a, name)
+    gate = ng.ref(a.contiguous())
+    assert 0.03 < gate.mean() < 0.97
     e_ref = ks.float().view(Tq, rows, nH, 32) * gate.unsqueeze(-1)
     assert torch.equal(e.float().view(Tq, rows, nH, 32), e_ref), "gated spikes differ"
     assert 0.01 < e_ref.mean() < 0.9
@@ -211,11 +234,11 @@ def test_wide_attention_steps_against_the_oracle(B, D, H, W, Cc, window, shift, 
     assert err <= 1e-5 * ref.abs().max().item(), err
     # (e) the emitted first neuron of the MLP: SN over D of the kernel's own updated x, bit-exact
     s1 = ws_mlp.cpu().view(B, D, H * W, Cc)
-    s1_ref = _ref_neuron(xg.cpu().view(B, D, H * W, Cc).permute(1, 0, 2, 3).contiguous(), name).permute(1, 0, 2, 3)
+    s1_ref = ne.ref(xg.cpu().view(B, D, H * W, Cc).permute(1, 0, 2, 3).contiguous()).permute(1, 0, 2, 3)
     assert torch.equal(s1.float(), s1_ref), "emitted SN1 spikes differ from the oracle"
     # (f) the general kernels of the same entry point
     xb, kb = x0.to(DEV).clone(), []
-    hip.qk_attn(xb, rowmap, B_, Tq, N1, nH, plin, p, p, p, p, keep_ws=kb, narrow=True, **kw)
+    hip.qk_attn(xb, rowmap, B_, Tq, N1, nH, plin, npj.p, nq.p, nk_.p, ng.p, keep_ws=kb, narrow=True, **kw)
     torch.cuda.synchronize()
     eb = kb[0].cpu()[:M * Cc].view(Tq, rows, Cc)
     assert (eb != e).float().mean().item() <= 2e-4
@@ -223,7 +246,7 @@ def test_wide_attention_steps_against_the_oracle(B, D, H, W, Cc, window, shift, 
     assert rows_same.float().mean().item() > 0.9
     # the production form (no tape, nothing emitted) must give the same x bit for bit
     xh = x0.to(DEV).clone()
-    hip.qk_attn(xh, rowmap, B_, Tq, N1, nH, plin, p, p, p, p, x_src=zsrc, **kw)
+    hip.qk_attn(xh, rowmap, B_, Tq, N1, nH, plin, npj.p, nq.p, nk_.p, ng.p, x_src=zsrc, **kw)
     torch.cuda.synchronize()
     assert torch.equal(xh, xg), "the tape changes the result"
 
@@ -236,7 +259,7 @@ def test_wide_block_through_the_engine_matches_the_general_kernels():
     B, D, H, W, Cc, window, shift = 1, 10, 18, 24, 384, (2, 9, 9), (1, 4, 4)
     nH, Tq, N1, x0, Wq, Wk, Wp, aq, bq, ak, bk, ap, bp, biasp, pe = _attn_case(B, D, H, W, Cc, window, shift, seed=40)
     Ch = 4 * Cc
-    p = _np("lif")
+    p = _N("lif", D).p
     plin = _L(Wp, ap, bp, biasp)
     wcat = torch.cat([Wq, Wk], 0).to(DEV).contiguous()
     qk = {"Wp": hip.split_weight(wcat, 2), "digits": hip.split_weight_i8x3(wcat), "alpha": torch.cat([aq, ak]).to(DEV),
@@ -266,25 +289,26 @@ def test_wide_block_through_the_engine_matches_the_general_kernels():
 
 
 # ------------------------------------------------------------------------- fc2's emission of the next neuron + patch merging
-@pytest.mark.parametrize("name", ["lif", "plif", "lif_hard", "if"])
+@pytest.mark.parametrize("name", ALL)
 @pytest.mark.parametrize("B,D,H,W,Cc", [(1, 10, 15, 20, 384), (1, 10, 8, 10, 768), (2, 10, 5, 7, 384), (1, 20, 6, 5, 384)])
 def test_wide_mlp_emits_the_next_layers_first_spikes(B, D, H, W, Cc, name):
     """SdfMsMlpDesc.emit_next: SN_next(x after the update), bit-equal to the oracle neuron on the kernel's OWN updated x (what the patch
     merging - reference Spiking_swin_transformer3D.py:970 - or the bottleneck's MS_ResBlock.sn1 - Spiking_modules.py:922 - computes
     first), and x itself unchanged by asking for it."""
-    if name != "lif" and (D != 10 or B != 1):
+    if name not in ("lif", "psn") and (D != 10 or B != 1):
         pytest.skip("the other neuron classes are covered on the shipped T = 10 shapes")
     Ch = 4 * Cc
     x0 = rnd((B, D, H, W, Cc), 900, -0.5, 1.0)
     fc1 = _L(rnd((Ch, Cc), 901, -0.15, 0.15), rnd((Ch,), 903, 0.5, 1.5), rnd((Ch,), 904, -0.2, 0.2))
     fc2 = _L(rnd((Cc, Ch), 902, -0.05, 0.05), rnd((Cc,), 905, 0.5, 1.5), rnd((Cc,), 906, -0.2, 0.2))
-    p, pn = _np("lif"), _np(name, v_th=0.25)
+    p, nn = _N("lif", D).p, _N(name, D, v_th=0.25, seed=21, bias=-0.2)
+    pn = nn.p
     buf = torch.full((B, D, H, W, Cc), 7, dtype=torch.uint8, device=DEV)
     xg = hip.ms_mlp(x0.to(DEV).clone(), fc1, fc2, p, p, emit_next=(buf, pn))
     xb = hip.ms_mlp(x0.to(DEV).clone(), fc1, fc2, p, p)
     torch.cuda.synchronize()
     assert torch.equal(xg, xb)
-    ref = _ref_neuron(xg.cpu().permute(1, 0, 2, 3, 4).contiguous(), name, v_th=0.25).permute(1, 0, 2, 3, 4)
+    ref = nn.ref(xg.cpu().permute(1, 0, 2, 3, 4).contiguous()).permute(1, 0, 2, 3, 4)
     assert torch.equal(buf.cpu().float(), ref), "emitted spikes differ from the oracle neuron on the updated x"
     assert 0.02 < ref.mean() < 0.98
 
@@ -341,7 +365,7 @@ def test_fc2_on_the_small_m_kernel_equals_the_wide_main_loop(B, D, H, W, Cc, mon
     x0 = rnd((B, D, H, W, Cc), 930, -0.5, 1.0)
     fc1 = _L(rnd((Ch, Cc), 931, -0.15, 0.15), rnd((Ch,), 933, 0.5, 1.5), rnd((Ch,), 934, -0.2, 0.2))
     fc2 = _L(rnd((Cc, Ch), 932, -0.05, 0.05), rnd((Cc,), 935, 0.5, 1.5), rnd((Cc,), 936, -0.2, 0.2))
-    p, pn = _np("lif"), _np("lif", v_th=0.25)
+    p, pn = _N("lif", D).p, _N("lif", D, v_th=0.25).p
 
     def run():
         buf = torch.full((B, D, H, W, Cc), 7, dtype=torch.uint8, device=DEV)

@@ -46,7 +46,10 @@ def test_fp32_epilogue_against_fp64(B, T, H, W, Cin, Cout, with_res, monkeypatch
     out = torch.full((imgs * H * W, Cout), float("nan"), device=DEV)
     hip.spike_conv2d(x.to(DEV), dg, imgs, H, W, Cin, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=out, alpha=alpha.to(DEV), beta=beta.to(DEV),
                      resid=None if resid is None else resid.to(DEV))
-    ref = _ref(x, _weff(dg), Cin, Cout, alpha, beta, resid)
+    we = _weff(dg)                                                         # what the digits carry: within 2^-22 of the row's largest weight
+    wrow = w.permute(0, 2, 3, 1).reshape(Cout, -1)
+    assert ((we - wrow.double()).abs().max(dim=1).values <= 2.0 ** -22 * wrow.abs().max(dim=1).values.double()).all()
+    ref = _ref(x, we, Cin, Cout, alpha, beta, resid)
     assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
     alt = torch.full_like(out, float("nan"))                               # the digits in fragment order (what the engine packs): bit-equal
     hip.spike_conv2d(x.to(DEV), hip.tile_weight_i8x3(dg), imgs, H, W, Cin, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=alt, alpha=alpha.to(DEV),
@@ -68,7 +71,7 @@ def test_fp32_epilogue_against_fp64(B, T, H, W, Cin, Cout, with_res, monkeypatch
         assert (out - old).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("kind,v_reset", [("lif", None), ("lif", 0.0), ("if", None)])
+@pytest.mark.parametrize("kind,v_reset", [("lif", None), ("lif", 0.0), ("if", None), ("psn", None)])
 @pytest.mark.parametrize("B,T,H,W,Cin,Cout", [(1, 10, 9, 12, 768, 768), (2, 10, 4, 5, 384, 96), (1, 20, 6, 5, 128, 64)])
 @pytest.mark.parametrize("membrane", [False, True])
 @pytest.mark.parametrize("tile", ["2", "3"])
@@ -76,7 +79,7 @@ def test_fused_neuron_forms(B, T, H, W, Cin, Cout, membrane, kind, v_reset, tile
     if tile == "3" and (Cout % 48 or not membrane):
         pytest.skip("the 48-column tile reads digits in fragment order, 48 | Cout")
     monkeypatch.setenv("SDF_SMALLM_CB", tile)
-    if kind != "lif" or v_reset is not None:
+    if kind not in ("lif", "psn") or v_reset is not None:
         if (H, W) != (9, 12):
             pytest.skip("the other neuron classes are covered on the shipped shape")
     imgs, hw = B * T, H * W
@@ -84,7 +87,15 @@ def test_fused_neuron_forms(B, T, H, W, Cin, Cout, membrane, kind, v_reset, tile
     w = rnd((Cout, Cin, 3, 3), 311, -0.05, 0.05)
     alpha, beta = rnd((Cout,), 312, 0.5, 1.5), rnd((Cout,), 313, -0.1, 0.3)
     resid = rnd((imgs * hw, Cout), 314, -0.3, 0.3) if membrane else None
-    p = hip.NeuronParams(kind, 2.0, 0.1, v_reset)
+    pw = pb = None
+    sd = {}
+    if kind == "psn":                    # the shipped neuron (reference Spiking_submodules.py:183-211): its T x T matrix and bias
+        pw = (torch.eye(T) * 0.8 + rnd((T, T), 315, -0.15, 0.15)).contiguous()
+        pb = (torch.full((T,), -0.1) + rnd((T,), 316, -0.03, 0.03)).contiguous()
+        p = hip.NeuronParams("psn", psn_w=pw.to(DEV), psn_b=pb.to(DEV))
+        sd = {"w.weight": pw, "w.bias": pb.view(-1, 1)}
+    else:
+        p = hip.NeuronParams(kind, 2.0, 0.1, v_reset)
     dg = hip.pack_conv_weight_i8x3(w.to(DEV), tiled=membrane)            # (both weight layouts take part)
     sp = torch.full((imgs * hw, Cout), 7, dtype=torch.uint8, device=DEV)
     m = torch.full((imgs * hw, Cout), float("nan"), device=DEV) if membrane else None
@@ -94,12 +105,12 @@ def test_fused_neuron_forms(B, T, H, W, Cin, Cout, membrane, kind, v_reset, tile
     got = sp.cpu().view(B, T, hw, Cout).permute(1, 0, 2, 3).float().contiguous()
     ht = ref.view(B, T, hw, Cout).permute(1, 0, 2, 3).float().contiguous()
     delta = 16 * 2.0 ** -23 * max(float(ht.pow(2).mean().sqrt()), 0.1)
-    rep = O.delta_consistent(ht, got, O.NeuronCfg(kind, 0.1, v_reset, 2.0, T), {}, "w.", delta)
+    rep = O.delta_consistent(ht, got, O.NeuronCfg(kind, 0.1, v_reset, 2.0, T), sd, "w.", delta)
     assert rep["unexplained"] == 0, rep
     assert 0.02 < got.mean() < 0.98
     if membrane:
         assert (m.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
-        own = R.neuron_ref(m.cpu().view(B, T, hw, Cout).permute(1, 0, 2, 3).contiguous(), kind, 2.0, 0.1, v_reset)
+        own = R.neuron_ref(m.cpu().view(B, T, hw, Cout).permute(1, 0, 2, 3).contiguous(), kind, 2.0, 0.1, v_reset, psn_w=pw, psn_b=pb)
         assert torch.equal(own, got), "spikes are not the neuron of the stored membrane"
 
 
@@ -114,6 +125,7 @@ def test_plain_product_with_fp32_epilogue(M, N, K, extras):
     dg = hip.tile_weight_i8x3(hip.split_weight_i8x3(Wt.to(DEV)))
     kw, ref = {}, None
     We = _weff(hip.split_weight_i8x3(Wt.to(DEV)))
+    assert ((We - Wt.double()).abs().max(dim=1).values <= 2.0 ** -22 * Wt.abs().max(dim=1).values.double()).all()
     ref = A.double() @ We.t()
     if extras:
         alpha, beta, bias, resid = rnd((N,), 402, 0.5, 1.5), rnd((N,), 403, -0.2, 0.2), rnd((N,), 404, -0.1, 0.1), rnd((M, N), 405)

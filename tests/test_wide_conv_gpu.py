@@ -52,7 +52,10 @@ def test_fp32_epilogue_against_fp64(B, T, H, W, Cin, Cout, with_res, monkeypatch
     out = torch.full((imgs * H * W, Cout), float("nan"), device=DEV)
     hip.spike_conv2d(x.to(DEV), dg, imgs, H, W, Cin, H, W, 3, 3, 1, (-1, 0, 1), (-1, 0, 1), out=out, alpha=alpha.to(DEV), beta=beta.to(DEV),
                      resid=None if resid is None else resid.to(DEV))
-    ref = _ref(x, _weff(dg), Cin, Cout, alpha, beta, resid)
+    we = _weff(dg)                                                         # what the digits carry: within 2^-22 of the row's largest weight
+    wrow = w.permute(0, 2, 3, 1).reshape(Cout, -1)
+    assert ((we - wrow.double()).abs().max(dim=1).values <= 2.0 ** -22 * wrow.abs().max(dim=1).values.double()).all()
+    ref = _ref(x, we, Cin, Cout, alpha, beta, resid)
     assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
     # the streaming kernel on the fp16 planes of the same weights
     if Cout % 96 == 0:
