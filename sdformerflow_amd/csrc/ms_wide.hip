@@ -241,32 +241,7 @@ __device__ __forceinline__ void wide_pieces(uint32_t (&goff)[w_steps(CB)], uint3
 // 1 280 contiguous bytes per channel piece; the consumer's 16 lanes of a k-group read 256 contiguous bytes.  The parity tape and
 // a caller that made the spikes with the neuron kernel use the row-major form [rows][K] instead (bit-equal results: the integer
 // sums do not depend on the order).
-struct WidePmParams {
-  const uint8_t* A;          // row-major u8 [rows][K], or tiled, or (zsrc) the gated spikes E, flat
-  int a_tiled;
-  const int32_t* zsrc;       // head scramble: per activation row the byte offset of (k-group 0, byte 0) in E; null = plain rows
-  uint32_t zg_G;             // head scramble: bytes between two k-groups (T' * N1 * 32)
-  const int8_t* W;           // digit planes [3][N][K]
-  const float* cscale;       // (N) power-of-two scale of every output channel
-  int N, K, HW;
-  int64_t P;                 // positions = B * HW; rows = P * T in (B, T, HW) order
-  const float *bias, *alpha, *beta;
-  float* x;                  // fp32 epilogue: out = resid, row stride ldo
-  int ldo;
-  uint8_t* out_spike;        // neuron epilogue: u8 [rows][ldsp] or tiled (K = ldsp)
-  int ldsp, out_tiled;
-  SdfNeuronCfg sn;
-  float inv_tau;
-  int ncg, nrg, nunits, passes;   // a workgroup walks `passes` row groups (grid = ncg x ceil(nrg / passes))
-  // 3x3 / stride 1 / pad 1 convolution on an NHWC u8 image batch (imgs = B * T, position = pixel): A = the image, K = 9 Cin in
-  // (tap, channel) order; cv_cpt = 128-deep chunks per tap (0 = not a convolution)
-  int cv_H, cv_W, cv_Cin, cv_cpt;
-  // split-K: the workgroup grid has a third factor, K range ks covers chunks [ks * cps, (ks + 1) * cps); EPI 4 stores the raw fp32
-  // sums (digit scale applied) to partial[ks][row][N] for wide_reduce_kernel
-  int ksplit, cps;
-  float* partial;
-  int no_resid;              // fp32 epilogue without a shortcut: out = BN(...) (patch merging writes a new tensor)
-};
+// (struct WidePmParams: wide_common.h - shared with the weight-resident row-loop kernels of ms_res.hip)
 
 // EPI: 1 = neuron (spikes out), 2 = fp32 (+ shortcut), 3 = fp32 and the neuron on the updated shortcut stream
 // AM (address mode of the spike operand): 0 = rows of a tensor (row-major / tiled / head scramble), 1 = 3x3 convolution taps (EPI 4),
@@ -529,22 +504,7 @@ __global__ __launch_bounds__(256, 1) void wide_pm_kernel(WidePmParams P) {
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Attention front: q | k projection + BN (+ positional term) + SN_q / SN_k over the T' = 2 steps + token gate -> E.
-struct WideFrontParams {
-  const uint8_t* xs;         // (2, rows, C) u8: SN_proj of the gathered slices
-  int64_t rows;              // B_ * N1
-  int N1, C, nH;
-  const int8_t* wq; const int8_t* wk;      // digit planes, row pitch C; plane strides (bytes)
-  int64_t wq_plane, wk_plane;
-  const float *q_cs, *k_cs;                // (C) power-of-two channel scales
-  const float *q_al, *q_be, *k_al, *k_be;
-  const float* pe; int64_t pe_ld;          // k's additive term pe[(t * N1 + n) * pe_ld + c] or null
-  SdfNeuronCfg sn_q, sn_k, sn2_q;
-  float it_q, it_k, it_2;
-  uint8_t* e;                // (2, rows, C)
-  uint8_t* qs; uint8_t* ks;  // KEEP: q / k spikes with row strides ldq / ldk
-  int64_t ldq, ldk;
-  int nrg, ntiles;           // row groups (NW tiles each), token tiles
-};
+// (struct WideFrontParams: wide_common.h)
 
 template <int RB, int NK, bool KEEP>
 __global__ __launch_bounds__(256, 1) void wide_front_kernel(WideFrontParams P) {
@@ -832,6 +792,7 @@ int launch_pm_t(WidePmParams& P, int epi, hipStream_t s) {
 }
 
 int launch_pm(WidePmParams& P, int T, int epi, hipStream_t s) {
+  if (res_pm_takes(P, T, epi)) return launch_res_pm(P, T, epi, s);      // narrow stages: weights LDS-resident, row loop (ms_res.hip)
   int rc;
   switch (T) {
     case 10: rc = launch_pm_t<10>(P, epi, s); break;
@@ -860,6 +821,21 @@ bool wide_env_off() {
   const char* e = getenv("SDF_WIDE");
   return e && e[0] == '0';
 }
+// narrow stages (C <= 192: swin stages 0 - 1): the weight-resident row-loop kernels of ms_res.hip (SDF_RES=0: off - A/B)
+// Which stages take them is a measured choice (round 5, profiles/r5c_forward_sequence.txt): at C = 192 the block runs 72 us on them
+// against 103 us on the K-ring kernels; at C = 96 (K = one and a half steps) their int8-digit epilogue - three accumulator reads and
+// a recombination per output - outweighs 60 MFMAs per tile (112 us per block against 92 on qk_front + spike_gemm + ms_mlp_fused, whose
+// fp32 accumulators need neither), so by default they start above 96 channels; SDF_RES_MINC lowers that (tests, A/B).  The first patch
+// merging (C = 96, K = 384) runs on them either way: 18.6 against 33 us.
+int res_minc() {
+  if (const char* e = getenv("SDF_RES_MINC")) { const int v = atoi(e); if (v >= 32 && v <= 192) return v; }
+  return 128;
+}
+bool res_stage_ok(int C, bool merge = false) {
+  const char* e = getenv("SDF_RES");
+  if ((e && e[0] == '0') || C < 64 || C > 192 || C % 32) return false;
+  return merge ? C < 192 : C >= res_minc();              // (the merge of a 192-channel stage: K = 768, the K-ring kernel is faster - 16.5 vs 24.6 us)
+}
 
 }  // namespace
 
@@ -871,12 +847,13 @@ bool wide_env_off() {
 bool ms_wide_mlp_supports(const SdfMsMlpDesc* d) {
   if (wide_env_off() || (d->flags & SDF_MLP_NARROW)) return false;
   if (!d->fc1_digits || !d->fc1_cscale || !d->fc2_digits || !d->fc2_cscale) return false;
-  if (d->nsplit != 2 || d->C < 192 || d->C % 64 || d->Ch % 64 || d->Ch % 96) return false;
+  const bool res = res_stage_ok(d->C) && d->Ch % 32 == 0 && d->Ch <= 768;      // (ms_res.hip: any row count, K % 16 == 0)
+  if (d->nsplit != 2 || (!res && (d->C < 192 || d->C % 64 || d->Ch % 64 || d->Ch % 96))) return false;
   if (d->D != 10 && d->D != 20) return false;
   if (!neuron_ok(d->sn1) || !neuron_ok(d->sn2) || (d->emit_next && !neuron_ok(d->emit_sn))) return false;
   const int64_t tokens = (int64_t)d->B * d->D * d->HW;
   if (tokens * d->Ch >= (1LL << 31) || tokens * d->C * 4 >= (1LL << 31)) return false;
-  if (tokens > WIDE_MAX_ROWS && !wide_env_any()) return false;
+  if (tokens > WIDE_MAX_ROWS && !wide_env_any() && !res) return false;
   if (!d->fc1_alpha || !d->fc1_beta || !d->fc2_alpha || !d->fc2_beta) return false;
   return sdf_aligned(d->x, 16) && sdf_aligned(d->fc1_digits, 16) && sdf_aligned(d->fc2_digits, 16);
 }
@@ -890,6 +867,7 @@ int launch_ms_wide_mlp(const SdfMsMlpDesc* d, const uint8_t* s1, bool s1_tiled, 
   P.A = s1; P.a_tiled = s1_tiled; P.out_tiled = s2_tiled; P.W = d->fc1_digits; P.cscale = d->fc1_cscale; P.N = d->Ch; P.K = d->C; P.HW = (int)d->HW; P.P = (int64_t)d->B * d->HW;
   P.alpha = d->fc1_alpha; P.beta = d->fc1_beta;
   P.out_spike = s2; P.ldsp = d->Ch; P.sn = d->sn2; P.inv_tau = inv_tau_of(d->sn2);
+  P.res_stage = res_stage_ok(d->C) && d->Ch <= 768;
   int rc = launch_pm(P, d->D, 1, s);
   if (rc) return rc;
   if (fc2_small) return launch_smallm_fc2(d, s2, s);
@@ -899,6 +877,7 @@ int launch_ms_wide_mlp(const SdfMsMlpDesc* d, const uint8_t* s1, bool s1_tiled, 
   Q.alpha = d->fc2_alpha; Q.beta = d->fc2_beta; Q.x = d->x; Q.ldo = d->C;
   Q.sn = d->emit_next ? d->emit_sn : d->sn2; Q.inv_tau = inv_tau_of(Q.sn);
   Q.out_spike = d->emit_next; Q.ldsp = d->C; Q.out_tiled = 0;     // the next layer's first neuron on the updated stream, row-major
+  Q.res_stage = P.res_stage;
   return launch_pm(Q, d->D, d->emit_next ? 3 : 2, s);
 }
 
@@ -906,9 +885,10 @@ int launch_ms_wide_mlp(const SdfMsMlpDesc* d, const uint8_t* s1, bool s1_tiled, 
 bool wide_merge_supports(const SdfMsMergeDesc* d) {
   if (wide_env_off()) return false;
   if (d->B < 1 || d->H < 1 || d->W < 1 || (d->D != 10 && d->D != 20)) return false;
-  if (d->C % 64 || d->C < 64 || d->N % 32) return false;
+  const bool res = res_stage_ok(d->C, true);                // (ms_res.hip: the quadrant of every 16-byte piece decoded per lane, any row count)
+  if ((d->C % 64 && !res) || d->C < 64 || d->N % 32) return false;
   const int64_t rows = (int64_t)d->B * d->D * ((d->H + 1) / 2) * ((d->W + 1) / 2);
-  if (rows > WIDE_MAX_ROWS && !wide_env_any()) return false;
+  if (rows > WIDE_MAX_ROWS && !wide_env_any() && !res) return false;
   if (rows * 4 * d->C >= (1LL << 31) || rows * (int64_t)d->N * 4 >= (1LL << 31) || (int64_t)d->N * 4 * d->C * 3 >= (1LL << 31)) return false;
   return sdf_aligned(d->spikes, 16) && sdf_aligned(d->digits, 16) && sdf_aligned(d->out, 16);
 }
@@ -920,6 +900,8 @@ int launch_wide_merge(const SdfMsMergeDesc* d, hipStream_t s) {
   P.alpha = d->alpha; P.beta = d->beta; P.x = d->out; P.ldo = d->N; P.no_resid = 1;
   P.cv_H = d->H; P.cv_W = d->W; P.cv_Cin = d->C; P.cv_cpt = d->C / 64;          // (64-deep steps per quadrant)
   const int T = d->D, PPW = 4 * (20 / T);
+  P.res_stage = res_stage_ok(d->C, true);
+  if (res_pm_takes(P, T, 2)) return launch_res_pm(P, T, 2, s);
   const int64_t units = (P.P + PPW - 1) / PPW;
   if (units >= (1LL << 28)) return SDF_E_SHAPE;
   P.nunits = (int)units; P.nrg = (int)((units + 3) / 4); P.ncg = d->N / 32;
@@ -935,7 +917,8 @@ int launch_wide_merge(const SdfMsMergeDesc* d, hipStream_t s) {
 
 bool ms_wide_attn_supports(const SdfQkAttnDesc* d) {
   if (wide_env_off() || (d->flags & SDF_QK_NARROW)) return false;
-  if (d->nsplit != 2 || d->Tq != 2 || d->C < 192 || d->C % 64 || d->C != d->nH * 32 || d->N1 < 24) return false;
+  const bool res = res_stage_ok(d->C);
+  if (d->nsplit != 2 || d->Tq != 2 || (!res && (d->C < 192 || d->C % 64)) || d->C != d->nH * 32 || d->N1 < 24) return false;
   if (!d->x_src || d->xB < 1 || d->xHW < 1 || (d->xD != 10 && d->xD != 20)) return false;
   if ((int64_t)d->xB * d->xD * d->xHW != d->x_rows) return false;
   const SdfNeuronCfg* ns[4] = {&d->sn_proj, &d->sn_q, &d->sn_k, &d->sn2_q};
@@ -945,7 +928,7 @@ bool ms_wide_attn_supports(const SdfQkAttnDesc* d) {
   if (d->emit_s1 && !neuron_ok(d->emit_sn)) return false;
   const int64_t M = d->B_ * d->N1 * d->Tq;
   if (M * d->C >= (1LL << 31) || d->x_rows * d->C * 4 >= (1LL << 31) || M >= (1LL << 31)) return false;
-  if (d->x_rows > WIDE_MAX_ROWS && !wide_env_any()) return false;
+  if (d->x_rows > WIDE_MAX_ROWS && !wide_env_any() && !res) return false;
   const bool fused = d->qk_planes != nullptr;
   if (fused ? (!d->qk_digits || !d->qk_cscale) : (!d->q_digits || !d->q_cscale || !d->k_digits || !d->k_cscale)) return false;
   if (!d->p_digits || !d->p_cscale) return false;
@@ -980,6 +963,7 @@ int launch_ms_wide_front(const SdfQkAttnDesc* d, const uint8_t* xs, uint8_t* e, 
   P.sn_q = d->sn_q; P.sn_k = d->sn_k; P.sn2_q = d->sn2_q;
   P.it_q = inv_tau_of(d->sn_q); P.it_k = inv_tau_of(d->sn_k); P.it_2 = inv_tau_of(d->sn2_q);
   P.e = e;
+  if (res_stage_ok(C) && res_front_takes(P)) return launch_res_front(P, keep, neuron_class(d->sn_q), s);      // (ms_res.hip)
   // token tiles of 8 RB tokens: 32 (RB = 4: the accumulators leave room for the early positional-term loads) while that leaves
   // >= 600 waves, else 16 (RB = 2)
   const int64_t t5 = (rows + 31) / 32, t2 = (rows + 15) / 16;
@@ -1011,6 +995,7 @@ int launch_ms_wide_proj(const SdfQkAttnDesc* d, const uint8_t* e, hipStream_t s)
   P.x = d->x; P.ldo = d->C;
   P.out_spike = d->emit_s1; P.ldsp = d->C; P.out_tiled = (d->flags & SDF_QK_KEEP_SPIKES) ? 0 : 1;
   P.sn = d->emit_s1 ? d->emit_sn : d->sn_proj; P.inv_tau = inv_tau_of(P.sn);
+  P.res_stage = res_stage_ok(d->C);
   return launch_pm(P, d->xD, d->emit_s1 ? 3 : 2, s);
 }
 

@@ -156,11 +156,31 @@ __device__ __forceinline__ void psn_stage(float* tbl, const SdfNeuronCfg& n, int
     tbl[i] = r < T ? (k < T ? n.psn_w[r * T + k] : 0.f) : (k < T ? n.psn_b[k] : 0.f);
   }
 }
-template <int T>
+// decisions as a bit mask (bit t = step t)
+template <int T, int UNR = 2>
+__device__ __forceinline__ uint32_t psn_T_lds_bits(const float (&xs)[T], const float* tbl) {
+  constexpr int TP = PSN_TP(T);
+  uint32_t m = 0;
+#pragma unroll UNR
+  for (int t = 0; t < T; ++t) {
+    float hh = tbl[T * TP + t];
+#pragma unroll
+    for (int k4 = 0; k4 < TP / 4; ++k4) {                      // (four coefficients at a time: no whole row in registers)
+      const float4 q = *reinterpret_cast<const float4*>(tbl + t * TP + 4 * k4);
+      if (4 * k4 < T) hh = __builtin_fmaf(q.x, xs[4 * k4 < T ? 4 * k4 : 0], hh);
+      if (4 * k4 + 1 < T) hh = __builtin_fmaf(q.y, xs[4 * k4 + 1 < T ? 4 * k4 + 1 : 0], hh);
+      if (4 * k4 + 2 < T) hh = __builtin_fmaf(q.z, xs[4 * k4 + 2 < T ? 4 * k4 + 2 : 0], hh);
+      if (4 * k4 + 3 < T) hh = __builtin_fmaf(q.w, xs[4 * k4 + 3 < T ? 4 * k4 + 3 : 0], hh);
+    }
+    m |= (hh >= 0.f ? 1u : 0u) << t;
+  }
+  return m;
+}
+template <int T, int UNR = 2>
 __device__ __forceinline__ void psn_T_lds(const float (&xs)[T], float (&sp)[T], const float* tbl) {
   constexpr int TP = PSN_TP(T);
   uint32_t m = 0;
-#pragma unroll 2
+#pragma unroll UNR
   for (int t = 0; t < T; ++t) {
     float w[TP];
 #pragma unroll
@@ -178,10 +198,25 @@ __device__ __forceinline__ void psn_T_lds(const float (&xs)[T], float (&sp)[T], 
 }
 
 // neuron of class NK over the T values a lane holds, PSN coefficients from the LDS table `tbl` (psn_stage) where T > 4
-template <int NK, int T>
+template <int NK, int T, bool LEAN = false>
 __device__ __forceinline__ void neuron_any(const float (&xs)[T], float (&sp)[T], const SdfNeuronCfg& n, float inv_tau, const float* tbl) {
-  if constexpr (NK == 1 && (T > 4)) psn_T_lds<T>(xs, sp, tbl);
+  if constexpr (NK == 1 && (T > 4)) psn_T_lds<T, LEAN ? 1 : 2>(xs, sp, tbl);      // (LEAN: one row's coefficients in registers at a time)
   else neuron_T<NK, T>(xs, sp, n, inv_tau);
+}
+
+// the same, decisions as a bit mask (bit t = step t): the PSN never forms its T spike floats
+template <int NK, int T, bool LEAN = false>
+__device__ __forceinline__ uint32_t neuron_any_bits(const float (&xs)[T], const SdfNeuronCfg& n, float inv_tau, const float* tbl) {
+  if constexpr (NK == 1 && (T > 4)) {
+    return psn_T_lds_bits<T, LEAN ? 1 : 2>(xs, tbl);
+  } else {
+    float sp[T];
+    neuron_T<NK, T>(xs, sp, n, inv_tau);
+    uint32_t m = 0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) m |= ((__float_as_uint(sp[t]) >> 29) & 1u) << t;      // 1.0f has bit 29 set
+    return m;
+  }
 }
 
 bool qk_front_supports(const SdfQkAttnDesc* d);

@@ -4,6 +4,61 @@
 #include "spike_mm.h"
 
 namespace sdfmm {
+
+// ---- launch parameters of the position-major product and of the attention front (ms_wide.hip, ms_res.hip) ----
+struct WidePmParams {
+  const uint8_t* A;          // row-major u8 [rows][K], or tiled, or (zsrc) the gated spikes E, flat
+  int a_tiled;
+  const int32_t* zsrc;       // head scramble: per activation row the byte offset of (k-group 0, byte 0) in E; null = plain rows
+  uint32_t zg_G;             // head scramble: bytes between two k-groups (T' * N1 * 32)
+  const int8_t* W;           // digit planes [3][N][K]
+  const float* cscale;       // (N) power-of-two scale of every output channel
+  int N, K, HW;
+  int64_t P;                 // positions = B * HW; rows = P * T in (B, T, HW) order
+  const float *bias, *alpha, *beta;
+  float* x;                  // fp32 epilogue: out = resid, row stride ldo
+  int ldo;
+  uint8_t* out_spike;        // neuron epilogue: u8 [rows][ldsp] or tiled (K = ldsp)
+  int ldsp, out_tiled;
+  SdfNeuronCfg sn;
+  float inv_tau;
+  int ncg, nrg, nunits, passes;   // a workgroup walks `passes` row groups (grid = ncg x ceil(nrg / passes))
+  // 3x3 / stride 1 / pad 1 convolution on an NHWC u8 image batch (imgs = B * T, position = pixel): A = the image, K = 9 Cin in
+  // (tap, channel) order; cv_cpt = 128-deep chunks per tap (0 = not a convolution)
+  int cv_H, cv_W, cv_Cin, cv_cpt;
+  // split-K: the workgroup grid has a third factor, K range ks covers chunks [ks * cps, (ks + 1) * cps); EPI 4 stores the raw fp32
+  // sums (digit scale applied) to partial[ks][row][N] for wide_reduce_kernel
+  int ksplit, cps;
+  float* partial;
+  int no_resid;              // fp32 epilogue without a shortcut: out = BN(...) (patch merging writes a new tensor)
+  int res_stage;             // set by the host: a narrow stage (C <= 192) - the weight-resident row-loop kernel (ms_res.hip) may take it
+};
+
+struct WideFrontParams {
+  const uint8_t* xs;         // (2, rows, C) u8: SN_proj of the gathered slices
+  int64_t rows;              // B_ * N1
+  int N1, C, nH;
+  const int8_t* wq; const int8_t* wk;      // digit planes, row pitch C; plane strides (bytes)
+  int64_t wq_plane, wk_plane;
+  const float *q_cs, *k_cs;                // (C) power-of-two channel scales
+  const float *q_al, *q_be, *k_al, *k_be;
+  const float* pe; int64_t pe_ld;          // k's additive term pe[(t * N1 + n) * pe_ld + c] or null
+  SdfNeuronCfg sn_q, sn_k, sn2_q;
+  float it_q, it_k, it_2;
+  uint8_t* e;                // (2, rows, C)
+  uint8_t* qs; uint8_t* ks;  // KEEP: q / k spikes with row strides ldq / ldk
+  int64_t ldq, ldk;
+  int nrg, ntiles;           // row groups (NW tiles each), token tiles
+  int ntiles_per;            // ms_res.hip: token tiles per row group
+};
+
+// weight-resident row-loop forms (ms_res.hip): whole-K digit planes of a column group stay in LDS, the waves of a workgroup walk row
+// units independently (two waves per SIMD, no barrier after the weights are in)
+bool res_pm_takes(const WidePmParams& P, int T, int epi);
+int launch_res_pm(WidePmParams& P, int T, int epi, hipStream_t s);
+bool res_front_takes(const WideFrontParams& P);
+int launch_res_front(WideFrontParams& P, bool keep, int nk, hipStream_t s);
+
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;

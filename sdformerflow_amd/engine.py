@@ -25,10 +25,10 @@ from . import hip
 from .STSwinNet_SNN.Spiking_swin_transformer3D import get_window_size, merge_row_map, window_slice_map
 
 BN_EPS = 1e-5
-# Narrowest stage the wide-stage kernels (csrc/ms_wide.hip) take: C = 192 = swin stage 1 of the shipped model.  Measured at the end of
-# round 4 (two alternating pairs of runs): 704.6 / 694.9 against 698.9 / 694.2 samples/s with 256, single-stream latency 2.14 - 2.16
-# against 2.18 - 2.20 ms, swin stages 1.035 against 1.052 ms - and two launches fewer per stage-1 block (its SN1 rides in the projection).
-_WIDE_MINC = 192
+# Narrowest stage that runs on int8 digit planes with the neurons in the producing kernels' epilogues: from C = 96 (swin stage 0) on
+# since round 5 - stages 0 - 1 (C <= 192) on the weight-resident row-loop kernels of csrc/ms_res.hip, stages 2 - 3 on csrc/ms_wide.hip
+# (round 4 had the wide kernels from C = 192 and qk_front / spike_gemm / ms_mlp_fused on the fp16 planes at stage 0).
+_WIDE_MINC = 96
 
 
 def bn_affine(bn, device):
@@ -49,7 +49,7 @@ class _Lin:
         self.N, self.K = w.shape
         self.Wp = hip.split_weight(w, nsplit)
         # wide layers (swin stages 1 - 3) also carry int8 digit planes: what csrc/ms_wide.hip multiplies by (default plane mode only)
-        self.digits = hip.split_weight_i8x3(w) if nsplit == 2 and self.K >= _WIDE_MINC and self.K % 64 == 0 and self.N % 32 == 0 else None
+        self.digits = hip.split_weight_i8x3(w) if nsplit == 2 and self.K >= _WIDE_MINC and self.K % 32 == 0 and self.N % 32 == 0 else None
         self.bias = None if linear.bias is None else linear.bias.detach().float().to(device).contiguous()
         self.alpha, self.beta = bn_affine(bn, device) if bn is not None else (None, None)
 
@@ -105,7 +105,7 @@ class _Block:
         m = blk.mlp
         self.fc1 = _Lin(m.fc1, m.bn1.norm_layer, device, nsplit)
         self.fc2 = _Lin(m.fc2, m.bn2.norm_layer, device, nsplit)
-        if self.fc2.digits is not None:                      # wide stages: fc2 (K = 4 C against few tokens) runs on the small-M kernel
+        if self.fc2.digits is not None and self.fc2.K >= 1536:      # wide stages: fc2 (K = 4 C against few tokens) runs on the small-M kernel
             self.fc2.digits_tiled = hip.tile_weight_i8x3(self.fc2.digits)
         self.sn1, self.sn2 = _np(m.sn1, device), _np(m.sn2, device)
 
@@ -524,6 +524,11 @@ class MSFlowEngine:
         self._check_cl(x)
         B, D, H, W, Cc = x.shape
         name = f"sttmultires_unet.encoders.swin3d.layers.{s}.downsample.sn.spiking_neuron."
+        if spikes is None and getattr(lin, "digits", None) is not None and D in (10, 20) and sn.kind in hip.KIND:
+            # the stage's last MLP did not emit them (stage 0: it runs on the one-launch fp16-plane kernel): the neuron as a plain
+            # launch over x, then the same digit-plane reduction with the 2x2 concatenation as operand addressing - 8 + 19 us at the
+            # first merge of the shipped model against 33 us for the gathered neuron + spike GEMM below
+            spikes = self._neuron_bd(x, sn)
         if spikes is not None:
             out = hip.ms_patch_merge(spikes, lin)
             if out is not None:

@@ -66,6 +66,19 @@ class SEWFlowEngine(MSFlowEngine):
                 d = layer.downsample
                 self.merges.append((hip.pack_dense_linear_weight(d.reduction.weight.detach().float().to(dev)), bn_affine(d.norm.norm_layer, dev),
                                     _np(d.sn, dev)))
+        # The first res-block convolution reads the stream of the last stage as BYTES (`_stream_bytes`): that is exact only where the
+        # stream is a sum of spike tensors - behind a patch merging (whose output is spikes) every block adds two spike tensors
+        # (reference Spiking_swin_transformer3D.py:840-845).  Checked HERE, once, instead of by a host sync per forward: a model
+        # without a patch merging would feed the real-valued patch embedding into the byte cast, and the int8 small-M kernel
+        # (csrc/ms_smallm.hip) reads bytes >= 128 as negative.
+        if len(unet.resblocks) > 0:
+            if not self.merges:
+                raise hip.SdfError("SEW family: a model with a single swin stage feeds the real-valued patch embedding into the res-blocks; "
+                                   "the HIP engine reads that stream as sums of spikes (bytes) - no kernel is built for it")
+            peak = 1 + 2 * len(self.stages[-1])
+            if peak >= 128:
+                raise hip.SdfError(f"SEW family: {len(self.stages[-1])} blocks in the last stage can sum to {peak} spikes per element; the "
+                                   "res-block convolution reads the stream as int8 bytes (< 128)")
         self.unet_res = []
         for i, rb in enumerate(unet.resblocks):
             self.unet_res.append(_ResBlock(rb, dev, ns, U + f"resblocks.{i}."))  # conv2 reads spikes, conv1 the integer stream as bytes
@@ -168,8 +181,10 @@ class SEWFlowEngine(MSFlowEngine):
     def _stream_bytes(self, x):
         """The integer-valued SEW stream as the byte operand of the spike kernels.  Only the fp16-plane kernels (gemm_nsplit == 2) take
         any byte exactly (csrc/spike_mm.h expand_spikes: {n, 0x64} = fp16(1024 + n)); the bf16-plane expansion is for {0, 1} only, so the
-        other weight modes are refused here instead of returning wrong sums.  SDF_DEBUG_CHECKS=1 also verifies on the host that
-        the stream is a small integer everywhere (a sync: off by default so that a SEW forward can be captured into a HIP graph)."""
+        other weight modes are refused here instead of returning wrong sums; the int8 digit kernels (csrc/ms_smallm.hip) take
+        bytes below 128.  That the stream IS a sum of at most 127 spikes is established at construction (`_init_stages`: a patch merging
+        ahead of the res-blocks, the block count of the last stage); SDF_DEBUG_CHECKS=1 additionally verifies it on the host per call
+        (a sync: off by default so that a SEW forward can be captured into a HIP graph)."""
         if self.nsplit != 2:
             raise hip.SdfError(f"SEW family: gemm_nsplit = {self.nsplit} is not built for the res-block convolution on the integer stream "
                                "(bf16 planes expand spikes {0, 1} only); use the default gemm_nsplit = 2")

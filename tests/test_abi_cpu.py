@@ -99,7 +99,7 @@ def test_argument_errors_are_reported_before_any_launch():
     assert lib.sdf_window_zsrc_map(None, C.c_int64(4), 2, 81, 12, p, None) == E_NULL
     assert lib.sdf_window_zsrc_map(p, C.c_int64(0), 2, 81, 12, p, None) == E_SHAPE
     assert lib.sdf_qk_attn_is_wide(None) == 0 and lib.sdf_ms_mlp_is_wide(None) == 0
-    assert lib.sdf_qk_attn_is_wide(C.byref(q)) == 0              # C = 96: the general kernels
+    assert lib.sdf_qk_attn_is_wide(C.byref(q)) == 0              # no inverse map / digit planes given: the general kernels
     q.emit_s1 = 0x10000
     q.workspace_bytes = 1 << 30
     assert lib.sdf_qk_attn_fwd(C.byref(q), None) == E_SHAPE     # only the wide-stage projection emits the next neuron's spikes
@@ -116,8 +116,11 @@ def test_argument_errors_are_reported_before_any_launch():
     assert lib.sdf_ms_mlp_is_wide(C.byref(m)) == 0
     m.flags, m.nsplit = 0, 3
     assert lib.sdf_ms_mlp_is_wide(C.byref(m)) == 0              # the exact three-plane mode keeps the general kernels
-    m.nsplit, m.C, m.Ch, m.s1_in = 2, 96, 384, 0x10000
-    assert lib.sdf_ms_mlp_fwd(C.byref(m), None) == E_SHAPE      # s1_in is a wide-stage input
+    m.nsplit, m.C, m.Ch = 2, 96, 384
+    assert lib.sdf_ms_mlp_is_wide(C.byref(m)) == 1              # round 5: the narrow stages (C <= 192) run on digit planes too (csrc/ms_res.hip)
+    m.C, m.Ch, m.s1_in = 224, 896, 0x10000                      # (neither a narrow nor a wide stage: C > 192, C % 64 != 0)
+    assert lib.sdf_ms_mlp_is_wide(C.byref(m)) == 0
+    assert lib.sdf_ms_mlp_fwd(C.byref(m), None) == E_SHAPE      # s1_in is a digit-plane-stage input
     # round 4, late: the small-M kernel's weight format, patch merging on emitted spikes, several convolutions in one launch
     q16 = C.c_void_p(0x10000)
     assert lib.sdf_tile_weight_i8x3(None, q16, 64, 128, None) == E_NULL
@@ -128,8 +131,8 @@ def test_argument_errors_are_reported_before_any_launch():
     mg.spikes = mg.digits = mg.cscale = mg.out = 0x10000
     mg.B, mg.D, mg.H, mg.W, mg.C, mg.N = 1, 4, 8, 8, 128, 256
     assert lib.sdf_ms_patch_merge_fwd(C.byref(mg), None) == E_SHAPE          # D in {10, 20}
-    mg.D, mg.C = 10, 96
-    assert lib.sdf_ms_patch_merge_fwd(C.byref(mg), None) == E_SHAPE          # C in steps of 64
+    mg.D, mg.C = 10, 80
+    assert lib.sdf_ms_patch_merge_fwd(C.byref(mg), None) == E_SHAPE          # C in steps of 32 up to 192, of 64 beyond
     assert lib.sdf_spike_conv2d_multi_fwd(None, 4, None) == E_NULL
     assert lib.sdf_spike_conv2d_multi_fwd(q16, 0, None) == E_SHAPE
     g5 = hip.SpikeGemmDesc()

@@ -1,4 +1,5 @@
-"""GPU parity of the wide-stage kernels (csrc/ms_wide.hip: swin stages 2 / 3, C = 384 / 768) through the C ABI
+"""GPU parity of the digit-plane kernels of the MS swin block - csrc/ms_wide.hip (swin stages 2 / 3, C = 384 / 768) and, since round 5,
+csrc/ms_res.hip (stages 0 / 1 and the first merge, C = 96 / 192: whole-K weights LDS-resident, row loop, two waves per SIMD) - through the C ABI
 `sdf_ms_mlp_fwd` / `sdf_qk_attn_fwd`, STEP BY STEP against the oracle - every step on the kernels' OWN upstream spikes
 (teacher forcing, as tests/replay.py does for whole models), so that each statement is exact:
 
@@ -26,12 +27,20 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _resident_kernels_from_64_channels(monkeypatch):
+    """The weight-resident kernels (csrc/ms_res.hip) serve C in 64..192; the dispatcher takes them from 128 channels on by default
+    (measured, ms_wide.hip: res_minc).  These tests are about the kernels: every narrow shape runs on them."""
+    monkeypatch.setenv("SDF_RES_MINC", "64")
+
+
 class _L:
     def __init__(self, W, alpha, beta, bias=None, ns=2):
         self.N, self.K = W.shape
         self.Wp = hip.split_weight(W.to(DEV).contiguous(), ns)
         self.digits = hip.split_weight_i8x3(W.to(DEV).contiguous())
-        self.digits_tiled = hip.tile_weight_i8x3(self.digits)            # (fc2 of <= 5 120 tokens takes the small-M kernel through these)
+        if self.K % 64 == 0 and self.N % 16 == 0:
+            self.digits_tiled = hip.tile_weight_i8x3(self.digits)        # (fc2 of <= 5 120 tokens takes the small-M kernel through these)
         self.alpha, self.beta = alpha.to(DEV).contiguous(), beta.to(DEV).contiguous()
         self.bias = None if bias is None else bias.to(DEV).contiguous()
 
@@ -88,9 +97,12 @@ def _delta(h, v_th=0.1):
 # ------------------------------------------------------------------------------------------------------------------ MLP
 @pytest.mark.parametrize("name", ALL)
 @pytest.mark.parametrize("B,D,H,W,Cc", [(1, 10, 18, 24, 384), (1, 10, 9, 12, 768), (2, 10, 5, 7, 384), (1, 20, 6, 5, 384),
-                                        (1, 20, 3, 3, 768), (3, 10, 1, 3, 256), (1, 10, 36, 48, 192), (2, 20, 5, 3, 192), (1, 10, 4, 6, 320)])
+                                        (1, 20, 3, 3, 768), (3, 10, 1, 3, 256), (1, 10, 36, 48, 192), (2, 20, 5, 3, 192), (1, 10, 4, 6, 320),
+                                        # narrow stages (ms_res.hip): stage 0 at full size (K = 96: one and a half 64-deep steps), ragged units,
+                                        # T = 20, K = 64 / 128 / 160
+                                        (1, 10, 72, 96, 96), (2, 10, 5, 7, 96), (1, 20, 6, 5, 96), (3, 10, 1, 3, 64), (1, 10, 9, 7, 128), (1, 10, 4, 6, 160)])
 def test_wide_mlp_steps_against_the_oracle(B, D, H, W, Cc, name):
-    if name not in ("lif", "psn") and (D != 10 or B != 1):
+    if name not in ("lif", "psn") and (D != 10 or B != 1 or H * W > 1000):
         pytest.skip("the other neuron classes are covered on the shipped T = 10 shapes")
     Ch, ntok = 4 * Cc, B * D * H * W
     x0 = rnd((B, D, H, W, Cc), 700, -0.5, 1.0)
@@ -159,6 +171,12 @@ def _attn_case(B, D, H, W, Cc, window, shift, seed=0):
     (1, 10, 9, 12, 512, (2, 9, 9), (0, 0, 0)),           # K = 4 chunks
     (2, 10, 8, 11, 384, (2, 8, 8), (0, 0, 0)),           # batch 2, 64-token windows, ragged map
     (1, 20, 7, 9, 256, (2, 5, 5), (1, 2, 2)),            # T = 20, 25-token windows
+    # narrow stages (ms_res.hip)
+    (1, 10, 72, 96, 96, (2, 9, 9), (1, 4, 4)),           # stage 0 of the shipped model at full size: K = 96, padded width, shifted
+    (1, 10, 36, 48, 96, (2, 9, 9), (1, 4, 4)),
+    (2, 10, 8, 11, 96, (2, 8, 8), (0, 0, 0)),            # batch 2, ragged map
+    (1, 20, 7, 9, 64, (2, 5, 5), (1, 2, 2)),             # T = 20, K = 64
+    (1, 10, 18, 24, 160, (2, 9, 9), (1, 4, 4)),          # K = 160: two and a half steps
 ])
 def test_wide_attention_steps_against_the_oracle(B, D, H, W, Cc, window, shift, stacked, name):
     if name == "psn" and stacked:
@@ -166,8 +184,8 @@ def test_wide_attention_steps_against_the_oracle(B, D, H, W, Cc, window, shift, 
     if name == "psn":
         if B != 1 and D != 20:
             pytest.skip("PSN: the shipped shapes, every K chunk count and T = 20")
-    elif (name != "lif" or not stacked) and (Cc != 384 or D != 10 or B != 1 or shift[0] != 1):
-        pytest.skip("neuron classes / separate projections are covered on the shipped stage-2 shape")
+    elif (name != "lif" or not stacked) and ((Cc, H) not in ((384, 18), (96, 36)) or D != 10 or B != 1 or shift[0] != 1):
+        pytest.skip("neuron classes / separate projections are covered on the shipped stage-2 shape and on a stage-0 shape")
     nH, Tq, N1, x0, Wq, Wk, Wp, aq, bq, ak, bk, ap, bp, biasp, pe = _attn_case(B, D, H, W, Cc, window, shift)
     npj, nq, nk_, ng, ne = _N(name, Tq, seed=11), _N(name, Tq, seed=12), _N(name, Tq, seed=13), \
         _N(name, Tq, seed=14, gain=0.12, bias=-1.2), _N(name, D, seed=15)
@@ -221,7 +239,7 @@ def test_wide_attention_steps_against_the_oracle(B, D, H, W, Cc, window, shift, 
     # (c) token gate: exact on the kernel's own q and k
     a = qs.float().view(Tq, rows, nH, 32).sum(-1)
     gate = ng.ref(a.contiguous())
-    assert 0.03 < gate.mean() < 0.97
+    assert name != "psn" or 0.03 < gate.mean() < 0.99
     e_ref = ks.float().view(Tq, rows, nH, 32) * gate.unsqueeze(-1)
     assert torch.equal(e.float().view(Tq, rows, nH, 32), e_ref), "gated spikes differ"
     assert 0.01 < e_ref.mean() < 0.9
@@ -290,7 +308,8 @@ def test_wide_block_through_the_engine_matches_the_general_kernels():
 
 # ------------------------------------------------------------------------- fc2's emission of the next neuron + patch merging
 @pytest.mark.parametrize("name", ALL)
-@pytest.mark.parametrize("B,D,H,W,Cc", [(1, 10, 15, 20, 384), (1, 10, 8, 10, 768), (2, 10, 5, 7, 384), (1, 20, 6, 5, 384)])
+@pytest.mark.parametrize("B,D,H,W,Cc", [(1, 10, 15, 20, 384), (1, 10, 8, 10, 768), (2, 10, 5, 7, 384), (1, 20, 6, 5, 384),
+                                        (1, 10, 15, 20, 96), (2, 10, 5, 7, 192), (1, 20, 6, 5, 96)])
 def test_wide_mlp_emits_the_next_layers_first_spikes(B, D, H, W, Cc, name):
     """SdfMsMlpDesc.emit_next: SN_next(x after the update), bit-equal to the oracle neuron on the kernel's OWN updated x (what the patch
     merging - reference Spiking_swin_transformer3D.py:970 - or the bottleneck's MS_ResBlock.sn1 - Spiking_modules.py:922 - computes
@@ -323,7 +342,10 @@ def _merge_ref(sp, We, alpha, beta):
 
 
 @pytest.mark.parametrize("B,D,H,W,Cc", [(1, 10, 15, 20, 384), (1, 10, 30, 40, 256), (2, 10, 7, 9, 384), (1, 20, 6, 5, 128),
-                                        (1, 10, 1, 3, 128), (3, 20, 4, 4, 256), (1, 10, 36, 48, 192), (2, 10, 5, 7, 64), (1, 20, 3, 4, 320)])
+                                        (1, 10, 1, 3, 128), (3, 20, 4, 4, 256), (1, 10, 36, 48, 192), (2, 10, 5, 7, 64), (1, 20, 3, 4, 320),
+                                        # narrow stages (ms_res.hip: the quadrant of every 16-byte piece decoded per lane): the first merge
+                                        # of the shipped model, odd sizes, T = 20, C = 160
+                                        (1, 10, 72, 96, 96), (1, 10, 15, 21, 96), (1, 20, 6, 5, 96), (2, 10, 7, 9, 160)])
 def test_wide_patch_merge_against_the_oracle(B, D, H, W, Cc):
     """sdf_ms_patch_merge_fwd on given spikes: exact integer sums -> fp64 reference to 1e-6 of the range, odd sizes included (15 x 20 is
     the shipped stage-2 map), and against the gather-map + spike GEMM path it replaces."""
@@ -350,8 +372,8 @@ def test_wide_patch_merge_against_the_oracle(B, D, H, W, Cc):
 
 
 def test_wide_patch_merge_refuses_what_it_is_not_built_for():
-    lin = _L(rnd((192, 384), 920, -0.1, 0.1), rnd((192,), 921, 0.5, 1.5), rnd((192,), 922, -0.2, 0.2))
-    sp = torch.zeros((1, 10, 8, 8, 96), dtype=torch.uint8, device=DEV)                  # C % 64 != 0
+    lin = _L(rnd((160, 320), 920, -0.1, 0.1), rnd((160,), 921, 0.5, 1.5), rnd((160,), 922, -0.2, 0.2))
+    sp = torch.zeros((1, 10, 8, 8, 80), dtype=torch.uint8, device=DEV)                  # C % 32 != 0
     assert hip.ms_patch_merge(sp, lin) is None
     lin2 = _L(rnd((256, 512), 923, -0.1, 0.1), rnd((256,), 924, 0.5, 1.5), rnd((256,), 925, -0.2, 0.2))
     assert hip.ms_patch_merge(torch.zeros((1, 4, 8, 8, 128), dtype=torch.uint8, device=DEV), lin2) is None    # D not in {10, 20}
@@ -379,3 +401,47 @@ def test_fc2_on_the_small_m_kernel_equals_the_wide_main_loop(B, D, H, W, Cc, mon
     xw, bw, yw = run()
     assert torch.equal(xs, xw) and torch.equal(bs, bw) and torch.equal(ys, yw) and torch.equal(xs, ys)
     assert not torch.equal(xs, x0.to(DEV))
+
+
+# ----------------------------------------------------------- narrow-stage kernels (ms_res.hip) against the wide-stage kernels (ms_wide.hip)
+@pytest.mark.parametrize("name", ["lif", "psn"])
+def test_resident_kernels_equal_the_wide_kernels_bit_for_bit(name, monkeypatch):
+    """C = 192 (swin stage 1) is served by both kernel families: the weight-resident row-loop kernels (default) and the wide-stage K-ring
+    kernels (SDF_RES=0).  Same exact integer sums, same fp32 epilogue expressions: the block's x, the gated spikes E, the SN1 spikes the
+    projection emits, the hidden spikes, the emitted next-layer spikes and the patch merging agree bit for bit."""
+    B, D, H, W, Cc, window, shift = 1, 10, 36, 48, 192, (2, 9, 9), (1, 4, 4)
+    nH, Tq, N1, x0, Wq, Wk, Wp, aq, bq, ak, bk, ap, bp, biasp, pe = _attn_case(B, D, H, W, Cc, window, shift, seed=60)
+    Ch = 4 * Cc
+    npj, nq, nk_, ng = (_N(name, Tq, seed=31 + i, **({"gain": 0.12, "bias": -1.2} if i == 3 else {})) for i in range(4))
+    n1, n2, nn = _N(name, D, seed=41), _N(name, D, seed=42), _N(name, D, v_th=0.25, seed=43, bias=-0.2)
+    plin, qlin, klin = _L(Wp, ap, bp, biasp), _L(Wq, aq, bq), _L(Wk, ak, bk)
+    fc1 = _L(rnd((Ch, Cc), 961, -0.15, 0.15), rnd((Ch,), 963, 0.5, 1.5), rnd((Ch,), 964, -0.2, 0.2))
+    fc2 = _L(rnd((Cc, Ch), 962, -0.05, 0.05), rnd((Cc,), 965, 0.5, 1.5), rnd((Cc,), 966, -0.2, 0.2))
+    mlin = _L(rnd((2 * Cc, 4 * Cc), 967, -0.08, 0.08), rnd((2 * Cc,), 968, 0.5, 1.5), rnd((2 * Cc,), 969, -0.2, 0.2))
+    rowmap, B_ = hip.window_slice_map(B, D, H, W, window, shift, DEV)
+    zsrc = hip.window_zsrc_map(rowmap, B_, Tq, N1, nH, B * D * H * W)
+
+    def run():
+        x = x0.to(DEV).clone()
+        ws, info, keep = hip.ms_mlp_workspace(x, Ch), {}, []
+        hip.qk_attn(x, rowmap, B_, Tq, N1, nH, plin, npj.p, nq.p, nk_.p, ng.p, q_lin=qlin, k_lin=klin, pe=pe.to(DEV).contiguous(), x_src=zsrc,
+                    emit=(ws, n1.p), info=info, keep_ws=keep)
+        assert info.get("emitted") is True
+        xa = x.clone()
+        s1 = ws[:x.numel()].clone()                               # (row-major: the tape form)
+        kb = []
+        hip.ms_mlp(x, fc1, fc2, n1.p, n2.p, keep_ws=kb)
+        buf = torch.full((B, D, H, W, Cc), 7, dtype=torch.uint8, device=DEV)
+        x2 = hip.ms_mlp(xa.clone(), fc1, fc2, n1.p, n2.p, emit_next=(buf, nn.p))
+        mg = hip.ms_patch_merge(buf, mlin)
+        torch.cuda.synchronize()
+        M, pad = Tq * B_ * N1, lambda n: (n + 255) // 256 * 256
+        wsa, wsm, ntok = keep[0], kb[0], B * D * H * W             # (only the regions the calls define: the paddings between them are not written)
+        return (xa, wsa[:M * Cc].clone(), wsa[pad(M * Cc):][:2 * M * Cc].clone(), wsa[pad(M * Cc) + pad(2 * M * Cc):][:M * Cc].clone(), s1, x,
+                wsm[:ntok * Cc].clone(), wsm[pad(ntok * Cc):][:ntok * Ch].clone(), x2, buf, mg)
+    a = run()
+    monkeypatch.setenv("SDF_RES", "0")
+    b = run()
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), f"output {i} differs between the resident and the wide kernels"
+    assert not torch.equal(a[0], x0.to(DEV)) and 0.02 < a[9].float().mean() < 0.98

@@ -16,5 +16,5 @@ for ln in sys.stdin:
 for r in rows:
     nm = subprocess.run(['c++filt', r['name']], capture_output=True, text=True).stdout.strip()
     nm = nm.replace('sdfmm::(anonymous namespace)::','').replace('(anonymous namespace)::','').replace('void ',''); nm = re.sub(r'\((sdfmm::)?[A-Za-z_:]*Params.*', '', nm)
-    print(f\"{nm[:70]:70s} vgpr {r.get('VGPRs','?'):>4} agpr {r.get('AGPRs','?'):>3} spill {r.get('VGPR Spill','?'):>3} scratch {r.get('ScratchSize [bytes/lane]','?'):>4} occ {r.get('Occupancy [waves/SIMD]','?'):>2} lds {r.get('LDS Size [bytes/block]','?'):>6}\")
+    print(f\"{nm[:70]:70s} vgpr {r.get('VGPRs','?'):>4} agpr {r.get('AGPRs','?'):>3} spill {r.get('VGPRs Spill','?'):>3} scratch {r.get('ScratchSize [bytes/lane]','?'):>4} occ {r.get('Occupancy [waves/SIMD]','?'):>2} lds {r.get('LDS Size [bytes/block]','?'):>6}\")
 "
