@@ -86,9 +86,9 @@ __device__ __forceinline__ void res_mainloop(i32x4 (&acc)[3][RB][CB], const __am
     aa.get(s, rb, voff, soff);
     dst = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(A_rs, voff, soff, 0));      // (a step beyond K: every piece is INV)
   };
-  auto step = [&](int s, auto par_c, i32x4 (&aC)[RB], auto refill_c) __attribute__((always_inline)) {
+  auto step = [&](int s, auto par_c, i32x4 (&aC)[RB], auto refill_c, auto zero_c) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_c)::value;
-    constexpr bool refill = decltype(refill_c)::value;
+    constexpr bool refill = decltype(refill_c)::value, zero = decltype(zero_c)::value;
     const uint8_t* wb = Wl + (uint32_t)(s >> 1) * (8u * BN * 16u);           // (steps 2 i and 2 i + 1 share the base: woff carries the parity)
     i32x4 b[3];
     auto load_b = [&](int g) __attribute__((always_inline)) {
@@ -104,24 +104,28 @@ __device__ __forceinline__ void res_mainloop(i32x4 (&acc)[3][RB][CB], const __am
       const int cb = g / 3, dg = g - 3 * cb;
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
-        mfma_i8(acc[dg][rb][cb], aC[rb], b[g % 3]);
+        if constexpr (zero) mfma_i8_zero(acc[dg][rb][cb], aC[rb], b[g % 3]);      // (the tile's first step: no accumulator input)
+        else mfma_i8(acc[dg][rb][cb], aC[rb], b[g % 3]);
         if (g == NU - 1 && refill) a_load1(aC[rb], s + 2, rb);                // (this set's last reader of row block rb: step s + 2 moves in)
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  using T0 = std::integral_constant<int, 0>;
+  using T1 = std::integral_constant<int, 1>;
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) a_load1(aX[rb], 0, rb);
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) a_load1(aY[rb], 1, rb);
-  int s = 0;
+  step(0, T0{}, aX, std::true_type{}, std::true_type{});  // step 0 starts the sums (the accumulators are never zeroed)
+  int s = 1;
 #pragma unroll 1
   for (; s + 1 < ksteps; s += 2) {
-    step(s, std::integral_constant<int, 0>{}, aX, std::true_type{});
-    step(s + 1, std::integral_constant<int, 1>{}, aY, std::true_type{});
+    step(s, T1{}, aY, std::true_type{}, std::false_type{});
+    step(s + 1, T0{}, aX, std::true_type{}, std::false_type{});
     mfma_drain(acc);                                     // (the exit edge of the round may shuffle accumulators: wide_common.h)
   }
-  if (s < ksteps) step(s, std::integral_constant<int, 0>{}, aX, std::false_type{});
+  if (s < ksteps) step(s, T1{}, aY, std::false_type{}, std::false_type{});
   mfma_drain(acc);                                       // (the accumulators are read by vector instructions from here on)
 }
 
@@ -129,8 +133,12 @@ __device__ __forceinline__ void res_mainloop(i32x4 (&acc)[3][RB][CB], const __am
 // is one int32 and v_cvt_f32_i32 rounds it once - the same value as fma(d2, 65536, d1 256 + d0) on exact operands, one instruction less
 template <bool SMALLK>
 __device__ __forceinline__ float res_digits_f32(int a0, int a1, int a2) {
-  if constexpr (SMALLK) return (float)((a2 << 16) + (a1 << 8) + a0);
-  else return digits_f32(a0, a1, a2);
+  if constexpr (SMALLK) {
+    const uint32_t lo = ((uint32_t)a1 << 8) + (uint32_t)a0;                  // (v_lshl_add_u32 twice)
+    return (float)(int)(((uint32_t)a2 << 16) + lo);
+  } else {
+    return digits_f32(a0, a1, a2);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -148,7 +156,8 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
   uint8_t* Wl = dyn;                                     // resident weights
   uint8_t* Sall = dyn + res_wbytes(K, BN);               // per-wave byte tiles [80][SP]
   int32_t* rowtab_all = reinterpret_cast<int32_t*>(Sall + ((EPI & 1) ? NWV * STILE : 0));
-  float* psn_tbl = reinterpret_cast<float*>(rowtab_all + NWV * ROWS);
+  f32x4* coltab = reinterpret_cast<f32x4*>(rowtab_all + NWV * ROWS);           // per column: {alpha x digit scale, beta, digit scale, bias}
+  float* psn_tbl = reinterpret_cast<float*>(coltab + BN);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, lq = lane >> 4;
   // (row range, column group), column group fastest: the workgroups of an XCD (ids equal mod 8) cover a contiguous range of rows
@@ -221,9 +230,6 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
     }
   };
 
-  float al[CB], be[CB], bs[CB], cs[CB];                  // BN / bias / digit scale of this lane's columns
-#pragma unroll
-  for (int cb = 0; cb < CB; ++cb) al[cb] = be[cb] = bs[cb] = cs[cb] = 0.f;
 
   // ---- first unit's row addressing, then the weights (their latency covers it), one barrier, then the waves part ways ----
   int unit = u_lo + wave;
@@ -232,27 +238,21 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
     return n0 + col < N ? (uint32_t)((p * N + n0 + col) * K) : INV;
   });
   if constexpr (NK == 1) psn_stage<T>(psn_tbl, P.sn, tid, 64 * NWV);
-#pragma unroll
-  for (int cb = 0; cb < CB; ++cb) {
-    const int n = n0 + 16 * cb + c;
-    const int nc = n < N ? n : 0;
-    al[cb] = P.alpha ? P.alpha[nc] : 1.f;
-    be[cb] = P.alpha ? P.beta[nc] : 0.f;
-    bs[cb] = P.bias ? P.bias[nc] : 0.f;
-    cs[cb] = P.cscale[nc];
+  // BN / bias / digit scale of the workgroup's columns: a small LDS table, read per column block in the epilogue (held in registers
+  // they cost ten across the main loop).  With a bias: h = fma(sum x scale + bias, alpha, beta); without, alpha x scale (exact: the
+  // scale is a power of two) is folded on the spot: fma(sum, alpha x scale, beta) is the same rounding of the same real number.
+  const bool has_bias = P.bias != nullptr;               // (wave-uniform)
+  if (tid < BN) {
+    const int nc = n0 + tid < N ? n0 + tid : 0;
+    const float al = P.alpha ? P.alpha[nc] : 1.f, be = P.alpha ? P.beta[nc] : 0.f, csn = P.cscale[nc];
+    coltab[tid] = f32x4{has_bias ? al : al * csn, be, csn, has_bias ? P.bias[nc] : 0.f};
   }
   __syncthreads();
 
 #pragma unroll 1
   for (; unit < u_hi; unit += NWV) {
     if (unit != u_lo + wave) prepare(unit);
-    i32x4 acc[3][RB][CB];
-#pragma unroll
-    for (int dg = 0; dg < 3; ++dg)
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) acc[dg][rb][cb] = i32x4{0, 0, 0, 0};
+    i32x4 acc[3][RB][CB];                                // (written by the main loop's first step)
     if constexpr (AM == 2) {
       AddrMerge aa{a_base, a_mask, lq, P.cv_Cin >> 4, P.cv_cpt, P.cv_W, P.cv_Cin, kpv};
       res_mainloop<RB, CB>(acc, A_rs, aa, ksteps, Wl, KP, lane);
@@ -294,15 +294,16 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
       if constexpr ((EPI & 2) != 0 && !RES_EARLY) request_res(cb, cb + 1);
+      const f32x4 cp = coltab[16 * cb + c];              // {alpha (x scale), beta, scale, bias} of this lane's column
       float h[SLOTS];
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
         const i32x4 a0 = acc_read(acc[0][rb][cb]), a1 = acc_read(acc[1][rb][cb]), a2 = acc_read(acc[2][rb][cb]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v = res_digits_f32<SK>(a0[e], a1[e], a2[e]) * cs[cb];
-          v = v + bs[cb];
-          h[4 * rb + e] = __builtin_fmaf(v, al[cb], be[cb]);
+          // no bias: alf = alpha x (power-of-two digit scale) is exact, so fma(sum, alf, beta) IS fma(sum x scale + 0, alpha, beta)
+          const float sum = res_digits_f32<SK>(a0[e], a1[e], a2[e]);
+          h[4 * rb + e] = has_bias ? __builtin_fmaf(sum * cp[2] + cp[3], cp[0], cp[1]) : __builtin_fmaf(sum, cp[0], cp[1]);
         }
         if constexpr ((EPI & 2) != 0) {
           const i32x4 g4 = *reinterpret_cast<const i32x4*>(rowtab + 16 * rb + 4 * q);
@@ -424,13 +425,7 @@ __global__ __launch_bounds__(64 * NWV) void res_front_kernel(WideFrontParams P) 
               pev[rb][m][t][cb] = P.pe ? P.pe[((int64_t)t * P.N1 + n) * P.pe_ld + hd * 32 + 16 * cb + c] : 0.f;
         }
     }
-    i32x4 acc[3][RB][CB];
-#pragma unroll
-    for (int dg = 0; dg < 3; ++dg)
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) acc[dg][rb][cb] = i32x4{0, 0, 0, 0};
+    i32x4 acc[3][RB][CB];                                // (written by the main loop's first step)
     AddrPlain aa{a_base, kpv - lq};
     res_mainloop<RB, CB>(acc, A_rs, aa, ksteps, Wl, KP, lane);
 
@@ -547,7 +542,7 @@ int res_pm_launch_t(const WidePmParams& P, int epi, int nk, dim3 grid, size_t ld
 
 size_t res_pm_lds(int K, int epi, int T, int nk) {
   constexpr int SP = s_pitch(32);
-  size_t b = (size_t)res_wbytes(K, 32) + ((epi & 1) ? NWV * 80 * SP : 0) + NWV * 80 * 4;
+  size_t b = (size_t)res_wbytes(K, 32) + ((epi & 1) ? NWV * 80 * SP : 0) + NWV * 80 * 4 + 32 * 16;
   if (nk == 1) b += PSN_TABLE(20) * 4;
   (void)T;
   return b;
@@ -599,7 +594,7 @@ int launch_res_pm(WidePmParams& P, int T, int epi, hipStream_t s) {
 
 bool res_front_takes(const WideFrontParams& P) {
   if (res_env_off()) return false;
-  return P.C % 32 == 0 && P.C >= 64 && P.C <= 256;
+  return P.C % 32 == 0 && P.C >= 64 && P.C <= 512;        // (the head's q | k planes, whole K: 3 x 64 x C bytes of LDS)
 }
 
 int launch_res_front(WideFrontParams& P, bool keep, int nk, hipStream_t s) {

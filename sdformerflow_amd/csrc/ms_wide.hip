@@ -831,10 +831,15 @@ int res_minc() {
   if (const char* e = getenv("SDF_RES_MINC")) { const int v = atoi(e); if (v >= 32 && v <= 192) return v; }
   return 128;
 }
+int res_maxc() {                                         // (SDF_RES_MAXC: tuning override - K = C <= 768 fits the resident image)
+  if (const char* e = getenv("SDF_RES_MAXC")) { const int v = atoi(e); if (v >= 32 && v <= 768) return v; }
+  return 192;
+}
 bool res_stage_ok(int C, bool merge = false) {
   const char* e = getenv("SDF_RES");
-  if ((e && e[0] == '0') || C < 64 || C > 192 || C % 32) return false;
-  return merge ? C < 192 : C >= res_minc();              // (the merge of a 192-channel stage: K = 768, the K-ring kernel is faster - 16.5 vs 24.6 us)
+  if ((e && e[0] == '0') || C < 64 || C % 32) return false;
+  if (merge) return C < 192;                             // (the merge of a 192-channel stage: K = 768, the K-ring kernel is faster - 16.5 vs 24.6 us)
+  return C >= res_minc() && C <= res_maxc();
 }
 
 }  // namespace
@@ -847,7 +852,7 @@ bool res_stage_ok(int C, bool merge = false) {
 bool ms_wide_mlp_supports(const SdfMsMlpDesc* d) {
   if (wide_env_off() || (d->flags & SDF_MLP_NARROW)) return false;
   if (!d->fc1_digits || !d->fc1_cscale || !d->fc2_digits || !d->fc2_cscale) return false;
-  const bool res = res_stage_ok(d->C) && d->Ch % 32 == 0 && d->Ch <= 768;      // (ms_res.hip: any row count, K % 16 == 0)
+  const bool res = res_stage_ok(d->C) && d->C <= 192 && d->Ch % 32 == 0 && d->Ch <= 768;      // (ms_res.hip: any row count, K % 16 == 0)
   if (d->nsplit != 2 || (!res && (d->C < 192 || d->C % 64 || d->Ch % 64 || d->Ch % 96))) return false;
   if (d->D != 10 && d->D != 20) return false;
   if (!neuron_ok(d->sn1) || !neuron_ok(d->sn2) || (d->emit_next && !neuron_ok(d->emit_sn))) return false;
@@ -867,7 +872,7 @@ int launch_ms_wide_mlp(const SdfMsMlpDesc* d, const uint8_t* s1, bool s1_tiled, 
   P.A = s1; P.a_tiled = s1_tiled; P.out_tiled = s2_tiled; P.W = d->fc1_digits; P.cscale = d->fc1_cscale; P.N = d->Ch; P.K = d->C; P.HW = (int)d->HW; P.P = (int64_t)d->B * d->HW;
   P.alpha = d->fc1_alpha; P.beta = d->fc1_beta;
   P.out_spike = s2; P.ldsp = d->Ch; P.sn = d->sn2; P.inv_tau = inv_tau_of(d->sn2);
-  P.res_stage = res_stage_ok(d->C) && d->Ch <= 768;
+  P.res_stage = res_stage_ok(d->C);                        // (per launch: res_pm_takes admits K <= 768)
   int rc = launch_pm(P, d->D, 1, s);
   if (rc) return rc;
   if (fc2_small) return launch_smallm_fc2(d, s2, s);
@@ -917,7 +922,7 @@ int launch_wide_merge(const SdfMsMergeDesc* d, hipStream_t s) {
 
 bool ms_wide_attn_supports(const SdfQkAttnDesc* d) {
   if (wide_env_off() || (d->flags & SDF_QK_NARROW)) return false;
-  const bool res = res_stage_ok(d->C);
+  const bool res = res_stage_ok(d->C) && d->C <= 192;
   if (d->nsplit != 2 || d->Tq != 2 || (!res && (d->C < 192 || d->C % 64)) || d->C != d->nH * 32 || d->N1 < 24) return false;
   if (!d->x_src || d->xB < 1 || d->xHW < 1 || (d->xD != 10 && d->xD != 20)) return false;
   if ((int64_t)d->xB * d->xD * d->xHW != d->x_rows) return false;

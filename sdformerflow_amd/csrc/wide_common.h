@@ -111,6 +111,11 @@ __device__ __forceinline__ void mfma_i8(i32x4& acc, const i32x4& a, const i32x4&
   asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 
+// acc = A x B (no accumulator input: the first k-step of a tile - saves zeroing the accumulators, one v_accvgpr_write per register)
+__device__ __forceinline__ void mfma_i8_zero(i32x4& acc, const i32x4& a, const i32x4& b) {
+  asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+}
+
 // The MFMAs above are inline assembly: hipcc's hazard recogniser does not see that they write the accumulators, so nothing pads the
 // wait states an MFMA result needs before any OTHER kind of instruction may read or move it (cdna_hip_programming.md section 5.7 item 2:
 // "an MFMA's D -> any reader ... including compiler code after the asm", 12 states for an 8-pass MFMA).  mfma_drain() is that pad: the

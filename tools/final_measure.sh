@@ -3,7 +3,7 @@
 #   bench line (default command), rocprofv3 kernel stats of that command, launch sequence of one forward, PMC per kernel over one
 #   forward, PMC of the dense convolution (config 3 traffic), stamps of the small-M convolution.
 TAG=${1:-r4}
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?run on the GPU box}" || exit 1
 timeout 1300 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 bash tools/prof_bench.sh ${TAG}b > /dev/null 2>&1
 bash tools/prof_forward_one.sh ${TAG}s > /dev/null 2>&1

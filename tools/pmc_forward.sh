@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # HBM bytes of ONE forward of BASELINE config 2: FETCH_SIZE and WRITE_SIZE in separate --pmc passes, summed over the kernels of the
 # last of three eager forwards (MI355X_MICROARCH.md: FETCH_SIZE x 2 on gfx950), with the per-kernel-name breakdown.
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}" || exit 1
 rm -rf gpurun_out/pmc_forward
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
   timeout 300 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_forward/$set -- python3 tools/forward_one.py > /dev/null 2>&1 < /dev/null

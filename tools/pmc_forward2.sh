@@ -2,19 +2,19 @@
 # Where one forward of BASELINE config 2 spends the chip: per kernel name, summed over the launches of the last of five eager
 # forwards - vector / matrix instruction counts, matrix-pipe busy cycles, wave-cycles, HBM bytes (separate --pmc passes; FETCH_SIZE
 # x 2 on gfx950, KiB) - and the kernel durations of a --kernel-trace pass.  usage (GPU box): tools/pmc_forward2.sh [tag]
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}" || exit 1
 TAG=${1:-r3}
 OUT=gpurun_out/pmcf_$TAG
-rm -rf $OUT; mkdir -p $OUT
+rm -rf ${OUT:?}; mkdir -p ${OUT:?}
 i=0
 for set_ in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
             "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
             "FETCH_SIZE" "WRITE_SIZE"; do
-  timeout 300 rocprofv3 --pmc $set_ --output-format csv -d $OUT/p$i -- python3 tools/forward_one.py 5 > /dev/null 2>&1 < /dev/null
+  timeout 300 rocprofv3 --pmc $set_ --output-format csv -d ${OUT:?}/p$i -- python3 tools/forward_one.py 5 > /dev/null 2>&1 < /dev/null
   i=$((i+1))
 done
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 tools/forward_one.py 5 > /dev/null 2>&1 < /dev/null
-python3 - $OUT <<'PY'
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d ${OUT:?}/trace -- python3 tools/forward_one.py 5 > /dev/null 2>&1 < /dev/null
+python3 - ${OUT:?} <<'PY'
 import csv, glob, sys, collections, re
 out = sys.argv[1]
 def short(n):
@@ -56,4 +56,4 @@ for k in sorted(per, key=lambda k: -dur[k]):
     print(f"{k:64s} {cnt[k]:3d} {dur[k]:7.1f} {v['SQ_INSTS_VALU'] / 1e6:8.2f} {v['SQ_INSTS_MFMA'] / 1e6:7.3f} {v['SQ_INSTS_VALU'] / max(v['SQ_INSTS_MFMA'], 1):9.1f} "
           f"{busy:11.1f} {100 * v['SQ_LDS_BANK_CONFLICT'] / max(v['SQ_LDS_IDX_ACTIVE'], 1):11.1f} {2 * v['FETCH_SIZE'] * 1024 / 1e6:8.1f} {v['WRITE_SIZE'] * 1024 / 1e6:8.1f}")
 PY
-rm -rf $OUT/p* $OUT/trace
+rm -rf ${OUT:?}/p* ${OUT:?}/trace

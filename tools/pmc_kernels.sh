@@ -4,10 +4,10 @@
 # durations from a --kernel-trace pass.  Prints, per kernel: instruction mix (VALU / MFMA / LDS per wave), MFMA-pipe busy share,
 # LDS bank-conflict share, effective clock (GRBM_GUI_ACTIVE / 8 / duration) and HBM bytes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE).
 # usage (GPU box): tools/pmc_kernels.sh [tag]
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}" || exit 1
 TAG=${1:-r3}
 OUT=gpurun_out/pmc_$TAG
-rm -rf $OUT; mkdir -p $OUT
+rm -rf ${OUT:?}; mkdir -p ${OUT:?}
 run_one() {   # name, kernel substring, program args...
   local name=$1 sub=$2; shift 2
   for i in 0 1 2 3 4 5; do
@@ -20,12 +20,12 @@ run_one() {   # name, kernel substring, program args...
       5) set_="";;
     esac
     if [ -n "$set_" ]; then
-      timeout 180 rocprofv3 --pmc $set_ --output-format csv -d $OUT/$name/p$i -- python3 "$@" > /dev/null 2>&1
+      timeout 180 rocprofv3 --pmc $set_ --output-format csv -d ${OUT:?}/$name/p$i -- python3 "$@" > /dev/null 2>&1
     else
-      timeout 180 rocprofv3 --kernel-trace --output-format csv -d $OUT/$name/trace -- python3 "$@" > /dev/null 2>&1
+      timeout 180 rocprofv3 --kernel-trace --output-format csv -d ${OUT:?}/$name/trace -- python3 "$@" > /dev/null 2>&1
     fi
   done
-  python3 - "$OUT/$name" "$sub" "$name" <<'PY'
+  python3 - "${OUT:?}/$name" "$sub" "$name" <<'PY'
 import csv, glob, sys, collections
 d, sub, name = sys.argv[1:4]
 acc = collections.defaultdict(list)
@@ -51,11 +51,12 @@ if g("SQ_WAVES"):
           f"SALU {g('SQ_INSTS_SALU', 0) / w:.0f}  VMEM rd {g('SQ_INSTS_VMEM_RD', 0) / w:.1f} wr {g('SQ_INSTS_VMEM_WR', 0) / w:.1f}  SMEM {g('SQ_INSTS_SMEM', 0) / w:.0f}"
           f"   -> VALU per MFMA {g('SQ_INSTS_VALU', 0) / max(g('SQ_INSTS_MFMA', 1), 1):.2f}")
 if g("GRBM_GUI_ACTIVE"):
-    clk = g("GRBM_GUI_ACTIVE") / 8 / (us * 1e-6) / 1e9
-    print(f"   GRBM_GUI_ACTIVE {g('GRBM_GUI_ACTIVE'):.0f} (sum over 8 XCDs) -> effective clock {clk:.2f} GHz (reads high on launches under 0.3 ms)")
+    quot = g("GRBM_GUI_ACTIVE") / 8 / (us * 1e-6) / 1e9
+    clk = min(quot, 2.4)                 # (the quotient reads high on launches under 0.3 ms: the counter window is longer than the kernel)
+    print(f"   GRBM_GUI_ACTIVE {g('GRBM_GUI_ACTIVE'):.0f} (sum over 8 XCDs) / 8 / duration = {quot:.2f} GHz -> clock taken {clk:.2f} GHz (never above the part's 2.4)")
     if g("SQ_VALU_MFMA_BUSY_CYCLES"):
-        # per-SIMD busy cycles summed over the chip's 1024 SIMDs (SQ counters of this set count per SE and are summed by rocprofv3)
-        cyc = g("GRBM_GUI_ACTIVE") / 8
+        # per-SIMD busy cycles summed over the chip's 1024 SIMDs; kernel cycles = the kernel's own duration x the clock
+        cyc = us * 1e-6 * clk * 1e9
         print(f"   SQ_VALU_MFMA_BUSY_CYCLES {g('SQ_VALU_MFMA_BUSY_CYCLES'):.3e}; SQ_BUSY_CYCLES {g('SQ_BUSY_CYCLES', 0):.3e}; SQ_WAVE_CYCLES {g('SQ_WAVE_CYCLES', 0):.3e}; "
               f"kernel cycles {cyc:.3e}: MFMA busy / (256 CUs x kernel cycles) = {g('SQ_VALU_MFMA_BUSY_CYCLES') / (256 * cyc):.2f} (x4 if the counter is per SIMD)")
 if g("SQ_LDS_IDX_ACTIVE"):
@@ -73,4 +74,4 @@ run_one mlp_stage0    "ms_mlp_fused_kernel"        tools/mlp_one.py 1 10 72 96 9
 run_one gemm_proj_s2  "spike_gemm_kernel"          tools/gemm_one.py 4860 384 384 0 3
 run_one gemm_fc1_s2   "spike_mm_pp_kernel"         tools/gemm_one.py 4320 1536 384 10 1
 run_one attn_ann_s0   "win_attn_tiled_f16_kernel"  tools/win_attn_one.py ann 704 3 162 mask
-rm -rf $OUT/*/p* $OUT/*/trace
+rm -rf ${OUT:?}/*/p* ${OUT:?}/*/trace

@@ -2,7 +2,7 @@
 # HBM traffic of the dominant spike-conv kernel: FETCH_SIZE and WRITE_SIZE in separate --pmc passes (TCC slots),
 # as MI355X_MICROARCH.md prescribes.  FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950.
 # usage: tools/pmc_traffic.sh [resid|fusedm|fused] [2|i8x3]
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}" || exit 1
 rm -rf gpurun_out/pmc_traffic
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
   timeout 120 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_traffic -- python3 tools/conv_one.py 10 144 192 96 96 1 ${1:-fusedm} ${2:-i8x3} > /dev/null 2>&1
