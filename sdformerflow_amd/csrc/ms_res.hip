@@ -29,6 +29,34 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifdef SDF_STAMP
+// diagnostic build only (tools/stamp_res.sh): cycle stamps of wave 0 of the middle workgroup per kernel kind (0 = front, 1 / 2 / 3 = the
+// position-major product's epilogue kinds) - entry, first unit's addresses, weights in + barrier, first unit's main loop, first unit's
+// epilogue, kernel end - and every workgroup's life in 100 MHz real time
+__device__ unsigned long long g_res_stamp[4 * 8];
+__device__ unsigned long long g_res_census[4 * 2 * 1024];
+#define RSTAMP(i) do { if (rs_n[i] == 0) { rs[i] = __builtin_readcyclecounter(); rs_n[i] = 1; } } while (0)
+#define RSTAMP_DECL unsigned long long rs[6] = {0, 0, 0, 0, 0, 0}; int rs_n[6] = {0, 0, 0, 0, 0, 0}; const unsigned long long rr0 = __builtin_amdgcn_s_memrealtime()
+#define RSTAMP_OUT(kind, nunits)                                                                                  \
+  do {                                                                                                            \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
+    RSTAMP(5);                                                                                                    \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                                  \
+      g_res_census[(kind) * 2048 + 2 * blockIdx.x] = rr0;                                                         \
+      g_res_census[(kind) * 2048 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();                        \
+    }                                                                                                             \
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) {                                                        \
+      unsigned long long* o = g_res_stamp + 8 * (kind);                                                           \
+      for (int i = 0; i < 5; ++i) o[i] = rs[i + 1] > rs[i] ? rs[i + 1] - rs[i] : 0;                               \
+      o[5] = __builtin_amdgcn_s_memrealtime() - rr0; o[6] = gridDim.x; o[7] = (nunits);                           \
+    }                                                                                                             \
+  } while (0)
+#else
+#define RSTAMP(i)
+#define RSTAMP_DECL
+#define RSTAMP_OUT(kind, nunits)
+#endif
+
 namespace sdfmm {
 namespace {
 
@@ -104,8 +132,8 @@ __device__ __forceinline__ void res_mainloop(i32x4 (&acc)[3][RB][CB], const __am
       const int cb = g / 3, dg = g - 3 * cb;
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
-        if constexpr (zero) mfma_i8_zero(acc[dg][rb][cb], aC[rb], b[g % 3]);      // (the tile's first step: no accumulator input)
-        else mfma_i8(acc[dg][rb][cb], aC[rb], b[g % 3]);
+        if constexpr (zero) mfma_i8_v_zero(acc[dg][rb][cb], aC[rb], b[g % 3]);      // (the tile's first step: no accumulator input)
+        else mfma_i8_v(acc[dg][rb][cb], aC[rb], b[g % 3]);
         if (g == NU - 1 && refill) a_load1(aC[rb], s + 2, rb);                // (this set's last reader of row block rb: step s + 2 moves in)
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -123,10 +151,10 @@ __device__ __forceinline__ void res_mainloop(i32x4 (&acc)[3][RB][CB], const __am
   for (; s + 1 < ksteps; s += 2) {
     step(s, T1{}, aY, std::true_type{}, std::false_type{});
     step(s + 1, T0{}, aX, std::true_type{}, std::false_type{});
-    mfma_drain(acc);                                     // (the exit edge of the round may shuffle accumulators: wide_common.h)
+    mfma_drain_v(acc);                                     // (the exit edge of the round may shuffle accumulators: wide_common.h)
   }
   if (s < ksteps) step(s, T1{}, aY, std::false_type{}, std::false_type{});
-  mfma_drain(acc);                                       // (the accumulators are read by vector instructions from here on)
+  mfma_drain_v(acc);                                       // (the accumulators are read by vector instructions from here on)
 }
 
 // the exact integer sum of the three digit sums as one fp32 number.  K <= 256: |d2| 65536 <= 256 x 127 x 65536 < 2^31, the whole sum
@@ -160,6 +188,8 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
   float* psn_tbl = reinterpret_cast<float*>(coltab + BN);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, lq = lane >> 4;
+  RSTAMP_DECL;
+  RSTAMP(0);
   // (row range, column group), column group fastest: the workgroups of an XCD (ids equal mod 8) cover a contiguous range of rows
   int item = blockIdx.x;
   const int G = gridDim.x;
@@ -234,6 +264,7 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
   // ---- first unit's row addressing, then the weights (their latency covers it), one barrier, then the waves part ways ----
   int unit = u_lo + wave;
   if (unit < u_hi) prepare(unit);
+  RSTAMP(1);
   res_load_weights<BN>(Wl, W_rs, K, tid, 64 * NWV, 0, BN, [&](int p, int col) -> uint32_t {
     return n0 + col < N ? (uint32_t)((p * N + n0 + col) * K) : INV;
   });
@@ -248,6 +279,7 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
     coltab[tid] = f32x4{has_bias ? al : al * csn, be, csn, has_bias ? P.bias[nc] : 0.f};
   }
   __syncthreads();
+  RSTAMP(2);
 
 #pragma unroll 1
   for (; unit < u_hi; unit += NWV) {
@@ -261,6 +293,7 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
       res_mainloop<RB, CB>(acc, A_rs, aa, ksteps, Wl, KP, lane);
     }
 
+    RSTAMP(3);
     // ---------------- epilogue ----------------
     // Register budget: 128 vector registers beside the 120 accumulators (two waves per SIMD).  The accumulators are read quad by quad
     // where they are used (acc_read: left to the allocator all 120 were copied out behind the main loop), one column block at a time;
@@ -298,7 +331,7 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
       float h[SLOTS];
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
-        const i32x4 a0 = acc_read(acc[0][rb][cb]), a1 = acc_read(acc[1][rb][cb]), a2 = acc_read(acc[2][rb][cb]);
+        const i32x4 a0 = acc[0][rb][cb], a1 = acc[1][rb][cb], a2 = acc[2][rb][cb];      // (vector-register accumulators: read in place)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           // no bias: alf = alpha x (power-of-two digit scale) is exact, so fma(sum, alf, beta) IS fma(sum x scale + 0, alpha, beta)
@@ -351,7 +384,9 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
         }
       }
     }
+    RSTAMP(4);
   }
+  RSTAMP_OUT(EPI, (u_hi - u_lo + NWV - 1) / NWV);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -624,3 +659,10 @@ int launch_res_front(WideFrontParams& P, bool keep, int nk, hipStream_t s) {
 }
 
 }  // namespace sdfmm
+
+#ifdef SDF_STAMP
+extern "C" int sdf_debug_read_stamps_res(unsigned long long* host32, unsigned long long* census) {
+  (void)hipMemcpyFromSymbol(census, HIP_SYMBOL(g_res_census), sizeof(g_res_census));
+  return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(g_res_stamp), sizeof(g_res_stamp));
+}
+#endif

@@ -111,6 +111,25 @@ __device__ __forceinline__ void mfma_i8(i32x4& acc, const i32x4& a, const i32x4&
   asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 
+// The same with the accumulator in VECTOR registers (ms_res.hip: 120 accumulators + the rest fit the 256 unified registers of two
+// waves per SIMD when no AGPR is used at all - and the epilogue reads them without one v_accvgpr_read per register)
+__device__ __forceinline__ void mfma_i8_v(i32x4& acc, const i32x4& a, const i32x4& b) {
+  asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_i8_v_zero(i32x4& acc, const i32x4& a, const i32x4& b) {
+  asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
+}
+template <int A, int B, int C_>
+__device__ __forceinline__ void mfma_drain_v(i32x4 (&acc)[A][B][C_]) {
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+#pragma unroll
+  for (int a = 0; a < A; ++a)
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int c = 0; c < C_; ++c) asm volatile("" : "+v"(acc[a][b][c]));
+}
+
 // acc = A x B (no accumulator input: the first k-step of a tile - saves zeroing the accumulators, one v_accvgpr_write per register)
 __device__ __forceinline__ void mfma_i8_zero(i32x4& acc, const i32x4& a, const i32x4& b) {
   asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));

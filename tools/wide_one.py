@@ -12,7 +12,8 @@ class L:
         self.N, self.K = W.shape
         self.Wp = hip.split_weight(W.to("cuda:0").contiguous(), 2)
         self.digits = hip.split_weight_i8x3(W.to("cuda:0").contiguous())
-        self.digits_tiled = hip.tile_weight_i8x3(self.digits)
+        if self.K % 64 == 0 and self.N % 16 == 0:
+            self.digits_tiled = hip.tile_weight_i8x3(self.digits)
         self.alpha, self.beta = alpha.to("cuda:0"), beta.to("cuda:0")
         self.bias = None if bias is None else bias.to("cuda:0")
 
