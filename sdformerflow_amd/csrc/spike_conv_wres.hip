@@ -705,11 +705,15 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
               if (lif_fast) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                  // h = v + (x - v) / tau; s = (h - v_th >= 0); v = h - s v_th: with s in {0, 1} the last line is the difference the
+                  // comparison already holds, or h itself, bit for bit (spike_mm.h neuron_T<0>) - two selects instead of a multiply, a
+                  // subtraction and three bit operations per output (round 5: the epilogue's vector instructions bound this kernel)
                   float& vm = vmem[rb * 16 + q4 * 4 + j];
                   const float hcur = vm + (xs[j] - vm) * P.inv_tau;
-                  const float sp = (hcur - d.v_th >= 0.f) ? 1.f : 0.f;
-                  vm = hcur - sp * d.v_th;
-                  pk |= ((__float_as_uint(sp) >> 29) & 1u) << (8 * j);   // 1.0f has bit 29 set
+                  const float dth = hcur - d.v_th;
+                  const bool fire = dth >= 0.f;
+                  vm = fire ? dth : hcur;
+                  pk |= fire ? (1u << (8 * j)) : 0u;
                 }
               } else {
 #pragma unroll
