@@ -96,9 +96,15 @@ __device__ __forceinline__ void res_load_weights(uint8_t* Wl, const __amdgpu_buf
 //                               row / piece that does not exist
 // Steps alternate between two register sets; a set is refilled (step s + 2) behind the last MFMAs that read it.  One step = 3 CB
 // units of RB MFMAs on one weight fragment; the fragments of units g + 1, g + 2 are in flight while unit g multiplies.
+// strip (STRIP builds, else null): ROW-MAJOR operands are requested as FULL LINES - a lane quad reads the 64 contiguous bytes of one row
+// (lane = 4 row + piece; the caller's addresses are formed that way) - and pass through a per-wave LDS strip of RB x 1 KB into the MFMA's
+// order (lane = row + 16 k-group) at the top of their step: written lane-linear, read back through the XOR swizzle of ms_smallm.hip (the
+// writer stores piece p of row r at slot 4 r + (p ^ 2 (r / 8))).  A fragment-shaped load of a row-major tensor has every lane of the wave
+// in a different cache line: 64 lines per instruction instead of 16 in the texture path - measured on the third decoder level's product
+// (17 280 x 864 x 416, tools/res_ablate.sh, profiles/r5m_res_ablation.txt): 14 of the launch's 40 us.
 template <int RB, int CB, class AAddr>
 __device__ __forceinline__ void res_mainloop(i32x4 (&acc)[3][RB][CB], const __amdgpu_buffer_rsrc_t A_rs, AAddr& aa, int ksteps, const uint8_t* Wl,
-                                              int KP, int lane) {
+                                              int KP, int lane, uint8_t* strip = nullptr) {
   constexpr int BN = 16 * CB, NU = 3 * CB;
   asm volatile("" : "+v"(lane));                         // (laundered per unit: the fragment offsets are formed here, not held across the epilogue)
   const int l16 = lane & 15, lj = lane >> 4;
@@ -112,12 +118,21 @@ __device__ __forceinline__ void res_mainloop(i32x4 (&acc)[3][RB][CB], const __am
   auto a_load1 = [&](i32x4& dst, int s, int rb) __attribute__((always_inline)) {
     uint32_t voff, soff;
     aa.get(s, rb, voff, soff);
+#ifdef RES_X_NOA
+    voff = INV;                                          // (diagnostic builds, tools/res_ablate.sh: the spike operand reads nothing)
+#endif
     dst = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(A_rs, voff, soff, 0));      // (a step beyond K: every piece is INV)
   };
   auto step = [&](int s, auto par_c, i32x4 (&aC)[RB], auto refill_c, auto zero_c) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_c)::value;
     constexpr bool refill = decltype(refill_c)::value, zero = decltype(zero_c)::value;
     const uint8_t* wb = Wl + (uint32_t)(s >> 1) * (8u * BN * 16u);           // (steps 2 i and 2 i + 1 share the base: woff carries the parity)
+    if (strip) {                                                                // (wave-uniform; same-wave LDS operations execute in order)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) *reinterpret_cast<i32x4*>(strip + rb * 1024 + 16 * lane) = aC[rb];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) aC[rb] = *reinterpret_cast<const i32x4*>(strip + rb * 1024 + (4 * l16 + (lj ^ ((l16 >> 2) & 2))) * 16);
+    }
     i32x4 b[3];
     auto load_b = [&](int g) __attribute__((always_inline)) {
       const int cb = g / 3, dg = g - 3 * cb;
@@ -132,8 +147,13 @@ __device__ __forceinline__ void res_mainloop(i32x4 (&acc)[3][RB][CB], const __am
       const int cb = g / 3, dg = g - 3 * cb;
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
+#ifdef RES_X_NOMFMA
+        if constexpr (zero) acc[dg][rb][cb] = aC[rb] ^ b[g % 3];                    // (diagnostic builds: no matrix instruction)
+        else asm volatile("" : "+v"(acc[dg][rb][cb]) : "v"(aC[rb]), "v"(b[g % 3]));
+#else
         if constexpr (zero) mfma_i8_v_zero(acc[dg][rb][cb], aC[rb], b[g % 3]);      // (the tile's first step: no accumulator input)
         else mfma_i8_v(acc[dg][rb][cb], aC[rb], b[g % 3]);
+#endif
         if (g == NU - 1 && refill) a_load1(aC[rb], s + 2, rb);                // (this set's last reader of row block rb: step s + 2 moves in)
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -173,7 +193,7 @@ __device__ __forceinline__ float res_digits_f32(int a0, int a1, int a2) {
 // Position-major product, weight-resident.  EPI / AM as wide_pm_kernel: EPI 1 = neuron (spikes out), 2 = fp32 (+ shortcut), 3 = fp32 and
 // the neuron on the updated stream; AM 0 = rows of a tensor (row-major / tiled / head scramble), 2 = the 2x2 concatenation of patch
 // merging (any C % 16 == 0: the quadrant of every 16-byte k-piece is decoded per lane).  SK: K <= 256 (res_digits_f32).
-template <int T, int EPI, int NK, int AM, bool SK>
+template <int T, int EPI, int NK, int AM, bool SK, bool STRIP = false>
 __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
   constexpr int RB = RBW, CB = 2, ROWS = 16 * RB, SLOTS = 4 * RB, PPG = SLOTS / T, PPW = 4 * PPG, BN = 16 * CB;
   constexpr int SP = s_pitch(BN), STILE = ROWS * SP;
@@ -186,6 +206,7 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
   int32_t* rowtab_all = reinterpret_cast<int32_t*>(Sall + ((EPI & 1) ? NWV * STILE : 0));
   f32x4* coltab = reinterpret_cast<f32x4*>(rowtab_all + NWV * ROWS);           // per column: {alpha x digit scale, beta, digit scale, bias}
   float* psn_tbl = reinterpret_cast<float*>(coltab + BN);
+  uint8_t* strips = reinterpret_cast<uint8_t*>(psn_tbl + (NK == 1 ? PSN_TABLE(20) : 0));      // STRIP: RB x 1 KB per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, lq = lane >> 4;
   RSTAMP_DECL;
@@ -220,9 +241,12 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
       rowtab[r] = g;
     }
     asm volatile("" ::: "memory");                       // (same-wave LDS operations execute in order: no wait between the table's writes and reads)
+    // STRIP: this lane requests piece lp of tile row 16 rb + lane / 4 (a lane quad = one row's 64 contiguous bytes), else piece lq of row lane % 16
+    const int lrow = STRIP ? (lane >> 2) : l16;
+    const int lpc = STRIP ? ((lane & 3) ^ ((lane >> 4) & 2)) : lq;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-      const int32_t g = rowtab[16 * rb + l16];
+      const int32_t g = rowtab[16 * rb + lrow];
       a_base[rb] = INV;
       a_mask[rb] = 0;
       if (AM == 2) {
@@ -236,7 +260,7 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
       } else if (P.a_tiled) {
         a_base[rb] = (((uint32_t)unit * (uint32_t)kpv + (uint32_t)lq) * ROWS + 16 * rb + l16) * 16u;
       } else if (g >= 0) {
-        a_base[rb] = P.zsrc ? (uint32_t)P.zsrc[g] + (uint32_t)(lq >> 1) * P.zg_G + 16u * (lq & 1) : (uint32_t)g * (uint32_t)K + 16u * lq;
+        a_base[rb] = P.zsrc ? (uint32_t)P.zsrc[g] + (uint32_t)(lq >> 1) * P.zg_G + 16u * (lq & 1) : (uint32_t)g * (uint32_t)K + 16u * lpc;
       }
     }
   };
@@ -285,12 +309,14 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
   for (; unit < u_hi; unit += NWV) {
     if (unit != u_lo + wave) prepare(unit);
     i32x4 acc[3][RB][CB];                                // (written by the main loop's first step)
+    const int lpiece = STRIP ? ((lane & 3) ^ ((lane >> 4) & 2)) : lq;        // (the k-piece of a step this lane requests)
+    uint8_t* strip = STRIP ? strips + wave * (RB * 1024) : nullptr;
     if constexpr (AM == 2) {
-      AddrMerge aa{a_base, a_mask, lq, P.cv_Cin >> 4, P.cv_cpt, P.cv_W, P.cv_Cin, kpv};
-      res_mainloop<RB, CB>(acc, A_rs, aa, ksteps, Wl, KP, lane);
+      AddrMerge aa{a_base, a_mask, lpiece, P.cv_Cin >> 4, P.cv_cpt, P.cv_W, P.cv_Cin, kpv};
+      res_mainloop<RB, CB>(acc, A_rs, aa, ksteps, Wl, KP, lane, strip);
     } else {
-      AddrPlain aa{a_base, a_step, kpv - lq};
-      res_mainloop<RB, CB>(acc, A_rs, aa, ksteps, Wl, KP, lane);
+      AddrPlain aa{a_base, a_step, kpv - lpiece};
+      res_mainloop<RB, CB>(acc, A_rs, aa, ksteps, Wl, KP, lane, strip);
     }
 
     RSTAMP(3);
@@ -345,7 +371,11 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
             const float v = h[4 * rb + e] + res[cb][4 * rb + e];
             h[4 * rb + e] = v;
             const uint32_t xo = (g4[e] >= 0 && n0 + 16 * cb + c < N) ? ((uint32_t)g4[e] * (uint32_t)P.ldo + (uint32_t)(n0 + c)) * 4u : INV;
+#ifdef RES_X_NOST
+            asm volatile("" :: "v"(v), "v"(xo));         // (diagnostic builds: the fp32 stores are dropped)
+#else
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), x_rs, xo, 64u * cb, 0);
+#endif
           }
         }
       }
@@ -551,22 +581,31 @@ int res_raise(KernelT kern) {
   return 0;
 }
 
-template <int T, int EPI, int NK, int AM>
+template <int T, int EPI, int NK, int AM, bool STRIP = false>
 int res_pm_launch(const WidePmParams& P, dim3 grid, size_t lds, hipStream_t s) {
   if (P.K <= 256) {
-    auto kern = res_pm_kernel<T, EPI, NK, AM, true>;
+    auto kern = res_pm_kernel<T, EPI, NK, AM, true, STRIP>;
     if (int rc = res_raise(kern)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), lds, s, P);
   } else {
-    auto kern = res_pm_kernel<T, EPI, NK, AM, false>;
+    auto kern = res_pm_kernel<T, EPI, NK, AM, false, STRIP>;
     if (int rc = res_raise(kern)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), lds, s, P);
   }
   return 0;
 }
 
+bool res_strip(const WidePmParams& P) {
+  const char* e = getenv("SDF_RES_STRIP");              // A/B: 0 = fragment-shaped loads everywhere
+  if (e && e[0] == '0') return false;
+  return P.cv_Cin != 0 || (!P.a_tiled && !P.zsrc);
+}
+
 template <int T, int AM>
 int res_pm_launch_t(const WidePmParams& P, int epi, int nk, dim3 grid, size_t lds, hipStream_t s) {
+  // row-major operands through the full-line loads + LDS strip: patch merging always, the plain fp32 product (the decoders' stacked taps,
+  // fc2 on the parity tape's row-major spikes) where the rows are a plain tensor
+  if (epi == 2 && res_strip(P)) return res_pm_launch<T, 2, 0, AM, true>(P, grid, lds, s);
   if (epi == 2) return res_pm_launch<T, 2, 0, AM>(P, grid, lds, s);
   if constexpr (AM == 0) {
     if (epi == 1) return nk == 0 ? res_pm_launch<T, 1, 0, 0>(P, grid, lds, s) : (nk == 1 ? res_pm_launch<T, 1, 1, 0>(P, grid, lds, s) : res_pm_launch<T, 1, 2, 0>(P, grid, lds, s));
@@ -579,6 +618,7 @@ size_t res_pm_lds(int K, int epi, int T, int nk) {
   constexpr int SP = s_pitch(32);
   size_t b = (size_t)res_wbytes(K, 32) + ((epi & 1) ? NWV * 80 * SP : 0) + NWV * 80 * 4 + 32 * 16;
   if (nk == 1) b += PSN_TABLE(20) * 4;
+  if (epi == 2) b += NWV * RBW * 1024;                  // (the operand strips of the STRIP builds)
   (void)T;
   return b;
 }
@@ -589,7 +629,7 @@ size_t res_pm_lds(int K, int epi, int T, int nk) {
 bool res_pm_takes(const WidePmParams& P, int T, int epi) {
   if (res_env_off() || !P.res_stage) return false;
   if (T != 10 && T != 20) return false;
-  if (P.K % 16 || P.K < 32 || P.K > 768 || P.N % 32 || P.ksplit > 1 || epi < 1 || epi > 3) return false;
+  if (P.K % 16 || P.K < 32 || P.K > 1024 || P.N % 32 || P.ksplit > 1 || epi < 1 || epi > 3) return false;      // (K <= 1024: 96 KB of resident digits)
   if (P.cv_Cin && !(epi == 2 && P.cv_Cin % 16 == 0 && 4 * P.cv_Cin == P.K && !P.zsrc && !P.a_tiled)) return false;      // (patch merging)
   if (P.zsrc && P.K % 32) return false;
   return true;

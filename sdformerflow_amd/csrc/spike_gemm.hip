@@ -23,7 +23,7 @@
 //           t = slot % T), i.e. the recurrence runs in registers straight out of the MFMA accumulators and the
 //           fp32 pre-activation never touches HBM.  Spikes are staged through LDS to leave as 16-byte stores.
 // Compiled with -ffp-contract=off: the neuron arithmetic is the same separately-rounded op sequence as neuron.hip.
-#include "spike_mm.h"
+#include "wide_common.h"
 #include <stdlib.h>
 
 namespace {
@@ -459,6 +459,24 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
     GemmParams Q;
     Q.d = *d;
     return smallm_gemm_supports(Q) ? launch_smallm_gemm(Q, sdf_stream(stream)) : SDF_E_SHAPE;
+  }
+  if (d->nsplit == SDF_PLANES_I8X3) {
+    // row-major digit planes [3][N][K]: a plain product with the fp32 epilogue on the weight-resident row-loop kernel (ms_res.hip) - the
+    // stacked-tap products of the middle decoder levels (reference Spiking_modules.py:461-474 written as one GEMM + col2im): rows are
+    // walked as 10 "steps" x M / 10 "positions" (any order serves the fp32 form), the shortcut, if any, is the output buffer itself
+    if (!d->col_scale) return SDF_E_NULL;
+    if (d->alpha && !d->beta) return SDF_E_NULL;
+    if (spike || d->M % 10 || d->K % 16 || d->K > 1024 || d->lda != d->K || d->ldo < d->N || d->out_rowmap || d->add || d->zg_nH) return SDF_E_SHAPE;
+    if (d->resid && d->resid != d->out) return SDF_E_SHAPE;
+    if (d->M * (int64_t)d->K >= (1LL << 31) || d->M * (int64_t)d->ldo * 4 >= (1LL << 31) || (int64_t)d->N * d->K * 3 >= (1LL << 31)) return SDF_E_SHAPE;
+    if (!sdf_aligned(d->A, 16) || !sdf_aligned(d->Wp, 16) || !sdf_aligned(d->out, 16)) return SDF_E_ALIGN;
+    WidePmParams P = {};
+    P.A = d->A; P.W = reinterpret_cast<const int8_t*>(d->Wp); P.cscale = d->col_scale; P.N = d->N; P.K = d->K;
+    P.HW = (int)(d->M / 10); P.P = d->M / 10;
+    P.bias = d->bias; P.alpha = d->alpha; P.beta = d->beta; P.x = d->out; P.ldo = (int)d->ldo; P.no_resid = d->resid ? 0 : 1;
+    P.res_stage = 1;
+    if (!res_pm_takes(P, 10, 2)) return SDF_E_SHAPE;
+    return launch_res_pm(P, 10, 2, sdf_stream(stream));
   }
   if (d->nsplit < 1 || d->nsplit > 3) return SDF_E_DTYPE;         // 1 = bf16, 2 = fp16 hi/lo (scaled), 3 = bf16 hi/mid/lo
   if (!sdf_scale_ok(d)) return SDF_E_DTYPE;

@@ -182,8 +182,12 @@ def deconv_tap_weights(w, cin_pad, nsplit):
     wk = torch.zeros((9 * Cout, cin_pad), dtype=torch.float32, device=w.device)
     wk[:, :Cin] = w.detach().float().permute(2, 3, 1, 0).reshape(9 * Cout, Cin)
     planes = hip.split_weight(wk, nsplit)
-    if nsplit == 2 and cin_pad % 64 == 0:                    # (the small-M kernel's operand: the same matrix as int8 digits in fragment order)
-        planes.digits = hip.tile_weight_i8x3(hip.split_weight_i8x3(wk))
+    if nsplit == 2 and cin_pad % 16 == 0:
+        dg = hip.split_weight_i8x3(wk)
+        if cin_pad % 64 == 0 and cin_pad >= 1024:            # (the small-M kernel's operand: the same matrix as int8 digits in fragment order)
+            planes.digits = hip.tile_weight_i8x3(dg)
+        elif cin_pad <= 1024:                                # (row-major digits: the weight-resident row-loop kernel, csrc/ms_res.hip)
+            planes.digits_rm = dg
     return planes
 
 
@@ -709,6 +713,8 @@ class MSFlowEngine:
                 taps = self._deconv[key]
                 if getattr(taps, "digits", None) is not None and hip.smallm_gemm_applicable(B * D * h * w, 9 * cout, cp):
                     taps = taps.digits                        # few rows against many weights (level 0: 1 080 x 3 456 x 1 536): csrc/ms_smallm.hip
+                elif getattr(taps, "digits_rm", None) is not None and hip.res_gemm_applicable(B * D * h * w, 9 * cout, cp):
+                    taps = taps.digits_rm                     # the middle levels (4 320 x 1 728 x 800, 17 280 x 864 x 416): csrc/ms_res.hip
                 hip.spike_gemm(s, taps, Y, B * D * h * w, 9 * cout, cp)
                 hip.deconv_col2im(Y, B * D, h, w, cout, alpha=bn[0], beta=bn[1], out=z)
             # the conv kernel addresses its operands with 31-bit byte offsets: a larger z (config 5: 80 images of

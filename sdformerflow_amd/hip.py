@@ -429,6 +429,14 @@ def smallm_gemm_applicable(M, N, K):
     return M <= 64 * 80 and K >= (int(os.environ["SDF_SMALLM_MINK"]) if "SDF_SMALLM_MINK" in os.environ else 1024)
 
 
+def res_gemm_applicable(M, N, K):
+    """Mirror of the library's rule for the plain product on row-major digit planes (csrc/spike_gemm.hip -> ms_res.hip: whole-K digits
+    LDS-resident per 32 columns, row loop): rows in tens, K <= 1024 in steps of 16."""
+    if os.environ.get("SDF_RES", "") == "0" or os.environ.get("SDF_RES_GEMM", "") == "0":
+        return False
+    return M % 10 == 0 and N % 32 == 0 and K % 16 == 0 and 32 <= K <= 1024 and M * max(K, 4 * N) < 1 << 31
+
+
 def pack_conv_weight_i8x3(w, tiled=False):
     """Conv2d weight (Cout, Cin, KH, KW) fp32 -> int8 digit planes (3, Cout, KH*KW*Cin), K in (ky, kx, cin) order; `tiled`: in the
     fragment order of tile_weight_i8x3."""
@@ -455,10 +463,11 @@ def spike_gemm(A, Wp, out, M, N, K, lda=None, ldo=None, bias=None, alpha=None, b
     d.lda = K if lda is None else lda
     d.ldo = N if ldo is None else ldo
     d.nsplit, d.acc_scale = Wp.shape[0], _acc_scale(Wp)
-    if Wp.dtype == torch.int8:                                   # digit planes in fragment order (tile_weight_i8x3): the small-M kernel
-        if not getattr(Wp, "sdf_tiled", False):
-            raise SdfError("sdf_spike_gemm_fwd reads int8 digit planes in fragment order only (tile_weight_i8x3)")
-        d.nsplit, d.col_scale = PLANES_I8X3_TILED, _ptr(Wp.sdf_col_scale, torch.float32)
+    if Wp.dtype == torch.int8:
+        # digit planes: in fragment order (tile_weight_i8x3) the small-M kernel's operand, row-major (split_weight_i8x3) the
+        # weight-resident row-loop kernel's (csrc/ms_res.hip: K <= 1024, M % 10 == 0)
+        d.nsplit = PLANES_I8X3_TILED if getattr(Wp, "sdf_tiled", False) else PLANES_I8X3
+        d.col_scale = _ptr(Wp.sdf_col_scale, torch.float32)
     elif Wp.dtype != torch.int16:
         raise SdfError(f"weight planes must be int16 (16-bit float planes) or int8 (tiled digit planes), got {Wp.dtype}")
     d.bias, d.alpha, d.beta = _ptr(bias, torch.float32), _ptr(alpha, torch.float32), _ptr(beta, torch.float32)

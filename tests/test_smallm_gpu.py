@@ -139,6 +139,33 @@ def test_plain_product_with_fp32_epilogue(M, N, K, extras):
     assert (out - old).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("M,N,K,extras", [(17280, 864, 416, False), (4320, 1728, 800, True), (200, 64, 96, True), (10, 32, 32, False), (1230, 96, 1024, True)])
+def test_plain_product_on_row_major_digits(M, N, K, extras):
+    """`sdf_spike_gemm_fwd` with ROW-MAJOR digit planes (nsplit = SDF_PLANES_I8X3): the stacked-tap products of the middle decoder levels
+    (reference Spiking_modules.py:461-474 as one GEMM + col2im) on the weight-resident row-loop kernel (csrc/ms_res.hip: whole-K digits in
+    LDS, K % 64 != 0 included) - exact integer sums against fp64 to 1e-6 of the range, in place over a shortcut, and against the streaming
+    kernel on the fp16 planes of the same weights."""
+    assert hip.res_gemm_applicable(M, N, K)
+    A = spikes((M, K), 420 + N, 0.25)
+    Wt = rnd((N, K), 421, -0.07, 0.07)
+    dg = hip.split_weight_i8x3(Wt.to(DEV))
+    We = _weff(dg)
+    assert ((We - Wt.double()).abs().max(dim=1).values <= 2.0 ** -22 * Wt.abs().max(dim=1).values.double()).all()
+    ref = A.double() @ We.t()
+    kw, resid = {}, None
+    if extras:
+        alpha, beta, bias, resid = rnd((N,), 422, 0.5, 1.5), rnd((N,), 423, -0.2, 0.2), rnd((N,), 424, -0.1, 0.1), rnd((M, N), 425)
+        kw = dict(alpha=alpha.to(DEV), beta=beta.to(DEV), bias=bias.to(DEV))
+        ref = (ref + bias.double()) * alpha.double() + beta.double() + resid.double()
+    out = resid.to(DEV).clone() if extras else torch.full((M, N), float("nan"), device=DEV)
+    hip.spike_gemm(A.to(DEV), dg, out, M, N, K, resid=out if extras else None, **kw)
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
+    if K % 32 == 0:
+        old = torch.empty((M, N), device=DEV)
+        hip.spike_gemm(A.to(DEV), hip.split_weight(Wt.to(DEV), 2), old, M, N, K, resid=resid.to(DEV) if extras else None, **kw)
+        assert (out - old).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
 def test_plain_product_refuses_what_it_is_not_built_for():
     Wt = rnd((64, 128), 410, -0.1, 0.1)
     dg = hip.tile_weight_i8x3(hip.split_weight_i8x3(Wt.to(DEV)))
@@ -146,4 +173,4 @@ def test_plain_product_refuses_what_it_is_not_built_for():
     with pytest.raises(hip.SdfError):
         hip.spike_gemm(spikes((12, 128), 411).to(DEV), dg, out, 12, 64, 128)                 # M % 10 != 0
     with pytest.raises(hip.SdfError):
-        hip.spike_gemm(spikes((10, 128), 412).to(DEV), hip.split_weight_i8x3(Wt.to(DEV)), torch.empty((10, 64), device=DEV), 10, 64, 128)   # row-major digits
+        hip.spike_gemm(spikes((12, 128), 412).to(DEV), hip.split_weight_i8x3(Wt.to(DEV)), torch.empty((12, 64), device=DEV), 12, 64, 128)   # row-major digits: rows in tens
