@@ -646,6 +646,7 @@ int launch_res_pm(WidePmParams& P, int T, int epi, hipStream_t s) {
   int r = 1;
   while ((int64_t)P.ncg * ((units + 8 * r - 1) / (8 * r)) > 256) ++r;
   if (const char* e = getenv("SDF_RES_UPW")) { const int v = atoi(e); if (v >= 1 && v <= 4096) r = v; }     // tuning override: units per wave
+  if (const char* e = getenv("SDF_RES_RMUL")) { const int v = atoi(e); if (v >= 1 && v <= 16) r *= v; }       // tuning: fewer, longer-lived workgroups
   P.passes = 8 * r;                                       // units per row range
   P.nrg = (int)((units + P.passes - 1) / P.passes);
   const int64_t items = (int64_t)P.ncg * P.nrg;
@@ -679,6 +680,7 @@ int launch_res_front(WideFrontParams& P, bool keep, int nk, hipStream_t s) {
   int r = 1;
   while ((int64_t)P.nH * ((ntiles + 8 * r - 1) / (8 * r)) > 256) ++r;
   if (const char* e = getenv("SDF_RES_UPW")) { const int v = atoi(e); if (v >= 1 && v <= 4096) r = v; }
+  if (const char* e = getenv("SDF_RES_RMUL")) { const int v = atoi(e); if (v >= 1 && v <= 16) r *= v; }
   P.ntiles_per = 8 * r;
   P.nrg = (int)((ntiles + P.ntiles_per - 1) / P.ntiles_per);
   const int64_t items = (int64_t)P.nrg * P.nH;

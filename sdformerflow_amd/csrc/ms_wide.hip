@@ -822,23 +822,27 @@ bool wide_env_off() {
   return e && e[0] == '0';
 }
 // narrow stages (C <= 192: swin stages 0 - 1): the weight-resident row-loop kernels of ms_res.hip (SDF_RES=0: off - A/B)
-// Which stages take them is a measured choice (round 5, profiles/r5c_forward_sequence.txt): at C = 192 the block runs 72 us on them
-// against 103 us on the K-ring kernels; at C = 96 (K = one and a half steps) their int8-digit epilogue - three accumulator reads and
-// a recombination per output - outweighs 60 MFMAs per tile (112 us per block against 92 on qk_front + spike_gemm + ms_mlp_fused, whose
-// fp32 accumulators need neither), so by default they start above 96 channels; SDF_RES_MINC lowers that (tests, A/B).  The first patch
-// merging (C = 96, K = 384) runs on them either way: 18.6 against 33 us.
+// Which stages take them is a measured choice, and the measure is CHIP TIME, not latency: bench.py keeps three forwards in flight, so a
+// launch costs the headline (compute units held) x (duration).  Same box, alternating runs (round 5, profiles/r5o_routing_ab.txt,
+// tools/res_routing_ab.sh): round 4's kernels everywhere 705 - 707 samples/s; these kernels at stage 1 only 734 - 737; at stages 1 - 2
+// 751 - 759; at stages 1 - 3 756 - 761 (the default) - although at C = 384 / 768 a launch is no faster alone (proj 19 against 15 us: but on
+// 88 compute units instead of 168).  At C = 96 (stage 0, K = one and a half steps) the block is 112 us against 92 us on qk_front +
+// spike_gemm + ms_mlp_fused alone and equal in flight (754 - 758): it keeps round 3's kernels (lower latency); SDF_RES_MINC lowers the
+// bound (tests, A/B).  Units per wave beyond what fills the chip once (SDF_RES_RMUL = 2, 3) trade latency for nothing (753, 711 - 723).
 int res_minc() {
   if (const char* e = getenv("SDF_RES_MINC")) { const int v = atoi(e); if (v >= 32 && v <= 192) return v; }
   return 128;
 }
 int res_maxc() {                                         // (SDF_RES_MAXC: tuning override - K = C <= 768 fits the resident image)
   if (const char* e = getenv("SDF_RES_MAXC")) { const int v = atoi(e); if (v >= 32 && v <= 768) return v; }
-  return 192;
+  return 768;
 }
 bool res_stage_ok(int C, bool merge = false) {
   const char* e = getenv("SDF_RES");
   if ((e && e[0] == '0') || C < 64 || C % 32) return false;
-  if (merge) return C < 192;                             // (the merge of a 192-channel stage: K = 768, the K-ring kernel is faster - 16.5 vs 24.6 us)
+  // (the merge of a 192-channel stage, K = 768: 24.6 us on 88 compute units against 16.1 us on 168 with the K-ring kernel - slower alone,
+  //  less chip time with three forwards in flight; K = 4 C <= 1024 is what the resident image admits)
+  if (merge) return C <= 256;
   return C >= res_minc() && C <= res_maxc();
 }
 

@@ -27,11 +27,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(autouse=True)
-def _resident_kernels_from_64_channels(monkeypatch):
-    """The weight-resident kernels (csrc/ms_res.hip) serve C in 64..192; the dispatcher takes them from 128 channels on by default
-    (measured, ms_wide.hip: res_minc).  These tests are about the kernels: every narrow shape runs on them."""
+@pytest.fixture(autouse=True, params=["row-loop", "k-ring"])
+def _kernel_family(request, monkeypatch):
+    """Two kernel families serve these entry points: the weight-resident row-loop kernels (csrc/ms_res.hip: any K <= 1024 in steps of 16;
+    by default every stage from 128 channels on - a chip-time choice measured on the headline, profiles/r5o_routing_ab.txt) and the
+    K-ring kernels (csrc/ms_wide.hip: C >= 192 in steps of 64, and whatever the row loop refuses - fc2 of the stages with 4 C > 1024).
+    Every test runs on both: "row-loop" = from 64 channels on, "k-ring" = the row loop below 192 channels only."""
     monkeypatch.setenv("SDF_RES_MINC", "64")
+    if request.param == "k-ring":
+        monkeypatch.setenv("SDF_RES_MAXC", "191")
 
 
 class _L:
