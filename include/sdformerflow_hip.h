@@ -222,9 +222,12 @@ typedef struct SdfSpikeGemmDesc {
   /* With out_rowmap: number of rows of out / resid (an upper bound of the scattered row indices + 1); 0 = unknown.
    * Lets the library pick kernels that address the output with 32-bit offsets. */
   int64_t out_rows;
-  /* nsplit == SDF_PLANES_I8X3 only (sdf_spike_conv2d_fwd, 3x3 / stride 1 / Cin 96 launches the weight-resident kernel takes):
-   * Wp is then int8_t[3][N][K] digit planes and col_scale[n] the power-of-two scale of output channel n, both made by
-   * sdf_split_weight_i8x3: w[n][k] = (d2*65536 + d1*256 + d0) * col_scale[n].  NULL otherwise. */
+  /* nsplit == SDF_PLANES_I8X3 only: Wp is then int8_t[3][N][K] digit planes and col_scale[n] the power-of-two scale of output channel
+   * n, both made by sdf_split_weight_i8x3: w[n][k] = (d2*65536 + d1*256 + d0) * col_scale[n].  NULL otherwise.  Taken by
+   * sdf_spike_conv2d_fwd (3x3 / stride 1 / Cin 96 launches of the weight-resident convolution; the small-M convolution) and, since
+   * round 5, by sdf_spike_gemm_fwd itself: a plain product with the fp32 epilogue (bias, alpha / beta, resid == out or NULL) on the
+   * weight-resident row-loop kernel (csrc/ms_res.hip) for M % 10 == 0, K % 16 == 0, K <= 1024, lda == K - the stacked-tap products
+   * of the middle decoder levels (reference Spiking_modules.py:461-474 as one product + sdf_deconv_col2im_fwd); SDF_E_SHAPE otherwise. */
   const float* col_scale;
 } SdfSpikeGemmDesc;
 
@@ -311,14 +314,16 @@ typedef struct SdfQkAttnDesc {
   void* workspace;      int64_t workspace_bytes;
   void* gemm_workspace; int64_t gemm_workspace_bytes;
   int32_t flags;        /* SDF_QK_* bits */
-  /* Wide stages (C >= 192 in steps of 64, T' = 2, LIF / IF neurons, digit planes given - see below; csrc/ms_wide.hip): with x_src set the call is THREE launches -
+  /* Digit-plane stages (T' = 2, LIF / IF / PSN neurons, digit planes given - see below; round 5: csrc/ms_res.hip - whole-K weights LDS-resident, a
+   * row loop per workgroup - for C in 64..768 in steps of 32 wherever K <= 1024, by default from 128 channels on; csrc/ms_wide.hip for C >= 192 in
+   * steps of 64 beside it): with x_src set the call is THREE launches -
    * slice neuron, one kernel for q | k + BN + neurons + token gate, and the projection as a "position-major" product whose waves own
    * all xD time steps of a few positions of the (xB, xD, xHW, C) buffer x (xB * xD * xHW == x_rows):
    *   x_src   : int32 per row of x, made by sdf_window_zsrc_map from slice_map (where that row's gated spikes start in E); NULL = the
    *             general kernels above
    *   emit_s1 : optional u8 [x_rows][C]: receives SN_emit( x after the update ) over the xD steps of every position - the first
    *             neuron of the MLP that follows (reference Spiking_swin_transformer3D.py:168; hand it to SdfMsMlpDesc.s1_in), so the
-   *             updated x is not read again; emit_sn = that neuron (LIF / IF).  Layout: the wide kernels' TILED hand-over form
+   *             updated x is not read again; emit_sn = that neuron (LIF / IF / PSN with its T = xD matrix).  Layout: the TILED hand-over form
    *             ([80-row unit][C / 16][row][16 B], (x_rows + 80) * C bytes) - opaque to the caller - unless SDF_QK_KEEP_SPIKES is
    *             set: then plain row-major [x_rows][C] (the parity tape). */
   const int32_t* x_src;
@@ -369,7 +374,8 @@ typedef struct SdfMsMlpDesc {
   void* workspace;      int64_t workspace_bytes;
   void* gemm_workspace; int64_t gemm_workspace_bytes;
   int32_t flags;        /* SDF_MLP_* bits */
-  /* Wide stages (C >= 192 in steps of 64, LIF / IF, digit planes given - see below, D in {10, 20}; csrc/ms_wide.hip): fc1 + BN1 + SN2 and fc2 + BN2 + shortcut as two
+  /* Digit-plane stages (C >= 64 in steps of 32 up to 192 and Ch <= 768 - csrc/ms_res.hip - or C >= 192 in steps of 64; LIF / IF / PSN, digit planes
+   * given - see below, D in {10, 20}; by default taken from 128 channels on): fc1 + BN1 + SN2 and fc2 + BN2 + shortcut as two
    * position-major launches.  s1_in != NULL: the SN1 spikes are already at the head of `workspace` (written there by
    * SdfQkAttnDesc.emit_s1 == workspace; tiled, or row-major when both calls carry their KEEP_SPIKES flag): no neuron launch, x is
    * only read by the last launch's shortcut.  Without SDF_MLP_KEEP_SPIKES the hidden spikes travel in the tiled form too. */
@@ -407,8 +413,8 @@ int sdf_ms_mlp_is_wide(const SdfMsMlpDesc* d);
  * planes, out (B, D, ceil(H/2), ceil(W/2), N) fp32 (odd sizes read zero spikes, the reference's F.pad in front of the neuron).  Replaces MS_SpikingPatchMerging.forward behind its neuron (reference
  * Spiking_swin_transformer3D.py:965-972: the four strided slices, the concatenation along channels in quadrant order
  * (dh, dw) = (q % 2, q / 2), sj_layer.Linear, the BatchNorm) - the concatenation is index arithmetic in the operand loads of the
- * wide-stage main loop (csrc/ms_wide.hip), nothing is materialised.  C % 64 == 0, N % 32 == 0, D in {10, 20}, at most
- * 32 000 output rows; SDF_E_SHAPE otherwise (the caller keeps its gather map + sdf_spike_gemm_fwd). */
+ * digit main loops (csrc/ms_res.hip for C <= 256 in steps of 32: any row count; csrc/ms_wide.hip for C % 64 == 0: at most 32 000 output
+ * rows), nothing is materialised.  N % 32 == 0, D in {10, 20}; SDF_E_SHAPE otherwise (the caller keeps its gather map + sdf_spike_gemm_fwd). */
 typedef struct SdfMsMergeDesc {
   const uint8_t* spikes;
   const int8_t* digits; const float* cscale;   /* sdf_split_weight_i8x3 of the (N, 4C) reduction weight */
