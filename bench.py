@@ -34,15 +34,16 @@ PEAK_BF16_DENSE_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: ~2
 PEAK_HBM_GBPS = 8000.0              # same guide: 8.0 TB/s spec (6.3 TB/s achievable)
 # HBM bytes per launch of the roofline shape from the PMC counters.  They cannot be read inside this process (rocprofv3 owns the
 # counters), so the figure is the one measured by tools/pmc_traffic.sh on the build named in CONV_TRAFFIC_SOURCE
-# (round 3: profiles/r3r_pmc_conv_mapping.txt, the shipped three-group kernel; both epilogue forms, since `roofline` averages over them)
-CONV_TRAFFIC_KIB = {"membrane_and_spikes": (68120.9, 130273.0), "spikes_only": (15407.2, 25879.0)}    # (FETCH_SIZE, WRITE_SIZE) KiB / launch
+# (round 5: profiles/r5u_pmc_conv_mapping.txt, re-measured on this round's tree; both epilogue forms, since `roofline` averages over them)
+CONV_TRAFFIC_KIB = {"membrane_and_spikes": (68172.0, 133.6e6 / 1024), "spikes_only": (15397.2, 26.5e6 / 1024)}    # (FETCH_SIZE, WRITE_SIZE) KiB / launch
 CONV_TRAFFIC_BYTES = sum(2 * f + w for f, w in CONV_TRAFFIC_KIB.values()) / 2 * 1024                 # FETCH_SIZE x 2: gfx950 correction
 CONV_ALGORITHMIC_BYTES = {"membrane_and_spikes": 10 * 144 * 192 * 96 * (1 + 4 + 4 + 1) + 3 * 96 * 864,
                           "spikes_only": 10 * 144 * 192 * 96 * (1 + 1) + 3 * 96 * 864}
-CONV_TRAFFIC_SOURCE = ("NOT measured in this run (rocprofv3 owns the counters): profiles/r3r_pmc_conv_mapping.txt (tools/pmc_conv_ab.sh: "
-                       "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes on this exact launch, gfx950 x2 read "
-                       "correction, KiB = 1024 B): membrane + spikes form 139.5 MB read + 133.4 MB written against 265.7 MB algorithmic "
-                       "(1.03x), spikes-only form 31.6 + 26.5 MB against 53.4 MB (1.09x).  The three workgroups that serve the column blocks "
+CONV_TRAFFIC_SOURCE = ("NOT measured in this run (rocprofv3 owns the counters): profiles/r5u_pmc_conv_mapping.txt (tools/pmc_conv_ab.sh on the "
+                       "round-5 tree: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes on this exact launch, gfx950 x2 read "
+                       "correction, KiB = 1024 B): membrane + spikes form 139.6 MB read + 133.6 MB written against 265.7 MB algorithmic "
+                       "(1.03x), spikes-only form 31.5 + 26.5 MB against 53.4 MB (1.09x); the four launches inside one forward: 341.6 MB read + "
+                       "320.9 MB written (profiles/r5q_pmc_forward.txt) = 165.6 MB per launch.  The three workgroups that serve the column blocks "
                        "of a tile range now sit on one XCD and walk it side by side (the spike image leaves HBM once; round 2's column-block-"
                        "major ranges read it 3x: 196.9 / 88.7 MB, same file); `traffic` is the mean of the two forms, as `achieved` is the "
                        "mean over the forward's two launches of each form")
@@ -144,14 +145,14 @@ def time_dominant_kernels(model, iters=40):
             "traffic": CONV_TRAFFIC_BYTES if digits else None, "traffic_unit": "bytes per launch (HBM read + write), mean of the two forms",
             "traffic_over_algorithmic": CONV_TRAFFIC_BYTES / (sum(CONV_ALGORITHMIC_BYTES.values()) / 2) if digits else None,
             "traffic_source": CONV_TRAFFIC_SOURCE,
-            "pmc": "profiles/r4e_pmc_forward.txt (the four launches inside one forward of the round-4 tree: 6.1 VALU per MFMA, pipe busy 39.5 %, LDS conflicts 5.9 %), r3s_pmc_forward.txt and r3i_pmc_kernels_after_operand_swap.txt: 683 MFMA "
+            "pmc": "profiles/r5q_pmc_forward.txt (the four launches inside one forward of the round-5 tree: 5.7 VALU per MFMA, pipe busy 40.0 %, LDS conflicts 5.9 %), r4e_pmc_forward.txt, r3s_pmc_forward.txt and r3i_pmc_kernels_after_operand_swap.txt: 683 MFMA "
                    "and ~4 000 VALU instructions per wave (6 VALU per MFMA; 8.2 before the weights became the MFMA's row operand, "
                    "r3g_pmc_kernels.txt), SQ_VALU_MFMA_BUSY_CYCLES = 39 % of the kernel's cycles per SIMD at an effective 2.2 GHz, LDS bank "
                    "conflicts 6 % of LDS cycles: the kernel is bound by its epilogue's vector instructions, not by the matrix pipe",
             "note": "algorithmic flops (2 per multiply-add of the convolution) against the dense bf16/f16 MFMA peak.  The kernel issues "
                     + ("3 int8 digit MFMAs (v_mfma_i32_32x32x32_i8, K = 32 in the cycles the 16-bit form needs for K = 16) per product: 1.5x "
                        "the algorithmic work on the 16-bit pipe's scale" if digits else f"{ns} 16-bit MFMAs per product") +
-                    "; the matrix pipe is busy 39 % of the kernel's cycles (PMC, profiles/r4e_pmc_forward.txt)"}
+                    "; the matrix pipe is busy 40 % of the kernel's cycles (PMC, profiles/r5q_pmc_forward.txt)"}
     gemm["frac"] = gemm["achieved"] / gemm["peak"]
     gemm["frac_of_issued_mfma"] = issued * gemm["frac"]
     # neuron: T=10 over the stage-0 MLP hidden tensor shape (10 x 72*96*384 fp32 in, u8 out)

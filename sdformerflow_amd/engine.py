@@ -44,12 +44,13 @@ def bn_affine(bn, device):
 class _Lin:
     """A Linear fed by spikes: bf16 weight planes + optional bias + the BN that follows it."""
 
-    def __init__(self, linear, bn, device, nsplit):
+    def __init__(self, linear, bn, device, nsplit, digits=True):
         w = linear.weight.detach().float().to(device).contiguous()
         self.N, self.K = w.shape
         self.Wp = hip.split_weight(w, nsplit)
         # wide layers (swin stages 1 - 3) also carry int8 digit planes: what csrc/ms_wide.hip multiplies by (default plane mode only)
-        self.digits = hip.split_weight_i8x3(w) if nsplit == 2 and self.K >= _WIDE_MINC and self.K % 32 == 0 and self.N % 32 == 0 else None
+        # (`digits=False`: callers whose layer never reaches a digit kernel - the SEW family's fc2 - skip the extra 3 bytes per weight, ADVICE r4)
+        self.digits = hip.split_weight_i8x3(w) if digits and nsplit == 2 and self.K >= _WIDE_MINC and self.K % 32 == 0 and self.N % 32 == 0 else None
         self.bias = None if linear.bias is None else linear.bias.detach().float().to(device).contiguous()
         self.alpha, self.beta = bn_affine(bn, device) if bn is not None else (None, None)
 
@@ -311,9 +312,16 @@ class MSFlowEngine:
             # workgroup, sum + BN + shortcut + neuron in its epilogue (csrc/ms_smallm.hip)
             out = None if sn is not None and not membrane else torch.empty((B, D, oh, ow, Cout), dtype=torch.float32, device=s.device)
             sp = torch.empty((B, D, oh, ow, Cout), dtype=torch.uint8, device=s.device) if sn is not None else None
-            hip.spike_conv2d(s, digits, B * D, h, w, Cin, oh, ow, 3, 3, stride, (-1, 0, 1), (-1, 0, 1), out=out, out_spike=sp, alpha=a, beta=b,
-                             resid=resid if (membrane or sn is None) else None, sn=sn, sn_T=D if sn is not None else 0, pos=(B * oh * ow, oh * ow, D * oh * ow, oh * ow))
-            return sp if sn is not None and not membrane else ((out, sp) if sn is not None else out)
+            try:
+                hip.spike_conv2d(s, digits, B * D, h, w, Cin, oh, ow, 3, 3, stride, (-1, 0, 1), (-1, 0, 1), out=out, out_spike=sp, alpha=a, beta=b,
+                                 resid=resid if (membrane or sn is None) else None, sn=sn, sn_T=D if sn is not None else 0,
+                                 pos=(B * oh * ow, oh * ow, D * oh * ow, oh * ow))
+                return sp if sn is not None and not membrane else ((out, sp) if sn is not None else out)
+            except hip.SdfError as e:
+                # the Python mirror `smallm_conv_applicable` admits a shape the library's own rule refuses (alignment, 31-bit sizes, an
+                # unusual tau: ADVICE r4): the 16-bit planes are still here - the general path below serves it
+                if "argument error -2" not in str(e):
+                    raise
         if digits is not None and B > 1 and not hip.conv_wres_applicable(B * D, h, w, Cin, Cout, stride, 1):
             # too large for the digit kernel's 31-bit operand offsets as one launch (configs[4]: 80 images of 240 x 320 x 96 fp32):
             # batch elements are independent - the largest batch chunk that fits runs per launch, writing into its slice of the outputs

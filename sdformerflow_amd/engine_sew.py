@@ -45,7 +45,7 @@ class _SewBlock:
         self.proj_bn, self.proj_sn = bn_affine(a.proj_bn.norm_layer, device), _np(a.proj_sn, device)
         self.w1 = hip.pack_dense_linear_weight(m.fc1.weight.detach().float().to(device))
         self.bn1, self.sn1 = bn_affine(m.bn1.norm_layer, device), _np(m.sn1, device)
-        self.fc2 = _Lin(m.fc2, m.bn2.norm_layer, device, nsplit)                 # fc2 reads spikes: the spike GEMM
+        self.fc2 = _Lin(m.fc2, m.bn2.norm_layer, device, nsplit, digits=False)   # fc2 reads spikes: the spike GEMM (fp16 planes only)
         self.sn2 = _np(m.sn2, device)
         self._bias = {}
 
