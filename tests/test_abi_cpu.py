@@ -116,8 +116,10 @@ def test_argument_errors_are_reported_before_any_launch():
     assert lib.sdf_ms_mlp_is_wide(C.byref(m)) == 0
     m.flags, m.nsplit = 0, 3
     assert lib.sdf_ms_mlp_is_wide(C.byref(m)) == 0              # the exact three-plane mode keeps the general kernels
-    m.nsplit, m.C, m.Ch = 2, 96, 384
-    assert lib.sdf_ms_mlp_is_wide(C.byref(m)) == 1              # round 5: the narrow stages (C <= 192) run on digit planes too (csrc/ms_res.hip)
+    m.nsplit, m.C, m.Ch = 2, 192, 768
+    assert lib.sdf_ms_mlp_is_wide(C.byref(m)) == 1              # round 5: stage 1 (C = 192) runs on digit planes too (csrc/ms_res.hip)
+    m.C, m.Ch = 96, 384
+    assert lib.sdf_ms_mlp_is_wide(C.byref(m)) == 0              # stage 0 keeps the general kernels by default (SDF_RES_MINC = 128)
     m.C, m.Ch, m.s1_in = 224, 896, 0x10000                      # (neither a narrow nor a wide stage: C > 192, C % 64 != 0)
     assert lib.sdf_ms_mlp_is_wide(C.byref(m)) == 0
     assert lib.sdf_ms_mlp_fwd(C.byref(m), None) == E_SHAPE      # s1_in is a digit-plane-stage input
