@@ -418,25 +418,55 @@ __device__ __forceinline__ void qt4(float& a0, float& a1, float& a2, float& a3, 
   a1 = o2 ? r : a1; a3 = o2 ? a3 : r;
 }
 
-template <int CIN16, int RB>
+template <int CIN16, int RB, bool S2>
 struct GeoI8 {
-  static constexpr int TH8 = 8 * RB, TW8 = 16, HH8 = TH8 + 2, HW8 = 18;   // RB row blocks of 32 pixels per wave
+  // stride 1: RB row blocks of 32 pixels per wave, halo (8 RB + 2) x 18 pixels.  Stride 2 (S2, RB = 1): the 8 x 16 output pixels of a
+  // tile read a 17 x 33 halo whose EVEN and ODD columns are kept as two planes of a halo row - tap kx of output pixel x is halo column
+  // 2 x + kx = plane kx & 1, entry x + (kx >> 1), so that the 16 lanes of a fragment read stay PS bytes apart (one plane, neighbouring
+  // entries) and conflict-free as at stride 1; interleaved they would be 2 PS apart and meet two to a bank quad
+  static constexpr int TH8 = 8 * RB, TW8 = 16, HH8 = S2 ? 2 * TH8 + 1 : TH8 + 2, HW8 = S2 ? 2 * TW8 + 1 : TW8 + 2;
   static constexpr int CIN = 16 * CIN16;
   static constexpr int K = 9 * CIN;
-  static constexpr int PS = CIN + 16;                                 // pixel stride: 4 x odd dwords (16-byte fragment reads)
-  static constexpr int RPB = (HW8 * PS + 255) / 256 * 256;            // halo row pitch: a whole number of bank rounds
+  static constexpr int NP = 9 * CIN16;                                // 16-byte pieces of a weight row
+  static constexpr int KS = (NP + 1) / 2;                             // K steps of 32 (two pieces: one per half wave); odd NP: one zero piece
+  static constexpr int PS = (S2 && CIN16 % 2) ? CIN : CIN + 16;       // pixel stride: 4 x odd dwords (16-byte fragment reads)
+  static constexpr int XE = (HW8 + 1) / 2;                            // S2: entries of the even-column plane
+  static constexpr int RPB = S2 ? HW8 * PS : (HW8 * PS + 255) / 256 * 256;   // halo row pitch (stride 1: a whole number of bank rounds)
   static constexpr int HALO = HH8 * RPB;
-  static constexpr int WP = K + 16;                                   // digit-plane row pitch (bytes): 4 x odd dwords
-  static constexpr int RCH = HW8 * CIN16;                             // 16-byte pieces of a halo row (108): one per lane of a half group
+  static constexpr int WP = 32 * KS + 16;                             // digit-plane row pitch (bytes): 4 x odd dwords
+  static constexpr int RCH = HW8 * CIN16;                             // 16-byte pieces of a halo row: one per lane of a half group
   static constexpr int CPL = (HH8 + 1) / 2;                           // pieces per lane: two halo rows per pass of the group's 256 lanes
   static_assert(RCH <= 128, "a halo row must fit the 128 lanes of a half group");
   static_assert((PS / 4) % 8 == 4 && (WP / 4) % 8 == 4, "pitches must be 4 x odd dwords");
-  static_assert(CIN % 32 == 0, "K steps of 32 must not straddle taps");
+  static_assert(S2 || CIN % 32 == 0, "stride 1: K steps of 32 must not straddle taps");
+  static_assert(!S2 || RB == 1, "stride 2: one row block per wave");
+  // S2: the K order of the LDS weight image is chosen so that the two 16-byte pieces of a K step (lower / upper half wave) sit a
+  // CONSTANT distance apart in the halo image - the half wave's share is folded into one of three lane bases, every step's offset is
+  // an immediate and the main loop has no address arithmetic at all (the kernel's K order is free: integer sums are exact):
+  //   steps [0, 3n):   taps (ky, 0) | (ky, 2), piece c      - even plane, entries x and x + 1:   PS apart      (n = CIN16)
+  //   steps [3n, 4n):  taps (0, 1) | (1, 1), piece c        - odd plane, rows y and y + 1:       RPB apart
+  //   steps [4n, KS):  tap (2, 1), pieces 2j | 2j + 1       - neighbours:                         16 apart (odd n: the last one is zero)
+  static constexpr int step_off(int ks) {                             // halo offset of the lower half wave's piece of step ks
+    constexpr int n = CIN16;
+    if (ks < 3 * n) return (ks / n) * RPB + (ks % n) * 16;
+    if (ks < 4 * n) return XE * PS + (ks - 3 * n) * 16;
+    return 2 * RPB + XE * PS + (ks - 4 * n) * 32;
+  }
+  static constexpr int step_base(int ks) { return ks < 3 * CIN16 ? 0 : (ks < 4 * CIN16 ? 1 : 2); }   // which lane base
+  // LDS slot (16-byte pieces from the row start) of piece kc = tap * n + c of a weight row as sdf_split_weight_i8x3 left it
+  static __device__ __forceinline__ int slot(int kc) {
+    constexpr int n = CIN16;
+    const int tap = kc / n, c = kc - tap * n, ky = tap / 3, kx = tap - 3 * ky;
+    if (kx != 1) return 2 * (ky * n + c) + (kx >> 1);
+    if (ky < 2) return 2 * (3 * n + c) + ky;
+    return 2 * 4 * n + c;
+  }
 };
 
-template <int TT, int CIN16, int RB, int NGRP>
+template <int TT, int CIN16, int RB, int NGRP, bool S2 = false>
 __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmParams P, const float* __restrict__ col_scale) {
-  using G = GeoI8<CIN16, RB>;
+  using G = GeoI8<CIN16, RB, S2>;
+  constexpr int ST = S2 ? 2 : 1;
   constexpr bool SPIKE = TT > 0;
   const int T = SPIKE ? P.d.sn_T : 1;             // the time loop is rolled: TT > 0 selects the fused form, its length comes with the call (5 / 10 / 20)
   constexpr int CIN = G::CIN, K = G::K, PS = G::PS, RPB = G::RPB, WP = G::WP, TH8 = G::TH8, TW8 = G::TW8;
@@ -450,13 +480,14 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
   uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + W_BYTES + NGRP * G::HALO + PAR);   // [g]: halo written, [NGRP + g]: halo read
 
   const SdfSpikeGemmDesc& d = P.d;
-  const int H = P.cv.H, W = P.cv.W;
+  const int H = P.cv.OH, W = P.cv.OW;                                 // the output image (== the input image at stride 1)
+  const int Hin = P.cv.H, Win = P.cv.W;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int grp = wave >> 2, cw = wave & 3;
   const int gl = tid & 255;
   const int N = d.N;
-  const bool has_res = d.resid != nullptr;
+  const bool has_res = !(S2 && SPIKE) && d.resid != nullptr;           // (stride 2 + fused neuron: no shortcut form - registers)
   const bool memb = !SPIKE || d.out != nullptr;
   const int ohw = H * W;
   const int pm = SPIKE ? (int)(d.pos_inner / ohw) : 1, pso = SPIKE ? (int)(d.pos_ostride / ohw) : 0;
@@ -491,18 +522,18 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
   const int hhalf = gl >> 7, hj = gl & 127;
   const bool hj_ok = hj < G::RCH;
   const int hpx = (hj_ok ? hj : 0) / CIN16, hc16 = (hj_ok ? hj : 0) - hpx * CIN16;
-  const uint32_t h_lds0 = (uint32_t)(hhalf * RPB + hpx * PS + hc16 * 16);
-  const int h_rel0 = ((hhalf - 1) * W + (hpx - 1)) * CIN + hc16 * 16;
+  const uint32_t h_lds0 = (uint32_t)(hhalf * RPB + (S2 ? (hpx & 1) * G::XE * PS + (hpx >> 1) * PS : hpx * PS) + hc16 * 16);
+  const int h_rel0 = ((hhalf - 1) * Win + (hpx - 1)) * CIN + hc16 * 16;
   const __amdgpu_buffer_rsrc_t A_rs = make_rsrc(d.A);
   u32x4 hreg[G::CPL];
-  auto halo_load = [&](int img, int y0, int x0) __attribute__((always_inline)) {
-    const uint32_t org = (uint32_t)(((img * H + y0) * W + x0) * CIN) + (uint32_t)h_rel0;
-    const bool xok = hj_ok && (unsigned)(x0 + hpx - 1) < (unsigned)W;
+  auto halo_load = [&](int img, int y0, int x0) __attribute__((always_inline)) {          // (y0, x0): the tile's first OUTPUT pixel
+    const uint32_t org = (uint32_t)(((img * Hin + ST * y0) * Win + ST * x0) * CIN) + (uint32_t)h_rel0;
+    const bool xok = hj_ok && (unsigned)(ST * x0 + hpx - 1) < (unsigned)Win;
 #pragma unroll
     for (int i = 0; i < G::CPL; ++i) {
       const int hy = 2 * i + hhalf;
-      const bool ok = xok && hy < G::HH8 && (unsigned)(y0 + hy - 1) < (unsigned)H;
-      hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(A_rs, ok ? org + (uint32_t)(2 * i * W * CIN) : INV, 0, 0);
+      const bool ok = xok && hy < G::HH8 && (unsigned)(ST * y0 + hy - 1) < (unsigned)Hin;
+      hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(A_rs, ok ? org + (uint32_t)(2 * i * Win * CIN) : INV, 0, 0);
     }
   };
   uint8_t* H_s = smem + W_BYTES + grp * G::HALO;
@@ -522,7 +553,9 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
   int ln = lane;
   asm volatile("" : "+v"(ln));
   const int l31 = ln & 31, lh = ln >> 5;
-  const uint32_t a_lane = (uint32_t)((2 * RB * cw + (l31 >> 4)) * RPB + (l31 & 15) * PS + 16 * lh);      // + 2*rb rows
+  const uint32_t a_lane = S2 ? (uint32_t)(2 * (2 * cw + (l31 >> 4)) * RPB + (l31 & 15) * PS)            // (+ the half wave's share: a_base)
+                              : (uint32_t)((2 * RB * cw + (l31 >> 4)) * RPB + (l31 & 15) * PS + 16 * lh);      // + 2*rb rows
+  const uint32_t a_base[3] = {a_lane + (uint32_t)(lh * PS), a_lane + (uint32_t)(lh * RPB), a_lane + (uint32_t)(lh * 16)};   // S2 (GeoI8::step_off)
   const uint32_t w_lane = (uint32_t)(l31 * WP + 16 * lh);
   // The WEIGHT digits are the MFMA's row operand and the pixels its column operand: the accumulator then holds, per lane, pixel
   // l31 of the row block and in registers 4 q4 .. 4 q4 + 3 the four CONSECUTIVE channels n0 + 8 q4 + 4 lh + 0..3 - one 16-byte
@@ -549,12 +582,14 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
       constexpr int WCH = 3 * NB * KC16;
       const __amdgpu_buffer_rsrc_t W_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(d.Wp), 0, 3 * N * K, 0x00020000);
       constexpr int WB = 6, NBATCH = (WCH + NT * WB - 1) / (NT * WB);
+      int tl = tid;                                                    // (laundered: the piece indices below are loop-invariant and would be
+      asm volatile("" : "+v"(tl));                                    //  kept in registers across the whole kernel otherwise - 65 spills at S2)
 #pragma unroll 1
       for (int b = 0; b < NBATCH; ++b) {
         u32x4 wv[WB];
 #pragma unroll
         for (int i = 0; i < WB; ++i) {
-          const int c = tid + NT * (b * WB + i);
+          const int c = tl + NT * (b * WB + i);
           const int cc = c < WCH ? c : 0;
           const int row = cc / KC16, kc = cc - row * KC16;             // row = digit * 32 + n
           const int dg = row / NB, n = row - dg * NB;
@@ -562,11 +597,15 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
         }
 #pragma unroll
         for (int i = 0; i < WB; ++i) {
-          const int c = tid + NT * (b * WB + i);
+          const int c = tl + NT * (b * WB + i);
           const int cc = c < WCH ? c : 0;
           const int row = cc / KC16, kc = cc - row * KC16;
-          if (c < WCH) *reinterpret_cast<u32x4*>(W_s + row * WP + kc * 16) = wv[i];
+          if (c < WCH) *reinterpret_cast<u32x4*>(W_s + row * WP + (S2 ? G::slot(kc) : kc) * 16) = wv[i];
         }
+      }
+      if (S2 && (G::NP & 1) && tid < 3 * NB) {                         // an odd number of pieces: the last K step's upper half is zero
+        u32x4 z; z.x = z.y = z.z = z.w = 0u;
+        *reinterpret_cast<u32x4*>(W_s + tid * WP + G::NP * 16) = z;
       }
       // BN folded with the channel's digit scale: fma(D * s, alpha, beta) == fma(D, s * alpha, beta) exactly (s is a power of two)
       if (tid < 2 * NB) {
@@ -636,19 +675,23 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
           for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[dg][rb][e] = 0;
-        constexpr int KS = 9 * (CIN / 32);
+        constexpr int KS = G::KS;
         constexpr int PF = (RB == 1 && NGRP == 2) ? 2 : 1;              // three groups live on 168 registers
         i32x4 fa[PF + 1][RB], fb[PF + 1][3];
         auto frag = [&](int ks, int set) __attribute__((always_inline)) {
-          constexpr int C32 = CIN / 32;
-          const int tap = ks / C32, c = ks - tap * C32;
-          const int ky = tap / 3, kx = tap - 3 * ky;
+          if constexpr (S2) {
+            fa[set][0] = *reinterpret_cast<const i32x4*>(H_s + a_base[G::step_base(ks)] + G::step_off(ks));
+          } else {
+            constexpr int C32 = CIN / 32;
+            const int tap = ks / C32, c = ks - tap * C32;
+            const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
-          for (int rb = 0; rb < RB; ++rb)
-            fa[set][rb] = *reinterpret_cast<const i32x4*>(H_s + a_lane + ((2 * rb + ky) * RPB + kx * PS + c * 32));
+            for (int rb = 0; rb < RB; ++rb)
+              fa[set][rb] = *reinterpret_cast<const i32x4*>(H_s + a_lane + ((2 * rb + ky) * RPB + kx * PS + c * 32));
+          }
 #pragma unroll
           for (int dg = 0; dg < 3; ++dg)
-            fb[set][dg] = *reinterpret_cast<const i32x4*>(W_s + w_lane + (dg * NB * WP + tap * CIN + c * 32));
+            fb[set][dg] = *reinterpret_cast<const i32x4*>(W_s + w_lane + (dg * NB * WP + ks * 32));
         };
 #pragma unroll
         for (int i = 0; i < PF; ++i) frag(i, i);
@@ -790,7 +833,12 @@ int launch_c(const GemmParams& P, dim3 grid, hipStream_t s) {
 bool spike_conv_wres_supports(const GemmParams& P, bool any_size) {
   const SdfSpikeGemmDesc& d = P.d;
   const ConvGeom& c = P.cv;
-  if (c.Cin != 96 || c.KWc != 3 || d.K != 9 * c.Cin || c.sy != 1 || c.sx != 1 || c.H != c.OH || c.W != c.OW) return false;
+  // 96 channels at stride 1 (every form), or - digit planes only - 48 channels at stride 2 (the patch embedding's first 3x3: halo
+  // tiles with the even / odd columns as two planes, GeoI8<.., S2>)
+  const bool s1 = c.Cin == 96 && c.sy == 1 && c.sx == 1 && c.H == c.OH && c.W == c.OW;
+  const bool s2 = c.Cin == 48 && c.sy == 2 && c.sx == 2 && c.OH == (c.H - 1) / 2 + 1 && c.OW == (c.W - 1) / 2 + 1 &&
+                  d.nsplit == SDF_PLANES_I8X3 && !(d.sn_T > 0 && d.resid);
+  if ((!s1 && !s2) || c.KWc != 3 || d.K != 9 * c.Cin) return false;
   if (c.dy[0] != -1 || c.dy[1] != 0 || c.dy[2] != 1 || c.dx[0] != -1 || c.dx[1] != 0 || c.dx[2] != 1) return false;
   if (d.N % NB || (d.nsplit != 1 && d.nsplit != 2 && d.nsplit != SDF_PLANES_I8X3) || d.out_rowmap || d.add || d.zg_nH > 0) return false;
   if (d.nsplit == SDF_PLANES_I8X3 && (!d.col_scale || d.bias)) return false;
@@ -823,7 +871,7 @@ int launch_spike_conv_wres(const GemmParams& Pin, hipStream_t s) {
   if (d.nsplit == SDF_PLANES_I8X3) {
     const int64_t items16 = (imgs / T) * ((c.OH + 15) / 16) * ((c.OW + TW - 1) / TW) * (d.N / NB);
     const char* erb = getenv("SDF_CONV_WRES_RB");                     // tuning override
-    th = (erb ? erb[0] == '2' : items16 >= 2048) ? 16 : 8;
+    th = (c.sy == 1 && (erb ? erb[0] == '2' : items16 >= 2048)) ? 16 : 8;
   }
   P.tiles_m = (int)((imgs / T) * ((c.OH + th - 1) / th) * ((c.OW + TW - 1) / TW));   // fused: imgs / T = pos_count / (OH*OW) batch elements
   P.tiles_n = d.N / NB;
@@ -832,7 +880,7 @@ int launch_spike_conv_wres(const GemmParams& Pin, hipStream_t s) {
   int G = P.ntiles < 256 ? P.ntiles : 256;
   int rc;
   if (d.nsplit == SDF_PLANES_I8X3) {
-    if (c.Cin != 96) return SDF_E_SHAPE;
+    if (c.Cin != 96 && c.Cin != 48) return SDF_E_SHAPE;
     {
       // a workgroup's wave groups take its items in turn: give every workgroup a whole number of items per group and size the
       // grid for equal rounds (648 fused items, 3 groups: 216 workgroups x 3 items instead of 256 of which 120 leave a group
@@ -856,6 +904,11 @@ int launch_spike_conv_wres(const GemmParams& Pin, hipStream_t s) {
     const char* eg = getenv("SDF_CONV_WRES_GROUPS");                   // tuning override: 2 or 3
     const bool g3 = d.sn_T > 0 && th == 8 && (eg ? eg[0] == '3' : true);
     const dim3 grid((unsigned)G);
+    if (c.Cin == 48) {
+      if (d.sn_T == 0) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 3, 1, 2, true>), grid, dim3(512), 0, s, P, d.col_scale);
+      else if (g3) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 3, 1, 3, true>), grid, dim3(768), 0, s, P, d.col_scale);
+      else hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 3, 1, 2, true>), grid, dim3(512), 0, s, P, d.col_scale);
+    } else
     if (d.sn_T == 0 && th == 16) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 6, 2, 2>), grid, dim3(512), 0, s, P, d.col_scale);
     else if (d.sn_T == 0) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 6, 1, 2>), grid, dim3(512), 0, s, P, d.col_scale);
     else if (th == 16) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 2, 2>), grid, dim3(512), 0, s, P, d.col_scale);

@@ -119,9 +119,9 @@ def _conv_digits(w, nsplit):
     """int8 digit planes of a 3x3 convolution: on 96 input channels what the weight-resident kernel reads for large launches
     (csrc/spike_conv_wres.hip), on multiples of 64 what the small-M kernel reads (csrc/ms_smallm.hip: the U-Net bottleneck); None where
     neither has an instantiation or the exact 3-plane / 1-plane modes were asked for."""
-    if nsplit != 2 or tuple(w.shape[2:]) != (3, 3) or w.shape[0] % 32 or not (w.shape[1] == 96 or w.shape[1] % 64 == 0):
+    if nsplit != 2 or tuple(w.shape[2:]) != (3, 3) or w.shape[0] % 32 or not (w.shape[1] in (48, 96) or w.shape[1] % 64 == 0):
         return None
-    return hip.pack_conv_weight_i8x3(w.detach().float(), tiled=w.shape[1] != 96)       # (fragment order: only the small-M kernel reads those)
+    return hip.pack_conv_weight_i8x3(w.detach().float(), tiled=w.shape[1] not in (48, 96))   # (fragment order: only the small-M kernel reads those)
 
 
 class _ResBlock:
@@ -220,6 +220,7 @@ class MSFlowEngine:
         self.head_w_oihw = pe.head.conv[0].weight.detach().float().contiguous()
         self.head_bn, self.head_sn = bn_affine(pe.head.norm_layer.norm_layer, dev), _np(pe.head.sn, dev)
         self.conv_w, self.conv_bn = _conv_planes(pe.conv.conv[0].weight, ns), bn_affine(pe.conv.norm_layer.norm_layer, dev)
+        self.conv_w.digits = _conv_digits(pe.conv.conv[0].weight, ns)      # 48 -> 96 at stride 2: the digit kernel's even / odd halo form
         U = "sttmultires_unet."
         self.pe_name = U + "encoders.swin3d.patch_embed."
         self.pe_res = [_ResBlock(rb, dev, ns, self.pe_name + f"residual_encoding.resblocks.{i}.") for i, rb in enumerate(pe.residual_encoding.resblocks)]

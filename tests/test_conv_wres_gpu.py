@@ -171,6 +171,68 @@ def test_digit_kernel_fused_neuron_at_T5_and_T20(T, B, H, W):
     assert (sp2.cpu().float() != w0).float().mean().item() <= 2e-4
 
 
+@pytest.mark.parametrize("imgs,H,W,Cout,with_res", [(10, 48, 64, 96, True), (3, 21, 37, 96, True), (2, 16, 32, 64, False), (4, 35, 66, 32, False),
+                                                    (1, 1, 1, 96, False)])
+def test_stride2_on_48_channels_fp32_epilogue(imgs, H, W, Cout, with_res):
+    """The patch embedding's first 3x3 (48 -> 96, stride 2, pad 1: Spiking_modules.py:1776-1779) on the digit kernel's stride-2 form
+    (17 x 33 halo with the even / odd columns as two planes, K order permuted so that a K step's two pieces sit a constant distance
+    apart): even, odd and ragged images - the last input row / column is a tap of the last output only when H / W is even."""
+    Cin = 48
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = spikes((imgs, H, W, Cin), 300 + H)
+    w = rnd((Cout, Cin, 3, 3), 301, -0.1, 0.1)
+    alpha, beta = rnd((Cout,), 302, 0.5, 1.5), rnd((Cout,), 303, -0.2, 0.2)
+    resid = rnd((imgs * OH * OW, Cout), 304) if with_res else None
+    Wp = pack(w, "i8x3")
+    out = torch.full((imgs * OH * OW, Cout), float("nan"), device=DEV)
+    hip.spike_conv2d(x.to(DEV), Wp, imgs, H, W, Cin, OH, OW, 3, 3, 2, (-1, 0, 1), (-1, 0, 1), out=out, alpha=alpha.to(DEV),
+                     beta=beta.to(DEV), resid=None if resid is None else resid.to(DEV))
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 2, 1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    ref = ref * alpha.double() + beta.double() + (resid.double() if with_res else 0)
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    # and bit-equal to the 16-bit-plane streaming kernel's result where the digits and the planes hold the same weight: a weight
+    # that is a multiple of 2^-10 below 1/8 is exact in both
+    wq = (w * 1024).round() / 1024
+    if Cout % 96 == 0:                                                  # (the streaming kernels work on 96-column blocks)
+        o2 = []
+        for P in (pack(wq, "i8x3"), pack(wq, 2)):
+            o2.append(torch.full((imgs * OH * OW, Cout), float("nan"), device=DEV))
+            hip.spike_conv2d(x.to(DEV), P, imgs, H, W, Cin, OH, OW, 3, 3, 2, (-1, 0, 1), (-1, 0, 1), out=o2[-1])
+        assert torch.equal(o2[0], o2[1])                                # (sums of multiples of 2^-10 below 2^6: exact in fp32 whatever the order)
+
+
+@pytest.mark.parametrize("kind,v_reset", [("lif", None), ("lif", 0.0), ("if", None)])
+@pytest.mark.parametrize("T,B,H,W", [(10, 1, 48, 64), (10, 2, 21, 37), (20, 2, 24, 32), (5, 1, 40, 48)])
+def test_stride2_on_48_channels_fused_neuron(T, B, H, W, kind, v_reset):
+    """conv (stride 2) -> BN -> neuron over T with the membrane handed on as well ((b, t) images, as the engine calls it): fp32
+    membrane within 1e-5 of fp64, spikes = C-oracle neuron of the kernel's OWN membrane bit for bit; the spikes-only form gives the
+    same spikes bit for bit (same arithmetic, nothing stored)."""
+    Cin, Cc = 48, 96
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = spikes((B * T, H, W, Cin), 310 + T)
+    w = rnd((Cc, Cin, 3, 3), 311, -0.15, 0.15)
+    alpha, beta = rnd((Cc,), 312, 0.5, 1.5), rnd((Cc,), 313, -0.2, 0.2)
+    n = OH * OW
+    Wp = pack(w, "i8x3")
+    pos = (B * n, n, T * n, n)
+    sn = hip.NeuronParams(kind, 2.0, 0.1, v_reset)
+    m = torch.full((B * T * n, Cc), float("nan"), device=DEV)
+    sp = torch.zeros((B * T * n, Cc), dtype=torch.uint8, device=DEV)
+    hip.spike_conv2d(x.to(DEV), Wp, B * T, H, W, Cin, OH, OW, 3, 3, 2, (-1, 0, 1), (-1, 0, 1), out=m, out_spike=sp, alpha=alpha.to(DEV),
+                     beta=beta.to(DEV), sn=sn, sn_T=T, pos=pos)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 2, 1).permute(0, 2, 3, 1).reshape(-1, Cc)
+    ref = ref * alpha.double() + beta.double()
+    m = m.cpu()
+    assert (m.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    mt = m.view(B, T, n * Cc).permute(1, 0, 2).contiguous()
+    want = R.neuron_ref(mt.view(T, -1), kind, 2.0, 0.1, v_reset).view(T, B, n * Cc).permute(1, 0, 2).reshape(B * T * n, Cc)
+    assert torch.equal(sp.cpu().float(), want) and 0.03 < want.mean() < 0.97
+    sp2 = torch.zeros_like(sp)
+    hip.spike_conv2d(x.to(DEV), Wp, B * T, H, W, Cin, OH, OW, 3, 3, 2, (-1, 0, 1), (-1, 0, 1), out_spike=sp2, alpha=alpha.to(DEV),
+                     beta=beta.to(DEV), sn=sn, sn_T=T, pos=pos)
+    assert torch.equal(sp2, sp)
+
+
 def test_i8x3_digit_planes_reconstruct_the_weight():
     """sdf_split_weight_i8x3: (d2*65536 + d1*256 + d0) * scale is the weight to 2^-23 of the row maximum, digits in range."""
     w = rnd((96, 864), 230, -0.2, 0.2)
