@@ -418,28 +418,33 @@ __device__ __forceinline__ void qt4(float& a0, float& a1, float& a2, float& a3, 
   a1 = o2 ? r : a1; a3 = o2 ? a3 : r;
 }
 
-template <int CIN16, int RB, bool S2>
+template <int CIN16, int RB, bool S2, int KH = 1>
 struct GeoI8 {
+  // KH > 1 (stride 2 on 16 CIN16 KH input channels): the halo image holds 16 CIN16 channels of its pixels at a time and a tile takes KH
+  // passes over K - one halo image + MFMA phase per channel group, the accumulators carried across - so that the 17 x 33 pixel halo of
+  // 96 channels (63 KB: one per workgroup beside 85 KB of digit planes) becomes two of 27 KB and two wave groups fit
   // stride 1: RB row blocks of 32 pixels per wave, halo (8 RB + 2) x 18 pixels.  Stride 2 (S2, RB = 1): the 8 x 16 output pixels of a
   // tile read a 17 x 33 halo whose EVEN and ODD columns are kept as two planes of a halo row - tap kx of output pixel x is halo column
   // 2 x + kx = plane kx & 1, entry x + (kx >> 1), so that the 16 lanes of a fragment read stay PS bytes apart (one plane, neighbouring
   // entries) and conflict-free as at stride 1; interleaved they would be 2 PS apart and meet two to a bank quad
   static constexpr int TH8 = 8 * RB, TW8 = 16, HH8 = S2 ? 2 * TH8 + 1 : TH8 + 2, HW8 = S2 ? 2 * TW8 + 1 : TW8 + 2;
-  static constexpr int CIN = 16 * CIN16;
-  static constexpr int K = 9 * CIN;
-  static constexpr int NP = 9 * CIN16;                                // 16-byte pieces of a weight row
+  static constexpr int CIN = 16 * CIN16;                              // channels of a pixel in the halo image
+  static constexpr int CING = CIN * KH;                               // channels of a pixel in global memory
+  static constexpr int K = 9 * CING;
+  static constexpr int NP = 9 * CIN16;                                // 16-byte pieces of a weight row (per channel pass)
   static constexpr int KS = (NP + 1) / 2;                             // K steps of 32 (two pieces: one per half wave); odd NP: one zero piece
   static constexpr int PS = (S2 && CIN16 % 2) ? CIN : CIN + 16;       // pixel stride: 4 x odd dwords (16-byte fragment reads)
   static constexpr int XE = (HW8 + 1) / 2;                            // S2: entries of the even-column plane
   static constexpr int RPB = S2 ? HW8 * PS : (HW8 * PS + 255) / 256 * 256;   // halo row pitch (stride 1: a whole number of bank rounds)
   static constexpr int HALO = HH8 * RPB;
-  static constexpr int WP = 32 * KS + 16;                             // digit-plane row pitch (bytes): 4 x odd dwords
+  static constexpr int WP = 32 * KS * KH + 16;                        // digit-plane row pitch (bytes): 4 x odd dwords
   static constexpr int RCH = HW8 * CIN16;                             // 16-byte pieces of a halo row: one per lane of a half group
   static constexpr int CPL = (HH8 + 1) / 2;                           // pieces per lane: two halo rows per pass of the group's 256 lanes
   static_assert(RCH <= 128, "a halo row must fit the 128 lanes of a half group");
   static_assert((PS / 4) % 8 == 4 && (WP / 4) % 8 == 4, "pitches must be 4 x odd dwords");
   static_assert(S2 || CIN % 32 == 0, "stride 1: K steps of 32 must not straddle taps");
   static_assert(!S2 || RB == 1, "stride 2: one row block per wave");
+  static_assert(KH == 1 || S2, "channel passes: stride-2 form only");
   // S2: the K order of the LDS weight image is chosen so that the two 16-byte pieces of a K step (lower / upper half wave) sit a
   // CONSTANT distance apart in the halo image - the half wave's share is folded into one of three lane bases, every step's offset is
   // an immediate and the main loop has no address arithmetic at all (the kernel's K order is free: integer sums are exact):
@@ -456,17 +461,20 @@ struct GeoI8 {
   // LDS slot (16-byte pieces from the row start) of piece kc = tap * n + c of a weight row as sdf_split_weight_i8x3 left it
   static __device__ __forceinline__ int slot(int kc) {
     constexpr int n = CIN16;
-    const int tap = kc / n, c = kc - tap * n, ky = tap / 3, kx = tap - 3 * ky;
-    if (kx != 1) return 2 * (ky * n + c) + (kx >> 1);
-    if (ky < 2) return 2 * (3 * n + c) + ky;
-    return 2 * 4 * n + c;
+    const int tap = kc / (n * KH), cg = kc - tap * (n * KH), hf = cg / n, c = cg - hf * n, ky = tap / 3, kx = tap - 3 * ky;
+    const int base = 2 * KS * hf;                                     // channel pass hf: its own 2 KS pieces of the row
+    if (kx != 1) return base + 2 * (ky * n + c) + (kx >> 1);
+    if (ky < 2) return base + 2 * (3 * n + c) + ky;
+    return base + 2 * 4 * n + c;
   }
 };
 
-template <int TT, int CIN16, int RB, int NGRP, bool S2 = false>
+template <int TT, int CIN16, int RB, int NGRP, bool S2 = false, int KH = 1>
 __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmParams P, const float* __restrict__ col_scale) {
-  using G = GeoI8<CIN16, RB, S2>;
+  using G = GeoI8<CIN16, RB, S2, KH>;
   constexpr int ST = S2 ? 2 : 1;
+  constexpr int CING = G::CING;
+  constexpr bool EARLY = KH > 1;                                      // the next halo is requested BEFORE the MFMA phase (see the time loop)
   constexpr bool SPIKE = TT > 0;
   const int T = SPIKE ? P.d.sn_T : 1;             // the time loop is rolled: TT > 0 selects the fused form, its length comes with the call (5 / 10 / 20)
   constexpr int CIN = G::CIN, K = G::K, PS = G::PS, RPB = G::RPB, WP = G::WP, TH8 = G::TH8, TW8 = G::TW8;
@@ -523,17 +531,17 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
   const bool hj_ok = hj < G::RCH;
   const int hpx = (hj_ok ? hj : 0) / CIN16, hc16 = (hj_ok ? hj : 0) - hpx * CIN16;
   const uint32_t h_lds0 = (uint32_t)(hhalf * RPB + (S2 ? (hpx & 1) * G::XE * PS + (hpx >> 1) * PS : hpx * PS) + hc16 * 16);
-  const int h_rel0 = ((hhalf - 1) * Win + (hpx - 1)) * CIN + hc16 * 16;
+  const int h_rel0 = ((hhalf - 1) * Win + (hpx - 1)) * CING + hc16 * 16;
   const __amdgpu_buffer_rsrc_t A_rs = make_rsrc(d.A);
   u32x4 hreg[G::CPL];
-  auto halo_load = [&](int img, int y0, int x0) __attribute__((always_inline)) {          // (y0, x0): the tile's first OUTPUT pixel
-    const uint32_t org = (uint32_t)(((img * Hin + ST * y0) * Win + ST * x0) * CIN) + (uint32_t)h_rel0;
+  auto halo_load = [&](int img, int y0, int x0, int hf) __attribute__((always_inline)) {  // (y0, x0): the tile's first OUTPUT pixel; hf: channel pass
+    const uint32_t org = (uint32_t)(((img * Hin + ST * y0) * Win + ST * x0) * CING + hf * CIN) + (uint32_t)h_rel0;
     const bool xok = hj_ok && (unsigned)(ST * x0 + hpx - 1) < (unsigned)Win;
 #pragma unroll
     for (int i = 0; i < G::CPL; ++i) {
       const int hy = 2 * i + hhalf;
       const bool ok = xok && hy < G::HH8 && (unsigned)(ST * y0 + hy - 1) < (unsigned)Hin;
-      hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(A_rs, ok ? org + (uint32_t)(2 * i * Win * CIN) : INV, 0, 0);
+      hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(A_rs, ok ? org + (uint32_t)(2 * i * Win * CING) : INV, 0, 0);
     }
   };
   uint8_t* H_s = smem + W_BYTES + grp * G::HALO;
@@ -605,7 +613,8 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
       }
       if (S2 && (G::NP & 1) && tid < 3 * NB) {                         // an odd number of pieces: the last K step's upper half is zero
         u32x4 z; z.x = z.y = z.z = z.w = 0u;
-        *reinterpret_cast<u32x4*>(W_s + tid * WP + G::NP * 16) = z;
+#pragma unroll
+        for (int hf = 0; hf < KH; ++hf) *reinterpret_cast<u32x4*>(W_s + tid * WP + (2 * G::KS * hf + G::NP) * 16) = z;
       }
       // BN folded with the channel's digit scale: fma(D * s, alpha, beta) == fma(D, s * alpha, beta) exactly (s is a power of two)
       if (tid < 2 * NB) {
@@ -620,7 +629,7 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
     int it = seg_begin + grp;
     if (it < seg_end) {
       item_decode(t_begin + it, cb, img0, y0, x0);
-      halo_load(img0, y0, x0);
+      halo_load(img0, y0, x0, 0);
       if (nstep) wait_ge(&cnt[NGRP + grp], 4 * nstep);
       halo_store();
       signal(&cnt[grp], lane);
@@ -662,12 +671,28 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
         };
         constexpr bool RES_EARLY = !SPIKE || RB == 1;               // registers allow it: the residual's latency hides behind the MFMAs
         if (RES_EARLY && has_res) load_res();
-        ++nstep;
-        STAMP(s1);
-        wait_ge(&cnt[grp], 4 * nstep);
-        STAMP(s2);
+        // the halo image that follows (t, hf): the next channel pass, the next step, or the group's next item
+        bool have_next = true;
+        auto request_next = [&](int hf) __attribute__((always_inline)) {
+          int ni = img, ny = y0, nx = x0, nhf = hf + 1;
+          if (nhf == KH) {
+            nhf = 0; ni = img0 + (t + 1) * tstep;
+            if (t + 1 == T) {
+              if (it + NGRP < seg_end) { int ncb; item_decode(t_begin + it + NGRP, ncb, ni, ny, nx); }
+              else have_next = false;
+            }
+          }
+          if (have_next) halo_load(ni, ny, nx, nhf);
+        };
+        auto hand_over = [&]() __attribute__((always_inline)) {
+          if (have_next) {
+            wait_ge(&cnt[NGRP + grp], 4 * nstep);
+            halo_store();
+            signal(&cnt[grp], lane);
+          }
+        };
 
-        // ------------------------------ MFMA phase: 27 K-steps of 32 x 3 digits x RB row blocks ------------------------------
+        // ------------------------------ MFMA phase: KH passes of KS K-steps of 32 x 3 digits x RB row blocks ------------------------------
         i32x16 acc[3][RB];
 #pragma unroll
         for (int dg = 0; dg < 3; ++dg)
@@ -677,51 +702,54 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
             for (int e = 0; e < 16; ++e) acc[dg][rb][e] = 0;
         constexpr int KS = G::KS;
         constexpr int PF = (RB == 1 && NGRP == 2) ? 2 : 1;              // three groups live on 168 registers
-        i32x4 fa[PF + 1][RB], fb[PF + 1][3];
-        auto frag = [&](int ks, int set) __attribute__((always_inline)) {
-          if constexpr (S2) {
-            fa[set][0] = *reinterpret_cast<const i32x4*>(H_s + a_base[G::step_base(ks)] + G::step_off(ks));
-          } else {
-            constexpr int C32 = CIN / 32;
-            const int tap = ks / C32, c = ks - tap * C32;
-            const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-              fa[set][rb] = *reinterpret_cast<const i32x4*>(H_s + a_lane + ((2 * rb + ky) * RPB + kx * PS + c * 32));
+        for (int hf = 0; hf < KH; ++hf) {
+          ++nstep;
+          // channel passes (EARLY): the next image is requested ahead of this pass's MFMAs - between two passes of a tile there is
+          // no epilogue to hide it behind (two groups: 256 registers, the 36 of the image in flight are affordable)
+          if (EARLY) request_next(hf);
+          STAMP(s1);
+          wait_ge(&cnt[grp], 4 * nstep);
+          STAMP(s2);
+          i32x4 fa[PF + 1][RB], fb[PF + 1][3];
+          auto frag = [&](int ks, int set) __attribute__((always_inline)) {
+            if constexpr (S2) {
+              fa[set][0] = *reinterpret_cast<const i32x4*>(H_s + a_base[G::step_base(ks)] + G::step_off(ks));
+            } else {
+              constexpr int C32 = CIN / 32;
+              const int tap = ks / C32, c = ks - tap * C32;
+              const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+              for (int rb = 0; rb < RB; ++rb)
+                fa[set][rb] = *reinterpret_cast<const i32x4*>(H_s + a_lane + ((2 * rb + ky) * RPB + kx * PS + c * 32));
+            }
+#pragma unroll
+            for (int dg = 0; dg < 3; ++dg)
+              fb[set][dg] = *reinterpret_cast<const i32x4*>(W_s + w_lane + (dg * NB * WP + (hf * KS + ks) * 32));
+          };
+#pragma unroll
+          for (int i = 0; i < PF; ++i) frag(i, i);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            if (ks + PF < KS) frag(ks + PF, (ks + PF) % (PF + 1));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dg = 0; dg < 3; ++dg)
+#pragma unroll
+              for (int rb = 0; rb < RB; ++rb)
+                acc[dg][rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[ks % (PF + 1)][dg], fa[ks % (PF + 1)][rb], acc[dg][rb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
           }
-#pragma unroll
-          for (int dg = 0; dg < 3; ++dg)
-            fb[set][dg] = *reinterpret_cast<const i32x4*>(W_s + w_lane + (dg * NB * WP + ks * 32));
-        };
-#pragma unroll
-        for (int i = 0; i < PF; ++i) frag(i, i);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          if (ks + PF < KS) frag(ks + PF, (ks + PF) % (PF + 1));
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int dg = 0; dg < 3; ++dg)
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-              acc[dg][rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[ks % (PF + 1)][dg], fa[ks % (PF + 1)][rb], acc[dg][rb], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
+          signal(&cnt[NGRP + grp], lane);
+          if (EARLY && hf + 1 < KH) hand_over();                        // the next pass's image goes in as soon as this one is read
         }
-        signal(&cnt[NGRP + grp], lane);
         STAMP(s3);
 
         // ------------------------------ epilogue: RB row blocks of 32 pixels ------------------------------
         if (!RES_EARLY && has_res) load_res();
-        // the NEXT step's halo is requested here: its latency hides behind this epilogue and, beyond it, behind the other
-        // group's MFMAs; its registers are not live across this group's own MFMA phase
-        bool have_next = true;
-        {
-          int ni = img0 + (t + 1) * tstep, ny = y0, nx = x0;
-          if (t + 1 == T) {
-            if (it + NGRP < seg_end) { int ncb; item_decode(t_begin + it + NGRP, ncb, ni, ny, nx); }
-            else have_next = false;
-          }
-          if (have_next) halo_load(ni, ny, nx);
-        }
+        // one pass per tile: the NEXT step's halo is requested here - its latency hides behind this epilogue and, beyond it, behind
+        // the other groups' MFMAs; its registers are not live across this group's own MFMA phase
+        if (!EARLY) request_next(KH - 1);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
           float4 om[4];                                                 // the row block's fp32 outputs (membrane), quad by quad
@@ -799,11 +827,7 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
           }
         }
         STAMP(s4);
-        if (have_next) {
-          wait_ge(&cnt[NGRP + grp], 4 * nstep);
-          halo_store();
-          signal(&cnt[grp], lane);
-        }
+        hand_over();
         STAMP(s5);
         STAMP_ADD(a_issue, s0, s1); STAMP_ADD(a_wait, s1, s2); STAMP_ADD(a_mfma, s2, s3); STAMP_ADD(a_epi, s3, s4); STAMP_ADD(a_hand, s4, s5);
       }
@@ -836,8 +860,9 @@ bool spike_conv_wres_supports(const GemmParams& P, bool any_size) {
   // 96 channels at stride 1 (every form), or - digit planes only - 48 channels at stride 2 (the patch embedding's first 3x3: halo
   // tiles with the even / odd columns as two planes, GeoI8<.., S2>)
   const bool s1 = c.Cin == 96 && c.sy == 1 && c.sx == 1 && c.H == c.OH && c.W == c.OW;
-  const bool s2 = c.Cin == 48 && c.sy == 2 && c.sx == 2 && c.OH == (c.H - 1) / 2 + 1 && c.OW == (c.W - 1) / 2 + 1 &&
-                  d.nsplit == SDF_PLANES_I8X3 && !(d.sn_T > 0 && d.resid);
+  // (and 96 channels at stride 2 in two channel passes, fp32 epilogue only: the patch embedding's projection)
+  const bool s2 = (c.Cin == 48 || (c.Cin == 96 && d.sn_T == 0)) && c.sy == 2 && c.sx == 2 && c.OH == (c.H - 1) / 2 + 1 &&
+                  c.OW == (c.W - 1) / 2 + 1 && d.nsplit == SDF_PLANES_I8X3 && !(d.sn_T > 0 && d.resid);
   if ((!s1 && !s2) || c.KWc != 3 || d.K != 9 * c.Cin) return false;
   if (c.dy[0] != -1 || c.dy[1] != 0 || c.dy[2] != 1 || c.dx[0] != -1 || c.dx[1] != 0 || c.dx[2] != 1) return false;
   if (d.N % NB || (d.nsplit != 1 && d.nsplit != 2 && d.nsplit != SDF_PLANES_I8X3) || d.out_rowmap || d.add || d.zg_nH > 0) return false;
@@ -904,7 +929,9 @@ int launch_spike_conv_wres(const GemmParams& Pin, hipStream_t s) {
     const char* eg = getenv("SDF_CONV_WRES_GROUPS");                   // tuning override: 2 or 3
     const bool g3 = d.sn_T > 0 && th == 8 && (eg ? eg[0] == '3' : true);
     const dim3 grid((unsigned)G);
-    if (c.Cin == 48) {
+    if (c.sy == 2 && c.Cin == 96) {
+      hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 3, 1, 2, true, 2>), grid, dim3(512), 0, s, P, d.col_scale);
+    } else if (c.Cin == 48) {
       if (d.sn_T == 0) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 3, 1, 2, true>), grid, dim3(512), 0, s, P, d.col_scale);
       else if (g3) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 3, 1, 3, true>), grid, dim3(768), 0, s, P, d.col_scale);
       else hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 3, 1, 2, true>), grid, dim3(512), 0, s, P, d.col_scale);

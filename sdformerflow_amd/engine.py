@@ -228,6 +228,7 @@ class MSFlowEngine:
         self.proj_res_w2 = pe.proj.conv_res.weight.detach().float().reshape(pe.proj.conv_res.weight.shape[0], -1).contiguous()
         self.proj_res_b = None if pe.proj.conv_res.bias is None else pe.proj.conv_res.bias.detach().float().contiguous()
         self.proj_w = _conv_planes(pe.proj.conv.weight, ns)
+        self.proj_w.digits = _conv_digits(pe.proj.conv.weight, ns)         # 96 -> C at stride 2: the digit kernel's two-channel-pass form
         self.proj_bn, self.proj_sn = bn_affine(pe.proj.norm_layer, dev), _np(pe.proj.sn, dev)
         self._maps, self._deconv = {}, {}
         self.tape = None            # parity tests set a list: every neuron layer's spikes are recorded (see _rec)

@@ -380,13 +380,13 @@ def split_weight_i8x3(W):
 
 def conv_wres_applicable(imgs, H, W, Cin, Cout, stride, T=1):
     """Mirror of the library's dispatch rule (csrc/spike_conv_wres.hip: spike_conv_wres_supports): 3x3 on 96 input channels at
-    stride 1 or - digit planes only - on 48 at stride 2 (the patch embedding's first 3x3), output columns in blocks of 32, and enough
+    stride 1 or - digit planes only - at stride 2 on 48 (the patch embedding's first 3x3) or 96 channels (its projection), output columns in blocks of 32, and enough
     8 x 16 pixel OUTPUT tiles (x T steps each when the neuron is fused) to give every half workgroup of the chip work - below that
     the streaming kernels' split-K wins.  H, W: the input image."""
     if os.environ.get("SDF_CONV_WRES", "") == "0":             # the library's A/B override: always the streaming kernels (which
         return False                                             # do not read digit planes: the caller must keep its 16-bit planes)
-    if (Cin, stride) not in ((96, 1), (48, 2)) or Cout % 32:
-        return False
+    if (Cin, stride) not in ((96, 1), (48, 2), (96, 2)) or Cout % 32 or ((Cin, stride) == (96, 2) and T != 1):
+        return False                                             # (96 channels at stride 2: two channel passes, fp32 epilogue only)
     oh, ow = (H - 1) // stride + 1, (W - 1) // stride + 1
     if imgs * max(oh * ow * Cout * 4, H * W * Cin) >= 1 << 31:   # the kernel addresses its operands with 31-bit byte offsets
         return False

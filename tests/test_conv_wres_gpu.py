@@ -171,13 +171,14 @@ def test_digit_kernel_fused_neuron_at_T5_and_T20(T, B, H, W):
     assert (sp2.cpu().float() != w0).float().mean().item() <= 2e-4
 
 
+@pytest.mark.parametrize("Cin", [48, 96])
 @pytest.mark.parametrize("imgs,H,W,Cout,with_res", [(10, 48, 64, 96, True), (3, 21, 37, 96, True), (2, 16, 32, 64, False), (4, 35, 66, 32, False),
                                                     (1, 1, 1, 96, False)])
-def test_stride2_on_48_channels_fp32_epilogue(imgs, H, W, Cout, with_res):
+def test_stride2_on_48_channels_fp32_epilogue(imgs, H, W, Cout, with_res, Cin):
     """The patch embedding's first 3x3 (48 -> 96, stride 2, pad 1: Spiking_modules.py:1776-1779) on the digit kernel's stride-2 form
     (17 x 33 halo with the even / odd columns as two planes, K order permuted so that a K step's two pieces sit a constant distance
-    apart): even, odd and ragged images - the last input row / column is a tap of the last output only when H / W is even."""
-    Cin = 48
+    apart): even, odd and ragged images - the last input row / column is a tap of the last output only when H / W is even.
+    Cin = 96 (the projection 96 -> C at stride 2, :1786-1789): the same halo form in two channel passes of 48."""
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     x = spikes((imgs, H, W, Cin), 300 + H)
     w = rnd((Cout, Cin, 3, 3), 301, -0.1, 0.1)
