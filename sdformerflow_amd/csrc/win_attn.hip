@@ -520,17 +520,24 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 constexpr int KRS = 80;                // K row pitch in bytes: 32 fp16 + 16 pad
 
-// four fp32 -> four hi and four lo fp16 (round to nearest; beyond the fp16 range: inf / NaN, visible in the output)
+// two fp32 -> their hi and lo fp16 halves, packed (round to nearest; beyond the fp16 range: inf / NaN, visible in the output):
+// v_cvt_pk_f16_f32, two conversions back, one packed subtraction (exact), v_cvt_pk_f16_f32.
+// (Round 5 tried lo = v_fma_mixlo/hi_f16(hi, -1.0, x) - three instructions instead of five - as inline assembly: the results were
+// corrupted, because the compiler's hazard recogniser does not see an assembly statement's register write as a vector write, so
+// nothing kept it the required wait states behind an MFMA still reading that register as its accumulator input; hipcc does not
+// select the mix instructions from C.)
+__device__ __forceinline__ void split2_f16(float x, float y, uint32_t& hi, uint32_t& lo) {
+  const f32x2 v = {x, y};
+  const f16x2 h = __builtin_convertvector(v, f16x2);
+  const f32x2 r = v - __builtin_convertvector(h, f32x2);
+  const f16x2 l = __builtin_convertvector(r, f16x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+// four fp32 -> four hi and four lo fp16
 __device__ __forceinline__ void split4_f16(float x, float y, float z, float w, uint2& hi, uint2& lo) {
-  f32x2 a, b;
-  a.x = x; a.y = y;
-  b.x = z; b.y = w;
-  const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
-  f32x2 ra, rb;
-  ra.x = a.x - (float)ha.x; ra.y = a.y - (float)ha.y; rb.x = b.x - (float)hb.x; rb.y = b.y - (float)hb.y;
-  const f16x2 la = __builtin_convertvector(ra, f16x2), lb = __builtin_convertvector(rb, f16x2);
-  hi = make_uint2(__builtin_bit_cast(uint32_t, ha), __builtin_bit_cast(uint32_t, hb));
-  lo = make_uint2(__builtin_bit_cast(uint32_t, la), __builtin_bit_cast(uint32_t, lb));
+  split2_f16(x, y, hi.x, lo.x);
+  split2_f16(z, w, hi.y, lo.y);
 }
 
 template <int MODE, int NTC, bool HAS_MASK>
@@ -652,19 +659,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
   const __amdgpu_buffer_rsrc_t mask_rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(HAS_MASK ? d.mask + (int64_t)(b % d.nW) * N * N : d.bias), 0, HAS_MASK ? (int)tbytes : 0, 0x00020000);
 
+  const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t map_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(d.row_map ? d.row_map : reinterpret_cast<const int*>(d.out)), 0,
+                                                                          d.row_map ? 0x7FFFFFFF : 0, 0x00020000);
   for (int qt = wv; qt < NTC; qt += 4) {
     if (qt * 16 >= N) break;
     const int qi = qt * 16 + l15;
     float qreg[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) qreg[i] = qnext[i];
-    if (MODE == SDF_ATTN_ANN) {                                    // F.normalize(q, dim=-1)
+    if (MODE == SDF_ATTN_ANN) {
+      // F.normalize(q, dim=-1), with the head's logit scale and log2(e) folded into the same multiplier: the scores leave the
+      // matrix pipe in the log2 domain of the softmax (K Q^T * ls * log2 e), 8 multiplications per lane instead of 4 NTC
       float ss = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) ss += qreg[i] * qreg[i];
       ss += __shfl_xor(ss, 16);
       ss += __shfl_xor(ss, 32);
-      const float iq = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+      const float iq = (ls * 1.4426950408889634f) / fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
       for (int i = 0; i < 8; ++i) qreg[i] *= iq;
     }
@@ -676,13 +688,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
     const f16x8 q_lo = __builtin_bit_cast(f16x8, make_uint4(ql0.x, ql0.y, ql1.x, ql1.y));
 
     u32x4 bb[NTC], mm[NTC];
+    // one lane offset per strip (its query's row + the lane group's four keys; out of range as a whole for a padding query), the
+    // key tile is the instruction's scalar offset: no address arithmetic per load
     const uint32_t rowoff = (uint32_t)qi * (uint32_t)N * 4u;
+    const uint32_t rbase = qi < N ? rowoff + 16u * (uint32_t)lg : INV_OFF;
     auto load_strip = [&](const __amdgpu_buffer_rsrc_t& rs, u32x4 (&dst)[NTC]) __attribute__((always_inline)) {
 #pragma unroll
       for (int jt = 0; jt < NTC; ++jt) {
         const int kb = jt * 16 + 4 * lg;
         if (jt < NTC - 1) {
-          dst[jt] = __builtin_amdgcn_raw_buffer_load_b128(rs, qi < N ? rowoff + (uint32_t)kb * 4u : INV_OFF, 0, 0);
+          dst[jt] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbase, jt * 64, 0);
         } else {
           const uint32_t o0 = (qi < N && kb < N) ? rowoff + (uint32_t)kb * 4u : INV_OFF;
           const uint32_t o1 = (qi < N && kb + 2 < N) ? rowoff + (uint32_t)kb * 4u + 8u : INV_OFF;
@@ -695,7 +710,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
     load_strip(bias_rs, bb);
     if (HAS_MASK) load_strip(mask_rs, mm);
     // ---- S^T = K Q^T: three 16x16x32 products per key tile ----
+    // ANN: the accumulator STARTS as (bias + mask) * log2 e - the additions of the score come out of the matrix pipe for free and
+    // the strip is in the softmax's log2 domain when it lands; keys beyond N start at -inf (their K rows are zero: -inf + 0)
     f32x4 st[NTC];
+    constexpr float L2E = 1.4426950408889634f;
 #pragma unroll
     for (int jt = 0; jt < NTC; ++jt) {
       const int kj = jt * 16 + l15;
@@ -703,58 +721,72 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
       const f16x8 k_lo = *reinterpret_cast<const f16x8*>(Klo + kj * KRS + 16 * lg);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       if (MODE == SDF_ATTN_ANN) {                                  // binary operands have no lo halves: one exact product
+        f32x2 b01 = {__uint_as_float(bb[jt].x), __uint_as_float(bb[jt].y)}, b23 = {__uint_as_float(bb[jt].z), __uint_as_float(bb[jt].w)};
+        if (HAS_MASK) {
+          const f32x2 m01 = {__uint_as_float(mm[jt].x), __uint_as_float(mm[jt].y)}, m23 = {__uint_as_float(mm[jt].z), __uint_as_float(mm[jt].w)};
+          b01 += m01; b23 += m23;
+        }
+        const f32x2 l2 = {L2E, L2E};
+        b01 *= l2; b23 *= l2;
+        if (jt == NTC - 1) {
+          const int kb = jt * 16 + 4 * lg;
+          b01.x = (kb + 0 < N) ? b01.x : -INFINITY; b01.y = (kb + 1 < N) ? b01.y : -INFINITY;
+          b23.x = (kb + 2 < N) ? b23.x : -INFINITY; b23.y = (kb + 3 < N) ? b23.y : -INFINITY;
+        }
+        acc = f32x4{b01.x, b01.y, b23.x, b23.y};
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, q_lo, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_lo, q_hi, acc, 0, 0, 0);
       }
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_hi, q_hi, acc, 0, 0, 0);
       st[jt] = acc;
     }
-#pragma unroll
-    for (int jt = 0; jt < NTC; ++jt) {
-      const int kb = jt * 16 + 4 * lg;
-      const uint32_t b0 = bb[jt].x, b1 = bb[jt].y, b2 = bb[jt].z, b3 = bb[jt].w;
-      float s0 = st[jt][0] * ls + __uint_as_float(b0), s1 = st[jt][1] * ls + __uint_as_float(b1);
-      float s2 = st[jt][2] * ls + __uint_as_float(b2), s3 = st[jt][3] * ls + __uint_as_float(b3);
-      if (HAS_MASK) {
-        const uint32_t m0 = mm[jt].x, m1 = mm[jt].y, m2 = mm[jt].z, m3 = mm[jt].w;
-        s0 += __uint_as_float(m0); s1 += __uint_as_float(m1); s2 += __uint_as_float(m2); s3 += __uint_as_float(m3);
-      }
-      if (jt == NTC - 1) {
-        const float NEG = (MODE == SDF_ATTN_ANN) ? -INFINITY : 0.f;
-        s0 = (kb + 0 < N) ? s0 : NEG; s1 = (kb + 1 < N) ? s1 : NEG;
-        s2 = (kb + 2 < N) ? s2 : NEG; s3 = (kb + 3 < N) ? s3 : NEG;
-      }
-      st[jt][0] = s0; st[jt][1] = s1; st[jt][2] = s2; st[jt][3] = s3;
-    }
+    float rinv[4] = {1.f, 1.f, 1.f, 1.f};                          // ANN: 1 / (row sum) of this lane's four OUTPUT rows (queries 4 lg + r)
     if (MODE == SDF_ATTN_ANN) {
-      float m = -INFINITY;
+      float m = st[0][0];
 #pragma unroll
-      for (int jt = 0; jt < NTC; ++jt) m = fmaxf(fmaxf(fmaxf(m, st[jt][0]), fmaxf(st[jt][1], st[jt][2])), st[jt][3]);
+      for (int jt = 0; jt < NTC; ++jt) {
+        m = fmaxf(fmaxf(m, st[jt][0]), st[jt][1]);
+        m = fmaxf(fmaxf(m, st[jt][2]), st[jt][3]);
+      }
       m = fmaxf(m, __shfl_xor(m, 16));
       m = fmaxf(m, __shfl_xor(m, 32));
-      const float L2E = 1.4426950408889634f, mneg = -m * L2E;
-      float sum = 0.f;
+      const f32x2 m2 = {m, m};
+      f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
       for (int jt = 0; jt < NTC; ++jt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(fmaf(st[jt][r], L2E, mneg));
-          st[jt][r] = e;
-          sum += e;
-        }
+        const f32x2 a01 = f32x2{st[jt][0], st[jt][1]} - m2, a23 = f32x2{st[jt][2], st[jt][3]} - m2;
+        const f32x2 e01 = {__builtin_amdgcn_exp2f(a01.x), __builtin_amdgcn_exp2f(a01.y)};
+        const f32x2 e23 = {__builtin_amdgcn_exp2f(a23.x), __builtin_amdgcn_exp2f(a23.y)};
+        sum2 += e01; sum2 += e23;
+        st[jt] = f32x4{e01.x, e01.y, e23.x, e23.y};
       }
+      float sum = sum2.x + sum2.y;
       sum += __shfl_xor(sum, 16);
       sum += __shfl_xor(sum, 32);
-      // probabilities leave as 2^10 p: a p of 1/162 keeps its 22 bits in hi + lo instead of a subnormal lo half; the factor
-      // comes off the finished product (both exact: powers of two)
-      const float inv = (1.f / sum) * 1024.f;
+      // the probabilities go to the matrix pipe UNNORMALISED (e in (0, 1], the row maximum is 1: hi + lo carry 22 bits of every
+      // term that matters) and the finished rows are divided instead: 8 multiplications per lane for 4 NTC.  The output rows of a
+      // lane are queries 4 lg + r, the sums sit with lanes l15 = query: one cross-lane read each
+      const float inv = 1.f / sum;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rinv[r] = __shfl(inv, (lane & 48) | (4 * lg + r));
+    } else {
 #pragma unroll
       for (int jt = 0; jt < NTC; ++jt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) st[jt][r] *= inv;
+        const int kb = jt * 16 + 4 * lg;
+        const uint32_t b0 = bb[jt].x, b1 = bb[jt].y, b2 = bb[jt].z, b3 = bb[jt].w;
+        float s0 = st[jt][0] * ls + __uint_as_float(b0), s1 = st[jt][1] * ls + __uint_as_float(b1);
+        float s2 = st[jt][2] * ls + __uint_as_float(b2), s3 = st[jt][3] * ls + __uint_as_float(b3);
+        if (HAS_MASK) {
+          const uint32_t m0 = mm[jt].x, m1 = mm[jt].y, m2 = mm[jt].z, m3 = mm[jt].w;
+          s0 += __uint_as_float(m0); s1 += __uint_as_float(m1); s2 += __uint_as_float(m2); s3 += __uint_as_float(m3);
+        }
+        if (jt == NTC - 1) {
+          s0 = (kb + 0 < N) ? s0 : 0.f; s1 = (kb + 1 < N) ? s1 : 0.f;
+          s2 = (kb + 2 < N) ? s2 : 0.f; s3 = (kb + 3 < N) ? s3 : 0.f;
+        }
+        st[jt][0] = s0; st[jt][1] = s1; st[jt][2] = s2; st[jt][3] = s3;
       }
     }
-    constexpr float OSC = MODE == SDF_ATTN_ANN ? 0.0009765625f : 1.f;
     // ---- O = P V: the lane's four probabilities of key tile jt are the A operand (keys 16 jt + 4 lg + 0..3) ----
     f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -775,22 +807,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SDF_ATTN_WP
       o0 = __builtin_amdgcn_mfma_f32_16x16x16f16(p_hi, v0h, o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_16x16x16f16(p_hi, v1h, o1, 0, 0, 0);
     }
+    // 32-bit buffer offsets (the host admits this kernel only while B_ * N * C * 4 < 2^31): no 64-bit address arithmetic
+    int orow[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = qt * 16 + 4 * lg + r;
-      if (i < N) {
-        int64_t off;
-        if (MODE == SDF_ATTN_ANN) {
-          const int64_t orow = d.row_map ? d.row_map[(int64_t)b * N + i] : (int64_t)b * N + i;   // window reverse + roll back + crop
-          if (orow < 0) continue;
-          off = orow * C + g * HD;
-        } else {
-          const int t = i / d.N1, n1 = i - t * d.N1;
-          off = (((int64_t)t * d.B_ + b) * d.N1 + n1) * C + g * HD;
-        }
-        d.out[off + l15] = o0[r] * OSC;
-        d.out[off + 16 + l15] = o1[r] * OSC;
+      if (MODE == SDF_ATTN_ANN) {                                    // window reverse + roll back + crop: the row map (< 0: a padding token)
+        orow[r] = b * N + i;
+        if (d.row_map) orow[r] = (int)__builtin_amdgcn_raw_buffer_load_b32(map_rs, i < N ? (uint32_t)(b * N + i) * 4u : INV_OFF, 0, 0);
+        if (i >= N) orow[r] = -1;
+      } else {
+        const int t = i / d.N1, n1 = i - t * d.N1;
+        orow[r] = i < N ? (t * d.B_ + b) * d.N1 + n1 : -1;
       }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t off = orow[r] >= 0 ? ((uint32_t)orow[r] * (uint32_t)C + (uint32_t)(g * HD + l15)) * 4u : INV_OFF;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o0[r] * rinv[r]), out_rs, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o1[r] * rinv[r]), out_rs, off, 64, 0);
     }
   }
 }
@@ -844,7 +879,8 @@ extern "C" int sdf_win_attn_fwd(const SdfWinAttnDesc* d, void* stream) {
   if (d->N % 2 == 0 && (int64_t)d->N * d->N * 4 < (1LL << 31) && !(ge && ge[0] == '1')) {
     const int nt = (d->N + 15) / 16;                         // compiled tile counts: windows (2,8,8) and (2,9,9)
     const char* f32 = getenv("SDF_ATTN_F32");                // A/B override: 1 = the fp32-pipe kernels
-    const bool pipe16 = !(f32 && f32[0] == '1');
+    // (the 16-bit-pipe kernels address the output and the row map with 32-bit byte offsets)
+    const bool pipe16 = !(f32 && f32[0] == '1') && (int64_t)d->B_ * d->N * d->nH * HD * 4 < (1LL << 31);
     if (d->mode == SDF_ATTN_ANN) {
       if (pipe16 && nt == 8) return launch_tiled_f16<SDF_ATTN_ANN, 8>(P, s);
       if (pipe16 && nt == 11) return launch_tiled_f16<SDF_ATTN_ANN, 11>(P, s);
