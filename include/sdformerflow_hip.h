@@ -628,6 +628,39 @@ typedef struct SdfWinAttnDesc {
 
 int sdf_win_attn_fwd(const SdfWinAttnDesc* d, void* stream);
 
+/* ---- the attention half of an ANN video-swin block as one launch (BASELINE config 3, first stage) -----------------
+ * Replaces `SwinTransformerBlock3D.forward_part1` + the shortcut (reference models/STSwinNet/swin_transformer3D_v2.py:272-310, :331)
+ * with `WindowAttention3D.forward` (:169-205) inside:
+ *   out = x + proj(softmax(normalize(q) normalize(k)^T * logit_scale + bias (+ mask)) v),  q | k | v = LayerNorm(x) Wqkv^T + qkv_bias
+ * over the windows `row_map` describes (the table of sdf_window_slice_map: row_map[b_ * N + n] = row of token n of window b_ in the
+ * (rows, C) tensors, -1 = a padding token: a zero row behind the norm, its output dropped).  q | k | v never exist in memory.
+ * Built for C = 96, nH = 3, N = 162 (sdf_ann_attn_block_supported); other shapes: SDF_E_SHAPE, the caller keeps
+ * sdf_layer_norm_fwd + sdf_dense_linear_fwd + sdf_win_attn_fwd + sdf_dense_linear_fwd.  x == out is allowed (windows are disjoint).
+ * wqkv: fp16 planes [2][3C][C] with W = plane0 + plane1 (plane0 = fp16(W), plane1 = fp16(W - plane0)), rows in the module's
+ * order (q | k | v).  wproj: fp16 planes [2][C][C] of the projection weight with the input channels of every head g in the
+ * kernel's accumulator order: wproj[., o, 32 g + 8 a + i] = Wproj[o, 32 g + (i < 4 ? 4 a + i : 16 + 4 a + i - 4)], a = 0..3, i = 0..7. */
+typedef struct SdfAnnAttnBlockDesc {
+  const float* x;            /* (rows, C) */
+  float* out;                /* (rows, C) */
+  const int32_t* row_map;    /* (B_ * N) */
+  int32_t B_, nW, nH, N, C;
+  int64_t rows;
+  const float* ln_w;         /* (C) */
+  const float* ln_b;         /* (C) */
+  float ln_eps;
+  const uint16_t* wqkv;      /* fp16 planes [2][3C][C] */
+  const float* qkv_bias;     /* (3C) or NULL */
+  const float* scale;        /* (nH): exp(min(logit_scale, ln 100)) * log2(e) */
+  const float* table;        /* (nW, nH, N, N): (16 sigmoid(cpb_mlp(...))[h] + mask[w]) * log2(e), combined once per parameter version
+                              * (nW = 1 and no mask for un-shifted windows): the softmax runs in the log2 domain and the score's
+                              * additions are the matrix pipe's accumulator input */
+  const uint16_t* wproj;     /* fp16 planes [2][C][C], input channels permuted (above) */
+  const float* proj_bias;    /* (C) or NULL */
+} SdfAnnAttnBlockDesc;
+
+int sdf_ann_attn_block_supported(int C, int nH, int N);
+int sdf_ann_attn_block_fwd(const SdfAnnAttnBlockDesc* d, void* stream);
+
 /* ---- dense 3x3 convolution of real-valued activations (ANN patch embedding, BASELINE config 3) ----------------------
  * Replaces the library convolutions of reference models/STSwinNet/PatchEmbed.py:166-196 (`PatchEmbedLocal`: head Conv2d +
  * four `ResidualBlock`s, models/submodules.py:160-229) together with their BatchNorm2d (eval: folded to alpha / beta), residual

@@ -138,10 +138,25 @@ class WindowAttention3D(nn.Module):
             o = hip.win_attn_ann(qkv, scale, bias, None if mask is None else mask.contiguous(), self.num_heads)
             return self.proj(o), None
 
-    def forward_rows(self, y2, row_map, B_, mask, resid=None):
+    def forward_rows(self, y2, row_map, B_, mask, resid=None, norm=None):
         """Attention on un-partitioned rows y2 (rows, C): windows are formed by `row_map` inside the kernel -> (rows, C),
-        plus `resid` (the block's shortcut, added in the projection's epilogue)."""
+        plus `resid` (the block's shortcut, added in the projection's epilogue).  y2 None: `resid` is the block input x and `norm`
+        its LayerNorm - the whole half block x + proj(attention(norm(x))) as one launch (csrc/ann_block.hip)."""
         with torch.no_grad():
+            if y2 is None:
+                stamp = (self.qkv.weight.data_ptr(), self.qkv.weight._version, self.proj.weight.data_ptr(), self.proj.weight._version)
+                if getattr(self, "_blk_stamp", None) != stamp:
+                    self._blk, self._blk_stamp = hip.pack_ann_attn_block_weights(self.qkv.weight, self.proj.weight, self.num_heads), stamp
+                bias, scale = self._bias_and_scale()
+                tkey = (bias.data_ptr(), None if mask is None else (mask.data_ptr(), mask._version))
+                if getattr(self, "_tab_key", None) != tkey:               # (bias + mask) * log2 e: once per parameter version and mask
+                    self._tab, self._tab_key = hip.ann_attn_block_table(scale, bias, mask), tkey
+                    self._tab_keep = (bias, mask)                          # (the key's pointers stay valid while the table does)
+                N = self.window_size[0] * self.window_size[1] * self.window_size[2]
+                x2 = resid.contiguous()
+                return hip.ann_attn_block(x2, torch.empty_like(x2), row_map, B_, N, self.num_heads, norm.weight.detach(), norm.bias.detach(),
+                                          norm.eps, self._blk[0], None if self.qkv.bias is None else self.qkv.bias.detach(), self._tab[0],
+                                          self._tab[1], self._blk[1], None if self.proj.bias is None else self.proj.bias.detach())
             qkv = linear_rows(self.qkv, y2)
             pad = self.qkv.bias.detach().float().contiguous() if self.qkv.bias is not None else torch.zeros(3 * self.dim, device=y2.device)
             bias, scale = self._bias_and_scale()
@@ -196,11 +211,16 @@ class SwinTransformerBlock3D(nn.Module):
             # the nominal window, to the smaller scores (:190, RuntimeError); the same input is refused here, not mis-addressed
             raise RuntimeError(f"feature map {(D, H, W)} is smaller than the window {self.window_size}: the relative position bias of "
                                "WindowAttention3D is defined for the nominal window only (reference swin_transformer3D_v2.py:184-190)")
-        y = layer_norm(self.norm1, x)
+        materialise = os.environ.get("SDF_ATTN_MATERIALISE") == "1" or self.training
+        # first stage (C = 96, three heads, 162-token windows): LayerNorm -> qkv -> attention -> proj -> + x is ONE launch that reads x
+        # through the slice map (csrc/ann_block.hip); elsewhere the norm runs here and forward_rows takes its output
+        fused = (not materialise and x.is_cuda and x.dtype == torch.float32 and self.norm1.elementwise_affine and self.norm1.bias is not None
+                 and hip.ann_attn_block_supported(C, self.num_heads, ws[0] * ws[1] * ws[2]) and x.numel() * 4 < 1 << 31)
+        y = None if fused else layer_norm(self.norm1, x)
         Dp, Hp, Wp = D + (-D) % ws[0], H + (-H) % ws[1], W + (-W) % ws[2]
         shifted = any(s > 0 for s in ss)
         mask = (mask_matrix if mask_matrix is not None else compute_mask(Dp, Hp, Wp, ws, ss, x.device)) if shifted else None
-        if os.environ.get("SDF_ATTN_MATERIALISE") == "1" or self.training:
+        if materialise:
             y = F.pad(y, (0, 0, 0, Wp - W, 0, Hp - H, 0, Dp - D))
             if shifted:
                 y = torch.roll(y, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
@@ -219,8 +239,8 @@ class SwinTransformerBlock3D(nn.Module):
             else:
                 maps[key] = maps.pop(key)                               # most recently used last
             row_map, B_ = maps[key]
-            x = self.attn.forward_rows(y.reshape(-1, C), row_map, B_, None if mask is None else mask.contiguous(),
-                                       x.reshape(-1, C)).view(B, D, H, W, C)
+            x = self.attn.forward_rows(y.reshape(-1, C) if y is not None else None, row_map, B_, None if mask is None else mask.contiguous(),
+                                       x.reshape(-1, C), norm=self.norm1).view(B, D, H, W, C)
         return self.mlp(layer_norm(self.norm2, x), x)
 
 

@@ -84,6 +84,14 @@ class WinAttnDesc(C.Structure):
                 ("scale", C.c_void_p), ("bias", C.c_void_p), ("mask", C.c_void_p), ("row_map", C.c_void_p), ("pad_qkv", C.c_void_p)]
 
 
+class AnnAttnBlockDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("row_map", C.c_void_p),
+                ("B_", C.c_int32), ("nW", C.c_int32), ("nH", C.c_int32), ("N", C.c_int32), ("C", C.c_int32), ("rows", C.c_int64),
+                ("ln_w", C.c_void_p), ("ln_b", C.c_void_p), ("ln_eps", C.c_float),
+                ("wqkv", C.c_void_p), ("qkv_bias", C.c_void_p), ("scale", C.c_void_p), ("table", C.c_void_p),
+                ("wproj", C.c_void_p), ("proj_bias", C.c_void_p)]
+
+
 class DenseConvDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("alpha", C.c_void_p), ("beta", C.c_void_p), ("resid", C.c_void_p),
                 ("out", C.c_void_p), ("imgs", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("cin_records", C.c_int32),
@@ -890,6 +898,53 @@ def win_attn_ann_windowed(qkv, row_map, B_, N, pad_qkv, scale, bias, mask, nH):
     d.scale, d.bias, d.mask = _ptr(scale, torch.float32), _ptr(bias, torch.float32), _ptr(mask, torch.float32)
     d.row_map, d.pad_qkv = _ptr(row_map, torch.int32), _ptr(pad_qkv, torch.float32)
     _check(lib().sdf_win_attn_fwd(C.byref(d), _stream()), "sdf_win_attn_fwd")
+    return out
+
+
+def ann_attn_block_supported(Cc, nH, N):
+    """Mirror of sdf_ann_attn_block_supported: the one-launch attention half block is built for C = 96, three heads, windows of 162.
+    SDF_ANN_BLOCK=0 (A/B) and SDF_DENSE_LINEAR=0 (library GEMMs for every Linear, the two inside this kernel included) select the
+    four-launch path."""
+    return (Cc, nH, N) == (96, 3, 162) and os.environ.get("SDF_ANN_BLOCK", "1") != "0" and os.environ.get("SDF_DENSE_LINEAR", "1") != "0"
+
+
+def pack_ann_attn_block_weights(wqkv, wproj, nH):
+    """fp16 hi / lo planes of the qkv weight (3C, C) as it stands and of the projection weight (C, C) with the 32 input channels of
+    every head in the kernel's accumulator order (include/sdformerflow_hip.h: SdfAnnAttnBlockDesc) -> (planes (2,3C,C), planes (2,C,C))."""
+    def planes(w):
+        w = w.detach().float()
+        hi = w.half()
+        return torch.stack([hi, (w - hi.float()).half()]).contiguous()
+    Cc = wproj.shape[0]
+    j = torch.arange(32)
+    a, i = j // 8, j % 8
+    perm = torch.where(i < 4, 4 * a + i, 16 + 4 * a + i - 4)
+    idx = (torch.arange(nH)[:, None] * 32 + perm[None, :]).reshape(-1).to(wproj.device)
+    return planes(wqkv), planes(wproj.detach()[:, idx])
+
+
+LOG2E = 1.4426950408889634
+
+
+def ann_attn_block_table(scale, bias, mask):
+    """(logit scale * log2 e (nH,), ((bias[h] + mask[w]) * log2 e) (nW, nH, N, N)) - what sdf_ann_attn_block_fwd reads: the softmax runs
+    in the log2 domain and the additions of the score are the matrix pipe's accumulator input.  Once per parameter version / mask."""
+    t = bias[None] if mask is None else bias[None] + mask[:, None]
+    return (scale * LOG2E).contiguous(), (t * LOG2E).contiguous()
+
+
+def ann_attn_block(x, out, row_map, B_, N, nH, ln_w, ln_b, ln_eps, wqkv_planes, qkv_bias, scale2, table, wproj_planes, proj_bias):
+    """sdf_ann_attn_block_fwd: out = x + proj(window attention(LayerNorm(x))) on rows x (rows, C) fp32 through the slice map, one launch
+    (reference swin_transformer3D_v2.py:272-310 + :331).  (scale2, table) = ann_attn_block_table(...).  out may be x."""
+    rows, Cc = x.shape
+    d = AnnAttnBlockDesc()
+    d.x, d.out, d.row_map = _ptr(x, torch.float32), _ptr(out, torch.float32), _ptr(row_map, torch.int32)
+    d.B_, d.nW, d.nH, d.N, d.C, d.rows = B_, table.shape[0], nH, N, Cc, rows
+    d.ln_w, d.ln_b, d.ln_eps = _ptr(ln_w, torch.float32), _ptr(ln_b, torch.float32), float(ln_eps)
+    d.wqkv, d.qkv_bias = _ptr(wqkv_planes, torch.float16), _ptr(qkv_bias, torch.float32)
+    d.scale, d.table = _ptr(scale2, torch.float32), _ptr(table, torch.float32)
+    d.wproj, d.proj_bias = _ptr(wproj_planes, torch.float16), _ptr(proj_bias, torch.float32)
+    _check(lib().sdf_ann_attn_block_fwd(C.byref(d), _stream()), "sdf_ann_attn_block_fwd")
     return out
 
 
