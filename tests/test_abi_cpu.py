@@ -78,6 +78,16 @@ def test_argument_errors_are_reported_before_any_launch():
     d.mode, d.q, d.k, d.v, d.out, d.scale, d.bias = 0, 0x10000, 0x10000, 0x10000, 0x10000, 0x10000, 0x10000
     d.B_, d.nW, d.nH, d.N, d.hd = 4, 1, 3, 162, 16
     assert lib.sdf_win_attn_fwd(C.byref(d), None) == E_SHAPE    # head dim must be 32
+    # the one-launch attention half block (round 5): built for C = 96 / 3 heads / 162-token windows, refused before any launch otherwise
+    assert lib.sdf_ann_attn_block_supported(96, 3, 162) == 1 and lib.sdf_ann_attn_block_supported(192, 6, 162) == 0
+    ab = hip.AnnAttnBlockDesc()
+    assert lib.sdf_ann_attn_block_fwd(None, None) == E_NULL and lib.sdf_ann_attn_block_fwd(C.byref(ab), None) == E_NULL
+    for f in ("x", "out", "row_map", "ln_w", "ln_b", "wqkv", "wproj", "scale", "table"):
+        setattr(ab, f, 0x10000)
+    ab.B_, ab.nW, ab.nH, ab.N, ab.C, ab.rows = 8, 4, 6, 162, 192, 1296
+    assert lib.sdf_ann_attn_block_fwd(C.byref(ab), None) == E_SHAPE
+    ab.nH, ab.C, ab.nW = 3, 96, 3
+    assert lib.sdf_ann_attn_block_fwd(C.byref(ab), None) == E_SHAPE     # windows must be a multiple of the mask tables
     d.hd, d.N = 32, 200
     assert lib.sdf_win_attn_fwd(C.byref(d), None) == E_SHAPE    # at most 192 tokens per window
     d.N, d.mode = 162, 5
