@@ -93,7 +93,10 @@ struct MlpGeo {
   static constexpr int PPW = 4 * PPG;              // positions per row group (wave)
   static constexpr int PPI = PPW * RG;             // positions per work item (workgroup)
   static constexpr int A1P = C + 16, A2P = CH + 16;                 // LDS row pitches (bytes): pitch / 4 = 4 x odd dwords
-  static constexpr int W1P = (C + 8) * 2, W2P = (CH + 8) * 2;       // weight row pitches (bytes)
+  // weight row pitches (bytes): 4 m + 2 pieces of 16 bytes - conflict-free for the (row = lane % 16, piece = lane / 16) fragment
+  // reads under ds_read_b128's real, non-contiguous lane groups (round 5, brute force; the "4 x odd dwords" pitch of rounds 2 - 4,
+  // 13 pieces at C = 96, made every group a 2-way conflict: 36 % of this kernel's LDS cycles, profiles/r5q_pmc_forward.txt)
+  static constexpr int W1P = (C + 16) * 2, W2P = (CH + 16) * 2;
   static constexpr int W1B = NSPLIT * CH * W1P, W2B = NSPLIT * C * W2P;
   static constexpr int WB = W1B > W2B ? W1B : W2B;
   static constexpr int A1B = RG * ROWS * A1P, A2B = RG * ROWS * A2P;
@@ -108,7 +111,7 @@ struct MlpGeo {
   static_assert(SLOTS % T == 0, "T must divide the 20 accumulator slots of a lane");
   static_assert(CH % 32 == 0 && C % 32 == 0, "K steps are 32 deep");
   static_assert((A1P / 4) % 8 == 4 && (A2P / 4) % 8 == 4, "spike image pitches must be 4 x odd dwords");
-  static_assert((W1P / 4) % 8 == 4 && (W2P / 4) % 8 == 4, "weight pitches must be 4 x odd dwords");
+  static_assert((W1P / 16) % 4 == 2 && (W2P / 16) % 4 == 2, "weight pitches must be 4 m + 2 pieces");
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 

@@ -435,7 +435,10 @@ struct GeoI8 {
   static constexpr int KS = (NP + 1) / 2;                             // K steps of 32 (two pieces: one per half wave); odd NP: one zero piece
   static constexpr int PS = (S2 && CIN16 % 2) ? CIN : CIN + 16;       // pixel stride: 4 x odd dwords (16-byte fragment reads)
   static constexpr int XE = (HW8 + 1) / 2;                            // S2: entries of the even-column plane
-  static constexpr int RPB = S2 ? HW8 * PS : (HW8 * PS + 255) / 256 * 256;   // halo row pitch (stride 1: a whole number of bank rounds)
+  // halo row pitch: the two pixel rows of a wave's fragment read (one row apart at stride 1, two at stride 2) a whole number of
+  // bank rounds apart - ds_read_b128's 16-lane groups mix lanes of both rows (brute force over pitches: the unpadded 1 584 bytes of the
+  // stride-2 halo made every group a 2-way conflict)
+  static constexpr int RPB = S2 ? (HW8 * PS + 127) / 128 * 128 : (HW8 * PS + 255) / 256 * 256;
   static constexpr int HALO = HH8 * RPB;
   static constexpr int WP = 32 * KS * KH + 16;                        // digit-plane row pitch (bytes): 4 x odd dwords
   static constexpr int RCH = HW8 * CIN16;                             // 16-byte pieces of a halo row: one per lane of a half group
