@@ -131,7 +131,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4h;
 
 template <int T, int CIN, int NOUT, bool FAST>
-__global__ __launch_bounds__(256) void head_conv_mfma_kernel(HeadParams P, int tiles) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void head_conv_mfma_kernel(HeadParams P, int tiles) {
   constexpr int KS = 9 * CIN / 2, NBLK = (NOUT + 31) / 32, TF = 5, ROW = 32 * NOUT;        // ROW: spike bytes of a tile per time step
   static_assert(T % TF == 0, "flush period");
   const SdfHeadConvDesc& d = P.d;
