@@ -214,7 +214,32 @@ def time_config3(iters=10):
     t = _timed(lambda s_: hip.dense_conv3x3(s_[0], wp, al, be, s_[1], True), sets, 20)
     flop = 2 * B * H * W * 96 * 864 * 2
     del sets
+    # the attention half of a first-stage block (704 windows of 162 tokens, C = 96): the one-launch kernel against the four launches it
+    # replaces (LayerNorm, qkv Linear, window attention, proj Linear), HIP events on the launch stream, four input sets in rotation
+    half = {}
+    try:
+        from sdformerflow_amd.STSwinNet.swin_transformer3D_v2 import SwinTransformerBlock3D, compute_mask, layer_norm
+        blocks = [m for m in net.modules() if isinstance(m, SwinTransformerBlock3D) and m.dim == 96]
+        for name, blk in (("plain", blocks[0]), ("shifted", blocks[1])):
+            ws, ss = blk.window_size, blk.shift_size
+            D_, H_, W_ = 2, 72, 96
+            row_map, B_ = hip.window_slice_map(B, D_, H_, W_, ws, ss, "cuda")
+            pad = [d + (-d) % w for d, w in zip((D_, H_, W_), ws)]
+            mask = compute_mask(*pad, ws, ss, torch.device("cuda")).contiguous() if any(ss) else None
+            xs = [torch.randn(B * D_ * H_ * W_, 96, generator=g).cuda() for _ in range(4)]
+            with torch.no_grad():
+                t1 = _timed(lambda x2: blk.attn.forward_rows(None, row_map, B_, mask, x2, norm=blk.norm1), xs, 20)
+                t4 = _timed(lambda x2: blk.attn.forward_rows(layer_norm(blk.norm1, x2), row_map, B_, mask, x2), xs, 20)
+            fl = B_ * (2 * 162 * 96 * 288 + 4 * 162 * 162 * 32 * 3 + 2 * 162 * 96 * 96)
+            half[name] = {"one_launch_us": t1 * 1e6, "four_launches_us": t4 * 1e6, "windows": B_, "algorithmic_gflop": fl / 1e9,
+                          "tflops": fl / t1 / 1e12, "frac_of_2500": fl / t1 / 1e12 / 2500.0}
+        half["note"] = ("x + proj(window attention(LayerNorm(x))) of BASELINE configs[2]'s first stage (8 x 2 x 72 x 96 tokens, C = 96, three heads): "
+                        "csrc/ann_block.hip (q | k | v never in HBM) against sdf_layer_norm_fwd + sdf_dense_linear_fwd + sdf_win_attn_fwd + "
+                        "sdf_dense_linear_fwd; matrix pipe busy 24.7 % (profiles/r5z_pmc_ann_block.txt)")
+    except Exception as e:                                         # a side line must never take the headline down with it
+        half = {"error": repr(e)[:300]}
     return {"workload": "BASELINE configs[2]: STTFlowNet (ANN) forward, batch 8, 20-bin 288x384 voxel, fp32 activations", "samples_per_s": B / dt,
+            "attention_half_block_stage0": half,
             "ms_per_batch": dt * 1e3, "dtype": "f32 as f16x2 (hi + lo planes of both operands, three products, fp32 accumulate)",
             "roofline": {"kernel": "dense_conv_wres_kernel<6> (16 x 96 x 288 x 384, 3x3, BN + residual + ReLU fused)", "bound": "mfma",
                          "achieved": flop / t / 1e12, "executed_on_pipe": 3 * flop / t / 1e12, "peak": 2500.0, "unit": "TFLOP/s",

@@ -33,6 +33,14 @@
 // Compiled with -ffp-contract=off.
 #include "common.h"
 
+#ifdef SDF_STAMP
+// diagnostic build only (tools/stamp_ann_block.sh): 100 MHz timestamps of wave 0 of three workgroups along the kernel's phases
+__device__ unsigned long long g_ann_stamp[3 * 24];
+#define STAMP(i) do { if (st_on) st_buf[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(i)
+#endif
+
 namespace {
 
 constexpr int C = 96, NH = 3, HD = 32, N = 162, NTC = 11, NP = NTC * 16;
@@ -104,6 +112,13 @@ __global__ __launch_bounds__(NTHR) void ann_attn_block_kernel(BlockParams P) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
   const bool worker = wave < NTC;                // the twelfth wave only helps to stage weights
+#ifdef SDF_STAMP
+  const int st_slot = blockIdx.x == 0 ? 0 : (blockIdx.x == 300 ? 1 : (blockIdx.x == 600 ? 2 : -1));
+  const bool st_on = st_slot >= 0 && tid == 0;
+  unsigned long long st_buf[24];
+  for (int i = 0; i < 24; ++i) st_buf[i] = 0;
+#endif
+  STAMP(0);
 
   const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, 0x7FFFFFFF, 0x00020000);
   const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, 0x7FFFFFFF, 0x00020000);
@@ -185,6 +200,7 @@ __global__ __launch_bounds__(NTHR) void ann_attn_block_kernel(BlockParams P) {
     }
   };
   request_head(0);
+  STAMP(1);
 
 #pragma unroll 1
   for (int g = 0; g < NH; ++g) {
@@ -207,6 +223,7 @@ __global__ __launch_bounds__(NTHR) void ann_attn_block_kernel(BlockParams P) {
       }
     }
     __syncthreads();                                                // every wave is done with the previous head's weights, K and V
+    STAMP(2 + 5 * g);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int i = tid + NTHR * j;
@@ -214,6 +231,7 @@ __global__ __launch_bounds__(NTHR) void ann_attn_block_kernel(BlockParams P) {
       *reinterpret_cast<u32x4*>(Wg + prow * WPB + pc * 16) = wpre[j];
     }
     __syncthreads();
+    STAMP(3 + 5 * g);
     f16x8 q_hi, q_lo;
     if (worker) {
       // ---- Q^T and K^T of the wave's tokens: weights as rows, a lane ends with dims 4 lg + r (dt = 0) and 16 + 4 lg + r (dt = 1) ----
@@ -270,7 +288,9 @@ __global__ __launch_bounds__(NTHR) void ann_attn_block_kernel(BlockParams P) {
         *reinterpret_cast<u32x4*>(Vt + (((4 * wave + lg) * HD) + 16 * dt + l15) * 16) = u32x4{h01, h23, l01, l23};
       }
     }
+    STAMP(4 + 5 * g);
     __syncthreads();                                                // K and V of the window are complete
+    STAMP(5 + 5 * g);
     if (g + 1 < NH) request_head(g + 1);
     if (worker && wave * 16 < N) {
       // ---- S^T = K Q^T on top of the table row: the scores land in the softmax's log2 domain ----
@@ -329,6 +349,7 @@ __global__ __launch_bounds__(NTHR) void ann_attn_block_kernel(BlockParams P) {
         pacc[ct] = mma3(wh, wl, o_hi, o_lo, pacc[ct]);
       }
     }
+    STAMP(6 + 5 * g);
   }
   // ---- + projection bias + shortcut, rows back through the slice map ----
   if (row >= 0) {
@@ -346,9 +367,20 @@ __global__ __launch_bounds__(NTHR) void ann_attn_block_kernel(BlockParams P) {
                                              o_rs, ro, 64 * ct, 0);
     }
   }
+#ifdef SDF_STAMP
+  __builtin_amdgcn_s_waitcnt(0);
+  STAMP(17);
+  if (st_on) for (int i = 0; i < 24; ++i) g_ann_stamp[st_slot * 24 + i] = st_buf[i];
+#endif
 }
 
 }  // namespace
+
+#ifdef SDF_STAMP
+extern "C" int sdf_debug_read_stamps_ann(unsigned long long* host72) {
+  return (int)hipMemcpyFromSymbol(host72, HIP_SYMBOL(g_ann_stamp), 72 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" int sdf_ann_attn_block_supported(int C_, int nH, int N_) { return C_ == C && nH == NH && N_ == N; }
 
