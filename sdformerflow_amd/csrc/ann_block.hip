@@ -125,28 +125,51 @@ __global__ __launch_bounds__(NTHR) void ann_attn_block_kernel(BlockParams P) {
   const __amdgpu_buffer_rsrc_t wq_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(d.wqkv), 0, 2 * 3 * C * C * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t wp_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(d.wproj), 0, 2 * C * C * 2, 0x00020000);
 
-  // ---- the projection weights: 2 planes x 96 rows x 12 pieces of 16 bytes, once per workgroup ----
-  for (int i = tid; i < 2 * C * 12; i += NTHR) {
-    const int row = i / 12, pc = i - row * 12;                      // row = plane * 96 + out channel
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wp_rs, (uint32_t)(row * C * 2 + pc * 16), 0, 0);
-    *reinterpret_cast<u32x4*>(Wp + row * WPB + pc * 16) = v;
-  }
-
-  // ---- this wave's 16 tokens: rows of x -> LayerNorm -> fp16 hi / lo operand (channels 32 s + 8 lg + 0..7 of token l15) ----
+  // ---- requests first, in the order of their dependency depth: the slice-map entry of this lane's token (the rows of x hang on it),
+  // the projection weights (2 planes x 96 rows x 12 pieces of 16 bytes = 3 per thread, stored to LDS behind the x requests) ----
   const int tok = wave * 16 + l15;                                  // token of this lane in the window
   int row = -1;
   if (worker && tok < N) row = d.row_map[(int64_t)b * N + tok];
+  u32x4 wpv[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int i = tid + NTHR * j, prow = i / 12, pc = i - prow * 12;   // prow = plane * 96 + out channel
+    wpv[j] = __builtin_amdgcn_raw_buffer_load_b128(wp_rs, (uint32_t)(prow * C * 2 + pc * 16), 0, 0);
+  }
+  // the LayerNorm's weight / bias of this lane's 24 channels: requested now - behind the rows of x each of the three channel groups
+  // paid its own L2 round trip (stamps: 3 - 4 us of a window's 37)
+  float4 lng[3][2], lnb[3][2];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    lng[s][0] = *reinterpret_cast<const float4*>(d.ln_w + 32 * s + 8 * lg); lng[s][1] = *reinterpret_cast<const float4*>(d.ln_w + 32 * s + 8 * lg + 4);
+    lnb[s][0] = *reinterpret_cast<const float4*>(d.ln_b + 32 * s + 8 * lg); lnb[s][1] = *reinterpret_cast<const float4*>(d.ln_b + 32 * s + 8 * lg + 4);
+  }
+  // ---- this wave's 16 tokens: rows of x -> LayerNorm -> fp16 hi / lo operand (channels 32 s + 8 lg + 0..7 of token l15) ----
   f16x8 yh[3], yl[3];
   {
     float xv[3][8];
     const uint32_t xo = row >= 0 ? (uint32_t)row * (uint32_t)(C * 4) + (uint32_t)(32 * lg) : INV_OFF;
+#ifdef SDF_STAMP
+    asm volatile("" ::"v"(xo));
+    STAMP(18);
+#endif
+    u32x4 xa[3], xc[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-      const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(x_rs, xo, s * 128, 0);
-      const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(x_rs, xo, s * 128 + 16, 0);
+      xa[s] = __builtin_amdgcn_raw_buffer_load_b128(x_rs, xo, s * 128, 0);
+      xc[s] = __builtin_amdgcn_raw_buffer_load_b128(x_rs, xo, s * 128 + 16, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const u32x4 a = xa[s], c = xc[s];
       xv[s][0] = __uint_as_float(a.x); xv[s][1] = __uint_as_float(a.y); xv[s][2] = __uint_as_float(a.z); xv[s][3] = __uint_as_float(a.w);
       xv[s][4] = __uint_as_float(c.x); xv[s][5] = __uint_as_float(c.y); xv[s][6] = __uint_as_float(c.z); xv[s][7] = __uint_as_float(c.w);
     }
+#ifdef SDF_STAMP
+    STAMP(19);
+    asm volatile("" ::"v"(xv[2][7]));
+    STAMP(20);
+#endif
     float sum = 0.f;
 #pragma unroll
     for (int s = 0; s < 3; ++s)
@@ -168,8 +191,7 @@ __global__ __launch_bounds__(NTHR) void ann_attn_block_kernel(BlockParams P) {
     const float rstd = 1.f / sqrtf(sq * (1.f / C) + d.ln_eps);      // biased variance (torch.nn.LayerNorm)
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-      const float4 g0 = *reinterpret_cast<const float4*>(d.ln_w + 32 * s + 8 * lg), g1 = *reinterpret_cast<const float4*>(d.ln_w + 32 * s + 8 * lg + 4);
-      const float4 b0 = *reinterpret_cast<const float4*>(d.ln_b + 32 * s + 8 * lg), b1 = *reinterpret_cast<const float4*>(d.ln_b + 32 * s + 8 * lg + 4);
+      const float4 g0 = lng[s][0], g1 = lng[s][1], b0 = lnb[s][0], b1 = lnb[s][1];
       const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
       float y[8];
 #pragma unroll
@@ -177,7 +199,16 @@ __global__ __launch_bounds__(NTHR) void ann_attn_block_kernel(BlockParams P) {
       split8(y, yh[s], yl[s]);
     }
   }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {                                     // the projection weights (long since arrived) into LDS
+    const int i = tid + NTHR * j, prow = i / 12, pc = i - prow * 12;
+    *reinterpret_cast<u32x4*>(Wp + prow * WPB + pc * 16) = wpv[j];
+  }
 
+#ifdef SDF_STAMP
+  asm volatile("" ::"v"(yl[2]));
+  STAMP(21);
+#endif
   f32x4 pacc[6];                                                    // out^T: channels 16 ct + 4 lg + r of token l15
 #pragma unroll
   for (int ct = 0; ct < 6; ++ct) pacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};

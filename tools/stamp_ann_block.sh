@@ -34,6 +34,8 @@ for wg, slot in ((0, 0), (300, 1), (600, 2)):
     o = list(b[24 * slot:24 * slot + 24])
     idx = [0, 1] + [2 + 5 * g + k for g in range(3) for k in range(5)] + [17]
     print(f"workgroup {wg}, wave 0 (100 MHz ticks -> us): total {(o[17] - o[0]) / 100:.2f} us")
+    print(f"    prologue: slice-map entry arrived {(o[18] - o[0]) / 100:.2f} | projection weights arrived {(o[19] - o[18]) / 100:.2f} | rows of x arrived {(o[20] - o[19]) / 100:.2f} | "
+          f"LayerNorm + split {(o[21] - o[20]) / 100:.2f} | table row + weight requests issued {(o[1] - o[21]) / 100:.2f} us")
     prev = o[0]
     for i, nm in zip(idx[1:], names[1:]):
         print(f"    {nm:45s} {(o[i] - prev) / 100:6.2f} us")
