@@ -921,8 +921,9 @@ int launch_spike_conv_wres(const GemmParams& Pin, hipStream_t s) {
       // tiles_n with every workgroup's share still `per` items
       static const bool cbi = [] { const char* e = getenv("SDF_CONV_WRES_CB_INNER"); return !e || e[0] != '0'; }();
       if (cbi && P.ntiles >= 64) {
-        const int nr = (P.tiles_m + per - 1) / per;                     // tile ranges of at most `per` items
-        const int g2 = nr * P.tiles_n;
+        int nr = (P.tiles_m + per - 1) / per;                           // tile ranges of at most `per` items ...
+        while (nr * P.tiles_n <= 256 && (nr * P.tiles_n) % 8) ++nr;     // ... a few more of them where that makes the grid a multiple of 8
+        const int g2 = nr * P.tiles_n;                                  // (the kernel splits tiles_m evenly over the ranges)
         if (g2 <= 256 && g2 % 8 == 0) { G = g2; P.cb_inner = 1; }
       }
     }
