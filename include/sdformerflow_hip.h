@@ -426,6 +426,29 @@ typedef struct SdfMsMergeDesc {
 int sdf_ms_patch_merge_fwd(const SdfMsMergeDesc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Stride-2 3x3 transposed convolution on spikes as ONE product (round 5; csrc/ms_res.hip):
+ *   out[img, oy, ox, co] = alpha[co] * sum_{ky, kx, c : oy = 2 iy - 1 + ky, ox = 2 ix - 1 + kx} S[img, iy, ix, c] W[c, co, ky, kx] + beta[co]
+ * - `layer.ConvTranspose2d(3, stride 2, padding 1, output_padding 1)` + the decoder's BatchNorm behind its neuron (reference
+ * MS_SpikingTransposeDecoderLayer, Spiking_modules.py:461-474).  A row of the product is an input pixel (img, a, b), its K = 4 Cin the
+ * 2 x 2 input neighbourhood (a..a+1, b..b+1; zero beyond the image) in patch merging's quadrant order (dh, dw) = (q % 2, q / 2), its
+ * N = 4 Cout columns the four output pixels (2a + py, 2b + px) of the row's 2 x 2 output block, column (2 py + px) Cout + co: the weight
+ * matrix holds W[., ., ky, kx] in the blocks a tap reaches and zeros elsewhere (7 of 16 blocks), as int8 digit planes
+ * (sdf_split_weight_i8x3 of the (4 Cout, 4 Cin) matrix).  The four parity-class convolutions it replaces wrote every other pixel of a
+ * row each (half-written 128-byte lines: twice the output's bytes reached HBM); here a row's two output pixels of a line are stored together.
+ * S (imgs, H, W, Cin) u8 NHWC, imgs % T == 0 with T in {10, 20}; Cin % 16 == 0, 4 Cin <= 1024; Cout % 8 == 0; out (imgs, 2H, 2W, Cout)
+ * fp32; alpha / beta (4 Cout): the BatchNorm pair of channel co at every column (2 py + px) Cout + co, or NULL.  SDF_E_SHAPE otherwise
+ * (the caller keeps sdf_spike_conv2d_multi_fwd). */
+typedef struct SdfSpikeDeconvDesc {
+  const uint8_t* spikes;
+  const int8_t* digits; const float* cscale;   /* [3][4 Cout][4 Cin] + (4 Cout) */
+  const float* alpha; const float* beta;       /* (4 Cout) or NULL */
+  float* out;
+  int32_t imgs, T, H, W, Cin, Cout;
+} SdfSpikeDeconvDesc;
+
+int sdf_spike_deconv3x3s2_fwd(const SdfSpikeDeconvDesc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Spike convolution (implicit GEMM):  out = epilogue( im2col(X) x W^T ) with X an NHWC u8 spike image batch.
  * Replaces: layer.Conv2d / nn.Conv2d / ConvTranspose2d on spikes + the SpikingNormLayer, shortcut add and
  * Spiking_neuron around it in the patch embedding and the U-Net tail (reference Spiking_modules.py:339-347,

@@ -198,7 +198,8 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
   constexpr int RB = RBW, CB = 2, ROWS = 16 * RB, SLOTS = 4 * RB, PPG = SLOTS / T, PPW = 4 * PPG, BN = 16 * CB;
   constexpr int SP = s_pitch(BN), STILE = ROWS * SP;
   static_assert(SLOTS % T == 0, "T must divide the 20 accumulator slots of a lane");
-  static_assert(EPI >= 1 && EPI <= 3 && (AM == 0 || AM == 2), "epilogue 1 neuron / 2 fp32 / 3 both; operand rows or merge quadrants");
+  static_assert(EPI >= 1 && EPI <= 3 && (AM == 0 || AM == 2 || AM == 3), "epilogue 1 neuron / 2 fp32 / 3 both; operand rows, merge quadrants or the transposed convolution's 2 x 2 neighbourhood");
+  static_assert(AM != 3 || EPI == 2, "the transposed convolution has the fp32 epilogue only");
   extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
   const int K = P.K, N = P.N, HW = P.HW, KP = res_kp(K);
   uint8_t* Wl = dyn;                                     // resident weights
@@ -249,7 +250,15 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
       const int32_t g = rowtab[16 * rb + lrow];
       a_base[rb] = INV;
       a_mask[rb] = 0;
-      if (AM == 2) {
+      if (AM == 3) {
+        if (g >= 0) {                                    // input pixel (img, a, b): its 2 x 2 neighbourhood (a + dh, b + dw), zero beyond the image
+          const uint32_t img = (uint32_t)g / (uint32_t)HW, pix = (uint32_t)g - img * (uint32_t)HW;
+          const uint32_t a = pix / (uint32_t)P.cv_W, b = pix - a * (uint32_t)P.cv_W;
+          a_base[rb] = (uint32_t)g * (uint32_t)P.cv_Cin;
+          const uint32_t hin = a + 1 < (uint32_t)P.cv_H ? 0xFu : 0x5u, win = b + 1 < (uint32_t)P.cv_W ? 0xFu : 0x3u;
+          a_mask[rb] = hin & win;
+        }
+      } else if (AM == 2) {
         if (g >= 0) {                                    // merged position (b, t, h2, w2) -> source pixel (2 h2, 2 w2) of the same (b, t)
           const uint32_t W2 = ((uint32_t)P.cv_W + 1u) >> 1, img = (uint32_t)g / (uint32_t)HW, pix = (uint32_t)g - img * (uint32_t)HW;
           const uint32_t h2 = pix / W2, w2 = pix - h2 * W2;
@@ -262,6 +271,19 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
       } else if (g >= 0) {
         a_base[rb] = P.zsrc ? (uint32_t)P.zsrc[g] + (uint32_t)(lq >> 1) * P.zg_G + 16u * (lq & 1) : (uint32_t)g * (uint32_t)K + 16u * lpc;
       }
+    }
+    if (AM == 3) {
+      // the epilogue addresses the OUTPUT: the table now takes the pixel index of (2a, 2b) in the (imgs, 2H, 2W) grid (same-wave LDS
+      // operations execute in order: every lane's reads above precede these writes)
+      for (int r = lane; r < ROWS; r += 64) {
+        const int32_t g = rowtab[r];
+        if (g >= 0) {
+          const uint32_t img = (uint32_t)g / (uint32_t)HW, pix = (uint32_t)g - img * (uint32_t)HW;
+          const uint32_t a = pix / (uint32_t)P.cv_W, b = pix - a * (uint32_t)P.cv_W;
+          rowtab[r] = (int32_t)(((img * 2u * (uint32_t)P.cv_H + 2u * a) * 2u * (uint32_t)P.cv_W) + 2u * b);
+        }
+      }
+      asm volatile("" ::: "memory");
     }
   };
   // this lane's piece of (step, row block).  Plain rows: piece 4 s + lq must exist (K % 64 != 0: the last step's upper pieces do not).
@@ -311,7 +333,7 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
     i32x4 acc[3][RB][CB];                                // (written by the main loop's first step)
     const int lpiece = STRIP ? ((lane & 3) ^ ((lane >> 4) & 2)) : lq;        // (the k-piece of a step this lane requests)
     uint8_t* strip = STRIP ? strips + wave * (RB * 1024) : nullptr;
-    if constexpr (AM == 2) {
+    if constexpr (AM >= 2) {
       AddrMerge aa{a_base, a_mask, lpiece, P.cv_Cin >> 4, P.cv_cpt, P.cv_W, P.cv_Cin, kpv};
       res_mainloop<RB, CB>(acc, A_rs, aa, ksteps, Wl, KP, lane, strip);
     } else {
@@ -370,7 +392,12 @@ __global__ __launch_bounds__(64 * NWV) void res_pm_kernel(WidePmParams P) {
           for (int e = 0; e < 4; ++e) {
             const float v = h[4 * rb + e] + res[cb][4 * rb + e];
             h[4 * rb + e] = v;
-            const uint32_t xo = (g4[e] >= 0 && n0 + 16 * cb + c < N) ? ((uint32_t)g4[e] * (uint32_t)P.ldo + (uint32_t)(n0 + c)) * 4u : INV;
+            uint32_t xo = (g4[e] >= 0 && n0 + 16 * cb + c < N) ? ((uint32_t)g4[e] * (uint32_t)P.ldo + (uint32_t)(n0 + c)) * 4u : INV;
+            if constexpr (AM == 3) {                     // column -> (output pixel of the row's 2 x 2 block, channel)
+              const uint32_t n = (uint32_t)(n0 + 16 * cb + c), cls = n / (uint32_t)P.dc_cout, co = n - cls * (uint32_t)P.dc_cout;
+              xo = (g4[e] >= 0 && n < (uint32_t)N)
+                       ? (((uint32_t)g4[e] + (cls >> 1) * 2u * (uint32_t)P.cv_W + (cls & 1u)) * (uint32_t)P.dc_cout + co) * 4u - 64u * cb : INV;
+            }
 #ifdef RES_X_NOST
             asm volatile("" :: "v"(v), "v"(xo));         // (diagnostic builds: the fp32 stores are dropped)
 #else
@@ -630,7 +657,8 @@ bool res_pm_takes(const WidePmParams& P, int T, int epi) {
   if (res_env_off() || !P.res_stage) return false;
   if (T != 10 && T != 20) return false;
   if (P.K % 16 || P.K < 32 || P.K > 1024 || P.N % 32 || P.ksplit > 1 || epi < 1 || epi > 3) return false;      // (K <= 1024: 96 KB of resident digits)
-  if (P.cv_Cin && !(epi == 2 && P.cv_Cin % 16 == 0 && 4 * P.cv_Cin == P.K && !P.zsrc && !P.a_tiled)) return false;      // (patch merging)
+  if (P.cv_Cin && !(epi == 2 && P.cv_Cin % 16 == 0 && 4 * P.cv_Cin == P.K && !P.zsrc && !P.a_tiled)) return false;      // (patch merging, transposed convolution)
+  if (P.dc_cout && !(P.cv_Cin && P.dc_cout % 4 == 0 && P.N == 4 * P.dc_cout && P.no_resid)) return false;
   if (P.zsrc && P.K % 32) return false;
   return true;
 }
@@ -659,7 +687,8 @@ int launch_res_pm(WidePmParams& P, int T, int epi, hipStream_t s) {
     P.cv_cpt = (65536 + (P.cv_Cin >> 4) - 1) / (P.cv_Cin >> 4);
     for (int p = 0; p < (P.K >> 4) + 8; ++p)
       if ((int)(((uint32_t)p * (uint32_t)P.cv_cpt) >> 16) != p / (P.cv_Cin >> 4)) return SDF_E_SHAPE;
-    rc = T == 10 ? res_pm_launch_t<10, 2>(P, epi, nk, grid, lds, s) : res_pm_launch_t<20, 2>(P, epi, nk, grid, lds, s);
+    if (P.dc_cout) rc = T == 10 ? res_pm_launch_t<10, 3>(P, epi, nk, grid, lds, s) : res_pm_launch_t<20, 3>(P, epi, nk, grid, lds, s);
+    else rc = T == 10 ? res_pm_launch_t<10, 2>(P, epi, nk, grid, lds, s) : res_pm_launch_t<20, 2>(P, epi, nk, grid, lds, s);
   } else {
     rc = T == 10 ? res_pm_launch_t<10, 0>(P, epi, nk, grid, lds, s) : res_pm_launch_t<20, 0>(P, epi, nk, grid, lds, s);
   }

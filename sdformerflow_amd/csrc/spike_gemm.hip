@@ -609,6 +609,30 @@ static int conv2d_build(const SdfSpikeConvDesc* c, GemmParams& P, bool& i8x3, bo
   return 0;
 }
 
+// the stride-2 3x3 transposed convolution as one product over the 2 x 2 input neighbourhood (header; csrc/ms_res.hip, AM = 3)
+extern "C" int sdf_spike_deconv3x3s2_fwd(const SdfSpikeDeconvDesc* d, void* stream) {
+  if (!d) return SDF_E_NULL;
+  if (!d->spikes || !d->digits || !d->cscale || !d->out) return SDF_E_NULL;
+  if ((d->alpha != nullptr) != (d->beta != nullptr)) return SDF_E_NULL;
+  if (d->imgs < 1 || d->H < 1 || d->W < 1 || (d->T != 10 && d->T != 20) || d->imgs % d->T) return SDF_E_SHAPE;
+  if (d->Cin < 16 || d->Cin % 16 || 4 * d->Cin > 1024 || d->Cout < 8 || d->Cout % 8) return SDF_E_SHAPE;
+  const int64_t rows = (int64_t)d->imgs * d->H * d->W;
+  if (rows * d->Cin >= (1LL << 31) || rows * 4 * d->Cout * 4 >= (1LL << 31)) return SDF_E_SHAPE;      // 32-bit buffer offsets
+  if (!sdf_aligned(d->spikes, 16) || !sdf_aligned(d->digits, 16) || !sdf_aligned(d->out, 16)) return SDF_E_ALIGN;
+  // the decoder's last level (208 channels, tens of thousands of pixels): halo tiles in LDS, weights resident (spike_deconv_wres.hip);
+  // other shapes: the row-loop kernel's form of the same product (ms_res.hip, AM = 3)
+  if (spike_deconv_wres_supports(d->imgs, d->H, d->W, d->Cin, d->Cout))
+    return launch_spike_deconv_wres(d->spikes, d->digits, d->cscale, d->alpha, d->beta, d->out, d->imgs, d->H, d->W, d->Cout, sdf_stream(stream));
+  WidePmParams P = {};
+  P.A = d->spikes; P.W = d->digits; P.cscale = d->cscale; P.N = 4 * d->Cout; P.K = 4 * d->Cin;
+  P.HW = d->H * d->W; P.P = (int64_t)(d->imgs / d->T) * P.HW;
+  P.alpha = d->alpha; P.beta = d->beta; P.x = d->out; P.ldo = d->Cout; P.no_resid = 1;
+  P.cv_H = d->H; P.cv_W = d->W; P.cv_Cin = d->Cin; P.dc_cout = d->Cout;
+  P.res_stage = 1;
+  if (!res_pm_takes(P, d->T, 2)) return SDF_E_SHAPE;
+  return launch_res_pm(P, d->T, 2, sdf_stream(stream));
+}
+
 extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
   GemmParams P;
   bool i8x3 = false, tiled = false;

@@ -32,6 +32,11 @@ struct WidePmParams {
   float* partial;
   int no_resid;              // fp32 epilogue without a shortcut: out = BN(...) (patch merging writes a new tensor)
   int res_stage;             // set by the host: a narrow stage (C <= 192) - the weight-resident row-loop kernel (ms_res.hip) may take it
+  // stride-2 3x3 transposed convolution as ONE product (ms_res.hip, AM = 3): a row = input pixel (img, a, b), K = the 2 x 2 input
+  // neighbourhood (a..a+1, b..b+1) in patch-merging's quadrant order (cv_H / cv_W / cv_Cin = the INPUT image), N = 4 dc_cout columns =
+  // the four output pixels (2a + py, 2b + px) of that row's 2 x 2 output block (column = (2 py + px) * dc_cout + co): x = the
+  // (imgs, 2 cv_H, 2 cv_W, dc_cout) fp32 output.  0 = not this form
+  int dc_cout;
 };
 
 struct WideFrontParams {
@@ -54,6 +59,10 @@ struct WideFrontParams {
 
 // weight-resident row-loop forms (ms_res.hip): whole-K digit planes of a column group stay in LDS, the waves of a workgroup walk row
 // units independently (two waves per SIMD, no barrier after the weights are in)
+// stride-2 3x3 transposed convolution, weight-resident halo-tile kernel (spike_deconv_wres.hip): Cin = 208
+bool spike_deconv_wres_supports(int imgs, int H, int W, int Cin, int Cout);
+int launch_spike_deconv_wres(const uint8_t* A, const int8_t* Wd, const float* cscale, const float* alpha, const float* beta, float* out,
+                             int imgs, int H, int W, int Cout, hipStream_t s);
 bool res_pm_takes(const WidePmParams& P, int T, int epi);
 int launch_res_pm(WidePmParams& P, int T, int epi, hipStream_t s);
 bool res_front_takes(const WideFrontParams& P);

@@ -21,7 +21,7 @@ SDF_LIF, SDF_PSN, SDF_IF = 0, 1, 2
 KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
 
 EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
-           "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_ann_attn_block_fwd", "sdf_ann_attn_block_supported", "sdf_spike_conv2d_fwd", "sdf_head_conv_sn_fwd",
+           "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_ann_attn_block_fwd", "sdf_ann_attn_block_supported", "sdf_spike_conv2d_fwd", "sdf_spike_deconv3x3s2_fwd", "sdf_head_conv_sn_fwd",
            "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes",
            "sdf_window_slice_map", "sdf_window_zsrc_map", "sdf_qk_attn_fwd", "sdf_qk_attn_is_wide", "sdf_ms_mlp_is_wide", "sdf_ms_patch_merge_fwd", "sdf_tile_weight_i8x3", "sdf_spike_conv2d_multi_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
            "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_pred_head_fwd", "sdf_pointwise_conv_f32_fwd", "sdf_neuron_multi_fwd", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
@@ -82,6 +82,12 @@ class WinAttnDesc(C.Structure):
                 ("B_", C.c_int32), ("nW", C.c_int32), ("nH", C.c_int32), ("N", C.c_int32), ("hd", C.c_int32),
                 ("Tq", C.c_int32), ("N1", C.c_int32),
                 ("scale", C.c_void_p), ("bias", C.c_void_p), ("mask", C.c_void_p), ("row_map", C.c_void_p), ("pad_qkv", C.c_void_p)]
+
+
+class SpikeDeconvDesc(C.Structure):
+    _fields_ = [("spikes", C.c_void_p), ("digits", C.c_void_p), ("cscale", C.c_void_p), ("alpha", C.c_void_p), ("beta", C.c_void_p),
+                ("out", C.c_void_p), ("imgs", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+                ("Cout", C.c_int32)]
 
 
 class AnnAttnBlockDesc(C.Structure):
@@ -1334,6 +1340,53 @@ def pred_head(z, wgt, bias, sn, H, W, want_pred=True, nxt=None, keep=False):
     d.keep_spikes = _ptr(sp)
     _check(lib().sdf_pred_head_fwd(C.byref(d), _stream()), "sdf_pred_head_fwd")
     return pred, flow, sp
+
+
+def deconv2x2_applicable(imgs, T, H, W, Cin, Cout, fast_only=False):
+    """Mirror of sdf_spike_deconv3x3s2_fwd's shape rules (csrc/spike_gemm.hip).  `fast_only`: only where the halo-tile kernel
+    (csrc/spike_deconv_wres.hip: 208 padded input channels, at least 4 096 input pixels) serves it - the row-loop kernel's form of the
+    product, which takes every other admitted shape, is slower than the parity-class launches it would replace."""
+    if os.environ.get("SDF_DECONV_GEMM", "1") == "0" or os.environ.get("SDF_RES", "1") == "0":
+        return False
+    rows = imgs * H * W
+    ok = T in (10, 20) and imgs % T == 0 and Cin % 16 == 0 and 16 <= Cin <= 256 and Cout % 8 == 0 and Cout >= 8 and \
+        rows * Cin < 1 << 31 and rows * 16 * Cout < 1 << 31
+    if fast_only:
+        ok = ok and Cin == 208 and rows >= 4096 and os.environ.get("SDF_DECONV_WRES", "1") != "0"
+    return ok
+
+
+def pack_deconv2x2_weight(w, cin_pad):
+    """ConvTranspose2d(3, stride 2, padding 1, output_padding 1) weight (Cin, Cout, 3, 3) -> int8 digit planes of the (4 Cout, 4 cin_pad)
+    matrix of sdf_spike_deconv3x3s2_fwd: row (2 py + px) Cout + co, column q cin_pad + c with q = dh + 2 dw the neighbour (a + dh, b + dw);
+    output row 2a + py takes kernel row 1 from input row a when py = 0, kernel rows 2 / 0 from input rows a / a + 1 when py = 1 (columns alike)."""
+    Cin, Cout = w.shape[:2]
+    w = w.detach().float()
+    M = torch.zeros((4 * Cout, 4 * cin_pad), dtype=torch.float32, device=w.device)
+    tap = {(0, 0): 1, (1, 0): 2, (1, 1): 0}                      # (output parity, input offset) -> kernel index
+    for py in range(2):
+        for px in range(2):
+            for dh in range(2):
+                for dw in range(2):
+                    if (py, dh) in tap and (px, dw) in tap:
+                        q, cls = dh + 2 * dw, 2 * py + px
+                        M[cls * Cout:(cls + 1) * Cout, q * cin_pad:q * cin_pad + Cin] = w[:, :, tap[(py, dh)], tap[(px, dw)]].t()
+    return split_weight_i8x3(M)
+
+
+def spike_deconv3x3s2(s, planes, imgs, T, H, W, Cin, Cout, alpha=None, beta=None, out=None, tiled_bn=False):
+    """sdf_spike_deconv3x3s2_fwd: s (imgs, H, W, Cin) u8 -> (imgs, 2H, 2W, Cout) fp32 = BN(ConvTranspose2d(3, 2, 1, 1)(s)), one launch.
+    alpha / beta: (Cout), or with `tiled_bn` already repeated to the product's (4 Cout) columns."""
+    if out is None:
+        out = torch.empty((imgs, 2 * H, 2 * W, Cout), dtype=torch.float32, device=s.device)
+    d = SpikeDeconvDesc()
+    d.spikes, d.digits, d.cscale = _ptr(s, torch.uint8), _ptr(planes, torch.int8), _ptr(planes.sdf_col_scale, torch.float32)
+    if alpha is not None and not tiled_bn:
+        alpha, beta = alpha.repeat(4).contiguous(), beta.repeat(4).contiguous()
+    d.alpha, d.beta = _ptr(alpha, torch.float32), _ptr(beta, torch.float32)
+    d.out, d.imgs, d.T, d.H, d.W, d.Cin, d.Cout = _ptr(out, torch.float32), imgs, T, H, W, Cin, Cout
+    _check(lib().sdf_spike_deconv3x3s2_fwd(C.byref(d), _stream()), "sdf_spike_deconv3x3s2_fwd")
+    return out
 
 
 def deconv_col2im(Y, imgs, H, W, Cout, alpha=None, beta=None, out=None):
