@@ -78,6 +78,19 @@ def test_argument_errors_are_reported_before_any_launch():
     d.mode, d.q, d.k, d.v, d.out, d.scale, d.bias = 0, 0x10000, 0x10000, 0x10000, 0x10000, 0x10000, 0x10000
     d.B_, d.nW, d.nH, d.N, d.hd = 4, 1, 3, 162, 16
     assert lib.sdf_win_attn_fwd(C.byref(d), None) == E_SHAPE    # head dim must be 32
+    # the transposed convolution as one product (round 5): T in {10, 20} dividing the images, Cin % 16, 4 Cin <= 1024, Cout % 8
+    dc = hip.SpikeDeconvDesc()
+    assert lib.sdf_spike_deconv3x3s2_fwd(None, None) == E_NULL and lib.sdf_spike_deconv3x3s2_fwd(C.byref(dc), None) == E_NULL
+    dc.spikes = dc.digits = dc.cscale = dc.out = 0x10000
+    dc.imgs, dc.T, dc.H, dc.W, dc.Cin, dc.Cout = 10, 10, 72, 96, 208, 48
+    dc.alpha = 0x10000
+    assert lib.sdf_spike_deconv3x3s2_fwd(C.byref(dc), None) == E_NULL          # alpha without beta
+    dc.alpha = None
+    for field, bad in (("T", 7), ("imgs", 15), ("Cin", 200), ("Cin", 272), ("Cout", 44)):
+        keep = getattr(dc, field)
+        setattr(dc, field, bad)
+        assert lib.sdf_spike_deconv3x3s2_fwd(C.byref(dc), None) == E_SHAPE, field
+        setattr(dc, field, keep)
     # the one-launch attention half block (round 5): built for C = 96 / 3 heads / 162-token windows, refused before any launch otherwise
     assert lib.sdf_ann_attn_block_supported(96, 3, 162) == 1 and lib.sdf_ann_attn_block_supported(192, 6, 162) == 0
     ab = hip.AnnAttnBlockDesc()
