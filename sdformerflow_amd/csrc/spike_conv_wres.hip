@@ -472,8 +472,11 @@ struct GeoI8 {
   }
 };
 
-template <int TT, int CIN16, int RB, int NGRP, bool S2 = false, int KH = 1>
+// SPK: the spikes-only fused form (no fp32 membrane out, no shortcut in) as its own instantiation - without the shortcut's 16 registers
+// and the store transposes the three-group kernel has room for a second K step of fragments in flight
+template <int TT, int CIN16, int RB, int NGRP, bool S2 = false, int KH = 1, bool SPK = false>
 __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmParams P, const float* __restrict__ col_scale) {
+  static_assert(!SPK || TT > 0, "spikes-only: a fused-neuron form");
   using G = GeoI8<CIN16, RB, S2, KH>;
   constexpr int ST = S2 ? 2 : 1;
   constexpr int CING = G::CING;
@@ -498,8 +501,8 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
   const int grp = wave >> 2, cw = wave & 3;
   const int gl = tid & 255;
   const int N = d.N;
-  const bool has_res = !(S2 && SPIKE) && d.resid != nullptr;           // (stride 2 + fused neuron: no shortcut form - registers)
-  const bool memb = !SPIKE || d.out != nullptr;
+  const bool has_res = !SPK && !(S2 && SPIKE) && d.resid != nullptr;   // (stride 2 + fused neuron: no shortcut form - registers)
+  const bool memb = !SPK && (!SPIKE || d.out != nullptr);
   const int ohw = H * W;
   const int pm = SPIKE ? (int)(d.pos_inner / ohw) : 1, pso = SPIKE ? (int)(d.pos_ostride / ohw) : 0;
   const int tstep = SPIKE ? (int)(d.t_stride / ohw) : 0;
@@ -704,7 +707,7 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[dg][rb][e] = 0;
         constexpr int KS = G::KS;
-        constexpr int PF = (RB == 1 && NGRP == 2) ? 2 : 1;              // three groups live on 168 registers
+        constexpr int PF = (RB == 1 && (NGRP == 2 || SPK)) ? 2 : 1;     // three groups live on 168 registers
 #pragma unroll
         for (int hf = 0; hf < KH; ++hf) {
           ++nstep;
@@ -943,6 +946,8 @@ int launch_spike_conv_wres(const GemmParams& Pin, hipStream_t s) {
     if (d.sn_T == 0 && th == 16) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 6, 2, 2>), grid, dim3(512), 0, s, P, d.col_scale);
     else if (d.sn_T == 0) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 6, 1, 2>), grid, dim3(512), 0, s, P, d.col_scale);
     else if (th == 16) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 2, 2>), grid, dim3(512), 0, s, P, d.col_scale);
+    else if (g3 && !d.out && !d.resid && !getenv("SDF_CONV_WRES_NOSPK"))
+      hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 1, 3, false, 1, true>), grid, dim3(768), 0, s, P, d.col_scale);
     else if (g3) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 1, 3>), grid, dim3(768), 0, s, P, d.col_scale);
     else hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 1, 2>), grid, dim3(512), 0, s, P, d.col_scale);
     rc = 0;
