@@ -807,10 +807,13 @@ int launch_pm(WidePmParams& P, int T, int epi, hipStream_t s) {
 // These kernels are built for problems that are small in rows (one workgroup per compute unit, a prologue per 320 rows): up to 400
 // 80-row units (configs[4]'s stage 3 - 24 000 rows - measured +1 % on them: 119.5 against 118.1 samples/s).  Larger problems
 // (configs[4]: 96 000 rows at stage 2) keep the streaming kernels, which they fill: measured 119 -> 109 samples/s with the limit lifted
-// (SDF_WIDE=2: tests, A/B).
+// (SDF_WIDE=2: tests, A/B).  Round 5: 131 072 rows - with the row-loop kernels of ms_res.hip taking the front, the projection and fc1
+// of a block at any row count, the limit only decides whether fc2 of the C >= 384 stages (K > 1 024: not theirs) runs here or drags the
+// WHOLE block back to the streaming kernels: configs[4] (96 000 rows at stage 2) 129.7 -> 143.4 samples/s with it lifted
+// (profiles/r5ao_config5_kernel_stats.txt, same box A/B).
 static int64_t wide_max_rows() {                      // (SDF_WIDE_MAXROWS: tuning override)
   if (const char* e = getenv("SDF_WIDE_MAXROWS")) { const long v = atol(e); if (v >= 80) return v; }
-  return 400 * 80;
+  return 131072;
 }
 #define WIDE_MAX_ROWS wide_max_rows()
 bool wide_env_any() {
@@ -852,7 +855,7 @@ bool res_stage_ok(int C, bool merge = false) {
 // Shapes the wide forms are built for: int8 digit planes beside the 16-bit ones (the caller packs both; the default two-plane
 // mode only - the exact three-plane and the one-plane bf16 modes keep the general kernels), LIF / IF / PSN neurons (round 5: the PSN's
 // T x T matrix is staged in LDS, its rows read as broadcasts), C >= 192 in steps of 64 with Ch % 96 == 0, T in {10, 20}, at most
-// WIDE_MAX_ROWS (32 000, SDF_WIDE_MAXROWS) rows, operands within the kernels' 31-bit buffer offsets.
+// WIDE_MAX_ROWS (131 072, SDF_WIDE_MAXROWS) rows, operands within the kernels' 31-bit buffer offsets.
 bool ms_wide_mlp_supports(const SdfMsMlpDesc* d) {
   if (wide_env_off() || (d->flags & SDF_MLP_NARROW)) return false;
   if (!d->fc1_digits || !d->fc1_cscale || !d->fc2_digits || !d->fc2_cscale) return false;

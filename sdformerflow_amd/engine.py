@@ -735,14 +735,16 @@ class MSFlowEngine:
             # the last level: the transposed convolution as ONE digit product over the 2 x 2 input neighbourhood (a row = an input pixel,
             # its 4 cout columns = the 2 x 2 output block; halo tiles in LDS, weights resident: csrc/spike_deconv_wres.hip) instead of
             # four parity-class convolutions
-            one_gemm = not as_gemm and per == imgs and self.nsplit == 2 and hip.deconv2x2_applicable(imgs, D, h, w, cp, cout, fast_only=True)
+            one_gemm = not as_gemm and self.nsplit == 2 and per % D == 0 and imgs % per == 0 and \
+                hip.deconv2x2_applicable(per, D, h, w, cp, cout, fast_only=True)
             if one_gemm:
                 key = ("d2x2", i, cp, wkey)
                 if key not in self._deconv:
                     self._deconv[key] = (hip.pack_deconv2x2_weight(wuse, cp), bn[0].repeat(4).contiguous(), bn[1].repeat(4).contiguous())
                 pl, a4, b4 = self._deconv[key]
-                hip.spike_deconv3x3s2(s.view(imgs, h, w, cp), pl, imgs, D, h, w, cp, cout, alpha=a4, beta=b4, out=z.view(imgs, 2 * h, 2 * w, cout),
-                                      tiled_bn=True)
+                sv, zv = s.view(imgs, h, w, cp), z.view(imgs, 2 * h, 2 * w, cout)
+                for i0 in range(0, imgs, per):                            # (image chunks: the kernel's 31-bit offsets, as below)
+                    hip.spike_deconv3x3s2(sv[i0:i0 + per], pl, per, D, h, w, cp, cout, alpha=a4, beta=b4, out=zv[i0:i0 + per], tiled_bn=True)
             classes = [] if as_gemm or one_gemm else self._deconv_classes(i, B, D, h, w, cp, wkey, wuse)
             if classes and per == imgs:
                 # the four parity classes write disjoint rows of z and each fills about half of the chip: one launch for all of them

@@ -410,10 +410,10 @@ def conv_wres_applicable(imgs, H, W, Cin, Cout, stride, T=1):
 
 def wide_conv_applicable(imgs, H, W, Cin, Cout, stride, T):
     """Mirror of the library's dispatch rule for the small-M digit convolution (csrc/ms_wide.hip: wide_conv_supports): 3x3 / stride 1
-    on Cin % 128 == 0 channels, at most 32 000 output rows (SDF_WIDE_MAXROWS) in (B, T, H, W) order with T in {10, 20}."""
+    on Cin % 128 == 0 channels, at most 131 072 output rows (SDF_WIDE_MAXROWS) in (B, T, H, W) order with T in {10, 20}."""
     if os.environ.get("SDF_WIDE", "") == "0" or os.environ.get("SDF_WIDE_CONV", "") != "1" or stride != 1 or Cin % 128 or Cout % 32:
         return False                                             # (opt-in: measured no faster than the streaming kernel + split-K, DESIGN.md)
-    return T in (10, 20) and imgs % T == 0 and imgs * H * W <= int(os.environ.get("SDF_WIDE_MAXROWS", 400 * 80))
+    return T in (10, 20) and imgs % T == 0 and imgs * H * W <= int(os.environ.get("SDF_WIDE_MAXROWS", 131072))
 
 
 def smallm_conv_applicable(imgs, H, W, Cin, Cout, stride, T):
