@@ -432,7 +432,13 @@ class MSFlowEngine:
         sns = [rb.sn1 for rb in self.pe_res] + [self.proj_sn]
         C0 = self.conv_w.shape[1]
         oh, ow = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        if self._fusable(B, T, oh, ow, C0):
+        fus = self._fusable(B, T, oh, ow, C0)
+        if not fus and T in (5, 20) and getattr(self.conv_w, "digits", None) is not None and sns[0].kind != "psn":
+            # T = 5 / 20 (configs[4]): the digit kernel's stride-2 form rolls its time loop as the stride-1 form does (_fusable's rule)
+            c0 = s.shape[-1]
+            bc = B if hip.conv_wres_applicable(B * T, H, W, c0, C0, 2, 1) else self._digit_chunk(B, T, H, W, c0, C0, 2)
+            fus = bc > 0 and hip.conv_wres_applicable(bc * T, H, W, c0, C0, 2, T)
+        if fus:
             m, s1 = self._conv3x3(s, self.conv_w, C0, stride=2, bn=self.conv_bn, sn=sns[0], membrane=True)
         else:
             m = self._conv3x3(s, self.conv_w, C0, stride=2, bn=self.conv_bn)
