@@ -246,7 +246,7 @@ int sdf_split_weight_i8x3(const float* W, int8_t* planes, float* col_scale, int 
 /* Digit planes [3][N][K] (sdf_split_weight_i8x3) -> fragment order [N / 16][K / 64][3][64][16 B]: the 1 KB a wave reads for one
  * 16-column x 64-deep x one-plane MFMA operand is contiguous and in lane order (lane l: column 16 j + l % 16, k = 64 s + 16 (l / 16) ..).
  * Same size as the planes; passed to sdf_spike_conv2d_fwd with nsplit = SDF_PLANES_I8X3_TILED and the same col_scale.  Only the
- * small-M kernels read it: the convolution (3x3 / stride 1, Cin % 64 == 0, at most 5 120 rows in (B, T, H, W) order: the U-Net
+ * small-M kernels read it: the convolution (3x3 / stride 1, Cin % 64 == 0, at most 32 000 rows in (B, T, H, W) order: the U-Net
  * bottleneck of reference Spiking_modules.py:906-933) and, through sdf_spike_gemm_fwd with the same nsplit, the plain product with the
  * fp32 epilogue (M % 10 == 0, M <= 5 120, lda == K, K % 64 == 0, no out_rowmap / zg / add / neuron: the first decoder's stacked-tap GEMM,
  * reference Spiking_modules.py:461-474); other shapes return SDF_E_SHAPE.  N % 16 == 0, K % 64 == 0. */

@@ -462,6 +462,12 @@ static bool smallm_neuron_ok(const SdfNeuronCfg& n) {
 // 3x3 / stride 1 / pad 1 spike convolution in (B, T, H, W) row order with int8 digit planes, up to SMALLM_MAX_ROWS rows: beyond that the
 // weight re-reads of the (unit x column group) grid outgrow what the streaming kernels pay (they keep those shapes)
 constexpr int64_t SMALLM_MAX_ROWS = 64 * 80;
+// the convolution's own limit (SDF_SMALLM_CONV_ROWS: tuning override): 32 000 rows since round 5 - configs[4]'s bottleneck (24 000 rows x
+// 768 x 6 912) measured 146.9 -> 151.9 samples/s on this kernel against the streaming convolution + split-K it fell back to
+static int64_t smallm_conv_rows() {
+  if (const char* e = getenv("SDF_SMALLM_CONV_ROWS")) { const long v = atol(e); if (v >= 80) return v; }
+  return 400 * 80;
+}
 
 bool smallm_conv_supports(const GemmParams& P) {
   const SdfSpikeGemmDesc& d = P.d;
@@ -475,7 +481,7 @@ bool smallm_conv_supports(const GemmParams& P) {
   int T = d.sn_T;
   if (T == 0) T = imgs % 10 == 0 ? 10 : (imgs % 20 == 0 ? 20 : 0);
   if (T != 10 && T != 20) return false;
-  if (imgs % T || d.M > SMALLM_MAX_ROWS) return false;
+  if (imgs % T || d.M > smallm_conv_rows()) return false;
   if (d.sn_T > 0) {
     if (!smallm_neuron_ok({d.sn_kind, d.tau, d.v_th, d.v_reset, d.soft_reset, d.psn_w, d.psn_b})) return false;
     if (d.pos_inner != hw || d.t_stride != hw || d.pos_ostride != (int64_t)T * hw || d.pos_count * T != d.M) return false;   // rows (b, t, pixel)

@@ -418,10 +418,10 @@ def wide_conv_applicable(imgs, H, W, Cin, Cout, stride, T):
 
 def smallm_conv_applicable(imgs, H, W, Cin, Cout, stride, T):
     """Mirror of the library's dispatch rule for the small-M digit convolution (csrc/ms_smallm.hip: smallm_conv_supports): 3x3 / stride 1
-    on Cin % 64 == 0 channels, at most 5 120 output rows in (B, T, H, W) order with T in {10, 20}."""
+    on Cin % 64 == 0 channels, at most 32 000 output rows (SDF_SMALLM_CONV_ROWS; 5 120 until round 5) in (B, T, H, W) order with T in {10, 20}."""
     if os.environ.get("SDF_SMALLM", "") == "0" or stride != 1 or Cin % 64 or Cout % 32:
         return False
-    return T in (10, 20) and imgs % T == 0 and imgs * H * W <= 64 * 80
+    return T in (10, 20) and imgs % T == 0 and imgs * H * W <= int(os.environ.get("SDF_SMALLM_CONV_ROWS", 400 * 80))
 
 
 def tile_weight_i8x3(planes):
