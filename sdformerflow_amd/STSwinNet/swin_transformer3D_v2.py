@@ -148,7 +148,8 @@ class WindowAttention3D(nn.Module):
                 if getattr(self, "_blk_stamp", None) != stamp:
                     self._blk, self._blk_stamp = hip.pack_ann_attn_block_weights(self.qkv.weight, self.proj.weight, self.num_heads), stamp
                 bias, scale = self._bias_and_scale()
-                tkey = (bias.data_ptr(), None if mask is None else (mask.data_ptr(), mask._version))
+                # (keyed by the parameter versions the bias was made from - not by its address, which a later bias may be given again)
+                tkey = (self._bs_stamp, None if mask is None else (mask.data_ptr(), mask._version))
                 if getattr(self, "_tab_key", None) != tkey:               # (bias + mask) * log2 e: once per parameter version and mask
                     self._tab, self._tab_key = hip.ann_attn_block_table(scale, bias, mask), tkey
                     self._tab_keep = (bias, mask)                          # (the key's pointers stay valid while the table does)

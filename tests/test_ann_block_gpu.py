@@ -81,3 +81,22 @@ def test_half_block_alone_against_fp64():
         blk.mlp.fc2.bias.zero_()
     got = blk(x.to(DEV)).cpu().double()
     assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+def test_tables_and_weight_planes_follow_the_parameters():
+    """The (bias + mask) * log2 e table and the fp16 weight planes are cached per parameter version: an in-place update of the logit
+    scale, the cpb_mlp and the qkv / proj weights must reach the next forward."""
+    blk, sd = _block((1, 4, 4), True, 600)
+    x = rnd((1, 2, 18, 18, 96), 601, -1.5, 1.5)
+    blk = blk.to(DEV)
+    first = blk(x.to(DEV)).cpu()
+    with torch.no_grad():
+        blk.attn.logit_scale.add_(0.4)
+        blk.attn.cpb_mlp[2].weight.mul_(1.5)
+        blk.attn.qkv.weight.mul_(0.9)
+        blk.attn.proj.weight.add_(0.01)
+    sd2 = {k: v.detach().cpu().clone() for k, v in blk.state_dict().items() if not k.endswith(("relative_position_index", "relative_coords_table"))}
+    ref = O.ann_block(x, sd2, "", 3, (2, 9, 9), (1, 4, 4))
+    got = blk(x.to(DEV)).cpu()
+    assert (got - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+    assert (got - first).abs().max().item() > 1e-3                          # (the update did change the result)
