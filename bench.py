@@ -233,6 +233,17 @@ def time_config3(iters=10):
             fl = B_ * (2 * 162 * 96 * 288 + 4 * 162 * 162 * 32 * 3 + 2 * 162 * 96 * 96)
             half[name] = {"one_launch_us": t1 * 1e6, "four_launches_us": t4 * 1e6, "windows": B_, "algorithmic_gflop": fl / 1e9,
                           "tflops": fl / t1 / 1e12, "frac_of_2500": fl / t1 / 1e12 / 2500.0}
+        # the MLP half of the same block: LayerNorm -> fc1 -> GELU -> fc2 -> + x, one launch (csrc/ann_mlp_block.hip) against three
+        blk = blocks[0]
+        xs = [torch.randn(B * 2 * 72 * 96, 96, generator=g).cuda() for _ in range(4)]
+        with torch.no_grad():
+            pk = hip.pack_ann_mlp_block_weights(blk.mlp.fc1.weight, blk.mlp.fc2.weight)
+            n2 = blk.norm2
+            t1 = _timed(lambda x2: hip.ann_mlp_block(x2, torch.empty_like(x2), n2.weight.detach(), n2.bias.detach(), n2.eps, pk[0], blk.mlp.fc1.bias.detach(),
+                                                     pk[1], blk.mlp.fc2.bias.detach()), xs, 20)
+            t3 = _timed(lambda x2: blk.mlp(layer_norm(n2, x2), x2), xs, 20)
+        half["mlp_half"] = {"one_launch_us": t1 * 1e6, "three_launches_us": t3 * 1e6, "rows": xs[0].shape[0],
+                            "note": "x + fc2(GELU(fc1(LayerNorm(x)))), C = 96, hidden 384: the hidden activations (170 MB) never reach HBM"}
         half["note"] = ("x + proj(window attention(LayerNorm(x))) of BASELINE configs[2]'s first stage (8 x 2 x 72 x 96 tokens, C = 96, three heads): "
                         "csrc/ann_block.hip (q | k | v never in HBM) against sdf_layer_norm_fwd + sdf_dense_linear_fwd + sdf_win_attn_fwd + "
                         "sdf_dense_linear_fwd; matrix pipe busy 24.7 % (profiles/r5z_pmc_ann_block.txt)")

@@ -684,6 +684,31 @@ typedef struct SdfAnnAttnBlockDesc {
 int sdf_ann_attn_block_supported(int C, int nH, int N);
 int sdf_ann_attn_block_fwd(const SdfAnnAttnBlockDesc* d, void* stream);
 
+/* ---- the MLP half of an ANN video-swin block as one launch (BASELINE config 3, first stage) ---------------------------
+ * Replaces `SwinTransformerBlock3D.forward_part2` + the shortcut (reference models/STSwinNet/swin_transformer3D_v2.py:312-336) with
+ * `Mlp.forward` (:15-34) inside:  out = x + fc2(GELU(fc1(LayerNorm(x)))), erf-form GELU (F.gelu), on rows x (rows, C) fp32; the hidden
+ * activations never exist in memory.  Built for C = 96, hidden 384 (sdf_ann_mlp_block_supported); other shapes: SDF_E_SHAPE, the caller
+ * keeps sdf_layer_norm_fwd + sdf_dense_linear_fwd (GELU) + sdf_dense_linear_fwd (shortcut).  x == out is allowed.
+ * w1: fp16 planes [2][Ch][C] of fc1's weight (plane0 = fp16(W), plane1 = fp16(W - plane0)); w2: fp16 planes [2][C][Ch] of fc2's weight
+ * with the hidden channels of every group of 32 in the kernel's accumulator order: w2[., o, 32 g + 8 a + i] =
+ * W2[o, 32 g + (i < 4 ? 4 a + i : 16 + 4 a + i - 4)], a = 0..3, i = 0..7. */
+typedef struct SdfAnnMlpBlockDesc {
+  const float* x;            /* (rows, C) */
+  float* out;                /* (rows, C) */
+  int64_t rows;
+  int32_t C, Ch;
+  const float* ln_w;         /* (C) */
+  const float* ln_b;         /* (C) */
+  float ln_eps;
+  const uint16_t* w1;        /* fp16 planes [2][Ch][C] */
+  const float* b1;           /* (Ch) or NULL */
+  const uint16_t* w2;        /* fp16 planes [2][C][Ch], hidden channels permuted (above) */
+  const float* b2;           /* (C) or NULL */
+} SdfAnnMlpBlockDesc;
+
+int sdf_ann_mlp_block_supported(int C, int Ch);
+int sdf_ann_mlp_block_fwd(const SdfAnnMlpBlockDesc* d, void* stream);
+
 /* ---- dense 3x3 convolution of real-valued activations (ANN patch embedding, BASELINE config 3) ----------------------
  * Replaces the library convolutions of reference models/STSwinNet/PatchEmbed.py:166-196 (`PatchEmbedLocal`: head Conv2d +
  * four `ResidualBlock`s, models/submodules.py:160-229) together with their BatchNorm2d (eval: folded to alpha / beta), residual

@@ -242,6 +242,20 @@ class SwinTransformerBlock3D(nn.Module):
             row_map, B_ = maps[key]
             x = self.attn.forward_rows(y.reshape(-1, C) if y is not None else None, row_map, B_, None if mask is None else mask.contiguous(),
                                        x.reshape(-1, C), norm=self.norm1).view(B, D, H, W, C)
+        # first stage (C = 96, hidden 384): LayerNorm -> fc1 -> GELU -> fc2 -> + x is one launch, the hidden activations stay in registers
+        # (csrc/ann_mlp_block.hip); elsewhere LayerNorm, fc1 (+ GELU) and fc2 (+ shortcut) are three
+        if (not self.training and x.is_cuda and x.dtype == torch.float32 and self.norm2.elementwise_affine and self.norm2.bias is not None
+                and hip.ann_mlp_block_supported(C, self.mlp.fc1.out_features) and x.numel() * 4 < 1 << 31):
+            with torch.no_grad():
+                m = self.mlp
+                stamp = (m.fc1.weight.data_ptr(), m.fc1.weight._version, m.fc2.weight.data_ptr(), m.fc2.weight._version)
+                if getattr(self, "_mlp_stamp", None) != stamp:
+                    self._mlp_pk, self._mlp_stamp = hip.pack_ann_mlp_block_weights(m.fc1.weight, m.fc2.weight), stamp
+                x2 = x.reshape(-1, C).contiguous()
+                y = hip.ann_mlp_block(x2, torch.empty_like(x2), self.norm2.weight.detach(), self.norm2.bias.detach(), self.norm2.eps, self._mlp_pk[0],
+                                      None if m.fc1.bias is None else m.fc1.bias.detach(), self._mlp_pk[1],
+                                      None if m.fc2.bias is None else m.fc2.bias.detach())
+            return y.view(B, D, H, W, C)
         return self.mlp(layer_norm(self.norm2, x), x)
 
 

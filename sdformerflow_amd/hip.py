@@ -21,7 +21,7 @@ SDF_LIF, SDF_PSN, SDF_IF = 0, 1, 2
 KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
 
 EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
-           "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_ann_attn_block_fwd", "sdf_ann_attn_block_supported", "sdf_spike_conv2d_fwd", "sdf_spike_deconv3x3s2_fwd", "sdf_head_conv_sn_fwd",
+           "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_ann_attn_block_fwd", "sdf_ann_attn_block_supported", "sdf_ann_mlp_block_fwd", "sdf_ann_mlp_block_supported", "sdf_spike_conv2d_fwd", "sdf_spike_deconv3x3s2_fwd", "sdf_head_conv_sn_fwd",
            "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes",
            "sdf_window_slice_map", "sdf_window_zsrc_map", "sdf_qk_attn_fwd", "sdf_qk_attn_is_wide", "sdf_ms_mlp_is_wide", "sdf_ms_patch_merge_fwd", "sdf_tile_weight_i8x3", "sdf_spike_conv2d_multi_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
            "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_pred_head_fwd", "sdf_pointwise_conv_f32_fwd", "sdf_neuron_multi_fwd", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
@@ -82,6 +82,12 @@ class WinAttnDesc(C.Structure):
                 ("B_", C.c_int32), ("nW", C.c_int32), ("nH", C.c_int32), ("N", C.c_int32), ("hd", C.c_int32),
                 ("Tq", C.c_int32), ("N1", C.c_int32),
                 ("scale", C.c_void_p), ("bias", C.c_void_p), ("mask", C.c_void_p), ("row_map", C.c_void_p), ("pad_qkv", C.c_void_p)]
+
+
+class AnnMlpBlockDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int64), ("C", C.c_int32), ("Ch", C.c_int32),
+                ("ln_w", C.c_void_p), ("ln_b", C.c_void_p), ("ln_eps", C.c_float), ("w1", C.c_void_p), ("b1", C.c_void_p),
+                ("w2", C.c_void_p), ("b2", C.c_void_p)]
 
 
 class SpikeDeconvDesc(C.Structure):
@@ -927,6 +933,44 @@ def pack_ann_attn_block_weights(wqkv, wproj, nH):
     perm = torch.where(i < 4, 4 * a + i, 16 + 4 * a + i - 4)
     idx = (torch.arange(nH)[:, None] * 32 + perm[None, :]).reshape(-1).to(wproj.device)
     return planes(wqkv), planes(wproj.detach()[:, idx])
+
+
+def _hi_lo_planes(w):
+    w = w.detach().float()
+    hi = w.half()
+    return torch.stack([hi, (w - hi.float()).half()]).contiguous()
+
+
+def _acc_order(n32, device):
+    """Column permutation of n32 groups of 32 channels into the order the 16 x 16 MFMA accumulators of two neighbouring tiles leave them."""
+    j = torch.arange(32)
+    a, i = j // 8, j % 8
+    perm = torch.where(i < 4, 4 * a + i, 16 + 4 * a + i - 4)
+    return (torch.arange(n32)[:, None] * 32 + perm[None, :]).reshape(-1).to(device)
+
+
+def ann_mlp_block_supported(Cc, Ch):
+    """Mirror of sdf_ann_mlp_block_supported: the one-launch MLP half block is built for C = 96, hidden 384.  SDF_ANN_MLP=0 (A/B) and
+    SDF_DENSE_LINEAR=0 (library GEMMs for every Linear) select the three-launch path."""
+    return (Cc, Ch) == (96, 384) and os.environ.get("SDF_ANN_MLP", "1") != "0" and os.environ.get("SDF_DENSE_LINEAR", "1") != "0"
+
+
+def pack_ann_mlp_block_weights(w1, w2):
+    """fp16 hi / lo planes of fc1's weight (Ch, C) as it stands and of fc2's weight (C, Ch) with the hidden channels in the kernel's
+    accumulator order (include/sdformerflow_hip.h: SdfAnnMlpBlockDesc) -> (planes (2, Ch, C), planes (2, C, Ch))."""
+    return _hi_lo_planes(w1), _hi_lo_planes(w2.detach()[:, _acc_order(w2.shape[1] // 32, w2.device)])
+
+
+def ann_mlp_block(x, out, ln_w, ln_b, ln_eps, w1_planes, b1, w2_planes, b2):
+    """sdf_ann_mlp_block_fwd: out = x + fc2(gelu(fc1(LayerNorm(x)))) on rows x (rows, C) fp32, one launch (reference
+    swin_transformer3D_v2.py:312-336).  out may be x."""
+    rows, Cc = x.shape
+    d = AnnMlpBlockDesc()
+    d.x, d.out, d.rows, d.C, d.Ch = _ptr(x, torch.float32), _ptr(out, torch.float32), rows, Cc, w1_planes.shape[1]
+    d.ln_w, d.ln_b, d.ln_eps = _ptr(ln_w, torch.float32), _ptr(ln_b, torch.float32), float(ln_eps)
+    d.w1, d.b1, d.w2, d.b2 = _ptr(w1_planes, torch.float16), _ptr(b1, torch.float32), _ptr(w2_planes, torch.float16), _ptr(b2, torch.float32)
+    _check(lib().sdf_ann_mlp_block_fwd(C.byref(d), _stream()), "sdf_ann_mlp_block_fwd")
+    return out
 
 
 LOG2E = 1.4426950408889634

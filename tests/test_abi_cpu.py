@@ -91,6 +91,14 @@ def test_argument_errors_are_reported_before_any_launch():
         setattr(dc, field, bad)
         assert lib.sdf_spike_deconv3x3s2_fwd(C.byref(dc), None) == E_SHAPE, field
         setattr(dc, field, keep)
+    # the one-launch MLP half block (round 5): C = 96, hidden 384
+    assert lib.sdf_ann_mlp_block_supported(96, 384) == 1 and lib.sdf_ann_mlp_block_supported(192, 768) == 0
+    mb = hip.AnnMlpBlockDesc()
+    assert lib.sdf_ann_mlp_block_fwd(None, None) == E_NULL and lib.sdf_ann_mlp_block_fwd(C.byref(mb), None) == E_NULL
+    for f in ("x", "out", "ln_w", "ln_b", "w1", "w2"):
+        setattr(mb, f, 0x10000)
+    mb.rows, mb.C, mb.Ch = 1000, 192, 768
+    assert lib.sdf_ann_mlp_block_fwd(C.byref(mb), None) == E_SHAPE
     # the one-launch attention half block (round 5): built for C = 96 / 3 heads / 162-token windows, refused before any launch otherwise
     assert lib.sdf_ann_attn_block_supported(96, 3, 162) == 1 and lib.sdf_ann_attn_block_supported(192, 6, 162) == 0
     ab = hip.AnnAttnBlockDesc()

@@ -37,7 +37,7 @@ def _block(shift, qkv_bias, seed):
 @pytest.mark.parametrize("shift", [(0, 0, 0), (1, 4, 4)])
 @pytest.mark.parametrize("B,D,H,W", [(2, 2, 18, 27), (1, 2, 20, 30), (3, 4, 9, 9)])
 def test_block_equals_oracle_and_the_four_launch_path(B, D, H, W, shift, qkv_bias):
-    """Aligned (18 x 27), padded (20 x 30 -> 27 x 36: padding tokens are zero rows behind the norm, their outputs dropped) and
+    """Both halves of the block as one launch each (csrc/ann_block.hip, csrc/ann_mlp_block.hip).  Aligned (18 x 27), padded (20 x 30 -> 27 x 36: padding tokens are zero rows behind the norm, their outputs dropped) and
     single-window-per-slab feature maps; plain and shifted windows (mask, roll); with and without the qkv bias.  Whole block
     (attention half + MLP half) within 3e-5 of the fp32 CPU oracle relative to the output's magnitude; the one-launch half block
     within 2e-5 of the four-launch path (both carry 22-bit products)."""
@@ -48,11 +48,12 @@ def test_block_equals_oracle_and_the_four_launch_path(B, D, H, W, shift, qkv_bia
     xg = x.to(DEV)
     assert hip.ann_attn_block_supported(96, 3, 162)
     got = blk(xg).cpu()
-    os.environ["SDF_ANN_BLOCK"] = "0"
+    os.environ["SDF_ANN_BLOCK"] = os.environ["SDF_ANN_MLP"] = "0"     # LayerNorm, qkv, attention, proj | LayerNorm, fc1 + GELU, fc2: seven launches
     try:
         old = blk(xg).cpu()
     finally:
         os.environ.pop("SDF_ANN_BLOCK", None)
+        os.environ.pop("SDF_ANN_MLP", None)
     scale = ref.abs().max().item()
     assert (got - ref).abs().max().item() <= 3e-5 * scale
     assert (got - old).abs().max().item() <= 2e-5 * scale

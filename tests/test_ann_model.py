@@ -149,9 +149,9 @@ def test_config3_batch8_dense_convolution_path(monkeypatch):
     assert len(calls) == 25 and not lin_calls
     monkeypatch.delenv("SDF_DENSE_LINEAR")
     net(vox.cuda(), None)
-    # qkv, proj, fc1, fc2 of the 10 blocks + the 2 patch-merging reductions, less qkv and proj of the first stage's two blocks: their
-    # attention half is one launch with both products inside (csrc/ann_block.hip)
-    assert len(lin_calls) == 4 * (2 + 2 + 6) + 2 - 2 * 2, len(lin_calls)
+    # qkv, proj, fc1, fc2 of the 10 blocks + the 2 patch-merging reductions, less all four of the first stage's two blocks: their
+    # attention half and their MLP half are one launch each with both products inside (csrc/ann_block.hip, csrc/ann_mlp_block.hip)
+    assert len(lin_calls) == 4 * (2 + 2 + 6) + 2 - 2 * 4, len(lin_calls)
     for i, (a, b) in enumerate(zip(got, lib)):
         d = (a - b).abs().max().item()
         assert d <= 5e-5 * b.abs().mean().item(), (i, d, b.abs().mean().item())
