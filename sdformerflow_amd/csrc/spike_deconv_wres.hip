@@ -23,6 +23,7 @@
 // Compiled with -ffp-contract=off.
 #include "spike_mm.h"
 #include "wide_common.h"
+#include <type_traits>
 
 namespace sdfmm {
 namespace {
@@ -50,6 +51,10 @@ struct DeconvParams {
   const uint8_t* A; const int8_t* W; const float* cscale; const float* alpha; const float* beta; float* out;
   int imgs, H, W_, Cout, N;
   int tiles_m, tiles_n, ntiles;
+  // Cout % 32 == 0: a column block lies inside ONE output-parity class and only multiplies the quadrants that class receives; the
+  // workgroups of class c are ids [cls_start[c], cls_start[c + 1]), cls_nr[c] tile ranges x (Cout / 32) column blocks, the ranges sized
+  // by the class's K steps (7 / 13 / 14 / 26 of 26) so that every workgroup has about the same work.  cls_nr[0] = 0: the uniform form
+  int cls_start[5], cls_nr[4];
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p) {
@@ -91,6 +96,17 @@ __device__ __forceinline__ constexpr int step_off(int ks) {
   return (ks - 4 * (C16 / 2)) * RPB + 16 * (C16 - 1);        // left-over pieces: (q0 | q2) then (q1 | q3), one pixel apart
 }
 __device__ __forceinline__ constexpr int step_base(int ks) { return ks < 4 * (C16 / 2) ? 0 : 1; }
+// the K steps an output-parity class needs (class = 2 py + px receives quadrants with dh <= py, dw <= px; 4 = all: the uniform form):
+// class 0: q0; class 1: q0, q2; class 2: q0, q1; class 3: all four.  Steps [6 q, 6 q + 6) are quadrant q's pairs, 24 = left-overs (q0 | q2),
+// 25 = (q1 | q3).
+__host__ __device__ constexpr int cls_nsteps(int cls) { return cls == 0 ? 7 : (cls == 1 ? 13 : (cls == 2 ? 14 : KS)); }
+__device__ __forceinline__ constexpr int cls_step(int cls, int i) {
+  constexpr int Q = C16 / 2;
+  if (cls >= 3) return i;
+  if (cls == 0) return i < Q ? i : 4 * Q;
+  if (cls == 1) return i < Q ? i : (i < 2 * Q ? 2 * Q + (i - Q) : 4 * Q);
+  return i < 2 * Q ? i : 4 * Q + (i - 2 * Q);
+}
 // LDS slot (16-byte pieces from the row start) of piece kc = q * C16 + c of a weight row
 __device__ __forceinline__ int slot(int kc) {
   const int q = kc / C16, c = kc - q * C16;
@@ -115,9 +131,17 @@ __global__ __launch_bounds__(NT) void spike_deconv_wres_kernel(DeconvParams P) {
   // XCD and walk the range side by side (the halo leaves HBM once and comes out of that L2 for the other column blocks)
   const int tiles_x = (W + TW - 1) / TW, tiles_img = tiles_x * ((H + TH - 1) / TH);
   const int Gd = gridDim.x;
-  int wg = blockIdx.x;
-  if ((Gd & 7) == 0) wg = (wg & 7) * (Gd >> 3) + (wg >> 3);
-  const int nr = Gd / P.tiles_n, r = wg / P.tiles_n, cbw = wg - r * P.tiles_n;
+  int wg = blockIdx.x, nr, r, cbw, kcls = 4;
+  if (P.cls_nr[0] > 0) {                                   // class-balanced form
+    const int cbc = P.Cout / NB;
+    kcls = wg >= P.cls_start[3] ? 3 : (wg >= P.cls_start[2] ? 2 : (wg >= P.cls_start[1] ? 1 : 0));
+    kcls = __builtin_amdgcn_readfirstlane(kcls);
+    const int wl = wg - P.cls_start[kcls];
+    nr = P.cls_nr[kcls]; r = wl / cbc; cbw = kcls * cbc + (wl - r * cbc);
+  } else {
+    if ((Gd & 7) == 0) wg = (wg & 7) * (Gd >> 3) + (wg >> 3);
+    nr = Gd / P.tiles_n; r = wg / P.tiles_n; cbw = wg - r * P.tiles_n;
+  }
   if (r >= nr) return;
   const int base = P.tiles_m / nr, rem = P.tiles_m % nr;
   const int t_begin = r * base + (r < rem ? r : rem), n_my = base + (r < rem ? 1 : 0);
@@ -222,22 +246,32 @@ __global__ __launch_bounds__(NT) void spike_deconv_wres_kernel(DeconvParams P) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[dg][e] = 0;
     constexpr int PF = 2;
-    i32x4 fa[PF + 1], fb[PF + 1][3];
-    auto frag = [&](int ks, int set) __attribute__((always_inline)) {
-      fa[set] = *reinterpret_cast<const i32x4*>(H_s + a_base[step_base(ks)] + step_off(ks));
+    auto mfma_phase = [&](auto tag) __attribute__((always_inline)) {
+      constexpr int CLS = decltype(tag)::value, NS = cls_nsteps(CLS);
+      i32x4 fa[PF + 1], fb[PF + 1][3];
+      auto frag = [&](int i, int set) __attribute__((always_inline)) {
+        const int ks = cls_step(CLS, i);
+        fa[set] = *reinterpret_cast<const i32x4*>(H_s + a_base[step_base(ks)] + step_off(ks));
 #pragma unroll
-      for (int dg = 0; dg < 3; ++dg) fb[set][dg] = *reinterpret_cast<const i32x4*>(W_s + w_lane + (dg * NB * WP + ks * 32));
+        for (int dg = 0; dg < 3; ++dg) fb[set][dg] = *reinterpret_cast<const i32x4*>(W_s + w_lane + (dg * NB * WP + ks * 32));
+      };
+#pragma unroll
+      for (int i = 0; i < PF; ++i) frag(i, i);
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        if (i + PF < NS) frag(i + PF, (i + PF) % (PF + 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dg = 0; dg < 3; ++dg)
+          acc[dg] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[i % (PF + 1)][dg], fa[i % (PF + 1)], acc[dg], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     };
-#pragma unroll
-    for (int i = 0; i < PF; ++i) frag(i, i);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + PF < KS) frag(ks + PF, (ks + PF) % (PF + 1));
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int dg = 0; dg < 3; ++dg)
-        acc[dg] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[ks % (PF + 1)][dg], fa[ks % (PF + 1)], acc[dg], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+    switch (kcls) {                                          // (wave-uniform: a workgroup's column block lies in one class)
+      case 0: mfma_phase(std::integral_constant<int, 0>{}); break;
+      case 1: mfma_phase(std::integral_constant<int, 1>{}); break;
+      case 2: mfma_phase(std::integral_constant<int, 2>{}); break;
+      default: mfma_phase(std::integral_constant<int, 4>{}); break;
     }
     signal(&cnt[NGRP + grp], lane);
 
@@ -299,19 +333,45 @@ int launch_spike_deconv_wres(const uint8_t* A, const int8_t* Wd, const float* cs
   P.tiles_m = imgs * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
   P.tiles_n = (P.N + NB - 1) / NB;
   P.ntiles = P.tiles_m * P.tiles_n;
-  // tile ranges x column blocks, column block fastest: as many ranges as fill the chip once with the grid a multiple of 8 (a range's
-  // column blocks then share an XCD: the kernel's id remap)
-  int nr = 256 / P.tiles_n;
-  while (nr > 1 && (nr * P.tiles_n) % 8) --nr;
-  if (nr > P.tiles_m) nr = P.tiles_m;
-  if (nr < 1) nr = 1;
+  int grid;
+  const char* eb = getenv("SDF_DECONV_BALANCE");           // A/B: 0 = every column block multiplies all four quadrants
+  if (Cout % NB == 0 && P.tiles_m >= 64 && !(eb && eb[0] == '0')) {
+    // class-balanced: ranges per class in proportion to a tile's cost in that class - its K steps plus the part every tile pays (halo,
+    // epilogue, stores: 16 K steps' worth measured best; SDF_DECONV_EPI: tuning override) - 250 - 256 workgroups in all
+    const int cbc = Cout / NB, budget = 256 / cbc;
+    int epi = 16;
+    if (const char* e = getenv("SDF_DECONV_EPI")) { const int v = atoi(e); if (v >= 0 && v <= 100) epi = v; }
+    int tot = 0, nrc[4];
+    for (int c = 0; c < 4; ++c) tot += cls_nsteps(c) + epi;
+    int used = 0;
+    for (int c = 0; c < 4; ++c) {
+      nrc[c] = budget * (cls_nsteps(c) + epi) / tot;
+      if (nrc[c] < 1) nrc[c] = 1;
+      if (nrc[c] > P.tiles_m) nrc[c] = P.tiles_m;
+      used += nrc[c];
+    }
+    while (used < budget && nrc[3] < P.tiles_m) { ++nrc[3]; ++used; }
+    P.cls_start[0] = 0;
+    for (int c = 0; c < 4; ++c) { P.cls_nr[c] = nrc[c]; P.cls_start[c + 1] = P.cls_start[c] + nrc[c] * cbc; }
+    grid = P.cls_start[4];
+  } else {
+    // tile ranges x column blocks, column block fastest: as many ranges as fill the chip once with the grid a multiple of 8 (a range's
+    // column blocks then share an XCD: the kernel's id remap)
+    int nr = 256 / P.tiles_n;
+    while (nr > 1 && (nr * P.tiles_n) % 8) --nr;
+    if (nr > P.tiles_m) nr = P.tiles_m;
+    if (nr < 1) nr = 1;
+    for (int c = 0; c < 4; ++c) P.cls_nr[c] = 0;
+    for (int c = 0; c < 5; ++c) P.cls_start[c] = 0;
+    grid = nr * P.tiles_n;
+  }
   static bool raised = false;
   if (!raised) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spike_deconv_wres_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     raised = true;
   }
-  hipLaunchKernelGGL(spike_deconv_wres_kernel, dim3((unsigned)(nr * P.tiles_n)), dim3(NT), LDS_BYTES, s, P);
+  hipLaunchKernelGGL(spike_deconv_wres_kernel, dim3((unsigned)grid), dim3(NT), LDS_BYTES, s, P);
   hipError_t e = hipGetLastError();
   return e != hipSuccess ? (int)e : 0;
 }
