@@ -19,7 +19,10 @@
 //     half wave's share is one of two lane bases and every step's offset an immediate (the K order of an exact sum is free);
 //   * two groups per workgroup run out of phase (hand-over through LDS counters as in the convolution kernel);
 //   * epilogue: digits -> fp32, BatchNorm, and a 16-byte piece of 4 channels goes to output pixel (2a + py, 2b + px) of its column's
-//     class: the two pixels of a row's line are written by neighbouring pieces of the same wave.
+//     class: the two pixels of a row's line are written by neighbouring pieces of the same wave;
+//   * Cout % 32 == 0: a 32-column block lies inside ONE class, and a class only receives the quadrants with dh <= py, dw <= px - the
+//     workgroup runs just those K steps (7 / 13 / 14 / 26 of 26: the zero blocks are never multiplied), and the tile ranges per class
+//     are sized by a tile's cost in that class so that all workgroups finish together.
 // Compiled with -ffp-contract=off.
 #include "spike_mm.h"
 #include "wide_common.h"
