@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), name
     lib.sdf_version.restype = ctypes.c_int
-    assert lib.sdf_version() == 104            # host-only call, no GPU needed
+    assert lib.sdf_version() == 105            # host-only call, no GPU needed
 
 
 def test_product_refuses_cpu_tensors():
