@@ -772,6 +772,24 @@ typedef struct SdfDenseLinearDesc {
 
 int sdf_dense_linear_fwd(const SdfDenseLinearDesc* d, void* stream);
 
+/* Weight gradient of a Linear layer fed by spikes (training path, BASELINE configs[3]): dw[n, k] = sum_m dy[m, n] * x[m, k] - what
+ * autograd computes for every nn.Linear of the MS swin blocks in the reference's step (train_flow_parallel_supervised_SNN.py:233-336
+ * `loss.backward()`; layers Spiking_swin_transformer3D.py:661-717, :164-181, :952-974).  dy (M, N) and x (M, K) fp32 row-major, x
+ * holding values exact in bf16 (spikes: 0 / 1); dy is split into three bf16 planes inside the kernel (exact), fp32 accumulation.
+ * N % 96 == 0, K % 96 == 0.  nsplit = sdf_linear_dw_splits(M, N, K) ranges of m are summed in a fixed order through `partial`
+ * (nsplit x N x K fp32; may be NULL when nsplit == 1).  dw is overwritten. */
+typedef struct SdfLinearDwDesc {
+  const float* dy;
+  const float* x;
+  float* dw;
+  float* partial;
+  int64_t M;
+  int32_t N, K, nsplit;
+} SdfLinearDwDesc;
+
+int sdf_linear_dw_splits(int64_t M, int N, int K);
+int sdf_linear_dw_fwd(const SdfLinearDwDesc* d, void* stream);
+
 /* nn.LayerNorm over the last dim of x (rows, C) fp32, elementwise affine (reference models/STSwinNet/swin_transformer3D_v2.py:
  * `norm1` / `norm2` of the blocks :231-233, `PatchMerging.norm` :356, the per-stage output norms :622-624).  C % 4 == 0, C <= 2048. */
 int sdf_layer_norm_fwd(const float* x, const float* gamma, const float* beta, float* out, int64_t rows, int C, float eps, void* stream);

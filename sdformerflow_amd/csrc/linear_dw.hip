@@ -1,0 +1,257 @@
+// Weight gradient of a Linear layer fed by SPIKES, for gfx950 (training path, BASELINE configs[3]):
+//
+//   dW[n, k] = sum_m dY[m, n] * X[m, k]          dY (M, N) fp32 row-major, X (M, K) fp32 row-major holding 0 / 1
+//
+// what torch.autograd computes for every nn.Linear of the MS swin blocks in the reference's training step
+// (train_flow_parallel_supervised_SNN.py:233-336 `loss.backward()`; the layers: Spiking_swin_transformer3D.py:661-717 linear_q /
+// linear_k / proj, :164-181 fc1 / fc2, :952-974 reduction) - until round 5 a library fp32 GEMM with a 276 480-long reduction
+// and a 96 x 96 result at stage 0.
+//
+// Both operands are m-major in memory and the matrix pipe wants the reduction index contiguous per lane: the tiles go into LDS as
+// they lie in memory (row = m, 16-bit elements) and are read back with ds_read_b64_tr_b16, gfx950's transposing LDS read - a 16-lane
+// group takes a 4-row x 16-column block and each lane receives one COLUMN of it, which is the operand layout of
+// v_mfma_f32_16x16x32_bf16 (lane = (column, k group), 8 reduction indices per lane in two such reads).  The order of the reduction
+// inside a 32-row chunk is free as long as both operands agree: k group g takes rows 4g..4g+3 and 16+4g..16+4g+3, so that the two
+// groups of a 32-lane half read rows 0..7 of a 224-byte pitch = 8 disjoint runs of 8 banks (conflict-free; the natural 8g..8g+7
+// cannot be: rows r and r + 8 share banks at every pitch whose runs are 8-bank aligned).
+//
+// Numerics: the spikes are exact in bf16.  dY is a gradient - its range is not the activations' - and is split, where it enters LDS,
+// into THREE bf16 planes by truncation (hi = top 16 bits, mid = top 16 bits of the exact remainder, lo = the rest: 8 + 8 + 8
+// mantissa bits, hi + mid + lo == dY exactly, fp32's exponent range, no scale to choose), three products per block, fp32 accumulation.
+// The kernel is HBM-bound at N = K = 96 (480 B of operands per row against 55 kflop x 3) and the third product is free there.
+//
+// A workgroup (4 waves) owns a 96 x 96 tile of dW over a contiguous range of m; a wave 48 x 48 (3 x 3 blocks of 16 x 16).  m advances
+// in chunks of 32 through a double-buffered LDS image (next chunk requested before the MFMAs, split / written after them, one
+// barrier per chunk).  The m ranges of a tile (split count chosen for ~3 workgroups per compute unit) leave fp32 partial tiles that a
+// second kernel adds in a fixed order - no atomics, the same bits every run.
+#include "common.h"
+
+namespace {
+
+constexpr int TN = 96, TK = 96, MC = 32;
+constexpr int RP = 224;                                  // LDS row pitch in bytes: 96 x 16 bit + 32 pad = 7 x 32 (see above)
+constexpr int PLANE = MC * RP;
+constexpr int BUF = 4 * PLANE;                           // dY hi, mid, lo, X
+constexpr uint32_t INV = 0x80000000u;
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct DwParams {
+  SdfLinearDwDesc d;
+  int tiles_n, tiles_k, rows_per_split;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// two fp32 values -> the dword {bf16(a), bf16(b)} of their top halves
+__device__ __forceinline__ uint32_t top2(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+// four fp32 values -> three 8-byte words of bf16 planes, hi + mid + lo == v exactly (truncation splits)
+__device__ __forceinline__ void split3(u32x4 v, uint2& hi, uint2& mid, uint2& lo) {
+  uint32_t h[4], m[4], l[4];
+  const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = x[i] & 0xFFFF0000u;
+    const float r1 = __uint_as_float(x[i]) - __uint_as_float(h[i]);
+    m[i] = __float_as_uint(r1) & 0xFFFF0000u;
+    l[i] = __float_as_uint(r1 - __uint_as_float(m[i]));            // <= 8 significant bits: its top half is all of it
+  }
+  hi = make_uint2(top2(h[0], h[1]), top2(h[2], h[3]));
+  mid = make_uint2(top2(m[0], m[1]), top2(m[2], m[3]));
+  lo = make_uint2(top2(l[0], l[1]), top2(l[2], l[3]));
+}
+
+__device__ __forceinline__ bf16x8 tr_frag(const uint8_t* p) {
+  // rows 4g + q (this read) and 16 + 4g + q (the next): element j of the lane = reduction index 4g + j, 16 + 4g + (j - 4)
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * RP));
+  s16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+__global__ __launch_bounds__(256, 2) void linear_dw_kernel(DwParams P) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[2 * BUF];
+  const SdfLinearDwDesc& d = P.d;
+  const int N = d.N, K = d.K;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int tiles = P.tiles_n * P.tiles_k;
+  const int split = blockIdx.x / tiles, tile = blockIdx.x - split * tiles;   // the tiles of one m range are neighbours: its rows come out of L2
+  const int tn = tile / P.tiles_k, tk = tile - tn * P.tiles_k;
+  const int n0 = tn * TN, k0 = tk * TK;
+  const int64_t m_begin = (int64_t)split * P.rows_per_split;
+  int64_t m_end = m_begin + P.rows_per_split;
+  if (m_end > d.M) m_end = d.M;
+  const int nchunk = m_end > m_begin ? (int)((m_end - m_begin + MC - 1) / MC) : 0;
+
+  const __amdgpu_buffer_rsrc_t Y_rs = rsrc(d.dy, (uint32_t)(d.M * N * 4));
+  const __amdgpu_buffer_rsrc_t X_rs = rsrc(d.x, (uint32_t)(d.M * K * 4));
+
+  // loader: a chunk is 32 rows x 24 float4 of each operand = 768 pieces, 3 per thread and operand
+  uint32_t y_off[3], x_off[3], lds_off[3];
+  int prow[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int p = tid + 256 * i, row = p / 24, c4 = p - row * 24;
+    prow[i] = row;
+    y_off[i] = (uint32_t)(((m_begin + row) * N + n0 + c4 * 4) * 4);
+    x_off[i] = (uint32_t)(((m_begin + row) * K + k0 + c4 * 4) * 4);
+    lds_off[i] = (uint32_t)(row * RP + c4 * 8);
+  }
+  // two register sets: chunks c + 1 AND c + 2 are in flight while chunk c is multiplied (a chunk's MFMAs are ~0.5 us, a load ~2)
+  u32x4 yA[3], xA[3], yB[3], xB[3];
+  auto request = [&](int c, u32x4 (&yreg)[3], u32x4 (&xreg)[3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const bool ok = m_begin + (int64_t)c * MC + prow[i] < m_end;
+      yreg[i] = __builtin_amdgcn_raw_buffer_load_b128(Y_rs, ok ? y_off[i] + (uint32_t)c * (uint32_t)(MC * N * 4) : INV, 0, 0);
+      xreg[i] = __builtin_amdgcn_raw_buffer_load_b128(X_rs, ok ? x_off[i] + (uint32_t)c * (uint32_t)(MC * K * 4) : INV, 0, 0);
+    }
+  };
+  auto deposit = [&](uint8_t* buf, u32x4 (&yreg)[3], u32x4 (&xreg)[3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      uint2 hi, mid, lo;
+      split3(yreg[i], hi, mid, lo);
+      *reinterpret_cast<uint2*>(buf + lds_off[i]) = hi;
+      *reinterpret_cast<uint2*>(buf + PLANE + lds_off[i]) = mid;
+      *reinterpret_cast<uint2*>(buf + 2 * PLANE + lds_off[i]) = lo;
+      *reinterpret_cast<uint2*>(buf + 3 * PLANE + lds_off[i]) = make_uint2(top2(xreg[i].x, xreg[i].y), top2(xreg[i].z, xreg[i].w));
+    }
+  };
+
+  // transposed reads: lane (g, q, p) of a fragment supplies the address of row 4g + q, columns 4p .. 4p + 3 of the block
+  int ln = lane;
+  asm volatile("" : "+v"(ln));
+  const int g = ln >> 4, li = ln & 15;
+  const uint32_t tr_lane = (uint32_t)((4 * g + (li >> 2)) * RP + (li & 3) * 8);
+  const int wn = wave >> 1, wk = wave & 1;
+  const uint32_t a_base = tr_lane + (uint32_t)(48 * wn * 2);           // dY columns n0 + 48 wn + ...
+  const uint32_t b_base = 3 * PLANE + tr_lane + (uint32_t)(48 * wk * 2);
+
+  f32x4 acc[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto multiply = [&](const uint8_t* cur) __attribute__((always_inline)) {
+    bf16x8 b[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) b[j] = tr_frag(cur + b_base + j * 32);
+#pragma unroll
+    for (int pl = 2; pl >= 0; --pl) {                                   // small terms first
+      bf16x8 a[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) a[i] = tr_frag(cur + pl * PLANE + a_base + i * 32);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  // (requests past the range load nothing: every offset is INV)
+  request(0, yA, xA);
+  request(1, yB, xB);
+  deposit(smem, yA, xA);
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < nchunk; c += 2) {
+    request(c + 2, yA, xA);
+    multiply(smem);
+    deposit(smem + BUF, yB, xB);                                        // chunk c + 1
+    __syncthreads();
+    if (c + 1 < nchunk) {
+      request(c + 3, yB, xB);
+      multiply(smem + BUF);
+    }
+    deposit(smem, yA, xA);                                              // chunk c + 2
+    __syncthreads();
+  }
+
+  // accumulator register r of block (i, j): dW[n0 + 48 wn + 16 i + 4 g + r][k0 + 48 wk + 16 j + li]
+  float* out = d.nsplit > 1 ? d.partial + (int64_t)split * N * K : d.dw;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* row = out + (int64_t)(n0 + 48 * wn + 16 * i + 4 * g + r) * K + k0 + 48 * wk + li;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) row[16 * j] = acc[i][j][r];
+    }
+}
+
+// dw[i] = sum over the m ranges in a FIXED order: 16 lanes take the ranges s = l, l + 16, ... of a float4 column in turn and their
+// sums meet in a fixed tree (a 96 x 96 layer has 768 ranges and only 2 304 float4 columns: one thread per column walked them for
+// longer than the product took)
+__global__ __launch_bounds__(256) void linear_dw_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int n4, int nsplit) {
+  __shared__ float4 red[256];
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < n4) {
+    const float4* p = reinterpret_cast<const float4*>(partial) + col;
+    for (int k = sl; k < nsplit; k += 16) {
+      const float4 v = p[(int64_t)k * n4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+#pragma unroll
+  for (int h = 8; h >= 1; h >>= 1) {
+    if (sl < h) {
+      const float4 a = red[threadIdx.x], b = red[threadIdx.x + 16 * h];
+      red[threadIdx.x] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    __syncthreads();
+  }
+  if (sl == 0 && col < n4) reinterpret_cast<float4*>(dw)[col] = red[threadIdx.x];
+}
+
+}  // namespace
+
+// the number of m ranges sdf_linear_dw_fwd wants for this shape (the caller provides `partial` of that many N x K fp32 tiles when > 1)
+extern "C" int sdf_linear_dw_splits(int64_t M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || N % TN || K % TK) return 0;
+  const int64_t tiles = (int64_t)(N / TN) * (K / TK);
+  int64_t want = (768 + tiles - 1) / tiles;                           // ~3 workgroups per compute unit in all
+  const int64_t most = (M + 8 * MC - 1) / (8 * MC);                   // a range is at least 8 chunks long
+  if (want > most) want = most;
+  if (want < 1) want = 1;
+  return (int)want;
+}
+
+extern "C" int sdf_linear_dw_fwd(const SdfLinearDwDesc* d, void* stream) {
+  if (!d || !d->dy || !d->x || !d->dw) return SDF_E_NULL;
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->N % TN || d->K % TK || d->nsplit < 1) return SDF_E_SHAPE;
+  if (d->nsplit > 1 && !d->partial) return SDF_E_NULL;
+  const int64_t lim = (int64_t)1 << 31;
+  if (d->M * d->N * 4 >= lim || d->M * d->K * 4 >= lim || (int64_t)d->N * d->K * 4 >= lim) return SDF_E_SHAPE;
+  if (!sdf_aligned(d->dy, 16) || !sdf_aligned(d->x, 16) || !sdf_aligned(d->dw, 16) || (d->partial && !sdf_aligned(d->partial, 16))) return SDF_E_ALIGN;
+  DwParams P;
+  P.d = *d;
+  P.tiles_n = d->N / TN;
+  P.tiles_k = d->K / TK;
+  const int64_t chunks = (d->M + MC - 1) / MC;
+  P.rows_per_split = (int)((chunks + d->nsplit - 1) / d->nsplit) * MC;
+  const int64_t wgs = (int64_t)d->nsplit * P.tiles_n * P.tiles_k;
+  if (wgs >= lim) return SDF_E_SHAPE;
+  hipStream_t s = sdf_stream(stream);
+  hipLaunchKernelGGL(linear_dw_kernel, dim3((unsigned)wgs), dim3(256), 0, s, P);
+  SDF_LAUNCH_CHECK();
+  if (d->nsplit > 1) {
+    const int n4 = d->N * d->K / 4;
+    hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, d->partial, d->dw, n4, d->nsplit);
+    SDF_LAUNCH_CHECK();
+  }
+  return 0;
+}

@@ -27,7 +27,8 @@ EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_s
            "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_pred_head_fwd", "sdf_pointwise_conv_f32_fwd", "sdf_neuron_multi_fwd", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
            "sdf_rows_gather_fwd", "sdf_rows_scatter_fwd",
            "sdf_split_weight_i8x3", "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd",
-           "sdf_dense_conv3x3_fwd", "sdf_pack_planes", "sdf_unpack_planes", "sdf_pack_planes_up2", "sdf_dense_linear_fwd", "sdf_layer_norm_fwd")
+           "sdf_dense_conv3x3_fwd", "sdf_pack_planes", "sdf_unpack_planes", "sdf_pack_planes_up2", "sdf_dense_linear_fwd", "sdf_layer_norm_fwd",
+           "sdf_linear_dw_fwd", "sdf_linear_dw_splits")
 
 
 class SdfError(RuntimeError):
@@ -115,6 +116,11 @@ class DenseLinearDesc(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("gelu", C.c_int32),
                 ("cv_H", C.c_int32), ("cv_W", C.c_int32), ("cv_C", C.c_int32), ("cv_stride", C.c_int32), ("cv_OH", C.c_int32),
                 ("cv_OW", C.c_int32), ("out_T", C.c_int32), ("acc_scale", C.c_float)]
+
+
+class LinearDwDesc(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("partial", C.c_void_p),
+                ("M", C.c_int64), ("N", C.c_int32), ("K", C.c_int32), ("nsplit", C.c_int32)]
 
 
 _lib = None
@@ -1174,6 +1180,31 @@ def dense_linear(a, wplanes, bias=None, gelu=False, resid=None, out=None):
     d.acc_scale = _dense_scale(wplanes)
     _check(lib().sdf_dense_linear_fwd(C.byref(d), _stream()), "sdf_dense_linear_fwd")
     return out
+
+
+def linear_dw_applicable(M, N, K):
+    return N % 96 == 0 and K % 96 == 0 and M * max(N, K) * 4 < 1 << 31
+
+
+def linear_dw(dy, x):
+    """dW (N, K) = dy.T @ x for dy (M, N) fp32 and x (M, K) fp32 holding spikes (values exact in bf16) - the weight gradient of a
+    spike-fed Linear layer (sdf_linear_dw_fwd): dy split into three bf16 planes in the kernel, fp32 accumulation, m ranges summed in a
+    fixed order."""
+    M, N = dy.shape
+    K = x.shape[1]
+    if x.shape[0] != M or not dy.is_contiguous() or not x.is_contiguous():
+        raise SdfError("linear_dw needs contiguous (M, N) and (M, K) operands")
+    ns = lib().sdf_linear_dw_splits(C.c_int64(M), C.c_int(N), C.c_int(K))
+    if ns < 1:
+        raise SdfError(f"sdf_linear_dw_fwd: unsupported shape M={M} N={N} K={K} (N and K must be multiples of 96)")
+    dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    part = torch.empty((ns, N, K), dtype=torch.float32, device=dy.device) if ns > 1 else None
+    d = LinearDwDesc()
+    d.dy, d.x, d.dw, d.partial = _ptr(dy, torch.float32), _ptr(x, torch.float32), _ptr(dw, torch.float32), _ptr(part, torch.float32)
+    d.M, d.N, d.K, d.nsplit = M, N, K, ns
+    _note(flop=2.0 * M * N * K, bytes=4.0 * M * (N + K), what=f"linear dW {M}x{N}x{K}")
+    _check(lib().sdf_linear_dw_fwd(C.byref(d), _stream()), "sdf_linear_dw_fwd")
+    return dw
 
 
 def layer_norm(x, gamma, beta, eps):

@@ -1,0 +1,57 @@
+"""Weight gradient of a spike-fed Linear layer (csrc/linear_dw.hip, `sdf_linear_dw_fwd`): dW = dY^T X, what autograd computes for
+nn.Linear in the reference's training step (train_flow_parallel_supervised_SNN.py:233-336).  Checked against the same product in
+fp64 on the SAME inputs: the kernel's three-plane bf16 split of dY is exact, so what remains is fp32 accumulation - the bound is
+stated against sum_m |dY| |X| per element, and gradient-like inputs span twelve decades."""
+import pytest
+import torch
+
+from sdformerflow_amd import hip
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _inputs(M, N, K, seed, decades=12.0, rate=0.3):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    dy = torch.randn((M, N), generator=g) * torch.pow(10.0, -decades * torch.rand((M, N), generator=g))
+    x = (torch.rand((M, K), generator=g) < rate).float()
+    return dy.to(DEV), x.to(DEV)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 96, 96), (33, 96, 192), (4096, 192, 96), (20000, 96, 384), (2500, 384, 96), (7, 96, 96),
+                                   (4320, 768, 768)])
+def test_dw_equals_the_fp64_product(M, N, K):
+    dy, x = _inputs(M, N, K, 1000 + M)
+    dw = hip.linear_dw(dy, x)
+    ref = dy.double().t() @ x.double()
+    bound = dy.double().abs().t() @ x.double()
+    err = (dw.double() - ref).abs()
+    # fp32 accumulation of exact products: a few ulp of the running sum per chunk; 2e-6 of the sum of magnitudes is generous
+    assert bool((err <= 2e-6 * bound + 1e-37).all()), float((err / (bound + 1e-37)).max())
+    # and, as the training tests state it, against the largest element
+    assert float(err.max()) <= 2e-6 * float(ref.abs().max())
+
+
+def test_the_split_of_dy_is_exact():
+    """One row, one spike per column: dW[n, k] must be dY[0, n] bit for bit wherever x[0, k] = 1 - hi + mid + lo == dY."""
+    N = K = 96
+    g = torch.Generator(device="cpu").manual_seed(5)
+    dy = (torch.randn((1, N), generator=g) * torch.pow(10.0, -30 * torch.rand((1, N), generator=g))).to(DEV)
+    x = torch.ones((1, K), device=DEV)
+    dw = hip.linear_dw(dy, x)
+    assert torch.equal(dw, dy.t().expand(N, K))
+
+
+def test_m_ranges_are_summed_in_a_fixed_order():
+    dy, x = _inputs(50000, 96, 96, 77)
+    assert hip.lib().sdf_linear_dw_splits(50000, 96, 96) > 1
+    a, b = hip.linear_dw(dy, x), hip.linear_dw(dy, x)
+    assert torch.equal(a, b)
+
+
+def test_shapes_outside_the_kernel_are_refused():
+    dy, x = _inputs(64, 96, 80, 3)
+    with pytest.raises(hip.SdfError):
+        hip.linear_dw(dy, x)
+    with pytest.raises(hip.SdfError):
+        hip.linear_dw(dy.cpu(), x.cpu())

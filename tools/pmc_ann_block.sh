@@ -14,7 +14,7 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("gpurun_out/pmc_ann_block/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "ann_attn_block" in r["Kernel_Name"]:
+        if ("ann_attn_block" in r["Kernel_Name"] or "ann_mlp_block" in r["Kernel_Name"]):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(acc):
     v = acc[k]
