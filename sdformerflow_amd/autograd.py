@@ -151,6 +151,32 @@ class WindowScatterFunction(torch.autograd.Function):
         return hip.rows_gather(g.float().contiguous().view(-1, g.shape[-1]), row_map).to(ctx.in_dtype), None, None
 
 
+class LinearDwFunction(torch.autograd.Function):
+    """nn.Linear on a SPIKE tensor with its weight gradient on csrc/linear_dw.hip: dW = dY^T X has a reduction as long as the
+    token count (276 480 at stage 0, local batch 4) and a 96 x 96 ... 768 x 3 072 result - the library's fp32 product took 20 ms of a
+    117 ms step on it, the kernel 4 ms (tools/linear_dw_bench.py).  Forward and dX = dY W stay library products.  The activation
+    is saved as autograd would save it (fp32); what the kernel needs of it is that its values are exact in bf16 (0 / 1).
+    Reference: autograd through nn.Linear in train_flow_parallel_supervised_SNN.py:233-336."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        N, K = weight.shape
+        g2 = g.reshape(-1, N)
+        gx = (g2 @ weight.to(g2.dtype)).view(x.shape).to(x.dtype) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = hip.linear_dw(g2.float().contiguous(), x.reshape(-1, K).float().contiguous()).to(weight.dtype)
+        gb = g2.sum(0).to(weight.dtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
 class SpikeLinearFunction(torch.autograd.Function):
     """Linear layer on a spike tensor in the training path: the FORWARD is the inference path's spike GEMM (binary activations
     exact in 16 bits, fp32-grade weight planes re-split from the current weights, fp32 accumulate) and the activation is kept

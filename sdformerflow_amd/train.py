@@ -2,9 +2,10 @@
 autograd, the supervised loss, one optimiser step, and the data-parallel gradient all-reduce.
 
 What is hand-written HIP here: every spiking neuron, forward AND backward (`autograd.LIFFunction` / `PSNFunction` ->
-csrc/neuron.hip, csrc/neuron_bwd.hip; 105 neuron calls per forward).  The dense operators between them - Linear /
-Conv2d / ConvTranspose2d and their gradients, batch-statistics BatchNorm - are library work through torch on the same
-stream (rocBLAS / MIOpen); their spike-aware replacements are the next row.  Nothing here touches `oracle/`, and CPU
+csrc/neuron.hip, csrc/neuron_bwd.hip; 105 neuron calls per forward), the batch-statistics BatchNorm, the token gate, and -
+since round 5 - the WEIGHT GRADIENT of every Linear layer (`autograd.LinearDwFunction` -> csrc/linear_dw.hip: 20 ms of library
+product -> 4 ms).  The other dense products - Linear forward / dX, Conv2d / ConvTranspose2d and their gradients - are library work
+through torch on the same stream (rocBLAS / MIOpen); their replacements are the next row.  Nothing here touches `oracle/`, and CPU
 tensors are refused by the neuron kernels (`SdfError`).
 
 Reference semantics mirrored (file:line under /root/reference):
@@ -20,6 +21,8 @@ Reference semantics mirrored (file:line under /root/reference):
   data parallelism        the reference wraps the model in DataParallel: replicas, local batch statistics, summed
                           gradients; here one process per GPU and ONE bucketed all-reduce(sum)/world per step (RCCL)
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -33,6 +36,8 @@ from . import hip
 # 130 ms: u8 conversion + per-step weight split + fp32 re-expansion in the backward; under bf16 autocast 95 -> 114 ms because
 # the backward products leave autocast) - so it stays off until the backward products are spike-aware too.
 SPIKE_LINEAR_PLANES = 0
+# Weight gradient of the Linear layers on csrc/linear_dw.hip (round 5; SDF_TRAIN_LINEAR_DW=0: the library product, for A/B runs)
+LINEAR_DW_HIP = os.environ.get("SDF_TRAIN_LINEAR_DW", "1") != "0"
 
 
 def _linear(x, lin):
@@ -42,6 +47,9 @@ def _linear(x, lin):
     if SPIKE_LINEAR_PLANES and K % 32 == 0 and N % 32 == 0:
         from .autograd import SpikeLinearFunction
         return SpikeLinearFunction.apply(x, lin.weight, lin.bias, SPIKE_LINEAR_PLANES)
+    if LINEAR_DW_HIP and x.is_cuda and hip.linear_dw_applicable(x.numel() // K, N, K):
+        from .autograd import LinearDwFunction
+        return LinearDwFunction.apply(x, lin.weight, lin.bias)
     return F.linear(x, lin.weight, lin.bias)
 
 

@@ -55,3 +55,27 @@ def test_shapes_outside_the_kernel_are_refused():
         hip.linear_dw(dy, x)
     with pytest.raises(hip.SdfError):
         hip.linear_dw(dy.cpu(), x.cpu())
+
+
+def test_linear_function_gradients_equal_autograd_of_f_linear():
+    """`autograd.LinearDwFunction` (the training path's Linear on spikes, train._linear) against torch.autograd through
+    F.linear on the same inputs: same output bits, same dX bits (both library products), dW / db within fp32 accumulation."""
+    import torch.nn.functional as F
+    from sdformerflow_amd.autograd import LinearDwFunction
+    g = torch.Generator(device="cpu").manual_seed(9)
+    x = (torch.rand((2, 50, 162, 96), generator=g) < 0.25).float().to(DEV)
+    w = (torch.randn((384, 96), generator=g) * 0.05).to(DEV)
+    b = (torch.randn((384,), generator=g) * 0.1).to(DEV)
+    go = (torch.randn((2, 50, 162, 384), generator=g) * 1e-4).to(DEV)
+    res = []
+    for fn in (lambda x_, w_, b_: F.linear(x_, w_, b_), LinearDwFunction.apply):
+        x_, w_, b_ = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = fn(x_, w_, b_)
+        y.backward(go)
+        res.append((y.detach(), x_.grad, w_.grad, b_.grad))
+    (y0, gx0, gw0, gb0), (y1, gx1, gw1, gb1) = res
+    assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
+    ref = go.reshape(-1, 384).double().t() @ x.reshape(-1, 96).double()
+    assert float((gw1.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    assert float((gw0.double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())      # (the library's own distance, for scale)
+    assert torch.allclose(gb0, gb1, rtol=1e-5, atol=1e-9)
