@@ -776,8 +776,15 @@ int sdf_dense_linear_fwd(const SdfDenseLinearDesc* d, void* stream);
  * autograd computes for every nn.Linear of the MS swin blocks in the reference's step (train_flow_parallel_supervised_SNN.py:233-336
  * `loss.backward()`; layers Spiking_swin_transformer3D.py:661-717, :164-181, :952-974).  dy (M, N) and x (M, K) fp32 row-major, x
  * holding values exact in bf16 (spikes: 0 / 1); dy is split into three bf16 planes inside the kernel (exact), fp32 accumulation.
- * N % 96 == 0, K % 96 == 0.  nsplit = sdf_linear_dw_splits(M, N, K) ranges of m are summed in a fixed order through `partial`
- * (nsplit x N x K fp32; may be NULL when nsplit == 1).  dw is overwritten. */
+ * N % 96 == 0, K % 96 == 0.  nsplit = sdf_linear_dw_splits(M, N, K, cv_C) ranges of m are summed in a fixed order through `partial`
+ * (nsplit x N x K fp32; may be NULL when nsplit == 1).  dw is overwritten.
+ *
+ * Convolution form (cv_C > 0): the weight gradient of a 3x3 / stride 1 / pad 1 convolution fed by spikes (the patch embedding's and
+ * the bottleneck's MS_ResBlock convolutions, reference Spiking_modules.py:291-347; autograd's `conv2d_weight`) on ZERO-RINGED
+ * channels-last images: row m is a pixel of the (H + 2) x cv_Wp grid of an image (cv_Wp = W + 2), dy (M, N) is zero on the ring, x is
+ * (M, cv_C) with the ring zero (the convolution's padding), K = 9 cv_C and
+ *   dw[n, (ky * 3 + kx) * cv_C + c] = sum_m dy[m, n] * x[m + (ky - 1) * cv_Wp + (kx - 1), c]       (rows outside [0, M) read as zero)
+ * cv_C % 96 == 0. */
 typedef struct SdfLinearDwDesc {
   const float* dy;
   const float* x;
@@ -785,10 +792,13 @@ typedef struct SdfLinearDwDesc {
   float* partial;
   int64_t M;
   int32_t N, K, nsplit;
+  int32_t cv_C, cv_Wp;
 } SdfLinearDwDesc;
 
-int sdf_linear_dw_splits(int64_t M, int N, int K);
+int sdf_linear_dw_splits(int64_t M, int N, int K, int cv_C);
 int sdf_linear_dw_fwd(const SdfLinearDwDesc* d, void* stream);
+/* src (imgs, C, H, W) fp32 -> dst (imgs, H + 2, W + 2, C) fp32, the ring zero: the layout of the convolution form above.  C % 96 == 0. */
+int sdf_ringed_rows_fwd(const float* src, float* dst, int imgs, int C, int H, int W, void* stream);
 
 /* nn.LayerNorm over the last dim of x (rows, C) fp32, elementwise affine (reference models/STSwinNet/swin_transformer3D_v2.py:
  * `norm1` / `norm2` of the blocks :231-233, `PatchMerging.norm` :356, the per-stage output norms :622-624).  C % 4 == 0, C <= 2048. */

@@ -177,6 +177,30 @@ class LinearDwFunction(torch.autograd.Function):
         return gx, gw, gb
 
 
+class Conv3x3DwFunction(torch.autograd.Function):
+    """3x3 / stride 1 / pad 1 Conv2d on a SPIKE image (the MS_ResBlock convolutions of the patch embedding and the bottleneck,
+    reference Spiking_modules.py:291-347) with its weight gradient on csrc/linear_dw.hip's convolution form: 1.1 M pixels x 96 x 864
+    per layer of the patch embedding at local batch 4.  Forward and dX are library convolutions, as before."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.conv2d(x, weight, bias, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.nn.grad.conv2d_input(x.shape, weight.to(g.dtype), g, stride=1, padding=1).to(x.dtype)
+        if ctx.needs_input_grad[1]:
+            gw = hip.conv3x3_dw(g.float().contiguous(), x.float()).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum((0, 2, 3)).to(weight.dtype)
+        return gx, gw, gb
+
+
 class SpikeLinearFunction(torch.autograd.Function):
     """Linear layer on a spike tensor in the training path: the FORWARD is the inference path's spike GEMM (binary activations
     exact in 16 bits, fp32-grade weight planes re-split from the current weights, fp32 accumulate) and the activation is kept

@@ -31,7 +31,6 @@ namespace {
 constexpr int TN = 96, TK = 96, MC = 32;
 constexpr int RP = 224;                                  // LDS row pitch in bytes: 96 x 16 bit + 32 pad = 7 x 32 (see above)
 constexpr int PLANE = MC * RP;
-constexpr int BUF = 4 * PLANE;                           // dY hi, mid, lo, X
 constexpr uint32_t INV = 0x80000000u;
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -43,6 +42,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 struct DwParams {
   SdfLinearDwDesc d;
   int tiles_n, tiles_k, rows_per_split;
+  int x_ld;                                              // row pitch of X in floats (Linear: K; convolution form: C)
+  int cblocks, Wp;                                       // convolution form: 96-channel blocks of C, padded image width
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, uint32_t bytes) {
@@ -78,46 +79,61 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint8_t* p) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
+// TAPS = 1: the Linear form.  TAPS = 3: the 3x3 / stride 1 / pad 1 CONVOLUTION form on zero-ringed channels-last images - row m is a
+// pixel of the (H + 2) x (W + 2) grid, dY is zero on the ring, and tap (ky, kx) multiplies dY[m] with X[m + (ky - 1) Wp + kx - 1]: a
+// column tile is (ky, 96 input channels) and its three kx taps are ONE staged X image of 34 rows read at row offsets 0, 1, 2 - in an
+// m-major image a pixel shift is an address offset of the transposing read, nothing else.
+template <int TAPS>
 __global__ __launch_bounds__(256, 2) void linear_dw_kernel(DwParams P) {
+  constexpr int XR = MC + TAPS - 1;                                   // rows of the X image
+  constexpr int XPLANE = XR * RP, BUF = 3 * PLANE + XPLANE;
+  constexpr int NXP = (XR * 24 + 255) / 256;                          // X pieces per thread
   __shared__ __attribute__((aligned(16))) uint8_t smem[2 * BUF];
   const SdfLinearDwDesc& d = P.d;
-  const int N = d.N, K = d.K;
+  const int N = d.N;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int tiles = P.tiles_n * P.tiles_k;
   const int split = blockIdx.x / tiles, tile = blockIdx.x - split * tiles;   // the tiles of one m range are neighbours: its rows come out of L2
   const int tn = tile / P.tiles_k, tk = tile - tn * P.tiles_k;
-  const int n0 = tn * TN, k0 = tk * TK;
+  const int ky = TAPS == 3 ? tk / P.cblocks : 0, cb = TAPS == 3 ? tk - ky * P.cblocks : tk;
+  const int n0 = tn * TN;
   const int64_t m_begin = (int64_t)split * P.rows_per_split;
   int64_t m_end = m_begin + P.rows_per_split;
   if (m_end > d.M) m_end = d.M;
   const int nchunk = m_end > m_begin ? (int)((m_end - m_begin + MC - 1) / MC) : 0;
+  const int64_t xshift = TAPS == 3 ? (int64_t)(ky - 1) * P.Wp - 1 : 0;  // X row of tap 0 for dY row 0 (may be before the tensor)
 
   const __amdgpu_buffer_rsrc_t Y_rs = rsrc(d.dy, (uint32_t)(d.M * N * 4));
-  const __amdgpu_buffer_rsrc_t X_rs = rsrc(d.x, (uint32_t)(d.M * K * 4));
+  const __amdgpu_buffer_rsrc_t X_rs = rsrc(d.x, (uint32_t)(d.M * P.x_ld * 4));
 
-  // loader: a chunk is 32 rows x 24 float4 of each operand = 768 pieces, 3 per thread and operand
-  uint32_t y_off[3], x_off[3], lds_off[3];
-  int prow[3];
+  // loader: a chunk is 32 rows x 24 float4 of dY (3 pieces per thread) and XR rows x 24 of X.  No bounds arithmetic: a range is a
+  // whole number of chunks, so only the tensors' ends matter and the buffer descriptor returns zero past them - also for the rows
+  // BEFORE the tensor that the convolution form's first chunks ask for (their 32-bit offsets wrap far beyond the descriptor's size)
+  uint32_t y_off[3], lds_off[3], x_off[NXP], xlds_off[NXP];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int p = tid + 256 * i, row = p / 24, c4 = p - row * 24;
-    prow[i] = row;
     y_off[i] = (uint32_t)(((m_begin + row) * N + n0 + c4 * 4) * 4);
-    x_off[i] = (uint32_t)(((m_begin + row) * K + k0 + c4 * 4) * 4);
     lds_off[i] = (uint32_t)(row * RP + c4 * 8);
   }
-  // two register sets: chunks c + 1 AND c + 2 are in flight while chunk c is multiplied (a chunk's MFMAs are ~0.5 us, a load ~2)
-  u32x4 yA[3], xA[3], yB[3], xB[3];
-  auto request = [&](int c, u32x4 (&yreg)[3], u32x4 (&xreg)[3]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const bool ok = m_begin + (int64_t)c * MC + prow[i] < m_end;
-      yreg[i] = __builtin_amdgcn_raw_buffer_load_b128(Y_rs, ok ? y_off[i] + (uint32_t)c * (uint32_t)(MC * N * 4) : INV, 0, 0);
-      xreg[i] = __builtin_amdgcn_raw_buffer_load_b128(X_rs, ok ? x_off[i] + (uint32_t)c * (uint32_t)(MC * K * 4) : INV, 0, 0);
-    }
+  for (int i = 0; i < NXP; ++i) {
+    const int p = tid + 256 * i, row = p / 24, c4 = p - row * 24;
+    x_off[i] = (uint32_t)(((m_begin + row + xshift) * P.x_ld + cb * TK + c4 * 4) * 4);
+    xlds_off[i] = (uint32_t)(3 * PLANE + row * RP + c4 * 8);
+  }
+  const bool xlast = XR * 24 % 256 == 0 || tid + 256 * (NXP - 1) < XR * 24;   // the last X piece of this thread exists
+  const uint32_t ystep = (uint32_t)(MC * N * 4), xstep = (uint32_t)(MC * P.x_ld * 4);
+  u32x4 yA[3], xA[NXP], yB[3], xB[NXP];
+  auto request = [&](int c, u32x4 (&yreg)[3], u32x4 (&xreg)[NXP]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) yreg[i] = __builtin_amdgcn_raw_buffer_load_b128(Y_rs, y_off[i] + (uint32_t)c * ystep, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NXP; ++i)
+      xreg[i] = __builtin_amdgcn_raw_buffer_load_b128(X_rs, (i + 1 < NXP || xlast) ? x_off[i] + (uint32_t)c * xstep : INV, 0, 0);
   };
-  auto deposit = [&](uint8_t* buf, u32x4 (&yreg)[3], u32x4 (&xreg)[3]) __attribute__((always_inline)) {
+  auto deposit = [&](uint8_t* buf, u32x4 (&yreg)[3], u32x4 (&xreg)[NXP]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       uint2 hi, mid, lo;
@@ -125,8 +141,10 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(DwParams P) {
       *reinterpret_cast<uint2*>(buf + lds_off[i]) = hi;
       *reinterpret_cast<uint2*>(buf + PLANE + lds_off[i]) = mid;
       *reinterpret_cast<uint2*>(buf + 2 * PLANE + lds_off[i]) = lo;
-      *reinterpret_cast<uint2*>(buf + 3 * PLANE + lds_off[i]) = make_uint2(top2(xreg[i].x, xreg[i].y), top2(xreg[i].z, xreg[i].w));
     }
+#pragma unroll
+    for (int i = 0; i < NXP; ++i)
+      if (i + 1 < NXP || xlast) *reinterpret_cast<uint2*>(buf + xlds_off[i]) = make_uint2(top2(xreg[i].x, xreg[i].y), top2(xreg[i].z, xreg[i].w));
   };
 
   // transposed reads: lane (g, q, p) of a fragment supplies the address of row 4g + q, columns 4p .. 4p + 3 of the block
@@ -138,56 +156,82 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(DwParams P) {
   const uint32_t a_base = tr_lane + (uint32_t)(48 * wn * 2);           // dY columns n0 + 48 wn + ...
   const uint32_t b_base = 3 * PLANE + tr_lane + (uint32_t)(48 * wk * 2);
 
-  f32x4 acc[3][3];
+  f32x4 acc[TAPS][3][3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   auto multiply = [&](const uint8_t* cur) __attribute__((always_inline)) {
-    bf16x8 b[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) b[j] = tr_frag(cur + b_base + j * 32);
 #pragma unroll
     for (int pl = 2; pl >= 0; --pl) {                                   // small terms first
       bf16x8 a[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) a[i] = tr_frag(cur + pl * PLANE + a_base + i * 32);
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+      for (int t = 0; t < TAPS; ++t) {
+        bf16x8 b[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 3; ++j) b[j] = tr_frag(cur + b_base + t * RP + j * 32);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[t][i][j], 0, 0, 0);
+      }
     }
   };
-  // (requests past the range load nothing: every offset is INV)
-  request(0, yA, xA);
-  request(1, yB, xB);
-  deposit(smem, yA, xA);
-  __syncthreads();
+  // (requests past the range read the next range's rows, or zeros past the tensor: deposited, never multiplied)
+  if constexpr (TAPS == 1) {
+    // two register sets: chunks c + 1 AND c + 2 are in flight while chunk c is multiplied (a chunk's MFMAs are ~0.5 us, a load ~2)
+    request(0, yA, xA);
+    request(1, yB, xB);
+    deposit(smem, yA, xA);
+    __syncthreads();
 #pragma unroll 1
-  for (int c = 0; c < nchunk; c += 2) {
-    request(c + 2, yA, xA);
-    multiply(smem);
-    deposit(smem + BUF, yB, xB);                                        // chunk c + 1
-    __syncthreads();
-    if (c + 1 < nchunk) {
-      request(c + 3, yB, xB);
-      multiply(smem + BUF);
+    for (int c = 0; c < nchunk; c += 2) {
+      request(c + 2, yA, xA);
+      multiply(smem);
+      deposit(smem + BUF, yB, xB);                                      // chunk c + 1
+      __syncthreads();
+      if (c + 1 < nchunk) {
+        request(c + 3, yB, xB);
+        multiply(smem + BUF);
+      }
+      deposit(smem, yA, xA);                                            // chunk c + 2
+      __syncthreads();
     }
-    deposit(smem, yA, xA);                                              // chunk c + 2
+  } else {
+    // three taps: 81 MFMAs per chunk and 108 accumulator registers - one chunk in flight, the other workgroup of the compute unit
+    // covers the rest of the latency
+    request(0, yA, xA);
+    deposit(smem, yA, xA);
     __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+      request(c + 1, yA, xA);
+      multiply(smem + (c & 1) * BUF);
+      deposit(smem + ((c + 1) & 1) * BUF, yA, xA);
+      __syncthreads();
+    }
   }
 
-  // accumulator register r of block (i, j): dW[n0 + 48 wn + 16 i + 4 g + r][k0 + 48 wk + 16 j + li]
-  float* out = d.nsplit > 1 ? d.partial + (int64_t)split * N * K : d.dw;
+  // accumulator register r of block (t, i, j): dW[n0 + 48 wn + 16 i + 4 g + r][column of (tap, 96 cb + 48 wk + 16 j + li)]
+  const int ld = d.K;
+  float* out = d.nsplit > 1 ? d.partial + (int64_t)split * N * ld : d.dw;
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int t = 0; t < TAPS; ++t) {
+    const int k0 = TAPS == 3 ? (ky * 3 + t) * P.x_ld + cb * TK : cb * TK;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float* row = out + (int64_t)(n0 + 48 * wn + 16 * i + 4 * g + r) * K + k0 + 48 * wk + li;
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) row[16 * j] = acc[i][j][r];
-    }
+      for (int r = 0; r < 4; ++r) {
+        float* row = out + (int64_t)(n0 + 48 * wn + 16 * i + 4 * g + r) * ld + k0 + 48 * wk + li;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) row[16 * j] = acc[t][i][j][r];
+      }
+  }
 }
 
 // dw[i] = sum over the m ranges in a FIXED order: 16 lanes take the ranges s = l, l + 16, ... of a float4 column in turn and their
@@ -217,12 +261,34 @@ __global__ __launch_bounds__(256) void linear_dw_reduce_kernel(const float* __re
   if (sl == 0 && col < n4) reinterpret_cast<float4*>(dw)[col] = red[threadIdx.x];
 }
 
+// (imgs, C, H, W) fp32 -> zero-ringed channels-last pixel rows (imgs, H + 2, W + 2, C): what the convolution form reads.  One
+// workgroup moves 64 pixels of a padded row x 96 channels through LDS (global reads run along x, global writes along c).
+__global__ __launch_bounds__(256) void ringed_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W) {
+  __shared__ float tile[64 * 97];
+  const int Wp = W + 2, cblocks = C / 96;
+  const int img = blockIdx.z / cblocks, c0 = (blockIdx.z - img * cblocks) * 96;
+  const int yy = blockIdx.y, px0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, lx = tid & 63, cw = tid >> 6;
+  const int px = px0 + lx;
+  const bool inside = yy >= 1 && yy <= H && px >= 1 && px <= W;
+  const float* s = src + (((int64_t)img * C + c0) * H + (yy - 1)) * W + (px - 1);
+#pragma unroll 4
+  for (int c = cw; c < 96; c += 4) tile[lx * 97 + c] = inside ? s[(int64_t)c * H * W] : 0.f;
+  __syncthreads();
+  float* d = dst + (((int64_t)img * (H + 2) + yy) * Wp + px0) * C + c0;
+  const int npx = Wp - px0 < 64 ? Wp - px0 : 64;
+  for (int i = tid; i < npx * 96; i += 256) {
+    const int p = i / 96, c = i - p * 96;
+    d[(int64_t)p * C + c] = tile[p * 97 + c];
+  }
+}
+
 }  // namespace
 
 // the number of m ranges sdf_linear_dw_fwd wants for this shape (the caller provides `partial` of that many N x K fp32 tiles when > 1)
-extern "C" int sdf_linear_dw_splits(int64_t M, int N, int K) {
-  if (M <= 0 || N <= 0 || K <= 0 || N % TN || K % TK) return 0;
-  const int64_t tiles = (int64_t)(N / TN) * (K / TK);
+extern "C" int sdf_linear_dw_splits(int64_t M, int N, int K, int cv_C) {
+  if (M <= 0 || N <= 0 || K <= 0 || N % TN || K % TK || cv_C < 0 || (cv_C > 0 && (cv_C % TK || K != 9 * cv_C))) return 0;
+  const int64_t tiles = (int64_t)(N / TN) * (cv_C > 0 ? 3 * (cv_C / TK) : K / TK);
   int64_t want = (768 + tiles - 1) / tiles;                           // ~3 workgroups per compute unit in all
   const int64_t most = (M + 8 * MC - 1) / (8 * MC);                   // a range is at least 8 chunks long
   if (want > most) want = most;
@@ -233,25 +299,41 @@ extern "C" int sdf_linear_dw_splits(int64_t M, int N, int K) {
 extern "C" int sdf_linear_dw_fwd(const SdfLinearDwDesc* d, void* stream) {
   if (!d || !d->dy || !d->x || !d->dw) return SDF_E_NULL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->N % TN || d->K % TK || d->nsplit < 1) return SDF_E_SHAPE;
+  const bool conv = d->cv_C > 0;
+  if (d->cv_C < 0 || (conv && (d->cv_C % TK || d->K != 9 * d->cv_C || d->cv_Wp < 3))) return SDF_E_SHAPE;
   if (d->nsplit > 1 && !d->partial) return SDF_E_NULL;
   const int64_t lim = (int64_t)1 << 31;
-  if (d->M * d->N * 4 >= lim || d->M * d->K * 4 >= lim || (int64_t)d->N * d->K * 4 >= lim) return SDF_E_SHAPE;
+  const int x_ld = conv ? d->cv_C : d->K;
+  if (d->M * d->N * 4 >= lim || d->M * x_ld * 4 >= lim || (int64_t)d->N * d->K * 4 >= lim) return SDF_E_SHAPE;
   if (!sdf_aligned(d->dy, 16) || !sdf_aligned(d->x, 16) || !sdf_aligned(d->dw, 16) || (d->partial && !sdf_aligned(d->partial, 16))) return SDF_E_ALIGN;
   DwParams P;
   P.d = *d;
   P.tiles_n = d->N / TN;
-  P.tiles_k = d->K / TK;
+  P.x_ld = x_ld;
+  P.cblocks = conv ? d->cv_C / TK : 0;
+  P.Wp = d->cv_Wp;
+  P.tiles_k = conv ? 3 * P.cblocks : d->K / TK;
   const int64_t chunks = (d->M + MC - 1) / MC;
   P.rows_per_split = (int)((chunks + d->nsplit - 1) / d->nsplit) * MC;
   const int64_t wgs = (int64_t)d->nsplit * P.tiles_n * P.tiles_k;
   if (wgs >= lim) return SDF_E_SHAPE;
   hipStream_t s = sdf_stream(stream);
-  hipLaunchKernelGGL(linear_dw_kernel, dim3((unsigned)wgs), dim3(256), 0, s, P);
+  if (conv) hipLaunchKernelGGL(linear_dw_kernel<3>, dim3((unsigned)wgs), dim3(256), 0, s, P);
+  else hipLaunchKernelGGL(linear_dw_kernel<1>, dim3((unsigned)wgs), dim3(256), 0, s, P);
   SDF_LAUNCH_CHECK();
   if (d->nsplit > 1) {
     const int n4 = d->N * d->K / 4;
     hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, d->partial, d->dw, n4, d->nsplit);
     SDF_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+extern "C" int sdf_ringed_rows_fwd(const float* src, float* dst, int imgs, int C, int H, int W, void* stream) {
+  if (!src || !dst) return SDF_E_NULL;
+  if (imgs < 1 || C < 96 || C % 96 || H < 1 || W < 1 || H + 2 > 65535 || (int64_t)imgs * (C / 96) > 65535) return SDF_E_SHAPE;
+  const dim3 grid((unsigned)((W + 2 + 63) / 64), (unsigned)(H + 2), (unsigned)(imgs * (C / 96)));
+  hipLaunchKernelGGL(ringed_rows_kernel, grid, dim3(256), 0, sdf_stream(stream), src, dst, C, H, W);
+  SDF_LAUNCH_CHECK();
   return 0;
 }

@@ -28,7 +28,7 @@ EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_s
            "sdf_rows_gather_fwd", "sdf_rows_scatter_fwd",
            "sdf_split_weight_i8x3", "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd",
            "sdf_dense_conv3x3_fwd", "sdf_pack_planes", "sdf_unpack_planes", "sdf_pack_planes_up2", "sdf_dense_linear_fwd", "sdf_layer_norm_fwd",
-           "sdf_linear_dw_fwd", "sdf_linear_dw_splits")
+           "sdf_linear_dw_fwd", "sdf_linear_dw_splits", "sdf_ringed_rows_fwd")
 
 
 class SdfError(RuntimeError):
@@ -120,7 +120,7 @@ class DenseLinearDesc(C.Structure):
 
 class LinearDwDesc(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("partial", C.c_void_p),
-                ("M", C.c_int64), ("N", C.c_int32), ("K", C.c_int32), ("nsplit", C.c_int32)]
+                ("M", C.c_int64), ("N", C.c_int32), ("K", C.c_int32), ("nsplit", C.c_int32), ("cv_C", C.c_int32), ("cv_Wp", C.c_int32)]
 
 
 _lib = None
@@ -1186,15 +1186,16 @@ def linear_dw_applicable(M, N, K):
     return N % 96 == 0 and K % 96 == 0 and M * max(N, K) * 4 < 1 << 31
 
 
-def linear_dw(dy, x):
+def linear_dw(dy, x, conv_wp=0):
     """dW (N, K) = dy.T @ x for dy (M, N) fp32 and x (M, K) fp32 holding spikes (values exact in bf16) - the weight gradient of a
     spike-fed Linear layer (sdf_linear_dw_fwd): dy split into three bf16 planes in the kernel, fp32 accumulation, m ranges summed in a
-    fixed order."""
+    fixed order.  conv_wp > 0: the convolution form on zero-ringed channels-last pixel rows (see conv3x3_dw) -> (N, 9 C)."""
     M, N = dy.shape
-    K = x.shape[1]
+    Cx = x.shape[1]
+    K = 9 * Cx if conv_wp else Cx
     if x.shape[0] != M or not dy.is_contiguous() or not x.is_contiguous():
         raise SdfError("linear_dw needs contiguous (M, N) and (M, K) operands")
-    ns = lib().sdf_linear_dw_splits(C.c_int64(M), C.c_int(N), C.c_int(K))
+    ns = lib().sdf_linear_dw_splits(C.c_int64(M), C.c_int(N), C.c_int(K), C.c_int(Cx if conv_wp else 0))
     if ns < 1:
         raise SdfError(f"sdf_linear_dw_fwd: unsupported shape M={M} N={N} K={K} (N and K must be multiples of 96)")
     dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
@@ -1202,9 +1203,38 @@ def linear_dw(dy, x):
     d = LinearDwDesc()
     d.dy, d.x, d.dw, d.partial = _ptr(dy, torch.float32), _ptr(x, torch.float32), _ptr(dw, torch.float32), _ptr(part, torch.float32)
     d.M, d.N, d.K, d.nsplit = M, N, K, ns
-    _note(flop=2.0 * M * N * K, bytes=4.0 * M * (N + K), what=f"linear dW {M}x{N}x{K}")
+    d.cv_C, d.cv_Wp = (Cx, conv_wp) if conv_wp else (0, 0)
+    _note(flop=2.0 * M * N * K, bytes=4.0 * M * (N + Cx), what=f"linear dW {M}x{N}x{K}")
     _check(lib().sdf_linear_dw_fwd(C.byref(d), _stream()), "sdf_linear_dw_fwd")
     return dw
+
+
+def conv3x3_dw_applicable(imgs, Cin, Cout, H, W):
+    return Cin % 96 == 0 and Cout % 96 == 0 and imgs * (H + 2) * (W + 2) * max(Cin, Cout) * 4 < 1 << 31
+
+
+def _ringed_rows(t):
+    """(imgs, C, H, W) fp32 -> zero-ringed channels-last pixel rows (imgs * (H + 2) * (W + 2), C) (sdf_ringed_rows_fwd)."""
+    imgs, Cc, H, W = t.shape
+    if not t.is_contiguous():
+        raise SdfError("ringed rows need a contiguous (imgs, C, H, W) tensor")
+    out = torch.empty((imgs * (H + 2) * (W + 2), Cc), dtype=torch.float32, device=t.device)
+    _check(lib().sdf_ringed_rows_fwd(C.c_void_p(_ptr(t, torch.float32)), C.c_void_p(out.data_ptr()), C.c_int(imgs), C.c_int(Cc), C.c_int(H),
+                                     C.c_int(W), _stream()), "sdf_ringed_rows_fwd")
+    return out
+
+
+def conv3x3_dw(dy, x):
+    """Weight gradient (Cout, Cin, 3, 3) of a 3x3 / stride 1 / pad 1 convolution fed by spikes: dy (imgs, Cout, H, W), x (imgs, Cin,
+    H, W) fp32 NCHW as the training path holds them (sdf_linear_dw_fwd, convolution form).  Both go to zero-ringed channels-last
+    pixel rows first - on that grid a tap is a row offset, and the zero ring of dy removes what a row offset wraps around an image
+    edge."""
+    imgs, N, H, W = dy.shape
+    Cc = x.shape[1]
+    if tuple(x.shape) != (imgs, Cc, H, W):
+        raise SdfError("conv3x3_dw needs dy (imgs, Cout, H, W) and x (imgs, Cin, H, W)")
+    dw = linear_dw(_ringed_rows(dy), _ringed_rows(x.contiguous()), conv_wp=W + 2)
+    return dw.view(N, 3, 3, Cc).permute(0, 3, 1, 2).contiguous()
 
 
 def layer_norm(x, gamma, beta, eps):

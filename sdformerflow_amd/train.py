@@ -38,6 +38,8 @@ from . import hip
 SPIKE_LINEAR_PLANES = 0
 # Weight gradient of the Linear layers on csrc/linear_dw.hip (round 5; SDF_TRAIN_LINEAR_DW=0: the library product, for A/B runs)
 LINEAR_DW_HIP = os.environ.get("SDF_TRAIN_LINEAR_DW", "1") != "0"
+# ... and of the MS_ResBlock convolutions (3x3 / stride 1 / pad 1 on spikes; SDF_TRAIN_CONV_DW=0: MIOpen's)
+CONV_DW_HIP = os.environ.get("SDF_TRAIN_CONV_DW", "1") != "0"
 
 
 def _linear(x, lin):
@@ -77,11 +79,19 @@ def _bn_ch2(x, bn):
     return _bn(x.flatten(0, 1), bn).view(x.shape)
 
 
-def _conv_seq(x, conv, stride=None, padding=None):
-    """layer.Conv2d in multi-step mode: (T, B, C, H, W) through one conv2d call on the flattened batch."""
+def _conv_seq(x, conv, stride=None, padding=None, spikes=False):
+    """layer.Conv2d in multi-step mode: (T, B, C, H, W) through one conv2d call on the flattened batch.  spikes=True: x is a neuron's
+    output - a 3x3 / stride 1 / pad 1 convolution with 96-multiples of channels then takes its WEIGHT gradient on csrc/linear_dw.hip
+    (convolution form); forward and dX stay library convolutions."""
     T, B = x.shape[:2]
-    y = F.conv2d(x.flatten(0, 1), conv.weight, conv.bias, conv.stride if stride is None else stride,
-                 conv.padding if padding is None else padding)
+    x2 = x.flatten(0, 1)
+    if (spikes and CONV_DW_HIP and stride is None and padding is None and x2.is_cuda and tuple(conv.kernel_size) == (3, 3)
+            and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
+            and hip.conv3x3_dw_applicable(x2.shape[0], conv.in_channels, conv.out_channels, x2.shape[2], x2.shape[3])):
+        from .autograd import Conv3x3DwFunction
+        y = Conv3x3DwFunction.apply(x2, conv.weight, conv.bias)
+    else:
+        y = F.conv2d(x2, conv.weight, conv.bias, conv.stride if stride is None else stride, conv.padding if padding is None else padding)
     return y.view(T, B, *y.shape[1:])
 
 
@@ -105,9 +115,9 @@ def rebin_events(x, num_bins, num_steps):
 
 def ms_resblock(x, rb):
     y = rb.sn1(x)
-    y = _bn_ch2(_conv_seq(y, rb.conv1[0]), rb.norm1.norm_layer)
+    y = _bn_ch2(_conv_seq(y, rb.conv1[0], spikes=True), rb.norm1.norm_layer)
     y = rb.sn2(y)
-    y = _bn_ch2(_conv_seq(y, rb.conv2[0]), rb.norm2.norm_layer)
+    y = _bn_ch2(_conv_seq(y, rb.conv2[0], spikes=True), rb.norm2.norm_layer)
     return y + x
 
 

@@ -2,6 +2,8 @@
 nn.Linear in the reference's training step (train_flow_parallel_supervised_SNN.py:233-336).  Checked against the same product in
 fp64 on the SAME inputs: the kernel's three-plane bf16 split of dY is exact, so what remains is fp32 accumulation - the bound is
 stated against sum_m |dY| |X| per element, and gradient-like inputs span twelve decades."""
+import ctypes
+
 import pytest
 import torch
 
@@ -44,7 +46,7 @@ def test_the_split_of_dy_is_exact():
 
 def test_m_ranges_are_summed_in_a_fixed_order():
     dy, x = _inputs(50000, 96, 96, 77)
-    assert hip.lib().sdf_linear_dw_splits(50000, 96, 96) > 1
+    assert hip.lib().sdf_linear_dw_splits(ctypes.c_int64(50000), 96, 96, 0) > 1
     a, b = hip.linear_dw(dy, x), hip.linear_dw(dy, x)
     assert torch.equal(a, b)
 
@@ -79,3 +81,43 @@ def test_linear_function_gradients_equal_autograd_of_f_linear():
     assert float((gw1.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
     assert float((gw0.double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())      # (the library's own distance, for scale)
     assert torch.allclose(gb0, gb1, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("imgs,Cin,Cout,H,W", [(3, 96, 96, 20, 37), (2, 192, 96, 9, 12), (1, 96, 192, 33, 5), (5, 96, 96, 64, 48)])
+def test_conv_weight_gradient_equals_autograd_in_fp64(imgs, Cin, Cout, H, W):
+    """The convolution form (zero-ringed channels-last rows, taps as row offsets) against torch.autograd's conv2d weight gradient
+    in fp64 on the CPU - every tap, the image edges, and the wrap of a row offset from one image into the next."""
+    import torch.nn.functional as F
+    g = torch.Generator(device="cpu").manual_seed(imgs * 100 + H)
+    x = (torch.rand((imgs, Cin, H, W), generator=g) < 0.3).float()
+    dy = torch.randn((imgs, Cout, H, W), generator=g) * torch.pow(10.0, -8 * torch.rand((imgs, Cout, H, W), generator=g))
+    w = torch.zeros((Cout, Cin, 3, 3), dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, None, 1, 1).backward(dy.double())
+    ref = w.grad
+    dw = hip.conv3x3_dw(dy.to(DEV), x.to(DEV)).cpu().double()
+    assert dw.shape == ref.shape
+    bound = torch.zeros_like(ref)
+    wb = torch.zeros((Cout, Cin, 3, 3), dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wb, None, 1, 1).backward(dy.double().abs())
+    err = (dw - ref).abs()
+    assert bool((err <= 2e-6 * wb.grad + 1e-37).all()), float((err / (wb.grad + 1e-37)).max())
+    assert float(ref.abs().max()) > 0
+
+
+def test_conv_function_gradients_equal_autograd_of_conv2d():
+    import torch.nn.functional as F
+    from sdformerflow_amd.autograd import Conv3x3DwFunction
+    g = torch.Generator(device="cpu").manual_seed(21)
+    x = (torch.rand((4, 96, 24, 32), generator=g) < 0.2).float().to(DEV)
+    w = (torch.randn((96, 96, 3, 3), generator=g) * 0.03).to(DEV)
+    go = (torch.randn((4, 96, 24, 32), generator=g) * 1e-3).to(DEV)
+    res = []
+    for fn in (lambda x_, w_: F.conv2d(x_, w_, None, 1, 1), lambda x_, w_: Conv3x3DwFunction.apply(x_, w_, None)):
+        x_, w_ = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y = fn(x_, w_)
+        y.backward(go)
+        res.append((y.detach(), x_.grad, w_.grad))
+    (y0, gx0, gw0), (y1, gx1, gw1) = res
+    assert torch.equal(y0, y1)
+    assert torch.allclose(gx0, gx1, rtol=1e-4, atol=1e-7)              # (two library calls; the algorithm may differ between them)
+    assert float((gw0 - gw1).abs().max()) <= 1e-4 * float(gw0.abs().max())

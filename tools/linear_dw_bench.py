@@ -25,3 +25,15 @@ for stage, (M, C, blocks) in enumerate([(276480, 96, 2), (69120, 192, 2), (17280
               f"{2.0 * M * N * K / ours / 1e6:6.1f} TF)  max diff / max {err:.1e}")
         del dy, x
 print(f"all dW of a step's swin blocks: ours {tot_a / 1e3:.2f} ms, library {tot_b / 1e3:.2f} ms")
+# the convolution form: MS_ResBlock convolutions of the patch embedding (local batch 4 x 10 steps = 40 images of 144 x 192) and of the bottleneck
+for imgs, Cc, H, W in ((40, 96, 144, 192), (40, 768, 9, 12)):
+    x = (torch.rand((imgs, Cc, H, W), device=dev) < 0.2).float()
+    dy = torch.randn((imgs, Cc, H, W), device=dev) * 1e-3
+    w = torch.randn((Cc, Cc, 3, 3), device=dev)
+    ours = t(lambda: hip.conv3x3_dw(dy, x), 5)
+    rows = t(lambda: (hip._ringed_rows(dy), hip._ringed_rows(x)), 5)
+    libt = t(lambda: torch.nn.grad.conv2d_weight(x, w.shape, dy, stride=1, padding=1), 5)
+    a, b = hip.conv3x3_dw(dy, x), torch.nn.grad.conv2d_weight(x, w.shape, dy, stride=1, padding=1)
+    print(f"conv dW imgs={imgs} C={Cc} {H}x{W}: ours {ours:7.1f} us (of which the two ringed channels-last copies {rows:7.1f})  library {libt:7.1f} us  "
+          f"max diff / max {float((a - b).abs().max() / b.abs().max()):.1e}")
+    del x, dy
