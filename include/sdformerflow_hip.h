@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SDF_VERSION 105   /* round 5: + sdf_ann_attn_block_fwd, sdf_ann_mlp_block_fwd, sdf_spike_deconv3x3s2_fwd, row-major digit planes in sdf_spike_gemm_fwd */
+#define SDF_VERSION 106   /* round 5: + sdf_ann_attn_block_fwd, sdf_ann_mlp_block_fwd, sdf_spike_deconv3x3s2_fwd, row-major digit planes in sdf_spike_gemm_fwd; 106: + sdf_linear_dw_fwd, sdf_ringed_rows_fwd */
 
 enum { SDF_F32 = 0, SDF_U8 = 1 };
 enum { SDF_LIF = 0, SDF_PSN = 1, SDF_IF = 2 };

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), name
     lib.sdf_version.restype = ctypes.c_int
-    assert lib.sdf_version() == 105            # host-only call, no GPU needed
+    assert lib.sdf_version() == 106            # host-only call, no GPU needed
 
 
 def test_product_refuses_cpu_tensors():
@@ -199,6 +199,24 @@ def test_argument_errors_are_reported_before_any_launch():
     assert lib.sdf_pack_planes_up2(p, p, 1, 16, 4, 4, C.c_int64(256), C.c_int64(16), C.c_int64(4), C.c_int64(1), 1, 1, None) == E_SHAPE   # records past the tensor
     assert lib.sdf_layer_norm_fwd(p, p, p, p, C.c_int64(8), 98, C.c_float(1e-5), None) == E_SHAPE      # C % 4
     assert lib.sdf_layer_norm_fwd(p, p, p, odd, C.c_int64(8), 96, C.c_float(1e-5), None) == E_ALIGN
+
+    # training path: weight gradients (round 5)
+    assert lib.sdf_linear_dw_fwd(None, None) == E_NULL
+    assert lib.sdf_linear_dw_splits(C.c_int64(276480), 96, 96, 0) == 768 and lib.sdf_linear_dw_splits(C.c_int64(4320), 768, 3072, 0) == 3
+    assert lib.sdf_linear_dw_splits(C.c_int64(100), 96, 80, 0) == 0 and lib.sdf_linear_dw_splits(C.c_int64(100), 96, 864, 48) == 0
+    assert lib.sdf_linear_dw_splits(C.c_int64(1132960), 96, 864, 96) == 256       # convolution form: three taps per column tile
+    dwd = hip.LinearDwDesc()
+    dwd.dy, dwd.x, dwd.dw, dwd.M, dwd.N, dwd.K, dwd.nsplit = 0x10000, 0x10000, 0x10000, 100, 96, 80, 1
+    assert lib.sdf_linear_dw_fwd(C.byref(dwd), None) == E_SHAPE           # K % 96
+    dwd.K, dwd.nsplit = 96, 2
+    assert lib.sdf_linear_dw_fwd(C.byref(dwd), None) == E_NULL            # several ranges need the partial buffer
+    dwd.nsplit, dwd.cv_C, dwd.cv_Wp = 1, 96, 10
+    assert lib.sdf_linear_dw_fwd(C.byref(dwd), None) == E_SHAPE           # convolution form: K = 9 C
+    dwd.cv_C, dwd.cv_Wp, dwd.M = 0, 0, 1 << 23
+    assert lib.sdf_linear_dw_fwd(C.byref(dwd), None) == E_SHAPE           # 31-bit offsets
+    dwd.M, dwd.dy = 100, 0x10004
+    assert lib.sdf_linear_dw_fwd(C.byref(dwd), None) == E_ALIGN
+    assert lib.sdf_ringed_rows_fwd(None, p, 1, 96, 4, 4, None) == E_NULL and lib.sdf_ringed_rows_fwd(p, p, 1, 48, 4, 4, None) == E_SHAPE
 
 
 def test_product_never_imports_the_oracle():

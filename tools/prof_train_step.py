@@ -7,7 +7,8 @@ win = float(sys.argv[2]) * 1e6
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 end = int(rows[-1]["End_Timestamp"])
 sel = [r for r in rows if int(r["Start_Timestamp"]) > end - win]
-groups = (("lif_bwd_kernel", "ours: LIF backward"), ("neuron_kernel", "ours: neuron forward"), ("psn_bwd", "ours: PSN backward"),
+groups = (("linear_dw_kernel", "ours: Linear / conv weight gradient"), ("linear_dw_reduce", "ours: weight-gradient range sums"), ("ringed_rows", "ours: ringed channels-last rows"),
+          ("lif_bwd_kernel", "ours: LIF backward"), ("neuron_kernel", "ours: neuron forward"), ("psn_bwd", "ours: PSN backward"),
           ("bn_reduce", "ours: batch-norm reductions"), ("bn_apply", "ours: batch-norm apply"), ("bn_finish", "ours: batch-norm finish"),
           ("qk_gate_train", "ours: token gate fwd / bwd"), ("Cijk", "rocBLAS GEMM"), ("miopenSp3AsmConv", "MIOpen Winograd conv"),
           ("igemm", "MIOpen implicit-GEMM conv"), ("BatchNorm", "MIOpen batch-norm (NCHW conv outputs)"),
@@ -21,5 +22,5 @@ for r in sel:
     acc[label][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 tot = sum(v[1] for v in acc.values())
 print(f"last {win/1e6:.0f} ms of the trace: {len(sel)} launches, kernel time {tot:.1f} ms")
-for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1])[:20]:
+for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1])[:26]:
     print(f"{v[1]:8.2f} ms  x{v[0]:<5d} {k}")
