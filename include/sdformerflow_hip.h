@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SDF_VERSION 106   /* round 5: + sdf_ann_attn_block_fwd, sdf_ann_mlp_block_fwd, sdf_spike_deconv3x3s2_fwd, row-major digit planes in sdf_spike_gemm_fwd; 106: + sdf_linear_dw_fwd, sdf_ringed_rows_fwd */
+#define SDF_VERSION 106   /* round 5: + sdf_ann_attn_block_fwd, sdf_ann_mlp_block_fwd, sdf_spike_deconv3x3s2_fwd, row-major digit planes in sdf_spike_gemm_fwd; 106: + sdf_linear_dw_fwd, sdf_ringed_rows_fwd, sdf_linear_train_fwd */
 
 enum { SDF_F32 = 0, SDF_U8 = 1 };
 enum { SDF_LIF = 0, SDF_PSN = 1, SDF_IF = 2 };
@@ -799,6 +799,23 @@ int sdf_linear_dw_splits(int64_t M, int N, int K, int cv_C);
 int sdf_linear_dw_fwd(const SdfLinearDwDesc* d, void* stream);
 /* src (imgs, C, H, W) fp32 -> dst (imgs, H + 2, W + 2, C) fp32, the ring zero: the layout of the convolution form above.  C % 96 == 0. */
 int sdf_ringed_rows_fwd(const float* src, float* dst, int imgs, int C, int H, int W, void* stream);
+
+/* The two activation-side products of a Linear layer in the training path, from the fp32 tensors autograd holds (reference: nn.Linear
+ * forward / autograd in train_flow_parallel_supervised_SNN.py:233-336; layers Spiking_swin_transformer3D.py:661-717, :164-181, :952-974):
+ *   mode 0  out (M, N) = a (M, K) * w^T + bias     a holds spikes (values exact in bf16), w (N, K) fp32;   K % 32 == 0, N % 96 == 0
+ *   mode 1  out (M, K) = a (M, N) * w              a = dY fp32 (any range), w (N, K) fp32;                 N % 32 == 0, K % 96 == 0
+ * Real operands are split into three bf16 planes inside the kernel (exact; fp32 exponent range), fp32 accumulation.  bias: mode 0 only,
+ * may be NULL. */
+typedef struct SdfLinearTrainDesc {
+  const float* a;
+  const float* w;
+  const float* bias;
+  float* out;
+  int32_t M, N, K;
+  int32_t mode;
+} SdfLinearTrainDesc;
+
+int sdf_linear_train_fwd(const SdfLinearTrainDesc* d, void* stream);
 
 /* nn.LayerNorm over the last dim of x (rows, C) fp32, elementwise affine (reference models/STSwinNet/swin_transformer3D_v2.py:
  * `norm1` / `norm2` of the blocks :231-233, `PatchMerging.norm` :356, the per-stage output norms :622-624).  C % 4 == 0, C <= 2048. */

@@ -1,9 +1,13 @@
 """torch.autograd bridges for the training path: forward and backward are both HIP kernels
 (csrc/neuron.hip, csrc/neuron_bwd.hip); nothing is saved between them except the input itself - the backward
 recomputes the membrane trajectory.  No CPU fallback: CPU tensors raise `SdfError` inside `hip`."""
+import os
+
 import torch
 
 from . import hip
+
+_LIBRARY_DX = os.environ.get("SDF_TRAIN_LINEAR_DX", "1") == "0"
 
 
 class LIFFunction(torch.autograd.Function):
@@ -174,6 +178,39 @@ class LinearDwFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = hip.linear_dw(g2.float().contiguous(), x.reshape(-1, K).float().contiguous()).to(weight.dtype)
         gb = g2.sum(0).to(weight.dtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+class LinearHipFunction(torch.autograd.Function):
+    """nn.Linear on a SPIKE tensor with all three of its products on hand-written kernels: forward and dX = dY W on
+    csrc/linear_train.hip (operands split into exact bf16 planes inside the kernel, straight from the fp32 weight - nothing to pack,
+    nothing to keep in step with the optimiser), dW = dY^T X on csrc/linear_dw.hip.  fp32 in, fp32 out.
+    Reference: nn.Linear forward / autograd in train_flow_parallel_supervised_SNN.py:233-336."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        K = weight.shape[1]
+        x2 = x.reshape(-1, K).float().contiguous()
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias, ctx.xshape, ctx.in_dtype = bias is not None, x.shape, x.dtype
+        w = weight.detach().float().contiguous()
+        out = hip.linear_train(x2, w, None if bias is None else bias.detach().float().contiguous(), mode=0)
+        return out.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, weight = ctx.saved_tensors
+        g2 = g.reshape(-1, weight.shape[0]).float().contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            if _LIBRARY_DX:                                                  # diagnostic (SDF_TRAIN_LINEAR_DX=0): the library's dX behind the HIP forward
+                gx = (g2 @ weight.detach().float()).view(ctx.xshape).to(ctx.in_dtype)
+            else:
+                gx = hip.linear_train(g2, weight.detach().float().contiguous(), mode=1).view(ctx.xshape).to(ctx.in_dtype)
+        if ctx.needs_input_grad[1]:
+            gw = hip.linear_dw(g2, x2).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0).to(weight.dtype)
         return gx, gw, gb
 
 

@@ -28,7 +28,7 @@ EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_s
            "sdf_rows_gather_fwd", "sdf_rows_scatter_fwd",
            "sdf_split_weight_i8x3", "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd",
            "sdf_dense_conv3x3_fwd", "sdf_pack_planes", "sdf_unpack_planes", "sdf_pack_planes_up2", "sdf_dense_linear_fwd", "sdf_layer_norm_fwd",
-           "sdf_linear_dw_fwd", "sdf_linear_dw_splits", "sdf_ringed_rows_fwd")
+           "sdf_linear_dw_fwd", "sdf_linear_dw_splits", "sdf_ringed_rows_fwd", "sdf_linear_train_fwd")
 
 
 class SdfError(RuntimeError):
@@ -121,6 +121,11 @@ class DenseLinearDesc(C.Structure):
 class LinearDwDesc(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("partial", C.c_void_p),
                 ("M", C.c_int64), ("N", C.c_int32), ("K", C.c_int32), ("nsplit", C.c_int32), ("cv_C", C.c_int32), ("cv_Wp", C.c_int32)]
+
+
+class LinearTrainDesc(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("mode", C.c_int32)]
 
 
 _lib = None
@@ -1179,6 +1184,26 @@ def dense_linear(a, wplanes, bias=None, gelu=False, resid=None, out=None):
     d.M, d.N, d.K, d.gelu = M, N, K, int(gelu)
     d.acc_scale = _dense_scale(wplanes)
     _check(lib().sdf_dense_linear_fwd(C.byref(d), _stream()), "sdf_dense_linear_fwd")
+    return out
+
+
+def linear_train_applicable(M, N, K):
+    return N % 96 == 0 and K % 96 == 0 and M * max(N, K) * 4 < 1 << 31
+
+
+def linear_train(a, w, bias=None, mode=0):
+    """Training-path Linear products from fp32 tensors (sdf_linear_train_fwd).  mode 0: a (M, K) spikes @ w.T + bias -> (M, N);
+    mode 1: a = dY (M, N) @ w -> (M, K).  w is the layer's (N, K) fp32 weight as it is."""
+    N, K = w.shape
+    M = a.shape[0]
+    if a.shape[1] != (K if mode == 0 else N) or not a.is_contiguous() or not w.is_contiguous():
+        raise SdfError("linear_train needs contiguous a (M, K | N) and w (N, K)")
+    out = torch.empty((M, N if mode == 0 else K), dtype=torch.float32, device=a.device)
+    d = LinearTrainDesc()
+    d.a, d.w, d.bias, d.out = _ptr(a, torch.float32), _ptr(w, torch.float32), _ptr(bias if mode == 0 else None, torch.float32), _ptr(out, torch.float32)
+    d.M, d.N, d.K, d.mode = M, N, K, mode
+    _note(flop=2.0 * M * N * K, bytes=4.0 * M * (N + K), what=f"linear {'fwd' if mode == 0 else 'dX'} {M}x{N}x{K}")
+    _check(lib().sdf_linear_train_fwd(C.byref(d), _stream()), "sdf_linear_train_fwd")
     return out
 
 

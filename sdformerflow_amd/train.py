@@ -3,9 +3,10 @@ autograd, the supervised loss, one optimiser step, and the data-parallel gradien
 
 What is hand-written HIP here: every spiking neuron, forward AND backward (`autograd.LIFFunction` / `PSNFunction` ->
 csrc/neuron.hip, csrc/neuron_bwd.hip; 105 neuron calls per forward), the batch-statistics BatchNorm, the token gate, and -
-since round 5 - the WEIGHT GRADIENT of every Linear layer (`autograd.LinearDwFunction` -> csrc/linear_dw.hip: 20 ms of library
-product -> 4 ms).  The other dense products - Linear forward / dX, Conv2d / ConvTranspose2d and their gradients - are library work
-through torch on the same stream (rocBLAS / MIOpen); their replacements are the next row.  Nothing here touches `oracle/`, and CPU
+since round 5 - ALL THREE products of every Linear layer (`autograd.LinearHipFunction`: forward and dX on csrc/linear_train.hip,
+dW on csrc/linear_dw.hip: 35 ms of library fp32 GEMM -> 13 ms; no rocBLAS kernel is left in a step) and the weight gradient of the
+MS_ResBlock convolutions (`autograd.Conv3x3DwFunction`).  The other dense products - Conv2d / ConvTranspose2d forward and dX, the
+remaining convolutions' dW - are library work through torch on the same stream (MIOpen); their replacements are the next row.  Nothing here touches `oracle/`, and CPU
 tensors are refused by the neuron kernels (`SdfError`).
 
 Reference semantics mirrored (file:line under /root/reference):
@@ -38,6 +39,8 @@ from . import hip
 SPIKE_LINEAR_PLANES = 0
 # Weight gradient of the Linear layers on csrc/linear_dw.hip (round 5; SDF_TRAIN_LINEAR_DW=0: the library product, for A/B runs)
 LINEAR_DW_HIP = os.environ.get("SDF_TRAIN_LINEAR_DW", "1") != "0"
+# Forward and dX of the Linear layers on csrc/linear_train.hip (fp32 path; SDF_TRAIN_LINEAR=0: the library products)
+LINEAR_HIP = os.environ.get("SDF_TRAIN_LINEAR", "1") != "0"
 # ... and of the MS_ResBlock convolutions (3x3 / stride 1 / pad 1 on spikes; SDF_TRAIN_CONV_DW=0: MIOpen's)
 CONV_DW_HIP = os.environ.get("SDF_TRAIN_CONV_DW", "1") != "0"
 
@@ -50,7 +53,9 @@ def _linear(x, lin):
         from .autograd import SpikeLinearFunction
         return SpikeLinearFunction.apply(x, lin.weight, lin.bias, SPIKE_LINEAR_PLANES)
     if LINEAR_DW_HIP and x.is_cuda and hip.linear_dw_applicable(x.numel() // K, N, K):
-        from .autograd import LinearDwFunction
+        from .autograd import LinearDwFunction, LinearHipFunction
+        if LINEAR_HIP and not torch.is_autocast_enabled():               # (bf16 autocast keeps the library's bf16 forward / dX)
+            return LinearHipFunction.apply(x, lin.weight, lin.bias)
         return LinearDwFunction.apply(x, lin.weight, lin.bias)
     return F.linear(x, lin.weight, lin.bias)
 
