@@ -216,6 +216,16 @@ def test_argument_errors_are_reported_before_any_launch():
     assert lib.sdf_linear_dw_fwd(C.byref(dwd), None) == E_SHAPE           # 31-bit offsets
     dwd.M, dwd.dy = 100, 0x10004
     assert lib.sdf_linear_dw_fwd(C.byref(dwd), None) == E_ALIGN
+    assert lib.sdf_linear_train_fwd(None, None) == E_NULL
+    lt = hip.LinearTrainDesc()
+    lt.a, lt.w, lt.out, lt.M, lt.N, lt.K, lt.mode = 0x10000, 0x10000, 0x10000, 100, 96, 80, 0
+    assert lib.sdf_linear_train_fwd(C.byref(lt), None) == E_SHAPE          # forward: K % 32
+    lt.K, lt.mode = 96, 2
+    assert lib.sdf_linear_train_fwd(C.byref(lt), None) == E_SHAPE          # mode 0 | 1
+    lt.mode, lt.N, lt.K = 1, 96, 64
+    assert lib.sdf_linear_train_fwd(C.byref(lt), None) == E_SHAPE          # dX: K % 96 (its output columns)
+    lt.K, lt.w = 96, 0x10008
+    assert lib.sdf_linear_train_fwd(C.byref(lt), None) == E_ALIGN
     assert lib.sdf_ringed_rows_fwd(None, p, 1, 96, 4, 4, None) == E_NULL and lib.sdf_ringed_rows_fwd(p, p, 1, 48, 4, 4, None) == E_SHAPE
 
 
