@@ -17,6 +17,7 @@
 // apart: conflict-free ds_read_b128 over 16 consecutive rows).
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -35,6 +36,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 struct LinearParams {
   SdfDenseLinearDesc d;
   int tiles_n;
+  int xcd;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, uint32_t bytes) {
@@ -64,7 +66,11 @@ __global__ __launch_bounds__(256) void dense_linear_kernel(LinearParams P) {
   const int M = d.M, N = d.N, K = d.K;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int tn = blockIdx.x % P.tiles_n, tm = blockIdx.x / P.tiles_n;   // column tiles fastest: the A tile is shared through L2
+  // column tiles fastest: the A tile is shared through L2 - which is per XCD, and consecutive workgroup ids go round the 8 XCDs: ids are
+  // re-dealt so that consecutive LOGICAL ids are neighbours on one XCD (round 5; SDF_DENSE_LINEAR_XCD=0 in the launcher: the old order)
+  const int G = gridDim.x;
+  const int wg = (P.xcd && (G & 7) == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int tn = wg % P.tiles_n, tm = wg / P.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
   // convolution form: row m = (img, oy, ox) of a 3x3 / pad 1 / stride cv_stride convolution over a channels-last fp32 image,
@@ -229,6 +235,8 @@ extern "C" int sdf_dense_linear_fwd(const SdfDenseLinearDesc* d, void* stream) {
   LinearParams P;
   P.d = *d;
   P.tiles_n = d->N / BN;
+  static const bool xcd = [] { const char* e = getenv("SDF_DENSE_LINEAR_XCD"); return !e || e[0] != '0'; }();
+  P.xcd = xcd ? 1 : 0;
   const int64_t tiles = (int64_t)((d->M + BM - 1) / BM) * P.tiles_n;
   hipLaunchKernelGGL(dense_linear_kernel, dim3((unsigned)tiles), dim3(256), 0, sdf_stream(stream), P);
   SDF_LAUNCH_CHECK();

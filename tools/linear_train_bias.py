@@ -16,3 +16,12 @@ for M, N, K in ((200000, 96, 96), (50000, 384, 96), (50000, 96, 384)):
         up = float(e.mean() / ref.abs().mean())                                   # signed: toward +inf / -inf
         rms = float(e.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
         print(f"dX {M}x{N}x{K} {name:8s}: rms error {rms:.2e} of rms; mean signed error {up:+.2e} of mean |dx|; mean error along sign(dx) {toward0:+.2e}")
+# the same statistics for dW = dY^T X (sdf_linear_dw_fwd): every element is a 276 480-long sum
+for M, N, K in ((276480, 96, 96), (276480, 96, 384)):
+    dy = torch.randn((M, N), device=dev) * 1e-3
+    x = (torch.rand((M, K), device=dev) < 0.2).float()
+    ref = dy.double().t() @ x.double()
+    for name, got in (("ours", hip.linear_dw(dy, x)), ("library", dy.t() @ x)):
+        e = got.double() - ref
+        print(f"dW {M}x{N}x{K} {name:8s}: rms error {float(e.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()):.2e} of rms; mean signed error "
+              f"{float(e.mean() / ref.abs().mean()):+.2e} of mean |dw|; mean error along sign(dw) {float((e * torch.sign(ref)).mean() / ref.abs().mean()):+.2e}")
