@@ -799,13 +799,19 @@ int sdf_linear_dw_splits(int64_t M, int N, int K, int cv_C);
 int sdf_linear_dw_fwd(const SdfLinearDwDesc* d, void* stream);
 /* src (imgs, C, H, W) fp32 -> dst (imgs, H + 2, W + 2, C) fp32, the ring zero: the layout of the convolution form above.  C % 96 == 0. */
 int sdf_ringed_rows_fwd(const float* src, float* dst, int imgs, int C, int H, int W, void* stream);
+/* the way back: src (imgs, H + 2, W + 2, C) ringed channels-last rows -> dst (imgs, C, H, W), + bias[c] when bias != NULL.  C % 96 == 0. */
+int sdf_unring_rows_fwd(const float* src, const float* bias, float* dst, int imgs, int C, int H, int W, void* stream);
 
 /* The two activation-side products of a Linear layer in the training path, from the fp32 tensors autograd holds (reference: nn.Linear
  * forward / autograd in train_flow_parallel_supervised_SNN.py:233-336; layers Spiking_swin_transformer3D.py:661-717, :164-181, :952-974):
  *   mode 0  out (M, N) = a (M, K) * w^T + bias     a holds spikes (values exact in bf16), w (N, K) fp32;   K % 32 == 0, N % 96 == 0
  *   mode 1  out (M, K) = a (M, N) * w              a = dY fp32 (any range), w (N, K) fp32;                 N % 32 == 0, K % 96 == 0
  * Real operands are split into three bf16 planes inside the kernel (exact; fp32 exponent range), fp32 accumulation.  bias: mode 0 only,
- * may be NULL. */
+ * may be NULL.
+ * Convolution form of mode 0 (cv_C > 0): the FORWARD of a 3x3 / stride 1 / pad 1 convolution fed by spikes (MS_ResBlock, reference
+ * Spiking_modules.py:291-347) on the zero-ringed channels-last pixel rows of sdf_ringed_rows_fwd: a is (M, cv_C), w is (N, 9 cv_C) ordered
+ * (ky, kx, c) [= weight.permute(0, 2, 3, 1)], K = 9 cv_C, out (M, N) on the same ringed grid (ring rows hold no result: sdf_unring_rows_fwd
+ * drops them on the way back to NCHW). */
 typedef struct SdfLinearTrainDesc {
   const float* a;
   const float* w;
@@ -813,6 +819,7 @@ typedef struct SdfLinearTrainDesc {
   float* out;
   int32_t M, N, K;
   int32_t mode;
+  int32_t cv_C, cv_Wp;
 } SdfLinearTrainDesc;
 
 int sdf_linear_train_fwd(const SdfLinearTrainDesc* d, void* stream);

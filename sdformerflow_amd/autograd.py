@@ -238,6 +238,35 @@ class Conv3x3DwFunction(torch.autograd.Function):
         return gx, gw, gb
 
 
+class Conv3x3HipFunction(torch.autograd.Function):
+    """3x3 / stride 1 / pad 1 Conv2d on a SPIKE image with its FORWARD and its weight gradient on hand-written kernels: the image goes
+    to zero-ringed channels-last pixel rows once (csrc/linear_dw.hip `ringed_rows_kernel`), the forward is a product over those rows
+    with the tap as a row offset of the loader (csrc/linear_train.hip, convolution form; spike plane x three exact bf16 weight
+    planes), and the rows are what the backward's dW product needs - they are saved instead of the image.  dX stays MIOpen's
+    (a product of real-valued dY with eight plane pairs would not beat its Winograd kernel).
+    Reference: MS_ResBlock's convolutions, Spiking_modules.py:291-347."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        imgs, Cc, H, W = x.shape
+        xr = hip._ringed_rows(x.float().contiguous())
+        ctx.save_for_backward(xr, weight)
+        ctx.has_bias, ctx.xshape, ctx.in_dtype = bias is not None, tuple(x.shape), x.dtype
+        return hip.conv3x3_fwd_ringed(xr, weight, None if bias is None else bias.detach().float().contiguous(), imgs, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        xr, weight = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.nn.grad.conv2d_input(ctx.xshape, weight.to(g.dtype), g, stride=1, padding=1).to(ctx.in_dtype)
+        if ctx.needs_input_grad[1]:
+            gw = hip.conv3x3_dw(g.float().contiguous(), xr).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum((0, 2, 3)).to(weight.dtype)
+        return gx, gw, gb
+
+
 class SpikeLinearFunction(torch.autograd.Function):
     """Linear layer on a spike tensor in the training path: the FORWARD is the inference path's spike GEMM (binary activations
     exact in 16 bits, fp32-grade weight planes re-split from the current weights, fp32 accumulate) and the activation is kept

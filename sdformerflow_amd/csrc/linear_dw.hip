@@ -288,6 +288,29 @@ __global__ __launch_bounds__(256) void ringed_rows_kernel(const float* __restric
   }
 }
 
+// the way back: ringed channels-last rows (imgs, H + 2, W + 2, C) -> (imgs, C, H, W) (+ bias): reads run along c, writes along x
+__global__ __launch_bounds__(256) void unring_rows_kernel(const float* __restrict__ src, const float* __restrict__ bias, float* __restrict__ dst,
+                                                          int C, int H, int W) {
+  __shared__ float tile[64 * 97];
+  const int Wp = W + 2, cblocks = C / 96;
+  const int img = blockIdx.z / cblocks, c0 = (blockIdx.z - img * cblocks) * 96;
+  const int y = blockIdx.y, x0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  const int npx = W - x0 < 64 ? W - x0 : 64;
+  const float* s = src + (((int64_t)img * (H + 2) + y + 1) * Wp + x0 + 1) * C + c0;
+  for (int i = tid; i < npx * 96; i += 256) {
+    const int p = i / 96, c = i - p * 96;
+    tile[p * 97 + c] = s[(int64_t)p * C + c];
+  }
+  __syncthreads();
+  const int lx = tid & 63, cw = tid >> 6;
+  if (lx < npx) {
+    float* d = dst + (((int64_t)img * C + c0) * H + y) * W + x0 + lx;
+#pragma unroll 4
+    for (int c = cw; c < 96; c += 4) d[(int64_t)c * H * W] = tile[lx * 97 + c] + (bias ? bias[c0 + c] : 0.f);
+  }
+}
+
 }  // namespace
 
 // the number of m ranges sdf_linear_dw_fwd wants for this shape (the caller provides `partial` of that many N x K fp32 tiles when > 1)
@@ -339,6 +362,15 @@ extern "C" int sdf_ringed_rows_fwd(const float* src, float* dst, int imgs, int C
   if (imgs < 1 || C < 96 || C % 96 || H < 1 || W < 1 || H + 2 > 65535 || (int64_t)imgs * (C / 96) > 65535) return SDF_E_SHAPE;
   const dim3 grid((unsigned)((W + 2 + 63) / 64), (unsigned)(H + 2), (unsigned)(imgs * (C / 96)));
   hipLaunchKernelGGL(ringed_rows_kernel, grid, dim3(256), 0, sdf_stream(stream), src, dst, C, H, W);
+  SDF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sdf_unring_rows_fwd(const float* src, const float* bias, float* dst, int imgs, int C, int H, int W, void* stream) {
+  if (!src || !dst) return SDF_E_NULL;
+  if (imgs < 1 || C < 96 || C % 96 || H < 1 || W < 1 || H > 65535 || (int64_t)imgs * (C / 96) > 65535) return SDF_E_SHAPE;
+  const dim3 grid((unsigned)((W + 63) / 64), (unsigned)H, (unsigned)(imgs * (C / 96)));
+  hipLaunchKernelGGL(unring_rows_kernel, grid, dim3(256), 0, sdf_stream(stream), src, bias, dst, C, H, W);
   SDF_LAUNCH_CHECK();
   return 0;
 }

@@ -33,6 +33,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 struct TrainParams {
   SdfLinearTrainDesc d;
   int tiles_c;
+  int cchunks;                                           // convolution form (mode 0): chunks of 32 per tap = cv_C / 32, else 0
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, uint32_t bytes) {
@@ -83,6 +84,10 @@ __global__ __launch_bounds__(256) void linear_train_kernel(TrainParams P) {
   const SdfLinearTrainDesc& d = P.d;
   const int M = d.M, N = d.N, K = d.K;
   const int R = MODE == 0 ? K : N, Cn = MODE == 0 ? N : K;            // reduction length, output columns
+  // convolution form (mode 0, cv_C > 0): a is (M, cv_C) zero-ringed channels-last pixel rows, K = 9 cv_C ordered (ky, kx, c), and the chunk
+  // of tap (ky, kx) reads the rows (ky - 1) * cv_Wp + (kx - 1) further on - a shift of the loader's offset, nothing else (rows before the
+  // tensor wrap to offsets beyond the descriptor and read as zero, like those past its end)
+  const int lda = (MODE == 0 && P.cchunks > 0) ? d.cv_C : R;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   // the column tiles of one row tile read the same activation rows: consecutive logical ids share an XCD (its L2)
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(256) void linear_train_kernel(TrainParams P) {
   const int tm = wg / P.tiles_c, tc = wg - tm * P.tiles_c;
   const int m0 = tm * BM, c0 = tc * BC;
 
-  const __amdgpu_buffer_rsrc_t A_rs = rsrc(d.a, (uint32_t)M * (uint32_t)R * 4u);
+  const __amdgpu_buffer_rsrc_t A_rs = rsrc(d.a, (uint32_t)M * (uint32_t)lda * 4u);
   const __amdgpu_buffer_rsrc_t W_rs = rsrc(d.w, (uint32_t)N * (uint32_t)K * 4u);
 
   // loader.  A: 128 rows x 8 float4 per chunk, 4 per thread.  W: mode 0 - 96 rows (n) x 8 float4; mode 1 - 32 rows (n) x 24 float4: 3 per thread
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(256) void linear_train_kernel(TrainParams P) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int p = tid + 256 * i, row = p >> 3, c4 = p & 7;
-    a_off[i] = m0 + row < M ? (uint32_t)((m0 + row) * R + c4 * 4) * 4u : INV;
+    a_off[i] = m0 + row < M ? (uint32_t)((m0 + row) * lda + c4 * 4) * 4u : INV;
     a_lds[i] = (uint32_t)(row * RS + c4 * 8);
   }
 #pragma unroll
@@ -118,8 +123,13 @@ __global__ __launch_bounds__(256) void linear_train_kernel(TrainParams P) {
   const uint32_t a_step = RC * 4u, w_step = MODE == 0 ? RC * 4u : (uint32_t)(RC * K) * 4u;
   u32x4 areg[4], wreg[3];
   auto request = [&](int c) __attribute__((always_inline)) {
+    uint32_t a_add = (uint32_t)c * a_step;
+    if (MODE == 0 && P.cchunks > 0) {
+      const int tap = c / P.cchunks, cc = c - tap * P.cchunks, ky = tap / 3, kx = tap - 3 * ky;
+      a_add = (uint32_t)(((ky - 1) * d.cv_Wp + (kx - 1)) * lda * 4 + cc * (int)a_step);   // (two's complement: may be "negative")
+    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) areg[i] = __builtin_amdgcn_raw_buffer_load_b128(A_rs, a_off[i] != INV ? a_off[i] + (uint32_t)c * a_step : INV, 0, 0);
+    for (int i = 0; i < 4; ++i) areg[i] = __builtin_amdgcn_raw_buffer_load_b128(A_rs, a_off[i] != INV ? a_off[i] + a_add : INV, 0, 0);
 #pragma unroll
     for (int i = 0; i < 3; ++i) wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(W_rs, w_off[i] + (uint32_t)c * w_step, 0, 0);
   };
@@ -227,14 +237,17 @@ __global__ __launch_bounds__(256) void linear_train_kernel(TrainParams P) {
 extern "C" int sdf_linear_train_fwd(const SdfLinearTrainDesc* d, void* stream) {
   if (!d || !d->a || !d->w || !d->out) return SDF_E_NULL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->mode != 0 && d->mode != 1)) return SDF_E_SHAPE;
+  if (d->cv_C < 0 || (d->cv_C > 0 && (d->mode != 0 || d->cv_C % RC || d->K != 9 * d->cv_C || d->cv_Wp < 3))) return SDF_E_SHAPE;
   const int R = d->mode == 0 ? d->K : d->N, Cn = d->mode == 0 ? d->N : d->K;
   if (R % RC || Cn % BC) return SDF_E_SHAPE;
   const int64_t lim = (int64_t)1 << 31;
-  if ((int64_t)d->M * d->K * 4 >= lim || (int64_t)d->M * d->N * 4 >= lim || (int64_t)d->N * d->K * 4 >= lim) return SDF_E_SHAPE;
+  const int64_t a_cols = d->cv_C > 0 ? d->cv_C : d->K;                // (convolution form: a is (M, cv_C), K counts the nine taps)
+  if ((int64_t)d->M * a_cols * 4 >= lim || (int64_t)d->M * d->N * 4 >= lim || (int64_t)d->N * d->K * 4 >= lim) return SDF_E_SHAPE;
   if (!sdf_aligned(d->a, 16) || !sdf_aligned(d->w, 16) || !sdf_aligned(d->out, 16) || (d->bias && !sdf_aligned(d->bias, 16))) return SDF_E_ALIGN;
   TrainParams P;
   P.d = *d;
   P.tiles_c = Cn / BC;
+  P.cchunks = d->cv_C > 0 ? d->cv_C / RC : 0;
   const int64_t wgs = (int64_t)((d->M + BM - 1) / BM) * P.tiles_c;
   hipStream_t s = sdf_stream(stream);
   if (d->mode == 0) hipLaunchKernelGGL(linear_train_kernel<0>, dim3((unsigned)wgs), dim3(256), 0, s, P);

@@ -28,7 +28,7 @@ EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_s
            "sdf_rows_gather_fwd", "sdf_rows_scatter_fwd",
            "sdf_split_weight_i8x3", "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd",
            "sdf_dense_conv3x3_fwd", "sdf_pack_planes", "sdf_unpack_planes", "sdf_pack_planes_up2", "sdf_dense_linear_fwd", "sdf_layer_norm_fwd",
-           "sdf_linear_dw_fwd", "sdf_linear_dw_splits", "sdf_ringed_rows_fwd", "sdf_linear_train_fwd")
+           "sdf_linear_dw_fwd", "sdf_linear_dw_splits", "sdf_ringed_rows_fwd", "sdf_linear_train_fwd", "sdf_unring_rows_fwd")
 
 
 class SdfError(RuntimeError):
@@ -125,7 +125,7 @@ class LinearDwDesc(C.Structure):
 
 class LinearTrainDesc(C.Structure):
     _fields_ = [("a", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
-                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("mode", C.c_int32)]
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("mode", C.c_int32), ("cv_C", C.c_int32), ("cv_Wp", C.c_int32)]
 
 
 _lib = None
@@ -1191,18 +1191,20 @@ def linear_train_applicable(M, N, K):
     return N % 96 == 0 and K % 96 == 0 and M * max(N, K) * 4 < 1 << 31
 
 
-def linear_train(a, w, bias=None, mode=0):
+def linear_train(a, w, bias=None, mode=0, conv_wp=0):
     """Training-path Linear products from fp32 tensors (sdf_linear_train_fwd).  mode 0: a (M, K) spikes @ w.T + bias -> (M, N);
-    mode 1: a = dY (M, N) @ w -> (M, K).  w is the layer's (N, K) fp32 weight as it is."""
+    mode 1: a = dY (M, N) @ w -> (M, K).  w is the layer's (N, K) fp32 weight as it is.  conv_wp > 0 (mode 0): the convolution form -
+    a (M, C) ringed channels-last rows, w (N, 9 C) ordered (ky, kx, c), result on the ringed grid."""
     N, K = w.shape
     M = a.shape[0]
-    if a.shape[1] != (K if mode == 0 else N) or not a.is_contiguous() or not w.is_contiguous():
+    if a.shape[1] != ((K // 9 if conv_wp else K) if mode == 0 else N) or not a.is_contiguous() or not w.is_contiguous():
         raise SdfError("linear_train needs contiguous a (M, K | N) and w (N, K)")
     out = torch.empty((M, N if mode == 0 else K), dtype=torch.float32, device=a.device)
     d = LinearTrainDesc()
     d.a, d.w, d.bias, d.out = _ptr(a, torch.float32), _ptr(w, torch.float32), _ptr(bias if mode == 0 else None, torch.float32), _ptr(out, torch.float32)
     d.M, d.N, d.K, d.mode = M, N, K, mode
-    _note(flop=2.0 * M * N * K, bytes=4.0 * M * (N + K), what=f"linear {'fwd' if mode == 0 else 'dX'} {M}x{N}x{K}")
+    d.cv_C, d.cv_Wp = (K // 9, conv_wp) if conv_wp else (0, 0)
+    _note(flop=2.0 * M * N * K, bytes=4.0 * M * (N + a.shape[1]), what=f"linear {'fwd' if mode == 0 else 'dX'} {M}x{N}x{K}")
     _check(lib().sdf_linear_train_fwd(C.byref(d), _stream()), "sdf_linear_train_fwd")
     return out
 
@@ -1249,6 +1251,24 @@ def _ringed_rows(t):
     return out
 
 
+def unring_rows(rows, imgs, Cc, H, W, bias=None):
+    """Ringed channels-last rows (imgs * (H + 2) * (W + 2), C) -> (imgs, C, H, W) (+ bias) (sdf_unring_rows_fwd)."""
+    if tuple(rows.shape) != (imgs * (H + 2) * (W + 2), Cc) or not rows.is_contiguous():
+        raise SdfError("unring_rows: shape does not match the ringed grid")
+    out = torch.empty((imgs, Cc, H, W), dtype=torch.float32, device=rows.device)
+    _check(lib().sdf_unring_rows_fwd(C.c_void_p(_ptr(rows, torch.float32)), C.c_void_p(_ptr(bias, torch.float32)), C.c_void_p(out.data_ptr()),
+                                     C.c_int(imgs), C.c_int(Cc), C.c_int(H), C.c_int(W), _stream()), "sdf_unring_rows_fwd")
+    return out
+
+
+def conv3x3_fwd_ringed(xr, weight, bias, imgs, H, W):
+    """Forward of a 3x3 / stride 1 / pad 1 convolution on the ringed rows xr (imgs * (H + 2) * (W + 2), Cin) of a SPIKE image ->
+    (imgs, Cout, H, W) fp32 (sdf_linear_train_fwd, convolution form + sdf_unring_rows_fwd)."""
+    N = weight.shape[0]
+    w9 = weight.detach().float().permute(0, 2, 3, 1).reshape(N, -1).contiguous()
+    return unring_rows(linear_train(xr, w9, None, mode=0, conv_wp=W + 2), imgs, N, H, W, bias)
+
+
 def conv3x3_dw(dy, x):
     """Weight gradient (Cout, Cin, 3, 3) of a 3x3 / stride 1 / pad 1 convolution fed by spikes: dy (imgs, Cout, H, W), x (imgs, Cin,
     H, W) fp32 NCHW as the training path holds them (sdf_linear_dw_fwd, convolution form).  Both go to zero-ringed channels-last
@@ -1256,9 +1276,10 @@ def conv3x3_dw(dy, x):
     edge."""
     imgs, N, H, W = dy.shape
     Cc = x.shape[1]
-    if tuple(x.shape) != (imgs, Cc, H, W):
-        raise SdfError("conv3x3_dw needs dy (imgs, Cout, H, W) and x (imgs, Cin, H, W)")
-    dw = linear_dw(_ringed_rows(dy), _ringed_rows(x.contiguous()), conv_wp=W + 2)
+    if tuple(x.shape) != (imgs, Cc, H, W) and tuple(x.shape) != (imgs * (H + 2) * (W + 2), Cc):
+        raise SdfError("conv3x3_dw needs dy (imgs, Cout, H, W) and x (imgs, Cin, H, W) or its ringed rows")
+    xr = x if x.dim() == 2 else _ringed_rows(x.contiguous())           # (the forward may have kept the ringed rows)
+    dw = linear_dw(_ringed_rows(dy), xr, conv_wp=W + 2)
     return dw.view(N, 3, 3, Cc).permute(0, 3, 1, 2).contiguous()
 
 

@@ -43,6 +43,8 @@ LINEAR_DW_HIP = os.environ.get("SDF_TRAIN_LINEAR_DW", "1") != "0"
 LINEAR_HIP = os.environ.get("SDF_TRAIN_LINEAR", "1") != "0"
 # ... and of the MS_ResBlock convolutions (3x3 / stride 1 / pad 1 on spikes; SDF_TRAIN_CONV_DW=0: MIOpen's)
 CONV_DW_HIP = os.environ.get("SDF_TRAIN_CONV_DW", "1") != "0"
+# ... and their forward (SDF_TRAIN_CONV_FWD=0: MIOpen's; the ringed rows are then made in the backward)
+CONV_FWD_HIP = os.environ.get("SDF_TRAIN_CONV_FWD", "1") != "0"
 
 
 def _linear(x, lin):
@@ -93,8 +95,11 @@ def _conv_seq(x, conv, stride=None, padding=None, spikes=False):
     if (spikes and CONV_DW_HIP and stride is None and padding is None and x2.is_cuda and tuple(conv.kernel_size) == (3, 3)
             and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
             and hip.conv3x3_dw_applicable(x2.shape[0], conv.in_channels, conv.out_channels, x2.shape[2], x2.shape[3])):
-        from .autograd import Conv3x3DwFunction
-        y = Conv3x3DwFunction.apply(x2, conv.weight, conv.bias)
+        from .autograd import Conv3x3DwFunction, Conv3x3HipFunction
+        if CONV_FWD_HIP and not torch.is_autocast_enabled() and conv.in_channels % 32 == 0:
+            y = Conv3x3HipFunction.apply(x2, conv.weight, conv.bias)
+        else:
+            y = Conv3x3DwFunction.apply(x2, conv.weight, conv.bias)
     else:
         y = F.conv2d(x2, conv.weight, conv.bias, conv.stride if stride is None else stride, conv.padding if padding is None else padding)
     return y.view(T, B, *y.shape[1:])

@@ -24,3 +24,9 @@ tot = sum(v[1] for v in acc.values())
 print(f"last {win/1e6:.0f} ms of the trace: {len(sel)} launches, kernel time {tot:.1f} ms")
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1])[:26]:
     print(f"{v[1]:8.2f} ms  x{v[0]:<5d} {k}")
+
+# the library launches one by one (what is left to replace): duration, grid
+lib = [r for r in sel if any(k in r["Kernel_Name"] for k in ("igemm", "miopenSp3AsmConv", "Cijk"))]
+print("library convolution / GEMM launches of the step, largest first:")
+for r in sorted(lib, key=lambda r: int(r["Start_Timestamp"]) - int(r["End_Timestamp"]))[:44]:
+    print(f"  {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f} us  grid {r.get('Grid_Size_X', '?'):>8s}  {r['Kernel_Name'][:110]}")
