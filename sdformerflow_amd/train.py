@@ -4,9 +4,10 @@ autograd, the supervised loss, one optimiser step, and the data-parallel gradien
 What is hand-written HIP here: every spiking neuron, forward AND backward (`autograd.LIFFunction` / `PSNFunction` ->
 csrc/neuron.hip, csrc/neuron_bwd.hip; 105 neuron calls per forward), the batch-statistics BatchNorm, the token gate, and -
 since round 5 - ALL THREE products of every Linear layer (`autograd.LinearHipFunction`: forward and dX on csrc/linear_train.hip,
-dW on csrc/linear_dw.hip: 35 ms of library fp32 GEMM -> 13 ms; no rocBLAS kernel is left in a step) and the weight gradient of the
-MS_ResBlock convolutions (`autograd.Conv3x3DwFunction`).  The other dense products - Conv2d / ConvTranspose2d forward and dX, the
-remaining convolutions' dW - are library work through torch on the same stream (MIOpen); their replacements are the next row.  Nothing here touches `oracle/`, and CPU
+dW on csrc/linear_dw.hip: 35 ms of library fp32 GEMM -> 13 ms; no rocBLAS GEMM of a Linear layer is left in a step) and the forward and
+weight gradient of the MS_ResBlock convolutions (`autograd.Conv3x3HipFunction`: products over zero-ringed channels-last pixel rows).
+The other dense products - the convolutions' dX, the remaining convolutions' forward and dW - are library work through torch on the
+same stream (MIOpen); their replacements are the next row.  Nothing here touches `oracle/`, and CPU
 tensors are refused by the neuron kernels (`SdfError`).
 
 Reference semantics mirrored (file:line under /root/reference):

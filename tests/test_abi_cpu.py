@@ -226,6 +226,11 @@ def test_argument_errors_are_reported_before_any_launch():
     assert lib.sdf_linear_train_fwd(C.byref(lt), None) == E_SHAPE          # dX: K % 96 (its output columns)
     lt.K, lt.w = 96, 0x10008
     assert lib.sdf_linear_train_fwd(C.byref(lt), None) == E_ALIGN
+    lt.w, lt.mode, lt.N, lt.K, lt.cv_C, lt.cv_Wp = 0x10000, 0, 96, 864, 64, 10
+    assert lib.sdf_linear_train_fwd(C.byref(lt), None) == E_SHAPE          # convolution form: K = 9 cv_C
+    lt.cv_C, lt.mode = 96, 1
+    assert lib.sdf_linear_train_fwd(C.byref(lt), None) == E_SHAPE          # convolution form: forward only
+    assert lib.sdf_unring_rows_fwd(None, None, p, 1, 96, 4, 4, None) == E_NULL and lib.sdf_unring_rows_fwd(p, None, p, 1, 100, 4, 4, None) == E_SHAPE
     assert lib.sdf_ringed_rows_fwd(None, p, 1, 96, 4, 4, None) == E_NULL and lib.sdf_ringed_rows_fwd(p, p, 1, 48, 4, 4, None) == E_SHAPE
 
 
