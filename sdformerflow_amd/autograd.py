@@ -249,7 +249,7 @@ class Conv3x3HipFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         imgs, Cc, H, W = x.shape
-        xr = hip._ringed_rows(x.float().contiguous())
+        xr = hip.ringed_rows(x.float().contiguous())
         ctx.save_for_backward(xr, weight)
         ctx.has_bias, ctx.xshape, ctx.in_dtype = bias is not None, tuple(x.shape), x.dtype
         return hip.conv3x3_fwd_ringed(xr, weight, None if bias is None else bias.detach().float().contiguous(), imgs, H, W)

@@ -1240,7 +1240,7 @@ def conv3x3_dw_applicable(imgs, Cin, Cout, H, W):
     return Cin % 96 == 0 and Cout % 96 == 0 and imgs * (H + 2) * (W + 2) * max(Cin, Cout) * 4 < 1 << 31
 
 
-def _ringed_rows(t):
+def ringed_rows(t):
     """(imgs, C, H, W) fp32 -> zero-ringed channels-last pixel rows (imgs * (H + 2) * (W + 2), C) (sdf_ringed_rows_fwd)."""
     imgs, Cc, H, W = t.shape
     if not t.is_contiguous():
@@ -1269,6 +1269,9 @@ def conv3x3_fwd_ringed(xr, weight, bias, imgs, H, W):
     return unring_rows(linear_train(xr, w9, None, mode=0, conv_wp=W + 2), imgs, N, H, W, bias)
 
 
+_ringed_rows = ringed_rows
+
+
 def conv3x3_dw(dy, x):
     """Weight gradient (Cout, Cin, 3, 3) of a 3x3 / stride 1 / pad 1 convolution fed by spikes: dy (imgs, Cout, H, W), x (imgs, Cin,
     H, W) fp32 NCHW as the training path holds them (sdf_linear_dw_fwd, convolution form).  Both go to zero-ringed channels-last
@@ -1278,8 +1281,8 @@ def conv3x3_dw(dy, x):
     Cc = x.shape[1]
     if tuple(x.shape) != (imgs, Cc, H, W) and tuple(x.shape) != (imgs * (H + 2) * (W + 2), Cc):
         raise SdfError("conv3x3_dw needs dy (imgs, Cout, H, W) and x (imgs, Cin, H, W) or its ringed rows")
-    xr = x if x.dim() == 2 else _ringed_rows(x.contiguous())           # (the forward may have kept the ringed rows)
-    dw = linear_dw(_ringed_rows(dy), xr, conv_wp=W + 2)
+    xr = x if x.dim() == 2 else ringed_rows(x.contiguous())           # (the forward may have kept the ringed rows)
+    dw = linear_dw(ringed_rows(dy), xr, conv_wp=W + 2)
     return dw.view(N, 3, 3, Cc).permute(0, 3, 1, 2).contiguous()
 
 
