@@ -41,17 +41,34 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(BnParams P) {
         mu = *reinterpret_cast<const float4*>(P.mean + 4 * q);
         is = *reinterpret_cast<const float4*>(P.invstd + 4 * q);
       }
-      for (int64_t r = (int64_t)blockIdx.x * RL + rl; r < P.R; r += (int64_t)gridDim.x * RL) {
-        const float4 a = *reinterpret_cast<const float4*>(P.x + r * P.C + 4 * q);
+      auto accum = [&](const float4& a, const float4& g) __attribute__((always_inline)) {
         if (!BWD) {
           s0[0] += a.x; s0[1] += a.y; s0[2] += a.z; s0[3] += a.w;
           s1[0] += (double)a.x * a.x; s1[1] += (double)a.y * a.y; s1[2] += (double)a.z * a.z; s1[3] += (double)a.w * a.w;
         } else {
-          const float4 g = *reinterpret_cast<const float4*>(P.gy + r * P.C + 4 * q);
           s0[0] += g.x; s0[1] += g.y; s0[2] += g.z; s0[3] += g.w;
           s1[0] += (double)g.x * ((a.x - mu.x) * is.x); s1[1] += (double)g.y * ((a.y - mu.y) * is.y);
           s1[2] += (double)g.z * ((a.z - mu.z) * is.z); s1[3] += (double)g.w * ((a.w - mu.w) * is.w);
         }
+      };
+      // four rows' loads in flight per thread (one at a time left 2 MB in flight on the whole chip: a latency-bound stream); the
+      // additions keep their order, the sums their bits
+      const int64_t step = (int64_t)gridDim.x * RL;
+      int64_t r = (int64_t)blockIdx.x * RL + rl;
+      for (; r + 3 * step < P.R; r += 4 * step) {
+        float4 a[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a[u] = *reinterpret_cast<const float4*>(P.x + (r + u * step) * P.C + 4 * q);
+          g[u] = BWD ? *reinterpret_cast<const float4*>(P.gy + (r + u * step) * P.C + 4 * q) : a[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) accum(a[u], g[u]);
+      }
+      for (; r < P.R; r += step) {
+        const float4 a = *reinterpret_cast<const float4*>(P.x + r * P.C + 4 * q);
+        const float4 g = BWD ? *reinterpret_cast<const float4*>(P.gy + r * P.C + 4 * q) : a;
+        accum(a, g);
       }
     }
     __syncthreads();
@@ -153,17 +170,31 @@ __global__ __launch_bounds__(256) void bn_reduce_nchw_kernel(BnParams P) {
     const float* gp = BWD ? P.gy + pl * P.HW : nullptr;
     const float mu = BWD ? P.mean[c] : 0.f, is = BWD ? P.invstd[c] : 0.f;
     double s0 = 0, s1 = 0;
-    for (int q = threadIdx.x; q < Q; q += 256) {
-      const float4 a = *reinterpret_cast<const float4*>(xp + 4 * q);
+    auto accum = [&](const float4& a, const float4& g) __attribute__((always_inline)) {
       if (!BWD) {
         s0 += ((double)a.x + a.y) + ((double)a.z + a.w);
         s1 += ((double)a.x * a.x + (double)a.y * a.y) + ((double)a.z * a.z + (double)a.w * a.w);
       } else {
-        const float4 g = *reinterpret_cast<const float4*>(gp + 4 * q);
         s0 += ((double)g.x + g.y) + ((double)g.z + g.w);
         s1 += ((double)g.x * ((a.x - mu) * is) + (double)g.y * ((a.y - mu) * is)) +
               ((double)g.z * ((a.z - mu) * is) + (double)g.w * ((a.w - mu) * is));
       }
+    };
+    int q = threadIdx.x;                                            // four loads in flight per thread, additions in the same order
+    for (; q + 768 < Q; q += 1024) {
+      float4 a[4], g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = *reinterpret_cast<const float4*>(xp + 4 * (q + 256 * u));
+        g[u] = BWD ? *reinterpret_cast<const float4*>(gp + 4 * (q + 256 * u)) : a[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) accum(a[u], g[u]);
+    }
+    for (; q < Q; q += 256) {
+      const float4 a = *reinterpret_cast<const float4*>(xp + 4 * q);
+      const float4 g = BWD ? *reinterpret_cast<const float4*>(gp + 4 * q) : a;
+      accum(a, g);
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
