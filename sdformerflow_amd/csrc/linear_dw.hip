@@ -248,7 +248,15 @@ __global__ __launch_bounds__(256) void linear_dw_reduce_kernel(const float* __re
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (col < n4) {
     const float4* p = reinterpret_cast<const float4*>(partial) + col;
-    for (int k = sl; k < nsplit; k += 16) {
+    int k = sl;
+    for (; k + 48 < nsplit; k += 64) {                                 // four loads in flight, additions in range order
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = p[(int64_t)(k + 16 * u) * n4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; k < nsplit; k += 16) {
       const float4 v = p[(int64_t)k * n4];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
