@@ -17,6 +17,6 @@ for f in ms_wide ms_res ms_smallm neuron neuron_bwd bn_train qk_attn qk_front ms
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait $p; done
 # the kernels that hold whole compute units must not touch scratch (its traffic is vmcnt-ordered and drains the operand prefetch)
-python3 ../../tools/check_spills.py obj/ms_smallm.res obj/ms_wide.res obj/ms_res.res
+python3 ../../tools/check_spills.py obj/ms_smallm.res obj/ms_wide.res obj/ms_res.res obj/linear_dw.res obj/linear_train.res obj/ann_mlp_block.res
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o libsdformerflow_hip.so obj/*.o
 echo "built $(pwd)/libsdformerflow_hip.so"
