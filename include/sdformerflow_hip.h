@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SDF_VERSION 106   /* round 5: + sdf_ann_attn_block_fwd, sdf_ann_mlp_block_fwd, sdf_spike_deconv3x3s2_fwd, row-major digit planes in sdf_spike_gemm_fwd; 106: + sdf_linear_dw_fwd, sdf_ringed_rows_fwd, sdf_linear_train_fwd */
+#define SDF_VERSION 107   /* round 6 (107): + sdf_switches_reload; the diagnostic SDF_* switches are read once, not per call.  106 / round 5: + sdf_ann_attn_block_fwd, sdf_ann_mlp_block_fwd, sdf_spike_deconv3x3s2_fwd, row-major digit planes in sdf_spike_gemm_fwd; 106: + sdf_linear_dw_fwd, sdf_ringed_rows_fwd, sdf_linear_train_fwd */
 
 enum { SDF_F32 = 0, SDF_U8 = 1 };
 enum { SDF_LIF = 0, SDF_PSN = 1, SDF_IF = 2 };
@@ -35,6 +35,12 @@ enum {
 };
 
 int sdf_version(void);
+
+/* The library's diagnostic switches (the SDF_* environment variables listed in INTEGRATION.md's appendix: A/B and tuning overrides,
+ * none needed in production) are read from the environment ONCE, at the first call that asks for one, into a read-only table - no
+ * entry point calls getenv() on its per-call path.  A test harness that changes the environment between calls re-reads the table
+ * with this call (not concurrently with other calls into the library).  No reference counterpart. */
+void sdf_switches_reload(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-step LIF over the leading (time) axis of a contiguous fp32 (T, N) tensor.

@@ -97,7 +97,7 @@ class PatchEmbedLocal(nn.Module):
         T, B = x.shape[:2]
         x = x.flatten(0, 1)                                                           # the T chunks share every weight
         imgs, C, H, W = x.shape
-        if (not self.training and x.is_cuda and os.environ.get("SDF_DENSE_CONV", "1") != "0"
+        if (not self.training and x.is_cuda and hip.sw("SDF_DENSE_CONV", "1") != "0"
                 and hip.dense_conv_applicable(imgs, H, W, C, self.embed_dim) and C <= 16 and self.embed_dim == 96):
             a = self._encode_planes(x)                                                # (imgs, H, W, C) channels last
             st = self.proj.stride

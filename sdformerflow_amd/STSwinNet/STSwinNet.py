@@ -39,7 +39,7 @@ class UpsampleConvLayer(ConvLayer):
         """Record layout of the parts, or None when this layer / these shapes have no dense-convolution form."""
         conv = self.conv2d
         if (self.training or conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.out_channels % 32 or self.activation != "relu"
-                or os.environ.get("SDF_DENSE_CONV", "1") == "0" or not all(p.is_cuda and p.dtype == torch.float32 for p in parts)):
+                or hip.sw("SDF_DENSE_CONV", "1") == "0" or not all(p.is_cuda and p.dtype == torch.float32 for p in parts)):
             return None
         if any(p.shape[1] % 16 for p in parts[:-1]):
             return None

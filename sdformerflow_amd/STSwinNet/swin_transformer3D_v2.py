@@ -22,7 +22,7 @@ def linear_rows(lin, a, gelu=False, resid=None):
     parameter version."""
     M, K = a.shape
     N = lin.out_features
-    if (not lin.training and a.is_cuda and a.dtype == torch.float32 and os.environ.get("SDF_DENSE_LINEAR", "1") != "0"
+    if (not lin.training and a.is_cuda and a.dtype == torch.float32 and hip.sw("SDF_DENSE_LINEAR", "1") != "0"
             and hip.dense_linear_applicable(M, N, K)):
         stamp = (lin.weight.data_ptr(), lin.weight._version)
         if getattr(lin, "_pk_stamp", None) != stamp:
@@ -39,7 +39,7 @@ def layer_norm(ln, x):
     """nn.LayerNorm `ln` on x (..., C): the HIP kernel in eval on the GPU (one read, one write), torch otherwise."""
     C = x.shape[-1]
     if (not ln.training and x.is_cuda and x.dtype == torch.float32 and ln.elementwise_affine and ln.bias is not None and C % 4 == 0
-            and C <= 2048 and os.environ.get("SDF_LAYER_NORM", "1") != "0"):
+            and C <= 2048 and hip.sw("SDF_LAYER_NORM", "1") != "0"):
         return hip.layer_norm(x.contiguous(), ln.weight.detach(), ln.bias.detach(), ln.eps)
     return ln(x)
 
@@ -212,7 +212,7 @@ class SwinTransformerBlock3D(nn.Module):
             # the nominal window, to the smaller scores (:190, RuntimeError); the same input is refused here, not mis-addressed
             raise RuntimeError(f"feature map {(D, H, W)} is smaller than the window {self.window_size}: the relative position bias of "
                                "WindowAttention3D is defined for the nominal window only (reference swin_transformer3D_v2.py:184-190)")
-        materialise = os.environ.get("SDF_ATTN_MATERIALISE") == "1" or self.training
+        materialise = hip.sw("SDF_ATTN_MATERIALISE") == "1" or self.training
         # first stage (C = 96, three heads, 162-token windows): LayerNorm -> qkv -> attention -> proj -> + x is ONE launch that reads x
         # through the slice map (csrc/ann_block.hip); elsewhere the norm runs here and forward_rows takes its output
         fused = (not materialise and x.is_cuda and x.dtype == torch.float32 and self.norm1.elementwise_affine and self.norm1.bias is not None

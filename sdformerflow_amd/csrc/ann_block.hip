@@ -427,12 +427,8 @@ extern "C" int sdf_ann_attn_block_fwd(const SdfAnnAttnBlockDesc* d, void* stream
     return SDF_E_ALIGN;
   BlockParams P;
   P.d = *d;
-  static bool raised = false;                                                    // > 64 KiB of dynamic LDS: one-time opt-in
-  if (!raised) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(ann_attn_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e1 != hipSuccess) return (int)e1;
-    raised = true;
-  }
+  static std::atomic<uint64_t> raised{0};                                        // > 64 KiB of dynamic LDS: opt-in once per device
+  if (const int e1 = sdf_lds_opt_in(raised, reinterpret_cast<const void*>(ann_attn_block_kernel), LDS_BYTES)) return e1;
   hipStream_t s = sdf_stream(stream);
   const dim3 grid((unsigned)d->B_), block(NTHR);
   hipLaunchKernelGGL(ann_attn_block_kernel, grid, block, LDS_BYTES, s, P);

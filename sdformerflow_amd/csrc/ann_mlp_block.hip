@@ -234,12 +234,8 @@ extern "C" int sdf_ann_mlp_block_fwd(const SdfAnnMlpBlockDesc* d, void* stream) 
     return SDF_E_ALIGN;
   MlpParams P;
   P.d = *d;
-  static bool raised = false;                                                    // > 64 KiB of dynamic LDS: one-time opt-in
-  if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ann_mlp_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    raised = true;
-  }
+  static std::atomic<uint64_t> raised{0};                                        // > 64 KiB of dynamic LDS: opt-in once per device
+  if (const int e = sdf_lds_opt_in(raised, reinterpret_cast<const void*>(ann_mlp_block_kernel), LDS_BYTES)) return e;
   const int64_t wgs = (d->rows + ROWS_WG - 1) / ROWS_WG;
   hipLaunchKernelGGL(ann_mlp_block_kernel, dim3((unsigned)wgs), dim3(NTHR), LDS_BYTES, sdf_stream(stream), P);
   SDF_LAUNCH_CHECK();

@@ -37,6 +37,7 @@
 // consecutive halo rows; four consecutive pixels cover the four 64-byte quarters of a 256-byte bank row, and the four rows put
 // the slot they all ask for at four different places of its quarter.  Weight rows are 2K + 16 bytes (4 x odd dwords).
 #include "spike_mm.h"
+#include "switches.h"
 #include <stdlib.h>
 
 #ifdef SDF_STAMP
@@ -527,7 +528,7 @@ extern "C" int sdf_dense_conv3x3_fwd(const SdfDenseConvDesc* d, void* stream) {
   const int ncb = d->N / NB;
   if (ncb > 32) return SDF_E_SHAPE;
   // two pixel blocks per wave where the map is tall enough for 8-row tiles to waste little (a 36-row map would multiply 40 rows)
-  static const int tpw_env = [] { const char* e = getenv("SDF_DENSE_TPW"); return e ? atoi(e) : 0; }();
+  const int tpw_env = [] { const char* e = sdf_sw(SW_DENSE_TPW); return e ? atoi(e) : 0; }();
   const int waste8 = ((d->H + 7) / 8) * 8 - d->H, waste4 = ((d->H + 3) / 4) * 4 - d->H;
   int tpw = (d->cin_records == 6 && (waste8 == waste4 || d->H >= 128)) ? 2 : 1;
   if (d->cin_records == 6 && (tpw_env == 1 || tpw_env == 2)) tpw = tpw_env;

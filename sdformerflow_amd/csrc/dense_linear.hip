@@ -16,6 +16,7 @@
 // F.gelu) and the residual are applied on 16-byte pieces and stored as such.  LDS rows are 64 data bytes + 16 pad (slots 5
 // apart: conflict-free ds_read_b128 over 16 consecutive rows).
 #include "common.h"
+#include "switches.h"
 #include <math.h>
 #include <stdlib.h>
 
@@ -235,7 +236,7 @@ extern "C" int sdf_dense_linear_fwd(const SdfDenseLinearDesc* d, void* stream) {
   LinearParams P;
   P.d = *d;
   P.tiles_n = d->N / BN;
-  static const bool xcd = [] { const char* e = getenv("SDF_DENSE_LINEAR_XCD"); return !e || e[0] != '0'; }();
+  const bool xcd = [] { const char* e = sdf_sw(SW_DENSE_LINEAR_XCD); return !e || e[0] != '0'; }();
   P.xcd = xcd ? 1 : 0;
   const int64_t tiles = (int64_t)((d->M + BM - 1) / BM) * P.tiles_n;
   hipLaunchKernelGGL(dense_linear_kernel, dim3((unsigned)tiles), dim3(256), 0, sdf_stream(stream), P);

@@ -12,6 +12,7 @@
 //      resolution (reference Spiking_STSwinNet.py:289-303: flow.sum(0) then F.interpolate(scale_factor=H/h, W/w)).
 // Compiled with -ffp-contract=off (the neuron arithmetic is the separately-rounded op sequence of neuron.hip).
 #include "spike_mm.h"
+#include "switches.h"
 #include <stdlib.h>
 
 namespace {
@@ -476,7 +477,7 @@ extern "C" int sdf_head_conv_sn_fwd(const SdfHeadConvDesc* d, void* stream) {
     for (int ci = 0; ci < 4; ++ci) P.d.x_sc[ci] = ci;
   }
   // fp32 matrix-pipe kernel: LIF / IF, 32-pixel tiles, 31-bit byte offsets into the voxel
-  const char* e_hm = getenv("SDF_HEAD_MFMA");                        // (read per call)
+  const char* e_hm = sdf_sw(SW_HEAD_MFMA);                        // (read per call)
   const bool no_mfma = e_hm && e_hm[0] == '0';
   int64_t span = (int64_t)(d->B - 1) * P.d.x_sb + (int64_t)(d->T - 1) * P.d.x_st + (int64_t)(d->H - 1) * P.d.x_sy + (int64_t)(d->W - 1) * P.d.x_sx;
   int64_t scmax = 0;

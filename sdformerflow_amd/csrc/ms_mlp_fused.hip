@@ -26,6 +26,7 @@
 // global -> registers one phase ahead and stored to the single LDS weight buffer between the barriers.
 // Compiled with -ffp-contract=off: neuron arithmetic is the separately-rounded op sequence of neuron.hip.
 #include "spike_mm.h"
+#include "switches.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -508,7 +509,7 @@ bool ms_mlp_fused_supports(const SdfMsMlpDesc* d) {
   }
   // C = 192 (stage 1): a work item streams 1.2 MB of weights for 8 positions; with few positions (batch 1 at 288 x 384: 1 728) the
   // three-launch form is as fast (measured 65 us both), from a few thousand on the one-launch form wins (config 5: -30 %)
-  if (d->C == 192 && (int64_t)d->B * d->HW < 4096 && !getenv("SDF_MLP_FUSED_ANY")) return false;
+  if (d->C == 192 && (int64_t)d->B * d->HW < 4096 && !sdf_sw(SW_MLP_FUSED_ANY)) return false;
   if (!sdf_aligned(d->x, 16) || !sdf_aligned(d->fc1_planes, 16) || !sdf_aligned(d->fc2_planes, 16)) return false;
   if (!d->fc1_alpha || !d->fc1_beta || !d->fc2_alpha || !d->fc2_beta) return false;
   if (!sdf_aligned(d->fc2_alpha, 16) || !sdf_aligned(d->fc2_beta, 16)) return false;

@@ -26,6 +26,7 @@
 //                      :709-714, :810-820, :840-845, :952-974
 //   res_front_kernel : q | k = SN_q/k( BN( xs [Wq;Wk]^T ) [+ PE] ), E = k AND SN2_q( head sums of q )      reference :671-694
 #include "wide_common.h"
+#include "switches.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -592,20 +593,15 @@ __global__ __launch_bounds__(64 * NWV) void res_front_kernel(WideFrontParams P) 
 }
 
 bool res_env_off() {
-  const char* e = getenv("SDF_RES");                    // A/B: 0 = the kernels these replaced (ms_wide.hip / qk_front / ms_mlp_fused / spike_gemm)
+  const char* e = sdf_sw(SW_RES);                    // A/B: 0 = the kernels these replaced (ms_wide.hip / qk_front / ms_mlp_fused / spike_gemm)
   return e && e[0] == '0';
 }
 
 // dynamic LDS above 64 KB needs the attribute, once per kernel function (process-wide, read-only afterwards)
 template <class KernelT>
 int res_raise(KernelT kern) {
-  static bool done = false;                              // (one instance per kernel type: the template parameter is the function's type)
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-    if (e != hipSuccess) return (int)e;
-    done = true;
-  }
-  return 0;
+  static std::atomic<uint64_t> done{0};                  // (one instance per kernel type: the template parameter is the function's type; one bit per device)
+  return sdf_lds_opt_in(done, reinterpret_cast<const void*>(kern), 158 * 1024);
 }
 
 template <int T, int EPI, int NK, int AM, bool STRIP = false>
@@ -623,7 +619,7 @@ int res_pm_launch(const WidePmParams& P, dim3 grid, size_t lds, hipStream_t s) {
 }
 
 bool res_strip(const WidePmParams& P) {
-  const char* e = getenv("SDF_RES_STRIP");              // A/B: 0 = fragment-shaped loads everywhere
+  const char* e = sdf_sw(SW_RES_STRIP);              // A/B: 0 = fragment-shaped loads everywhere
   if (e && e[0] == '0') return false;
   return P.cv_Cin != 0 || (!P.a_tiled && !P.zsrc);
 }
@@ -673,8 +669,8 @@ int launch_res_pm(WidePmParams& P, int T, int epi, hipStream_t s) {
   // (column groups) x (row ranges of 8 r units) fits the chip's 256 compute units
   int r = 1;
   while ((int64_t)P.ncg * ((units + 8 * r - 1) / (8 * r)) > 256) ++r;
-  if (const char* e = getenv("SDF_RES_UPW")) { const int v = atoi(e); if (v >= 1 && v <= 4096) r = v; }     // tuning override: units per wave
-  if (const char* e = getenv("SDF_RES_RMUL")) { const int v = atoi(e); if (v >= 1 && v <= 16) r *= v; }       // tuning: fewer, longer-lived workgroups
+  if (const char* e = sdf_sw(SW_RES_UPW)) { const int v = atoi(e); if (v >= 1 && v <= 4096) r = v; }     // tuning override: units per wave
+  if (const char* e = sdf_sw(SW_RES_RMUL)) { const int v = atoi(e); if (v >= 1 && v <= 16) r *= v; }       // tuning: fewer, longer-lived workgroups
   P.passes = 8 * r;                                       // units per row range
   P.nrg = (int)((units + P.passes - 1) / P.passes);
   const int64_t items = (int64_t)P.ncg * P.nrg;
@@ -708,8 +704,8 @@ int launch_res_front(WideFrontParams& P, bool keep, int nk, hipStream_t s) {
   P.ntiles = (int)ntiles;
   int r = 1;
   while ((int64_t)P.nH * ((ntiles + 8 * r - 1) / (8 * r)) > 256) ++r;
-  if (const char* e = getenv("SDF_RES_UPW")) { const int v = atoi(e); if (v >= 1 && v <= 4096) r = v; }
-  if (const char* e = getenv("SDF_RES_RMUL")) { const int v = atoi(e); if (v >= 1 && v <= 16) r *= v; }
+  if (const char* e = sdf_sw(SW_RES_UPW)) { const int v = atoi(e); if (v >= 1 && v <= 4096) r = v; }
+  if (const char* e = sdf_sw(SW_RES_RMUL)) { const int v = atoi(e); if (v >= 1 && v <= 16) r *= v; }
   P.ntiles_per = 8 * r;
   P.nrg = (int)((ntiles + P.ntiles_per - 1) / P.ntiles_per);
   const int64_t items = (int64_t)P.nrg * P.nH;

@@ -29,6 +29,7 @@
 //
 // Results are bit-equal to any other order of the same integer sums (wide_pm_kernel, the row-major reference in the tests).
 #include "wide_common.h"
+#include "switches.h"
 #include <stdlib.h>
 
 #ifdef SDF_STAMP
@@ -465,14 +466,14 @@ constexpr int64_t SMALLM_MAX_ROWS = 64 * 80;
 // the convolution's own limit (SDF_SMALLM_CONV_ROWS: tuning override): 32 000 rows since round 5 - configs[4]'s bottleneck (24 000 rows x
 // 768 x 6 912) measured 146.9 -> 151.9 samples/s on this kernel against the streaming convolution + split-K it fell back to
 static int64_t smallm_conv_rows() {
-  if (const char* e = getenv("SDF_SMALLM_CONV_ROWS")) { const long v = atol(e); if (v >= 80) return v; }
+  if (const char* e = sdf_sw(SW_SMALLM_CONV_ROWS)) { const long v = atol(e); if (v >= 80) return v; }
   return 400 * 80;
 }
 
 bool smallm_conv_supports(const GemmParams& P) {
   const SdfSpikeGemmDesc& d = P.d;
   const ConvGeom& cv = P.cv;
-  if (const char* e = getenv("SDF_SMALLM")) { if (e[0] == '0') return false; }
+  if (const char* e = sdf_sw(SW_SMALLM)) { if (e[0] == '0') return false; }
   if ((d.nsplit != SDF_PLANES_I8X3 && d.nsplit != SDF_PLANES_I8X3_TILED) || !d.col_scale) return false;
   if (cv.KWc != 3 || d.K != 9 * cv.Cin || cv.Cin % 64 || cv.sy != 1 || cv.sx != 1 || cv.OH != cv.H || cv.OW != cv.W) return false;
   if (cv.dy[0] != -1 || cv.dy[1] != 0 || cv.dy[2] != 1 || cv.dx[0] != -1 || cv.dx[1] != 0 || cv.dx[2] != 1) return false;
@@ -518,7 +519,7 @@ int launch_smallm_conv(const GemmParams& G, hipStream_t s) {
   // 336 workgroups onto 168: with three forwards in flight the headline measured +0.9 % with the narrow tile (three alternating pairs
   // of runs on one box: 687.8 / 683.5 / 685.7 against 680.7 / 677.2 / 679.6 samples/s).  SDF_SMALLM_CB=3 selects the wide tile.
   int cb = 2;
-  if (const char* e = getenv("SDF_SMALLM_CB")) { if (bt && e[0] == '3' && d.N % 48 == 0) cb = 3; else if (e[0] == '2') cb = 2; }   // tuning override
+  if (const char* e = sdf_sw(SW_SMALLM_CB)) { if (bt && e[0] == '3' && d.N % 48 == 0) cb = 3; else if (e[0] == '2') cb = 2; }   // tuning override
   P.ncg = d.N / (16 * cb);
   const int64_t items = (int64_t)P.ncg * P.nunits;
   const dim3 grid((unsigned)((items + 7) / 8 * 8));
@@ -534,15 +535,15 @@ int launch_smallm_conv(const GemmParams& G, hipStream_t s) {
 // 20.1 -> 24.0 us at stage 2 (4 320 x 384 x 1 536: 648 tiles of 6 steps per wave - two rounds of mostly prologue and reduction), so the
 // form is taken while the tiles fit the chip in one round (<= 512).
 bool smallm_fc2_supports(const SdfMsMlpDesc* d) {
-  if (const char* e = getenv("SDF_SMALLM")) { if (e[0] == '0') return false; }
-  if (const char* e = getenv("SDF_SMALLM_FC2")) { if (e[0] == '0') return false; }
+  if (const char* e = sdf_sw(SW_SMALLM)) { if (e[0] == '0') return false; }
+  if (const char* e = sdf_sw(SW_SMALLM_FC2)) { if (e[0] == '0') return false; }
   if (!d->fc2_tiled || !d->fc2_cscale || (d->D != 10 && d->D != 20) || d->Ch % 64 || d->C % 32) return false;
   const int64_t tokens = (int64_t)d->B * d->D * d->HW;
   if (tokens > SMALLM_MAX_ROWS || tokens * d->Ch >= (1LL << 31) || tokens * d->C * 4 >= (1LL << 31) || (int64_t)d->C * d->Ch * 3 >= (1LL << 31)) return false;
   if (d->emit_next && !smallm_neuron_ok(d->emit_sn)) return false;
   {
     const int64_t ppw = 4 * (20 / d->D), units = ((int64_t)d->B * d->HW + ppw - 1) / ppw;
-    const char* e = getenv("SDF_SMALLM_FC2");
+    const char* e = sdf_sw(SW_SMALLM_FC2);
     if (units * (d->C / 32) > 512 && !(e && e[0] == '2')) return false;       // (SDF_SMALLM_FC2=2: at any size, tests / A/B)
   }
   return sdf_aligned(d->fc2_tiled, 16) && sdf_aligned(d->x, 16) && (!d->emit_next || sdf_aligned(d->emit_next, 16));
@@ -569,7 +570,7 @@ int launch_smallm_fc2(const SdfMsMlpDesc* d, const uint8_t* s2, hipStream_t s) {
 // decoder (reference Spiking_modules.py:461-474 as one GEMM, 1 080 rows x 3 456 columns x K = 1 536) and anything else of that shape
 bool smallm_gemm_supports(const GemmParams& P) {
   const SdfSpikeGemmDesc& d = P.d;
-  if (const char* e = getenv("SDF_SMALLM")) { if (e[0] == '0') return false; }
+  if (const char* e = sdf_sw(SW_SMALLM)) { if (e[0] == '0') return false; }
   if (d.nsplit != SDF_PLANES_I8X3_TILED || !d.col_scale || d.sn_T > 0 || !d.out) return false;
   if (d.K % 64 || d.K < 64 || d.N % 32 || d.lda != d.K || d.out_rowmap || d.add || d.zg_nH) return false;
   if (d.M % 10 || d.M > SMALLM_MAX_ROWS) return false;            // (rows are walked as 10 "steps" x M / 10 "positions": any order serves the fp32 form)
@@ -584,7 +585,7 @@ int launch_smallm_gemm(const GemmParams& G, hipStream_t s) {
   P.alpha = d.alpha; P.beta = d.beta; P.bias = d.bias; P.resid = d.resid; P.out = d.out; P.ldo = (int)d.ldo;
   P.nunits = (int)((P.P + 7) / 8);
   int cb = 2;                                                     // (as the convolution: the narrow tile packs two workgroups per compute unit)
-  if (const char* e = getenv("SDF_SMALLM_CB")) { if (e[0] == '3' && d.N % 48 == 0) cb = 3; else if (e[0] == '2') cb = 2; }   // tuning override
+  if (const char* e = sdf_sw(SW_SMALLM_CB)) { if (e[0] == '3' && d.N % 48 == 0) cb = 3; else if (e[0] == '2') cb = 2; }   // tuning override
   P.ncg = d.N / (16 * cb);
   const int64_t items = (int64_t)P.ncg * P.nunits;
   if (items >= (1LL << 31) - 8) return SDF_E_SHAPE;

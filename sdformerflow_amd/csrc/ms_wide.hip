@@ -33,6 +33,7 @@
 // one ds_write_b32 into a per-wave LDS tile and 16-byte global stores.  The fp32 shortcut is read and written in the accumulator
 // layout (64-byte runs per row and column block; the buffers are L2-resident at these sizes).
 #include "wide_common.h"
+#include "switches.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -769,7 +770,7 @@ int launch_pm_t(WidePmParams& P, int epi, hipStream_t s) {
   // epilogue (fc1) takes three where that still fills the chip
   static const int cbs[2] = {2, 3};
   int cb = pick_cb(units, P.N, cbs, epi == 1 ? 2 : 1);
-  if (const char* e = getenv("SDF_WIDE_CB")) {                     // tuning override (fc1): 2 / 3
+  if (const char* e = sdf_sw(SW_WIDE_CB)) {                     // tuning override (fc1): 2 / 3
     const int v = e[0] - '0';
     if (epi == 1 && (v == 2 || v == 3) && P.N % (16 * v) == 0) cb = v;
   }
@@ -781,7 +782,7 @@ int launch_pm_t(WidePmParams& P, int epi, hipStream_t s) {
   // workgroups that walk several row groups (the prologue is paid once, no second dispatch wave)
   const int64_t all = (int64_t)P.ncg * P.nrg;
   P.passes = all > 256 && all <= 1024 ? (int)((all + 255) / 256) : 1;
-  if (const char* e = getenv("SDF_WIDE_PASSES")) { const int v = atoi(e); if (v >= 1 && v <= 8) P.passes = v; }     // tuning override
+  if (const char* e = sdf_sw(SW_WIDE_PASSES)) { const int v = atoi(e); if (v >= 1 && v <= 8) P.passes = v; }     // tuning override
   const int64_t items = (int64_t)P.ncg * ((P.nrg + P.passes - 1) / P.passes);
   if (items >= (1LL << 31) - 8) return SDF_E_SHAPE;
   const dim3 grid((unsigned)((items + 7) / 8 * 8));
@@ -812,16 +813,16 @@ int launch_pm(WidePmParams& P, int T, int epi, hipStream_t s) {
 // WHOLE block back to the streaming kernels: configs[4] (96 000 rows at stage 2) 129.7 -> 143.4 samples/s with it lifted
 // (profiles/r5ao_config5_kernel_stats.txt, same box A/B).
 static int64_t wide_max_rows() {                      // (SDF_WIDE_MAXROWS: tuning override)
-  if (const char* e = getenv("SDF_WIDE_MAXROWS")) { const long v = atol(e); if (v >= 80) return v; }
+  if (const char* e = sdf_sw(SW_WIDE_MAXROWS)) { const long v = atol(e); if (v >= 80) return v; }
   return 131072;
 }
 #define WIDE_MAX_ROWS wide_max_rows()
 bool wide_env_any() {
-  const char* e = getenv("SDF_WIDE");
+  const char* e = sdf_sw(SW_WIDE);
   return e && e[0] == '2';
 }
 bool wide_env_off() {
-  const char* e = getenv("SDF_WIDE");
+  const char* e = sdf_sw(SW_WIDE);
   return e && e[0] == '0';
 }
 // narrow stages (C <= 192: swin stages 0 - 1): the weight-resident row-loop kernels of ms_res.hip (SDF_RES=0: off - A/B)
@@ -833,15 +834,15 @@ bool wide_env_off() {
 // spike_gemm + ms_mlp_fused alone and equal in flight (754 - 758): it keeps round 3's kernels (lower latency); SDF_RES_MINC lowers the
 // bound (tests, A/B).  Units per wave beyond what fills the chip once (SDF_RES_RMUL = 2, 3) trade latency for nothing (753, 711 - 723).
 int res_minc() {
-  if (const char* e = getenv("SDF_RES_MINC")) { const int v = atoi(e); if (v >= 32 && v <= 192) return v; }
+  if (const char* e = sdf_sw(SW_RES_MINC)) { const int v = atoi(e); if (v >= 32 && v <= 192) return v; }
   return 128;
 }
 int res_maxc() {                                         // (SDF_RES_MAXC: tuning override - K = C <= 768 fits the resident image)
-  if (const char* e = getenv("SDF_RES_MAXC")) { const int v = atoi(e); if (v >= 32 && v <= 768) return v; }
+  if (const char* e = sdf_sw(SW_RES_MAXC)) { const int v = atoi(e); if (v >= 32 && v <= 768) return v; }
   return 768;
 }
 bool res_stage_ok(int C, bool merge = false) {
-  const char* e = getenv("SDF_RES");
+  const char* e = sdf_sw(SW_RES);
   if ((e && e[0] == '0') || C < 64 || C % 32) return false;
   // (the merge of a 192-channel stage, K = 768: 24.6 us on 88 compute units against 16.1 us on 168 with the K-ring kernel - slower alone,
   //  less chip time with three forwards in flight; K = 4 C <= 1024 is what the resident image admits)
@@ -1023,7 +1024,7 @@ bool wide_conv_supports(const GemmParams& P) {
   // the pipeline fill; the reduce pass is latency-bound on 81 workgroups), so the engine does not take it: SDF_WIDE_CONV=1 opts in
   // (tests, A/B).
   {
-    const char* e = getenv("SDF_WIDE_CONV");
+    const char* e = sdf_sw(SW_WIDE_CONV);
     if (!(e && e[0] == '1')) return false;
   }
   if (d.nsplit != SDF_PLANES_I8X3 || !d.col_scale) return false;

@@ -10,6 +10,7 @@
 //                          GEMM reading through the head scramble, bias + BN + scatter + residual in its epilogue.
 // The intermediates (three u8 spike tensors) live in the caller's workspace; nothing is allocated here.
 #include "spike_mm.h"
+#include "switches.h"
 #include <stdlib.h>
 
 namespace {
@@ -109,7 +110,7 @@ extern "C" int sdf_qk_attn_fwd(const SdfQkAttnDesc* d, void* stream) {
   // steps 1 - 3 as one launch where the kernel has an instantiation (SDF_QK_FRONT=0 / SDF_QK_FOUR_LAUNCHES: the A/B reference below)
   bool front = false;
   {
-    const char* e_front = getenv("SDF_QK_FRONT");                    // (read per call, like SDF_MLP_FUSED)
+    const char* e_front = sdf_sw(SW_QK_FRONT);                    // (read per call, like SDF_MLP_FUSED)
     const bool off = e_front && e_front[0] == '0';
     if (!off && !(d->flags & SDF_QK_FOUR_LAUNCHES) && sdfmm::qk_front_supports(d)) {
       const int rc0 = sdfmm::launch_qk_front(d, xs, qk, (d->flags & SDF_QK_KEEP_SPIKES) != 0, sdf_stream(stream));
@@ -206,7 +207,7 @@ extern "C" int sdf_ms_mlp_fwd(const SdfMsMlpDesc* d, void* stream) {
   if (d->s1_in || d->emit_next) return SDF_E_SHAPE;            // wide-stage inputs / outputs
   // one launch where the kernel has an instantiation (SDF_MLP_FUSED=0 / SDF_MLP_THREE_LAUNCHES: the A/B reference below)
   {
-    const char* e = getenv("SDF_MLP_FUSED");
+    const char* e = sdf_sw(SW_MLP_FUSED);
     if (!(d->flags & SDF_MLP_THREE_LAUNCHES) && !(e && e[0] == '0') && sdfmm::ms_mlp_fused_supports(d)) {
       const bool keep = (d->flags & SDF_MLP_KEEP_SPIKES) != 0;
       return sdfmm::launch_ms_mlp_fused(d, keep ? s1 : nullptr, keep ? s2 : nullptr, sdf_stream(stream));

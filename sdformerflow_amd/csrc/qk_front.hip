@@ -22,6 +22,7 @@
 // The second half (projection through the head scramble + BN + scatter + shortcut) reads E exactly as before.
 // Compiled with -ffp-contract=off (the neuron arithmetic is the separately-rounded op sequence of neuron.hip).
 #include "spike_mm.h"
+#include "switches.h"
 #include <stdlib.h>
 
 namespace sdfmm {
@@ -273,7 +274,7 @@ bool qk_front_supports(const SdfQkAttnDesc* d) {
   // chunks on (C >= 288: few pairs, every head's workgroup repeats the pair's SN_proj, a chain of chunk latencies per workgroup)
   // the three pipelined launches are as fast or faster (stage 2: 32 vs 32 us, stage 3: 33 vs 55 us) and stay.  SDF_QK_FRONT_ANY=1
   // lifts the limit (tests).
-  const char* e_any = getenv("SDF_QK_FRONT_ANY");                     // (read per call: a test may scope it)
+  const char* e_any = sdf_sw(SW_QK_FRONT_ANY);                     // (read per call: a test may scope it)
   const bool any = e_any && e_any[0] == '1';
   if (!any && d->C / QF_KC > 2) return false;
   const SdfNeuronCfg* ns[4] = {&d->sn_proj, &d->sn_q, &d->sn_k, &d->sn2_q};

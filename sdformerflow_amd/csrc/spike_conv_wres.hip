@@ -30,6 +30,7 @@
 // distinct bank quads).
 // Compiled with -ffp-contract=off (the neuron arithmetic is the separately-rounded op sequence of neuron.hip).
 #include "spike_mm.h"
+#include "switches.h"
 
 #ifdef SDF_STAMP
 // diagnostic build only (tools/stamp_wres.sh): cycle accounting of wave 0 of each group of workgroup 0
@@ -901,7 +902,7 @@ int launch_spike_conv_wres(const GemmParams& Pin, hipStream_t s) {
   int th = TH;
   if (d.nsplit == SDF_PLANES_I8X3) {
     const int64_t items16 = (imgs / T) * ((c.OH + 15) / 16) * ((c.OW + TW - 1) / TW) * (d.N / NB);
-    const char* erb = getenv("SDF_CONV_WRES_RB");                     // tuning override
+    const char* erb = sdf_sw(SW_CONV_WRES_RB);                     // tuning override
     th = (c.sy == 1 && (erb ? erb[0] == '2' : items16 >= 2048)) ? 16 : 8;
   }
   P.tiles_m = (int)((imgs / T) * ((c.OH + th - 1) / th) * ((c.OW + TW - 1) / TW));   // fused: imgs / T = pos_count / (OH*OW) batch elements
@@ -916,13 +917,13 @@ int launch_spike_conv_wres(const GemmParams& Pin, hipStream_t s) {
       // a workgroup's wave groups take its items in turn: give every workgroup a whole number of items per group and size the
       // grid for equal rounds (648 fused items, 3 groups: 216 workgroups x 3 items instead of 256 of which 120 leave a group
       // idle) - same duration, and the compute units this launch does not need go to the other in-flight forwards' kernels
-      const char* eg0 = getenv("SDF_CONV_WRES_GROUPS");
+      const char* eg0 = sdf_sw(SW_CONV_WRES_GROUPS);
       const int ng = (d.sn_T > 0 && th == 8 && (eg0 ? eg0[0] == '3' : true)) ? 3 : 2;
       const int rounds = (P.ntiles + 256 * ng - 1) / (256 * ng), per = ng * rounds;
       if (P.ntiles >= 64) G = (P.ntiles + per - 1) / per;
       // column blocks of a tile range side by side on one XCD (see the kernel): the grid becomes a multiple of 8 * tiles_n, or of
       // tiles_n with every workgroup's share still `per` items
-      static const bool cbi = [] { const char* e = getenv("SDF_CONV_WRES_CB_INNER"); return !e || e[0] != '0'; }();
+      const bool cbi = [] { const char* e = sdf_sw(SW_CONV_WRES_CB_INNER); return !e || e[0] != '0'; }();
       if (cbi && P.ntiles >= 64) {
         int nr = (P.tiles_m + per - 1) / per;                           // tile ranges of at most `per` items ...
         while (nr * P.tiles_n <= 256 && (nr * P.tiles_n) % 8) ++nr;     // ... a few more of them where that makes the grid a multiple of 8
@@ -933,7 +934,7 @@ int launch_spike_conv_wres(const GemmParams& Pin, hipStream_t s) {
     // fused-neuron items are T steps long and their epilogue (neuron + two stores) outweighs their MFMAs: with few of them
     // (batch 1: 648 on this shape) THREE groups of waves per workgroup - 768 slots, one item each, the matrix pipe shared
     // three ways - instead of two groups with one or two items each
-    const char* eg = getenv("SDF_CONV_WRES_GROUPS");                   // tuning override: 2 or 3
+    const char* eg = sdf_sw(SW_CONV_WRES_GROUPS);                   // tuning override: 2 or 3
     const bool g3 = d.sn_T > 0 && th == 8 && (eg ? eg[0] == '3' : true);
     const dim3 grid((unsigned)G);
     if (c.sy == 2 && c.Cin == 96) {
@@ -946,7 +947,7 @@ int launch_spike_conv_wres(const GemmParams& Pin, hipStream_t s) {
     if (d.sn_T == 0 && th == 16) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 6, 2, 2>), grid, dim3(512), 0, s, P, d.col_scale);
     else if (d.sn_T == 0) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 6, 1, 2>), grid, dim3(512), 0, s, P, d.col_scale);
     else if (th == 16) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 2, 2>), grid, dim3(512), 0, s, P, d.col_scale);
-    else if (g3 && !d.out && !d.resid && !getenv("SDF_CONV_WRES_NOSPK"))
+    else if (g3 && !d.out && !d.resid && !sdf_sw(SW_CONV_WRES_NOSPK))
       hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 1, 3, false, 1, true>), grid, dim3(768), 0, s, P, d.col_scale);
     else if (g3) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 1, 3>), grid, dim3(768), 0, s, P, d.col_scale);
     else hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 1, 2>), grid, dim3(512), 0, s, P, d.col_scale);

@@ -25,6 +25,7 @@
 //     are sized by a tile's cost in that class so that all workgroups finish together.
 // Compiled with -ffp-contract=off.
 #include "spike_mm.h"
+#include "switches.h"
 #include "wide_common.h"
 #include <type_traits>
 
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(NT) void spike_deconv_wres_kernel(DeconvParams P) {
 }  // namespace
 
 bool spike_deconv_wres_supports(int imgs, int H, int W, int Cin, int Cout) {
-  const char* e = getenv("SDF_DECONV_WRES");                   // A/B: 0 = the row-loop kernel's form (ms_res.hip)
+  const char* e = sdf_sw(SW_DECONV_WRES);                   // A/B: 0 = the row-loop kernel's form (ms_res.hip)
   if (e && e[0] == '0') return false;
   if (Cin != CIN || Cout < 8 || Cout % 4 || (4 * Cout) % 4) return false;
   const int64_t rows = (int64_t)imgs * H * W;
@@ -337,13 +338,13 @@ int launch_spike_deconv_wres(const uint8_t* A, const int8_t* Wd, const float* cs
   P.tiles_n = (P.N + NB - 1) / NB;
   P.ntiles = P.tiles_m * P.tiles_n;
   int grid;
-  const char* eb = getenv("SDF_DECONV_BALANCE");           // A/B: 0 = every column block multiplies all four quadrants
+  const char* eb = sdf_sw(SW_DECONV_BALANCE);           // A/B: 0 = every column block multiplies all four quadrants
   if (Cout % NB == 0 && P.tiles_m >= 64 && !(eb && eb[0] == '0')) {
     // class-balanced: ranges per class in proportion to a tile's cost in that class - its K steps plus the part every tile pays (halo,
     // epilogue, stores: 16 K steps' worth measured best; SDF_DECONV_EPI: tuning override) - 250 - 256 workgroups in all
     const int cbc = Cout / NB, budget = 256 / cbc;
     int epi = 16;
-    if (const char* e = getenv("SDF_DECONV_EPI")) { const int v = atoi(e); if (v >= 0 && v <= 100) epi = v; }
+    if (const char* e = sdf_sw(SW_DECONV_EPI)) { const int v = atoi(e); if (v >= 0 && v <= 100) epi = v; }
     int tot = 0, nrc[4];
     for (int c = 0; c < 4; ++c) tot += cls_nsteps(c) + epi;
     int used = 0;
@@ -368,12 +369,8 @@ int launch_spike_deconv_wres(const uint8_t* A, const int8_t* Wd, const float* cs
     for (int c = 0; c < 5; ++c) P.cls_start[c] = 0;
     grid = nr * P.tiles_n;
   }
-  static bool raised = false;
-  if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spike_deconv_wres_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    raised = true;
-  }
+  static std::atomic<uint64_t> raised{0};                  // > 64 KiB of dynamic LDS: opt-in once per device
+  if (const int e = sdf_lds_opt_in(raised, reinterpret_cast<const void*>(spike_deconv_wres_kernel), LDS_BYTES)) return e;
   hipLaunchKernelGGL(spike_deconv_wres_kernel, dim3((unsigned)grid), dim3(NT), LDS_BYTES, s, P);
   hipError_t e = hipGetLastError();
   return e != hipSuccess ? (int)e : 0;

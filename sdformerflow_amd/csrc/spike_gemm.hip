@@ -24,6 +24,7 @@
 //           fp32 pre-activation never touches HBM.  Spikes are staged through LDS to leave as 16-byte stores.
 // Compiled with -ffp-contract=off: the neuron arithmetic is the same separately-rounded op sequence as neuron.hip.
 #include "wide_common.h"
+#include "switches.h"
 #include <stdlib.h>
 
 namespace {
@@ -526,23 +527,21 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
     cfg = r2 <= r3 ? 2 : 3;
   }
   if (!ok(cfg)) cfg = ok(2) ? 2 : 0;
-  if (const char* e = getenv("SDF_GEMM_CFG")) {                  // tuning override: 0..3
+  if (const char* e = sdf_sw(SW_GEMM_CFG)) {                  // tuning override: 0..3
     const int c = e[0] - '0';
     if (c >= 0 && c < 4 && ok(c)) cfg = c;
   }
   // Ping-pong 256 x 96 kernel (spike_mm_pp.hip) where it measured faster than the small-tile kernel on the model's
   // layers (tools/gemm_shapes.py, profiles/r1_gemm_shapes.txt): the fused T = 10 neuron epilogue (the MLP's fc1 - long
   // epilogues that the other consumer group hides) and fp32 epilogues with a long K loop over many rows, a very
-  // long one, or many column tiles per row tile (the decoders' stacked tap matrices).  SDF_GEMM_WS: 0 = never, 2 = whenever legal, 1 = the barrier-synchronised predecessor (spike_mm_ws.hip).
+  // long one, or many column tiles per row tile (the decoders' stacked tap matrices).  SDF_GEMM_WS: 0 = never, 2 = whenever legal.
   {
-    const char* e = getenv("SDF_GEMM_WS");
+    const char* e = sdf_sw(SW_GEMM_WS);
     const bool legal = d->N % 96 == 0 && spike_mm_pp_supports(P, false);
     bool use_pp = legal && ((spike && (d->sn_T == 10 || d->sn_T == 20)) ||
                            (!spike && ((d->K >= 384 && d->M >= 32768) || d->K >= 2048 || (d->K >= 384 && d->N >= 864))));
     if (e && e[0] == '0') use_pp = false;
     if (e && e[0] == '2') use_pp = legal;
-    if (e && e[0] == '1' && d->N % 96 == 0 && d->nsplit != 2 && (d->sn_T == 0 || d->sn_T == 2 || d->sn_T == 10))
-      return launch_spike_mm_ws(P, false, sdf_stream(stream));
     if (use_pp) return launch_spike_mm_pp(P, false, sdf_stream(stream));
   }
   if (!ok(cfg)) return SDF_E_SHAPE;
@@ -554,7 +553,7 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
   P.ntiles = P.tiles_m * P.tiles_n;
   const size_t lds = (size_t)32 * rb * waves * A_LD + (size_t)d->nsplit * 32 * nb * W_LD * 2;
   int wg_per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);   // more resident workgroups measured no faster (profiles/r1_gemm_shapes.txt)
-  if (const char* e = getenv("SDF_GEMM_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 8) wg_per_cu = v; }   // tuning override
+  if (const char* e = sdf_sw(SW_GEMM_WGS)) { const int v = atoi(e); if (v >= 1 && v <= 8) wg_per_cu = v; }   // tuning override
   const int G = P.ntiles < 256 * wg_per_cu ? P.ntiles : 256 * wg_per_cu;
   dim3 grid((unsigned)G);
   hipStream_t s = sdf_stream(stream);
@@ -648,16 +647,15 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
   if (i8x3 && smallm_conv_supports(P)) return launch_smallm_conv(P, sdf_stream(stream));
   if (tiled) return SDF_E_SHAPE;
   // 3x3 / stride 1 on 96 channels with enough tiles to fill the chip: weights resident in LDS, halo tiles instead of im2col
-  const char* ewr = getenv("SDF_CONV_WRES");                  // A/B override: 0 = always the streaming kernels below, 2 = at any size
+  const char* ewr = sdf_sw(SW_CONV_WRES);                  // A/B override: 0 = always the streaming kernels below, 2 = at any size
   if (!(ewr && ewr[0] == '0') && spike_conv_wres_supports(P, i8x3 || (ewr && ewr[0] == '2'))) return launch_spike_conv_wres(P, sdf_stream(stream));
   if (i8x3) return SDF_E_SHAPE;                                 // digit planes have no streaming-kernel form: the caller packs per shape
   // 256 x 96 tiles, producer waves do the im2col addressing; the ping-pong kernel overlaps epilogues with the MFMAs
-  const char* e = getenv("SDF_CONV_PP");                      // tuning override: 0 = barrier-synchronised kernel
-  if (spike_mm_pp_supports(P, true) && !(e && e[0] == '0')) return launch_spike_mm_pp(P, true, sdf_stream(stream));
+  if (spike_mm_pp_supports(P, true)) return launch_spike_mm_pp(P, true, sdf_stream(stream));
   // operands beyond the kernel's 31-bit buffer offsets (e.g. 80 images of 240 x 320 x 96 fp32 out): images are
   // independent, so the fp32 epilogue form is launched in image chunks that fit
   const int64_t imgs = d->M / ((int64_t)c->OH * c->OW);
-  if (!spike && imgs > 1 && !(e && e[0] == '0')) {
+  if (!spike && imgs > 1) {
     for (int64_t nch = 2; nch <= imgs; ++nch) {
       const int64_t per = (imgs + nch - 1) / nch;
       GemmParams Q = P;
@@ -680,9 +678,7 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
       return 0;
     }
   }
-  if (d->N % 96) return SDF_E_SHAPE;                              // the streaming kernels work on 96-column blocks
-  if (d->nsplit == 2 || (spike && d->out)) return SDF_E_DTYPE;   // only the ping-pong kernel has these
-  return launch_spike_mm_ws(P, true, sdf_stream(stream));
+  return SDF_E_SHAPE;                                           // no streaming-kernel form of this problem (round 6: the barrier-synchronised predecessor of the ping-pong kernel is gone)
 }
 
 // n convolutions on the same images that differ only in taps / weights / output row map (the four output-parity classes of a
@@ -690,16 +686,15 @@ extern "C" int sdf_spike_conv2d_fwd(const SdfSpikeConvDesc* c, void* stream) {
 extern "C" int sdf_spike_conv2d_multi_fwd(const SdfSpikeConvDesc* cs, int n, void* stream) {
   if (!cs) return SDF_E_NULL;
   if (n < 1) return SDF_E_SHAPE;
-  const char* epp = getenv("SDF_CONV_PP");
-  const char* emu = getenv("SDF_CONV_MULTI");                 // A/B override: 0 = one launch per convolution
-  if (n >= 2 && n <= 4 && !(epp && epp[0] == '0') && !(emu && emu[0] == '0')) {
+  const char* emu = sdf_sw(SW_CONV_MULTI);                 // A/B override: 0 = one launch per convolution
+  if (n >= 2 && n <= 4 && !(emu && emu[0] == '0')) {
     GemmParams Ps[4];
     bool one = true;
     for (int i = 0; i < n; ++i) {
       bool i8x3 = false, tiled = false;
       const int rc = conv2d_build(cs + i, Ps[i], i8x3, tiled);
       if (rc) return rc;
-      const char* ewr = getenv("SDF_CONV_WRES");
+      const char* ewr = sdf_sw(SW_CONV_WRES);
       const bool wres = !(ewr && ewr[0] == '0') && spike_conv_wres_supports(Ps[i], i8x3 || (ewr && ewr[0] == '2'));
       one = one && !i8x3 && cs[i].g.sn_T == 0 && !wres && spike_mm_pp_supports(Ps[i], true);
     }

@@ -1,4 +1,4 @@
-// Shared definitions of the spike matrix-multiply kernels (spike_gemm.hip, spike_mm_ws.hip).
+// Shared definitions of the spike matrix-multiply kernels (spike_gemm.hip, spike_mm_pp.hip, spike_splitk.hip).
 #pragma once
 #include "common.h"
 #include <math.h>
@@ -251,8 +251,6 @@ __device__ __forceinline__ void quad_transpose(float (&v)[4], int q) {
   }
 }
 
-// warp-specialised kernel (spike_mm_ws.hip): 256 x 96 tiles, N % 96 == 0; returns 0 or an SDF_E_* / hipError code
-int launch_spike_mm_ws(const GemmParams& P, bool conv, hipStream_t s);
 // ping-pong kernel, several convolutions of one family (same images / output / epilogue, own taps, weights, row map) in one launch;
 // SDF_E_SHAPE when they are not one family or any of them wants split-K
 int launch_spike_mm_pp_multi(const GemmParams* Ps, int n, hipStream_t s);

@@ -15,7 +15,7 @@
 // waves of the owning group bump `empty` after their last read), and the waiting side polls.  So while one group
 // runs the epilogue of its tile (BN / residual / neuron, global loads and stores - long and latency-bound), the
 // other group is already multiplying the next tile: the matrix pipe of every SIMD stays fed across epilogues, which
-// the barrier-synchronised kernel (spike_mm_ws.hip) cannot do.
+// a barrier-synchronised kernel (rounds 1 - 5: spike_mm_ws.hip, deleted in round 6) cannot do.
 //
 // Weights: NSPLIT = 2 -> two fp16 planes of wscale * W (hi + lo = 22 significant bits; wscale is a power of two
 // that places the largest |w| just under the fp16 range, the accumulator is multiplied by 1 / wscale - exact -
@@ -30,6 +30,7 @@
 // LDS rows are padded (A 18-dword stride for ds_read_b64, W 36-dword stride for ds_read_b128): conflict-free.
 // Compiled with -ffp-contract=off (the neuron arithmetic is the separately-rounded op sequence of neuron.hip).
 #include "spike_mm.h"
+#include "switches.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -683,7 +684,7 @@ int launch_t(const GemmParams& P, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
-// true when the ping-pong kernel has an instantiation for this problem (the caller falls back to spike_mm_ws)
+// true when the ping-pong kernel has an instantiation for this problem (the caller refuses the shape otherwise)
 bool spike_mm_pp_supports(const GemmParams& P, bool conv) {
   const SdfSpikeGemmDesc& d = P.d;
   if (d.N % BN) return false;
@@ -722,7 +723,7 @@ static int pp_plan(GemmParams& P) {
   // same duration, and the other in-flight forwards' kernels get the compute units this launch does not need
   // A workgroup's two consumer groups alternate items, so a workgroup wants an EVEN number of items: with one item per workgroup
   // half of its matrix-pipe time is idle.  SDF_PP_PAIR=0: the round-2 rule (one item per workgroup up to 256 workgroups).
-  static const bool pair = !(getenv("SDF_PP_PAIR") && getenv("SDF_PP_PAIR")[0] == '0');
+  const bool pair = !(sdf_sw(SW_PP_PAIR) && sdf_sw(SW_PP_PAIR)[0] == '0');
   int G;
   if (pair && nitems >= 16) {
     const int rounds = (nitems + 511) / 512;                     // items per workgroup = 2 * rounds

@@ -17,6 +17,7 @@
 // registers and across the 4 lane groups with two DPP-free shuffles.  Bias and mask are read as float4
 // (4 consecutive keys) from L2-resident tables.
 #include "common.h"
+#include "switches.h"
 
 namespace {
 
@@ -880,10 +881,10 @@ extern "C" int sdf_win_attn_fwd(const SdfWinAttnDesc* d, void* stream) {
   dim3 grid((unsigned)(d->B_ * d->nH)), block(256);
   hipStream_t s = sdf_stream(stream);
   // even N that fits a compiled tile count: the MFMA-paced kernel (8-byte bias / mask loads need N % 2 == 0)
-  const char* ge = getenv("SDF_ATTN_GENERIC");                 // A/B override: 1 = always the general kernel
+  const char* ge = sdf_sw(SW_ATTN_GENERIC);                 // A/B override: 1 = always the general kernel
   if (d->N % 2 == 0 && (int64_t)d->N * d->N * 4 < (1LL << 31) && !(ge && ge[0] == '1')) {
     const int nt = (d->N + 15) / 16;                         // compiled tile counts: windows (2,8,8) and (2,9,9)
-    const char* f32 = getenv("SDF_ATTN_F32");                // A/B override: 1 = the fp32-pipe kernels
+    const char* f32 = sdf_sw(SW_ATTN_F32);                // A/B override: 1 = the fp32-pipe kernels
     // (the 16-bit-pipe kernels address the output and the row map with 32-bit byte offsets)
     const bool pipe16 = !(f32 && f32[0] == '1') && (int64_t)d->B_ * d->N * d->nH * HD * 4 < (1LL << 31);
     if (d->mode == SDF_ATTN_ANN) {
@@ -898,16 +899,9 @@ extern "C" int sdf_win_attn_fwd(const SdfWinAttnDesc* d, void* stream) {
       if (nt == 11) return launch_tiled<SDF_ATTN_SEW, 11>(P, s);
     }
   }
-  static bool lds_opt_in = false;       // > 64 KiB of dynamic LDS needs a one-time opt-in (read-only afterwards)
-  if (!lds_opt_in) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn_kernel<SDF_ATTN_ANN>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 16 * NT_MAX * LDW * 4);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn_kernel<SDF_ATTN_SEW>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 16 * NT_MAX * LDW * 4);
-    if (e1 != hipSuccess) return (int)e1;
-    if (e2 != hipSuccess) return (int)e2;
-    lds_opt_in = true;
-  }
+  static std::atomic<uint64_t> opt_ann{0}, opt_sew{0};      // > 64 KiB of dynamic LDS: opt-in once per kernel and device
+  if (const int e1 = sdf_lds_opt_in(opt_ann, reinterpret_cast<const void*>(win_attn_kernel<SDF_ATTN_ANN>), 3 * 16 * NT_MAX * LDW * 4)) return e1;
+  if (const int e2 = sdf_lds_opt_in(opt_sew, reinterpret_cast<const void*>(win_attn_kernel<SDF_ATTN_SEW>), 3 * 16 * NT_MAX * LDW * 4)) return e2;
   if (d->mode == SDF_ATTN_ANN) {
     hipLaunchKernelGGL(win_attn_kernel<SDF_ATTN_ANN>, grid, block, lds, s, P);
   } else {

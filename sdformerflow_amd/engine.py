@@ -320,10 +320,18 @@ class MSFlowEngine:
                                  pos=(B * oh * ow, oh * ow, D * oh * ow, oh * ow))
                 return sp if sn is not None and not membrane else ((out, sp) if sn is not None else out)
             except hip.SdfError as e:
-                # the Python mirror `smallm_conv_applicable` admits a shape the library's own rule refuses (alignment, 31-bit sizes, an
-                # unusual tau: ADVICE r4): the 16-bit planes are still here - the general path below serves it
-                if "argument error -2" not in str(e):
+                # the Python mirror `smallm_conv_applicable` admits a shape the library's own rule refuses (size / alignment, 31-bit sizes,
+                # an unusual tau: ADVICE r4 / r5): the 16-bit planes are still here - the general path below serves it
+                if e.rc not in (hip.E_SHAPE, hip.E_ALIGN):
                     raise
+                if sn is not None and sn.kind == "psn":
+                    # a PSN res-block was sent here because the small-M kernel fuses its neuron; refused, it runs as the fp32
+                    # convolution (streaming kernels, 16-bit planes) + the neuron kernel, not on the streaming kernels' fused epilogue
+                    m = torch.empty((B, D, oh, ow, Cout), dtype=torch.float32, device=s.device)
+                    hip.spike_conv2d(s, Wp, B * D, h, w, Cin, oh, ow, 3, 3, stride, (-1, 0, 1), (-1, 0, 1), out=m, alpha=a, beta=b,
+                                     resid=resid if membrane else None)
+                    sp = self._neuron_bd(m, sn)
+                    return (m, sp) if membrane else sp
         if digits is not None and B > 1 and not hip.conv_wres_applicable(B * D, h, w, Cin, Cout, stride, 1):
             # too large for the digit kernel's 31-bit operand offsets as one launch (configs[4]: 80 images of 240 x 320 x 96 fp32):
             # batch elements are independent - the largest batch chunk that fits runs per launch, writing into its slice of the outputs

@@ -189,7 +189,7 @@ class SEWFlowEngine(MSFlowEngine):
             raise hip.SdfError(f"SEW family: gemm_nsplit = {self.nsplit} is not built for the res-block convolution on the integer stream "
                                "(bf16 planes expand spikes {0, 1} only); use the default gemm_nsplit = 2")
         xu = x.to(torch.uint8)
-        if os.environ.get("SDF_DEBUG_CHECKS", "") == "1" and not (torch.equal(xu.float(), x) and int(xu.max()) < 128):
+        if hip.sw("SDF_DEBUG_CHECKS", "") == "1" and not (torch.equal(xu.float(), x) and int(xu.max()) < 128):
             raise hip.SdfError("the SEW stream in front of a res-block is not a sum of spike tensors (a model with a single swin "
                                "stage feeds the real-valued patch embedding here)")
         return xu

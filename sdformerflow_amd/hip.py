@@ -20,7 +20,7 @@ SDF_F32, SDF_U8 = 0, 1
 SDF_LIF, SDF_PSN, SDF_IF = 0, 1, 2
 KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
 
-EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
+EXPORTS = ("sdf_version", "sdf_switches_reload", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
            "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_ann_attn_block_fwd", "sdf_ann_attn_block_supported", "sdf_ann_mlp_block_fwd", "sdf_ann_mlp_block_supported", "sdf_spike_conv2d_fwd", "sdf_spike_deconv3x3s2_fwd", "sdf_head_conv_sn_fwd",
            "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes",
            "sdf_window_slice_map", "sdf_window_zsrc_map", "sdf_qk_attn_fwd", "sdf_qk_attn_is_wide", "sdf_ms_mlp_is_wide", "sdf_ms_patch_merge_fwd", "sdf_tile_weight_i8x3", "sdf_spike_conv2d_multi_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
@@ -32,7 +32,56 @@ EXPORTS = ("sdf_version", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_s
 
 
 class SdfError(RuntimeError):
-    pass
+    """`rc` = the C ABI's return code when the error came from an entry point (negative: SDF_E_* argument refusal before any launch,
+    positive: hipError_t), else None."""
+
+    def __init__(self, msg, rc=None):
+        super().__init__(msg)
+        self.rc = rc
+
+
+# The diagnostic SDF_* switches (INTEGRATION.md, appendix) are read ONCE - at import here, at the first call that asks for one in the
+# library (csrc/switches.hip) - not per call.  A harness that changes the environment afterwards says so: reload_switches().
+_SW = {k: v for k, v in os.environ.items() if k.startswith("SDF_")}
+
+
+def sw(name, default=None):
+    """Value of the switch SDF_<...> as of import / the last reload_switches() (a drop-in for os.environ.get)."""
+    return _SW.get(name, default)
+
+
+def reload_switches():
+    """Re-read every SDF_* switch from the environment, on both sides of the C ABI (tests/conftest.py calls it around setenv)."""
+    _SW.clear()
+    _SW.update({k: v for k, v in os.environ.items() if k.startswith("SDF_")})
+    if _lib is not None:
+        _lib.sdf_switches_reload()
+
+
+class scoped_switches:
+    """`with hip.scoped_switches(SDF_CONV_WRES="0"):` - set (value None: unset) diagnostic switches for a block of calls and restore
+    them afterwards, refreshing the tables both times (A/B legs of tests and tools)."""
+
+    def __init__(self, **kw):
+        self._kw = kw
+
+    def __enter__(self):
+        self._old = {k: os.environ.get(k) for k in self._kw}
+        for k, v in self._kw.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        reload_switches()
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self._old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        reload_switches()
 
 
 class NeuronDesc(C.Structure):
@@ -194,7 +243,8 @@ def lib():
                            "(sdformerflow_amd/csrc/build.sh); there is no CPU fallback")
         _lib = C.CDLL(LIB_PATH)
         _lib.sdf_version.restype = C.c_int
-        for name in EXPORTS[1:]:
+        _lib.sdf_switches_reload.restype = None
+        for name in EXPORTS[2:]:
             getattr(_lib, name).restype = C.c_int
         _lib.sdf_psn_bwd_workspace_bytes.restype = C.c_int64
         _lib.sdf_qk_attn_workspace_bytes.restype = C.c_int64
@@ -204,13 +254,13 @@ def lib():
     return _lib
 
 
-E_NULL, E_SHAPE = -1, -2          # include/sdformerflow_hip.h: SDF_E_NULL, SDF_E_SHAPE
+E_NULL, E_SHAPE, E_DTYPE, E_ALIGN = -1, -2, -3, -4          # include/sdformerflow_hip.h: SDF_E_*
 
 
 def _check(rc, what):
     if rc != 0:
         kind = "argument error" if rc < 0 else "hipError_t"
-        raise SdfError(f"{what} failed: {kind} {rc}")
+        raise SdfError(f"{what} failed: {kind} {rc}", rc=rc)
 
 
 def _ptr(t, dtype=None):
@@ -414,7 +464,7 @@ def conv_wres_applicable(imgs, H, W, Cin, Cout, stride, T=1):
     stride 1 or - digit planes only - at stride 2 on 48 (the patch embedding's first 3x3) or 96 channels (its projection), output columns in blocks of 32, and enough
     8 x 16 pixel OUTPUT tiles (x T steps each when the neuron is fused) to give every half workgroup of the chip work - below that
     the streaming kernels' split-K wins.  H, W: the input image."""
-    if os.environ.get("SDF_CONV_WRES", "") == "0":             # the library's A/B override: always the streaming kernels (which
+    if sw("SDF_CONV_WRES", "") == "0":             # the library's A/B override: always the streaming kernels (which
         return False                                             # do not read digit planes: the caller must keep its 16-bit planes)
     if (Cin, stride) not in ((96, 1), (48, 2), (96, 2)) or Cout % 32 or ((Cin, stride) == (96, 2) and T != 1):
         return False                                             # (96 channels at stride 2: two channel passes, fp32 epilogue only)
@@ -428,17 +478,17 @@ def conv_wres_applicable(imgs, H, W, Cin, Cout, stride, T=1):
 def wide_conv_applicable(imgs, H, W, Cin, Cout, stride, T):
     """Mirror of the library's dispatch rule for the small-M digit convolution (csrc/ms_wide.hip: wide_conv_supports): 3x3 / stride 1
     on Cin % 128 == 0 channels, at most 131 072 output rows (SDF_WIDE_MAXROWS) in (B, T, H, W) order with T in {10, 20}."""
-    if os.environ.get("SDF_WIDE", "") == "0" or os.environ.get("SDF_WIDE_CONV", "") != "1" or stride != 1 or Cin % 128 or Cout % 32:
+    if sw("SDF_WIDE", "") == "0" or sw("SDF_WIDE_CONV", "") != "1" or stride != 1 or Cin % 128 or Cout % 32:
         return False                                             # (opt-in: measured no faster than the streaming kernel + split-K, DESIGN.md)
-    return T in (10, 20) and imgs % T == 0 and imgs * H * W <= int(os.environ.get("SDF_WIDE_MAXROWS", 131072))
+    return T in (10, 20) and imgs % T == 0 and imgs * H * W <= int(sw("SDF_WIDE_MAXROWS", 131072))
 
 
 def smallm_conv_applicable(imgs, H, W, Cin, Cout, stride, T):
     """Mirror of the library's dispatch rule for the small-M digit convolution (csrc/ms_smallm.hip: smallm_conv_supports): 3x3 / stride 1
     on Cin % 64 == 0 channels, at most 32 000 output rows (SDF_SMALLM_CONV_ROWS; 5 120 until round 5) in (B, T, H, W) order with T in {10, 20}."""
-    if os.environ.get("SDF_SMALLM", "") == "0" or stride != 1 or Cin % 64 or Cout % 32:
+    if sw("SDF_SMALLM", "") == "0" or stride != 1 or Cin % 64 or Cout % 32:
         return False
-    return T in (10, 20) and imgs % T == 0 and imgs * H * W <= int(os.environ.get("SDF_SMALLM_CONV_ROWS", 400 * 80))
+    return T in (10, 20) and imgs % T == 0 and imgs * H * W <= int(sw("SDF_SMALLM_CONV_ROWS", 400 * 80))
 
 
 def tile_weight_i8x3(planes):
@@ -457,15 +507,15 @@ def smallm_gemm_applicable(M, N, K):
     """Mirror of the library's rule for the plain small-M product (csrc/ms_smallm.hip: smallm_gemm_supports) plus the engine's
     own bound: it pays where K is long enough to amortise a workgroup's prologue and reduction (measured: the first decoder's
     1 080 x 3 456 x 1 536 product; not the second's 4 320 x 1 728 x 832)."""
-    if os.environ.get("SDF_SMALLM", "") == "0" or M % 10 or N % 32 or K % 64:
+    if sw("SDF_SMALLM", "") == "0" or M % 10 or N % 32 or K % 64:
         return False
-    return M <= 64 * 80 and K >= (int(os.environ["SDF_SMALLM_MINK"]) if "SDF_SMALLM_MINK" in os.environ else 1024)
+    return M <= 64 * 80 and K >= int(sw("SDF_SMALLM_MINK", 1024))
 
 
 def res_gemm_applicable(M, N, K):
     """Mirror of the library's rule for the plain product on row-major digit planes (csrc/spike_gemm.hip -> ms_res.hip: whole-K digits
     LDS-resident per 32 columns, row loop): rows in tens, K <= 1024 in steps of 16."""
-    if os.environ.get("SDF_RES", "") == "0" or os.environ.get("SDF_RES_GEMM", "") == "0":
+    if sw("SDF_RES", "") == "0" or sw("SDF_RES_GEMM", "") == "0":
         return False
     return M % 10 == 0 and N % 32 == 0 and K % 16 == 0 and 32 <= K <= 1024 and M * max(K, 4 * N) < 1 << 31
 
@@ -928,7 +978,7 @@ def ann_attn_block_supported(Cc, nH, N):
     """Mirror of sdf_ann_attn_block_supported: the one-launch attention half block is built for C = 96, three heads, windows of 162.
     SDF_ANN_BLOCK=0 (A/B) and SDF_DENSE_LINEAR=0 (library GEMMs for every Linear, the two inside this kernel included) select the
     four-launch path."""
-    return (Cc, nH, N) == (96, 3, 162) and os.environ.get("SDF_ANN_BLOCK", "1") != "0" and os.environ.get("SDF_DENSE_LINEAR", "1") != "0"
+    return (Cc, nH, N) == (96, 3, 162) and sw("SDF_ANN_BLOCK", "1") != "0" and sw("SDF_DENSE_LINEAR", "1") != "0"
 
 
 def pack_ann_attn_block_weights(wqkv, wproj, nH):
@@ -963,7 +1013,7 @@ def _acc_order(n32, device):
 def ann_mlp_block_supported(Cc, Ch):
     """Mirror of sdf_ann_mlp_block_supported: the one-launch MLP half block is built for C = 96, hidden 384.  SDF_ANN_MLP=0 (A/B) and
     SDF_DENSE_LINEAR=0 (library GEMMs for every Linear) select the three-launch path."""
-    return (Cc, Ch) == (96, 384) and os.environ.get("SDF_ANN_MLP", "1") != "0" and os.environ.get("SDF_DENSE_LINEAR", "1") != "0"
+    return (Cc, Ch) == (96, 384) and sw("SDF_ANN_MLP", "1") != "0" and sw("SDF_DENSE_LINEAR", "1") != "0"
 
 
 def pack_ann_mlp_block_weights(w1, w2):
@@ -1500,13 +1550,13 @@ def deconv2x2_applicable(imgs, T, H, W, Cin, Cout, fast_only=False):
     """Mirror of sdf_spike_deconv3x3s2_fwd's shape rules (csrc/spike_gemm.hip).  `fast_only`: only where the halo-tile kernel
     (csrc/spike_deconv_wres.hip: 208 padded input channels, at least 4 096 input pixels) serves it - the row-loop kernel's form of the
     product, which takes every other admitted shape, is slower than the parity-class launches it would replace."""
-    if os.environ.get("SDF_DECONV_GEMM", "1") == "0" or os.environ.get("SDF_RES", "1") == "0":
+    if sw("SDF_DECONV_GEMM", "1") == "0" or sw("SDF_RES", "1") == "0":
         return False
     rows = imgs * H * W
     ok = T in (10, 20) and imgs % T == 0 and Cin % 16 == 0 and 16 <= Cin <= 256 and Cout % 8 == 0 and Cout >= 8 and \
         rows * Cin < 1 << 31 and rows * 16 * Cout < 1 << 31
     if fast_only:
-        ok = ok and Cin == 208 and rows >= 4096 and os.environ.get("SDF_DECONV_WRES", "1") != "0"
+        ok = ok and Cin == 208 and rows >= 4096 and sw("SDF_DECONV_WRES", "1") != "0"
     return ok
 
 

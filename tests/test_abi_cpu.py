@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "sdformerflow_hip.h")).read()
-    return sorted(set(re.findall(r"^(?:int|int64_t) (sdf_\w+)\(", src, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|int64_t|void) (sdf_\w+)\(", src, flags=re.M)))
 
 
 def test_header_declares_the_expected_entry_points():
@@ -27,7 +27,32 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), name
     lib.sdf_version.restype = ctypes.c_int
-    assert lib.sdf_version() == 106            # host-only call, no GPU needed
+    assert lib.sdf_version() == 107            # host-only call, no GPU needed
+
+
+def test_switches_are_read_once_and_reloaded_on_request(monkeypatch):
+    """The diagnostic SDF_* switches are a read-once table on both sides of the C ABI (csrc/switches.hip, hip.sw): a change of the
+    environment is seen after sdf_switches_reload() / hip.reload_switches() and not before; no entry point calls getenv per call."""
+    import subprocess
+    from sdformerflow_amd import hip
+    hip.lib()
+    os.environ["SDF_WIDE_MAXROWS"] = "12345"                        # (behind monkeypatch's back: no reload)
+    try:
+        assert hip.sw("SDF_WIDE_MAXROWS") is None
+        hip.reload_switches()
+        assert hip.sw("SDF_WIDE_MAXROWS") == "12345"
+    finally:
+        os.environ.pop("SDF_WIDE_MAXROWS", None)
+        hip.reload_switches()
+    assert hip.sw("SDF_WIDE_MAXROWS") is None
+    with hip.scoped_switches(SDF_RES="0"):
+        assert hip.sw("SDF_RES") == "0"
+    assert hip.sw("SDF_RES") is None
+    # getenv is referenced by exactly one translation unit of the library: the table builder
+    src = os.path.join(ROOT, "sdformerflow_amd", "csrc")
+    code = lambda f: "\n".join(l.split("//")[0] for l in open(os.path.join(src, f)).read().split("\n"))      # (comments dropped)
+    users = [f for f in sorted(os.listdir(src)) if f.endswith((".hip", ".h")) and "getenv(" in code(f)]
+    assert users == ["switches.hip"], users
 
 
 def test_product_refuses_cpu_tensors():
@@ -46,7 +71,7 @@ def test_argument_errors_are_reported_before_any_launch():
         import __graft_entry__ as g
         g.build()
     lib = C.CDLL(hip.LIB_PATH)
-    for name in hip.EXPORTS[1:]:
+    for name in hip.EXPORTS[2:]:
         getattr(lib, name).restype = C.c_int
     p, odd = C.c_void_p(0x10000), C.c_void_p(0x10004)
     E_NULL, E_SHAPE, E_DTYPE, E_ALIGN = -1, -2, -3, -4

@@ -48,12 +48,8 @@ def test_block_equals_oracle_and_the_four_launch_path(B, D, H, W, shift, qkv_bia
     xg = x.to(DEV)
     assert hip.ann_attn_block_supported(96, 3, 162)
     got = blk(xg).cpu()
-    os.environ["SDF_ANN_BLOCK"] = os.environ["SDF_ANN_MLP"] = "0"     # LayerNorm, qkv, attention, proj | LayerNorm, fc1 + GELU, fc2: seven launches
-    try:
+    with hip.scoped_switches(SDF_ANN_BLOCK="0", SDF_ANN_MLP="0"):     # LayerNorm, qkv, attention, proj | LayerNorm, fc1 + GELU, fc2: seven launches
         old = blk(xg).cpu()
-    finally:
-        os.environ.pop("SDF_ANN_BLOCK", None)
-        os.environ.pop("SDF_ANN_MLP", None)
     scale = ref.abs().max().item()
     assert (got - ref).abs().max().item() <= 3e-5 * scale
     assert (got - old).abs().max().item() <= 2e-5 * scale

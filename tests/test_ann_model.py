@@ -8,6 +8,7 @@ import pytest
 import torch
 import yaml
 
+from sdformerflow_amd import hip
 from sdformerflow_amd.synthetic import synth_state_dict, synth_voxel
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -109,11 +110,8 @@ def test_window_partition_inside_the_attention_kernel_equals_the_materialised_se
     x = rnd((2, 3, 20, 25, 96), 61, -1.0, 1.0).to("cuda:0")              # D = 3 -> 4, H = 20 -> 27, W = 25 -> 27 padded
     with torch.no_grad():
         fused = blk(x)
-        os.environ["SDF_ATTN_MATERIALISE"] = "1"
-        try:
+        with hip.scoped_switches(SDF_ATTN_MATERIALISE="1"):
             ref = blk(x)
-        finally:
-            os.environ.pop("SDF_ATTN_MATERIALISE", None)
     assert fused.shape == ref.shape == x.shape
     assert (fused - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
 

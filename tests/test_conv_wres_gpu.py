@@ -25,11 +25,8 @@ def both(fn):
     """fn() with the weight-resident kernel forced and with it disabled."""
     outs = []
     for mode in ("2", "0"):
-        os.environ["SDF_CONV_WRES"] = mode
-        try:
+        with hip.scoped_switches(SDF_CONV_WRES=mode):
             outs.append(fn())
-        finally:
-            os.environ.pop("SDF_CONV_WRES", None)
     return outs
 
 
@@ -50,11 +47,8 @@ def test_fp32_epilogue_equals_streaming_kernel_and_fp64(imgs, H, W, Cout, with_r
                          beta=beta.to(DEV), resid=None if resid is None else resid.to(DEV))
         return out.cpu()
     if ns == "i8x3" or Cout % 96:                                        # no streaming-kernel form (digit planes / N % 96 != 0)
-        os.environ["SDF_CONV_WRES"] = "2"
-        try:
+        with hip.scoped_switches(SDF_CONV_WRES="2"):
             new = old = run()
-        finally:
-            os.environ.pop("SDF_CONV_WRES", None)
     else:
         new, old = both(run)
     if Cout % 96 == 0 and ns != "i8x3":

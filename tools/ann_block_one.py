@@ -4,6 +4,7 @@ the one-launch kernel (csrc/ann_block.hip) against the four launches it replaces
 usage: ann_block_one.py [plain|shifted] [fused|four] [mlp]     (mlp: time the MLP half instead - one launch vs LayerNorm + fc1 + fc2)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sdformerflow_amd import hip
 from sdformerflow_amd.STSwinNet.swin_transformer3D_v2 import SwinTransformerBlock3D
 shifted = len(sys.argv) > 1 and sys.argv[1] == "shifted"
 which = sys.argv[2] if len(sys.argv) > 2 else "fused"
@@ -22,6 +23,7 @@ if mlp_half:                                    # the MLP half only: the attenti
 else:
     blk.mlp = _Shortcut()
     os.environ["SDF_ANN_MLP"] = "0"
+hip.reload_switches()                      # (the switches are read once: say that the environment changed)
 for _ in range(5): blk(x)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 reps = 20

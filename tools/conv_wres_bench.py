@@ -50,7 +50,9 @@ flop = 2.0 * imgs * H * W * C * 9 * C
 for name, fn in (("fp32+resid", f32), ("fused LIF T=10", fused), ("fused LIF + membrane", fused_m)):
     for mode in ("1",) if ns == "i8x3" else ("1", "0"):
         os.environ["SDF_CONV_WRES"] = mode
+        hip.reload_switches()
         t_l3, t_hbm = timed(fn, sets[:1]), timed(fn, sets)
         print(f"{name:22s} planes {ns} {'weight-resident' if mode == '1' else 'streaming      '}: L3-resident {t_l3:7.1f} us ({flop / t_l3 / 1e6:6.1f} TF/s)  "
               f"rotating {t_hbm:7.1f} us ({flop / t_hbm / 1e6:6.1f} TF/s)")
 os.environ.pop("SDF_CONV_WRES", None)
+hip.reload_switches()

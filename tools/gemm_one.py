@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sdformerflow_amd import hip
 M, N, K, T = (int(v) for v in sys.argv[1:5])
 os.environ["SDF_GEMM_CFG"] = sys.argv[5]
+hip.reload_switches()
 dev = "cuda:0"
 A = (torch.rand((M, K), device=dev) < 0.3).to(torch.uint8)
 Wp = hip.split_weight(torch.randn((N, K), device=dev) * 0.1, int(sys.argv[6]) if len(sys.argv) > 6 else 2)

@@ -22,6 +22,7 @@ def case(imgs, H, W, Cin, Cout, KH=3, KW=3):
     r = []
     for m in ("1", "2", "3", "4"):
         os.environ["SDF_KSPLIT_MULT"] = m
+        hip.reload_switches()
         r.append(timeit(lambda: hip.spike_conv2d(x, Wp, imgs, H, W, Cin, H, W, KH, KW, 1, dy, dx, out=out, alpha=al, beta=be)))
     fl = 2.0 * imgs * H * W * Cout * KH * KW * Cin
     print(f"conv {imgs}x{H}x{W} {Cin}->{Cout} {KH}x{KW}: ksplit x1|x2|x3|x4 " + " ".join(f"{v:6.1f}" for v in r) + f" us   ({fl / min(r) / 1e6:.0f} TF best)")
