@@ -263,11 +263,95 @@ def time_config3(iters=10):
                                          "kernel: 2.61e9, profiles/r2p_pmc_dense.txt)"}}
 
 
-def inflight_rate(model, chunks_cpu, dev, F_, steps, warmup=6):
-    """samples/s of `steps` batch-1 forwards dealt round-robin over F_ streams, each replaying its own HIP graph (the headline's
-    timed region without the multi-rank plumbing), and the median latency of a synchronous forward."""
+class InFlight:
+    """The headline's execution scheme: F streams, each replaying a HIP graph of ONE launch sequence that carries R independent
+    batch-1 forwards ("replicas", model.forward_replicas: every sample keeps the reference's batch-1 semantics and its flows are
+    bit-equal to a plain forward of that sample - checked by `verify`; R = 1 is the plain forward).  A step is one forward of one
+    sample: run(n) issues exactly n of them - n // R replays dealt round-robin to the streams plus, when R does not divide n, one
+    replay of a graph captured for the remainder."""
+
+    def __init__(self, model, dev, F_, R, eager=False, seed0=1235):
+        self.model, self.dev, self.F, self.R, self.eager = model, dev, F_, R, eager
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(F_)]
+        self.seed0 = seed0
+        self._voxels = {}
+        self.slots = {}                                          # (stream index, batch) -> [input, output, graph]
+        for j in range(F_):
+            self._slot(j, R)
+        torch.cuda.synchronize()
+        self._rr = 0
+
+    def voxel(self, k):
+        """Sample k of the synthetic stream (seed seed0 + k), on the device; every (stream, position in the batch) has its own."""
+        if k not in self._voxels:
+            self._voxels[k] = synthetic_chunk(self.seed0 + k).to(self.dev)
+        return self._voxels[k]
+
+    def _fwd(self, x):
+        return self.model.forward_replicas(x) if x.shape[0] > 1 else self.model(x)
+
+    def _slot(self, j, n):
+        if (j, n) not in self.slots:
+            x = torch.cat([self.voxel(j * self.R + b) for b in range(n)], 0)
+            st = self.streams[j]
+            with torch.cuda.stream(st):
+                for _ in range(2):
+                    o = self._fwd(x)                             # also creates this stream's split-K workspace and plan caches
+            torch.cuda.synchronize()
+            g = None
+            if not self.eager:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    o = self._fwd(x)
+            self.slots[(j, n)] = [x, o, g]
+        return self.slots[(j, n)]
+
+    def prepare(self, *sample_counts):
+        """Capture the remainder graphs the given run() sizes will need (outside any timed region)."""
+        for n in sample_counts:
+            if n % self.R:
+                self._slot(0, n % self.R)
+        torch.cuda.synchronize()
+
+    def _issue(self, j, n):
+        s = self.slots[(j, n)]
+        with torch.cuda.stream(self.streams[j]):
+            if s[2] is not None:
+                s[2].replay()
+            else:
+                s[1] = self._fwd(s[0])
+
+    def run(self, n):
+        for _ in range(n // self.R):
+            self._issue(self._rr % self.F, self.R)
+            self._rr += 1
+        if n % self.R:
+            self._issue(0, n % self.R)
+
+    def verify(self):
+        """Every sample of every slot equals the plain single-stream batch-1 forward of its voxel, bit for bit."""
+        torch.cuda.synchronize()
+        for (j, n), (x, o, g) in self.slots.items():
+            for b in range(n):
+                ref = self.model(x[b:b + 1])["flow"]
+                assert all(torch.equal(a[b], r[0]) for a, r in zip(o["flow"], ref)), "an in-flight forward differs from the plain forward of its voxel"
+            assert torch.isfinite(o["flow"][-1]).all()
+        a = self.slots[(0, self.R)][1]["flow"][-1]
+        if self.R > 1:
+            assert not torch.equal(a[0], a[1]), "the samples of a launch sequence were meant to be different voxels"
+        if self.F > 1:
+            assert not torch.equal(a, self.slots[(1, self.R)][1]["flow"][-1]), "streams were meant to carry different voxels"
+
+    def release(self):
+        self.slots.clear()
+        self._voxels.clear()
+
+
+def inflight_rate(model, dev, F_, R, steps, warmup=6):
+    """samples/s of `steps` batch-1 forwards in the headline's scheme (InFlight: F_ streams x R replicas per launch sequence; the timed
+    region without the multi-rank plumbing), and the median latency of a synchronous forward."""
     with torch.no_grad():
-        x0 = chunks_cpu[0].to(dev)
+        x0 = synthetic_chunk(1235).to(dev)
         for _ in range(3):
             model(x0)
         torch.cuda.synchronize()
@@ -277,36 +361,21 @@ def inflight_rate(model, chunks_cpu, dev, F_, steps, warmup=6):
             model(x0)
             torch.cuda.synchronize()
             lat.append((time.perf_counter() - t0) * 1e3)
-        streams = [torch.cuda.Stream(device=dev) for _ in range(F_)]
-        graphs, keep = [], []
-        for j, st in enumerate(streams):
-            x = chunks_cpu[j].to(dev)
-            with torch.cuda.stream(st):
-                for _ in range(2):
-                    model(x)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=st):
-                o = model(x)
-            graphs.append(g)
-            keep.append((x, o))
-        torch.cuda.synchronize()
-        for i in range(warmup):
-            with torch.cuda.stream(streams[i % F_]):
-                graphs[i % F_].replay()
+        fl = InFlight(model, dev, F_, R)
+        fl.prepare(warmup, steps)
+        fl.run(warmup)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(steps):
-            with torch.cuda.stream(streams[i % F_]):
-                graphs[i % F_].replay()
+        fl.run(steps)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    assert all(torch.isfinite(o["flow"][-1]).all() for _, o in keep)
+        fl.verify()
+        fl.release()
     return {"samples_per_s": steps / dt, "ms_per_step": dt / steps * 1e3, "latency_ms_single_stream": sorted(lat)[len(lat) // 2],
-            "steps": steps, "in_flight": F_}
+            "steps": steps, "in_flight": F_, "replicas_per_launch": R}
 
 
-def side_measurements(args, dev, chunks_cpu):
+def side_measurements(args, dev):
     """The other modes / BASELINE configurations beside the headline, each a short run of the same code paths (the default line's
     own configuration is never changed by them): the exact 3-plane and the 1-plane bf16 weight modes, the shipped PSN neuron,
     BASELINE configs[4] (20 bins / T = 20, 480 x 640, batch 4) and one configs[3] training step at local batch 4 on this GPU."""
@@ -318,7 +387,7 @@ def side_measurements(args, dev, chunks_cpu):
         try:
             m, _ = build_model(kind, dev)
             m.gemm_nsplit = planes
-            r = inflight_rate(m, chunks_cpu, dev, args.inflight, 90)
+            r = inflight_rate(m, dev, args.inflight, args.replicas, 96)
             r["workload"] = f"configs[1] forward, neuron={kind}, weight planes={planes} ({ {1: 'one bf16', 2: 'fp16 hi+lo', 3: 'bf16 hi+mid+lo = fp32 exactly'}[planes] })"
             out[name] = r
             del m
@@ -701,7 +770,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-config3", action="store_true", help="skip the BASELINE configs[2] (ANN, batch 8) side measurement")
     ap.add_argument("--no-sides", action="store_true", help="skip the other side measurements (weight-plane modes, PSN, configs[3] / [4])")
-    ap.add_argument("--inflight", type=int, default=3, help="independent forwards in flight per GPU (HIP streams)")
+    ap.add_argument("--inflight", type=int, default=2, help="HIP streams per GPU, each replaying its own graph")
+    ap.add_argument("--replicas", type=int, default=4, help="independent batch-1 forwards carried by ONE launch sequence (model.forward_replicas: "
+                                                            "bit-equal to separate forwards); 1 = one sample per launch sequence")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying HIP graphs")
     ap.add_argument("--planes", type=int, default=2, choices=[1, 2, 3],
                     help="16-bit weight planes of the spike GEMMs / convolutions: 2 = fp16 hi+lo (22 significand bits, the default "
@@ -709,8 +780,8 @@ def main():
                          "stated bf16 precision; a separately labelled throughput line, never the parity mode)")
     ap.add_argument("--plumbing", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
-    if args.inflight < 1:
-        ap.error("--inflight must be >= 1")
+    if args.inflight < 1 or args.replicas < 1:
+        ap.error("--inflight and --replicas must be >= 1")
     if args.steps is None:
         args.steps = 10 if args.train else 300
     if args.warmup is None:
@@ -728,9 +799,8 @@ def main():
     model, sd = build_model(args.neuron, dev)
     model.gemm_nsplit = args.planes
     F_ = args.inflight
-    # every in-flight stream gets its OWN synthetic voxel (seed 1235 + j); stream 0's is the one the CPU baseline runs
-    chunks_cpu = [synthetic_chunk(1235 + j) for j in range(F_)]
-    chunk_cpu = chunks_cpu[0]
+    # every (stream, position in the launch sequence) gets its OWN synthetic voxel (seed 1235 + k); voxel 0 is the one the CPU baseline runs
+    chunk_cpu = synthetic_chunk(1235)
     chunk = chunk_cpu.to(dev)
 
     def barrier():
@@ -751,55 +821,26 @@ def main():
             lat.append((time.perf_counter() - t0) * 1e3)
         latency_ms = sorted(lat)[len(lat) // 2]                      # median of 9 synchronous forwards
 
-        # F independent forwards in flight: own stream, own static input, own graph (own activation memory)
-        streams = [torch.cuda.Stream(device=dev) for _ in range(F_)]
-        inputs, outputs, graphs, refs = [], [], [], []
-        for j, st in enumerate(streams):
-            x = chunks_cpu[j].to(dev)
-            refs.append([f.clone() for f in model(x)["flow"]])   # plain single-stream forward of this stream's voxel
-            with torch.cuda.stream(st):
-                for _ in range(2):
-                    o = model(x)                                 # also creates this stream's split-K workspace and plan caches
-            torch.cuda.synchronize()
-            g = None
-            if not args.eager:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=st):
-                    o = model(x)
-            inputs.append(x); outputs.append(o); graphs.append(g)
-        torch.cuda.synchronize()
-
-        def step(i):
-            j = i % F_
-            with torch.cuda.stream(streams[j]):
-                if graphs[j] is not None:
-                    graphs[j].replay()
-                else:
-                    outputs[j] = model(inputs[j])
-
-        for i in range(args.warmup):
-            step(i)
+        # F streams, each replaying its own HIP graph of one launch sequence over R independent samples (class InFlight)
+        long_steps = max(args.steps, 96)
+        fl = InFlight(model, dev, F_, args.replicas, eager=args.eager)
+        fl.prepare(args.warmup, args.steps, long_steps)
+        fl.run(args.warmup)
         barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
+        fl.run(args.steps)                                       # EXACTLY --steps forwards of one sample each
         barrier()
         dt_local = time.perf_counter() - t0
-        # the same loop over >= 90 samples when the contract's --steps is shorter (a 20-step region is 30 ms: VERDICT r3); reported
+        # the same loop over >= 96 samples when the contract's --steps is shorter (a 20-step region is 30 ms: VERDICT r3); reported
         # beside `value`, which stays the contract's EXACTLY --steps
-        long_steps, dt_long = max(args.steps, 90), dt_local
+        dt_long = dt_local
         if long_steps > args.steps:
             barrier()
             t0 = time.perf_counter()
-            for i in range(long_steps):
-                step(i)
+            fl.run(long_steps)
             barrier()
             dt_long = time.perf_counter() - t0
-    for o, r in zip(outputs, refs):
-        assert all(torch.equal(a, b) for a, b in zip(o["flow"], r)), "an in-flight forward differs from the plain forward of its voxel"
-        assert torch.isfinite(o["flow"][-1]).all()
-    if F_ > 1:
-        assert not torch.equal(outputs[0]["flow"][-1], outputs[1]["flow"][-1]), "streams were meant to carry different voxels"
+        fl.verify()                                              # every in-flight sample == the plain forward of its voxel, bit for bit
     dt = max_over_ranks(dt_local, dev, dist)
     ranks = gather_ranks(rank_record(rank, dev, args.steps, dt_local), dist, td)
 
@@ -825,9 +866,12 @@ def main():
             "dtype": {1: "bf16", 2: "f16x2", 3: "f32"}[args.planes], "data": "synthetic",
             "dtype_note": "binary u8 spikes x " + planes_txt + ", fp32 accumulate on the 16-bit MFMA pipe; membranes, BN, neurons fp32",
             "config": {"workload": "BASELINE configs[1]: MS_SpikingformerFlowNet_en4 forward, batch 1 per GPU, 10-bin 288x384 "
-                                   "voxel, neuron=" + args.neuron + f"; {args.inflight} independent forwards (different voxels) in flight "
-                                   f"per GPU on HIP streams ({'eager launches' if args.eager else 'HIP-graph replay'}); replicas per GPU",
-                       "in_flight": args.inflight, "hip_graph": not args.eager, "weight_planes": args.planes},
+                                   "voxel, neuron=" + args.neuron + f"; a step = one forward of one sample; {args.inflight} HIP streams per GPU, each "
+                                   f"{'launching' if args.eager else 'replaying the HIP graph of'} one launch sequence that carries {args.replicas} "
+                                   "independent batch-1 forwards of different voxels (replicas: every flow map bit-equal to a separate batch-1 "
+                                   "forward, asserted in this run); one process per GPU",
+                       "in_flight": args.inflight, "replicas_per_launch": args.replicas, "samples_in_flight": args.inflight * args.replicas,
+                       "hip_graph": not args.eager, "weight_planes": args.planes},
             "ranks": ranks,
             "roofline": gemm, "roofline_neuron": neuron,
             "attention_gemm_roofline_frac": blocks["frac"], "attention_gemm": blocks,
@@ -837,10 +881,11 @@ def main():
         if not args.no_sides and world == 1 and args.planes == 2 and args.neuron == "lif":
             # the headline's graphs, static inputs and outputs are released first (their memory pools would stay beside the side runs),
             # and no side run can take the headline down: each is wrapped, the line is printed whatever happens
-            del model, graphs, outputs, inputs, refs
+            fl.release()
+            del model, fl
             torch.cuda.empty_cache()
             try:
-                res["side_measurements"] = side_measurements(args, dev, chunks_cpu)
+                res["side_measurements"] = side_measurements(args, dev)
             except Exception as e:
                 res["side_measurements"] = {"error": repr(e)[:300]}
         if not args.no_cpu and world == 1:

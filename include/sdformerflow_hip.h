@@ -186,6 +186,9 @@ int sdf_neuron_multi_fwd(const SdfNeuronDesc* descs, int n, void* stream);
  * A addressing: zg_nH == 0: A[m*lda + k].  zg_nH > 0: the reference's head-scramble
  *   Z[t,b,n,g*32+d] = E_flat[((((b*nH+g)*Tq+t)*N1+n)*32+d]   (Spiking_swin_transformer3D.py:709-710)
  * with m = (t*zg_B + b)*zg_N1 + n, k = g*32 + d, Tq = zg_T; requires K == nH*32.
+ * zg_rep > 0 (round 6): the zg_B windows are zg_B / zg_rep INDEPENDENT problems of zg_rep windows each - replica r owns windows
+ * r*zg_rep .. and its E_flat is the (Tq, zg_rep, N1, C) sub-tensor of the (Tq, zg_B, N1, C) buffer at those windows - so that one
+ * launch sequence serves several batch-1 forwards with the reference's batch-1 semantics each (zg_rep % Tq == 0, zg_B % zg_rep == 0).
  * Requirements: K % 32 == 0, N % 32 == 0, lda % 16 == 0.
  */
 typedef struct SdfSpikeGemmDesc {
@@ -235,6 +238,7 @@ typedef struct SdfSpikeGemmDesc {
    * weight-resident row-loop kernel (csrc/ms_res.hip) for M % 10 == 0, K % 16 == 0, K <= 1024, lda == K - the stacked-tap products
    * of the middle decoder levels (reference Spiking_modules.py:461-474 as one product + sdf_deconv_col2im_fwd); SDF_E_SHAPE otherwise. */
   const float* col_scale;
+  int32_t zg_rep;           /* head scramble: windows per independent replica (0 = zg_B: one problem) */
 } SdfSpikeGemmDesc;
 
 #define SDF_PLANES_I8X3 4
@@ -344,6 +348,12 @@ typedef struct SdfQkAttnDesc {
   const int8_t* q_digits;  const float* q_cscale;
   const int8_t* k_digits;  const float* k_cscale;
   const int8_t* p_digits;  const float* p_cscale;
+  /* Round 6 - several independent batch-1 forwards in one call ("replicas"): the B_ windows are B_ / rep_windows problems of
+   * rep_windows windows each.  slice_map (and x_src) are the caller's concatenation of the per-replica tables - entry
+   * (t' * B_ + r * rep_windows + b') * N1 + n = r * x_rows_1 + map_1[(t' * rep_windows + b') * N1 + n] - so steps 1 - 3 run unchanged on
+   * the (T', B_, N1, C) workspace; only the head scramble of step 4 is per replica (SdfSpikeGemmDesc.zg_rep).  0 = one problem (the
+   * reference's own batch semantics, which couples the samples of a batch through window_partition_v2's raw view).  rep_windows % T' == 0. */
+  int32_t rep_windows;
 } SdfQkAttnDesc;
 
 enum {

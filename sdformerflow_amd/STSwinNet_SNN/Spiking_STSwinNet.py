@@ -219,6 +219,17 @@ class MS_SpikingformerFlowNet(nn.Module):
             flows = self.engine().forward(x, scores)
         return {"flow": flows, "attn": scores}
 
+    def forward_replicas(self, x):
+        """x (R, bins, 2, H, W) = R INDEPENDENT samples -> {"flow": [(R, 2, H, W)] * E}: flow[i] is bit-equal to
+        `self(x[i:i+1])["flow"]` - R batch-1 forwards of the reference (`eval_DSEC_flow_SNN.py:219` with `batch_size: 1`) served by one
+        launch sequence whose kernels see R times the rows.  (`self(x)` on a batch keeps the reference's own batch semantics, which
+        couples the samples through `window_partition_v2`'s raw view.)  Eval mode only."""
+        if self.training:
+            raise RuntimeError("forward_replicas is an inference entry point: call model.eval()")
+        with torch.no_grad():
+            flows = self.engine().forward(x, None, replicas=True)
+        return {"flow": flows, "attn": None}
+
 
 class MS_SpikingformerFlowNet_en4(MS_SpikingformerFlowNet):
     """MS-shortcut SDformerFlow, 4 encoders - the shipped model (reference :319-325)."""

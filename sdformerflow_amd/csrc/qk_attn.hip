@@ -84,6 +84,7 @@ extern "C" int sdf_qk_attn_fwd(const SdfQkAttnDesc* d, void* stream) {
   if (!fused && (!d->q_planes || !d->k_planes)) return SDF_E_NULL;
   if (d->B_ < 1 || d->Tq < 1 || d->N1 < 1 || d->C < 32 || d->C % 32 || d->nH < 1 || d->C != d->nH * 32) return SDF_E_SHAPE;
   if (d->workspace_bytes < sdf_qk_attn_workspace_bytes(d->B_, d->Tq, d->N1, d->C)) return SDF_E_SHAPE;
+  if (d->rep_windows < 0 || (d->rep_windows > 0 && (d->B_ % d->rep_windows || d->rep_windows % d->Tq))) return SDF_E_SHAPE;
   if (!sdf_aligned(d->workspace, 256)) return SDF_E_ALIGN;
   const int C = d->C, Tq = d->Tq;
   const int64_t rows = d->B_ * d->N1, M = rows * Tq;
@@ -164,7 +165,7 @@ extern "C" int sdf_qk_attn_fwd(const SdfQkAttnDesc* d, void* stream) {
   g.A = xs; g.Wp = d->p_planes; g.out = d->x; g.M = M; g.N = C; g.K = C; g.lda = C; g.ldo = C; g.nsplit = d->nsplit;
   g.acc_scale = d->p_acc_scale; g.bias = d->p_bias; g.alpha = d->p_alpha; g.beta = d->p_beta; g.resid = d->x;
   g.out_rowmap = d->slice_map; g.out_rows = d->x_rows;
-  g.zg_nH = d->nH; g.zg_T = Tq; g.zg_B = (int32_t)d->B_; g.zg_N1 = d->N1;
+  g.zg_nH = d->nH; g.zg_T = Tq; g.zg_B = (int32_t)d->B_; g.zg_N1 = d->N1; g.zg_rep = d->rep_windows;
   g.workspace = d->gemm_workspace; g.workspace_bytes = d->gemm_workspace_bytes;
   return sdf_spike_gemm_fwd(&g, stream);
 }

@@ -118,6 +118,13 @@ __global__ __launch_bounds__(64 * WAVES) void spike_gemm_kernel(GemmParams P) {
         const uint32_t r2 = (uint32_t)g - zt * bn;
         const uint32_t zb = r2 / (uint32_t)d.zg_N1;
         const uint32_t zn = r2 - zb * (uint32_t)d.zg_N1;
+        if (d.zg_rep > 0) {                                          // independent replicas: the scramble stays inside replica zb / zg_rep
+          const uint32_t rr = zb / (uint32_t)d.zg_rep, zbr = zb - rr * (uint32_t)d.zg_rep;
+          const uint32_t half = (uint32_t)d.zg_rep * (uint32_t)d.zg_N1 * (uint32_t)d.K;        // bytes of one attention step of a replica
+          const uint32_t o = (((zbr * (uint32_t)d.zg_nH) * (uint32_t)d.zg_T + zt) * (uint32_t)d.zg_N1 + zn) * 32u;
+          const uint32_t te = o / half;
+          a_off[i] = ((int64_t)te * d.zg_B + (int64_t)rr * d.zg_rep) * d.zg_N1 * d.K + (o - te * half);
+        } else
         a_off[i] = (((int64_t)zb * d.zg_nH * d.zg_T + zt) * d.zg_N1 + zn) * 32;
       }
     }
@@ -499,6 +506,7 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
   } else if (d->zg_nH > 0) {
     if (d->K != d->zg_nH * 32 || d->zg_T < 1 || d->zg_B < 1 || d->zg_N1 < 1) return SDF_E_SHAPE;
     if ((int64_t)d->zg_T * d->zg_B * d->zg_N1 != d->M) return SDF_E_SHAPE;
+    if (d->zg_rep < 0 || (d->zg_rep > 0 && (d->zg_B % d->zg_rep || d->zg_rep % d->zg_T))) return SDF_E_SHAPE;
   }
   if (!sdf_aligned(d->A, 16) || !sdf_aligned(d->Wp, 16)) return SDF_E_ALIGN;
   if (!spike && (d->ldo % 4 || !sdf_aligned(d->out, 16) || (d->resid && !sdf_aligned(d->resid, 16)) ||

@@ -235,6 +235,13 @@ __device__ __forceinline__ void spike_mm_pp_body(const GemmParams& P, const int 
           const uint32_t zb = r2 / (uint32_t)d.zg_N1;
           const uint32_t zn = r2 - zb * (uint32_t)d.zg_N1;
           off = (((zb * (uint32_t)d.zg_nH) * (uint32_t)d.zg_T + zt) * (uint32_t)d.zg_N1 + zn) * 32u;
+          if (d.zg_rep > 0) {                                        // independent replicas (SdfSpikeGemmDesc.zg_rep)
+            const uint32_t rr = zb / (uint32_t)d.zg_rep, zbr = zb - rr * (uint32_t)d.zg_rep;
+            const uint32_t half = (uint32_t)d.zg_rep * (uint32_t)d.zg_N1 * (uint32_t)d.K;
+            const uint32_t o = (((zbr * (uint32_t)d.zg_nH) * (uint32_t)d.zg_T + zt) * (uint32_t)d.zg_N1 + zn) * 32u;
+            const uint32_t te = o / half;
+            off = (te * (uint32_t)d.zg_B + rr * (uint32_t)d.zg_rep) * (uint32_t)d.zg_N1 * (uint32_t)d.K + (o - te * half);
+          }
         }
         dec_off[i] = off;
         dec_val[i] = vm;

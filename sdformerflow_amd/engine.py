@@ -202,6 +202,7 @@ class MSFlowEngine:
             raise hip.SdfError("module forwards run on the MI355X HIP engine only (no CPU fallback): move the module and its input to 'cuda'")
         hip.lib()
         e.device, e.nsplit, e._maps, e._deconv, e.tape, e._masks, e.scores = torch.device(device), nsplit, {}, {}, None, {}, None
+        e.replicas = False
         return e
 
     def __init__(self, model):
@@ -233,6 +234,7 @@ class MSFlowEngine:
         self._maps, self._deconv = {}, {}
         self.tape = None            # parity tests set a list: every neuron layer's spikes are recorded (see _rec)
         self.scores = None          # `log=True`: a list that receives the attention score of the last block of every stage
+        self.replicas = False       # forward(..., replicas=True): the batch is B independent batch-1 forwards (see forward)
         self._init_stages(model, unet, sw, dev, ns, U)
 
     def _init_stages(self, model, unet, sw, dev, ns, U):
@@ -259,9 +261,20 @@ class MSFlowEngine:
 
     # ------------------------------------------------------------------ helpers
     def _slice_map(self, B, D, H, W, ws, ss):
-        key = ("win", B, D, H, W, ws, ss)
+        key = ("win", B, D, H, W, ws, ss, self.replicas)
         if key not in self._maps:
-            self._maps[key] = hip.window_slice_map(B, D, H, W, ws, ss, self.device)        # built on the device, cached per shape
+            if self.replicas and B > 1:
+                # B independent batch-1 problems in one launch sequence: every sample keeps ITS batch-1 window view (hip.replica_slice_map)
+                m1, nW = self._slice_map_1(D, H, W, ws, ss)
+                self._maps[key] = (hip.replica_slice_map(m1, nW, B, ws[0], ws[1] * ws[2], D * H * W), B * nW)
+            else:
+                self._maps[key] = hip.window_slice_map(B, D, H, W, ws, ss, self.device)    # built on the device, cached per shape
+        return self._maps[key]
+
+    def _slice_map_1(self, D, H, W, ws, ss):
+        key = ("win", 1, D, H, W, ws, ss, False)
+        if key not in self._maps:
+            self._maps[key] = hip.window_slice_map(1, D, H, W, ws, ss, self.device)
         return self._maps[key]
 
     def _merge_map(self, B, D, H, W):
@@ -464,9 +477,16 @@ class MSFlowEngine:
         return self._conv3x3(s1, self.proj_w, self.proj_w.shape[1], stride=2, bn=self.proj_bn, resid=res)
 
     def _zsrc_map(self, rowmap, B_, Tq, N1, nH, x_rows, key):
-        key = ("zsrc", nH) + key
+        key = ("zsrc", nH, self.replicas) + key
         if key not in self._maps:
-            self._maps[key] = hip.window_zsrc_map(rowmap, B_, Tq, N1, nH, x_rows)     # built on the device, cached per shape
+            B = key[3]
+            if self.replicas and B > 1:
+                _, D, H, W, ws, ss = key[3:]
+                m1, nW = self._slice_map_1(D, H, W, ws, ss)
+                z1 = hip.window_zsrc_map(m1, nW, Tq, N1, nH, x_rows // B)
+                self._maps[key] = hip.replica_zsrc_map(z1, nW, B, Tq, N1, nH * 32)
+            else:
+                self._maps[key] = hip.window_zsrc_map(rowmap, B_, Tq, N1, nH, x_rows)     # built on the device, cached per shape
         return self._maps[key]
 
     def attention(self, x, blk: _Block, score_out=None, emit=None):
@@ -484,6 +504,9 @@ class MSFlowEngine:
                                "Spiking_QK_WindowAttention3D is defined for the nominal window only (reference Spiking_swin_transformer3D.py:678)")
         rowmap, B_ = self._slice_map(B, D, H, W, ws, ss)
         Tq, N1 = ws[0], ws[1] * ws[2]
+        rep_windows = B_ // B if self.replicas and B > 1 else 0
+        if rep_windows and (self.tape is not None or score_out is not None):
+            raise hip.SdfError("the parity tape and log=True follow one forward: run them without replicas")
         # one C-ABI call: neuron over the gathered slices -> q|k spike GEMM (+BN, +PE, neurons fused) -> token gate ->
         # projection spike GEMM through the head scramble with bias + BN + scatter + residual (csrc/qk_attn.hip)
         keep = [] if score_out is not None else None
@@ -497,7 +520,7 @@ class MSFlowEngine:
         zsrc = self._zsrc_map(rowmap, B_, Tq, N1, blk.nH, B * D * H * W, (B, D, H, W, tuple(ws), tuple(ss))) if Cc >= _WIDE_MINC and Tq == 2 else None
         kw = dict(qk=blk.qk) if blk.qk is not None else dict(q_lin=blk.q, k_lin=blk.k, pe=blk.pe)
         hip.qk_attn(x, rowmap, B_, Tq, N1, blk.nH, blk.p, blk.sn_proj, blk.sn_q, blk.sn_k, blk.sn2_q, keep_ws=keep, x_src=zsrc, emit=emit,
-                    info=info, **kw)
+                    info=info, rep_windows=rep_windows, **kw)
         if score_out is not None:
             # the gate's output replaced the slice spikes at the head of the workspace (csrc/qk_attn.hip)
             e = keep[0][:Tq * B_ * N1 * Cc].view(Tq, B_ * N1, Cc)
@@ -804,19 +827,24 @@ class MSFlowEngine:
             y = z
         return [None if p is None else p[..., :self.preds[0][3]] for p in preds]
 
-    def forward(self, x, scores=None):
+    def forward(self, x, scores=None, replicas=False):
         """(B,bins,2,H,W) fp32 on the GPU -> list of E flow maps (B,2,H,W) (reference :278-305).  `scores` (a list) receives the
         `log=True` output (:283-284): the attention score (T', B_, Wh, Ww, C) of the last block of every stage - what the reference's
-        `get_layer_attention_scores` is written to return (its own call chain raises: oracle/sdformer_oracle.py `swin_encoder`)."""
+        `get_layer_attention_scores` is written to return (its own call chain raises: oracle/sdformer_oracle.py `swin_encoder`).
+        `replicas`: the B samples are B INDEPENDENT batch-1 forwards served by one launch sequence - flow i is bit-equal to
+        forward(x[i:i+1]) - instead of one reference batch (whose samples window_partition_v2's raw view couples): the
+        only difference is the window tables (hip.replica_slice_map / replica_zsrc_map), every kernel sees B times the rows."""
         if not x.is_cuda:
             raise hip.SdfError("input must be a GPU tensor (no CPU fallback)")
         x = x.float().contiguous()
         H, W = x.shape[-2:]
         self.scores = scores
+        self.replicas = bool(replicas)
         try:
             feats = self.encoder(x, **self._tail_kwargs())
         finally:
             self.scores = None
+            self.replicas = False
         preds = self.unet_tail(feats, out_size=(H, W), **({"s1": self.tail_spikes} if getattr(self, "tail_spikes", None) is not None else {}))
         self.tail_spikes = None
         # sum over time + nearest upsampling to the input size: done by the prediction head's launch, else one small kernel per scale

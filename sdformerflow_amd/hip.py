@@ -110,7 +110,7 @@ class SpikeGemmDesc(C.Structure):
                 ("pos_count", C.c_int64), ("pos_inner", C.c_int64), ("pos_ostride", C.c_int64), ("t_stride", C.c_int64),
                 ("add", C.c_void_p), ("add_prows", C.c_int64), ("out_spike", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("acc_scale", C.c_float), ("out_rows", C.c_int64),
-                ("col_scale", C.c_void_p)]
+                ("col_scale", C.c_void_p), ("zg_rep", C.c_int32)]
 
 
 class SpikeConvDesc(C.Structure):
@@ -619,7 +619,8 @@ class QkAttnDesc(C.Structure):
                 ("x_src", C.c_void_p), ("xB", C.c_int32), ("xD", C.c_int32), ("xHW", C.c_int64), ("emit_s1", C.c_void_p),
                 ("emit_sn", NeuronCfg),
                 ("qk_digits", C.c_void_p), ("qk_cscale", C.c_void_p), ("q_digits", C.c_void_p), ("q_cscale", C.c_void_p),
-                ("k_digits", C.c_void_p), ("k_cscale", C.c_void_p), ("p_digits", C.c_void_p), ("p_cscale", C.c_void_p)]
+                ("k_digits", C.c_void_p), ("k_cscale", C.c_void_p), ("p_digits", C.c_void_p), ("p_cscale", C.c_void_p),
+                ("rep_windows", C.c_int32)]
 
 
 SDF_QK_KEEP_SPIKES, SDF_QK_FOUR_LAUNCHES, SDF_QK_NARROW = 1, 2, 4
@@ -645,6 +646,34 @@ def window_slice_map(B, D, H, W, ws, ss, device):
     return m, B_
 
 
+def replica_slice_map(map1, nW, R, Tq, N1, x_rows1):
+    """The slice map of R INDEPENDENT batch-1 problems from the batch-1 table `map1` ((Tq * nW * N1,) int32, nW windows, x_rows1
+    rows of x per sample): entry (t' * R * nW + r * nW + b') * N1 + n = r * x_rows1 + map1[(t' * nW + b') * N1 + n] (-1 stays -1).
+    Attention step t' of window b' of replica r is then that replica's own slice t' * nW + b' - the reference's batch-1
+    `window_partition_v2` view (Spiking_swin_transformer3D.py:100-113) per sample instead of its batch-coupling view over R samples -
+    while the kernels see ONE (Tq, R * nW, N1, C) problem.  Index arithmetic on the device, no kernel."""
+    m = map1.view(Tq, 1, nW * N1).expand(Tq, R, nW * N1)
+    off = (torch.arange(R, device=map1.device, dtype=torch.int32) * x_rows1).view(1, R, 1)
+    return torch.where(m >= 0, m + off, m).reshape(-1).contiguous()
+
+
+def replica_zsrc_map(z1, nW, R, Tq, N1, Cc):
+    """The projection's operand map (window_zsrc_map) of R independent batch-1 problems from the batch-1 table `z1` (int32 per row of
+    x: byte offset of the row's gated spikes in the replica's OWN E_flat, a (Tq, nW, N1, C) tensor): that tensor is the sub-block
+    [:, r * nW : (r + 1) * nW] of the (Tq, R * nW, N1, C) buffer the kernels share, so offset o of replica r moves to
+    ((o // half) * R * nW + r * nW) * N1 * C + o % half with half = nW * N1 * C.  nW % Tq == 0 keeps the nH pieces of a row on one side
+    of `half` (the kernels step from head to head by a constant Tq * N1 * 32)."""
+    if nW % Tq:
+        raise SdfError(f"replicas need a window count per sample ({nW}) that is a multiple of the window depth ({Tq})")
+    half = nW * N1 * Cc
+    te = z1 // half
+    r = torch.arange(R, device=z1.device, dtype=torch.int32).view(R, 1)
+    out = (te.view(1, -1) * (R * nW) + r * nW) * (N1 * Cc) + (z1 - te * half).view(1, -1)
+    if R * Tq * nW * N1 * Cc >= 1 << 31:
+        raise SdfError("replica batch too large for the 31-bit operand offsets of the projection")
+    return out.to(torch.int32).reshape(-1).contiguous()
+
+
 def _digits(dg):
     """(planes pointer, channel-scale pointer) of int8 digit planes made by split_weight_i8x3, or (None, None)."""
     if dg is None:
@@ -662,14 +691,16 @@ def window_zsrc_map(slice_map, B_, Tq, N1, nH, x_rows):
 
 
 def qk_attn(x, slice_map, B_, Tq, N1, nH, p_lin, sn_proj, sn_q, sn_k, sn2_q, qk=None, q_lin=None, k_lin=None, pe=None, keep_ws=None,
-            four_launches=False, x_src=None, emit=None, narrow=False, info=None):
+            four_launches=False, x_src=None, emit=None, narrow=False, info=None, rep_windows=0):
     """sdf_qk_attn_fwd: x (B,D,H,W,C) fp32 channel-last += SSA(x), in place.  `qk` = {"Wp", "alpha", "beta", "add"} for the
     stacked projection, or q_lin / k_lin (objects with Wp / alpha / beta) + pe for separate ones; p_lin has Wp / bias / alpha / beta.
     `x_src` (window_zsrc_map) lets the library take its wide-stage kernels; `emit` = (u8 buffer, NeuronParams): the projection
     also writes SN(x after the update) over D there (the MLP's first neuron) when the call runs on the wide-stage kernels - `info`
-    (a dict) then receives "emitted": True; `narrow` forces the general kernels (A/B)."""
+    (a dict) then receives "emitted": True; `narrow` forces the general kernels (A/B).  `rep_windows` > 0: the B_ windows are
+    B_ / rep_windows independent batch-1 problems and `slice_map` / `x_src` their concatenated tables (replica_slice_map, replica_zsrc_map)."""
     Cc = x.shape[-1]
     d = QkAttnDesc()
+    d.rep_windows = rep_windows
     d.x, d.slice_map = _ptr(x, torch.float32), _ptr(slice_map, torch.int32)
     d.B_, d.x_rows, d.Tq, d.N1, d.C, d.nH = B_, x.numel() // Cc, Tq, N1, Cc, nH
     d.nsplit = p_lin.Wp.shape[0]
