@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SDF_VERSION 107   /* round 6 (107): + sdf_switches_reload; the diagnostic SDF_* switches are read once, not per call.  106 / round 5: + sdf_ann_attn_block_fwd, sdf_ann_mlp_block_fwd, sdf_spike_deconv3x3s2_fwd, row-major digit planes in sdf_spike_gemm_fwd; 106: + sdf_linear_dw_fwd, sdf_ringed_rows_fwd, sdf_linear_train_fwd */
+#define SDF_VERSION 107   /* round 6 (107): + sdf_switches_reload, sdf_launch_log / sdf_launch_log_read, SdfQkAttnDesc.rep_windows, SdfSpikeGemmDesc.zg_rep; the diagnostic SDF_* switches are read once, not per call.  106 / round 5: + sdf_ann_attn_block_fwd, sdf_ann_mlp_block_fwd, sdf_spike_deconv3x3s2_fwd, row-major digit planes in sdf_spike_gemm_fwd; 106: + sdf_linear_dw_fwd, sdf_ringed_rows_fwd, sdf_linear_train_fwd */
 
 enum { SDF_F32 = 0, SDF_U8 = 1 };
 enum { SDF_LIF = 0, SDF_PSN = 1, SDF_IF = 2 };
@@ -41,6 +41,20 @@ int sdf_version(void);
  * entry point calls getenv() on its per-call path.  A test harness that changes the environment between calls re-reads the table
  * with this call (not concurrently with other calls into the library).  No reference counterpart. */
 void sdf_switches_reload(void);
+
+/* Diagnostic per-launch log (round 6; off by default, one relaxed atomic load per launch while off).  sdf_launch_log(1) clears the
+ * log and switches it on: every kernel launch of every entry point is then bracketed by two HIP events on its own stream and noted
+ * with its kernel, grid and block; sdf_launch_log(0) switches it off.  sdf_launch_log_read synchronises with the recorded launches
+ * and copies up to `max_records` records in launch order; returns the number of launches logged (may exceed max_records).
+ * `workgroups * us / 256` = the CHIP time of a launch (compute units x time it can hold), the measure bench.py's `roofline.by_time`
+ * reports beside the duration.  Not for use during stream capture (events).  No reference counterpart. */
+typedef struct SdfLaunchRecord {
+  char kernel[192];         /* demangled kernel name with its template arguments */
+  uint32_t workgroups, threads, lds_bytes;   /* grid size in workgroups, threads per workgroup, dynamic LDS bytes */
+  float us;                 /* duration between the two events around the launch; -1: unavailable */
+} SdfLaunchRecord;
+void sdf_launch_log(int enable);
+int sdf_launch_log_read(SdfLaunchRecord* out, int max_records);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-step LIF over the leading (time) axis of a contiguous fp32 (T, N) tensor.

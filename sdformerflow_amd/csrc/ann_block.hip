@@ -431,7 +431,7 @@ extern "C" int sdf_ann_attn_block_fwd(const SdfAnnAttnBlockDesc* d, void* stream
   if (const int e1 = sdf_lds_opt_in(raised, reinterpret_cast<const void*>(ann_attn_block_kernel), LDS_BYTES)) return e1;
   hipStream_t s = sdf_stream(stream);
   const dim3 grid((unsigned)d->B_), block(NTHR);
-  hipLaunchKernelGGL(ann_attn_block_kernel, grid, block, LDS_BYTES, s, P);
+  SDF_LAUNCH(ann_attn_block_kernel, grid, block, LDS_BYTES, s, P);
   SDF_LAUNCH_CHECK();
   return 0;
 }

@@ -237,7 +237,7 @@ extern "C" int sdf_ann_mlp_block_fwd(const SdfAnnMlpBlockDesc* d, void* stream) 
   static std::atomic<uint64_t> raised{0};                                        // > 64 KiB of dynamic LDS: opt-in once per device
   if (const int e = sdf_lds_opt_in(raised, reinterpret_cast<const void*>(ann_mlp_block_kernel), LDS_BYTES)) return e;
   const int64_t wgs = (d->rows + ROWS_WG - 1) / ROWS_WG;
-  hipLaunchKernelGGL(ann_mlp_block_kernel, dim3((unsigned)wgs), dim3(NTHR), LDS_BYTES, sdf_stream(stream), P);
+  SDF_LAUNCH(ann_mlp_block_kernel, dim3((unsigned)wgs), dim3(NTHR), LDS_BYTES, sdf_stream(stream), P);
   SDF_LAUNCH_CHECK();
   return 0;
 }

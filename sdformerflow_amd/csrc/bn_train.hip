@@ -265,10 +265,10 @@ extern "C" int sdf_bn_train_fwd(const float* x, const float* weight, const float
   P.R = R; P.C = C;
   hipStream_t s = sdf_stream(stream);
   const int nblk = nblocks(R, C);
-  hipLaunchKernelGGL((bn_reduce_kernel<false>), dim3(nblk), dim3(256), reduce_lds(C), s, P);
-  hipLaunchKernelGGL((bn_finish_kernel<false>), dim3(C), dim3(64), 0, s, P.partial, nblk, C, R, eps, momentum, save_mean, save_invstd,
+  SDF_LAUNCH((bn_reduce_kernel<false>), dim3(nblk), dim3(256), reduce_lds(C), s, P);
+  SDF_LAUNCH((bn_finish_kernel<false>), dim3(C), dim3(64), 0, s, P.partial, nblk, C, R, eps, momentum, save_mean, save_invstd,
                      running_mean, running_var);
-  hipLaunchKernelGGL((bn_apply_kernel<false>), dim3((unsigned)((R * (C / 4) + 255) / 256)), dim3(256), 0, s, P, nullptr, nullptr);
+  SDF_LAUNCH((bn_apply_kernel<false>), dim3((unsigned)((R * (C / 4) + 255) / 256)), dim3(256), 0, s, P, nullptr, nullptr);
   SDF_LAUNCH_CHECK();
   return 0;
 }
@@ -288,10 +288,10 @@ extern "C" int sdf_bn_train_bwd(const float* x, const float* grad_y, const float
   P.partial = reinterpret_cast<double*>(workspace); P.R = R; P.C = C;
   hipStream_t s = sdf_stream(stream);
   const int nblk = nblocks(R, C);
-  hipLaunchKernelGGL((bn_reduce_kernel<true>), dim3(nblk), dim3(256), reduce_lds(C), s, P);
-  hipLaunchKernelGGL((bn_finish_kernel<true>), dim3(C), dim3(64), 0, s, P.partial, nblk, C, R, 0.f, 0.f, grad_weight, grad_bias,
+  SDF_LAUNCH((bn_reduce_kernel<true>), dim3(nblk), dim3(256), reduce_lds(C), s, P);
+  SDF_LAUNCH((bn_finish_kernel<true>), dim3(C), dim3(64), 0, s, P.partial, nblk, C, R, 0.f, 0.f, grad_weight, grad_bias,
                      nullptr, nullptr);
-  hipLaunchKernelGGL((bn_apply_kernel<true>), dim3((unsigned)((R * (C / 4) + 255) / 256)), dim3(256), 0, s, P, grad_weight, grad_bias);
+  SDF_LAUNCH((bn_apply_kernel<true>), dim3((unsigned)((R * (C / 4) + 255) / 256)), dim3(256), 0, s, P, grad_weight, grad_bias);
   SDF_LAUNCH_CHECK();
   return 0;
 }
@@ -312,10 +312,10 @@ extern "C" int sdf_bn_train_nchw_fwd(const float* x, const float* weight, const 
   const int64_t planes = N * C;
   const int nblk = (int)(planes < BN_BLOCKS ? planes : BN_BLOCKS);
   const size_t lds = (size_t)(2 * C + 8) * sizeof(double);
-  hipLaunchKernelGGL((bn_reduce_nchw_kernel<false>), dim3(nblk), dim3(256), lds, s, P);
-  hipLaunchKernelGGL((bn_finish_kernel<false>), dim3(C), dim3(64), 0, s, P.partial, nblk, C, P.R, eps, momentum, save_mean, save_invstd,
+  SDF_LAUNCH((bn_reduce_nchw_kernel<false>), dim3(nblk), dim3(256), lds, s, P);
+  SDF_LAUNCH((bn_finish_kernel<false>), dim3(C), dim3(64), 0, s, P.partial, nblk, C, P.R, eps, momentum, save_mean, save_invstd,
                      running_mean, running_var);
-  hipLaunchKernelGGL((bn_apply_nchw_kernel<false>), dim3((unsigned)((N * C * (HW / 4) + 255) / 256)), dim3(256), 0, s, P, nullptr, nullptr);
+  SDF_LAUNCH((bn_apply_nchw_kernel<false>), dim3((unsigned)((N * C * (HW / 4) + 255) / 256)), dim3(256), 0, s, P, nullptr, nullptr);
   SDF_LAUNCH_CHECK();
   return 0;
 }
@@ -334,10 +334,10 @@ extern "C" int sdf_bn_train_nchw_bwd(const float* x, const float* grad_y, const 
   const int64_t planes = N * C;
   const int nblk = (int)(planes < BN_BLOCKS ? planes : BN_BLOCKS);
   const size_t lds = (size_t)(2 * C + 8) * sizeof(double);
-  hipLaunchKernelGGL((bn_reduce_nchw_kernel<true>), dim3(nblk), dim3(256), lds, s, P);
-  hipLaunchKernelGGL((bn_finish_kernel<true>), dim3(C), dim3(64), 0, s, P.partial, nblk, C, P.R, 0.f, 0.f, grad_weight, grad_bias, nullptr,
+  SDF_LAUNCH((bn_reduce_nchw_kernel<true>), dim3(nblk), dim3(256), lds, s, P);
+  SDF_LAUNCH((bn_finish_kernel<true>), dim3(C), dim3(64), 0, s, P.partial, nblk, C, P.R, 0.f, 0.f, grad_weight, grad_bias, nullptr,
                      nullptr);
-  hipLaunchKernelGGL((bn_apply_nchw_kernel<true>), dim3((unsigned)((N * C * (HW / 4) + 255) / 256)), dim3(256), 0, s, P, grad_weight, grad_bias);
+  SDF_LAUNCH((bn_apply_nchw_kernel<true>), dim3((unsigned)((N * C * (HW / 4) + 255) / 256)), dim3(256), 0, s, P, grad_weight, grad_bias);
   SDF_LAUNCH_CHECK();
   return 0;
 }

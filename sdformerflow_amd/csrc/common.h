@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <atomic>
 #include "../../include/sdformerflow_hip.h"
+#include "launch_log.h"
 
 #define SDF_LAUNCH_CHECK()                         \
   do {                                             \

@@ -538,9 +538,9 @@ extern "C" int sdf_dense_conv3x3_fwd(const SdfDenseConvDesc* d, void* stream) {
   P.ranges = want < 256 / ncb ? want : 256 / ncb;
   const int G = P.ranges == 256 / ncb ? 256 : P.ranges * ncb;
   hipStream_t s = sdf_stream(stream);
-  if (d->cin_records == 1) hipLaunchKernelGGL((dense_conv_wres_kernel<1, 1>), dim3(G), dim3(64 * NW), 0, s, P);
-  else if (tpw == 1) hipLaunchKernelGGL((dense_conv_wres_kernel<6, 1>), dim3(G), dim3(64 * NW), 0, s, P);
-  else hipLaunchKernelGGL((dense_conv_wres_kernel<6, 2>), dim3(G), dim3(64 * NW), 0, s, P);
+  if (d->cin_records == 1) SDF_LAUNCH((dense_conv_wres_kernel<1, 1>), dim3(G), dim3(64 * NW), 0, s, P);
+  else if (tpw == 1) SDF_LAUNCH((dense_conv_wres_kernel<6, 1>), dim3(G), dim3(64 * NW), 0, s, P);
+  else SDF_LAUNCH((dense_conv_wres_kernel<6, 2>), dim3(G), dim3(64 * NW), 0, s, P);
   SDF_LAUNCH_CHECK();
   return 0;
 }
@@ -562,7 +562,7 @@ extern "C" int sdf_pack_planes(const float* x, void* planes, int imgs, int C, in
   if (!sdf_aligned(planes, 16)) return SDF_E_ALIGN;
   const int nch = (C + 15) / 16;
   const int64_t total = (int64_t)imgs * nch * 4 * H * W;
-  hipLaunchKernelGGL(sdfmm::pack_planes_kernel, dim3(planes_grid(total)), dim3(256), 0, sdf_stream(stream), x,
+  SDF_LAUNCH(sdfmm::pack_planes_kernel, dim3(planes_grid(total)), dim3(256), 0, sdf_stream(stream), x,
                      reinterpret_cast<sdfmm::u32x4*>(planes), imgs, C, nch, H, W);
   SDF_LAUNCH_CHECK();
   return 0;
@@ -577,10 +577,10 @@ extern "C" int sdf_pack_planes_up2(const float* x, void* planes, int imgs, int C
   const bool cl = sc == 1 && C % 4 == 0 && sn % 4 == 0 && sh % 4 == 0 && sw % 4 == 0 && sdf_aligned(x, 16);
   const int64_t total = (int64_t)imgs * nch * (2 * h) * (2 * w) * (cl ? 4 : 1);
   if (cl)
-    hipLaunchKernelGGL(sdfmm::pack_planes_up2_kernel<true>, dim3(planes_grid(total)), dim3(256), 0, sdf_stream(stream), x,
+    SDF_LAUNCH(sdfmm::pack_planes_up2_kernel<true>, dim3(planes_grid(total)), dim3(256), 0, sdf_stream(stream), x,
                        reinterpret_cast<sdfmm::u32x4*>(planes), imgs, C, h, w, sn, sc, sh, sw, rec0, rec_total);
   else
-    hipLaunchKernelGGL(sdfmm::pack_planes_up2_kernel<false>, dim3(planes_grid(total)), dim3(256), 0, sdf_stream(stream), x,
+    SDF_LAUNCH(sdfmm::pack_planes_up2_kernel<false>, dim3(planes_grid(total)), dim3(256), 0, sdf_stream(stream), x,
                        reinterpret_cast<sdfmm::u32x4*>(planes), imgs, C, h, w, sn, sc, sh, sw, rec0, rec_total);
   SDF_LAUNCH_CHECK();
   return 0;
@@ -592,7 +592,7 @@ extern "C" int sdf_unpack_planes(const void* planes, float* x, int imgs, int C, 
   if (!sdf_aligned(planes, 16)) return SDF_E_ALIGN;
   const int nch = (C + 15) / 16;
   const int64_t total = (int64_t)imgs * nch * 4 * H * W;
-  hipLaunchKernelGGL(sdfmm::unpack_planes_kernel, dim3(planes_grid(total)), dim3(256), 0, sdf_stream(stream),
+  SDF_LAUNCH(sdfmm::unpack_planes_kernel, dim3(planes_grid(total)), dim3(256), 0, sdf_stream(stream),
                      reinterpret_cast<const sdfmm::u32x4*>(planes), x, imgs, C, nch, H, W);
   SDF_LAUNCH_CHECK();
   return 0;

@@ -239,7 +239,7 @@ extern "C" int sdf_dense_linear_fwd(const SdfDenseLinearDesc* d, void* stream) {
   const bool xcd = [] { const char* e = sdf_sw(SW_DENSE_LINEAR_XCD); return !e || e[0] != '0'; }();
   P.xcd = xcd ? 1 : 0;
   const int64_t tiles = (int64_t)((d->M + BM - 1) / BM) * P.tiles_n;
-  hipLaunchKernelGGL(dense_linear_kernel, dim3((unsigned)tiles), dim3(256), 0, sdf_stream(stream), P);
+  SDF_LAUNCH(dense_linear_kernel, dim3((unsigned)tiles), dim3(256), 0, sdf_stream(stream), P);
   SDF_LAUNCH_CHECK();
   return 0;
 }

@@ -43,7 +43,7 @@ extern "C" int sdf_affine_resid_fwd(const float* x, const float* alpha, const fl
   if (!sdf_aligned(x, 16) || !sdf_aligned(out, 16) || (resid && !sdf_aligned(resid, 16))) return SDF_E_ALIGN;
   if (inner == 1 && (!sdf_aligned(alpha, 16) || !sdf_aligned(beta, 16))) return SDF_E_ALIGN;
   int64_t quads = n / 4;
-  hipLaunchKernelGGL(affine_resid_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, sdf_stream(stream), x,
+  SDF_LAUNCH(affine_resid_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, sdf_stream(stream), x,
                      alpha, beta, resid, out, quads, C, inner);
   SDF_LAUNCH_CHECK();
   return 0;
@@ -79,7 +79,7 @@ extern "C" int sdf_rows_gather_fwd(const float* x, const int32_t* map, float* ou
   if (!x || !map || !out) return SDF_E_NULL;
   if (M < 1 || C < 4 || C % 4) return SDF_E_SHAPE;
   if (!sdf_aligned(x, 16) || !sdf_aligned(out, 16)) return SDF_E_ALIGN;
-  hipLaunchKernelGGL((rows_move_kernel<false>), dim3((unsigned)((M * (C / 4) + 255) / 256)), dim3(256), 0, sdf_stream(stream), x, map,
+  SDF_LAUNCH((rows_move_kernel<false>), dim3((unsigned)((M * (C / 4) + 255) / 256)), dim3(256), 0, sdf_stream(stream), x, map,
                      out, M, C / 4);
   SDF_LAUNCH_CHECK();
   return 0;
@@ -89,7 +89,7 @@ extern "C" int sdf_rows_scatter_fwd(const float* y, const int32_t* map, float* o
   if (!y || !map || !out) return SDF_E_NULL;
   if (M < 1 || C < 4 || C % 4) return SDF_E_SHAPE;
   if (!sdf_aligned(y, 16) || !sdf_aligned(out, 16)) return SDF_E_ALIGN;
-  hipLaunchKernelGGL((rows_move_kernel<true>), dim3((unsigned)((M * (C / 4) + 255) / 256)), dim3(256), 0, sdf_stream(stream), y, map,
+  SDF_LAUNCH((rows_move_kernel<true>), dim3((unsigned)((M * (C / 4) + 255) / 256)), dim3(256), 0, sdf_stream(stream), y, map,
                      out, M, C / 4);
   SDF_LAUNCH_CHECK();
   return 0;
@@ -149,12 +149,12 @@ int launch_layer_norm(const float* x, const float* g, const float* b, float* out
   const int V = (C + 4 * L - 1) / (4 * L);
   const dim3 grid((unsigned)((rows * L + 255) / 256));
   switch (V) {
-    case 1: hipLaunchKernelGGL((layer_norm_kernel<L, 1>), grid, dim3(256), 0, s, x, g, b, out, rows, C, eps); break;
-    case 2: hipLaunchKernelGGL((layer_norm_kernel<L, 2>), grid, dim3(256), 0, s, x, g, b, out, rows, C, eps); break;
-    case 3: hipLaunchKernelGGL((layer_norm_kernel<L, 3>), grid, dim3(256), 0, s, x, g, b, out, rows, C, eps); break;
-    case 4: hipLaunchKernelGGL((layer_norm_kernel<L, 4>), grid, dim3(256), 0, s, x, g, b, out, rows, C, eps); break;
-    case 5: case 6: hipLaunchKernelGGL((layer_norm_kernel<L, 6>), grid, dim3(256), 0, s, x, g, b, out, rows, C, eps); break;
-    case 7: case 8: hipLaunchKernelGGL((layer_norm_kernel<L, 8>), grid, dim3(256), 0, s, x, g, b, out, rows, C, eps); break;
+    case 1: SDF_LAUNCH((layer_norm_kernel<L, 1>), grid, dim3(256), 0, s, x, g, b, out, rows, C, eps); break;
+    case 2: SDF_LAUNCH((layer_norm_kernel<L, 2>), grid, dim3(256), 0, s, x, g, b, out, rows, C, eps); break;
+    case 3: SDF_LAUNCH((layer_norm_kernel<L, 3>), grid, dim3(256), 0, s, x, g, b, out, rows, C, eps); break;
+    case 4: SDF_LAUNCH((layer_norm_kernel<L, 4>), grid, dim3(256), 0, s, x, g, b, out, rows, C, eps); break;
+    case 5: case 6: SDF_LAUNCH((layer_norm_kernel<L, 6>), grid, dim3(256), 0, s, x, g, b, out, rows, C, eps); break;
+    case 7: case 8: SDF_LAUNCH((layer_norm_kernel<L, 8>), grid, dim3(256), 0, s, x, g, b, out, rows, C, eps); break;
     default: return SDF_E_SHAPE;
   }
   return 0;

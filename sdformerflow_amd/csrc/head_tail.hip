@@ -429,16 +429,16 @@ int launch_head_mfma(const HeadParams& P, hipStream_t s) {
   dim3 grid((unsigned)(want < 768 ? want : 768));                  // three workgroups per CU are resident; the rest of the tiles loop
   if (P.d.sn_kind == SDF_PSN) {
     if constexpr (T <= 10) {
-      if (P.d.Cin == 2 && P.d.Cout == 48) { hipLaunchKernelGGL((head_conv_mfma_psn_kernel<T, 2, 48>), grid, dim3(256), 0, s, P, tiles); return 0; }
-      if (P.d.Cin == 2 && P.d.Cout == 32) { hipLaunchKernelGGL((head_conv_mfma_psn_kernel<T, 2, 32>), grid, dim3(256), 0, s, P, tiles); return 0; }
+      if (P.d.Cin == 2 && P.d.Cout == 48) { SDF_LAUNCH((head_conv_mfma_psn_kernel<T, 2, 48>), grid, dim3(256), 0, s, P, tiles); return 0; }
+      if (P.d.Cin == 2 && P.d.Cout == 32) { SDF_LAUNCH((head_conv_mfma_psn_kernel<T, 2, 32>), grid, dim3(256), 0, s, P, tiles); return 0; }
     }
     return SDF_E_SHAPE;
   }
   const bool fast = P.d.sn_kind == SDF_LIF && P.d.soft_reset != 0 && P.inv_tau != 0.f;
 #define SDF_HEAD_CASE(CI, CO)                                                                                              \
   if (P.d.Cin == CI && P.d.Cout == CO) {                                                                                   \
-    if (fast) hipLaunchKernelGGL((head_conv_mfma_kernel<T, CI, CO, true>), grid, dim3(256), 0, s, P, tiles);               \
-    else hipLaunchKernelGGL((head_conv_mfma_kernel<T, CI, CO, false>), grid, dim3(256), 0, s, P, tiles);                   \
+    if (fast) SDF_LAUNCH((head_conv_mfma_kernel<T, CI, CO, true>), grid, dim3(256), 0, s, P, tiles);               \
+    else SDF_LAUNCH((head_conv_mfma_kernel<T, CI, CO, false>), grid, dim3(256), 0, s, P, tiles);                   \
     return 0;                                                                                                              \
   }
   SDF_HEAD_CASE(2, 48) SDF_HEAD_CASE(2, 32) SDF_HEAD_CASE(2, 64) SDF_HEAD_CASE(4, 48)
@@ -448,10 +448,10 @@ int launch_head_mfma(const HeadParams& P, hipStream_t s) {
 
 template <int T>
 int launch_head(const HeadParams& P, dim3 grid, hipStream_t s) {
-  if (P.d.Cin == 2 && P.d.Cout == 48) { hipLaunchKernelGGL((head_conv_sn_kernel<T, 3, 2>), grid, dim3(256), 0, s, P); return 0; }
-  if (P.d.Cin == 2 && P.d.Cout == 32) { hipLaunchKernelGGL((head_conv_sn_kernel<T, 2, 2>), grid, dim3(256), 0, s, P); return 0; }
-  if (P.d.Cin == 2 && P.d.Cout == 64) { hipLaunchKernelGGL((head_conv_sn_kernel<T, 4, 2>), grid, dim3(256), 0, s, P); return 0; }
-  if (P.d.Cin == 4 && P.d.Cout == 48) { hipLaunchKernelGGL((head_conv_sn_kernel<T, 3, 4>), grid, dim3(256), 0, s, P); return 0; }
+  if (P.d.Cin == 2 && P.d.Cout == 48) { SDF_LAUNCH((head_conv_sn_kernel<T, 3, 2>), grid, dim3(256), 0, s, P); return 0; }
+  if (P.d.Cin == 2 && P.d.Cout == 32) { SDF_LAUNCH((head_conv_sn_kernel<T, 2, 2>), grid, dim3(256), 0, s, P); return 0; }
+  if (P.d.Cin == 2 && P.d.Cout == 64) { SDF_LAUNCH((head_conv_sn_kernel<T, 4, 2>), grid, dim3(256), 0, s, P); return 0; }
+  if (P.d.Cin == 4 && P.d.Cout == 48) { SDF_LAUNCH((head_conv_sn_kernel<T, 3, 4>), grid, dim3(256), 0, s, P); return 0; }
   return SDF_E_SHAPE;
 }
 }  // namespace
@@ -515,7 +515,7 @@ extern "C" int sdf_flow_out_fwd(const float* pred, float* out, int B, int D, int
   if (!pred || !out) return SDF_E_NULL;
   if (B < 1 || D < 1 || h < 1 || w < 1 || C < 1 || H < 1 || W < 1 || ldp < C || !(scale_y > 0.f) || !(scale_x > 0.f)) return SDF_E_SHAPE;
   const int64_t n = (int64_t)B * C * H * W;
-  hipLaunchKernelGGL(flow_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sdf_stream(stream), pred, out, B, D, h, w,
+  SDF_LAUNCH(flow_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sdf_stream(stream), pred, out, B, D, h, w,
                      ldp, C, H, W, 1.0f / scale_y, 1.0f / scale_x);
   SDF_LAUNCH_CHECK();
   return 0;
@@ -529,7 +529,7 @@ extern "C" int sdf_deconv_col2im_fwd(const float* Y, const float* alpha, const f
   if (!sdf_aligned(Y, 16) || !sdf_aligned(out, 16) || (alpha && (!sdf_aligned(alpha, 16) || !sdf_aligned(beta, 16)))) return SDF_E_ALIGN;
   const int64_t n = (int64_t)imgs * 4 * H * W * (Cout / 4);
   if ((n + 255) / 256 >= (1LL << 31)) return SDF_E_SHAPE;
-  hipLaunchKernelGGL(deconv_col2im_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sdf_stream(stream), Y, alpha, beta, out,
+  SDF_LAUNCH(deconv_col2im_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sdf_stream(stream), Y, alpha, beta, out,
                      imgs, H, W, Cout);
   SDF_LAUNCH_CHECK();
   return 0;

@@ -354,12 +354,12 @@ extern "C" int sdf_linear_dw_fwd(const SdfLinearDwDesc* d, void* stream) {
   const int64_t wgs = (int64_t)d->nsplit * P.tiles_n * P.tiles_k;
   if (wgs >= lim) return SDF_E_SHAPE;
   hipStream_t s = sdf_stream(stream);
-  if (conv) hipLaunchKernelGGL(linear_dw_kernel<3>, dim3((unsigned)wgs), dim3(256), 0, s, P);
-  else hipLaunchKernelGGL(linear_dw_kernel<1>, dim3((unsigned)wgs), dim3(256), 0, s, P);
+  if (conv) SDF_LAUNCH(linear_dw_kernel<3>, dim3((unsigned)wgs), dim3(256), 0, s, P);
+  else SDF_LAUNCH(linear_dw_kernel<1>, dim3((unsigned)wgs), dim3(256), 0, s, P);
   SDF_LAUNCH_CHECK();
   if (d->nsplit > 1) {
     const int n4 = d->N * d->K / 4;
-    hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, d->partial, d->dw, n4, d->nsplit);
+    SDF_LAUNCH(linear_dw_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, d->partial, d->dw, n4, d->nsplit);
     SDF_LAUNCH_CHECK();
   }
   return 0;
@@ -369,7 +369,7 @@ extern "C" int sdf_ringed_rows_fwd(const float* src, float* dst, int imgs, int C
   if (!src || !dst) return SDF_E_NULL;
   if (imgs < 1 || C < 96 || C % 96 || H < 1 || W < 1 || H + 2 > 65535 || (int64_t)imgs * (C / 96) > 65535) return SDF_E_SHAPE;
   const dim3 grid((unsigned)((W + 2 + 63) / 64), (unsigned)(H + 2), (unsigned)(imgs * (C / 96)));
-  hipLaunchKernelGGL(ringed_rows_kernel, grid, dim3(256), 0, sdf_stream(stream), src, dst, C, H, W);
+  SDF_LAUNCH(ringed_rows_kernel, grid, dim3(256), 0, sdf_stream(stream), src, dst, C, H, W);
   SDF_LAUNCH_CHECK();
   return 0;
 }
@@ -378,7 +378,7 @@ extern "C" int sdf_unring_rows_fwd(const float* src, const float* bias, float* d
   if (!src || !dst) return SDF_E_NULL;
   if (imgs < 1 || C < 96 || C % 96 || H < 1 || W < 1 || H > 65535 || (int64_t)imgs * (C / 96) > 65535) return SDF_E_SHAPE;
   const dim3 grid((unsigned)((W + 63) / 64), (unsigned)H, (unsigned)(imgs * (C / 96)));
-  hipLaunchKernelGGL(unring_rows_kernel, grid, dim3(256), 0, sdf_stream(stream), src, bias, dst, C, H, W);
+  SDF_LAUNCH(unring_rows_kernel, grid, dim3(256), 0, sdf_stream(stream), src, bias, dst, C, H, W);
   SDF_LAUNCH_CHECK();
   return 0;
 }

@@ -250,8 +250,8 @@ extern "C" int sdf_linear_train_fwd(const SdfLinearTrainDesc* d, void* stream) {
   P.cchunks = d->cv_C > 0 ? d->cv_C / RC : 0;
   const int64_t wgs = (int64_t)((d->M + BM - 1) / BM) * P.tiles_c;
   hipStream_t s = sdf_stream(stream);
-  if (d->mode == 0) hipLaunchKernelGGL(linear_train_kernel<0>, dim3((unsigned)wgs), dim3(256), 0, s, P);
-  else hipLaunchKernelGGL(linear_train_kernel<1>, dim3((unsigned)wgs), dim3(256), 0, s, P);
+  if (d->mode == 0) SDF_LAUNCH(linear_train_kernel<0>, dim3((unsigned)wgs), dim3(256), 0, s, P);
+  else SDF_LAUNCH(linear_train_kernel<1>, dim3((unsigned)wgs), dim3(256), 0, s, P);
   SDF_LAUNCH_CHECK();
   return 0;
 }

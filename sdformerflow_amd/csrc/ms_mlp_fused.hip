@@ -452,8 +452,8 @@ int launch_one(const MlpFusedParams& P, hipStream_t s) {
   const dim3 grid((unsigned)wgs), block(G::NTW);
   const bool keep = P.keep_s1 != nullptr;                             // the parity tape: both spike tensors also go to memory
 #define SDF_MLP_LAUNCH(NK)                                                                                              \
-  if (keep) hipLaunchKernelGGL((ms_mlp_fused_kernel<NSPLIT, T, C16, CG, NB1, RG, TEAMS, NK, true>), grid, block, 0, s, P);     \
-  else hipLaunchKernelGGL((ms_mlp_fused_kernel<NSPLIT, T, C16, CG, NB1, RG, TEAMS, NK, false>), grid, block, 0, s, P);
+  if (keep) SDF_LAUNCH((ms_mlp_fused_kernel<NSPLIT, T, C16, CG, NB1, RG, TEAMS, NK, true>), grid, block, 0, s, P);     \
+  else SDF_LAUNCH((ms_mlp_fused_kernel<NSPLIT, T, C16, CG, NB1, RG, TEAMS, NK, false>), grid, block, 0, s, P);
   switch (neuron_class(P.sn1)) {
     case 0: SDF_MLP_LAUNCH(0) break;
     case 1:

@@ -609,11 +609,11 @@ int res_pm_launch(const WidePmParams& P, dim3 grid, size_t lds, hipStream_t s) {
   if (P.K <= 256) {
     auto kern = res_pm_kernel<T, EPI, NK, AM, true, STRIP>;
     if (int rc = res_raise(kern)) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), lds, s, P);
+    SDF_LAUNCH(kern, grid, dim3(64 * NWV), lds, s, P);
   } else {
     auto kern = res_pm_kernel<T, EPI, NK, AM, false, STRIP>;
     if (int rc = res_raise(kern)) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), lds, s, P);
+    SDF_LAUNCH(kern, grid, dim3(64 * NWV), lds, s, P);
   }
   return 0;
 }
@@ -715,9 +715,9 @@ int launch_res_front(WideFrontParams& P, bool keep, int nk, hipStream_t s) {
 #define SDF_RF(NK_)                                                                                       \
   do {                                                                                                    \
     if (keep) { auto kern = res_front_kernel<NK_, true>; if (int rc = res_raise(kern)) return rc;        \
-                hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), lds, s, P); }                             \
+                SDF_LAUNCH(kern, grid, dim3(64 * NWV), lds, s, P); }                             \
     else { auto kern = res_front_kernel<NK_, false>; if (int rc = res_raise(kern)) return rc;            \
-           hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), lds, s, P); }                                  \
+           SDF_LAUNCH(kern, grid, dim3(64 * NWV), lds, s, P); }                                  \
   } while (0)
   if (nk == 0) SDF_RF(0); else if (nk == 1) SDF_RF(1); else SDF_RF(2);
 #undef SDF_RF

@@ -420,15 +420,15 @@ __global__ __launch_bounds__(256, CB == 2 ? 2 : 1) void smallm_kernel(SmallMPara
 
 template <int T, int AM, bool BT, int CB>
 void launch_t(const SmallMParams& P, int epi, int nk, dim3 grid, hipStream_t s) {
-  if (epi == 2) hipLaunchKernelGGL((smallm_kernel<T, 2, 0, AM, BT, CB>), grid, dim3(256), 0, s, P);
+  if (epi == 2) SDF_LAUNCH((smallm_kernel<T, 2, 0, AM, BT, CB>), grid, dim3(256), 0, s, P);
   else if (epi == 1) {
-    if (nk == 0) hipLaunchKernelGGL((smallm_kernel<T, 1, 0, AM, BT, CB>), grid, dim3(256), 0, s, P);
-    else if (nk == 1) hipLaunchKernelGGL((smallm_kernel<T, 1, 1, AM, BT, CB>), grid, dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((smallm_kernel<T, 1, 2, AM, BT, CB>), grid, dim3(256), 0, s, P);
+    if (nk == 0) SDF_LAUNCH((smallm_kernel<T, 1, 0, AM, BT, CB>), grid, dim3(256), 0, s, P);
+    else if (nk == 1) SDF_LAUNCH((smallm_kernel<T, 1, 1, AM, BT, CB>), grid, dim3(256), 0, s, P);
+    else SDF_LAUNCH((smallm_kernel<T, 1, 2, AM, BT, CB>), grid, dim3(256), 0, s, P);
   } else {
-    if (nk == 0) hipLaunchKernelGGL((smallm_kernel<T, 3, 0, AM, BT, CB>), grid, dim3(256), 0, s, P);
-    else if (nk == 1) hipLaunchKernelGGL((smallm_kernel<T, 3, 1, AM, BT, CB>), grid, dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((smallm_kernel<T, 3, 2, AM, BT, CB>), grid, dim3(256), 0, s, P);
+    if (nk == 0) SDF_LAUNCH((smallm_kernel<T, 3, 0, AM, BT, CB>), grid, dim3(256), 0, s, P);
+    else if (nk == 1) SDF_LAUNCH((smallm_kernel<T, 3, 1, AM, BT, CB>), grid, dim3(256), 0, s, P);
+    else SDF_LAUNCH((smallm_kernel<T, 3, 2, AM, BT, CB>), grid, dim3(256), 0, s, P);
   }
 }
 
@@ -590,8 +590,8 @@ int launch_smallm_gemm(const GemmParams& G, hipStream_t s) {
   const int64_t items = (int64_t)P.ncg * P.nunits;
   if (items >= (1LL << 31) - 8) return SDF_E_SHAPE;
   const dim3 grid((unsigned)((items + 7) / 8 * 8));
-  if (cb == 3) hipLaunchKernelGGL((smallm_kernel<10, 2, 0, 0, true, 3>), grid, dim3(256), 0, s, P);
-  else hipLaunchKernelGGL((smallm_kernel<10, 2, 0, 0, true, 2>), grid, dim3(256), 0, s, P);
+  if (cb == 3) SDF_LAUNCH((smallm_kernel<10, 2, 0, 0, true, 3>), grid, dim3(256), 0, s, P);
+  else SDF_LAUNCH((smallm_kernel<10, 2, 0, 0, true, 2>), grid, dim3(256), 0, s, P);
   hipError_t e = hipGetLastError();
   return e != hipSuccess ? (int)e : 0;
 }
@@ -610,7 +610,7 @@ extern "C" int sdf_tile_weight_i8x3(const int8_t* planes, int8_t* tiled, int N, 
   if (N < 16 || N % 16 || K < 64 || K % 64 || (int64_t)3 * N * K >= (1LL << 31)) return SDF_E_SHAPE;
   if (!sdf_aligned(planes, 16) || !sdf_aligned(tiled, 16)) return SDF_E_ALIGN;
   const int64_t total = (int64_t)3 * N * (K >> 4);
-  hipLaunchKernelGGL(sdfmm::tile_weight_i8x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sdf_stream(stream), planes, tiled, N, K);
+  SDF_LAUNCH(sdfmm::tile_weight_i8x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sdf_stream(stream), planes, tiled, N, K);
   SDF_LAUNCH_CHECK();
   return 0;
 }

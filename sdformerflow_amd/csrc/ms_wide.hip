@@ -753,11 +753,11 @@ int pick_cb(int64_t units, int N, const int* cbs, int ncb) {
 template <int T, int CB, int EPI>
 int launch_pm_nk(const WidePmParams& P, int nk, dim3 grid, hipStream_t s) {
   if constexpr (EPI == 2) {
-    hipLaunchKernelGGL((wide_pm_kernel<T, CB, EPI, 0>), grid, dim3(256), 0, s, P);
+    SDF_LAUNCH((wide_pm_kernel<T, CB, EPI, 0>), grid, dim3(256), 0, s, P);
   } else {
-    if (nk == 0) hipLaunchKernelGGL((wide_pm_kernel<T, CB, EPI, 0>), grid, dim3(256), 0, s, P);
-    else if (nk == 1) hipLaunchKernelGGL((wide_pm_kernel<T, CB, EPI, 1>), grid, dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((wide_pm_kernel<T, CB, EPI, 2>), grid, dim3(256), 0, s, P);
+    if (nk == 0) SDF_LAUNCH((wide_pm_kernel<T, CB, EPI, 0>), grid, dim3(256), 0, s, P);
+    else if (nk == 1) SDF_LAUNCH((wide_pm_kernel<T, CB, EPI, 1>), grid, dim3(256), 0, s, P);
+    else SDF_LAUNCH((wide_pm_kernel<T, CB, EPI, 2>), grid, dim3(256), 0, s, P);
   }
   return 0;
 }
@@ -922,8 +922,8 @@ int launch_wide_merge(const SdfMsMergeDesc* d, hipStream_t s) {
   P.passes = all > 256 && all <= 1024 ? (int)((all + 255) / 256) : 1;
   const int64_t items = (int64_t)P.ncg * ((P.nrg + P.passes - 1) / P.passes);
   const dim3 grid((unsigned)((items + 7) / 8 * 8));
-  if (T == 10) hipLaunchKernelGGL((wide_pm_kernel<10, 2, 2, 0, 2>), grid, dim3(256), 0, s, P);
-  else hipLaunchKernelGGL((wide_pm_kernel<20, 2, 2, 0, 2>), grid, dim3(256), 0, s, P);
+  if (T == 10) SDF_LAUNCH((wide_pm_kernel<10, 2, 2, 0, 2>), grid, dim3(256), 0, s, P);
+  else SDF_LAUNCH((wide_pm_kernel<20, 2, 2, 0, 2>), grid, dim3(256), 0, s, P);
   hipError_t e = hipGetLastError();
   return e != hipSuccess ? (int)e : 0;
 }
@@ -990,8 +990,8 @@ int launch_ms_wide_front(const SdfQkAttnDesc* d, const uint8_t* xs, uint8_t* e, 
   const int nk = neuron_class(d->sn_q);
 #define SDF_WF(RB_, NK_)                                                                                  \
   do {                                                                                                    \
-    if (keep) hipLaunchKernelGGL((wide_front_kernel<RB_, NK_, true>), grid, dim3(256), 0, s, P);          \
-    else hipLaunchKernelGGL((wide_front_kernel<RB_, NK_, false>), grid, dim3(256), 0, s, P);              \
+    if (keep) SDF_LAUNCH((wide_front_kernel<RB_, NK_, true>), grid, dim3(256), 0, s, P);          \
+    else SDF_LAUNCH((wide_front_kernel<RB_, NK_, false>), grid, dim3(256), 0, s, P);              \
   } while (0)
   if (big) { if (nk == 0) SDF_WF(4, 0); else if (nk == 1) SDF_WF(4, 1); else SDF_WF(4, 2); }
   else { if (nk == 0) SDF_WF(2, 0); else if (nk == 1) SDF_WF(2, 1); else SDF_WF(2, 2); }
@@ -1073,8 +1073,8 @@ int launch_wide_conv(const GemmParams& G, hipStream_t s) {
   P.passes = P.nrg;                                         // one workgroup per (column group, K range) walks every row group
   const int64_t items = (int64_t)ncg * ks;
   const dim3 grid((unsigned)((items + 7) / 8 * 8));
-  if (T == 10) hipLaunchKernelGGL((wide_pm_kernel<10, 2, 4, 0>), grid, dim3(256), 0, s, P);
-  else hipLaunchKernelGGL((wide_pm_kernel<20, 2, 4, 0>), grid, dim3(256), 0, s, P);
+  if (T == 10) SDF_LAUNCH((wide_pm_kernel<10, 2, 4, 0>), grid, dim3(256), 0, s, P);
+  else SDF_LAUNCH((wide_pm_kernel<20, 2, 4, 0>), grid, dim3(256), 0, s, P);
   WideReduceParams R = {};
   R.partial = P.partial; R.ksplit = ks; R.N = d.N; R.HW = (int)hw; R.P = P.P;
   R.alpha = d.alpha; R.beta = d.beta; R.resid = d.resid; R.out = d.out; R.out_spike = d.sn_T > 0 ? d.out_spike : nullptr;
@@ -1083,8 +1083,8 @@ int launch_wide_conv(const GemmParams& G, hipStream_t s) {
   const int64_t nthr = R.P * (d.N / 4);
   const dim3 rgrid((unsigned)((nthr + 255) / 256));
   const int nk = d.sn_T > 0 ? neuron_class(R.sn) : 0;
-  if (T == 10) { if (nk == 0) hipLaunchKernelGGL((wide_reduce_kernel<10, 0>), rgrid, dim3(256), 0, s, R); else hipLaunchKernelGGL((wide_reduce_kernel<10, 2>), rgrid, dim3(256), 0, s, R); }
-  else { if (nk == 0) hipLaunchKernelGGL((wide_reduce_kernel<20, 0>), rgrid, dim3(256), 0, s, R); else hipLaunchKernelGGL((wide_reduce_kernel<20, 2>), rgrid, dim3(256), 0, s, R); }
+  if (T == 10) { if (nk == 0) SDF_LAUNCH((wide_reduce_kernel<10, 0>), rgrid, dim3(256), 0, s, R); else SDF_LAUNCH((wide_reduce_kernel<10, 2>), rgrid, dim3(256), 0, s, R); }
+  else { if (nk == 0) SDF_LAUNCH((wide_reduce_kernel<20, 0>), rgrid, dim3(256), 0, s, R); else SDF_LAUNCH((wide_reduce_kernel<20, 2>), rgrid, dim3(256), 0, s, R); }
   hipError_t e = hipGetLastError();
   return e != hipSuccess ? (int)e : 0;
 }
@@ -1112,7 +1112,7 @@ extern "C" int sdf_window_zsrc_map(const int32_t* slice_map, int64_t B_, int Tq,
   if (B_ < 1 || Tq < 1 || N1 < 1 || nH < 1) return SDF_E_SHAPE;
   const int64_t total = B_ * Tq * N1;
   if (total * nH * 32 >= (1LL << 31)) return SDF_E_SHAPE;
-  hipLaunchKernelGGL(sdfmm::zsrc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sdf_stream(stream), slice_map, x_src, B_, Tq,
+  SDF_LAUNCH(sdfmm::zsrc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sdf_stream(stream), slice_map, x_src, B_, Tq,
                      N1, nH, total);
   SDF_LAUNCH_CHECK();
   return 0;

@@ -245,7 +245,7 @@ int launch_scalar(const float* x, void* spike, float* v_last, int T, int64_t N, 
   if (kind == SDF_PSN && (!W || !b)) return SDF_E_NULL;
   if (!sdf_tau_ok(kind, tau)) return SDF_E_SHAPE;
   const float inv_tau = sdf_inv_tau(kind, tau);
-  hipLaunchKernelGGL(neuron_scalar_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, sdf_stream(stream), x, spike, v_last, T, N,
+  SDF_LAUNCH(neuron_scalar_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, sdf_stream(stream), x, spike, v_last, T, N,
                      kind, tau, inv_tau, v_th, v_reset, soft_reset, spike_dtype, W, b);
   SDF_LAUNCH_CHECK();
   return 0;
@@ -293,12 +293,12 @@ extern "C" int sdf_neuron_fwd(const SdfNeuronDesc* dp, void* stream) {
   P.inv_tau = sdf_inv_tau(dp->kind, dp->tau);
   dim3 grid((unsigned)((P.quads + 255) / 256)), block(256);
   hipStream_t s = sdf_stream(stream);
-#define SDF_T_CASE(TT) case TT: hipLaunchKernelGGL(neuron_kernel<TT>, grid, block, 0, s, P); break;
+#define SDF_T_CASE(TT) case TT: SDF_LAUNCH(neuron_kernel<TT>, grid, block, 0, s, P); break;
   switch (dp->T) {
     SDF_T_CASE(1) SDF_T_CASE(2) SDF_T_CASE(4) SDF_T_CASE(5) SDF_T_CASE(8) SDF_T_CASE(10) SDF_T_CASE(16) SDF_T_CASE(20)
     default:
       if (dp->kind == SDF_PSN) return SDF_E_SHAPE;
-      hipLaunchKernelGGL(neuron_kernel<0>, grid, block, 0, s, P);
+      SDF_LAUNCH(neuron_kernel<0>, grid, block, 0, s, P);
   }
 #undef SDF_T_CASE
   SDF_LAUNCH_CHECK();
@@ -340,11 +340,11 @@ extern "C" int sdf_neuron_multi_fwd(const SdfNeuronDesc* descs, int n, void* str
   dim3 grid((unsigned)wgs), block(256);
   hipStream_t s = sdf_stream(stream);
   switch (T) {
-    case 2: hipLaunchKernelGGL(neuron_multi_kernel<2>, grid, block, 0, s, M); break;
-    case 4: hipLaunchKernelGGL(neuron_multi_kernel<4>, grid, block, 0, s, M); break;
-    case 5: hipLaunchKernelGGL(neuron_multi_kernel<5>, grid, block, 0, s, M); break;
-    case 10: hipLaunchKernelGGL(neuron_multi_kernel<10>, grid, block, 0, s, M); break;
-    default: hipLaunchKernelGGL(neuron_multi_kernel<20>, grid, block, 0, s, M); break;
+    case 2: SDF_LAUNCH(neuron_multi_kernel<2>, grid, block, 0, s, M); break;
+    case 4: SDF_LAUNCH(neuron_multi_kernel<4>, grid, block, 0, s, M); break;
+    case 5: SDF_LAUNCH(neuron_multi_kernel<5>, grid, block, 0, s, M); break;
+    case 10: SDF_LAUNCH(neuron_multi_kernel<10>, grid, block, 0, s, M); break;
+    default: SDF_LAUNCH(neuron_multi_kernel<20>, grid, block, 0, s, M); break;
   }
   SDF_LAUNCH_CHECK();
   return 0;

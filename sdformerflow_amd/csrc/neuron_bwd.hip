@@ -257,7 +257,7 @@ extern "C" int sdf_lif_bwd(const float* x, const float* grad_spike, float* grad_
   P.half_alpha = (float)((double)alpha / 2);
   dim3 grid((unsigned)((N / 4 + 255) / 256)), block(256);
   hipStream_t s = sdf_stream(stream);
-#define SDF_T_CASE(TT) case TT: hipLaunchKernelGGL(lif_bwd_kernel<TT>, grid, block, 0, s, P); break;
+#define SDF_T_CASE(TT) case TT: SDF_LAUNCH(lif_bwd_kernel<TT>, grid, block, 0, s, P); break;
   switch (T) {
     SDF_T_CASE(1) SDF_T_CASE(2) SDF_T_CASE(4) SDF_T_CASE(5) SDF_T_CASE(8) SDF_T_CASE(10) SDF_T_CASE(16) SDF_T_CASE(20)
     default: return SDF_E_SHAPE;
@@ -294,10 +294,10 @@ extern "C" int sdf_psn_bwd(const float* x, const float* W, const float* b, const
   hipStream_t s = sdf_stream(stream);
 #define SDF_T_CASE(TT, V)                                                                  \
   case TT:                                                                                 \
-    if (reduce) hipLaunchKernelGGL((psn_bwd_kernel<TT, true, V>), grid, block, 0, s, P);   \
-    else hipLaunchKernelGGL((psn_bwd_kernel<TT, false, 4>), grid, block, 0, s, P);         \
+    if (reduce) SDF_LAUNCH((psn_bwd_kernel<TT, true, V>), grid, block, 0, s, P);   \
+    else SDF_LAUNCH((psn_bwd_kernel<TT, false, 4>), grid, block, 0, s, P);         \
     break;
-#define SDF_T_CASE_NR(TT) case TT: hipLaunchKernelGGL((psn_bwd_kernel<TT, false, 4>), grid, block, 0, s, P); break;
+#define SDF_T_CASE_NR(TT) case TT: SDF_LAUNCH((psn_bwd_kernel<TT, false, 4>), grid, block, 0, s, P); break;
   switch (T) {
     SDF_T_CASE(1, 4) SDF_T_CASE(2, 4) SDF_T_CASE(4, 4) SDF_T_CASE(5, 4) SDF_T_CASE(8, 2) SDF_T_CASE(10, 2)
     SDF_T_CASE_NR(16) SDF_T_CASE_NR(20)
@@ -308,7 +308,7 @@ extern "C" int sdf_psn_bwd(const float* x, const float* W, const float* b, const
   SDF_LAUNCH_CHECK();
   if (reduce) {
     const int nacc = T * T + T;
-    hipLaunchKernelGGL(psn_bwd_finish_kernel, dim3(nacc), dim3(256), 0, s, P.partial, nblk, nacc, T, grad_W, grad_b);
+    SDF_LAUNCH(psn_bwd_finish_kernel, dim3(nacc), dim3(256), 0, s, P.partial, nblk, nacc, T, grad_W, grad_b);
     SDF_LAUNCH_CHECK();
   }
   return 0;

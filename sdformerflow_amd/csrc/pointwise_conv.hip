@@ -82,8 +82,8 @@ extern "C" int sdf_pointwise_conv_f32_fwd(const SdfPointwiseConvDesc* d, void* s
   PwParams P;
   P.d = *d;
   hipStream_t s = sdf_stream(stream);
-  if (d->N == 96) hipLaunchKernelGGL((pointwise_conv_f32_kernel<96, 3>), dim3((unsigned)wgs), dim3(256), 0, s, P);
-  else hipLaunchKernelGGL((pointwise_conv_f32_kernel<96, 6>), dim3((unsigned)wgs), dim3(256), 0, s, P);
+  if (d->N == 96) SDF_LAUNCH((pointwise_conv_f32_kernel<96, 3>), dim3((unsigned)wgs), dim3(256), 0, s, P);
+  else SDF_LAUNCH((pointwise_conv_f32_kernel<96, 6>), dim3((unsigned)wgs), dim3(256), 0, s, P);
   SDF_LAUNCH_CHECK();
   return 0;
 }

@@ -151,11 +151,11 @@ __global__ __launch_bounds__(256) void pred_head_kernel(PredParams P) {
 template <int T, int LPP>
 int launch_nk(const PredParams& P, int nk, dim3 grid, hipStream_t s) {
   switch (nk) {
-    case 0: hipLaunchKernelGGL((pred_head_kernel<T, LPP, 0>), grid, dim3(256), 0, s, P); return 0;
+    case 0: SDF_LAUNCH((pred_head_kernel<T, LPP, 0>), grid, dim3(256), 0, s, P); return 0;
     case 1:
-      if constexpr (T <= 10) { hipLaunchKernelGGL((pred_head_kernel<T, LPP, 1>), grid, dim3(256), 0, s, P); return 0; }
+      if constexpr (T <= 10) { SDF_LAUNCH((pred_head_kernel<T, LPP, 1>), grid, dim3(256), 0, s, P); return 0; }
       return SDF_E_SHAPE;
-    default: hipLaunchKernelGGL((pred_head_kernel<T, LPP, 2>), grid, dim3(256), 0, s, P); return 0;
+    default: SDF_LAUNCH((pred_head_kernel<T, LPP, 2>), grid, dim3(256), 0, s, P); return 0;
   }
 }
 

@@ -52,7 +52,7 @@ extern "C" int sdf_window_slice_map(int32_t* map, int B, int D, int H, int W, in
   const int64_t B_ = (int64_t)B * nD * nHb * nWb, total = B_ * Wd * Wh * Ww;
   if ((int64_t)B * D * H * W >= (1LL << 31) || total >= (1LL << 40)) return SDF_E_SHAPE;
   if (n_windows) *n_windows = B_;
-  hipLaunchKernelGGL(slice_map_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sdf_stream(stream), map, B, D, H, W,
+  SDF_LAUNCH(slice_map_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sdf_stream(stream), map, B, D, H, W,
                      Wd, Wh, Ww, shift_d, shift_h, shift_w, total);
   SDF_LAUNCH_CHECK();
   return 0;

@@ -259,9 +259,9 @@ __global__ __launch_bounds__(256, 3) void qk_front_kernel(QkFrontParams P) {
 template <bool KEEP>
 int launch_nk(const QkFrontParams& P, int nk, dim3 grid, hipStream_t s) {
   switch (nk) {
-    case 0: hipLaunchKernelGGL((qk_front_kernel<0, KEEP>), grid, dim3(256), 0, s, P); return 0;
-    case 1: hipLaunchKernelGGL((qk_front_kernel<1, KEEP>), grid, dim3(256), 0, s, P); return 0;
-    default: hipLaunchKernelGGL((qk_front_kernel<2, KEEP>), grid, dim3(256), 0, s, P); return 0;
+    case 0: SDF_LAUNCH((qk_front_kernel<0, KEEP>), grid, dim3(256), 0, s, P); return 0;
+    case 1: SDF_LAUNCH((qk_front_kernel<1, KEEP>), grid, dim3(256), 0, s, P); return 0;
+    default: SDF_LAUNCH((qk_front_kernel<2, KEEP>), grid, dim3(256), 0, s, P); return 0;
   }
 }
 

@@ -101,7 +101,7 @@ extern "C" int sdf_qk_gate_strided_fwd(const uint8_t* q, const uint8_t* k, uint8
   P.inv_tau = sdf_inv_tau(kind, tau);
   P.psn_w = psn_w; P.psn_b = psn_b;
   int64_t n = rows * P.G;
-  hipLaunchKernelGGL(qk_gate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sdf_stream(stream), P);
+  SDF_LAUNCH(qk_gate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sdf_stream(stream), P);
   SDF_LAUNCH_CHECK();
   return 0;
 }

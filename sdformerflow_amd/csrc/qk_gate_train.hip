@@ -203,9 +203,9 @@ int launch(const GateTrainParams& P, int Tq, hipStream_t s) {
   const int64_t lanes = P.rows * P.G * 8;
   dim3 grid((unsigned)((lanes + 255) / 256)), block(256);
   switch (Tq) {
-    case 1: hipLaunchKernelGGL((qk_gate_train_kernel<1, BWD>), grid, block, 0, s, P); break;
-    case 2: hipLaunchKernelGGL((qk_gate_train_kernel<2, BWD>), grid, block, 0, s, P); break;
-    case 4: hipLaunchKernelGGL((qk_gate_train_kernel<4, BWD>), grid, block, 0, s, P); break;
+    case 1: SDF_LAUNCH((qk_gate_train_kernel<1, BWD>), grid, block, 0, s, P); break;
+    case 2: SDF_LAUNCH((qk_gate_train_kernel<2, BWD>), grid, block, 0, s, P); break;
+    case 4: SDF_LAUNCH((qk_gate_train_kernel<4, BWD>), grid, block, 0, s, P); break;
     default: return SDF_E_SHAPE;
   }
   SDF_LAUNCH_CHECK();
@@ -255,7 +255,7 @@ extern "C" int sdf_qk_gate_bwd(const float* q, const float* k, const float* grad
   if (rc2 || kind != SDF_PSN) return rc2;
   const int64_t nblk = (rows * (C / 32) * 8 + 255) / 256;
   const int nacc = Tq * Tq + Tq;
-  hipLaunchKernelGGL(gate_finish_kernel, dim3(nacc), dim3(256), 0, sdf_stream(stream), P.partial, nblk, nacc, Tq, grad_psn_w, grad_psn_b);
+  SDF_LAUNCH(gate_finish_kernel, dim3(nacc), dim3(256), 0, sdf_stream(stream), P.partial, nblk, nacc, Tq, grad_psn_w, grad_psn_b);
   SDF_LAUNCH_CHECK();
   return 0;
 }

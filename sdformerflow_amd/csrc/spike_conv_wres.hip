@@ -853,7 +853,7 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
 template <int NSPLIT, int TT>
 int launch_c(const GemmParams& P, dim3 grid, hipStream_t s) {
   switch (P.cv.Cin) {
-    case 96: hipLaunchKernelGGL((spike_conv_wres_kernel<NSPLIT, TT, 6>), grid, dim3(512), 0, s, P); return 0;
+    case 96: SDF_LAUNCH((spike_conv_wres_kernel<NSPLIT, TT, 6>), grid, dim3(512), 0, s, P); return 0;
     default: return SDF_E_SHAPE;
   }
 }
@@ -938,19 +938,19 @@ int launch_spike_conv_wres(const GemmParams& Pin, hipStream_t s) {
     const bool g3 = d.sn_T > 0 && th == 8 && (eg ? eg[0] == '3' : true);
     const dim3 grid((unsigned)G);
     if (c.sy == 2 && c.Cin == 96) {
-      hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 3, 1, 2, true, 2>), grid, dim3(512), 0, s, P, d.col_scale);
+      SDF_LAUNCH((spike_conv_wres_i8_kernel<0, 3, 1, 2, true, 2>), grid, dim3(512), 0, s, P, d.col_scale);
     } else if (c.Cin == 48) {
-      if (d.sn_T == 0) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 3, 1, 2, true>), grid, dim3(512), 0, s, P, d.col_scale);
-      else if (g3) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 3, 1, 3, true>), grid, dim3(768), 0, s, P, d.col_scale);
-      else hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 3, 1, 2, true>), grid, dim3(512), 0, s, P, d.col_scale);
+      if (d.sn_T == 0) SDF_LAUNCH((spike_conv_wres_i8_kernel<0, 3, 1, 2, true>), grid, dim3(512), 0, s, P, d.col_scale);
+      else if (g3) SDF_LAUNCH((spike_conv_wres_i8_kernel<10, 3, 1, 3, true>), grid, dim3(768), 0, s, P, d.col_scale);
+      else SDF_LAUNCH((spike_conv_wres_i8_kernel<10, 3, 1, 2, true>), grid, dim3(512), 0, s, P, d.col_scale);
     } else
-    if (d.sn_T == 0 && th == 16) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 6, 2, 2>), grid, dim3(512), 0, s, P, d.col_scale);
-    else if (d.sn_T == 0) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<0, 6, 1, 2>), grid, dim3(512), 0, s, P, d.col_scale);
-    else if (th == 16) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 2, 2>), grid, dim3(512), 0, s, P, d.col_scale);
+    if (d.sn_T == 0 && th == 16) SDF_LAUNCH((spike_conv_wres_i8_kernel<0, 6, 2, 2>), grid, dim3(512), 0, s, P, d.col_scale);
+    else if (d.sn_T == 0) SDF_LAUNCH((spike_conv_wres_i8_kernel<0, 6, 1, 2>), grid, dim3(512), 0, s, P, d.col_scale);
+    else if (th == 16) SDF_LAUNCH((spike_conv_wres_i8_kernel<10, 6, 2, 2>), grid, dim3(512), 0, s, P, d.col_scale);
     else if (g3 && !d.out && !d.resid && !sdf_sw(SW_CONV_WRES_NOSPK))
-      hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 1, 3, false, 1, true>), grid, dim3(768), 0, s, P, d.col_scale);
-    else if (g3) hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 1, 3>), grid, dim3(768), 0, s, P, d.col_scale);
-    else hipLaunchKernelGGL((spike_conv_wres_i8_kernel<10, 6, 1, 2>), grid, dim3(512), 0, s, P, d.col_scale);
+      SDF_LAUNCH((spike_conv_wres_i8_kernel<10, 6, 1, 3, false, 1, true>), grid, dim3(768), 0, s, P, d.col_scale);
+    else if (g3) SDF_LAUNCH((spike_conv_wres_i8_kernel<10, 6, 1, 3>), grid, dim3(768), 0, s, P, d.col_scale);
+    else SDF_LAUNCH((spike_conv_wres_i8_kernel<10, 6, 1, 2>), grid, dim3(512), 0, s, P, d.col_scale);
     rc = 0;
   } else {
     const dim3 grid((unsigned)G);
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(256) void split_weight_i8x3_kernel(const float* __r
 extern "C" int sdf_split_weight_i8x3(const float* W, int8_t* planes, float* col_scale, int N, int K, void* stream) {
   if (!W || !planes || !col_scale) return SDF_E_NULL;
   if (N < 1 || K < 1) return SDF_E_SHAPE;
-  hipLaunchKernelGGL(split_weight_i8x3_kernel, dim3((unsigned)N), dim3(256), 0, sdf_stream(stream), W, planes, col_scale, N, K);
+  SDF_LAUNCH(split_weight_i8x3_kernel, dim3((unsigned)N), dim3(256), 0, sdf_stream(stream), W, planes, col_scale, N, K);
   SDF_LAUNCH_CHECK();
   return 0;
 }

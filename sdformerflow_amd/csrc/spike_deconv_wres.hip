@@ -371,7 +371,7 @@ int launch_spike_deconv_wres(const uint8_t* A, const int8_t* Wd, const float* cs
   }
   static std::atomic<uint64_t> raised{0};                  // > 64 KiB of dynamic LDS: opt-in once per device
   if (const int e = sdf_lds_opt_in(raised, reinterpret_cast<const void*>(spike_deconv_wres_kernel), LDS_BYTES)) return e;
-  hipLaunchKernelGGL(spike_deconv_wres_kernel, dim3((unsigned)grid), dim3(NT), LDS_BYTES, s, P);
+  SDF_LAUNCH(spike_deconv_wres_kernel, dim3((unsigned)grid), dim3(NT), LDS_BYTES, s, P);
   hipError_t e = hipGetLastError();
   return e != hipSuccess ? (int)e : 0;
 }

@@ -422,7 +422,7 @@ int launch(const GemmParams& P, dim3 grid, hipStream_t s) {
 #define SDF_GEMM_T(TT)                                                                                      \
   case TT:                                                                                                  \
     if constexpr (TT == 0 || (16 * RB) / (TT ? TT : 1) >= 1) {                                              \
-      hipLaunchKernelGGL((spike_gemm_kernel<NSPLIT, NB, RB, TT, WAVES, CONV>), grid, dim3(64 * WAVES), 0, s, P);  \
+      SDF_LAUNCH((spike_gemm_kernel<NSPLIT, NB, RB, TT, WAVES, CONV>), grid, dim3(64 * WAVES), 0, s, P);  \
       return 0;                                                                                             \
     }                                                                                                       \
     return SDF_E_SHAPE;
@@ -723,7 +723,7 @@ extern "C" int sdf_split_weight_f16x2(const float* W, uint16_t* planes, int64_t 
   if (n < 1) return SDF_E_SHAPE;
   int ex;
   if (!(scale > 0.f) || frexpf(scale, &ex) != 0.5f) return SDF_E_DTYPE;
-  hipLaunchKernelGGL(split_weight_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sdf_stream(stream), W, planes, n,
+  SDF_LAUNCH(split_weight_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sdf_stream(stream), W, planes, n,
                      scale);
   SDF_LAUNCH_CHECK();
   return 0;
@@ -733,7 +733,7 @@ extern "C" int sdf_split_weight_bf16(const float* W, uint16_t* planes, int64_t n
   if (!W || !planes) return SDF_E_NULL;
   if (n < 1) return SDF_E_SHAPE;
   if (nsplit < 1 || nsplit > 3) return SDF_E_DTYPE;
-  hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sdf_stream(stream), W, planes, n,
+  SDF_LAUNCH(split_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sdf_stream(stream), W, planes, n,
                      nsplit);
   SDF_LAUNCH_CHECK();
   return 0;

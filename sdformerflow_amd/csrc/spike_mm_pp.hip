@@ -677,13 +677,13 @@ __global__ __launch_bounds__(768) void spike_mm_pp_multi_kernel(GemmMulti M) {
 template <int NSPLIT, bool CONV>
 int launch_t(const GemmParams& P, dim3 grid, hipStream_t s) {
   switch (P.d.sn_T) {
-    case 0: hipLaunchKernelGGL((spike_mm_pp_kernel<NSPLIT, 0, CONV>), grid, dim3(768), 0, s, P); return 0;
+    case 0: SDF_LAUNCH((spike_mm_pp_kernel<NSPLIT, 0, CONV>), grid, dim3(768), 0, s, P); return 0;
     case 2:
-      if constexpr (!CONV) { hipLaunchKernelGGL((spike_mm_pp_kernel<NSPLIT, 2, CONV>), grid, dim3(768), 0, s, P); return 0; }
+      if constexpr (!CONV) { SDF_LAUNCH((spike_mm_pp_kernel<NSPLIT, 2, CONV>), grid, dim3(768), 0, s, P); return 0; }
       return SDF_E_SHAPE;
-    case 10: hipLaunchKernelGGL((spike_mm_pp_kernel<NSPLIT, 10, CONV>), grid, dim3(768), 0, s, P); return 0;
+    case 10: SDF_LAUNCH((spike_mm_pp_kernel<NSPLIT, 10, CONV>), grid, dim3(768), 0, s, P); return 0;
     case 20:                                                       // one position per lane half (20 of its 32 accumulator slots)
-      if constexpr (!CONV && NSPLIT == 2) { hipLaunchKernelGGL((spike_mm_pp_kernel<NSPLIT, 20, CONV>), grid, dim3(768), 0, s, P); return 0; }
+      if constexpr (!CONV && NSPLIT == 2) { SDF_LAUNCH((spike_mm_pp_kernel<NSPLIT, 20, CONV>), grid, dim3(768), 0, s, P); return 0; }
       return SDF_E_SHAPE;
     default: return SDF_E_SHAPE;
   }
@@ -797,9 +797,9 @@ int launch_spike_mm_pp_multi(const GemmParams* Ps, int n, hipStream_t s) {
                                             M.kw_mul[i] = M.kw_mul[0]; M.acc_scale[i] = M.acc_scale[0]; }
   const dim3 grid((unsigned)wgs);
   switch (M.base.d.nsplit) {
-    case 1: hipLaunchKernelGGL((spike_mm_pp_multi_kernel<1>), grid, dim3(768), 0, s, M); break;
-    case 2: hipLaunchKernelGGL((spike_mm_pp_multi_kernel<2>), grid, dim3(768), 0, s, M); break;
-    case 3: hipLaunchKernelGGL((spike_mm_pp_multi_kernel<3>), grid, dim3(768), 0, s, M); break;
+    case 1: SDF_LAUNCH((spike_mm_pp_multi_kernel<1>), grid, dim3(768), 0, s, M); break;
+    case 2: SDF_LAUNCH((spike_mm_pp_multi_kernel<2>), grid, dim3(768), 0, s, M); break;
+    case 3: SDF_LAUNCH((spike_mm_pp_multi_kernel<3>), grid, dim3(768), 0, s, M); break;
     default: return SDF_E_SHAPE;
   }
   hipError_t e = hipGetLastError();

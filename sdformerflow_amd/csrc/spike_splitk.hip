@@ -73,7 +73,7 @@ int launch_splitk_reduce(const GemmParams& P, hipStream_t s) {
   if (P.ksplit <= 1) return 0;
   const SdfSpikeGemmDesc& d = P.d;
   const int64_t quads = d.M * (d.N / 4);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, P.partial, P.ksplit, d.M,
+  SDF_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, P.partial, P.ksplit, d.M,
                      d.N, P.acc_scale, d.bias, d.alpha, d.beta, d.resid, d.out_rowmap, d.out, d.ldo);
   const hipError_t e = hipGetLastError();
   return e != hipSuccess ? (int)e : 0;

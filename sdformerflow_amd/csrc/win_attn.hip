@@ -841,9 +841,9 @@ int launch_tiled_f16(const AttnParams& P, hipStream_t s) {
   constexpr size_t lds = (size_t)(2 * NTC * 16 * KRS + (NTC * 4) * HD * 16);
   dim3 grid((unsigned)(P.d.B_ * P.d.nH)), block(256);
   if (P.d.mask) {
-    hipLaunchKernelGGL((win_attn_tiled_f16_kernel<MODE, NTC, true>), grid, block, lds, s, P);
+    SDF_LAUNCH((win_attn_tiled_f16_kernel<MODE, NTC, true>), grid, block, lds, s, P);
   } else {
-    hipLaunchKernelGGL((win_attn_tiled_f16_kernel<MODE, NTC, false>), grid, block, lds, s, P);
+    SDF_LAUNCH((win_attn_tiled_f16_kernel<MODE, NTC, false>), grid, block, lds, s, P);
   }
   SDF_LAUNCH_CHECK();
   return 0;
@@ -854,9 +854,9 @@ int launch_tiled(const AttnParams& P, hipStream_t s) {
   constexpr size_t lds = (size_t)(NTC * 16 * LDW + HD * (NTC * 16 + 4)) * sizeof(float);
   dim3 grid((unsigned)(P.d.B_ * P.d.nH)), block(256);
   if (P.d.mask) {
-    hipLaunchKernelGGL((win_attn_tiled_kernel<MODE, NTC, true>), grid, block, lds, s, P);
+    SDF_LAUNCH((win_attn_tiled_kernel<MODE, NTC, true>), grid, block, lds, s, P);
   } else {
-    hipLaunchKernelGGL((win_attn_tiled_kernel<MODE, NTC, false>), grid, block, lds, s, P);
+    SDF_LAUNCH((win_attn_tiled_kernel<MODE, NTC, false>), grid, block, lds, s, P);
   }
   SDF_LAUNCH_CHECK();
   return 0;
@@ -903,9 +903,9 @@ extern "C" int sdf_win_attn_fwd(const SdfWinAttnDesc* d, void* stream) {
   if (const int e1 = sdf_lds_opt_in(opt_ann, reinterpret_cast<const void*>(win_attn_kernel<SDF_ATTN_ANN>), 3 * 16 * NT_MAX * LDW * 4)) return e1;
   if (const int e2 = sdf_lds_opt_in(opt_sew, reinterpret_cast<const void*>(win_attn_kernel<SDF_ATTN_SEW>), 3 * 16 * NT_MAX * LDW * 4)) return e2;
   if (d->mode == SDF_ATTN_ANN) {
-    hipLaunchKernelGGL(win_attn_kernel<SDF_ATTN_ANN>, grid, block, lds, s, P);
+    SDF_LAUNCH(win_attn_kernel<SDF_ATTN_ANN>, grid, block, lds, s, P);
   } else {
-    hipLaunchKernelGGL(win_attn_kernel<SDF_ATTN_SEW>, grid, block, lds, s, P);
+    SDF_LAUNCH(win_attn_kernel<SDF_ATTN_SEW>, grid, block, lds, s, P);
   }
   SDF_LAUNCH_CHECK();
   return 0;

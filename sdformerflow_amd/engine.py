@@ -322,6 +322,16 @@ class MSFlowEngine:
         a, b = bn if bn is not None else (None, None)
         # large 3x3 / stride-1 launches on 96 channels: int8 digit planes, weights resident in LDS (csrc/spike_conv_wres.hip)
         digits = getattr(Wp, "digits", None)
+        if self.replicas and B > 1 and _dst is None and digits is not None:
+            # replicas: every layer must take the kernel family (and weight representation) its batch-1 forward takes, whatever the
+            # size rules say about B-fold rows - else the flows are not the batch-1 flows bit for bit.  Where the rules answer
+            # differently for B samples, the largest sample chunk that is routed like ONE sample runs per launch.
+            route = lambda n: (hip.smallm_conv_applicable(n * D, h, w, Cin, Cout, stride, D), hip.conv_wres_applicable(n * D, h, w, Cin, Cout, stride, 1),
+                               hip.conv_wres_applicable(n * D, h, w, Cin, Cout, stride, D))
+            r1 = route(1)
+            if route(B) != r1:
+                bc = max(n for n in range(1, B) if B % n == 0 and route(n) == r1)
+                return self._conv3x3_chunks(s, Wp, Cout, stride, bn, resid, sn, membrane, bc)
         if digits is not None and (sn is None or sn.kind in ("lif", "if", "psn")) and hip.smallm_conv_applicable(B * D, h, w, Cin, Cout, stride, D):
             # few rows against many weights (the U-Net bottleneck: 1 080 rows x 768 x 6 912): one launch, K split over the waves of a
             # workgroup, sum + BN + shortcut + neuron in its epilogue (csrc/ms_smallm.hip)
@@ -350,16 +360,7 @@ class MSFlowEngine:
             # batch elements are independent - the largest batch chunk that fits runs per launch, writing into its slice of the outputs
             bc = self._digit_chunk(B, D, h, w, Cin, Cout, stride)
             if bc:
-                kinds = [torch.float32] if sn is None else ([torch.float32, torch.uint8] if membrane else [torch.uint8])
-                outs = tuple(torch.empty((B, D, oh, ow, Cout), dtype=k, device=s.device) for k in kinds)
-                for b0 in range(0, B, bc):
-                    dst = tuple(o[b0:b0 + bc] for o in outs)
-                    r = self._conv3x3(s[b0:b0 + bc], Wp, Cout, stride, bn, None if resid is None else resid[b0:b0 + bc], sn, membrane, dst)
-                    r = r if isinstance(r, tuple) else (r,)
-                    for o, t in zip(dst, r):
-                        if t.data_ptr() != o.data_ptr():                  # (the two-launch PSN form allocates its own)
-                            o.copy_(t)
-                return outs if len(outs) > 1 else outs[0]
+                return self._conv3x3_chunks(s, Wp, Cout, stride, bn, resid, sn, membrane, bc)
         if digits is not None and sn is not None and (sn.kind == "psn" or D not in (5, 10, 20)) and \
                 hip.conv_wres_applicable(B * D, h, w, Cin, Cout, stride, 1):
             # the digit kernel's fused form is LIF / IF over T = 5 / 10 / 20; other neurons (the shipped PSN) take its fp32 form and
@@ -384,6 +385,27 @@ class MSFlowEngine:
         hip.spike_conv2d(s, Wp, B * D, h, w, Cin, oh, ow, 3, 3, stride, (-1, 0, 1), (-1, 0, 1), out=m, out_spike=out, alpha=a, beta=b,
                          resid=resid if membrane else None, sn=sn, sn_T=D, pos=(B * oh * ow, oh * ow, D * oh * ow, oh * ow))
         return (m, out) if membrane else out
+
+    def _conv3x3_chunks(self, s, Wp, Cout, stride, bn, resid, sn, membrane, bc):
+        """_conv3x3 in chunks of bc batch elements (batch elements are independent), every chunk writing its slice of the outputs."""
+        B, D, h, w, _ = s.shape
+        oh, ow = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+        kinds = [torch.float32] if sn is None else ([torch.float32, torch.uint8] if membrane else [torch.uint8])
+        outs = tuple(torch.empty((B, D, oh, ow, Cout), dtype=k, device=s.device) for k in kinds)
+        if resid is not None:
+            resid = resid.view(B, D, oh, ow, Cout)                # (callers also hand it over as (B * D, oh, ow, Cout) images)
+        for b0 in range(0, B, bc):
+            dst = tuple(o[b0:b0 + bc] for o in outs)
+            r = self._conv3x3(s[b0:b0 + bc], Wp, Cout, stride, bn, None if resid is None else resid[b0:b0 + bc], sn, membrane, dst)
+            r = r if isinstance(r, tuple) else (r,)
+            for o, t in zip(dst, r):
+                if t.data_ptr() != o.data_ptr():                  # (the two-launch PSN form allocates its own)
+                    o.copy_(t)
+        return outs if len(outs) > 1 else outs[0]
+
+    def _rb(self, B):
+        """The batch size the ROUTING rules are asked about: with replicas every layer is routed like its batch-1 forward."""
+        return 1 if self.replicas else B
 
     @staticmethod
     def _digit_chunk(B, D, h, w, Cin, Cout, stride):
@@ -415,8 +437,8 @@ class MSFlowEngine:
         if s1 is None:
             s1 = self._neuron_bd(m, rb.sn1)
         self._rec(rb.name + "sn1.spiking_neuron.", s1, "BDHWC->TBCHW")
-        fus = self._fusable(B, D, h, w, rb.C, rb.w1) or \
-            (getattr(rb.w1, "digits", None) is not None and rb.sn2.kind in ("lif", "if", "psn") and hip.smallm_conv_applicable(B * D, h, w, rb.C, rb.C, 1, D))
+        fus = self._fusable(self._rb(B), D, h, w, rb.C, rb.w1) or \
+            (getattr(rb.w1, "digits", None) is not None and rb.sn2.kind in ("lif", "if", "psn") and hip.smallm_conv_applicable(self._rb(B) * D, h, w, rb.C, rb.C, 1, D))
         if fus:
             s2 = self._conv3x3(s1, rb.w1, rb.C, bn=rb.bn1, sn=rb.sn2)
         else:       # few rows (U-Net bottleneck): the fp32 epilogue can split K over the chip; neuron as its own launch
@@ -453,11 +475,12 @@ class MSFlowEngine:
         sns = [rb.sn1 for rb in self.pe_res] + [self.proj_sn]
         C0 = self.conv_w.shape[1]
         oh, ow = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        fus = self._fusable(B, T, oh, ow, C0)
+        fus = self._fusable(self._rb(B), T, oh, ow, C0)
         if not fus and T in (5, 20) and getattr(self.conv_w, "digits", None) is not None and sns[0].kind != "psn":
             # T = 5 / 20 (configs[4]): the digit kernel's stride-2 form rolls its time loop as the stride-1 form does (_fusable's rule)
             c0 = s.shape[-1]
-            bc = B if hip.conv_wres_applicable(B * T, H, W, c0, C0, 2, 1) else self._digit_chunk(B, T, H, W, c0, C0, 2)
+            Br = self._rb(B)
+            bc = Br if hip.conv_wres_applicable(Br * T, H, W, c0, C0, 2, 1) else self._digit_chunk(Br, T, H, W, c0, C0, 2)
             fus = bc > 0 and hip.conv_wres_applicable(bc * T, H, W, c0, C0, 2, T)
         if fus:
             m, s1 = self._conv3x3(s, self.conv_w, C0, stride=2, bn=self.conv_bn, sn=sns[0], membrane=True)
@@ -642,7 +665,7 @@ class MSFlowEngine:
         Small levels: ONE plain spike GEMM over the nine stacked tap matrices + a col2im pass fills the chip; the four parity-class
         convolutions (no 9x intermediate) are kept where that intermediate would cost more than it saves."""
         cout = self.decoders[i][0].shape[1]
-        as_gemm = B * D * h * w * 9 * cout * 4 <= 64 << 20
+        as_gemm = self._rb(B) * D * h * w * 9 * cout * 4 <= 64 << 20
         return as_gemm, (_pad32(cin) if as_gemm else _pad16(cin))
 
     def _prepare_decoder_images(self, feats, y0, out_size):
@@ -760,16 +783,25 @@ class MSFlowEngine:
                     self._deconv[key] = deconv_tap_weights(wuse, cp, self.nsplit)
                 Y = torch.empty((B * D * h * w, 9 * cout), dtype=torch.float32, device=y.device)
                 taps = self._deconv[key]
-                if getattr(taps, "digits", None) is not None and hip.smallm_gemm_applicable(B * D * h * w, 9 * cout, cp):
+                M1, bc = self._rb(B) * D * h * w, B                  # (rows the routing rules are asked about; samples per launch)
+                if getattr(taps, "digits", None) is not None and hip.smallm_gemm_applicable(M1, 9 * cout, cp):
                     taps = taps.digits                        # few rows against many weights (level 0: 1 080 x 3 456 x 1 536): csrc/ms_smallm.hip
-                elif getattr(taps, "digits_rm", None) is not None and hip.res_gemm_applicable(B * D * h * w, 9 * cout, cp):
+                    bc = max(n for n in range(1, B + 1) if B % n == 0 and hip.smallm_gemm_applicable(n * D * h * w, 9 * cout, cp))
+                elif getattr(taps, "digits_rm", None) is not None and hip.res_gemm_applicable(M1, 9 * cout, cp):
                     taps = taps.digits_rm                     # the middle levels (4 320 x 1 728 x 800, 17 280 x 864 x 416): csrc/ms_res.hip
-                hip.spike_gemm(s, taps, Y, B * D * h * w, 9 * cout, cp)
+                    bc = max(n for n in range(1, B + 1) if B % n == 0 and hip.res_gemm_applicable(n * D * h * w, 9 * cout, cp))
+                mc = bc * D * h * w                                   # (replicas: the kernel family of ONE sample, in sample chunks it admits)
+                for m0 in range(0, B * D * h * w, mc):
+                    hip.spike_gemm(s.view(-1, cp)[m0:m0 + mc], taps, Y[m0:m0 + mc], mc, 9 * cout, cp)
                 hip.deconv_col2im(Y, B * D, h, w, cout, alpha=bn[0], beta=bn[1], out=z)
             # the conv kernel addresses its operands with 31-bit byte offsets: a larger z (config 5: 80 images of
             # 240 x 320 x 96 fp32) goes image chunk by image chunk - the row map of the first n images serves every chunk
             imgs = per = B * D
-            while per * 4 * h * w * cout * 4 >= 1 << 31:
+            fits = lambda n: n * 4 * h * w * cout * 4 < 1 << 31
+            if not fits(per):
+                whole = [n * D for n in range(B, 0, -1) if B % n == 0 and fits(n * D)]      # whole batch elements, equal chunks
+                per = whole[0] if whole else per
+            while not fits(per):
                 per = (per + 1) // 2
             # the last level: the transposed convolution as ONE digit product over the 2 x 2 input neighbourhood (a row = an input pixel,
             # its 4 cout columns = the 2 x 2 output block; halo tiles in LDS, weights resident: csrc/spike_deconv_wres.hip) instead of
@@ -842,10 +874,11 @@ class MSFlowEngine:
         self.replicas = bool(replicas)
         try:
             feats = self.encoder(x, **self._tail_kwargs())
+            self.scores = None
+            preds = self.unet_tail(feats, out_size=(H, W), **({"s1": self.tail_spikes} if getattr(self, "tail_spikes", None) is not None else {}))
         finally:
             self.scores = None
             self.replicas = False
-        preds = self.unet_tail(feats, out_size=(H, W), **({"s1": self.tail_spikes} if getattr(self, "tail_spikes", None) is not None else {}))
         self.tail_spikes = None
         # sum over time + nearest upsampling to the input size: done by the prediction head's launch, else one small kernel per scale
         return [f if f is not None else hip.flow_out(p, H, W, H / p.shape[2], W / p.shape[3]) for p, f in zip(preds, self._flows)]

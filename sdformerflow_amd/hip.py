@@ -20,7 +20,8 @@ SDF_F32, SDF_U8 = 0, 1
 SDF_LIF, SDF_PSN, SDF_IF = 0, 1, 2
 KIND = {"lif": SDF_LIF, "psn": SDF_PSN, "if": SDF_IF}
 
-EXPORTS = ("sdf_version", "sdf_switches_reload", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
+VOID_EXPORTS = ("sdf_switches_reload", "sdf_launch_log")       # the entry points that return nothing
+EXPORTS = ("sdf_version", "sdf_switches_reload", "sdf_launch_log", "sdf_launch_log_read", "sdf_lif_fwd", "sdf_psn_fwd", "sdf_neuron_fwd", "sdf_spike_gemm_fwd",
            "sdf_split_weight_bf16", "sdf_split_weight_f16x2", "sdf_qk_gate_fwd", "sdf_qk_gate_strided_fwd", "sdf_affine_resid_fwd", "sdf_win_attn_fwd", "sdf_ann_attn_block_fwd", "sdf_ann_attn_block_supported", "sdf_ann_mlp_block_fwd", "sdf_ann_mlp_block_supported", "sdf_spike_conv2d_fwd", "sdf_spike_deconv3x3s2_fwd", "sdf_head_conv_sn_fwd",
            "sdf_flow_out_fwd", "sdf_deconv_col2im_fwd", "sdf_lif_bwd", "sdf_psn_bwd", "sdf_psn_bwd_workspace_bytes",
            "sdf_window_slice_map", "sdf_window_zsrc_map", "sdf_qk_attn_fwd", "sdf_qk_attn_is_wide", "sdf_ms_mlp_is_wide", "sdf_ms_patch_merge_fwd", "sdf_tile_weight_i8x3", "sdf_spike_conv2d_multi_fwd", "sdf_qk_attn_workspace_bytes", "sdf_spike_gemm_bn_fwd",
@@ -232,6 +233,29 @@ class profile_calls:
         return self._rows
 
 
+class LaunchRecord(C.Structure):
+    _fields_ = [("kernel", C.c_char * 192), ("workgroups", C.c_uint32), ("threads", C.c_uint32), ("lds_bytes", C.c_uint32), ("us", C.c_float)]
+
+
+class launch_log:
+    """`with hip.launch_log() as log:` - every kernel launch the library makes inside is timed with HIP events on its own stream
+    (sdf_launch_log); afterwards `log.rows` = [(kernel name, workgroups, threads per workgroup, dynamic LDS bytes, microseconds)] in
+    launch order.  workgroups x microseconds / 256 = the launch's chip time.  Eager launches only (not under graph capture)."""
+
+    def __enter__(self):
+        lib().sdf_launch_log(C.c_int(1))
+        return self
+
+    def __exit__(self, *exc):
+        c = _lib
+        c.sdf_launch_log(C.c_int(0))
+        n = c.sdf_launch_log_read(None, C.c_int(0))
+        buf = (LaunchRecord * max(n, 1))()
+        c.sdf_launch_log_read(buf, C.c_int(n))
+        self.rows = [(buf[i].kernel.decode(errors="replace"), int(buf[i].workgroups), int(buf[i].threads), int(buf[i].lds_bytes), float(buf[i].us))
+                     for i in range(n)]
+
+
 def lib():
     """Load the shared library once; fail loudly when it is absent."""
     global _lib
@@ -243,9 +267,8 @@ def lib():
                            "(sdformerflow_amd/csrc/build.sh); there is no CPU fallback")
         _lib = C.CDLL(LIB_PATH)
         _lib.sdf_version.restype = C.c_int
-        _lib.sdf_switches_reload.restype = None
-        for name in EXPORTS[2:]:
-            getattr(_lib, name).restype = C.c_int
+        for name in EXPORTS[1:]:
+            getattr(_lib, name).restype = None if name in VOID_EXPORTS else C.c_int
         _lib.sdf_psn_bwd_workspace_bytes.restype = C.c_int64
         _lib.sdf_qk_attn_workspace_bytes.restype = C.c_int64
         _lib.sdf_ms_mlp_workspace_bytes.restype = C.c_int64
