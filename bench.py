@@ -155,6 +155,21 @@ def time_dominant_kernels(model, iters=40):
                     "; the matrix pipe is busy 40 % of the kernel's cycles (PMC, profiles/r5q_pmc_forward.txt)"}
     gemm["frac"] = gemm["achieved"] / gemm["peak"]
     gemm["frac_of_issued_mfma"] = issued * gemm["frac"]
+    # round 6: the traffic of this kernel's four launches inside the headline's launch sequence, from the counters tools/pmc_forward2.sh
+    # took on this round's tree (profiles/r6_kernel_counters.json; rocprofv3 owns the counters, they cannot be read in this process)
+    try:
+        cj = json.load(open(os.path.join(ROOT, "profiles", "r6_kernel_counters.json")))
+        ks = [v for k, v in cj["per_sample"].items() if k.startswith("spike_conv_wres_i8_kernel<10, 6, 1, 3")]
+        if digits and ks:
+            per_launch = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in ks) / sum(v["launches"] for v in ks)
+            gemm.update(traffic=per_launch, traffic_over_algorithmic=per_launch / gemm["algorithmic_bytes"],
+                        traffic_source="profiles/r6_kernel_counters.json (tools/pmc_forward2.sh on the round-6 tree: rocprofv3 --pmc FETCH_SIZE and --pmc "
+                                       "WRITE_SIZE in separate passes over one eager launch sequence of " + str(cj["samples_per_launch_sequence"]) +
+                                       " samples, gfx950 x 2 read correction, KiB = 1024 B; bytes of this kernel's launches / (launches x samples): "
+                                       "the mean over its two epilogue forms, as `achieved` is); the round-5 figure from the isolated launches: " +
+                                       f"{CONV_TRAFFIC_BYTES:.0f} (profiles/r5u_pmc_conv_mapping.txt)")
+    except (OSError, ValueError, KeyError, ZeroDivisionError):
+        pass
     # neuron: T=10 over the stage-0 MLP hidden tensor shape (10 x 72*96*384 fp32 in, u8 out)
     blk = eng.stages[0][0]
     n = 72 * 96 * 384
@@ -387,7 +402,8 @@ def side_measurements(args, dev):
         try:
             m, _ = build_model(kind, dev)
             m.gemm_nsplit = planes
-            r = inflight_rate(m, dev, args.inflight, args.replicas, 96)
+            # (the 16-bit-plane modes have no one-launch-sequence form - forward_replicas runs their samples one by one -: three streams)
+            r = inflight_rate(m, dev, *((args.inflight, args.replicas) if planes == 2 else (3, 1)), 96)
             r["workload"] = f"configs[1] forward, neuron={kind}, weight planes={planes} ({ {1: 'one bf16', 2: 'fp16 hi+lo', 3: 'bf16 hi+mid+lo = fp32 exactly'}[planes] })"
             out[name] = r
             del m
@@ -486,26 +502,98 @@ def time_by_entry_point(model, chunk, top=5):
                     "absolute launch times - those are in profiles/r4*_forward_sequence.txt)"}
 
 
-def time_swin_blocks(model, chunk, iters=10):
+KERNEL_COUNTERS = os.path.join(ROOT, "profiles", "r6_kernel_counters.json")      # tools/pmc_forward2.sh on the round's tree (per sample)
+CLOCK_MHZ = 2400.0                                                               # peak engine clock (MI355X_MICROARCH.md)
+
+
+def _short_kernel(n):
+    import re
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "").replace("sdfmm::", "")
+    return re.sub(r"\(.*", "", n)[:64]
+
+
+def time_by_kernel(model, R, top=14):
+    """`roofline.by_kernel`: one eager launch sequence of the headline's scheme (R samples, forward_replicas) through the library's own
+    launch log (sdf_launch_log: HIP events around every kernel launch, grid and block noted) - per kernel, per SAMPLE: launches,
+    duration, CHIP TIME = sum over its launches of min(workgroups / 256, 1) x duration (the share of the 256 compute units a launch can
+    hold x the time it holds them: what adds up to the throughput when several launch sequences are in flight), and - from the
+    counters of the same launch sequence taken by tools/pmc_forward2.sh on this tree (profiles/r6_kernel_counters.json; rocprofv3 owns
+    the counters, they cannot be read here) - the kernel's VECTOR-ISSUE roof (wave-level VALU instructions x 4 cycles / 1024 SIMDs /
+    2.4 GHz: the time its vector instructions alone need on the whole chip), matrix-pipe time (SQ_VALU_MFMA_BUSY_CYCLES / 1024 / 2.4
+    GHz) and HBM time (bytes / 8 TB/s), each as a fraction of the measured duration: which resource a kernel is closest to."""
+    from sdformerflow_amd import hip
+    x = torch.cat([synthetic_chunk(1235 + i) for i in range(R)], 0).to(next(model.parameters()).device)
+    fwd = (lambda: model.forward_replicas(x)) if R > 1 else (lambda: model(x))
+    with torch.no_grad():
+        for _ in range(2):
+            fwd()
+        torch.cuda.synchronize()
+        with hip.launch_log() as log:
+            fwd()
+    agg = {}
+    for k, wgs, thr, lds, us in log.rows:
+        a = agg.setdefault(_short_kernel(k), {"launches": 0, "us": 0.0, "chip_us": 0.0, "max_workgroups": 0})
+        a["launches"] += 1
+        a["us"] += us
+        a["chip_us"] += min(wgs / 256.0, 1.0) * us
+        a["max_workgroups"] = max(a["max_workgroups"], wgs)
+    counters, csrc = {}, None
+    try:
+        cj = json.load(open(KERNEL_COUNTERS))
+        if cj.get("samples_per_launch_sequence") == R:
+            counters, csrc = cj["per_sample"], "profiles/r6_kernel_counters.json"
+    except (OSError, ValueError):
+        pass
+    tot_us, tot_chip = sum(a["us"] for a in agg.values()), sum(a["chip_us"] for a in agg.values())
+    rows = []
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["chip_us"])[:top]:
+        r = {"kernel": k, "launches": a["launches"], "us_per_sample": a["us"] / R, "chip_time_us_per_sample": a["chip_us"] / R,
+             "share_of_chip_time": a["chip_us"] / tot_chip, "max_workgroups": a["max_workgroups"]}
+        c = counters.get(k)
+        if c:
+            valu_us = c["valu_wave_insts"] * 4.0 / 1024.0 / CLOCK_MHZ
+            mfma_us = c["mfma_busy_cycles"] / 1024.0 / CLOCK_MHZ
+            hbm_us = (c["hbm_read_bytes"] + c["hbm_write_bytes"]) / (PEAK_HBM_GBPS * 1e3)
+            d = a["us"] / R
+            r.update(valu_issue_us=valu_us, valu_roof_frac=valu_us / d, matrix_pipe_us=mfma_us, matrix_pipe_frac=mfma_us / d, hbm_us=hbm_us,
+                     hbm_frac=hbm_us / d, nearest_roof=max((("vector issue", valu_us), ("matrix pipe", mfma_us), ("hbm", hbm_us)), key=lambda t: t[1])[0])
+        rows.append(r)
+    return {"rows": rows, "launches_per_sequence": len(log.rows), "samples_per_sequence": R, "kernel_us_per_sample": tot_us / R,
+            "chip_time_us_per_sample": tot_chip / R, "counters_from": csrc,
+            "note": "chip time counts one workgroup per compute unit (an upper bound where several fit); events add ~1 us per launch"}
+
+
+def time_swin_blocks(model, chunk, R=1, iters=10):
     """The attention-GEMM roofline fraction of the metric: SURVEY.md 8(d)'s 183.7 GFLOP of the swin blocks' Linear layers
     (q|k, proj, fc1, fc2, merge) per sample / the time of the swin stages themselves - the 12 blocks + 3 merges run alone on
     one stream between two HIP events (this includes the blocks' fused epilogues, gather neurons and token gates, so it is a
-    lower bound of the GEMM launches' own rate; the per-launch split is in profiles/)."""
+    lower bound of the GEMM launches' own rate; the per-launch split is in profiles/).  Measured twice: one sample per launch sequence
+    (`swin_stages_ms`: the figure of rounds 2 - 5) and in the headline's scheme, R independent samples per launch sequence (replicas:
+    `frac`, per sample) - the same kernels on R times the rows."""
     eng = model.engine()
+
+    def run(y0, replicas):
+        def stages(_):
+            eng.replicas = replicas
+            try:
+                y = y0.clone()
+                for s, blocks in enumerate(eng.stages):
+                    for i in range(len(blocks)):
+                        y = eng.swin_block(y, s, i)
+                    if s < len(eng.merges):
+                        y = eng.patch_merge(y, s)
+            finally:
+                eng.replicas = False
+        return _timed(stages, [None], iters)
     with torch.no_grad():
         y0 = eng.patch_embed(chunk)
-
-        def stages(_):
-            y = y0.clone()
-            for s, blocks in enumerate(eng.stages):
-                for i in range(len(blocks)):
-                    y = eng.swin_block(y, s, i)
-                if s < len(eng.merges):
-                    y = eng.patch_merge(y, s)
-        t = _timed(stages, [None], iters)
-    return {"flop": 183.7e9, "swin_stages_ms": t * 1e3, "tflops": 183.7e9 / t / 1e12,
-            "frac": 183.7e9 / t / (PEAK_BF16_DENSE_TFLOPS * 1e12),
-            "note": "183.7 GFLOP (SURVEY.md 8d) / time of the 12 swin blocks + 3 patch merges alone on one stream (HIP events); "
+        t1 = run(y0, False)
+        tR = run(torch.cat([y0] * R, 0).contiguous(), True) / R if R > 1 else t1
+    return {"flop": 183.7e9, "swin_stages_ms": t1 * 1e3, "frac_one_sample_per_launch": 183.7e9 / t1 / (PEAK_BF16_DENSE_TFLOPS * 1e12),
+            "replicas_per_launch": R, "swin_stages_ms_per_sample": tR * 1e3, "tflops": 183.7e9 / tR / 1e12,
+            "frac": 183.7e9 / tR / (PEAK_BF16_DENSE_TFLOPS * 1e12),
+            "note": "183.7 GFLOP (SURVEY.md 8d) per sample / time of the 12 swin blocks + 3 patch merges alone on one stream (HIP events), per "
+                    "sample, in the headline's scheme (R samples per launch sequence; `frac_one_sample_per_launch` / `swin_stages_ms`: R = 1); "
                     "dense bf16 MFMA peak"}
 
 
@@ -847,12 +935,16 @@ def main():
     if rank == 0:
         check_ranks(ranks, world, shared_ok=os.environ.get("SDF_DIST_BACKEND", "nccl") != "nccl")
         gemm, neuron = time_dominant_kernels(model)
-        blocks = time_swin_blocks(model, chunk)
+        blocks = time_swin_blocks(model, chunk, args.replicas)
         by_time = time_by_entry_point(model, chunk)
         gemm["by_time"] = by_time["rows"]
         gemm["by_time_note"] = by_time["note"]
         gemm["calls_per_forward"] = by_time["calls_per_forward"]
         gemm["largest_share"] = by_time["rows"][0]["entry_point"] + " " + str(by_time["rows"][0]["shape"])
+        try:
+            gemm["by_kernel"] = time_by_kernel(model, args.replicas)
+        except Exception as e:                                     # (diagnostic: never takes the line down)
+            gemm["by_kernel"] = {"error": repr(e)[:300]}
         planes_txt = {1: "ONE bf16 weight plane (8 significand bits; throughput mode at BASELINE configs[1]'s stated precision, NOT the "
                          "parity mode)",
                       2: "2 fp16 weight planes hi+lo (22 of fp32's 24 significand bits; the default parity mode)",

@@ -178,6 +178,9 @@ typedef struct SdfNeuronDesc {
   int32_t soft_reset;
   const float* psn_w;       /* (T,T) */
   const float* psn_b;       /* (T)   */
+  /* round 6: an outermost dimension - nrep > 1 equally laid out problems (dense mode only), problem p at x + p*x_srep / out + p*o_srep
+   * (v_last dense over all nrep*nb*ni): the batch elements of a pixel-strided channel slice in one descriptor.  0 / 1 = none. */
+  int64_t nrep, x_srep, o_srep;
 } SdfNeuronDesc;
 
 int sdf_neuron_fwd(const SdfNeuronDesc* d, void* stream);

@@ -227,7 +227,13 @@ class MS_SpikingformerFlowNet(nn.Module):
         if self.training:
             raise RuntimeError("forward_replicas is an inference entry point: call model.eval()")
         with torch.no_grad():
-            flows = self.engine().forward(x, None, replicas=True)
+            if self.gemm_nsplit != 2 and x.shape[0] > 1:
+                # the 16-bit-plane modes (3 = exact, 1 = bf16) run on the streaming kernels, whose split-K plans and tile families follow
+                # the row count: R-fold rows would change the summation order of a layer - the samples go one by one (same results)
+                outs = [self.engine().forward(x[i:i + 1], None) for i in range(x.shape[0])]
+                flows = [torch.cat([o[lvl] for o in outs], 0) for lvl in range(len(outs[0]))]
+            else:
+                flows = self.engine().forward(x, None, replicas=True)
         return {"flow": flows, "attn": None}
 
 

@@ -48,8 +48,8 @@ __device__ __forceinline__ void store_spikes(const NeuronParams& P, int64_t ooff
 }
 
 // Address of the quad in x for step t, or nullptr for a padding row.
-__device__ __forceinline__ const float* x_addr(const NeuronParams& P, int t, int64_t e, int64_t b, int64_t r) {
-  if (P.d.rowmap == nullptr) return P.d.x + b * P.d.x_sb + (int64_t)t * P.d.x_st + r;
+__device__ __forceinline__ const float* x_addr(const NeuronParams& P, int t, int64_t e, int64_t b, int64_t r, int64_t xrep = 0) {
+  if (P.d.rowmap == nullptr) return P.d.x + xrep + b * P.d.x_sb + (int64_t)t * P.d.x_st + r;
   int64_t row = e / P.d.rowlen;
   int64_t col = e - row * P.d.rowlen;
   int32_t src = P.d.rowmap[(int64_t)t * P.rows + row];
@@ -75,10 +75,16 @@ template <int TT>
 __device__ __forceinline__ void neuron_body(const NeuronParams& P, int64_t q) {
   if (q >= P.quads) return;
   const int T = TT > 0 ? TT : P.d.T;
-  const int64_t e = q * 4;
+  int64_t e = q * 4, xrep = 0, orep = 0;
+  if (P.d.nrep > 1) {                                            // outermost dimension: nrep equally laid out problems (dense mode)
+    const int64_t per = P.d.nb * P.d.ni, rp = e / per;
+    e -= rp * per;
+    xrep = rp * P.d.x_srep;
+    orep = rp * P.d.o_srep;
+  }
   const int64_t b = e / P.d.ni;
   const int64_t r = e - b * P.d.ni;
-  const int64_t obase = b * P.d.o_sb + r;
+  const int64_t obase = orep + b * P.d.o_sb + r;
 
   float4 al = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
   if (P.d.alpha) {
@@ -98,7 +104,7 @@ __device__ __forceinline__ void neuron_body(const NeuronParams& P, int64_t q) {
     float4 xv[TT];
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
-      const float* p = x_addr(P, t, e, b, r);
+      const float* p = x_addr(P, t, e, b, r, xrep);
       xv[t] = p ? load4(p) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -144,19 +150,19 @@ __device__ __forceinline__ void neuron_body(const NeuronParams& P, int64_t q) {
       s.w = fire_reset(v.w, h.w, P.d.v_th, P.d.v_reset, soft);
       store_spikes(P, obase + (int64_t)t * P.d.o_st, s);
     }
-    if (P.d.v_last) *reinterpret_cast<float4*>(P.d.v_last + e) = v;
+    if (P.d.v_last) *reinterpret_cast<float4*>(P.d.v_last + q * 4) = v;
   } else {
     // runtime T: sequential neurons only (PSN with an unlisted T is rejected on the host)
     const bool soft = P.d.soft_reset != 0;
     const bool reset0 = soft || P.d.v_reset == 0.f;
     const float v0 = soft ? 0.f : P.d.v_reset;
     float4 v = make_float4(v0, v0, v0, v0);
-    const float* p = x_addr(P, 0, e, b, r);
+    const float* p = x_addr(P, 0, e, b, r, xrep);
     float4 nxt = p ? load4(p) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int t = 0; t < T; ++t) {
       float4 x = nxt;
       if (t + 1 < T) {
-        const float* pn = x_addr(P, t + 1, e, b, r);
+        const float* pn = x_addr(P, t + 1, e, b, r, xrep);
         nxt = pn ? load4(pn) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       x = prologue(P, x, t, r, al, be);
@@ -175,7 +181,7 @@ __device__ __forceinline__ void neuron_body(const NeuronParams& P, int64_t q) {
       s.w = fire_reset(v.w, h.w, P.d.v_th, P.d.v_reset, soft);
       store_spikes(P, obase + (int64_t)t * P.d.o_st, s);
     }
-    if (P.d.v_last) *reinterpret_cast<float4*>(P.d.v_last + e) = v;
+    if (P.d.v_last) *reinterpret_cast<float4*>(P.d.v_last + q * 4) = v;
   }
 }
 
@@ -258,6 +264,7 @@ int validate(const SdfNeuronDesc& d) {
   if (d.kind != SDF_LIF && d.kind != SDF_PSN && d.kind != SDF_IF) return SDF_E_DTYPE;
   if (d.ni % 4 || d.o_sb % 4 || d.o_st % 4) return SDF_E_SHAPE;
   if (!sdf_aligned(d.x, 16) || !sdf_aligned(d.out, d.out_dtype == SDF_F32 ? 16 : 4)) return SDF_E_ALIGN;
+  if (d.nrep < 0 || (d.nrep > 1 && (d.rowmap || d.x_srep % 4 || d.o_srep % 4))) return SDF_E_SHAPE;      // (the outer dimension is a dense-mode feature)
   if (d.rowmap) {
     if (d.rowlen < 4 || d.rowlen % 4 || (d.nb * d.ni) % d.rowlen) return SDF_E_SHAPE;
   } else if (d.x_sb % 4 || d.x_st % 4) {
@@ -288,7 +295,7 @@ extern "C" int sdf_neuron_fwd(const SdfNeuronDesc* dp, void* stream) {
   if (rc) return rc;
   NeuronParams P;
   P.d = *dp;
-  P.quads = dp->nb * dp->ni / 4;
+  P.quads = (dp->nrep > 1 ? dp->nrep : 1) * dp->nb * dp->ni / 4;
   P.rows = dp->rowmap ? dp->nb * dp->ni / dp->rowlen : 0;
   P.inv_tau = sdf_inv_tau(dp->kind, dp->tau);
   dim3 grid((unsigned)((P.quads + 255) / 256)), block(256);
@@ -329,7 +336,7 @@ extern "C" int sdf_neuron_multi_fwd(const SdfNeuronDesc* descs, int n, void* str
   for (int i = 0; i < n; ++i) {
     NeuronParams& P = M.p[i];
     P.d = descs[i];
-    P.quads = descs[i].nb * descs[i].ni / 4;
+    P.quads = (descs[i].nrep > 1 ? descs[i].nrep : 1) * descs[i].nb * descs[i].ni / 4;
     P.rows = descs[i].rowmap ? descs[i].nb * descs[i].ni / descs[i].rowlen : 0;
     P.inv_tau = sdf_inv_tau(descs[i].kind, descs[i].tau);
     M.first[i] = (int)wgs;

@@ -677,7 +677,7 @@ class MSFlowEngine:
         B, D, h0, w0, _ = feats[-1].shape
         if tuple(y0.shape[2:4]) != (h0, w0):
             return None
-        imgs, calls, c1 = [], [[] for _ in range(feats[0].shape[0])], y0.shape[-1]
+        imgs, calls, c1 = [], [], y0.shape[-1]
         for i in range(E):
             skip = feats[E - 1 - i]
             h, w = h0 << i, w0 << i
@@ -697,17 +697,18 @@ class MSFlowEngine:
             if i == 0 and cp != cin:
                 img[..., cin:].zero_()                                  # (levels >= 1: zeroed by the head of the level above)
             hw = h * w
-            for b in range(B):                                            # (one multi-descriptor launch per batch element)
-                calls[b].append((skip[b], img[b].view(-1)[c1:], D, hw, C2, C2, hw * C2, cp, hw * cp, sn))
+            # (the batch elements are the descriptor's outermost dimension: one multi-descriptor launch for the whole batch)
+            calls.append((skip, img.view(-1)[c1:], D, hw, C2, C2, hw * C2, cp, hw * cp, sn, None, 0, None, None, 0, 1, None, 0, 0, None,
+                          (B, D * hw * C2, D * hw * cp)))
             imgs.append(img)
             c1 = cout
         # level 0's own input y rides in the same launch (its neuron is the level's `sn` too; six descriptors at most)
-        self._ready_has_y = len(calls[0]) < 6
-        for b in range(B):
-            if self._ready_has_y:
-                cy, hw0, cp0 = y0.shape[-1], h0 * w0, imgs[0].shape[-1]
-                calls[b].append((y0[b], imgs[0][b].view(-1), D, hw0, cy, cy, hw0 * cy, cp0, hw0 * cp0, self.decoders[0][2]))
-            hip.neuron_multi_fwd(calls[b])
+        self._ready_has_y = len(calls) < 6
+        if self._ready_has_y:
+            cy, hw0, cp0 = y0.shape[-1], h0 * w0, imgs[0].shape[-1]
+            calls.append((y0, imgs[0].view(-1), D, hw0, cy, cy, hw0 * cy, cp0, hw0 * cp0, self.decoders[0][2], None, 0, None, None, 0, 1, None, 0, 0,
+                          None, (B, D * hw0 * cy, D * hw0 * cp0)))
+        hip.neuron_multi_fwd(calls)
         return imgs
 
     def unet_tail(self, feats, out_size=None, s1=None):

@@ -95,7 +95,8 @@ class NeuronDesc(C.Structure):
                 ("alpha", C.c_void_p), ("beta", C.c_void_p), ("C", C.c_int32), ("inner", C.c_int32),
                 ("add", C.c_void_p), ("add_st", C.c_int64), ("add_period", C.c_int64),
                 ("tau", C.c_float), ("v_th", C.c_float), ("v_reset", C.c_float), ("soft_reset", C.c_int32),
-                ("psn_w", C.c_void_p), ("psn_b", C.c_void_p)]
+                ("psn_w", C.c_void_p), ("psn_b", C.c_void_p),
+                ("nrep", C.c_int64), ("x_srep", C.c_int64), ("o_srep", C.c_int64)]
 
 
 class SpikeGemmDesc(C.Structure):
@@ -326,8 +327,10 @@ class NeuronParams:
 
 
 def _neuron_desc(x, out, T, nb, ni, x_sb, x_st, o_sb, o_st, p: NeuronParams, rowmap=None, rowlen=0,
-                 alpha=None, beta=None, Cch=0, inner=1, add=None, add_st=0, add_period=0, v_last=None):
+                 alpha=None, beta=None, Cch=0, inner=1, add=None, add_st=0, add_period=0, v_last=None, rep=None):
     d = NeuronDesc()
+    if rep is not None:
+        d.nrep, d.x_srep, d.o_srep = rep                          # (count, stride in x, stride in out) of the outermost dimension
     d.x, d.out, d.v_last = _ptr(x, torch.float32), _ptr(out), _ptr(v_last, torch.float32)
     d.T = T
     d.out_dtype = SDF_F32 if out.dtype == torch.float32 else SDF_U8

@@ -1,20 +1,24 @@
 #!/usr/bin/env bash
 # Where one forward of BASELINE config 2 spends the chip: per kernel name, summed over the launches of the last of five eager
 # forwards - vector / matrix instruction counts, matrix-pipe busy cycles, wave-cycles, HBM bytes (separate --pmc passes; FETCH_SIZE
-# x 2 on gfx950, KiB) - and the kernel durations of a --kernel-trace pass.  usage (GPU box): tools/pmc_forward2.sh [tag]
+# x 2 on gfx950, KiB) - and the kernel durations of a --kernel-trace pass.  usage (GPU box): tools/pmc_forward2.sh [tag] [lif|psn] [R]
+# R > 1: one launch sequence over R samples (forward_replicas); the table is per launch sequence, gpurun_out/<tag>_kernel_counters.json
+# (what bench.py's `roofline.by_kernel` reads from profiles/) is per SAMPLE.
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}" || exit 1
 TAG=${1:-r3}
+KIND=${2:-lif}
+REP=${3:-1}
 OUT=gpurun_out/pmcf_$TAG
 rm -rf ${OUT:?}; mkdir -p ${OUT:?}
 i=0
 for set_ in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
             "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
             "FETCH_SIZE" "WRITE_SIZE"; do
-  timeout 300 rocprofv3 --pmc $set_ --output-format csv -d ${OUT:?}/p$i -- python3 tools/forward_one.py 5 > /dev/null 2>&1 < /dev/null
+  timeout 300 rocprofv3 --pmc $set_ --output-format csv -d ${OUT:?}/p$i -- python3 tools/forward_one.py 5 $KIND $REP > /dev/null 2>&1 < /dev/null
   i=$((i+1))
 done
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d ${OUT:?}/trace -- python3 tools/forward_one.py 5 > /dev/null 2>&1 < /dev/null
-python3 - ${OUT:?} <<'PY'
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d ${OUT:?}/trace -- python3 tools/forward_one.py 5 $KIND $REP > /dev/null 2>&1 < /dev/null
+python3 - ${OUT:?} $REP $KIND <<'PY'
 import csv, glob, sys, collections, re
 out = sys.argv[1]
 def short(n):
@@ -46,7 +50,14 @@ tot = collections.defaultdict(float)
 for k, v in per.items():
     for c, x in v.items():
         tot[c] += x
-print(f"one eager forward of config 2: {sum(cnt.values())} launches, kernel time {sum(dur.values()):.0f} us; VALU {tot['SQ_INSTS_VALU'] / 1e6:.1f} M wave-instructions, "
+R = int(sys.argv[2])
+import json
+json.dump({"source": "tools/pmc_forward2.sh (rocprofv3 --pmc, separate passes; FETCH_SIZE x 2, KiB) on one eager launch sequence", "neuron": sys.argv[3],
+           "samples_per_launch_sequence": R, "per_sample": {k: {"launches": cnt[k], "us": dur[k] / R, "valu_wave_insts": v["SQ_INSTS_VALU"] / R,
+           "mfma_insts": v["SQ_INSTS_MFMA"] / R, "mfma_busy_cycles": v["SQ_VALU_MFMA_BUSY_CYCLES"] / R, "hbm_read_bytes": 2 * v["FETCH_SIZE"] * 1024 / R,
+           "hbm_write_bytes": v["WRITE_SIZE"] * 1024 / R, "lds_conflict_frac": v["SQ_LDS_BANK_CONFLICT"] / max(v["SQ_LDS_IDX_ACTIVE"], 1)} for k, v in per.items()}},
+          open(out.replace("pmcf_", "") + "_kernel_counters.json", "w"), indent=1)
+print(f"one eager launch sequence of config 2 over {R} sample(s): {sum(cnt.values())} launches, kernel time {sum(dur.values()):.0f} us; VALU {tot['SQ_INSTS_VALU'] / 1e6:.1f} M wave-instructions, "
       f"MFMA {tot['SQ_INSTS_MFMA'] / 1e6:.2f} M, matrix-pipe busy {tot['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / 1e3:.0f} k cycles per SIMD, "
       f"HBM {2 * tot['FETCH_SIZE'] * 1024 / 1e9:.2f} GB read + {tot['WRITE_SIZE'] * 1024 / 1e9:.2f} GB written")
 print(f"{'kernel':64s} {'n':>3s} {'us':>7s} {'VALU M':>8s} {'MFMA M':>7s} {'VALU/MFMA':>9s} {'pipe busy %':>11s} {'LDS confl %':>11s} {'read MB':>8s} {'write MB':>8s}")
