@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the SDformerFlow forward hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--neuron lif|psn] [--no-cpu] [--inflight F] [--eager]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--neuron lif|psn] [--no-cpu] [--inflight F] [--replicas R] [--eager]
     python bench.py --train [--local-batch B] ...      (BASELINE configs[3], the training step; not the default workload)
 
 One "step" = one forward of MS_SpikingformerFlowNet_en4 over one synthetic 1 x 10 x 2 x 288 x 384 event
@@ -10,10 +10,13 @@ voxel (BASELINE config 2) already resident in HBM.  For N > 1 the driver launche
 coupled by the reference's raw reshapes), so every rank runs an independent replica: weak scaling, no
 data-path collective, value = N*K / max-over-ranks(time).
 
-Every rank keeps F (default 3) independent forwards in flight on F HIP streams, each captured once as a HIP graph and
-replayed (`--eager` launches kernel by kernel instead): the layers of a batch-1 forward are too small to fill 256 CUs one
-kernel at a time, independent samples overlap.  A step is still one whole forward of one sample; the K timed steps are dealt
-round-robin to the streams.  The single-stream latency is reported next to the throughput.
+Every rank keeps F (default 2) HIP streams busy, each replaying the HIP graph of ONE launch sequence that carries R (default 10)
+independent batch-1 forwards of different voxels (`model.forward_replicas`: every sample keeps the reference's batch-1
+semantics - a batch of R would couple the samples - and its flow maps are asserted bit-equal to a separate forward in this
+run; `--eager` launches kernel by kernel instead): the layers of a batch-1 forward are too small to fill 256 CUs one
+kernel at a time and spend a fixed few microseconds per launch on cold operands and weight staging, R samples share both.
+A step is still one whole forward of one sample; the K timed steps are dealt evenly to the streams (class InFlight).  The
+single-stream latency of a plain forward is reported next to the throughput.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant own kernel, timed live with HIP events on the
 launch stream) and `cpu_baseline` (the CPU oracle = port of the reference, timed on this box's host cores).
