@@ -48,9 +48,15 @@ CONV_DW_HIP = os.environ.get("SDF_TRAIN_CONV_DW", "1") != "0"
 CONV_FWD_HIP = os.environ.get("SDF_TRAIN_CONV_FWD", "1") != "0"
 
 
-def _linear(x, lin):
-    """Linear on a SPIKE tensor (every Linear of the MS models is fed by a neuron or by the token gate): forward on the spike
-    GEMM kernel, spikes saved as bytes for the backward."""
+def _linear(x, lin, spikes=True):
+    """Linear of the training path.  `spikes` (the caller's statement, as `_conv_seq`'s): x holds 0 / 1 values only - every Linear of
+    the MS models is fed by a neuron or by the token gate - which is what the hand-written products need: they keep the top 16 bits
+    of the activation (csrc/linear_train.hip, linear_dw.hip), exact for spikes and for nothing else.  `spikes=False`: F.linear.
+    SDF_DEBUG_CHECKS=1 verifies the statement on the host (one synchronisation per call)."""
+    if not spikes:
+        return F.linear(x, lin.weight, lin.bias)
+    if hip.sw("SDF_DEBUG_CHECKS", "") == "1" and not bool(((x == 0) | (x == 1)).all()):
+        raise hip.SdfError("_linear(spikes=True) was handed values other than 0 / 1: the 16-bit-plane products would truncate them")
     K, N = lin.weight.shape[1], lin.weight.shape[0]
     if SPIKE_LINEAR_PLANES and K % 32 == 0 and N % 32 == 0:
         from .autograd import SpikeLinearFunction
