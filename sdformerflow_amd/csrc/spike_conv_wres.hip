@@ -475,17 +475,9 @@ struct GeoI8 {
 
 // SPK: the spikes-only fused form (no fp32 membrane out, no shortcut in) as its own instantiation - without the shortcut's 16 registers
 // and the store transposes the three-group kernel has room for a second K step of fragments in flight
-// PSNF (round 6): the Parallel Spiking Neuron as the fused neuron.  H[t'] = b[t'] + sum_t W[t'][t] x[t] needs all T pre-activations of
-// an output at once - 16 x T accumulators per lane in this kernel's layout, which the register file does not have beside the MFMA
-// phase.  So the item's time loop only stores the fp32 pre-activation x[t] = BN(conv) (+ shortcut) - the membrane output of the
-// MS_ResBlock form, or a caller-provided scratch tensor - and a PSN phase behind it re-reads, lane by lane, exactly the 16-byte
-// pieces that lane wrote (still in L2: 160 KB per item), T of them at a time, runs the k-ordered fmaf chain (spike_mm.h
-// psn_T_lds_bits: bit-equal to the neuron kernel) and writes the spike bytes.  Replaces conv (fp32 form) + neuron_kernel<10>: the
-// tensor's second trip through HBM and a launch.  T = 10 only.
-template <int TT, int CIN16, int RB, int NGRP, bool S2 = false, int KH = 1, bool SPK = false, bool PSNF = false>
+template <int TT, int CIN16, int RB, int NGRP, bool S2 = false, int KH = 1, bool SPK = false>
 __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmParams P, const float* __restrict__ col_scale) {
   static_assert(!SPK || TT > 0, "spikes-only: a fused-neuron form");
-  static_assert(!PSNF || (TT == 10 && !SPK), "PSN phase: T = 10, pre-activations through d.out");
   using G = GeoI8<CIN16, RB, S2, KH>;
   constexpr int ST = S2 ? 2 : 1;
   constexpr int CING = G::CING;
@@ -496,18 +488,11 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
   constexpr int W_BYTES = 3 * NB * WP;
   constexpr int PAR = 2 * NB * 4;
   constexpr int NT = 256 * NGRP;                                      // NGRP groups of 4 waves, one halo buffer each
-  constexpr int PSN_BYTES = PSNF ? PSN_TABLE(10) * 4 : 0;             // the PSN's T x T matrix and bias, rows padded to 16 bytes
-  static_assert(W_BYTES + NGRP * G::HALO + PAR + 64 + PSN_BYTES <= 160 * 1024, "LDS budget");
-  __shared__ __attribute__((aligned(16))) uint8_t smem[W_BYTES + NGRP * G::HALO + PAR + 64 + PSN_BYTES];
+  static_assert(W_BYTES + NGRP * G::HALO + PAR + 64 <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) uint8_t smem[W_BYTES + NGRP * G::HALO + PAR + 64];
   uint8_t* W_s = smem;
   float* par_s = reinterpret_cast<float*>(smem + W_BYTES + NGRP * G::HALO);
   uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + W_BYTES + NGRP * G::HALO + PAR);   // [g]: halo written, [NGRP + g]: halo read
-  float* psn_tbl = reinterpret_cast<float*>(smem + W_BYTES + NGRP * G::HALO + PAR + 64);
-  if constexpr (PSNF) {                                               // (visible behind the first __syncthreads of the segment loop)
-    SdfNeuronCfg pc = {};
-    pc.psn_w = P.d.psn_w; pc.psn_b = P.d.psn_b;
-    psn_stage<10>(psn_tbl, pc, threadIdx.x, NT);
-  }
 
   const SdfSpikeGemmDesc& d = P.d;
   const int H = P.cv.OH, W = P.cv.OW;                                 // the output image (== the input image at stride 1)
@@ -658,8 +643,8 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
     }
     for (; it < seg_end; it += NGRP) {
       item_decode(t_begin + it, cb, img0, y0, x0);
-      float vmem[SPIKE && !PSNF ? 16 * RB : 1];
-      if (SPIKE && !PSNF) {
+      float vmem[SPIKE ? 16 * RB : 1];
+      if (SPIKE) {
 #pragma unroll
         for (int e = 0; e < 16 * RB; ++e) vmem[e] = soft ? 0.f : d.v_reset;
       }
@@ -792,7 +777,7 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
             o.x = __builtin_fmaf(v[0], al4.x, be4.x) + rs[rb][q4].x; o.y = __builtin_fmaf(v[1], al4.y, be4.y) + rs[rb][q4].y;
             o.z = __builtin_fmaf(v[2], al4.z, be4.z) + rs[rb][q4].z; o.w = __builtin_fmaf(v[3], al4.w, be4.w) + rs[rb][q4].w;
             om[q4] = o;
-            if (SPIKE && !PSNF) {
+            if (SPIKE) {
               const float xs[4] = {o.x, o.y, o.z, o.w};
               uint32_t pk = 0;
               if (lif_fast) {
@@ -853,40 +838,6 @@ __global__ __launch_bounds__(256 * NGRP) void spike_conv_wres_i8_kernel(GemmPara
         STAMP(s5);
         STAMP_ADD(a_issue, s0, s1); STAMP_ADD(a_wait, s1, s2); STAMP_ADD(a_mfma, s2, s3); STAMP_ADD(a_epi, s3, s4); STAMP_ADD(a_hand, s4, s5);
       }
-      if constexpr (PSNF) {
-        // ---- PSN phase: the item's T x (tile) pre-activations are in d.out, every 16-byte piece written by the lane that now reads it ----
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's stores have left for L2
-        const int ql = l31 & 3;
-        const uint32_t ld4 = (uint32_t)d.ldo * 4u;
-        const int xq = x0 + (l31 & 15) - ql;                            // first pixel of this lane's quad
-        const uint32_t tpix = (uint32_t)(tstep * ohw);                  // pixel rows between two time steps of the item
-#pragma unroll 1
-        for (int rb = 0; rb < RB; ++rb) {
-          const int yy = y0 + 2 * RB * cw + (l31 >> 4) + 2 * rb;
-#pragma unroll 1
-          for (int j = 0; j < 4; ++j) {
-            const bool ok = yy < H && xq + j < W;
-            const uint32_t p0 = (uint32_t)((img0 * H + yy) * W + xq + j);
-            float4 xv[10];
-#pragma unroll
-            for (int t = 0; t < 10; ++t)
-              xv[t] = buf_load16f(out_rs, ok ? (p0 + (uint32_t)t * tpix) * ld4 + (uint32_t)(n0 + 8 * ql + 4 * lh) * 4u : INV);
-            uint32_t m[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              float xs[10];
-#pragma unroll
-              for (int t = 0; t < 10; ++t) xs[t] = c == 0 ? xv[t].x : (c == 1 ? xv[t].y : (c == 2 ? xv[t].z : xv[t].w));
-              m[c] = psn_T_lds_bits<10, 1>(xs, psn_tbl);
-            }
-#pragma unroll
-            for (int t = 0; t < 10; ++t) {
-              const uint32_t pk = ((m[0] >> t) & 1u) | (((m[1] >> t) & 1u) << 8) | (((m[2] >> t) & 1u) << 16) | (((m[3] >> t) & 1u) << 24);
-              __builtin_amdgcn_raw_buffer_store_b32(pk, sp_rs, ok ? (p0 + (uint32_t)t * tpix) * (uint32_t)N + (uint32_t)(n0 + 8 * ql + 4 * lh) : INV, 0, 0);
-            }
-          }
-        }
-      }
     }
     seg_begin = seg_end;
   }
@@ -926,9 +877,7 @@ bool spike_conv_wres_supports(const GemmParams& P, bool any_size) {
   if (d.sn_T != 0 && d.sn_T != 10 && !(d.nsplit == SDF_PLANES_I8X3 && (d.sn_T == 5 || d.sn_T == 20))) return false;
   const int64_t imgs = d.M / ((int64_t)c.OH * c.OW);
   if (d.sn_T > 0) {
-    if (d.bias) return false;
-    // the PSN (round 6): digit planes, T = 10, and the pre-activations need a place (d.out: the membrane output or a caller's scratch)
-    if (d.sn_kind == SDF_PSN && !(d.nsplit == SDF_PLANES_I8X3 && d.sn_T == 10 && d.out && d.psn_w && d.psn_b)) return false;
+    if (d.sn_kind == SDF_PSN || d.bias) return false;
     if (d.nsplit != SDF_PLANES_I8X3 && !any_size) return false;     // 16-bit planes: the fused form measured slower than the streaming kernel
     // positions must enumerate whole images, time steps and outer blocks must be whole images apart
     const int64_t ohw = (int64_t)c.OH * c.OW;
@@ -969,8 +918,7 @@ int launch_spike_conv_wres(const GemmParams& Pin, hipStream_t s) {
       // grid for equal rounds (648 fused items, 3 groups: 216 workgroups x 3 items instead of 256 of which 120 leave a group
       // idle) - same duration, and the compute units this launch does not need go to the other in-flight forwards' kernels
       const char* eg0 = sdf_sw(SW_CONV_WRES_GROUPS);
-      const bool psn_s2 = d.sn_T > 0 && d.sn_kind == SDF_PSN && c.Cin == 48;     // (its PSN form runs two wave groups, below)
-      const int ng = (d.sn_T > 0 && th == 8 && !psn_s2 && (eg0 ? eg0[0] == '3' : true)) ? 3 : 2;
+      const int ng = (d.sn_T > 0 && th == 8 && (eg0 ? eg0[0] == '3' : true)) ? 3 : 2;
       const int rounds = (P.ntiles + 256 * ng - 1) / (256 * ng), per = ng * rounds;
       if (P.ntiles >= 64) G = (P.ntiles + per - 1) / per;
       // column blocks of a tile range side by side on one XCD (see the kernel): the grid becomes a multiple of 8 * tiles_n, or of
@@ -987,21 +935,14 @@ int launch_spike_conv_wres(const GemmParams& Pin, hipStream_t s) {
     // (batch 1: 648 on this shape) THREE groups of waves per workgroup - 768 slots, one item each, the matrix pipe shared
     // three ways - instead of two groups with one or two items each
     const char* eg = sdf_sw(SW_CONV_WRES_GROUPS);                   // tuning override: 2 or 3
-    const bool g3 = d.sn_T > 0 && th == 8 && !(d.sn_kind == SDF_PSN && c.Cin == 48) && (eg ? eg[0] == '3' : true);
+    const bool g3 = d.sn_T > 0 && th == 8 && (eg ? eg[0] == '3' : true);
     const dim3 grid((unsigned)G);
     if (c.sy == 2 && c.Cin == 96) {
       SDF_LAUNCH((spike_conv_wres_i8_kernel<0, 3, 1, 2, true, 2>), grid, dim3(512), 0, s, P, d.col_scale);
     } else if (c.Cin == 48) {
       if (d.sn_T == 0) SDF_LAUNCH((spike_conv_wres_i8_kernel<0, 3, 1, 2, true>), grid, dim3(512), 0, s, P, d.col_scale);
-      else if (d.sn_kind == SDF_PSN)                                   // (two wave groups: the three-group form spills 12 registers in the PSN phase)
-        SDF_LAUNCH((spike_conv_wres_i8_kernel<10, 3, 1, 2, true, 1, false, true>), grid, dim3(512), 0, s, P, d.col_scale);
       else if (g3) SDF_LAUNCH((spike_conv_wres_i8_kernel<10, 3, 1, 3, true>), grid, dim3(768), 0, s, P, d.col_scale);
       else SDF_LAUNCH((spike_conv_wres_i8_kernel<10, 3, 1, 2, true>), grid, dim3(512), 0, s, P, d.col_scale);
-    } else
-    if (d.sn_kind == SDF_PSN && d.sn_T > 0) {
-      if (th == 16) SDF_LAUNCH((spike_conv_wres_i8_kernel<10, 6, 2, 2, false, 1, false, true>), grid, dim3(512), 0, s, P, d.col_scale);
-      else if (g3) SDF_LAUNCH((spike_conv_wres_i8_kernel<10, 6, 1, 3, false, 1, false, true>), grid, dim3(768), 0, s, P, d.col_scale);
-      else SDF_LAUNCH((spike_conv_wres_i8_kernel<10, 6, 1, 2, false, 1, false, true>), grid, dim3(512), 0, s, P, d.col_scale);
     } else
     if (d.sn_T == 0 && th == 16) SDF_LAUNCH((spike_conv_wres_i8_kernel<0, 6, 2, 2>), grid, dim3(512), 0, s, P, d.col_scale);
     else if (d.sn_T == 0) SDF_LAUNCH((spike_conv_wres_i8_kernel<0, 6, 1, 2>), grid, dim3(512), 0, s, P, d.col_scale);

@@ -361,20 +361,6 @@ class MSFlowEngine:
             bc = self._digit_chunk(B, D, h, w, Cin, Cout, stride)
             if bc:
                 return self._conv3x3_chunks(s, Wp, Cout, stride, bn, resid, sn, membrane, bc)
-        if digits is not None and sn is not None and sn.kind == "psn" and D == 10 and hip.sw("SDF_CONV_WRES_PSN", "1") != "0" and \
-                hip.conv_wres_applicable(B * D, h, w, Cin, Cout, stride, D) and (stride == 1 or resid is None):
-            # the PSN inside the digit kernel (round 6): its time loop leaves the fp32 pre-activations in `m` - the membrane the caller
-            # asked for, or a scratch tensor - and a PSN phase behind it turns them into spikes while they are still in L2 (csrc/
-            # spike_conv_wres.hip PSNF): no neuron launch, the tensor makes one trip through HBM instead of two
-            if _dst is not None and len(_dst) == (2 if membrane else 1) and _dst[-1].dtype == torch.uint8:
-                sp, m = _dst[-1], (_dst[0] if membrane else None)
-            else:
-                sp, m = torch.empty((B, D, oh, ow, Cout), dtype=torch.uint8, device=s.device), None
-            if m is None:
-                m = torch.empty((B, D, oh, ow, Cout), dtype=torch.float32, device=s.device)
-            hip.spike_conv2d(s, digits, B * D, h, w, Cin, oh, ow, 3, 3, stride, (-1, 0, 1), (-1, 0, 1), out=m, out_spike=sp, alpha=a, beta=b,
-                             resid=resid if membrane else None, sn=sn, sn_T=D, pos=(B * oh * ow, oh * ow, D * oh * ow, oh * ow))
-            return (m, sp) if membrane else sp
         if digits is not None and sn is not None and (sn.kind == "psn" or D not in (5, 10, 20)) and \
                 hip.conv_wres_applicable(B * D, h, w, Cin, Cout, stride, 1):
             # the digit kernel's fused form is LIF / IF over T = 5 / 10 / 20; other neurons (the shipped PSN) take its fp32 form and

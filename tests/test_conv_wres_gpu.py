@@ -165,46 +165,6 @@ def test_digit_kernel_fused_neuron_at_T5_and_T20(T, B, H, W):
     assert (sp2.cpu().float() != w0).float().mean().item() <= 2e-4
 
 
-@pytest.mark.parametrize("form", ["three_groups", "two_groups", "two_row_blocks", "stride2"])
-@pytest.mark.parametrize("B,H,W,with_res", [(2, 24, 32, True), (1, 21, 37, False), (3, 40, 48, True)])
-def test_digit_kernel_fused_psn(form, B, H, W, with_res):
-    """The PSN as the digit convolution's fused neuron (round 6, PSNF): the time loop leaves the fp32 pre-activations in `out`, the PSN
-    phase behind it re-reads them and writes the spikes.  Every wave-group / row-block form the dispatcher can pick and the stride-2 form:
-    the membrane is the fp32-epilogue launch's membrane bit for bit, the spikes are the C oracle's PSN (k-ordered fmaf chain) of THAT
-    membrane bit for bit - i.e. exactly what conv + neuron_kernel<10> gave.  Tile-aligned and ragged images, with and without a shortcut."""
-    T, Cout = 10, 96
-    s2 = form == "stride2"
-    Cin, st = (48, 2) if s2 else (96, 1)
-    with_res = with_res and not s2                                      # (the stride-2 fused form has no shortcut input)
-    OH, OW = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if s2 else (H, W)
-    x = spikes((B * T, H, W, Cin), 400 + H)
-    w = rnd((Cout, Cin, 3, 3), 401, -0.1, 0.1)
-    alpha, beta = rnd((Cout,), 402, 0.5, 1.5), rnd((Cout,), 403, -0.4, 0.1)
-    n = OH * OW
-    resid = rnd((B * T * n, Cout), 404) if with_res else None
-    Wp = pack(w, "i8x3")
-    sn = hip.NeuronParams("psn", psn_w=rnd((T, T), 405, -0.6, 0.8).to(DEV), psn_b=rnd((T,), 406, -0.3, 0.1).to(DEV))
-    pos = (B * n, n, T * n, n)
-    sw = {"SDF_CONV_WRES": "2"}                                          # (at any size: these images are far below the dispatcher's rule)
-    if form == "two_groups":
-        sw["SDF_CONV_WRES_GROUPS"] = "2"
-    if form == "two_row_blocks":
-        sw["SDF_CONV_WRES_RB"] = "2"
-    args = (x.to(DEV), Wp, B * T, H, W, Cin, OH, OW, 3, 3, st, (-1, 0, 1), (-1, 0, 1))
-    kw = dict(alpha=alpha.to(DEV), beta=beta.to(DEV), resid=None if resid is None else resid.to(DEV))
-    with hip.scoped_switches(**sw):
-        m0 = torch.full((B * T * n, Cout), float("nan"), device=DEV)
-        hip.spike_conv2d(*args, out=m0, **kw)                           # the fp32-epilogue launch
-        m = torch.full((B * T * n, Cout), float("nan"), device=DEV)
-        sp = torch.full((B * T * n, Cout), 7, dtype=torch.uint8, device=DEV)
-        hip.spike_conv2d(*args, out=m, out_spike=sp, sn=sn, sn_T=T, pos=pos, **kw)
-    torch.cuda.synchronize()
-    assert torch.equal(m, m0)
-    mt = m.cpu().view(B, T, n * Cout).permute(1, 0, 2).contiguous().view(T, -1)                  # (T, B, ...)
-    want = R.neuron_ref(mt, "psn", psn_w=sn.psn_w.cpu(), psn_b=sn.psn_b.cpu()).view(T, B, n * Cout).permute(1, 0, 2).reshape(B * T * n, Cout)
-    assert torch.equal(sp.cpu().float(), want) and 0.03 < want.mean() < 0.97
-
-
 @pytest.mark.parametrize("Cin", [48, 96])
 @pytest.mark.parametrize("imgs,H,W,Cout,with_res", [(10, 48, 64, 96, True), (3, 21, 37, 96, True), (2, 16, 32, 64, False), (4, 35, 66, 32, False),
                                                     (1, 1, 1, 96, False)])
