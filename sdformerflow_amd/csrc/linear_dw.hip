@@ -19,6 +19,12 @@
 // into THREE bf16 planes by truncation (hi = top 16 bits, mid = top 16 bits of the exact remainder, lo = the rest: 8 + 8 + 8
 // mantissa bits, hi + mid + lo == dY exactly, fp32's exponent range, no scale to choose), three products per block, fp32 accumulation.
 // The kernel is HBM-bound at N = K = 96 (480 B of operands per row against 55 kflop x 3) and the third product is free there.
+// All three planes of a block share ONE accumulator (linear_train.hip keeps hi x hi apart: the 16-bit pipe drops alignment bits
+// one-sidedly when a small product meets a large running sum).  Measured for this kernel (tools/linear_train_bias.py,
+// profiles/r5bd_linear_train_bias.txt): per element of dW - a 276 480-long sum - rms error 2.1e-7 of mean |dw| against the
+// library's 2.2e-6, bias -1.4e-7 of mean |dw|; a weight gradient is consumed element by element (clip, AdamW), nothing sums over it the
+// way a PSN bias gradient sums over dX, so the second accumulator (27 more registers per tap set: the convolution form has none
+// left) buys nothing here.
 //
 // A workgroup (4 waves) owns a 96 x 96 tile of dW over a contiguous range of m; a wave 48 x 48 (3 x 3 blocks of 16 x 16).  m advances
 // in chunks of 32 through a double-buffered LDS image (next chunk requested before the MFMAs, split / written after them, one

@@ -530,9 +530,11 @@ extern "C" int sdf_spike_gemm_fwd(const SdfSpikeGemmDesc* d, void* stream) {
   int cfg = (spike && d->sn_T >= 5) ? (ok(1) ? 1 : 2) : 3;
   if (!spike) {
     // fp32 epilogue: 256 x 32 or 128 x 32 tiles, whichever needs less time in whole rounds of the 768 resident workgroups
-    // (a 256-row tile costs two 128-row ones); ties go to the larger tile (fewer weight reloads).  tools/gemm_cfg_sweep.py
+    // (a 256-row tile costs two 128-row ones); ties go to the SMALLER tile since round 6: with many rows (10 samples per launch
+    // sequence: 712 800 rows of the stage-0 projection) the count always ties and the 256-row tile measured 44.5 us per sample
+    // against 29.5 (gpurun_out -> profiles/r6_launch_table_R4.txt / _R10.txt; same-box A/B +0.4 % of the headline)
     const int64_t r2 = (ntiles_for(2) + 767) / 768 * 2, r3 = (ntiles_for(3) + 767) / 768;
-    cfg = r2 <= r3 ? 2 : 3;
+    cfg = r2 < r3 ? 2 : 3;
   }
   if (!ok(cfg)) cfg = ok(2) ? 2 : 0;
   if (const char* e = sdf_sw(SW_GEMM_CFG)) {                  // tuning override: 0..3
