@@ -15,6 +15,6 @@ if not fs:
     raise SystemExit("no kernel_stats.csv")
 rows = list(csv.DictReader(open(fs[0])))
 print("rocprofv3 --kernel-trace --stats of: python3 tools/ann_try.py  (15 forwards of config 3: 2 checked + 3 warm-up + 10 timed)")
-for r in rows[:26]:
+for r in rows:                                        # (every kernel of the run: library remnants included)
     print(f"{r['Name'][:120]:120s} calls {int(r['Calls']):6d}  total {float(r['TotalDurationNs'])/1e6:9.2f} ms  avg {float(r['AverageNs'])/1e3:8.1f} us  {float(r['Percentage']):5.1f} %")
 PY
