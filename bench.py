@@ -195,6 +195,36 @@ def time_dominant_kernels(model, iters=40):
     return gemm, neuron
 
 
+def streams_rate(fwd, inputs, iters):
+    """Seconds per call of fwd(x) with len(inputs) calls in flight: every input gets its own HIP stream and the HIP graph of one call,
+    the graphs are replayed round-robin (the headline's streams-and-graphs level for the side configurations, whose batches keep the
+    reference's own batch semantics).  Raises when a forward cannot be captured."""
+    streams = [torch.cuda.Stream() for _ in inputs]
+    graphs, outs = [], []
+    for st, x in zip(streams, inputs):
+        with torch.cuda.stream(st):
+            for _ in range(2):
+                fwd(x)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            outs.append(fwd(x))
+        graphs.append(g)
+    torch.cuda.synchronize()
+    for i in range(len(inputs)):
+        with torch.cuda.stream(streams[i]):
+            graphs[i].replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        with torch.cuda.stream(streams[i % len(inputs)]):
+            graphs[i % len(inputs)].replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    del graphs
+    return dt, outs
+
+
 def time_config3(iters=10):
     """BASELINE configs[2] beside the headline: the ANN STTFlowNet (STT_voxel config: 20 bins, patch (10,4,4), window (2,9,9)) at
     batch 8, 288 x 384, synthetic weights and voxels - ms per batch, samples/s - and its dominant kernel, the dense 3x3
@@ -221,6 +251,17 @@ def time_config3(iters=10):
             net(vox, None)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / iters
+        # the same forward with two batches in flight (own stream, own HIP graph each): what the headline's scheme gives this configuration
+        two = None
+        try:
+            vox2 = synth_voxel(B, 20, H, W, seed=1247).to("cuda")
+            dt2, outs2 = streams_rate(lambda v: net(v, None)["flow"], [vox, vox2], 2 * iters)
+            assert all(torch.equal(a, b) for a, b in zip(outs2[0], flow)), "a graph replay of config 3 differs from the eager forward"
+            two = {"samples_per_s": B / dt2, "ms_per_batch": dt2 * 1e3, "in_flight": 2, "hip_graph": True}
+            del outs2, vox2
+        except Exception as e:                                       # (a side figure: never takes the line down)
+            two = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
     g = torch.Generator().manual_seed(0)
     sets = []
     for _ in range(2):                                             # 2 x (0.68 GB in + 0.68 GB residual + 0.68 GB out) > 3 x the Infinity Cache
@@ -268,7 +309,7 @@ def time_config3(iters=10):
     except Exception as e:                                         # a side line must never take the headline down with it
         half = {"error": repr(e)[:300]}
     return {"workload": "BASELINE configs[2]: STTFlowNet (ANN) forward, batch 8, 20-bin 288x384 voxel, fp32 activations", "samples_per_s": B / dt,
-            "attention_half_block_stage0": half,
+            "two_batches_in_flight": two, "attention_half_block_stage0": half,
             "ms_per_batch": dt * 1e3, "dtype": "f32 as f16x2 (hi + lo planes of both operands, three products, fp32 accumulate)",
             "roofline": {"kernel": "dense_conv_wres_kernel<6> (16 x 96 x 288 x 384, 3x3, BN + residual + ReLU fused)", "bound": "mfma",
                          "achieved": flop / t / 1e12, "executed_on_pipe": 3 * flop / t / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
@@ -441,6 +482,15 @@ def side_measurements(args, dev):
         assert torch.isfinite(o["flow"][-1]).all()
         out["config5_T20_480x640_batch4"] = {"workload": "BASELINE configs[4]: en4 forward, 20 bins / T = 20, 480x640, batch 4, neuron=lif, one stream (eager)",
                                              "samples_per_s": 4 / dt, "ms_per_batch": dt * 1e3}
+        try:                                                       # two batches in flight (own stream, own HIP graph each): the headline's streams level
+            x5b = prepare_chunk(synth_voxel(4, 20, 480, 640, seed=1249)).to(dev)
+            with torch.no_grad():
+                dt2, outs2 = streams_rate(lambda v: m5(v)["flow"], [x5, x5b], 8)
+            assert all(torch.equal(a, b) for a, b in zip(outs2[0], o["flow"])), "a graph replay of configs[4] differs from the eager forward"
+            out["config5_T20_480x640_batch4"]["two_batches_in_flight"] = {"samples_per_s": 4 / dt2, "ms_per_batch": dt2 * 1e3, "hip_graph": True}
+            del outs2, x5b
+        except Exception as e:
+            out["config5_T20_480x640_batch4"]["two_batches_in_flight"] = {"error": repr(e)[:200]}
         del m5, x5, o
     except Exception as e:                                         # a side line must never take the headline down with it
         out["config5_T20_480x640_batch4"] = {"error": repr(e)[:300]}
