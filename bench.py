@@ -256,7 +256,8 @@ def time_config3(iters=10):
         try:
             vox2 = synth_voxel(B, 20, H, W, seed=1247).to("cuda")
             dt2, outs2 = streams_rate(lambda v: net(v, None)["flow"], [vox, vox2], 2 * iters)
-            assert all(torch.equal(a, b) for a, b in zip(outs2[0], flow)), "a graph replay of config 3 differs from the eager forward"
+            # (config 3 is not bit-equal run to run: the library convolutions of its 384-channel res-blocks pick their reduction order)
+            assert all(float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) for a, b in zip(outs2[0], flow)), "a graph replay of config 3 left the eager forward"
             two = {"samples_per_s": B / dt2, "ms_per_batch": dt2 * 1e3, "in_flight": 2, "hip_graph": True}
             del outs2, vox2
         except Exception as e:                                       # (a side figure: never takes the line down)
