@@ -565,7 +565,7 @@ def _acc_scale(Wp):
 def spike_gemm(A, Wp, out, M, N, K, lda=None, ldo=None, bias=None, alpha=None, beta=None, resid=None,
                out_rowmap=None, zg=None):
     """sdf_spike_gemm_fwd.  A: u8 spikes, Wp: int16 (nsplit,N,K) bf16 planes, out: fp32.
-    zg = (nH, Tq, B_, N1) selects the head-scramble A addressing."""
+    zg = (nH, Tq, B_, N1[, windows per replica]) selects the head-scramble A addressing."""
     d = SpikeGemmDesc()
     d.A, d.Wp, d.out = _ptr(A, torch.uint8), _ptr(Wp), _ptr(out, torch.float32)
     d.M, d.N, d.K = M, N, K
@@ -584,7 +584,8 @@ def spike_gemm(A, Wp, out, M, N, K, lda=None, ldo=None, bias=None, alpha=None, b
     if out_rowmap is not None:
         d.out_rows = out.numel() // d.ldo
     if zg is not None:
-        d.zg_nH, d.zg_T, d.zg_B, d.zg_N1 = zg
+        d.zg_nH, d.zg_T, d.zg_B, d.zg_N1 = zg[:4]
+        d.zg_rep = zg[4] if len(zg) > 4 else 0                 # (windows per independent replica: SdfSpikeGemmDesc.zg_rep)
     _set_ws(d, A)
     _note(flop=2 * int(d.M) * int(d.N) * int(d.K), shape=(int(d.M), int(d.N), int(d.K)))
     _check(lib().sdf_spike_gemm_fwd(C.byref(d), _stream()), "sdf_spike_gemm_fwd")

@@ -128,3 +128,69 @@ def test_replica_forward_refuses_the_tape():
             eng.forward(torch.zeros((2, 10, 2, 144, 192), device=DEV), None, replicas=True)
     finally:
         eng.tape = None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns", [2, 3])
+@pytest.mark.parametrize("nW,nH,R,rows_big", [(4, 3, 3, False), (2, 6, 2, False), (10, 3, 40, True)])
+def test_head_scramble_of_replicas_at_the_kernel(nW, nH, R, rows_big, ns):
+    """sdf_spike_gemm_fwd with zg_rep: the projection's operand gather of R independent problems in one (T', R nW, N1, C) buffer = R
+    separate calls on every replica's own (T', nW, N1, C) tensor, bit for bit (same tile kernel, same K order) - both the small-tile
+    kernel and, at many rows, whatever the dispatcher picks."""
+    from sdformerflow_amd.synthetic import synth_uniform as rnd
+    Tq, N1 = 2, 81
+    Cc = nH * 32
+    g = torch.Generator().manual_seed(7 + nW)
+    E = (torch.rand((Tq, R, nW, N1, Cc), generator=g) < 0.3).to(torch.uint8)
+    W = hip.split_weight(rnd((Cc, Cc), 41, -0.3, 0.3).to(DEV), ns)
+    M1 = Tq * nW * N1
+    out = torch.empty((Tq * R * nW * N1, Cc), device=DEV)
+    hip.spike_gemm(E.to(DEV), W, out, Tq * R * nW * N1, Cc, Cc, zg=(nH, Tq, R * nW, N1, nW))
+    out = out.view(Tq, R, nW * N1, Cc)
+    for r in (range(R) if not rows_big else (0, R // 2, R - 1)):
+        Er = E[:, r].contiguous().to(DEV)
+        o1 = torch.empty((M1, Cc), device=DEV)
+        hip.spike_gemm(Er, W, o1, M1, Cc, Cc, zg=(nH, Tq, nW, N1))
+        assert torch.equal(out[:, r].reshape(M1, Cc), o1), r
+    with pytest.raises(hip.SdfError):                                      # windows per replica must divide B_ and be a multiple of T'
+        hip.spike_gemm(E.to(DEV), W, out.view(-1, Cc), Tq * R * nW * N1, Cc, Cc, zg=(nH, Tq, R * nW, N1, 3 if nW != 3 else 5))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+def test_neuron_descriptor_outermost_dimension(kind):
+    """SdfNeuronDesc.nrep: the batch elements of a pixel-strided channel slice as ONE descriptor = one launch per batch element."""
+    from sdformerflow_amd.synthetic import synth_uniform as rnd
+    B, T, hw, C2, cp, c1 = 3, 10, 35, 96, 208, 16
+    x = rnd((B, T, hw, C2), 5, -0.4, 0.8).to(DEV)
+    p = hip.NeuronParams("psn", psn_w=rnd((T, T), 6, -0.3, 0.6).to(DEV), psn_b=rnd((T,), 7, -0.2, 0.1).to(DEV)) if kind == "psn" else \
+        hip.NeuronParams("lif", 2.0, 0.1, None)
+    one = torch.zeros((B, T, hw, cp), dtype=torch.uint8, device=DEV)
+    hip.neuron_multi_fwd([(x, one.view(-1)[c1:], T, hw, C2, C2, hw * C2, cp, hw * cp, p, None, 0, None, None, 0, 1, None, 0, 0, None,
+                           (B, T * hw * C2, T * hw * cp)),
+                          (x, one.view(-1)[c1 + C2:], T, hw, 32, C2, hw * C2, cp, hw * cp, p, None, 0, None, None, 0, 1, None, 0, 0, None,
+                           (B, T * hw * C2, T * hw * cp))])
+    ref = torch.zeros_like(one)
+    for b in range(B):
+        hip.neuron_fwd(x[b], ref[b].view(-1)[c1:], T, hw, C2, C2, hw * C2, cp, hw * cp, p)
+        hip.neuron_fwd(x[b], ref[b].view(-1)[c1 + C2:], T, hw, 32, C2, hw * C2, cp, hw * cp, p)
+    assert torch.equal(one, ref) and 0.02 < one[..., c1:c1 + C2].float().mean() < 0.98
+
+
+@pytest.mark.gpu
+def test_launch_log_reports_every_launch_of_a_call():
+    """sdf_launch_log: kernel name, workgroups, threads and an event-timed duration per launch; off again afterwards."""
+    x = torch.rand((10, 1 << 16), device=DEV)
+    with hip.launch_log() as log:
+        hip.lif_fwd(x, 2.0, 0.1, None, torch.uint8)
+        hip.lif_fwd(x, 2.0, 0.1, None, torch.uint8)
+    assert len(log.rows) == 2
+    for name, wgs, thr, lds, us in log.rows:
+        assert "neuron_kernel<10>" in name and wgs == (1 << 16) // 4 // 256 and thr == 256 and 0.0 < us < 1e4
+    with hip.launch_log() as log2:
+        pass
+    assert log2.rows == []
+    hip.lif_fwd(x, 2.0, 0.1, None, torch.uint8)                        # (not logged: the log is off)
+    with hip.launch_log() as log3:
+        pass
+    assert log3.rows == []
