@@ -1,7 +1,8 @@
 #!/usr/bin/env bash
 # Counters of BASELINE configs[3]'s training step (local batch 4), per kernel family: vector / matrix instructions, matrix-pipe busy
-# cycles, HBM bytes (separate --pmc passes; FETCH_SIZE x 2 on gfx950, KiB) summed over ALL launches of `python3 bench.py --train --steps 3
-# --warmup 1` (4 identical steps; MIOpen's one-time kernel search of the first step rides along) and divided by 4.
+# cycles, HBM bytes (separate --pmc passes; FETCH_SIZE x 2 on gfx950, KiB) summed over the launches of ONE steady-state step of `python3
+# bench.py --train --steps 3 --warmup 1`: from the gradient clip of the third step (its one `lpnorm_cleanup` launch) to the clip of the
+# fourth - optimiser update, forward, loss, backward; MIOpen's one-time kernel search of the first step stays outside.
 # usage (GPU box): tools/pmc_train_step.sh [tag] -> gpurun_out/<tag>_pmc_train_step.txt
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}" || exit 1
 TAG=${1:-r6}
@@ -27,18 +28,21 @@ def fam(n):
 per = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 for d in sorted(glob.glob(out + "/p*")):
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
+    rows = [r for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True) for r in csv.DictReader(open(f))]
+    clips = sorted({int(r["Dispatch_Id"]) for r in rows if "lpnorm_cleanup" in r["Kernel_Name"]})
+    lo, hi = clips[-2], clips[-1]
+    for r in rows:
+        if lo < int(r["Dispatch_Id"]) <= hi:
             k = fam(r["Kernel_Name"])
             per[k][r["Counter_Name"]] += float(r["Counter_Value"])
             if d.endswith("p0") and r["Counter_Name"] == "SQ_WAVES":
                 cnt[k] += 1
-S = 4.0
+S = 1.0
 tot = collections.defaultdict(float)
 for k, v in per.items():
     for c, x in v.items():
         tot[c] += x
-print(f"configs[3] training step, local batch 4 (per step = all launches of 4 steps / 4): VALU {tot['SQ_INSTS_VALU'] / S / 1e6:.0f} M wave-instructions "
+print(f"configs[3] training step, local batch 4, one steady-state step ({sum(cnt.values())} launches): VALU {tot['SQ_INSTS_VALU'] / S / 1e6:.0f} M wave-instructions "
       f"({tot['SQ_INSTS_VALU'] / S * 4 / 1024 / 2.4e6:.1f} ms of the chip's vector issue at 2.4 GHz), MFMA {tot['SQ_INSTS_MFMA'] / S / 1e6:.1f} M, matrix pipe busy "
       f"{tot['SQ_VALU_MFMA_BUSY_CYCLES'] / S / 1024 / 2.4e6:.1f} ms per SIMD, HBM {2 * tot['FETCH_SIZE'] * 1024 / S / 1e9:.1f} GB read + {tot['WRITE_SIZE'] * 1024 / S / 1e9:.1f} GB written "
       f"({(2 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024 / S / 8e9:.1f} ms at 8 TB/s)")
