@@ -109,7 +109,8 @@ class SEWFlowEngine(MSFlowEngine):
         out = torch.empty((M, Cc), dtype=out_dtype, device=y.device)
         n = M // T * Cc
         hip.neuron_fwd(y, out, T, 1, n, 0, n, 0, n, p, alpha=bn[0], beta=bn[1], Cch=Cc, inner=1)
-        self._rec(name, out.to(torch.uint8) if out_dtype != torch.uint8 else out, "flat")
+        if self.tape is not None:                     # (the byte copy is the tape's: not made when nothing records it)
+            self._rec(name, out.to(torch.uint8) if out_dtype != torch.uint8 else out, "flat")
         return out
 
     # ------------------------------------------------------------------ stages
@@ -152,7 +153,8 @@ class SEWFlowEngine(MSFlowEngine):
         y = torch.empty((B, D, H, W, Cc), dtype=torch.float32, device=x.device)
         hip.spike_gemm(s1, blk.fc2.Wp, y, B * D * H * W, Cc, blk.fc2.K, alpha=blk.fc2.alpha, beta=blk.fc2.beta)
         s2 = self._neuron_bd(y, blk.sn2, out_dtype=torch.float32)
-        self._rec(blk.name + "mlp.sn2.spiking_neuron.", s2.to(torch.uint8), "BDHWC->TBHWC")
+        if self.tape is not None:
+            self._rec(blk.name + "mlp.sn2.spiking_neuron.", s2.to(torch.uint8), "BDHWC->TBHWC")
         return s2
 
     def swin_block(self, x, s, i):
@@ -202,7 +204,8 @@ class SEWFlowEngine(MSFlowEngine):
         s1 = self._neuron_bd(y, rb.sn1, bn=rb.bn1)
         self._rec(rb.name + "sn1.spiking_neuron.", s1, "BDHWC->TBCHW")
         s2 = self._neuron_bd(self._conv3x3(s1, rb.w2, rb.C, bn=rb.bn2), rb.sn2, out_dtype=torch.float32)
-        self._rec(rb.name + "sn2.spiking_neuron.", s2.to(torch.uint8), "BDHWC->TBCHW")
+        if self.tape is not None:
+            self._rec(rb.name + "sn2.spiking_neuron.", s2.to(torch.uint8), "BDHWC->TBCHW")
         return s2 + x
 
     def _deconv_dense_fwd(self, i, parts, wdec):
