@@ -60,11 +60,12 @@ json.dump({"source": "tools/pmc_forward2.sh (rocprofv3 --pmc, separate passes; F
 print(f"one eager launch sequence of config 2 over {R} sample(s): {sum(cnt.values())} launches, kernel time {sum(dur.values()):.0f} us; VALU {tot['SQ_INSTS_VALU'] / 1e6:.1f} M wave-instructions, "
       f"MFMA {tot['SQ_INSTS_MFMA'] / 1e6:.2f} M, matrix-pipe busy {tot['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / 1e3:.0f} k cycles per SIMD, "
       f"HBM {2 * tot['FETCH_SIZE'] * 1024 / 1e9:.2f} GB read + {tot['WRITE_SIZE'] * 1024 / 1e9:.2f} GB written")
-print(f"{'kernel':64s} {'n':>3s} {'us':>7s} {'VALU M':>8s} {'MFMA M':>7s} {'VALU/MFMA':>9s} {'pipe busy %':>11s} {'LDS confl %':>11s} {'read MB':>8s} {'write MB':>8s}")
+print(f"{'kernel':64s} {'n':>3s} {'us':>7s} {'VALU M':>8s} {'MFMA M':>7s} {'VALU/MFMA':>9s} {'pipe busy %':>11s} {'LDS confl %':>11s} {'read MB':>8s} {'write MB':>8s} {'LDS M':>7s} {'LDS busy %':>10s}")
 for k in sorted(per, key=lambda k: -dur[k]):
     v = per[k]
     busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / max(dur[k] * 2200, 1) * 100          # per SIMD, against the launch time at ~2.2 GHz
     print(f"{k:64s} {cnt[k]:3d} {dur[k]:7.1f} {v['SQ_INSTS_VALU'] / 1e6:8.2f} {v['SQ_INSTS_MFMA'] / 1e6:7.3f} {v['SQ_INSTS_VALU'] / max(v['SQ_INSTS_MFMA'], 1):9.1f} "
-          f"{busy:11.1f} {100 * v['SQ_LDS_BANK_CONFLICT'] / max(v['SQ_LDS_IDX_ACTIVE'], 1):11.1f} {2 * v['FETCH_SIZE'] * 1024 / 1e6:8.1f} {v['WRITE_SIZE'] * 1024 / 1e6:8.1f}")
+          f"{busy:11.1f} {100 * v['SQ_LDS_BANK_CONFLICT'] / max(v['SQ_LDS_IDX_ACTIVE'], 1):11.1f} {2 * v['FETCH_SIZE'] * 1024 / 1e6:8.1f} {v['WRITE_SIZE'] * 1024 / 1e6:8.1f} "
+          f"{v['SQ_INSTS_LDS'] / 1e6:7.2f} {100 * v['SQ_LDS_IDX_ACTIVE'] / 1024 / max(dur[k] * 2200, 1):10.1f}")
 PY
 rm -rf ${OUT:?}/p* ${OUT:?}/trace
