@@ -4,7 +4,7 @@
 //
 // - reference models/STSwinNet/swin_transformer3D_v2.py:312-336 (`forward_part2` + the shortcut) with `Mlp.forward` (:15-34) inside.
 // Three launches before (LayerNorm, fc1 + GELU, fc2 + shortcut): the hidden activations - 4 C floats per token, 170 MB on BASELINE config
-// 3's first stage - were written and read back, and both Linear launches were HBM-bound on them.  The companion of
+// 3's first stage - were written and read back, and both Linear launches were HBM-bound on them (docs/history/DESIGN_rounds1-5.md section 5).  The companion of
 // ann_block.hip, same ownership: a wave keeps 16 tokens for the whole kernel, LayerNorm(x) lives in its registers as the fp16 hi / lo
 // operand of fc1; the hidden dimension is walked in chunks of 96: H^T chunk = W1[chunk] LN(x)^T with the weights as the MFMA's row
 // operand - a lane ends with hidden units of ITS token - GELU in registers, split into hi / lo: that IS the column operand of
@@ -58,7 +58,7 @@ __device__ __forceinline__ f32x4 mma3(const f16x8& ah, const f16x8& al, const f1
 //   erfc(u) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-u^2), t = 1 / (1 + p u), u = |x| / sqrt 2
 //   gelu(x) = x q for x < 0, x - x q for x >= 0, q = erfc(u) / 2   (no cancellation for large negative x)
 // One reciprocal, one exp2 and ten multiply-adds, branch-free: the library erff (two masked branches, ~ 50 instructions per value) made
-// this kernel's 96 GELUs per lane three times its matrix work (117 us per launch; with this form: see DESIGN.md section 6).
+// this kernel's 96 GELUs per lane three times its matrix work (117 us per launch; with this form: see docs/history/DESIGN_rounds1-5.md section 6).
 __device__ __forceinline__ float gelu_erf(float x) {
   const float u = fabsf(x) * 0.70710678118654752440f;
   const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, u, 1.f));

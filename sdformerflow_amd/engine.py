@@ -10,7 +10,8 @@ Turns the module tree (state_dict holder) into a flat schedule of C-ABI kernel l
   * spikes travel as 1 byte between kernels
   * the convolutions either side of the swin stages (patch embedding, U-Net tail: SURVEY.md 8f rows 1-2) are implicit-GEMM
     spike convolutions with the BN / residual / neuron epilogues fused; the large 96-channel 3x3 launches take int8 digit
-    planes and the weight-resident kernel (csrc/spike_conv_wres.hip); only the 1x1 PED shortcut on the fp32 membrane is MIOpen
+    planes and the weight-resident kernel (csrc/spike_conv_wres.hip); no library kernel is left in the SNN forward
+  * `forward(x, replicas=True)`: the B samples are B independent batch-1 forwards in one launch sequence (round 6; `_rb`, `_slice_map`)
   * `tape` (tests only) keeps every neuron layer's spikes for the spike-forced oracle replay (tests/replay.py)
 
 Reference schedule being replaced: models/STSwinNet_SNN/Spiking_STSwinNet.py:161-182,278-305 and the

@@ -505,7 +505,7 @@ def wide_conv_applicable(imgs, H, W, Cin, Cout, stride, T):
     """Mirror of the library's dispatch rule for the small-M digit convolution (csrc/ms_wide.hip: wide_conv_supports): 3x3 / stride 1
     on Cin % 128 == 0 channels, at most 131 072 output rows (SDF_WIDE_MAXROWS) in (B, T, H, W) order with T in {10, 20}."""
     if sw("SDF_WIDE", "") == "0" or sw("SDF_WIDE_CONV", "") != "1" or stride != 1 or Cin % 128 or Cout % 32:
-        return False                                             # (opt-in: measured no faster than the streaming kernel + split-K, DESIGN.md)
+        return False                                             # (opt-in: measured no faster than the streaming kernel + split-K, docs/history/DESIGN_rounds1-5.md)
     return T in (10, 20) and imgs % T == 0 and imgs * H * W <= int(sw("SDF_WIDE_MAXROWS", 131072))
 
 

@@ -36,7 +36,7 @@ from . import hip
 # with that many weight planes and the activation saved as 1-byte spikes.  Measured at local batch 4: same parity (block-level
 # gradients still equal the reference fixture element for element), 2.5 GiB less memory, but the step is SLOWER (fp32 123 ->
 # 130 ms: u8 conversion + per-step weight split + fp32 re-expansion in the backward; under bf16 autocast 95 -> 114 ms because
-# the backward products leave autocast) - so it stays off until the backward products are spike-aware too.
+# the backward products leave autocast) - so it stays off until the backward products are spike-aware too (docs/history/DESIGN_rounds1-5.md, round-2 list item 4).
 SPIKE_LINEAR_PLANES = 0
 # Weight gradient of the Linear layers on csrc/linear_dw.hip (round 5; SDF_TRAIN_LINEAR_DW=0: the library product, for A/B runs)
 LINEAR_DW_HIP = os.environ.get("SDF_TRAIN_LINEAR_DW", "1") != "0"

@@ -298,7 +298,7 @@ def test_spike_conv3x3_fp32_epilogue(imgs, H, W, Cin, Cout, stride, ns):
 def test_spike_conv3x3_fused_neuron(kind, B, H, W, ns):
     """conv -> BN -> neuron over T=10 in one kernel (MS_ResBlock conv1 -> norm1 -> sn2, Spiking_modules.py:914-920).
     The 72 x 96 case runs several tiles per workgroup with both consumer groups and the producers busy - the
-    configuration in which SLP-packed f32 FMAs once corrupted the PSN sums of the last 16 lanes."""
+    configuration in which SLP-packed f32 FMAs once corrupted the PSN sums of the last 16 lanes (findings)."""
     T, Cc = 10, 96
     x = spikes((T * B, H, W, Cc), 95)
     w = rnd((Cc, Cc, 3, 3), 96, -0.1, 0.1)

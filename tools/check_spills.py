@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build-time check (csrc/build.sh): no kernel of the given resource-remark files (hipcc -Rpass-analysis=kernel-resource-usage, kept as
 csrc/obj/<file>.res) may spill registers or use scratch.  VERDICT r4 #6: the small-M kernel's 32-column instantiations spilled 9 - 12
-VGPRs; scratch accesses are vmcnt-ordered vector memory operations and drain the operand prefetch."""
+VGPRs; scratch accesses are vmcnt-ordered vector memory operations and drain the operand prefetch (findings)."""
 import re
 import subprocess
 import sys
