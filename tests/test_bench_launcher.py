@@ -97,3 +97,19 @@ def test_train_gpus_2_runs_the_real_step_under_gloo():
     first, last = r["loss_first_last"]
     assert last < first and last == last
     assert abs(r["value"] - 2 * 2 * 6 / (r["ms_per_step"] * 6e-3)) < 1e-6 * r["value"]
+
+
+def test_inflight_plan_deals_exactly_n_samples_evenly():
+    """bench.InFlight._plan: the K timed steps (one forward of one sample each) are dealt evenly to the F streams, a stream's share as
+    replays of its R-sample graph plus one remainder graph - EXACTLY K samples whatever R and F are (the contract's "time exactly K steps")."""
+    import bench
+    for R in (1, 3, 4, 10):
+        for F_ in (1, 2, 3):
+            fl = bench.InFlight.__new__(bench.InFlight)
+            fl.F, fl.R = F_, R
+            for n in (1, 5, 20, 96, 97, 300):
+                plan = fl._plan(n)
+                assert sum(m for _, m in plan) == n and all(0 < m <= R and 0 <= j < F_ for j, m in plan)
+                share = [sum(m for j, m in plan if j == s) for s in range(F_)]
+                assert max(share) - min(share) <= 1                      # evenly over the streams
+                assert all(sum(1 for j, m in plan if j == s and m < R) <= 1 for s in range(F_))     # at most one remainder graph per stream
