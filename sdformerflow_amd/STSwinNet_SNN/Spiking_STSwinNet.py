@@ -226,14 +226,23 @@ class MS_SpikingformerFlowNet(nn.Module):
         couples the samples through `window_partition_v2`'s raw view.)  Eval mode only."""
         if self.training:
             raise RuntimeError("forward_replicas is an inference entry point: call model.eval()")
+        from .. import hip
+
+        def one_by_one():
+            outs = [self.engine().forward(x[i:i + 1], None) for i in range(x.shape[0])]
+            return [torch.cat([o[lvl] for o in outs], 0) for lvl in range(len(outs[0]))]
         with torch.no_grad():
             if self.gemm_nsplit != 2 and x.shape[0] > 1:
                 # the 16-bit-plane modes (3 = exact, 1 = bf16) run on the streaming kernels, whose split-K plans and tile families follow
                 # the row count: R-fold rows would change the summation order of a layer - the samples go one by one (same results)
-                outs = [self.engine().forward(x[i:i + 1], None) for i in range(x.shape[0])]
-                flows = [torch.cat([o[lvl] for o in outs], 0) for lvl in range(len(outs[0]))]
+                flows = one_by_one()
             else:
-                flows = self.engine().forward(x, None, replicas=True)
+                try:
+                    flows = self.engine().forward(x, None, replicas=True)
+                except hip.ReplicaGeometryError:
+                    # an odd window count per sample at some stage (e.g. 256 x 320: 175 windows at stage 0): the replica tables cannot
+                    # keep a sample's head scramble inside one attention step - one by one (nothing persistent was touched before the raise)
+                    flows = one_by_one()
         return {"flow": flows, "attn": None}
 
 

@@ -267,6 +267,9 @@ class MSFlowEngine:
             if self.replicas and B > 1:
                 # B independent batch-1 problems in one launch sequence: every sample keeps ITS batch-1 window view (hip.replica_slice_map)
                 m1, nW = self._slice_map_1(D, H, W, ws, ss)
+                if nW % ws[0]:
+                    # (the head scramble of a sample must stay on one side of its attention-step boundary: hip.replica_zsrc_map, zg_rep)
+                    raise hip.ReplicaGeometryError(f"replicas need a window count per sample ({nW}) that is a multiple of the window depth ({ws[0]})")
                 self._maps[key] = (hip.replica_slice_map(m1, nW, B, ws[0], ws[1] * ws[2], D * H * W), B * nW)
             else:
                 self._maps[key] = hip.window_slice_map(B, D, H, W, ws, ss, self.device)    # built on the device, cached per shape

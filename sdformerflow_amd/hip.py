@@ -41,6 +41,11 @@ class SdfError(RuntimeError):
         self.rc = rc
 
 
+class ReplicaGeometryError(SdfError):
+    """A replica launch sequence cannot serve this geometry (the window count per sample is not a multiple of the window depth at some
+    stage): the caller runs the samples one by one - same results."""
+
+
 # The diagnostic SDF_* switches (INTEGRATION.md, appendix) are read ONCE - at import here, at the first call that asks for one in the
 # library (csrc/switches.hip) - not per call.  A harness that changes the environment afterwards says so: reload_switches().
 _SW = {k: v for k, v in os.environ.items() if k.startswith("SDF_")}
@@ -691,7 +696,7 @@ def replica_zsrc_map(z1, nW, R, Tq, N1, Cc):
     ((o // half) * R * nW + r * nW) * N1 * C + o % half with half = nW * N1 * C.  nW % Tq == 0 keeps the nH pieces of a row on one side
     of `half` (the kernels step from head to head by a constant Tq * N1 * 32)."""
     if nW % Tq:
-        raise SdfError(f"replicas need a window count per sample ({nW}) that is a multiple of the window depth ({Tq})")
+        raise ReplicaGeometryError(f"replicas need a window count per sample ({nW}) that is a multiple of the window depth ({Tq})")
     half = nW * N1 * Cc
     te = z1 // half
     r = torch.arange(R, device=z1.device, dtype=torch.int32).view(R, 1)

@@ -64,7 +64,7 @@ def test_replica_tables_are_the_batch1_tables_per_sample(D, H, W, ws, ss, nH, R)
 
 
 def test_replica_tables_refuse_a_window_count_the_head_stride_cannot_serve():
-    with pytest.raises(hip.SdfError):
+    with pytest.raises(hip.ReplicaGeometryError):
         hip.replica_zsrc_map(torch.zeros(9 * 9 * 3, dtype=torch.int32), 3, 2, 2, 81, 96)
 
 
@@ -90,7 +90,7 @@ def _model(kind, H, W, en4):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,H,W,en4,R", [("lif", 144, 192, False, 3), ("psn", 144, 192, False, 2), ("lif", 288, 384, True, 4),
-                                             ("psn", 288, 384, True, 2), ("lif", 288, 384, True, 3), ("lif", 288, 384, True, 6), ("psn", 288, 384, True, 4), ("lif", 288, 384, True, 10)])
+                                             ("psn", 288, 384, True, 2), ("lif", 288, 384, True, 3), ("lif", 288, 384, True, 6), ("psn", 288, 384, True, 4), ("lif", 288, 384, True, 10), ("lif", 256, 320, True, 3), ("psn", 160, 224, False, 5)])
 def test_replica_forward_is_bit_equal_to_separate_batch1_forwards(kind, H, W, en4, R):
     """BASELINE configs[1] (en4, 288 x 384) and the 3-encoder model: R samples through forward_replicas = R forwards of one sample,
     every flow map bit for bit (the products are exact integer sums of digits / fp32 epilogues per element: no result depends on
@@ -109,7 +109,8 @@ def test_replica_forward_is_bit_equal_to_separate_batch1_forwards(kind, H, W, en
         assert f.shape == (R, 2, H, W)
         for i in range(R):
             assert torch.equal(f[i], ones[i][lvl][0]), (lvl, i, (f[i] - ones[i][lvl][0]).abs().max().item())
-    assert not torch.equal(bat[-1], rep[-1])                            # (the reference's batch view is a different network input order)
+    if (H, W) == (288, 384) or (H, W) == (144, 192):                    # (the other geometries have an odd window count per sample at some stage:
+        assert not torch.equal(bat[-1], rep[-1])                        #  forward_replicas serves them one by one - the reference's batch view differs either way)
     # and a second call (cached tables, no tape) reproduces it; then a plain forward still runs on its own tables
     with torch.no_grad():
         again = model.forward_replicas(torch.cat(xs, 0))["flow"]
