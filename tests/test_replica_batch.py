@@ -90,7 +90,7 @@ def _model(kind, H, W, en4):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,H,W,en4,R", [("lif", 144, 192, False, 3), ("psn", 144, 192, False, 2), ("lif", 288, 384, True, 4),
-                                             ("psn", 288, 384, True, 2), ("lif", 288, 384, True, 3), ("lif", 288, 384, True, 6), ("psn", 288, 384, True, 4), ("lif", 288, 384, True, 10), ("lif", 256, 320, False, 3), ("psn", 160, 224, False, 5)])
+                                             ("psn", 288, 384, True, 2), ("lif", 288, 384, True, 3), ("lif", 288, 384, True, 6), ("psn", 288, 384, True, 4), ("lif", 288, 384, True, 10), ("lif", 256, 320, False, 3), ("psn", 160, 224, False, 5), ("lif", 160, 256, False, 4)])
 def test_replica_forward_is_bit_equal_to_separate_batch1_forwards(kind, H, W, en4, R):
     """BASELINE configs[1] (en4, 288 x 384) and the 3-encoder model: R samples through forward_replicas = R forwards of one sample,
     every flow map bit for bit (the products are exact integer sums of digits / fp32 epilogues per element: no result depends on
@@ -109,7 +109,7 @@ def test_replica_forward_is_bit_equal_to_separate_batch1_forwards(kind, H, W, en
         assert f.shape == (R, 2, H, W)
         for i in range(R):
             assert torch.equal(f[i], ones[i][lvl][0]), (lvl, i, (f[i] - ones[i][lvl][0]).abs().max().item())
-    if (H, W) == (288, 384) or (H, W) == (144, 192):                    # (the other geometries have an odd window count per sample at some stage:
+    if (H, W) in ((288, 384), (144, 192), (160, 256)):                  # (the other geometries have an odd window count per sample at some stage:
         assert not torch.equal(bat[-1], rep[-1])                        #  forward_replicas serves them one by one - the reference's batch view differs either way)
     # and a second call (cached tables, no tape) reproduces it; then a plain forward still runs on its own tables
     with torch.no_grad():
