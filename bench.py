@@ -90,7 +90,7 @@ L3_BYTES = 256 << 20                # Infinity Cache of the MI355X (MI355X_MICRO
                                     # this measures the L3-resident rate, not HBM - both figures are reported
 
 
-def time_dominant_kernels(model, iters=40):
+def time_dominant_kernels(model, iters=40, R=1):
     """Live HIP-event timing of the dominant kernel of the forward - the 3x3 spike convolution of the patch embedding's
     res-blocks (10 images of 144x192, 96 -> 96 channels) in the form the forward launches it: BN + identity stored as the fp32
     membrane AND the next block's LIF over T=10 on it, one launch (MS_ResBlock conv2 + sn1; 2 of the forward's 5 big 3x3
@@ -124,6 +124,19 @@ def time_dominant_kernels(model, iters=40):
     t_f32 = _timed(conv_f32, sets, iters)
     t_f32_l3 = _timed(conv_f32, sets[:1], iters)
     del sets
+    # the same two launches as the headline's scheme makes them: R samples per launch sequence = 10 R images per launch (one set is
+    # R x 265 MB: beyond the Infinity Cache by itself from R = 2 on; two sets in rotation)
+    tR = None
+    if R > 1:
+        torch.cuda.empty_cache()
+        setsR = [((torch.rand((R, imgs, H, W, Cc), device=dev) < 0.3).to(torch.uint8), torch.rand((R, imgs, H, W, Cc), device=dev)) for _ in range(2)]
+        eng.replicas = True                                       # (routing as in forward_replicas)
+        try:
+            tR = (_timed(conv_fusedm, setsR, max(6, iters // 4)), _timed(conv_fused, setsR, max(6, iters // 4)))
+        finally:
+            eng.replicas = False
+        del setsR
+        torch.cuda.empty_cache()
     flops = 2.0 * imgs * H * W * Cc * 9 * Cc                    # algorithmic: one multiply-add per (pixel, cout, tap, cin)
     digits = getattr(rb.w2, "digits", None) is not None and sn.kind != "psn"
     ns = int(rb.w2.shape[0])
@@ -158,13 +171,30 @@ def time_dominant_kernels(model, iters=40):
                     "; the matrix pipe is busy 40 % of the kernel's cycles (PMC, profiles/r5q_pmc_forward.txt)"}
     gemm["frac"] = gemm["achieved"] / gemm["peak"]
     gemm["frac_of_issued_mfma"] = issued * gemm["frac"]
+    if tR is not None and digits:
+        # `achieved` / `frac` / `us_per_launch` describe the launch the TIMED REGION makes (R samples = 10 R images: the dispatcher takes two
+        # row blocks per wave at this row count, spike_conv_wres_i8_kernel<10,6,2,2>); the one-sample launch of rounds 2 - 5 stays beside it
+        one = {k: gemm[k] for k in ("achieved", "frac", "frac_of_issued_mfma", "us_per_launch", "forms", "l3_resident")}
+        tc = (tR[0] + tR[1]) / 2
+        gemm.update(achieved=R * flops / tc / 1e12, us_per_launch=tc * 1e6, images_per_launch=imgs * R, samples_per_launch=R,
+                    one_sample_per_launch=one,
+                    forms={"spikes_only": {"us_per_launch": tR[1] * 1e6, "frac": R * flops / tR[1] / 1e12 / PEAK_BF16_DENSE_TFLOPS},
+                           "membrane_and_spikes": {"us_per_launch": tR[0] * 1e6, "frac": R * flops / tR[0] / 1e12 / PEAK_BF16_DENSE_TFLOPS}})
+        gemm.pop("l3_resident", None)
+        gemm["frac"] = gemm["achieved"] / gemm["peak"]
+        gemm["frac_of_issued_mfma"] = issued * gemm["frac"]
+        gemm["algorithmic_bytes"] = R * gemm["algorithmic_bytes"]
+        gemm["kernel"] = (f"sdfmm::spike_conv_wres_i8_kernel (3 int8 digit planes resident in LDS, halo tiles, LIF over T fused) - 3x3 spike conv 96->96 on {imgs * R} "
+                          f"images of 144x192 = the launch of the headline's scheme ({R} samples per launch sequence; <10,6,2,2>: two row blocks per wave "
+                          "from 7 samples on, <10,6,1,3> below); average over the forward's four launches of it (2 x BN -> LIF(T=10) spikes, 2 x BN + "
+                          "identity -> fp32 membrane + LIF spikes); `one_sample_per_launch`: the 10-image launch of rounds 2 - 5")
     # round 6: the traffic of this kernel's four launches inside the headline's launch sequence, from the counters tools/pmc_forward2.sh
     # took on this round's tree (profiles/r6_kernel_counters.json; rocprofv3 owns the counters, they cannot be read in this process)
     try:
         cj = json.load(open(os.path.join(ROOT, "profiles", "r6_kernel_counters.json")))
-        ks = [v for k, v in cj["per_sample"].items() if k.startswith("spike_conv_wres_i8_kernel<10, 6, 1, 3")]
+        ks = [v for k, v in cj["per_sample"].items() if k.startswith("spike_conv_wres_i8_kernel<10, 6, ")]      # (the stride-1 96-channel forms: <10,6,1,3,..> / <10,6,2,2,..>)
         if digits and ks:
-            per_launch = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in ks) / sum(v["launches"] for v in ks)
+            per_launch = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in ks) / sum(v["launches"] for v in ks) * gemm.get("samples_per_launch", 1)
             gemm.update(traffic=per_launch, traffic_over_algorithmic=per_launch / gemm["algorithmic_bytes"],
                         traffic_source="profiles/r6_kernel_counters.json (tools/pmc_forward2.sh on the round-6 tree: rocprofv3 --pmc FETCH_SIZE and --pmc "
                                        "WRITE_SIZE in separate passes over one eager launch sequence of " + str(cj["samples_per_launch_sequence"]) +
@@ -999,7 +1029,7 @@ def main():
 
     if rank == 0:
         check_ranks(ranks, world, shared_ok=os.environ.get("SDF_DIST_BACKEND", "nccl") != "nccl")
-        gemm, neuron = time_dominant_kernels(model)
+        gemm, neuron = time_dominant_kernels(model, R=args.replicas)
         blocks = time_swin_blocks(model, chunk, args.replicas)
         by_time = time_by_entry_point(model, chunk)
         gemm["by_time"] = by_time["rows"]
