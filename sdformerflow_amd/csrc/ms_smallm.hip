@@ -573,7 +573,8 @@ bool smallm_gemm_supports(const GemmParams& P) {
   if (const char* e = sdf_sw(SW_SMALLM)) { if (e[0] == '0') return false; }
   if (d.nsplit != SDF_PLANES_I8X3_TILED || !d.col_scale || d.sn_T > 0 || !d.out) return false;
   if (d.K % 64 || d.K < 64 || d.N % 32 || d.lda != d.K || d.out_rowmap || d.add || d.zg_nH) return false;
-  if (d.M % 10 || d.M > SMALLM_MAX_ROWS) return false;            // (rows are walked as 10 "steps" x M / 10 "positions": any order serves the fp32 form)
+  if (d.M % 10 || d.M > smallm_conv_rows()) return false;         // (rows are walked as 10 "steps" x M / 10 "positions": any order serves the fp32 form;
+                                                                  //  the row bound is the convolution's since round 6: ten samples' stacked-tap product is one launch)
   if (d.M * (int64_t)d.K >= (1LL << 31) || d.M * (int64_t)d.ldo * 4 >= (1LL << 31) || (int64_t)d.N * d.K * 3 >= (1LL << 31)) return false;
   return sdf_aligned(d.A, 16) && sdf_aligned(d.Wp, 16) && sdf_aligned(d.out, 16) && (!d.resid || sdf_aligned(d.resid, 16)) && d.ldo >= d.N;
 }

@@ -791,7 +791,7 @@ class MSFlowEngine:
                 M1, bc = self._rb(B) * D * h * w, B                  # (rows the routing rules are asked about; samples per launch)
                 if getattr(taps, "digits", None) is not None and hip.smallm_gemm_applicable(M1, 9 * cout, cp):
                     taps = taps.digits                        # few rows against many weights (level 0: 1 080 x 3 456 x 1 536): csrc/ms_smallm.hip
-                    bc = max(n for n in range(1, B + 1) if B % n == 0 and hip.smallm_gemm_applicable(n * D * h * w, 9 * cout, cp))
+                    bc = max(n for n in range(1, B + 1) if B % n == 0 and hip.smallm_gemm_rows_ok(n * D * h * w))
                 elif getattr(taps, "digits_rm", None) is not None and hip.res_gemm_applicable(M1, 9 * cout, cp):
                     taps = taps.digits_rm                     # the middle levels (4 320 x 1 728 x 800, 17 280 x 864 x 416): csrc/ms_res.hip
                     bc = max(n for n in range(1, B + 1) if B % n == 0 and hip.res_gemm_applicable(n * D * h * w, 9 * cout, cp))

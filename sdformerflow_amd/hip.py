@@ -543,6 +543,12 @@ def smallm_gemm_applicable(M, N, K):
     return M <= 64 * 80 and K >= int(sw("SDF_SMALLM_MINK", 1024))
 
 
+def smallm_gemm_rows_ok(M):
+    """Rows ONE launch of the plain small-M product admits (the library's bound, csrc/ms_smallm.hip smallm_gemm_supports) - wider than the
+    routing rule above, which decides per sample: replicas run the product their batch-1 forward takes, in as few launches as this allows."""
+    return M % 10 == 0 and M <= int(sw("SDF_SMALLM_CONV_ROWS", 400 * 80))
+
+
 def res_gemm_applicable(M, N, K):
     """Mirror of the library's rule for the plain product on row-major digit planes (csrc/spike_gemm.hip -> ms_res.hip: whole-K digits
     LDS-resident per 32 columns, row loop): rows in tens, K <= 1024 in steps of 16."""
