@@ -398,6 +398,8 @@ class InFlight:
     def _plan(self, n):
         """n samples dealt as evenly as possible to the F streams; a stream's share runs as replays of its R-sample graph plus one
         replay of a graph captured for the remainder: [(stream, samples)] in issue order (round-robin over the streams)."""
+        if getattr(self, "plan_override", None) and sum(m for _, m in self.plan_override) == n:
+            return list(self.plan_override)                      # (diagnostic: --plan "0:10,1:5,1:5")
         share = [n // self.F + (1 if j < n % self.F else 0) for j in range(self.F)]
         per = [[self.R] * (s // self.R) + ([s % self.R] if s % self.R else []) for s in share]
         return [(j, per[j][i]) for i in range(max(len(p) for p in per)) for j in range(self.F) if i < len(per[j])]
@@ -954,6 +956,7 @@ def main():
                          "parity mode), 3 = bf16 hi+mid+lo (the fp32 weight exactly), 1 = one bf16 plane (BASELINE configs[1]'s "
                          "stated bf16 precision; a separately labelled throughput line, never the parity mode)")
     ap.add_argument("--plumbing", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--plan", default=None, help=argparse.SUPPRESS)       # diagnostic: the timed steps' dealing as "stream:samples,..."
     args = ap.parse_args()
     if args.inflight < 1 or args.replicas < 1:
         ap.error("--inflight and --replicas must be >= 1")
@@ -999,6 +1002,8 @@ def main():
         # F streams, each replaying its own HIP graph of one launch sequence over R independent samples (class InFlight)
         long_steps = max(args.steps, 96)
         fl = InFlight(model, dev, F_, args.replicas, eager=args.eager)
+        if args.plan:
+            fl.plan_override = [tuple(int(v) for v in p.split(":")) for p in args.plan.split(",")]
         fl.prepare(args.warmup, args.steps, long_steps)
         fl.run(args.warmup)
         barrier()
