@@ -478,6 +478,15 @@ def side_measurements(args, dev):
     from sdformerflow_amd.harness import prepare_chunk
     from sdformerflow_amd.synthetic import synth_label, synth_voxel
     out = {}
+    try:                                                           # the headline's model in round 5's scheme: three batch-1 graphs in flight
+        m, _ = build_model("lif", dev)
+        r = inflight_rate(m, dev, 3, 1, 96)
+        r["workload"] = "configs[1] forward, neuron=lif, weight planes=2: ONE sample per launch sequence, three streams (the scheme of rounds 1 - 5)"
+        out["one_sample_per_launch_three_streams"] = r
+        del m
+    except Exception as e:
+        out["one_sample_per_launch_three_streams"] = {"error": repr(e)[:300]}
+    torch.cuda.empty_cache()
     for name, kind, planes in (("planes3_exact_fp32_weights", "lif", 3), ("planes1_bf16_weights", "lif", 1), ("neuron_psn", "psn", 2)):
         try:
             m, _ = build_model(kind, dev)
@@ -1093,6 +1102,7 @@ def main():
             "value_sustained_2s": res["value_sustained"]["samples_per_s_this_rank"],
             "latency_ms_single_stream": latency_ms, "roofline_frac": gemm.get("frac"), "attention_gemm_roofline_frac": blocks["frac"],
             "swin_stages_ms": blocks.get("swin_stages_ms"), "neuron_psn_samples_per_s": (sm.get("neuron_psn") or {}).get("samples_per_s"),
+            "one_sample_per_launch_three_streams_samples_per_s": (sm.get("one_sample_per_launch_three_streams") or {}).get("samples_per_s"),
             "cpu_baseline_samples_per_s": (res.get("cpu_baseline") or {}).get("value")}
         print(json.dumps(res))
     if dist:
