@@ -71,13 +71,14 @@ def test_replica_tables_refuse_a_window_count_the_head_stride_cannot_serve():
 DEV = "cuda:0"
 
 
-def _model(kind, H, W, en4):
+def _model(kind, H, W, en4, T=10):
     import yaml, os
     from sdformerflow_amd.STSwinNet_SNN.Spiking_STSwinNet import MS_SpikingformerFlowNet, MS_SpikingformerFlowNet_en4
     from sdformerflow_amd.synthetic import synth_state_dict
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = yaml.safe_load(open(os.path.join(root, "sdformerflow_amd", "configs", "train_DSEC_supervised_SDformerFlow_en4.yml")))
-    cfg["model"]["spiking_neuron"] = dict(cfg["spiking_neuron"], neuron_type=kind)
+    cfg["model"]["spiking_neuron"] = dict(cfg["spiking_neuron"], neuron_type=kind, num_steps=T)
+    cfg["model"]["num_bins"] = T
     cfg["swin_transformer"]["input_size"] = [H, W]
     cls = MS_SpikingformerFlowNet_en4
     if not en4:
@@ -195,3 +196,21 @@ def test_launch_log_reports_every_launch_of_a_call():
     with hip.launch_log() as log3:
         pass
     assert log3.rows == []
+
+
+@pytest.mark.gpu
+def test_replica_forward_at_configs4_shape_T20():
+    """BASELINE configs[4]'s shape (20 bins / T = 20, 480 x 640): its kernels are other instantiations (the digit convolution's rolled
+    time loop, T = 20 row-loop and K-ring tiles, sample chunks where a launch would pass its 31-bit offsets) - two replicas are two
+    batch-1 forwards there too, bit for bit."""
+    from sdformerflow_amd.harness import prepare_chunk
+    from sdformerflow_amd.synthetic import synth_voxel
+    model = _model("lif", 480, 640, True, T=20)
+    xs = [prepare_chunk(synth_voxel(1, 20, 480, 640, seed=500 + i)).to(DEV) for i in range(2)]
+    with torch.no_grad():
+        ones = [[f.clone() for f in model(x)["flow"]] for x in xs]
+        rep = model.forward_replicas(torch.cat(xs, 0))["flow"]
+    torch.cuda.synchronize()
+    for lvl, f in enumerate(rep):
+        for i in range(2):
+            assert torch.equal(f[i], ones[i][lvl][0]), (lvl, i, (f[i] - ones[i][lvl][0]).abs().max().item())
