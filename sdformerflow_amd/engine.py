@@ -326,6 +326,9 @@ class MSFlowEngine:
         a, b = bn if bn is not None else (None, None)
         # large 3x3 / stride-1 launches on 96 channels: int8 digit planes, weights resident in LDS (csrc/spike_conv_wres.hip)
         digits = getattr(Wp, "digits", None)
+        if self.replicas and B > 1 and _dst is None and digits is None:
+            # 16-bit planes only (no digit form of this layer): the streaming kernels' tile family and split-K plan follow the row count
+            return self._conv3x3_chunks(s, Wp, Cout, stride, bn, resid, sn, membrane, 1)
         if self.replicas and B > 1 and _dst is None and digits is not None:
             # replicas: every layer must take the kernel family (and weight representation) its batch-1 forward takes, whatever the
             # size rules say about B-fold rows - else the flows are not the batch-1 flows bit for bit.  Where the rules answer
@@ -795,6 +798,8 @@ class MSFlowEngine:
                 elif getattr(taps, "digits_rm", None) is not None and hip.res_gemm_applicable(M1, 9 * cout, cp):
                     taps = taps.digits_rm                     # the middle levels (4 320 x 1 728 x 800, 17 280 x 864 x 416): csrc/ms_res.hip
                     bc = max(n for n in range(1, B + 1) if B % n == 0 and hip.res_gemm_applicable(n * D * h * w, 9 * cout, cp))
+                if self.replicas and taps is self._deconv[key]:
+                    bc = 1            # (16-bit planes on the streaming kernels: their split-K plan follows the row count - one sample per launch)
                 mc = bc * D * h * w                                   # (replicas: the kernel family of ONE sample, in sample chunks it admits)
                 for m0 in range(0, B * D * h * w, mc):
                     hip.spike_gemm(s.view(-1, cp)[m0:m0 + mc], taps, Y[m0:m0 + mc], mc, 9 * cout, cp)
@@ -822,6 +827,14 @@ class MSFlowEngine:
                 for i0 in range(0, imgs, per):                            # (image chunks: the kernel's 31-bit offsets, as below)
                     hip.spike_deconv3x3s2(sv[i0:i0 + per], pl, per, D, h, w, cp, cout, alpha=a4, beta=b4, out=zv[i0:i0 + per], tiled_bn=True)
             classes = [] if as_gemm or one_gemm else self._deconv_classes(i, B, D, h, w, cp, wkey, wuse)
+            if classes and self.replicas and B > 1:
+                # the parity classes run on the streaming kernels (16-bit planes: tile family and split-K plan follow the row count): every
+                # sample goes through the launches of its batch-1 forward (the row maps of the first D images serve every sample's slice)
+                c1 = self._deconv_classes(i, 1, D, h, w, cp, wkey, wuse)
+                sv, zv = s.view(imgs, h, w, cp), z.view(imgs, 4 * h * w, cout)
+                for b0 in range(0, imgs, D):
+                    hip.spike_conv2d_multi(sv[b0:b0 + D], c1, D, h, w, cp, h, w, zv[b0:b0 + D], alpha=bn[0], beta=bn[1])
+                classes = []
             if classes and per == imgs:
                 # the four parity classes write disjoint rows of z and each fills about half of the chip: one launch for all of them
                 hip.spike_conv2d_multi(s.view(imgs, h, w, cp), classes, imgs, h, w, cp, h, w, z.view(imgs, 4 * h * w, cout), alpha=bn[0], beta=bn[1])

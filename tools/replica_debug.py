@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where does a replica forward leave the separate batch-1 forwards?  Stage by stage on the engine's own methods.
-usage: replica_debug.py [lif|psn] R [H W] [en3]"""
+usage: replica_debug.py [lif|psn] R [H W] [en3] [T20]"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,9 +10,10 @@ from sdformerflow_amd.synthetic import synth_voxel
 kind, R = sys.argv[1], int(sys.argv[2])
 H, W = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (288, 384)
 en4 = "en3" not in sys.argv
-model = _model(kind, H, W, en4)
+TT = 20 if "T20" in sys.argv else 10
+model = _model(kind, H, W, en4, T=TT)
 eng = model.engine()
-xs = [prepare_chunk(synth_voxel(1, 10, H, W, seed=300 + 7 * i)).to("cuda:0") for i in range(R)]
+xs = [prepare_chunk(synth_voxel(1, TT, H, W, seed=300 + 7 * i)).to("cuda:0") for i in range(R)]
 
 
 def cmp(tag, rep, ones):
