@@ -889,6 +889,10 @@ class MSFlowEngine:
         x = x.float().contiguous()
         H, W = x.shape[-2:]
         self.scores = scores
+        if replicas and self.num_steps not in (10, 20):
+            # other step counts leave layers on the streaming kernels (no digit form at T = 5: the MDR config), whose split-K plans follow the
+            # row count - the caller (forward_replicas) serves those models one sample at a time
+            raise hip.ReplicaGeometryError(f"replicas are built for T = 10 / 20 (digit kernels throughout), not T = {self.num_steps}")
         self.replicas = bool(replicas)
         try:
             feats = self.encoder(x, **self._tail_kwargs())
