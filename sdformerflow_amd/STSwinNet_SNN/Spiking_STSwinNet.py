@@ -268,3 +268,12 @@ class SpikingformerFlowNet(MS_SpikingformerFlowNet):
             raise NotImplementedError("SEW attention maps (B_, nH, N, N) live in registers of the fused window-attention kernel and "
                                       "are never materialised; log=True is built for the MS (QK token-gate) family")
         return super().forward(x, log)
+
+    def forward_replicas(self, x):
+        """The SEW engine has no one-launch-sequence form (its window attention and integer stream keep the reference's batch view): the
+        samples go one by one - same contract as the MS models' call, flow[i] == self(x[i:i+1])["flow"]."""
+        if self.training:
+            raise RuntimeError("forward_replicas is an inference entry point: call model.eval()")
+        with torch.no_grad():
+            outs = [self.engine().forward(x[i:i + 1], None) for i in range(x.shape[0])]
+        return {"flow": [torch.cat([o[lvl] for o in outs], 0) for lvl in range(len(outs[0]))], "attn": None}
