@@ -199,13 +199,14 @@ def test_launch_log_reports_every_launch_of_a_call():
 
 
 @pytest.mark.gpu
-def test_replica_forward_at_configs4_shape_T20():
+@pytest.mark.parametrize("kind", ["lif", "psn"])
+def test_replica_forward_at_configs4_shape_T20(kind):
     """BASELINE configs[4]'s shape (20 bins / T = 20, 480 x 640): its kernels are other instantiations (the digit convolution's rolled
     time loop, T = 20 row-loop and K-ring tiles, sample chunks where a launch would pass its 31-bit offsets) - two replicas are two
     batch-1 forwards there too, bit for bit."""
     from sdformerflow_amd.harness import prepare_chunk
     from sdformerflow_amd.synthetic import synth_voxel
-    model = _model("lif", 480, 640, True, T=20)
+    model = _model(kind, 480, 640, True, T=20)
     xs = [prepare_chunk(synth_voxel(1, 20, 480, 640, seed=500 + i)).to(DEV) for i in range(2)]
     with torch.no_grad():
         ones = [[f.clone() for f in model(x)["flow"]] for x in xs]
