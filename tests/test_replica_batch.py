@@ -215,3 +215,39 @@ def test_replica_forward_at_configs4_shape_T20(kind):
     for lvl, f in enumerate(rep):
         for i in range(2):
             assert torch.equal(f[i], ones[i][lvl][0]), (lvl, i, (f[i] - ones[i][lvl][0]).abs().max().item())
+
+
+@pytest.mark.gpu
+def test_forward_replicas_serves_what_it_cannot_batch_one_by_one():
+    """The same call on models the replica tables / digit kernels do not cover - the MDR config (T = 5: layers on the streaming kernels),
+    the SEW family (its engine keeps the reference's batch view) and the exact 3-plane weight mode - returns the flows of separate
+    batch-1 forwards as well: it runs them one after the other."""
+    import os
+    import yaml
+    from sdformerflow_amd.STSwinNet_SNN.Spiking_STSwinNet import MS_SpikingformerFlowNet_en4, SpikingformerFlowNet
+    from sdformerflow_amd.harness import prepare_chunk
+    from sdformerflow_amd.synthetic import synth_state_dict, synth_voxel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cdir = os.path.join(root, "sdformerflow_amd", "configs")
+
+    def load(m):
+        m.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}), strict=True)
+        return m.eval().to(DEV)
+    cfg = yaml.safe_load(open(os.path.join(cdir, "train_MDR_supervised_SDformerFlow.yml")))
+    cfg["model"]["spiking_neuron"] = dict(cfg["spiking_neuron"])
+    cfg["swin_transformer"]["input_size"] = [256, 256]
+    mdr = load(MS_SpikingformerFlowNet_en4(cfg["model"].copy(), cfg["swin_transformer"].copy()))
+    cfg = yaml.safe_load(open(os.path.join(cdir, "train_DSEC_supervised_SDformerFlow_en4.yml")))
+    cfg["model"]["spiking_neuron"] = dict(cfg["spiking_neuron"], neuron_type="lif")
+    cfg["swin_transformer"].update(input_size=[144, 192], swin_depths=[2, 2, 6], swin_num_heads=[3, 6, 12], swin_out_indices=[0, 1, 2])
+    sew = load(SpikingformerFlowNet(cfg["model"].copy(), cfg["swin_transformer"].copy()))
+    exact = _model("lif", 144, 192, False)
+    exact.gemm_nsplit = 3
+    for model, T, H, W in ((mdr, mdr.engine().num_steps, 256, 256), (sew, 10, 144, 192), (exact, 10, 144, 192)):
+        xs = [prepare_chunk(synth_voxel(1, T, H, W, seed=700 + i)).to(DEV) for i in range(2)]
+        with torch.no_grad():
+            ones = [[f.clone() for f in model(x)["flow"]] for x in xs]
+            rep = model.forward_replicas(torch.cat(xs, 0))["flow"]
+        for lvl, f in enumerate(rep):
+            for i in range(2):
+                assert torch.equal(f[i], ones[i][lvl][0]), (type(model).__name__, lvl, i)
