@@ -243,7 +243,7 @@ def test_forward_replicas_serves_what_it_cannot_batch_one_by_one():
     sew = load(SpikingformerFlowNet(cfg["model"].copy(), cfg["swin_transformer"].copy()))
     exact = _model("lif", 144, 192, False)
     exact.gemm_nsplit = 3
-    for model, T, H, W in ((mdr, mdr.engine().num_steps, 256, 256), (sew, 10, 144, 192), (exact, 10, 144, 192)):
+    for model, T, H, W in ((mdr, mdr.engine().num_bins, 256, 256), (sew, 10, 144, 192), (exact, 10, 144, 192)):     # (T: voxel bins)
         xs = [prepare_chunk(synth_voxel(1, T, H, W, seed=700 + i)).to(DEV) for i in range(2)]
         with torch.no_grad():
             ones = [[f.clone() for f in model(x)["flow"]] for x in xs]
