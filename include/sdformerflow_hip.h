@@ -776,6 +776,11 @@ int sdf_unpack_planes(const void* planes, float* x, int imgs, int C, int H, int 
  * with element strides (sn,sc,sh,sw), written as records rec0 .. rec0+ceil(C/16)-1 of planes [imgs][rec_total][2h][2w] */
 int sdf_pack_planes_up2(const float* x, void* planes, int imgs, int C, int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
                         int rec0, int rec_total, void* stream);
+/* round 6: the same record addressing with ZERO INSERTION instead of interpolation - output pixel (2k, 2l) = input (k, l), all other
+ * pixels 0: the input of ConvTranspose2d(3, stride 2, padding 1, output_padding 1) as the stride-1 correlation sdf_dense_conv3x3_fwd
+ * runs with the flipped kernel (the SEW decoders, reference Spiking_modules.py:449-456), without a zero-filled fp32 image in between. */
+int sdf_pack_planes_zero_up2(const float* x, void* planes, int imgs, int C, int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                             int rec0, int rec_total, void* stream);
 
 /* ---- Linear layer on real-valued activations (ANN swin blocks, BASELINE config 3) --------------------------------
  * Replaces F.linear (+ F.gelu, + the residual add) of reference models/STSwinNet/swin_transformer3D_v2.py:176-202

@@ -452,7 +452,9 @@ __global__ __launch_bounds__(256) void unpack_planes_kernel(const u32x4* __restr
 // `UpsampleConvLayer`) of an (imgs, C, h, w) fp32 tensor with arbitrary strides, written as records rec0 .. of planes
 // [imgs][rec_total][2h][2w]: output pixel 2k takes 0.25 / 0.75 of inputs k-1 / k, pixel 2k+1 takes 0.75 / 0.25 of k / k+1,
 // indices clamped to the image.
-template <bool CL>
+// ZI (round 6): ZERO INSERTION instead of interpolation - output pixel (2k, 2l) = input (k, l), every other pixel 0: the input of a stride-2
+// transposed convolution written as a stride-1 correlation (the SEW decoders, engine_sew._deconv_dense_fwd), straight into the planes.
+template <bool CL, bool ZI = false>
 __global__ __launch_bounds__(256) void pack_planes_up2_kernel(const float* __restrict__ x, u32x4* __restrict__ planes, int imgs, int C,
                                                               int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int rec0,
                                                               int rec_total) {
@@ -477,6 +479,26 @@ __global__ __launch_bounds__(256) void pack_planes_up2_kernel(const float* __res
     const int64_t o00 = y0 * sh + x0 * sw, o01 = y0 * sh + x1 * sw, o10 = y1 * sh + x0 * sw, o11 = y1 * sh + x1 * sw;
     u32x4* dst = planes + (((int64_t)img * rec_total + rec0 + rec) * hw + pix) * 4;
     const float* bimg = x + img * sn;
+    if constexpr (ZI) {
+      const bool on = !(oy & 1) && !(ox & 1);
+      const int64_t o = ky * sh + kx * sw;
+      if (CL) {
+        const int c = rec * 16 + 4 * j0;
+        dst[j0] = piece_from((on && c < C) ? *reinterpret_cast<const float4*>(bimg + c + o) : make_float4(0.f, 0.f, 0.f, 0.f));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = rec * 16 + 4 * j + e;
+            v[e] = (on && c < C) ? bimg[c * sc + o] : 0.f;
+          }
+          dst[j] = piece_from(make_float4(v[0], v[1], v[2], v[3]));
+        }
+      }
+      continue;
+    }
     if (CL) {
       const int c = rec * 16 + 4 * j0;
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -582,6 +604,24 @@ extern "C" int sdf_pack_planes_up2(const float* x, void* planes, int imgs, int C
   else
     SDF_LAUNCH(sdfmm::pack_planes_up2_kernel<false>, dim3(planes_grid(total)), dim3(256), 0, sdf_stream(stream), x,
                        reinterpret_cast<sdfmm::u32x4*>(planes), imgs, C, h, w, sn, sc, sh, sw, rec0, rec_total);
+  SDF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sdf_pack_planes_zero_up2(const float* x, void* planes, int imgs, int C, int h, int w, int64_t sn, int64_t sc, int64_t sh,
+                                        int64_t sw, int rec0, int rec_total, void* stream) {
+  if (!x || !planes) return SDF_E_NULL;
+  const int nch = (C + 15) / 16;
+  if (imgs <= 0 || C <= 0 || h <= 0 || w <= 0 || rec0 < 0 || rec0 + nch > rec_total) return SDF_E_SHAPE;
+  if (!sdf_aligned(planes, 16)) return SDF_E_ALIGN;
+  const bool cl = sc == 1 && C % 4 == 0 && sn % 4 == 0 && sh % 4 == 0 && sw % 4 == 0 && sdf_aligned(x, 16);
+  const int64_t total = (int64_t)imgs * nch * (2 * h) * (2 * w) * (cl ? 4 : 1);
+  if (cl)
+    SDF_LAUNCH((sdfmm::pack_planes_up2_kernel<true, true>), dim3(planes_grid(total)), dim3(256), 0, sdf_stream(stream), x,
+               reinterpret_cast<sdfmm::u32x4*>(planes), imgs, C, h, w, sn, sc, sh, sw, rec0, rec_total);
+  else
+    SDF_LAUNCH((sdfmm::pack_planes_up2_kernel<false, true>), dim3(planes_grid(total)), dim3(256), 0, sdf_stream(stream), x,
+               reinterpret_cast<sdfmm::u32x4*>(planes), imgs, C, h, w, sn, sc, sh, sw, rec0, rec_total);
   SDF_LAUNCH_CHECK();
   return 0;
 }

@@ -28,7 +28,7 @@ EXPORTS = ("sdf_version", "sdf_switches_reload", "sdf_launch_log", "sdf_launch_l
            "sdf_ms_mlp_fwd", "sdf_ms_mlp_workspace_bytes", "sdf_pred_head_fwd", "sdf_pointwise_conv_f32_fwd", "sdf_neuron_multi_fwd", "sdf_qk_gate_f32_fwd", "sdf_qk_gate_bwd", "sdf_qk_gate_bwd_workspace_bytes",
            "sdf_rows_gather_fwd", "sdf_rows_scatter_fwd",
            "sdf_split_weight_i8x3", "sdf_bn_train_fwd", "sdf_bn_train_bwd", "sdf_bn_train_workspace_bytes", "sdf_bn_train_nchw_fwd", "sdf_bn_train_nchw_bwd",
-           "sdf_dense_conv3x3_fwd", "sdf_pack_planes", "sdf_unpack_planes", "sdf_pack_planes_up2", "sdf_dense_linear_fwd", "sdf_layer_norm_fwd",
+           "sdf_dense_conv3x3_fwd", "sdf_pack_planes", "sdf_unpack_planes", "sdf_pack_planes_up2", "sdf_pack_planes_zero_up2", "sdf_dense_linear_fwd", "sdf_layer_norm_fwd",
            "sdf_linear_dw_fwd", "sdf_linear_dw_splits", "sdf_ringed_rows_fwd", "sdf_linear_train_fwd", "sdf_unring_rows_fwd")
 
 
@@ -1187,6 +1187,20 @@ def pack_planes_up2(x, planes=None, rec0=0):
     _check(lib().sdf_pack_planes_up2(C.c_void_p(_ptr(x, torch.float32)), C.c_void_p(_ptr(planes, torch.float16)), C.c_int(imgs),
                                      C.c_int(Cc), C.c_int(h), C.c_int(w), C.c_int64(sn), C.c_int64(sc), C.c_int64(sh), C.c_int64(sw),
                                      C.c_int(rec0), C.c_int(planes.shape[1]), _stream()), "sdf_pack_planes_up2")
+    return planes
+
+
+def pack_planes_zero_up2(x, planes, rec0=0):
+    """Zero insertion x2 of x (imgs, C, h, w) fp32 - any strides - into records rec0 .. of the planes tensor (imgs, R, 2h, 2w, 32): output
+    pixel (2k, 2l) = x[k, l], every other pixel 0 (sdf_pack_planes_zero_up2): the input of a stride-2 transposed convolution as a stride-1
+    correlation, without the zero-filled fp32 image."""
+    imgs, Cc, h, w = x.shape
+    if tuple(planes.shape[2:]) != (2 * h, 2 * w, 32) or planes.shape[0] != imgs or not planes.is_contiguous():
+        raise SdfError("planes must be a contiguous (imgs, R, 2h, 2w, 32) tensor")
+    sn, sc, sh, sw_ = x.stride()
+    _check(lib().sdf_pack_planes_zero_up2(C.c_void_p(_ptr(x, torch.float32)), C.c_void_p(_ptr(planes, torch.float16)), C.c_int(imgs),
+                                          C.c_int(Cc), C.c_int(h), C.c_int(w), C.c_int64(sn), C.c_int64(sc), C.c_int64(sh), C.c_int64(sw_),
+                                          C.c_int(rec0), C.c_int(planes.shape[1]), _stream()), "sdf_pack_planes_zero_up2")
     return planes
 
 

@@ -117,6 +117,28 @@ def test_pack_planes_up2_is_bilinear_interpolation(channels_last):
     assert torch.count_nonzero(got[:, 34:]) == 0
 
 
+def test_pack_planes_zero_up2_is_the_packed_zero_upsampled_image():
+    """sdf_pack_planes_zero_up2 (round 6: the SEW decoders' transposed convolutions as stride-1 correlations): the planes it writes are,
+    bit for bit, sdf_pack_planes of the zero-filled image with x on the even pixels - channels-last parts (16-byte pieces), a strided
+    2-of-32 channel slice (the prediction) and a plain NCHW tensor, each into its record range of a wider tensor."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(6)
+    a = torch.randn(3, 9, 13, 32, generator=g).cuda().permute(0, 3, 1, 2)               # channels-last view, C % 4 == 0
+    p32 = torch.randn(3, 9, 13, 32, generator=g).cuda()
+    b = p32[..., :2].permute(0, 3, 1, 2)                                                # 2 of 32 channels, channel stride 1, pixel stride 32
+    c = torch.randn(3, 20, 9, 13, generator=g).cuda()                                   # NCHW
+    planes = torch.full((3, 6, 18, 26, 32), 7.0, dtype=torch.float16, device="cuda")
+    hip.pack_planes_zero_up2(a, planes, 0)                                              # records 0 - 1
+    hip.pack_planes_zero_up2(b, planes, 2)                                              # record 2
+    hip.pack_planes_zero_up2(c, planes, 3)                                              # records 3 - 4
+    planes[:, 5:].zero_()
+    up = torch.zeros((3, 96, 18, 26), device="cuda")
+    up[:, 0:32, ::2, ::2] = a
+    up[:, 32:34, ::2, ::2] = b
+    up[:, 48:68, ::2, ::2] = c
+    assert torch.equal(planes, hip.pack_planes(up))
+
+
 @pytest.mark.parametrize("Cin,Cout", [(194, 96), (386, 96), (768, 192)])
 def test_wide_convolution_as_a_chain_of_slices(Cin, Cout):
     """The decoders' convolutions (194, 386, 768 input channels) as chains of 96-channel slices plus one 16-channel record."""
